@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures.  RUNS ONLY IN THE BUILD CONTAINER, where
+/root/reference exists; nothing here is imported by tests or by the product.
+
+What it does (SURVEY.md section 8c "What pins results"):
+  1. executes the reference's *real* ``TLSAN/build_dataset.py`` (in a scratch dir under /tmp,
+     with ``../Data`` symlinked to /root/reference/Data; for Clothing the dataset path string is
+     swapped in memory, as the reference's README asks users to do by hand) to obtain
+     ``dataset.pkl`` = train_set, test_set, (U,I,C), item_cate_list;
+  2. imports the *real* ``TLSAN/input.py`` and records what ``DataInput`` / ``DataInputTest``
+     emit for chosen batches -> ``batches_<name>.npz`` (bit-exact integer/mask pins);
+  3. exports the built sample tuples as flat CSR arrays -> ``packed_<name>.npz`` (derived
+     data, so the GPU box -- which has no /root/reference -- can run the real datasets).
+No reference source text is written anywhere; only data (inputs and expected outputs).
+"""
+import importlib.util
+import os
+import pickle
+import sys
+import tempfile
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+DATASETS = {
+    "digital_music": "Digital_Music",
+    "clothing": "Clothing_Shoes_and_Jewelry",
+}
+
+
+def build_dataset(data_name):
+    work = tempfile.mkdtemp(prefix="tlsan_fx_")
+    os.makedirs(os.path.join(work, "TLSAN"))
+    os.symlink(os.path.join(REF, "Data"), os.path.join(work, "Data"))
+    src = open(os.path.join(REF, "TLSAN", "build_dataset.py")).read()
+    assert "../Data/Digital_Music.pkl" in src
+    src = src.replace("../Data/Digital_Music.pkl", "../Data/%s.pkl" % data_name)
+    cwd = os.getcwd()
+    os.chdir(os.path.join(work, "TLSAN"))
+    try:
+        exec(compile(src, "build_dataset.py", "exec"), {"__name__": "__main__"})
+        with open("dataset.pkl", "rb") as f:
+            train_set = pickle.load(f)
+            test_set = pickle.load(f)
+            counts = pickle.load(f)
+            item_cate_list = pickle.load(f)
+    finally:
+        os.chdir(cwd)
+    return train_set, test_set, counts, item_cate_list
+
+
+def load_ref_input():
+    spec = importlib.util.spec_from_file_location("ref_input", os.path.join(REF, "TLSAN", "input.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def pack(samples, is_test):
+    """Flat CSR export of the sample tuples of build_dataset.py:58-59 (train) / :71 (test)."""
+    n = len(samples)
+    u = np.array([t[0] for t in samples], np.int32)
+    hoff = np.zeros(n + 1, np.int64)
+    soff = np.zeros(n + 1, np.int64)
+    for k, t in enumerate(samples):
+        assert len(t[1]) == len(t[3])
+        hoff[k + 1] = hoff[k] + len(t[1])
+        soff[k + 1] = soff[k] + len(t[2])
+    hist = np.fromiter((x for t in samples for x in t[1]), np.int32, hoff[-1])
+    # time weights are python floats 1/k, k in 1..12 (build_dataset.py:18-21); input.py:35,43,49
+    # stores them into a float32 array, so float32 is lossless w.r.t. what the model sees.
+    hist_t64 = np.fromiter((x for t in samples for x in t[3]), np.float64, hoff[-1])
+    hist_t = hist_t64.astype(np.float32)
+    sess = np.fromiter((x for t in samples for x in t[2]), np.int32, soff[-1])
+    out = dict(u=u, hist_off=hoff, hist=hist, hist_t=hist_t, sess_off=soff, sess=sess)
+    if is_test:
+        out["pos"] = np.array([t[4][0] for t in samples], np.int32)
+        out["neg"] = np.array([t[4][1] for t in samples], np.int32)
+        out["cate"] = np.array([t[5] for t in samples], np.int32)
+    else:
+        out["target"] = np.array([t[4] for t in samples], np.int32)
+        out["label"] = np.array([t[5] for t in samples], np.int8)
+        out["cate"] = np.array([t[6] for t in samples], np.int32)
+    return out
+
+
+def record_batches(ref_input, data, cls_name, batch_size, k, which):
+    it = getattr(ref_input, cls_name)(data, batch_size, k)
+    rec = {}
+    n_batches = it.epoch_size
+    want = set(w if w >= 0 else n_batches + w for w in which)
+    for step, batch in it:
+        bi = step - 1
+        if bi not in want:
+            continue
+        u, i, yj, hist_i, hist_i_new, hist_t, sl, new_sl, c = batch
+        assert hist_i.dtype == np.int64 and hist_t.dtype == np.float32
+        pre = "%s_bs%d_k%d_b%d_" % (cls_name, batch_size, k, bi)
+        rec[pre + "u"] = np.array(u, np.int64)
+        rec[pre + "i"] = np.array(i, np.int64)
+        rec[pre + "yj"] = np.array(yj, np.int64)
+        rec[pre + "hist_i"] = hist_i
+        rec[pre + "hist_i_new"] = hist_i_new
+        rec[pre + "hist_t"] = hist_t
+        rec[pre + "sl"] = np.array(sl, np.int64)
+        rec[pre + "new_sl"] = np.array(new_sl, np.int64)
+        rec[pre + "c"] = np.array(c, np.int64)
+    rec["%s_bs%d_k%d_nbatches" % (cls_name, batch_size, k)] = np.array(n_batches)
+    return rec
+
+
+def main():
+    ref_input = load_ref_input()
+    for short, data_name in DATASETS.items():
+        print("building", data_name, flush=True)
+        train_set, test_set, counts, icl = build_dataset(data_name)
+        print("  train %d test %d counts %s" % (len(train_set), len(test_set), counts))
+        tr, te = pack(train_set, False), pack(test_set, True)
+        np.savez_compressed(
+            os.path.join(OUT, "packed_%s.npz" % short),
+            counts=np.array(counts, np.int64), item_cate_list=np.asarray(icl, np.int32),
+            **{"train_" + k: v for k, v in tr.items()}, **{"test_" + k: v for k, v in te.items()})
+        rec = {}
+        # reference defaults: train batch 32, test batch 128, Ls 10 (train.py:29,44,45)
+        rec.update(record_batches(ref_input, train_set, "DataInput", 32, 10, [0, 1, 2, 3, 4, 5, 6, 7, -1]))
+        rec.update(record_batches(ref_input, test_set, "DataInputTest", 128, 10, [0, 1, -1]))
+        # a shorter window (more truncation) and a big batch
+        rec.update(record_batches(ref_input, train_set, "DataInput", 64, 4, [0, 3, -1]))
+        rec.update(record_batches(ref_input, test_set, "DataInputTest", 50, 3, [0, -1]))
+        rec.update(record_batches(ref_input, train_set, "DataInput", 1024, 10, [0, -1]))
+        np.savez_compressed(os.path.join(OUT, "batches_%s.npz" % short), **rec)
+    print("done")
+
+
+if __name__ == "__main__":
+    sys.exit(main())
