@@ -1,0 +1,164 @@
+/*
+ * tlsan.h -- C ABI of libtlsan_hip.so: the MI355X (gfx950) TLSAN hot path.
+ *
+ * The reference (TsingZ0/TLSAN) has no FFI: its hot path sits behind the Python class
+ * `Model` (TLSAN/model.py:13-313) whose methods call `sess.run` on a TensorFlow-1.8 graph.
+ * Each entry point below replaces one such `sess.run` fetch; the Python `tlsan_amd.Model`
+ * (same constructor / method surface as the reference's Model) binds them with ctypes.
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer inside the structs is a DEVICE pointer unless marked "host";
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); all work is enqueued
+ *     on it, nothing synchronises, nothing allocates (caller supplies `ws` and `state`);
+ *   - return value: 0 = ok, negative = TLSAN_E_* (never throws across the ABI);
+ *     tlsan_last_error() returns a host string for the calling thread's last failure;
+ *   - single host thread per GPU, like the reference (one tf.Session, synchronous).
+ */
+#ifndef TLSAN_H_
+#define TLSAN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TLSAN_ABI_VERSION 1
+
+enum {
+  TLSAN_OK = 0,
+  TLSAN_E_BADARG = -1,      /* unsupported dims / null pointer / shape mismatch            */
+  TLSAN_E_WORKSPACE = -2,   /* ws or state buffer too small                              */
+  TLSAN_E_LAUNCH = -3,      /* HIP launch error (see tlsan_last_error)                   */
+  TLSAN_E_UNSUPPORTED = -4  /* valid request outside what this build implements          */
+};
+
+/* Shapes: config keys read by model.py:64,72,76,81,102,116-117. */
+typedef struct {
+  int32_t user_count, item_count, cate_count;
+  int32_t d;          /* hidden_units = d_item + d_cate = d_user + d_cate (model.py:100-109,135) */
+  int32_t d_item;     /* itemid_embedding_size (== userid_embedding_size)                        */
+  int32_t d_cate;     /* cateid_embedding_size                                                  */
+  int32_t num_heads;  /* 8 in every config; d/num_heads in {8,16,32}                             */
+  int32_t Ls;         /* long-term window (columns of hist_i / usert_emb), <= 10 in this build   */
+} tlsan_dims;
+
+/* Trainable variables of model.py:58-81 + attention/dense weights, fp32, row-major.
+ * `dense` packs the small weights (layout: tlsan_dense_layout):
+ *   fwa1{W1[dh,dh],b1[dh],W2[dh,dh],b2[dh]} | K[d,d] (tf.layers.dense kernel, model.py:347) |
+ *   k0[d] | fwa2{W1,b1,W2,b2} | gamma[1]
+ * `dense_KT` is K transposed, maintained by the library after every update
+ * (tlsan_sync_derived must be called after the caller writes `dense` itself). */
+typedef struct {
+  float* item_emb;            /* [I, d_item] */
+  float* item_b;              /* [I]         */
+  float* user_emb;            /* [U, d_item] */
+  float* usert_emb;           /* [U, Ls]     */
+  float* cate_emb;            /* [C, d_cate] */
+  float* dense;               /* [n_dense]   */
+  float* dense_KT;            /* [d, d]      */
+  const int32_t* item_cate;   /* [I] item -> category (model.py:85 graph constant) */
+} tlsan_params;
+
+typedef struct {
+  int32_t n_dense;
+  int32_t f1_W1, f1_b1, f1_W2, f1_b2, K, k0, f2_W1, f2_b1, f2_W2, f2_b2, gamma;
+} tlsan_dense_layout;
+
+/* One batch = the placeholders of model.py:27-53, int32 / fp32, as fed by
+ * model.py:210-222 (train) and :239-262 (eval). */
+typedef struct {
+  int32_t B;                  /* rows in this batch                                     */
+  int32_t Sn;                 /* columns of hist_i_new (max session length in batch)    */
+  const int32_t* u;           /* [B]                                                    */
+  const int32_t* i;           /* [B] candidate item (train target / eval positive)      */
+  const int32_t* j;           /* [B] optional second candidate (eval negative) or NULL  */
+  const float* y;             /* [B] labels (train only, may be NULL for forward)       */
+  const int32_t* hist_i;      /* [B, Ls]                                                */
+  const int32_t* hist_i_new;  /* [B, Sn]                                                */
+  const float* hist_t;        /* [B, Ls]                                                */
+  const int32_t* sl;          /* [B] valid length of hist_i  (1..Ls)                    */
+  const int32_t* sl_new;      /* [B] valid length of hist_i_new (0..Sn)                 */
+  const int32_t* u_cate;      /* [B]                                                    */
+} tlsan_batch;
+
+enum { TLSAN_NORM_TF18 = 0, TLSAN_NORM_DEDUP = 1 };
+enum { TLSAN_L2_DENSE = 0, TLSAN_L2_LAZY = 1 };
+
+/* Hyper-parameters of one step: model.py:172 (regulation_rate), :201 (max_gradient_norm),
+ * lr placeholder :49; optimizer = sgd (:195). */
+typedef struct {
+  float lr;
+  float reg;
+  float clip;
+  int32_t norm_mode;  /* TLSAN_NORM_*: how clip_by_global_norm's norm treats repeated ids */
+  int32_t l2_mode;    /* TLSAN_L2_*                                                       */
+} tlsan_hparams;
+
+/* Device-side results of a train step (all optional except loss). */
+typedef struct {
+  float* loss;    /* [1]  mean BCE + reg * l2 (model.py:171-172), value BEFORE the update */
+  float* gnorm;   /* [1]  global gradient norm used for clipping                           */
+  float* logits;  /* [B]  model.py:137 (may be NULL)                                       */
+} tlsan_step_out;
+
+int tlsan_abi_version(void);
+const char* tlsan_last_error(void);
+
+int tlsan_dense_layout_of(const tlsan_dims* dims, tlsan_dense_layout* out);
+
+/* Bytes of scratch for batches up to (max_B, max_Sn).  Contents need not persist. */
+size_t tlsan_workspace_bytes(const tlsan_dims* dims, int32_t max_B, int32_t max_Sn);
+
+/* Bytes of persistent optimizer-side state (running sums of squares of the four
+ * regularised tables for the L2 term / clip norm; scatter index counters). */
+size_t tlsan_state_bytes(const tlsan_dims* dims);
+
+/* (Re)initialise `state` from the current parameters and refresh dense_KT.  Call once
+ * after creating / restoring / externally modifying parameters. */
+int tlsan_state_init(const tlsan_dims* dims, const tlsan_params* p, void* state, void* stream);
+
+/* Refresh derived copies (dense_KT) after the caller wrote p->dense. */
+int tlsan_sync_derived(const tlsan_dims* dims, const tlsan_params* p, void* stream);
+
+/* Forward only -- replaces `sess.run(self.logits)` (model.py:239-262).
+ * logits_i[B] for candidate b->i; logits_j[B] for b->j when both are non-NULL;
+ * u_t[B,d] (model.py:135) when non-NULL (input of tlsan_eval_ranks). */
+int tlsan_forward(const tlsan_dims* dims, const tlsan_params* p, const tlsan_batch* b,
+                  float* logits_i, float* logits_j, float* u_t,
+                  void* ws, size_t ws_bytes, void* stream);
+
+/* One optimisation step -- replaces `sess.run([self.loss, self.train_op])`
+ * (model.py:208-234): forward, BCE + L2 loss, backward, global-norm clip, SGD update of
+ * every trainable, deterministic (bitwise reproducible) scatter-add of the embedding
+ * gradients. */
+int tlsan_train_step(const tlsan_dims* dims, const tlsan_params* p, const tlsan_batch* b,
+                     const tlsan_hparams* hp, const tlsan_step_out* out,
+                     void* state, void* ws, size_t ws_bytes, void* stream);
+
+/* Gradients only (no update) -- what `tf.gradients(self.loss, trainables)` (model.py:198)
+ * returns, with duplicate ids summed and reg*W added for the four regularised tables.
+ * Used by the parity tests.  Each output has the shape of the parameter it mirrors. */
+typedef struct {
+  float* item_emb; float* item_b; float* user_emb; float* usert_emb; float* cate_emb;
+  float* dense;    /* [n_dense] */
+} tlsan_grads_out;
+int tlsan_grads(const tlsan_dims* dims, const tlsan_params* p, const tlsan_batch* b,
+                const tlsan_hparams* hp, const tlsan_grads_out* g, const tlsan_step_out* out,
+                void* state, void* ws, size_t ws_bytes, void* stream);
+
+/* All-items scoring -- replaces the metric update ops on `eval_logits`
+ * (model.py:140-156): for each row, the rank of `labels[b]` inside
+ * u_t[b] . [item_emb || cate_emb[item_cate]]^T + item_b under tf.nn.top_k's order
+ * (higher score first, ties -> lower item id first).  hit@k == (rank < k).
+ * The [B, I] score matrix is never materialised. */
+int tlsan_eval_ranks(const tlsan_dims* dims, const tlsan_params* p, const float* u_t,
+                     const int32_t* labels, int32_t B, int32_t* ranks,
+                     void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TLSAN_H_ */

@@ -1,0 +1,221 @@
+"""GPU parity tests: the HIP path (through the C ABI, via tlsan_amd.Model) against the CPU
+oracle on the same seeded inputs.  Tolerances: fp32 logits within 1e-4 of the fp64 oracle
+(BASELINE.json north_star); gradients / updated parameters within 2e-4 relative to the tensor's
+max magnitude (fp32 accumulation order differs); index/mask behaviour exact."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import tlsan_oracle as orc
+from tests.helpers import fixture_batch, make_config, random_batch, random_params
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-4
+
+
+def _model(cfg, cat, p=None, **kw):
+    from tlsan_amd.model import Model
+    m = Model(cfg, cat, **kw)
+    if p is not None:
+        m.set_params({k: np.asarray(v, np.float32) for k, v in p.items()})
+    return m
+
+
+def _tuple(b, test=False):
+    return (b["u"], b["i"], b["j"] if test else b["y"], b["hist_i"], b["hist_i_new"], b["hist_t"],
+            b["sl"], b["sl_new"], b["u_cate"])
+
+
+def _p32(p):
+    """oracle params rounded to fp32 (what the device holds), kept in fp64 for the oracle."""
+    return {k: np.asarray(v, np.float32).astype(np.float64) for k, v in p.items()}
+
+
+def _relerr(a, b):
+    return np.abs(np.asarray(a, np.float64) - b).max() / (np.abs(b).max() + 1e-12)
+
+
+@pytest.mark.parametrize("d,B,Sn", [(64, 37, 3), (128, 50, 5), (128, 16, 0), (128, 1, 2), (256, 21, 4),
+                                    (64, 200, 12), (128, 300, 18)])
+def test_forward_logits(d, B, Sn):
+    cfg = make_config(U=70, I=90, C=11, d=d)
+    p = _p32(random_params(cfg, seed=d + B))
+    b, cat = random_batch(cfg, B=B, Sn=Sn, seed=B + Sn, test=True)
+    m = _model(cfg, cat, p)
+    li, lj, ut, _ = m.forward(_tuple(b, True), is_test=True, want_u_t=True)
+    ref = orc.forward(p, cat, b, 8)
+    bn = dict(b); bn["i"] = b["j"]
+    refj = orc.forward(p, cat, bn, 8)
+    assert np.abs(li.cpu().numpy() - ref["logits"]).max() < LOGIT_TOL
+    assert np.abs(lj.cpu().numpy() - refj["logits"]).max() < LOGIT_TOL
+    assert np.abs(ut.cpu().numpy() - ref["u_t"]).max() < LOGIT_TOL
+    auc = m.eval_auc(None, _tuple(b, True))
+    assert auc == pytest.approx(float(np.mean(ref["logits"] - refj["logits"] > 0)), abs=1e-6)
+
+
+@pytest.mark.parametrize("d,B,Sn", [(64, 45, 4), (128, 40, 3), (128, 33, 9), (256, 18, 2), (128, 1, 0)])
+def test_gradients(d, B, Sn):
+    cfg = make_config(U=30, I=50, C=7, d=d)  # small tables -> many duplicate ids
+    p = _p32(random_params(cfg, seed=3 * d + B))
+    b, cat = random_batch(cfg, B=B, Sn=Sn, seed=B * 7 + Sn)
+    reg = cfg["regulation_rate"]
+    loss, logits, g, sparse = orc.backward(p, cat, b, 8, reg)
+    m = _model(cfg, cat, p)
+    out = m.grads(_tuple(b))
+    assert np.abs(out["logits"] - logits).max() < LOGIT_TOL
+    assert abs(out["loss"] - loss) < 1e-4 * max(1.0, abs(loss))
+    for k in g:
+        gk = np.asarray(out["grads"][k], np.float64).reshape(g[k].shape)
+        assert _relerr(gk, g[k]) < 2e-4, (k, _relerr(gk, g[k]))
+    n18 = orc.global_norm(p, g, sparse, reg, "tf18")
+    assert abs(out["gnorm"] - n18) < 2e-4 * n18
+    m2 = _model(cfg, cat, p, norm_mode="dedup")
+    out2 = m2.grads(_tuple(b))
+    nd = orc.global_norm(p, g, sparse, reg, "dedup")
+    assert abs(out2["gnorm"] - nd) < 2e-4 * nd
+
+
+@pytest.mark.parametrize("norm_mode", ["tf18", "dedup"])
+@pytest.mark.parametrize("clip", [5.0, 0.02])
+def test_train_step_matches_oracle(norm_mode, clip):
+    cfg = make_config(U=40, I=60, C=9, d=128, max_gradient_norm=clip, regulation_rate=1e-3)
+    p = _p32(random_params(cfg, seed=11))
+    b, cat = random_batch(cfg, B=48, Sn=4, seed=12)
+    loss, newp, info = orc.train_step(p, cat, b, 8, cfg["regulation_rate"], lr=0.7, clip=clip,
+                                      norm_mode=norm_mode)
+    if clip < 1:
+        assert info["coef"] < 1.0
+    m = _model(cfg, cat, p, norm_mode=norm_mode)
+    l = m.train(None, _tuple(b), 0.7)
+    assert abs(l - loss) < 1e-4 * max(1.0, abs(loss))
+    assert abs(m.last_gnorm() - info["norm"]) < 2e-4 * info["norm"]
+    got = m.get_params()
+    for k in newp:
+        # compare the UPDATE (new - old), which is what the kernels compute
+        du = np.asarray(got[k], np.float64).reshape(p[k].shape) - p[k]
+        dr = newp[k] - p[k]
+        assert np.abs(du - dr).max() < 2e-4 * (np.abs(dr).max() + 1e-9) + 2e-7, k
+    # K^T copy is kept in sync
+    assert np.array_equal(m.dense_KT.cpu().numpy(), got["dense_K"].T)
+
+
+def test_multi_step_tracks_oracle_and_is_deterministic():
+    cfg = make_config(U=25, I=35, C=5, d=64, regulation_rate=5e-5)
+    p = _p32(random_params(cfg, seed=21))
+    _, cat = random_batch(cfg, B=8, Sn=3, seed=0)
+    batches = [random_batch(cfg, B=40, Sn=1 + s % 4, seed=100 + s)[0] for s in range(6)]
+    runs = []
+    for rep in range(2):
+        m = _model(cfg, cat, p)
+        losses = [m.train(None, _tuple(b), 0.5) for b in batches]
+        runs.append((losses, m.get_params()))
+    # bitwise reproducible (deterministic scatter-add and reductions)
+    assert runs[0][0] == runs[1][0]
+    for k in runs[0][1]:
+        assert np.array_equal(runs[0][1][k], runs[1][1][k]), k
+    q = dict(p)
+    ref_losses = []
+    for b in batches:
+        l, q, _ = orc.train_step(q, cat, b, 8, cfg["regulation_rate"], lr=0.5)
+        ref_losses.append(l)
+    assert np.allclose(runs[0][0], ref_losses, rtol=2e-4, atol=1e-5)
+    for k in q:
+        assert _relerr(runs[0][1][k].reshape(q[k].shape), q[k]) < 5e-4, k
+
+
+@pytest.mark.parametrize("name", ["clothing", "digital_music"])
+def test_real_fixture_batches(name):
+    """Real batches from the reference's input.py, reference default shapes (d=64, B=32/128)."""
+    batch, (U, I, C), icl = fixture_batch(name)
+    cfg = make_config(U=U, I=I, C=C, d=64)
+    p = _p32(orc.init_params(cfg, seed=1234))
+    rng = np.random.RandomState(5)
+    p["item_b"] = rng.uniform(-0.1, 0.1, p["item_b"].shape).astype(np.float32).astype(np.float64)
+    m = _model(cfg, icl, p)
+    b = orc.as_batch(batch)
+    loss, newp, info = orc.train_step(p, icl, b, 8, cfg["regulation_rate"], 1.0)
+    l = m.train(None, batch, 1.0)
+    assert abs(l - loss) < 1e-4 * max(1.0, loss)
+    got = m.get_params()
+    for k in newp:
+        du = np.asarray(got[k], np.float64).reshape(p[k].shape) - p[k]
+        dr = newp[k] - p[k]
+        assert np.abs(du - dr).max() < 3e-4 * (np.abs(dr).max() + 1e-9) + 2e-7, k
+    tb, _, _ = fixture_batch(name, "DataInputTest", 128, 10, 0)
+    tbd = orc.as_batch(tb, is_test=True)
+    q = _p32(got)
+    auc_ref, r1, r2 = orc.eval_auc_batch(q, icl, tbd, 8)
+    assert m.eval_auc(None, tb) == pytest.approx(auc_ref, abs=1.0 / 128 + 1e-9)
+    li, lj, _, _ = m.forward(tb, is_test=True)
+    assert np.abs(li.cpu().numpy() - r1).max() < LOGIT_TOL
+
+
+@pytest.mark.parametrize("d", [64, 128])
+def test_eval_ranks_and_metrics(d):
+    cfg = make_config(U=60, I=333, C=13, d=d)
+    p = _p32(random_params(cfg, seed=31))
+    b, cat = random_batch(cfg, B=77, Sn=3, seed=32, test=True)
+    m = _model(cfg, cat, p)
+    ranks = m.label_ranks(_tuple(b, True)).cpu().numpy()
+    ref = orc.forward(p, cat, b, 8)
+    scores = orc.all_item_scores(p, cat, ref["u_t"])
+    rr = orc.label_ranks(scores, b["i"])
+    # fp32 scores vs fp64 oracle: ranks may differ only where two scores are within rounding
+    srt = np.sort(scores, axis=1)
+    gap = np.abs(scores[np.arange(len(rr)), b["i"]][:, None] - scores)
+    gap[np.arange(len(rr)), b["i"]] = np.inf
+    clear = gap.min(1) > 1e-4
+    assert clear.sum() > 60
+    assert np.array_equal(ranks[clear], rr[clear])
+    assert np.abs(ranks - rr).max() <= 2
+    pr = m.eval_prec(None, _tuple(b, True))
+    rc = m.eval_recall(None, _tuple(b, True))
+    hits = orc.hits_at_k(scores, b["i"])
+    for i, k in enumerate((1, 10, 20, 30, 40, 50)):
+        assert abs(pr[i] - hits[i] / (k * 77)) <= 2 / (k * 77) + 1e-9
+        assert abs(rc[i] - hits[i] / 77) <= 2 / 77 + 1e-9
+    # cumulative semantics (reference never resets the streaming counters)
+    pr2 = m.eval_prec(None, _tuple(b, True))
+    assert np.allclose(pr2, pr)
+    assert m.prec_10.eval() == pytest.approx(pr2[1])
+
+
+def test_exact_ties_follow_topk_order():
+    """Two items with bit-identical rows and biases: the lower id ranks first (tf.nn.top_k)."""
+    cfg = make_config(U=20, I=64, C=4, d=64)
+    p = _p32(random_params(cfg, seed=41))
+    b, cat = random_batch(cfg, B=16, Sn=2, seed=42, test=True)
+    p["item_emb"][9] = p["item_emb"][5]
+    p["item_b"][9] = p["item_b"][5]
+    cat[9] = cat[5]
+    b["i"][:8] = 5
+    b["i"][8:] = 9
+    m = _model(cfg, cat, p)
+    ranks = m.label_ranks(_tuple(b, True)).cpu().numpy()
+    ref = orc.forward(p, cat, b, 8)
+    scores = orc.all_item_scores(p, cat, ref["u_t"]).astype(np.float32)
+    # label 9 must count item 5 as ahead of it, label 5 must not count item 9
+    m2 = _model(cfg, cat, p)
+    b2 = dict(b); b2["i"] = np.where(b["i"] == 5, 9, 5)
+    ranks2 = m2.label_ranks(_tuple(b2, True)).cpu().numpy()
+    assert np.array_equal(ranks2[:8], ranks[:8] + 1)
+    assert np.array_equal(ranks2[8:], ranks[8:] - 1)
+
+
+def test_errors():
+    from tlsan_amd.model import Model
+    from tlsan_amd._lib import TlsanError
+    cfg = make_config(d=96)
+    with pytest.raises(TlsanError):
+        Model(cfg, np.zeros(cfg["item_count"], np.int32))
+    cfg = make_config(d=64, optimizer="adam")
+    with pytest.raises(NotImplementedError):
+        Model(cfg, np.zeros(cfg["item_count"], np.int32))
+    cfg = make_config(d=64)
+    m = Model(cfg, np.zeros(cfg["item_count"], np.int32))
+    b, _ = random_batch(cfg, B=4, Sn=2, seed=1)
+    bad = list(_tuple(b)); bad[3] = bad[3][:, :5]
+    with pytest.raises(ValueError):
+        m.train(None, tuple(bad), 1.0)

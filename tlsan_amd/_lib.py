@@ -1,0 +1,105 @@
+"""ctypes binding of libtlsan_hip.so (include/tlsan.h).  The product path has no CPU
+fallback: if the HIP library is missing or fails to load, importing users get a loud error."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libtlsan_hip.so")
+
+ABI_VERSION = 1
+NORM_TF18, NORM_DEDUP = 0, 1
+L2_DENSE, L2_LAZY = 0, 1
+
+EXPORTS = [
+    "tlsan_abi_version", "tlsan_last_error", "tlsan_dense_layout_of", "tlsan_workspace_bytes",
+    "tlsan_state_bytes", "tlsan_state_init", "tlsan_sync_derived", "tlsan_forward",
+    "tlsan_train_step", "tlsan_grads", "tlsan_eval_ranks",
+]
+
+
+class Dims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("user_count", "item_count", "cate_count", "d", "d_item", "d_cate", "num_heads", "Ls")]
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("item_emb", "item_b", "user_emb", "usert_emb", "cate_emb", "dense", "dense_KT", "item_cate")]
+
+
+class DenseLayout(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("n_dense", "f1_W1", "f1_b1", "f1_W2", "f1_b2", "K", "k0", "f2_W1", "f2_b1", "f2_W2",
+                 "f2_b2", "gamma")]
+
+
+class Batch(C.Structure):
+    _fields_ = [("B", C.c_int32), ("Sn", C.c_int32)] + [(n, C.c_void_p) for n in
+                ("u", "i", "j", "y", "hist_i", "hist_i_new", "hist_t", "sl", "sl_new", "u_cate")]
+
+
+class HParams(C.Structure):
+    _fields_ = [("lr", C.c_float), ("reg", C.c_float), ("clip", C.c_float),
+                ("norm_mode", C.c_int32), ("l2_mode", C.c_int32)]
+
+
+class StepOut(C.Structure):
+    _fields_ = [("loss", C.c_void_p), ("gnorm", C.c_void_p), ("logits", C.c_void_p)]
+
+
+class GradsOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("item_emb", "item_b", "user_emb", "usert_emb", "cate_emb", "dense")]
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (building nothing).  Raises RuntimeError when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "tlsan_amd: %s not found -- build it with `python -m tlsan_amd.build` "
+            "(hipcc, --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    lib.tlsan_abi_version.restype = C.c_int
+    lib.tlsan_last_error.restype = C.c_char_p
+    lib.tlsan_dense_layout_of.argtypes = [P(Dims), P(DenseLayout)]
+    lib.tlsan_workspace_bytes.argtypes = [P(Dims), C.c_int32, C.c_int32]
+    lib.tlsan_workspace_bytes.restype = C.c_size_t
+    lib.tlsan_state_bytes.argtypes = [P(Dims)]
+    lib.tlsan_state_bytes.restype = C.c_size_t
+    lib.tlsan_state_init.argtypes = [P(Dims), P(Params), C.c_void_p, C.c_void_p]
+    lib.tlsan_sync_derived.argtypes = [P(Dims), P(Params), C.c_void_p]
+    lib.tlsan_forward.argtypes = [P(Dims), P(Params), P(Batch), C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.tlsan_train_step.argtypes = [P(Dims), P(Params), P(Batch), P(HParams), P(StepOut),
+                                     C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.tlsan_grads.argtypes = [P(Dims), P(Params), P(Batch), P(HParams), P(GradsOut), P(StepOut),
+                                C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.tlsan_eval_ranks.argtypes = [P(Dims), P(Params), C.c_void_p, C.c_void_p, C.c_int32,
+                                     C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    for name in ("tlsan_dense_layout_of", "tlsan_state_init", "tlsan_sync_derived", "tlsan_forward",
+                 "tlsan_train_step", "tlsan_grads", "tlsan_eval_ranks"):
+        getattr(lib, name).restype = C.c_int
+    if lib.tlsan_abi_version() != ABI_VERSION:
+        raise RuntimeError("tlsan_amd: ABI mismatch (library %d, binding %d)"
+                           % (lib.tlsan_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+class TlsanError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().tlsan_last_error()
+        raise TlsanError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))

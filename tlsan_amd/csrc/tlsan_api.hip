@@ -1,0 +1,429 @@
+// tlsan_api.hip -- the C ABI declared in include/tlsan.h: argument checking, workspace carving
+// and kernel sequencing.  No allocation, no synchronisation; everything is enqueued on the
+// caller's stream (so a whole step can be captured into a hipGraph).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "tlsan_common.h"
+#include "tlsan_eval.h"
+#include "tlsan_update.h"
+
+hipError_t tlsan_launch_fwd_bwd_d64(bool train, const FwdArgs& a, int grid, hipStream_t st);
+hipError_t tlsan_launch_fwd_bwd_d128(bool train, const FwdArgs& a, int grid, hipStream_t st);
+hipError_t tlsan_launch_fwd_bwd_d256(bool train, const FwdArgs& a, int grid, hipStream_t st);
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define CHECK_LAUNCH(what)                                                         \
+  do {                                                                             \
+    hipError_t e_ = hipGetLastError();                                             \
+    if (e_ != hipSuccess) return fail(TLSAN_E_LAUNCH, "%s: %s", what, hipGetErrorString(e_)); \
+  } while (0)
+
+static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Shape {  // derived geometry of the supported (d, heads) combinations
+  int D, DH, NSB, NPB, CW;
+};
+
+static int shape_of(const tlsan_dims* d, Shape* s) {
+  if (!d) return fail(TLSAN_E_BADARG, "dims is NULL");
+  if (d->num_heads <= 0 || d->d % d->num_heads) return fail(TLSAN_E_BADARG, "d %% num_heads != 0");
+  const int D = d->d, DH = D / d->num_heads;
+  if (d->d_item + d->d_cate != D) return fail(TLSAN_E_BADARG, "d_item + d_cate != d (model.py:100-109)");
+  if (d->d_item % 4 || d->d_cate % 4 || d->d_item > 128 || d->d_cate > 128)
+    return fail(TLSAN_E_UNSUPPORTED, "embedding widths must be multiples of 4 and <= 128");
+  if (d->Ls < 1 || d->Ls > TLSAN_LS_MAX) return fail(TLSAN_E_UNSUPPORTED, "Ls must be in 1..%d", TLSAN_LS_MAX);
+  if (d->user_count < 1 || d->item_count < 1 || d->cate_count < 1) return fail(TLSAN_E_BADARG, "empty table");
+  s->D = D;
+  s->DH = DH;
+  if (D == 64 && DH == 8) { using G = Geo<64, 8>; s->NSB = G::NSB; s->NPB = G::NPB; s->CW = G::CW; }
+  else if (D == 128 && DH == 16) { using G = Geo<128, 16>; s->NSB = G::NSB; s->NPB = G::NPB; s->CW = G::CW; }
+  else if (D == 256 && DH == 32) { using G = Geo<256, 32>; s->NSB = G::NSB; s->NPB = G::NPB; s->CW = G::CW; }
+  else return fail(TLSAN_E_UNSUPPORTED, "unsupported (hidden_units=%d, num_heads=%d): this build has 64/8, 128/8, 256/8", D, d->num_heads);
+  return TLSAN_OK;
+}
+
+#define DK_CHUNK 64
+
+struct Ws {  // carve-up of the caller's scratch buffer
+  float *G, *GT, *dlogit, *gLong, *gDB, *partials, *Kp, *gd, *sqd, *scal, *logits, *s_label;
+  int32_t *off_item, *off_cate, *off_user, *cur_item, *cur_cate, *cur_user;
+  int32_t *list_item, *list_cate, *list_user;
+  double* rownorm_part;
+  double* rownorm;
+  size_t bytes;
+  int ngroups, nsplit, nfin;
+};
+
+static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base, Ws* w) {
+  size_t o = 0;
+  auto take = [&](size_t n) { char* p = base ? base + o : nullptr; o += al(n); return p; };
+  const size_t S = (size_t)d->Ls + Sn + 2, D = s.D;
+  tlsan_dense_layout L;
+  tlsan_dense_layout_of(d, &L);
+  w->ngroups = (B + s.NSB - 1) / s.NSB;
+  w->nsplit = (B + DK_CHUNK - 1) / DK_CHUNK;
+  w->nfin = (L.n_dense + 255) / 256;
+  w->G = (float*)take(sizeof(float) * B * S * D);
+  w->GT = (float*)take(sizeof(float) * B * d->Ls);
+  w->dlogit = (float*)take(sizeof(float) * B);
+  w->gLong = (float*)take(sizeof(float) * B * D);
+  w->gDB = (float*)take(sizeof(float) * B * D);
+  w->partials = (float*)take(sizeof(float) * w->ngroups * s.NPB);
+  w->Kp = (float*)take(sizeof(float) * w->nsplit * D * D);
+  w->gd = (float*)take(sizeof(float) * L.n_dense);
+  w->sqd = (float*)take(sizeof(float) * w->nfin);
+  w->scal = (float*)take(sizeof(float) * 4);
+  w->logits = (float*)take(sizeof(float) * B);
+  w->s_label = (float*)take(sizeof(float) * B);
+  w->off_item = (int32_t*)take(4 * (size_t)d->item_count);
+  w->off_cate = (int32_t*)take(4 * (size_t)d->cate_count);
+  w->off_user = (int32_t*)take(4 * (size_t)d->user_count);
+  w->cur_item = (int32_t*)take(4 * (size_t)d->item_count);
+  w->cur_cate = (int32_t*)take(4 * (size_t)d->cate_count);
+  w->cur_user = (int32_t*)take(4 * (size_t)d->user_count);
+  w->list_item = (int32_t*)take(4 * (size_t)B * S);
+  w->list_cate = (int32_t*)take(4 * (size_t)B * S);
+  w->list_user = (int32_t*)take(4 * (size_t)B);
+  const size_t nrowblk = (size_t)(d->item_count + 3) / 4 + (d->user_count + 3) / 4 + d->cate_count;
+  w->rownorm_part = (double*)take(8 * nrowblk);
+  w->rownorm = (double*)take(8);
+  w->bytes = o;
+}
+
+struct St {  // persistent state
+  int32_t *cnt_item, *cnt_cate, *cnt_user;
+  double *S_part, *S_total;
+  size_t bytes;
+  int nbI, nbU, nbC;
+};
+
+static void carve_state(const tlsan_dims* d, char* base, St* s) {
+  size_t o = 0;
+  auto take = [&](size_t n) { char* p = base ? base + o : nullptr; o += al(n); return p; };
+  s->nbI = (d->item_count + 3) / 4;
+  s->nbU = (d->user_count + 3) / 4;
+  s->nbC = d->cate_count;
+  s->cnt_item = (int32_t*)take(4 * (size_t)d->item_count);
+  s->cnt_cate = (int32_t*)take(4 * (size_t)d->cate_count);
+  s->cnt_user = (int32_t*)take(4 * (size_t)d->user_count);
+  s->S_part = (double*)take(8 * (size_t)(s->nbI + s->nbU + s->nbC));
+  s->S_total = (double*)take(8);
+  s->bytes = o;
+}
+
+extern "C" {
+
+int tlsan_abi_version(void) { return TLSAN_ABI_VERSION; }
+const char* tlsan_last_error(void) { return g_err; }
+
+int tlsan_dense_layout_of(const tlsan_dims* d, tlsan_dense_layout* L) {
+  if (!d || !L || d->num_heads <= 0) return fail(TLSAN_E_BADARG, "null dims/layout");
+  const int D = d->d, dh = D / d->num_heads;
+  int o = 0;
+  L->f1_W1 = o; o += dh * dh;
+  L->f1_b1 = o; o += dh;
+  L->f1_W2 = o; o += dh * dh;
+  L->f1_b2 = o; o += dh;
+  L->K = o; o += D * D;
+  L->k0 = o; o += D;
+  L->f2_W1 = o; o += dh * dh;
+  L->f2_b1 = o; o += dh;
+  L->f2_W2 = o; o += dh * dh;
+  L->f2_b2 = o; o += dh;
+  L->gamma = o; o += 1;
+  L->n_dense = o;
+  return TLSAN_OK;
+}
+
+size_t tlsan_workspace_bytes(const tlsan_dims* d, int32_t max_B, int32_t max_Sn) {
+  Shape s;
+  if (shape_of(d, &s) != TLSAN_OK || max_B < 1 || max_Sn < 0) return 0;
+  Ws w;
+  carve(d, s, max_B, max_Sn, nullptr, &w);
+  return w.bytes;
+}
+
+size_t tlsan_state_bytes(const tlsan_dims* d) {
+  Shape s;
+  if (shape_of(d, &s) != TLSAN_OK) return 0;
+  St st;
+  carve_state(d, nullptr, &st);
+  return st.bytes;
+}
+
+static int check_params(const tlsan_params* p) {
+  if (!p || !p->item_emb || !p->item_b || !p->user_emb || !p->usert_emb || !p->cate_emb || !p->dense ||
+      !p->dense_KT || !p->item_cate)
+    return fail(TLSAN_E_BADARG, "NULL parameter pointer");
+  return TLSAN_OK;
+}
+
+static int check_batch(const tlsan_dims* d, const tlsan_batch* b, bool train) {
+  if (!b || b->B < 1 || b->Sn < 0) return fail(TLSAN_E_BADARG, "bad batch (B=%d, Sn=%d)", b ? b->B : -1, b ? b->Sn : -1);
+  if (!b->u || !b->i || !b->hist_i || !b->hist_t || !b->sl || !b->sl_new || !b->u_cate || (b->Sn > 0 && !b->hist_i_new))
+    return fail(TLSAN_E_BADARG, "NULL batch pointer");
+  if (train && !b->y) return fail(TLSAN_E_BADARG, "training needs labels y");
+  if ((size_t)b->B * (d->Ls + b->Sn + 2) >= ((size_t)1 << 31)) return fail(TLSAN_E_UNSUPPORTED, "B*S overflows int32");
+  return TLSAN_OK;
+}
+
+static void fill_apply(ApplyArgs& A, const tlsan_dims* d, const Shape& s, const tlsan_params* p, const tlsan_batch* b,
+                       const tlsan_hparams* hp, const Ws& w, const St& st, const tlsan_dense_layout& L) {
+  memset(&A, 0, sizeof(A));
+  A.p = *p;
+  A.lay = L;
+  A.I = d->item_count; A.U = d->user_count; A.C = d->cate_count; A.Ls = d->Ls; A.D = s.D;
+  A.di = d->d_item; A.dc = d->d_cate;
+  A.Sn = b ? b->Sn : 0;
+  A.S = d->Ls + A.Sn + 2;
+  A.G = w.G; A.GT = w.GT; A.dlogit = w.dlogit;
+  A.cnt_item = st.cnt_item; A.cnt_cate = st.cnt_cate; A.cnt_user = st.cnt_user;
+  A.off_item = w.off_item; A.off_cate = w.off_cate; A.off_user = w.off_user;
+  A.list_item = w.list_item; A.list_cate = w.list_cate; A.list_user = w.list_user;
+  A.gd = w.gd; A.sqd = w.sqd; A.nsqd = w.nfin; A.scal = w.scal;
+  A.part_out = st.S_part; A.S_total = st.S_total; A.rownorm = w.rownorm;
+  if (hp) { A.lr = hp->lr; A.reg = hp->reg; A.clip = hp->clip; A.norm_mode = hp->norm_mode; }
+  A.inv_B = b ? 1.0f / (float)b->B : 0.0f;
+  A.nbI = st.nbI; A.nbU = st.nbU; A.nbC = st.nbC; A.nbD = (L.n_dense + 255) / 256;
+}
+
+int tlsan_sync_derived(const tlsan_dims* d, const tlsan_params* p, void* stream) {
+  Shape s;
+  int rc = shape_of(d, &s);
+  if (rc) return rc;
+  if ((rc = check_params(p))) return rc;
+  tlsan_dense_layout L;
+  tlsan_dense_layout_of(d, &L);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_transpose_K, dim3((s.D * s.D + 255) / 256), dim3(256), 0, st, p->dense + L.K, p->dense_KT, s.D);
+  CHECK_LAUNCH("k_transpose_K");
+  return TLSAN_OK;
+}
+
+int tlsan_state_init(const tlsan_dims* d, const tlsan_params* p, void* state, void* stream) {
+  Shape s;
+  int rc = shape_of(d, &s);
+  if (rc) return rc;
+  if ((rc = check_params(p))) return rc;
+  if (!state) return fail(TLSAN_E_WORKSPACE, "state is NULL");
+  if ((rc = tlsan_sync_derived(d, p, stream))) return rc;
+  St st;
+  carve_state(d, (char*)state, &st);
+  hipStream_t hs = (hipStream_t)stream;
+  if (hipMemsetAsync(state, 0, st.bytes, hs) != hipSuccess) return fail(TLSAN_E_LAUNCH, "memset state");
+  tlsan_dense_layout L;
+  tlsan_dense_layout_of(d, &L);
+  Ws w;
+  memset(&w, 0, sizeof(w));
+  ApplyArgs A;
+  fill_apply(A, d, s, p, nullptr, nullptr, w, st, L);
+  hipLaunchKernelGGL(k_apply_rows<AP_SUMSQ>, dim3(st.nbI + st.nbU + st.nbC), dim3(256), 0, hs, A);
+  CHECK_LAUNCH("k_apply_rows<SUMSQ>");
+  hipLaunchKernelGGL(k_reduce_double, dim3(1), dim3(256), 0, hs, st.S_part, st.nbI + st.nbU + st.nbC, st.S_total);
+  CHECK_LAUNCH("k_reduce_double");
+  return TLSAN_OK;
+}
+
+static int launch_fwd(const Shape& s, bool train, const FwdArgs& a, hipStream_t hs) {
+  int grid = a.ngroups < 4096 ? a.ngroups : 4096;
+  hipError_t e;
+  if (s.D == 64) e = tlsan_launch_fwd_bwd_d64(train, a, grid, hs);
+  else if (s.D == 128) e = tlsan_launch_fwd_bwd_d128(train, a, grid, hs);
+  else e = tlsan_launch_fwd_bwd_d256(train, a, grid, hs);
+  if (e != hipSuccess) return fail(TLSAN_E_LAUNCH, "k_fwd_bwd: %s", hipGetErrorString(e));
+  return TLSAN_OK;
+}
+
+static void fill_fwd(FwdArgs& a, const tlsan_dims* d, const Shape& s, const tlsan_params* p, const tlsan_batch* b,
+                     const Ws& w, const tlsan_dense_layout& L) {
+  memset(&a, 0, sizeof(a));
+  a.p = *p;
+  a.b = *b;
+  a.lay = L;
+  a.Ls = d->Ls; a.di = d->d_item; a.dc = d->d_cate;
+  a.S = d->Ls + b->Sn + 2;
+  a.ngroups = (b->B + s.NSB - 1) / s.NSB;
+  a.inv_B = 1.0f / (float)b->B;
+}
+
+int tlsan_forward(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch* b, float* logits_i, float* logits_j,
+                  float* u_t, void* ws, size_t ws_bytes, void* stream) {
+  Shape s;
+  int rc = shape_of(d, &s);
+  if (rc) return rc;
+  if ((rc = check_params(p))) return rc;
+  if ((rc = check_batch(d, b, false))) return rc;
+  (void)ws; (void)ws_bytes;
+  tlsan_dense_layout L;
+  tlsan_dense_layout_of(d, &L);
+  Ws w;
+  memset(&w, 0, sizeof(w));
+  FwdArgs a;
+  fill_fwd(a, d, s, p, b, w, L);
+  a.logits_i = logits_i;
+  a.logits_j = logits_j;
+  a.u_t = u_t;
+  return launch_fwd(s, false, a, (hipStream_t)stream);
+}
+
+// shared front half of train_step / grads: index build, fused fwd+bwd, dense-grad reduction
+static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params* p, const tlsan_batch* b,
+                        const tlsan_step_out* out, const Ws& w, const St& st, const tlsan_dense_layout& L,
+                        hipStream_t hs) {
+  const int S = d->Ls + b->Sn + 2;
+  // --- inverted index: counts -> offsets -> lists
+  IdxArgs ia;
+  memset(&ia, 0, sizeof(ia));
+  ia.b = *b; ia.item_cate = p->item_cate; ia.Ls = d->Ls; ia.S = S;
+  ia.cnt_item = st.cnt_item; ia.cnt_cate = st.cnt_cate; ia.cnt_user = st.cnt_user;
+  ia.cur_item = w.cur_item; ia.cur_cate = w.cur_cate; ia.cur_user = w.cur_user;
+  ia.list_item = w.list_item; ia.list_cate = w.list_cate; ia.list_user = w.list_user;
+  const int nthr = b->B * S;
+  hipLaunchKernelGGL(k_index<false>, dim3((nthr + 255) / 256), dim3(256), 0, hs, ia);
+  CHECK_LAUNCH("k_index<count>");
+  ScanArgs sa;
+  sa.cnt[0] = st.cnt_item; sa.cnt[1] = st.cnt_cate; sa.cnt[2] = st.cnt_user;
+  sa.off[0] = w.off_item; sa.off[1] = w.off_cate; sa.off[2] = w.off_user;
+  sa.cur[0] = w.cur_item; sa.cur[1] = w.cur_cate; sa.cur[2] = w.cur_user;
+  sa.n[0] = d->item_count; sa.n[1] = d->cate_count; sa.n[2] = d->user_count;
+  hipLaunchKernelGGL(k_index_scan, dim3(3), dim3(1024), 0, hs, sa);
+  CHECK_LAUNCH("k_index_scan");
+  hipLaunchKernelGGL(k_index<true>, dim3((nthr + 255) / 256), dim3(256), 0, hs, ia);
+  CHECK_LAUNCH("k_index<fill>");
+  // --- fused forward + backward
+  FwdArgs a;
+  fill_fwd(a, d, s, p, b, w, L);
+  a.logits_i = (out && out->logits) ? out->logits : w.logits;
+  a.G = w.G; a.GT = w.GT; a.dlogit = w.dlogit; a.gLong = w.gLong; a.gDB = w.gDB; a.partials = w.partials;
+  int rc = launch_fwd(s, true, a, hs);
+  if (rc) return rc;
+  // --- dense-parameter gradients
+  if (s.D == 64) hipLaunchKernelGGL(k_dk_partial<64>, dim3(w.nsplit), dim3(512), 0, hs, w.gLong, w.gDB, b->B, DK_CHUNK, w.Kp);
+  else if (s.D == 128) hipLaunchKernelGGL(k_dk_partial<128>, dim3(w.nsplit), dim3(512), 0, hs, w.gLong, w.gDB, b->B, DK_CHUNK, w.Kp);
+  else hipLaunchKernelGGL(k_dk_partial<256>, dim3(w.nsplit), dim3(512), 0, hs, w.gLong, w.gDB, b->B, DK_CHUNK, w.Kp);
+  CHECK_LAUNCH("k_dk_partial");
+  FinArgs f;
+  memset(&f, 0, sizeof(f));
+  f.lay = L; f.partials = w.partials; f.nrec = w.ngroups; f.Kp = w.Kp; f.nsplit = w.nsplit;
+  f.gd = w.gd; f.sqd = w.sqd; f.scal = w.scal;
+  f.S_part = st.S_part; f.n_spart = st.nbI + st.nbU + st.nbC; f.S_total = st.S_total;
+  if (s.D == 64) hipLaunchKernelGGL((k_dense_finalize<64, 8>), dim3(w.nfin + 1), dim3(256), 0, hs, f);
+  else if (s.D == 128) hipLaunchKernelGGL((k_dense_finalize<128, 16>), dim3(w.nfin + 1), dim3(256), 0, hs, f);
+  else hipLaunchKernelGGL((k_dense_finalize<256, 32>), dim3(w.nfin + 1), dim3(256), 0, hs, f);
+  CHECK_LAUNCH("k_dense_finalize");
+  return TLSAN_OK;
+}
+
+static int prep_step(const tlsan_dims* d, Shape* s, const tlsan_params* p, const tlsan_batch* b, const tlsan_hparams* hp,
+                     void* state, void* ws, size_t ws_bytes, Ws* w, St* st) {
+  int rc = shape_of(d, s);
+  if (rc) return rc;
+  if ((rc = check_params(p))) return rc;
+  if ((rc = check_batch(d, b, true))) return rc;
+  if (!hp) return fail(TLSAN_E_BADARG, "hparams is NULL");
+  if (hp->l2_mode != TLSAN_L2_DENSE) return fail(TLSAN_E_UNSUPPORTED, "l2_mode: only TLSAN_L2_DENSE in this build");
+  if (hp->norm_mode != TLSAN_NORM_TF18 && hp->norm_mode != TLSAN_NORM_DEDUP) return fail(TLSAN_E_BADARG, "norm_mode");
+  if (!state || !ws) return fail(TLSAN_E_WORKSPACE, "state / ws is NULL");
+  carve(d, *s, b->B, b->Sn, (char*)ws, w);
+  if (w->bytes > ws_bytes) return fail(TLSAN_E_WORKSPACE, "workspace too small: need %zu have %zu", w->bytes, ws_bytes);
+  carve_state(d, (char*)state, st);
+  return TLSAN_OK;
+}
+
+int tlsan_train_step(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch* b, const tlsan_hparams* hp,
+                     const tlsan_step_out* out, void* state, void* ws, size_t ws_bytes, void* stream) {
+  Shape s; Ws w; St st;
+  int rc = prep_step(d, &s, p, b, hp, state, ws, ws_bytes, &w, &st);
+  if (rc) return rc;
+  hipStream_t hs = (hipStream_t)stream;
+  tlsan_dense_layout L;
+  tlsan_dense_layout_of(d, &L);
+  if ((rc = run_backward(d, s, p, b, out, w, st, L, hs))) return rc;
+  ApplyArgs A;
+  fill_apply(A, d, s, p, b, hp, w, st, L);
+  A.out_loss = out ? out->loss : nullptr;
+  A.out_gnorm = out ? out->gnorm : nullptr;
+  const int nrow = st.nbI + st.nbU + st.nbC;
+  if (hp->norm_mode == TLSAN_NORM_DEDUP) {
+    ApplyArgs R = A;
+    R.part_out = w.rownorm_part;
+    hipLaunchKernelGGL(k_apply_rows<AP_ROWNORM>, dim3(nrow), dim3(256), 0, hs, R);
+    CHECK_LAUNCH("k_apply_rows<ROWNORM>");
+    hipLaunchKernelGGL(k_reduce_double, dim3(1), dim3(256), 0, hs, w.rownorm_part, nrow, w.rownorm);
+    CHECK_LAUNCH("k_reduce_double");
+  }
+  hipLaunchKernelGGL(k_apply_rows<AP_UPDATE>, dim3(nrow + A.nbD), dim3(256), 0, hs, A);
+  CHECK_LAUNCH("k_apply_rows<UPDATE>");
+  return TLSAN_OK;
+}
+
+int tlsan_grads(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch* b, const tlsan_hparams* hp,
+                const tlsan_grads_out* g, const tlsan_step_out* out, void* state, void* ws, size_t ws_bytes, void* stream) {
+  Shape s; Ws w; St st;
+  int rc = prep_step(d, &s, p, b, hp, state, ws, ws_bytes, &w, &st);
+  if (rc) return rc;
+  if (!g || !g->item_emb || !g->item_b || !g->user_emb || !g->usert_emb || !g->cate_emb || !g->dense)
+    return fail(TLSAN_E_BADARG, "NULL gradient output");
+  hipStream_t hs = (hipStream_t)stream;
+  tlsan_dense_layout L;
+  tlsan_dense_layout_of(d, &L);
+  if ((rc = run_backward(d, s, p, b, out, w, st, L, hs))) return rc;
+  ApplyArgs A;
+  fill_apply(A, d, s, p, b, hp, w, st, L);
+  A.go = *g;
+  A.out_loss = out ? out->loss : nullptr;
+  A.out_gnorm = out ? out->gnorm : nullptr;
+  const int nrow = st.nbI + st.nbU + st.nbC;
+  if (hp->norm_mode == TLSAN_NORM_DEDUP) {
+    ApplyArgs R = A;
+    R.part_out = w.rownorm_part;
+    hipLaunchKernelGGL(k_apply_rows<AP_ROWNORM>, dim3(nrow), dim3(256), 0, hs, R);
+    CHECK_LAUNCH("k_apply_rows<ROWNORM>");
+    hipLaunchKernelGGL(k_reduce_double, dim3(1), dim3(256), 0, hs, w.rownorm_part, nrow, w.rownorm);
+    CHECK_LAUNCH("k_reduce_double");
+  }
+  hipLaunchKernelGGL(k_apply_rows<AP_GRADS>, dim3(nrow + A.nbD), dim3(256), 0, hs, A);
+  CHECK_LAUNCH("k_apply_rows<GRADS>");
+  return TLSAN_OK;
+}
+
+int tlsan_eval_ranks(const tlsan_dims* d, const tlsan_params* p, const float* u_t, const int32_t* labels, int32_t B,
+                     int32_t* ranks, void* ws, size_t ws_bytes, void* stream) {
+  Shape s;
+  int rc = shape_of(d, &s);
+  if (rc) return rc;
+  if ((rc = check_params(p))) return rc;
+  if (!u_t || !labels || !ranks || B < 1) return fail(TLSAN_E_BADARG, "bad eval arguments");
+  if (!ws) return fail(TLSAN_E_WORKSPACE, "ws is NULL");
+  Ws w;
+  carve(d, s, B, 0, (char*)ws, &w);
+  if (w.bytes > ws_bytes) return fail(TLSAN_E_WORKSPACE, "workspace too small: need %zu have %zu", w.bytes, ws_bytes);
+  hipStream_t hs = (hipStream_t)stream;
+  EvalArgs e;
+  memset(&e, 0, sizeof(e));
+  e.p = *p; e.u_t = u_t; e.labels = labels; e.B = B; e.I = d->item_count; e.di = d->d_item; e.dc = d->d_cate;
+  e.s_label = w.s_label; e.ranks = ranks;
+  if (hipMemsetAsync(ranks, 0, sizeof(int32_t) * (size_t)B, hs) != hipSuccess) return fail(TLSAN_E_LAUNCH, "memset ranks");
+  const int ut = (B + 15) / 16;
+  const int ntiles = (d->item_count + 15) / 16;
+  int chunks = (ntiles + 3) / 4;
+  const int want = (2048 + ut - 1) / ut;  // enough workgroups to fill the chip
+  if (chunks > want) chunks = want;
+  if (chunks < 1) chunks = 1;
+  if (s.D == 64) { hipLaunchKernelGGL(k_eval_label<64>, dim3(ut), dim3(64), 0, hs, e); hipLaunchKernelGGL(k_eval_rank<64>, dim3(ut, chunks), dim3(256), 0, hs, e); }
+  else if (s.D == 128) { hipLaunchKernelGGL(k_eval_label<128>, dim3(ut), dim3(64), 0, hs, e); hipLaunchKernelGGL(k_eval_rank<128>, dim3(ut, chunks), dim3(256), 0, hs, e); }
+  else { hipLaunchKernelGGL(k_eval_label<256>, dim3(ut), dim3(64), 0, hs, e); hipLaunchKernelGGL(k_eval_rank<256>, dim3(ut, chunks), dim3(256), 0, hs, e); }
+  CHECK_LAUNCH("k_eval");
+  return TLSAN_OK;
+}
+
+}  // extern "C"

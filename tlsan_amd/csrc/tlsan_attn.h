@@ -1,0 +1,605 @@
+// tlsan_attn.h -- the fused per-sample kernel: gathers -> long-term feature-wise attention
+// -> bridge -> short-term feature-wise attention -> logit (-> loss -> full backward).
+//
+// Follows reference TLSAN/model.py:84-137 (forward), :164-172 (loss), and what
+// tf.gradients (:198) differentiates.  Phases per workgroup pass over NSB samples:
+//   P1  per wave   gather long rows, scale by gamma*usert*hist_t, FWA block 1 -> long
+//   P2  workgroup  bridge = long . K + k0          (16x16x4 f32 MFMA, A from LDS, B = K^T rows)
+//   P3  per wave   gather session rows, FWA block 2, logit, BCE, backward of block 2
+//   P4  workgroup  dlong = dbridge . K^T           (MFMA, B = K rows)
+//   P5  per wave   backward of block 1, per-use gradient rows, usert / gamma gradients
+// Per-use gradient rows are written once with plain 16-B stores into G[b*S + slot];
+// k_apply_rows sums them per destination row with exact (order-independent) arithmetic.
+#pragma once
+#include "tlsan_common.h"
+
+// ---------------------------------------------------------------------------------------
+// feature_wise_attention forward (model.py:370-394) over NPOS static positions held in
+// registers.  e[p] = raw rows, sc[p] = per-position scale.  Returns out = sum_p a[p] x[p]
+// plus the per-channel softmax statistics (mx = max score, Z = 1/sum exp) from which the
+// backward recomputes a[p] = exp(m2[p] - mx) * Z (exactly 0 on masked positions).
+template <int NB, int NPOS>
+__device__ __forceinline__ void fwa_forward(const float (&FT1)[NB][NB][4], const f32x4 (&b1)[NB],
+                                            const float (&FT2)[NB][NB][4], const f32x4 (&b2)[NB],
+                                            const f32x4 (&e)[NPOS][NB], const float (&sc)[NPOS],
+                                            int n_valid, int pmax, f32x4 (&mx)[NB],
+                                            f32x4 (&Z)[NB], f32x4 (&out)[NB]) {
+  f32x4 a[NPOS][NB];
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb) mx[kb] = (f32x4)(TLSAN_NEG);
+#pragma unroll
+  for (int p = 0; p < NPOS; ++p) {
+    if (p < pmax) {  // wave-uniform
+      f32x4 xv[NB], z[NB], m2[NB];
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) xv[kb] = e[p][kb] * sc[p];
+      map_apply<NB>(FT1, b1, xv, z);  // model.py:380 (relu below)
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[kb][i] = fmaxf(z[kb][i], 0.0f);
+      map_apply<NB>(FT2, b2, z, m2);  // model.py:382
+      const bool valid = p < n_valid;
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) {
+        // model.py:384: m2 + (1-mask)*(-1e30) == -1e30 exactly in fp32
+        a[p][kb] = valid ? m2[kb] : (f32x4)(TLSAN_NEG);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mx[kb][i] = fmaxf(mx[kb][i], a[p][kb][i]);
+      }
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) a[p][kb] = (f32x4)(TLSAN_NEG);
+    }
+  }
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb) Z[kb] = (f32x4)(0.0f);
+#pragma unroll
+  for (int p = 0; p < NPOS; ++p)
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float ev = __expf(a[p][kb][i] - mx[kb][i]);  // softmax over positions, model.py:386
+        a[p][kb][i] = ev;
+        Z[kb][i] += ev;
+      }
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb) {
+    out[kb] = (f32x4)(0.0f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Z[kb][i] = 1.0f / Z[kb][i];
+  }
+#pragma unroll
+  for (int p = 0; p < NPOS; ++p)
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+      a[p][kb] = a[p][kb] * Z[kb];
+      out[kb] += a[p][kb] * (e[p][kb] * sc[p]);  // model.py:387
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Backward of one position of feature_wise_attention.  Inputs in C-layout: x (scaled row),
+// z1 = x W1 + b1 (recomputed by the caller, bitwise equal to the forward), a (softmax
+// weight), outv (block output), dout (gradient of block output).
+// Produces dx (gradient w.r.t. x) and accumulates dW1, dW2 (MFMA over the tile's 16
+// (sample, head) columns, operands transposed through the wave's LDS scratch), db1, db2.
+template <int NB, int TSTR>
+__device__ __forceinline__ void fwa_bwd_pos(const float (&FN2)[NB][NB][4],
+                                            const float (&FN1)[NB][NB][4], const f32x4 (&xv)[NB],
+                                            const f32x4 (&z1)[NB], const f32x4 (&av)[NB],
+                                            const f32x4 (&outv)[NB], const f32x4 (&dout)[NB],
+                                            float* __restrict__ T, int q, int r,
+                                            f32x4 (&dW1)[NB][NB], f32x4 (&dW2)[NB][NB],
+                                            f32x4 (&db1)[NB], f32x4 (&db2)[NB], f32x4 (&dx)[NB]) {
+  f32x4 m1[NB], dm2[NB], dm1[NB], dz1[NB], dxm[NB], zero[NB];
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb) {
+    zero[kb] = (f32x4)(0.0f);
+    dm2[kb] = av[kb] * dout[kb] * (xv[kb] - outv[kb]);  // softmax-over-positions backward
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m1[kb][i] = fmaxf(z1[kb][i], 0.0f);
+  }
+  map_apply<NB>(FN2, zero, dm2, dm1);  // dm1 = dm2 . W2^T
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dz1[kb][i] = z1[kb][i] > 0.0f ? dm1[kb][i] : 0.0f;
+  map_apply<NB>(FN1, zero, dz1, dxm);  // dz1 . W1^T
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb) {
+    dx[kb] = av[kb] * dout[kb] + dxm[kb];
+    db1[kb] += dz1[kb];
+    db2[kb] += dm2[kb];
+  }
+  // ---- dW1 += x^T dz1, dW2 += m1^T dm2 over the 16 columns of this tile ----
+  // tiles in the scratch: [0,NB) x, [NB,2NB) dz1, [2NB,3NB) m1, [3NB,4NB) dm2; each [16][TSTR]
+  const int wofs = r * TSTR + 4 * q;
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb) {
+    *(f32x4*)(T + (0 * NB + kb) * 16 * TSTR + wofs) = xv[kb];
+    *(f32x4*)(T + (1 * NB + kb) * 16 * TSTR + wofs) = dz1[kb];
+    *(f32x4*)(T + (2 * NB + kb) * 16 * TSTR + wofs) = m1[kb];
+    *(f32x4*)(T + (3 * NB + kb) * 16 * TSTR + wofs) = dm2[kb];
+  }
+  wave_lds_fence();
+  float ax[NB][4], bz[NB][4], am[NB][4], bd[NB][4];
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int rofs = (4 * q + s) * TSTR + r;
+      ax[kb][s] = T[(0 * NB + kb) * 16 * TSTR + rofs];
+      bz[kb][s] = T[(1 * NB + kb) * 16 * TSTR + rofs];
+      am[kb][s] = T[(2 * NB + kb) * 16 * TSTR + rofs];
+      bd[kb][s] = T[(3 * NB + kb) * 16 * TSTR + rofs];
+    }
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        dW1[kb][jb] = TLSAN_MFMA(ax[kb][s], bz[jb][s], dW1[kb][jb]);
+        dW2[kb][jb] = TLSAN_MFMA(am[kb][s], bd[jb][s], dW2[kb][jb]);
+      }
+  wave_lds_fence();
+}
+
+// 16-B gather of channels [c, c+4) of the concatenated row [item_emb[it] || cate_emb[cat[it]]]
+// (model.py:84-86,105-107,111-113)
+__device__ __forceinline__ f32x4 gather_item4(const FwdArgs& a, int it, int c) {
+  const float* ptr = (c < a.di)
+                         ? a.p.item_emb + (size_t)it * a.di + c
+                         : a.p.cate_emb + (size_t)a.p.item_cate[it] * a.dc + (c - a.di);
+  return *(const f32x4*)ptr;
+}
+
+// Per-pass, per-wave gradient accumulators of one attention block, and their deterministic
+// reduction over the workgroup's wavefronts into the pass's partial record.
+// LDS staging: stage[wave][vec][lane*4 + i]; vec order: dW1[kb][jb], dW2[kb][jb], db1[kb],
+// db2[kb], extra[kb] (extra = dk0 for block 2).
+template <int NB>
+struct AccSet {
+  f32x4 dW1[NB][NB], dW2[NB][NB], db1[NB], db2[NB];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int x = 0; x < NB; ++x) {
+      db1[x] = db2[x] = (f32x4)(0.0f);
+#pragma unroll
+      for (int y = 0; y < NB; ++y) dW1[x][y] = dW2[x][y] = (f32x4)(0.0f);
+    }
+  }
+};
+
+template <int NB, int CPS, bool EXTRA>
+__device__ __forceinline__ void stage_accs(AccSet<NB>& A, f32x4 (&extra)[NB], float* __restrict__ stage,
+                                           int wave, int lane) {
+  constexpr int NV = 2 * NB * NB + 2 * NB + (EXTRA ? NB : 0);
+  float* base = stage + (size_t)wave * NV * 256 + lane * 4;
+  int v = 0;
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb) *(f32x4*)(base + (v++) * 256) = A.dW1[kb][jb];
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb) *(f32x4*)(base + (v++) * 256) = A.dW2[kb][jb];
+  // biases: per-lane partial over the 16 columns r -> xor-reduce over r (owner r == 0)
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb) {
+    f32x4 t = A.db1[kb];
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) t[i] += __shfl_xor(t[i], o);
+    *(f32x4*)(base + (v++) * 256) = t;
+  }
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb) {
+    f32x4 t = A.db2[kb];
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) t[i] += __shfl_xor(t[i], o);
+    *(f32x4*)(base + (v++) * 256) = t;
+  }
+  if constexpr (EXTRA) {
+    // dk0: sum over the samples of the wave (column index bits >= CPS), owner s_loc == 0
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+      f32x4 t = extra[kb];
+#pragma unroll
+      for (int o = CPS; o < 16; o <<= 1)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] += __shfl_xor(t[i], o);
+      *(f32x4*)(base + (v++) * 256) = t;
+    }
+  }
+}
+
+// all threads: sum the staged vectors over the wavefronts (fixed order) and scatter them to
+// the partial record.  pW1/pB1/pW2/pB2 = section offsets of this attention block.
+template <typename G, bool EXTRA>
+__device__ __forceinline__ void reduce_staged(const float* __restrict__ stage, float* __restrict__ out,
+                                              int pW1, int pB1, int pW2, int pB2, int tid) {
+  constexpr int NB = G::NB, CW = G::CW, CPS = G::CPS, NW = G::NW;
+  constexpr int NV = 2 * NB * NB + 2 * NB + (EXTRA ? NB : 0);
+  for (int o = tid; o < NV * 256; o += NW * 64) {
+    const int v = o >> 8, l4 = o & 255, ln = l4 >> 2, i = l4 & 3;
+    const int q = ln >> 4, r = ln & 15;
+    float s = 0.0f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += stage[(size_t)w * NV * 256 + o];
+    if (v < 2 * NB * NB) {
+      const int m = v % (NB * NB), kb = m / NB, jb = m % NB;
+      const int idx = (16 * kb + 4 * q + i) * CW + 16 * jb + r;
+      out[(v < NB * NB ? pW1 : pW2) + idx] = s;
+    } else if (v < 2 * NB * NB + 2 * NB) {
+      const int m = v - 2 * NB * NB, kb = m % NB;
+      if (r == 0) out[(m < NB ? pB1 : pB2) + 16 * kb + 4 * q + i] = s;
+    } else {
+      const int kb = v - (2 * NB * NB + 2 * NB);
+      const int s_loc = r / CPS, col = r % CPS;
+      if (s_loc == 0) out[G::P_K0 + col * CW + 16 * kb + 4 * q + i] = s;
+    }
+  }
+}
+
+template <int D, int DH, bool TRAIN>
+__global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
+  using G = Geo<D, DH>;
+  constexpr int NB = G::NB, CPS = G::CPS, SPW = G::SPW, NW = G::NW, NSB = G::NSB;
+  constexpr int LS = TLSAN_LS_MAX, LSTR = G::LSTR, TSTR = G::TSTR, CW = G::CW;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sA = smem;                   // [NSB][LSTR]  long -> dbridge
+  float* sB = sA + NSB * LSTR;        // [NSB][LSTR]  bridge -> dlong
+  float* sS = sB + NSB * LSTR;        // [NW][4] scalar staging
+  float* sT = sS + NW * 4;            // per-wave transpose scratch / accumulator staging
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int q = lane >> 4, r = lane & 15;
+  const int s_loc = r / CPS, col = r % CPS;
+  const int srow = wave * SPW + s_loc;  // sample row inside the workgroup pass
+  float* T = sT + wave * G::WSCR;
+  int chb[NB];
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb) chb[kb] = col * CW + 16 * kb + 4 * q;
+  const bool lead = (q == 0) && (col == 0);  // one lane per sample
+
+  const float* dn = a.p.dense;
+  const float gamma = dn[a.lay.gamma];
+  const int Ls = a.Ls, Sn = a.b.Sn, B = a.b.B, S = a.S;
+
+  for (int g = blockIdx.x; g < a.ngroups; g += gridDim.x) {
+    const int bidx = g * NSB + srow;
+    const bool vs = bidx < B;
+    const int bb = vs ? bidx : 0;
+    const int uid = a.b.u[bb];
+    int n_l = vs ? a.b.sl[bb] : 0;
+    n_l = min(n_l, Ls);
+    float loss_acc = 0.0f, sq_acc = 0.0f, dgam = 0.0f;
+    // ------------------------------------------------------------------ P1: long block
+    f32x4 e1[LS][NB], long4[NB], mx1[NB], iz1[NB];
+    const int pmax1 = wave_max_i32(n_l);
+    {
+    float sc1[LS];
+#pragma unroll
+    for (int p = 0; p < LS; ++p) {
+      const bool vp = p < n_l;
+      const int it = vp ? a.b.hist_i[(size_t)bb * Ls + p] : 0;
+      const float ht = vp ? a.b.hist_t[(size_t)bb * Ls + p] : 0.0f;
+      const float ut = vp ? a.p.usert_emb[(size_t)uid * Ls + p] : 0.0f;
+      sc1[p] = gamma * (ut * ht);  // model.py:100-102,109
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb)
+        e1[p][kb] = vp ? gather_item4(a, it, chb[kb]) : (f32x4)(0.0f);
+    }
+    {
+      float FT1[NB][NB][4], FT2[NB][NB][4];
+      f32x4 b1[NB], b2[NB];
+      load_frag_T<DH, NB>(dn + a.lay.f1_W1, q, r, FT1);
+      load_frag_T<DH, NB>(dn + a.lay.f1_W2, q, r, FT2);
+      load_bias<DH, NB>(dn + a.lay.f1_b1, q, b1);
+      load_bias<DH, NB>(dn + a.lay.f1_b2, q, b2);
+      fwa_forward<NB, LS>(FT1, b1, FT2, b2, e1, sc1, n_l, pmax1, mx1, iz1, long4);
+    }
+    }
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+      *(f32x4*)(sA + srow * LSTR + chb[kb]) = long4[kb];
+      if (TRAIN && vs) *(f32x4*)(a.gLong + (size_t)bidx * D + chb[kb]) = long4[kb];
+    }
+    __syncthreads();
+    // ------------------------------------------------------------------ P2: bridge GEMM
+    // bridge[s][j] = sum_k long[s][k] K[k][j] + k0[j]   (tf.layers.dense, model.py:347)
+#pragma unroll
+    for (int t = 0; t < G::TPW; ++t) {
+      const int task = wave * G::TPW + t, rt = task / G::NT, ct = task % G::NT;
+      f32x4 acc = (f32x4)(dn[a.lay.k0 + 16 * ct + r]);
+      const float* Arow = sA + (16 * rt + r) * LSTR + 4 * q;
+      const float* Brow = a.p.dense_KT + (size_t)(16 * ct + r) * D + 4 * q;
+#pragma unroll 8
+      for (int kc = 0; kc < D / 16; ++kc) {
+        const f32x4 av = *(const f32x4*)(Arow + 16 * kc);
+        const f32x4 bv = *(const f32x4*)(Brow + 16 * kc);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = TLSAN_MFMA(av[s], bv[s], acc);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sB[(16 * rt + 4 * q + i) * LSTR + 16 * ct + r] = acc[i];
+    }
+    __syncthreads();
+    // ------------------------------------------------------------------ P3: short block
+    // positions: 0 = bridge, 1..n_s = session rows (model.py:350); streamed with an online
+    // softmax so registers do not grow with the session length.
+    int n_s = vs ? a.b.sl_new[bb] : 0;
+    n_s = min(n_s, Sn);
+    const int n_pos = n_s + 1;  // model.py:355: rep_length = sl_new + 1
+    const int pmax2 = wave_max_i32(n_pos);
+    float FT1[NB][NB][4], FT2[NB][NB][4];
+    f32x4 b1[NB], b2[NB];
+    load_frag_T<DH, NB>(dn + a.lay.f2_W1, q, r, FT1);
+    load_frag_T<DH, NB>(dn + a.lay.f2_W2, q, r, FT2);
+    load_bias<DH, NB>(dn + a.lay.f2_b1, q, b1);
+    load_bias<DH, NB>(dn + a.lay.f2_b2, q, b2);
+    f32x4 mx[NB], Zs[NB], short4[NB];
+    {
+      f32x4 xv[NB], z[NB];
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) xv[kb] = *(const f32x4*)(sB + srow * LSTR + chb[kb]);
+      map_apply<NB>(FT1, b1, xv, z);
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[kb][i] = fmaxf(z[kb][i], 0.0f);
+      map_apply<NB>(FT2, b2, z, mx);  // position 0 is always valid: running max = its score
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) {
+        Zs[kb] = (f32x4)(1.0f);
+        short4[kb] = xv[kb];
+      }
+    }
+    for (int p = 1; p < pmax2; ++p) {  // wave-uniform trip count
+      const bool vt = (p - 1) < n_s;
+      const int it = vt ? a.b.hist_i_new[(size_t)bb * Sn + (p - 1)] : 0;
+      f32x4 xv[NB], z[NB], m2[NB];
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) xv[kb] = vt ? gather_item4(a, it, chb[kb]) : (f32x4)(0.0f);
+      map_apply<NB>(FT1, b1, xv, z);
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[kb][i] = fmaxf(z[kb][i], 0.0f);
+      map_apply<NB>(FT2, b2, z, m2);
+      if (vt) {
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float mn = fmaxf(mx[kb][i], m2[kb][i]);
+            const float so = __expf(mx[kb][i] - mn), ev = __expf(m2[kb][i] - mn);
+            Zs[kb][i] = Zs[kb][i] * so + ev;
+            short4[kb][i] = short4[kb][i] * so + ev * xv[kb][i];
+            mx[kb][i] = mn;
+          }
+      }
+    }
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        Zs[kb][i] = 1.0f / Zs[kb][i];
+        short4[kb][i] *= Zs[kb][i];
+      }
+    // u_t = short + [user_emb[u] || cate_emb[u_cate]]   (model.py:93-95,135)
+    f32x4 ut4[NB], iemb[NB];
+    const int it_i = a.b.i[bb];
+    float part = 0.0f;
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+      const int c = chb[kb];
+      const float* up = (c < a.di) ? a.p.user_emb + (size_t)uid * a.di + c
+                                   : a.p.cate_emb + (size_t)a.b.u_cate[bb] * a.dc + (c - a.di);
+      ut4[kb] = short4[kb] + *(const f32x4*)up;
+      iemb[kb] = gather_item4(a, it_i, c);
+      part += dot4(ut4[kb], iemb[kb]);
+      if (a.u_t != nullptr && vs) *(f32x4*)(a.u_t + (size_t)bidx * D + c) = ut4[kb];
+    }
+    const float logit = sample_sum<CPS>(part) + a.p.item_b[it_i];  // model.py:137
+    if (lead && vs && a.logits_i != nullptr) a.logits_i[bidx] = logit;
+    if (a.b.j != nullptr && a.logits_j != nullptr) {  // second candidate (eval_auc's negative)
+      const int it_j = a.b.j[bb];
+      float pj = 0.0f;
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) pj += dot4(ut4[kb], gather_item4(a, it_j, chb[kb]));
+      const float lj = sample_sum<CPS>(pj) + a.p.item_b[it_j];
+      if (lead && vs) a.logits_j[bidx] = lj;
+    }
+    if constexpr (TRAIN) {
+      float* prec = a.partials + (size_t)g * G::NPB;
+      // BCE with logits, mean over the batch (model.py:171)
+      const float yv = a.b.y[bb];
+      const float lb = fmaxf(logit, 0.0f) - logit * yv + log1pf(expf(-fabsf(logit)));
+      const float dl = vs ? (1.0f / (1.0f + expf(-logit)) - yv) * a.inv_B : 0.0f;
+      if (lead && vs) {
+        a.dlogit[bidx] = dl;
+        loss_acc += lb;
+        sq_acc += dl * dl;  // per-use item_b gradient
+      }
+      f32x4 dout[NB], dk0[NB];
+      const size_t gU = ((size_t)bidx * S + Ls + Sn + 1) * D;  // user slot: [user || u_cate]
+      const size_t gI = ((size_t)bidx * S + Ls + Sn) * D;      // candidate slot
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) {
+        dout[kb] = iemb[kb] * dl;  // d loss / d u_t
+        dk0[kb] = (f32x4)(0.0f);
+        const f32x4 gi = ut4[kb] * dl;
+        if (vs) {
+          *(f32x4*)(a.G + gU + chb[kb]) = dout[kb];
+          *(f32x4*)(a.G + gI + chb[kb]) = gi;
+          sq_acc += dot4(dout[kb], dout[kb]) + dot4(gi, gi);
+        }
+      }
+      {
+        float FN1[NB][NB][4], FN2[NB][NB][4];
+        load_frag_N<DH, NB>(dn + a.lay.f2_W1, q, r, FN1);
+        load_frag_N<DH, NB>(dn + a.lay.f2_W2, q, r, FN2);
+        AccSet<NB> acc;
+        acc.zero();
+        for (int p = 0; p < pmax2; ++p) {  // wave-uniform trip count
+          const bool vt = p < n_pos;
+          f32x4 xv[NB], z1[NB], zr[NB], m2[NB], av[NB], dx[NB];
+          if (p == 0) {
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) xv[kb] = *(const f32x4*)(sB + srow * LSTR + chb[kb]);
+          } else {
+            const int it = vt ? a.b.hist_i_new[(size_t)bb * Sn + (p - 1)] : 0;
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb)
+              xv[kb] = vt ? gather_item4(a, it, chb[kb]) : (f32x4)(0.0f);
+          }
+          map_apply<NB>(FT1, b1, xv, z1);
+#pragma unroll
+          for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) zr[kb][i] = fmaxf(z1[kb][i], 0.0f);
+          map_apply<NB>(FT2, b2, zr, m2);
+#pragma unroll
+          for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              av[kb][i] = vt ? __expf(m2[kb][i] - mx[kb][i]) * Zs[kb][i] : 0.0f;
+          fwa_bwd_pos<NB, TSTR>(FN2, FN1, xv, z1, av, short4, dout, T, q, r, acc.dW1, acc.dW2,
+                                acc.db1, acc.db2, dx);
+          if (p == 0) {
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+              *(f32x4*)(sA + srow * LSTR + chb[kb]) = dx[kb];  // dbridge
+              if (vs) {
+                *(f32x4*)(a.gDB + (size_t)bidx * D + chb[kb]) = dx[kb];
+                dk0[kb] += dx[kb];
+              }
+            }
+          } else if (vs && vt) {
+            const size_t go = ((size_t)bidx * S + Ls + (p - 1)) * D;
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+              *(f32x4*)(a.G + go + chb[kb]) = dx[kb];
+              sq_acc += dot4(dx[kb], dx[kb]);
+            }
+          }
+        }
+        stage_accs<NB, CPS, true>(acc, dk0, sT, wave, lane);
+      }
+      __syncthreads();
+      reduce_staged<G, true>(sT, prec, G::P_F2W1, G::P_F2B1, G::P_F2W2, G::P_F2B2, tid);
+      // ---------------------------------------------------------------- P4: dlong GEMM
+      // dlong[s][k] = sum_j dbridge[s][j] K[k][j]
+#pragma unroll
+      for (int t = 0; t < G::TPW; ++t) {
+        const int task = wave * G::TPW + t, rt = task / G::NT, kt = task % G::NT;
+        f32x4 acc = (f32x4)(0.0f);
+        const float* Arow = sA + (16 * rt + r) * LSTR + 4 * q;
+        const float* Brow = dn + a.lay.K + (size_t)(16 * kt + r) * D + 4 * q;
+#pragma unroll 8
+        for (int jc = 0; jc < D / 16; ++jc) {
+          const f32x4 av = *(const f32x4*)(Arow + 16 * jc);
+          const f32x4 bv = *(const f32x4*)(Brow + 16 * jc);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc = TLSAN_MFMA(av[s], bv[s], acc);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sB[(16 * rt + 4 * q + i) * LSTR + 16 * kt + r] = acc[i];
+      }
+      __syncthreads();
+      // ---------------------------------------------------------------- P5: long backward
+      {
+        f32x4 dlong[NB], dummy[NB];
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) dlong[kb] = *(const f32x4*)(sB + srow * LSTR + chb[kb]);
+        float FN1[NB][NB][4], FN2[NB][NB][4];
+        load_frag_T<DH, NB>(dn + a.lay.f1_W1, q, r, FT1);
+        load_bias<DH, NB>(dn + a.lay.f1_b1, q, b1);
+        load_frag_T<DH, NB>(dn + a.lay.f1_W2, q, r, FT2);
+        load_bias<DH, NB>(dn + a.lay.f1_b2, q, b2);
+        load_frag_N<DH, NB>(dn + a.lay.f1_W1, q, r, FN1);
+        load_frag_N<DH, NB>(dn + a.lay.f1_W2, q, r, FN2);
+        AccSet<NB> acc;
+        acc.zero();
+#pragma unroll
+        for (int p = 0; p < LS; ++p) {
+          if (p < pmax1) {
+            const bool vp = p < n_l;
+            const float ht = vp ? a.b.hist_t[(size_t)bb * Ls + p] : 0.0f;
+            const float ut = vp ? a.p.usert_emb[(size_t)uid * Ls + p] : 0.0f;
+            const float scp = gamma * (ut * ht);
+            f32x4 xv[NB], z1[NB], zr[NB], m2[NB], av[NB], dx[NB];
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) xv[kb] = e1[p][kb] * scp;
+            map_apply<NB>(FT1, b1, xv, z1);
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) zr[kb][i] = fmaxf(z1[kb][i], 0.0f);
+            map_apply<NB>(FT2, b2, zr, m2);
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                av[kb][i] = vp ? __expf(m2[kb][i] - mx1[kb][i]) * iz1[kb][i] : 0.0f;
+            fwa_bwd_pos<NB, TSTR>(FN2, FN1, xv, z1, av, long4, dlong, T, q, r, acc.dW1, acc.dW2,
+                                  acc.db1, acc.db2, dx);
+            float dsp = 0.0f;
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) dsp += dot4(dx[kb], e1[p][kb]);
+            const float ds = sample_sum<CPS>(dsp);  // d loss / d scale[p]
+            if (vs && p < n_l) {
+              const size_t go = ((size_t)bidx * S + p) * D;
+#pragma unroll
+              for (int kb = 0; kb < NB; ++kb) {
+                const f32x4 de = dx[kb] * scp;
+                *(f32x4*)(a.G + go + chb[kb]) = de;
+                sq_acc += dot4(de, de);
+              }
+              if (lead) {
+                const float gt = ds * (gamma * ht);  // d / d usert_emb[u][p]
+                a.GT[(size_t)bidx * Ls + p] = gt;
+                sq_acc += gt * gt;
+                dgam += ds * (ut * ht);
+              }
+            }
+          }
+        }
+        stage_accs<NB, CPS, false>(acc, dummy, sT, wave, lane);
+      }
+      // scalars of this pass: wave-reduce, stage, one thread sums the waves in fixed order
+      {
+        float s0 = dgam, s1 = loss_acc, s2 = sq_acc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          s0 += __shfl_xor(s0, o);
+          s1 += __shfl_xor(s1, o);
+          s2 += __shfl_xor(s2, o);
+        }
+        if (lane == 0) {
+          sS[wave * 4 + 0] = s0;
+          sS[wave * 4 + 1] = s1;
+          sS[wave * 4 + 2] = s2;
+        }
+      }
+      __syncthreads();
+      reduce_staged<G, false>(sT, prec, G::P_F1W1, G::P_F1B1, G::P_F1W2, G::P_F1B2, tid);
+      if (tid < 3) {
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += sS[w * 4 + tid];
+        prec[G::P_GAMMA + tid] = s;
+      }
+    }
+    // Next pass: sA is rewritten in P1 (last read in P4), sB in P2 (last read at the top of
+    // P5), sT/sS in P3/P5 (last read right above; P1->P2 barrier separates) -> no extra barrier.
+  }
+}

@@ -1,0 +1,187 @@
+// tlsan_common.h -- shared device helpers for the gfx950 TLSAN kernels.
+//
+// Register layout used by every attention kernel ("C-layout"): a wavefront (64 lanes) is
+// viewed as 4 quarters q = lane>>4 of 16 columns r = lane&15.  A column is one
+// (sample, 16*NB-channel group) pair; the lane owns channels  col*CW + 16*kb + 4*q + {0..3}
+// of that sample as one float4 per 16-block kb.  This is exactly the C/D layout of
+// v_mfma_f32_16x16x4_f32 (row = 4*q + reg, col = lane&15) with the channel on the MFMA row
+// and the (sample, head) pair on the MFMA column, so:
+//   * the per-head maps  m = W^T x  are MFMAs whose B operand is the lane's own float4
+//     (k-step s uses k = 4q+s; the weight fragment is pre-permuted to match), and whose
+//     result lands back in the same layout -- map1 -> relu -> map2 chain with no data
+//     movement;
+//   * the per-channel softmax over sequence positions is purely in-lane (positions are
+//     different registers of the same lane): no shuffles, no LDS;
+//   * a float4 is 16 contiguous bytes of an embedding row, so gathers are 16-B loads and
+//     one wave-instruction covers whole 256/512-B rows.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tlsan.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define TLSAN_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define TLSAN_NEG (-1e30f)  // VERY_NEGATIVE_NUMBER, reference TLSAN/model.py:10-11
+
+#define TLSAN_LS_MAX 10  // static bound on the long-term window (reference default Ls = 10)
+
+template <int D_, int DH_>
+struct Geo {
+  static constexpr int D = D_;
+  static constexpr int DH = DH_;                // channels per head (d / num_heads)
+  static constexpr int CW = DH < 16 ? 16 : DH;  // column width: one head, or 2 heads when DH == 8
+  static constexpr int NB = CW / 16;            // 16-channel blocks per column
+  static constexpr int CPS = D / CW;            // columns per sample
+  static constexpr int SPW = 16 / CPS;          // samples per wavefront
+  static constexpr int NW = 8;                  // wavefronts per workgroup
+  static constexpr int NSB = NW * SPW;          // samples per workgroup pass
+  static constexpr int RT = NSB / 16;           // 16-row tiles of the bridge GEMM
+  static constexpr int NT = D / 16;             // 16-col tiles of the bridge GEMM
+  static constexpr int TPW = RT * NT / NW;      // bridge tiles per wavefront
+  static constexpr int LSTR = D + 4;            // LDS row stride of [sample][channel] buffers
+  static constexpr int TSTR = 20;               // LDS row stride of the 16x16 transpose tiles
+  // per-wave LDS scratch (floats): 4*NB transpose tiles, or the staged gradient accumulators
+  static constexpr int WSCR_T = 4 * NB * 16 * TSTR;
+  static constexpr int WSCR_A = (2 * NB * NB + 3 * NB) * 256;
+  static constexpr int WSCR = WSCR_T > WSCR_A ? WSCR_T : WSCR_A;
+  // per-workgroup partial record (effective CWxCW layout), see k_dense_finalize
+  static constexpr int P_W = CW * CW;
+  static constexpr int P_F1W1 = 0;
+  static constexpr int P_F1B1 = P_F1W1 + P_W;
+  static constexpr int P_F1W2 = P_F1B1 + CW;
+  static constexpr int P_F1B2 = P_F1W2 + P_W;
+  static constexpr int P_F2W1 = P_F1B2 + CW;
+  static constexpr int P_F2B1 = P_F2W1 + P_W;
+  static constexpr int P_F2W2 = P_F2B1 + CW;
+  static constexpr int P_F2B2 = P_F2W2 + P_W;
+  static constexpr int P_K0 = P_F2B2 + CW;
+  static constexpr int P_GAMMA = P_K0 + D;
+  static constexpr int P_LOSS = P_GAMMA + 1;
+  static constexpr int P_SQ = P_LOSS + 1;
+  static constexpr int NPB = P_SQ + 2;  // +1 pad: the scalar record is stored as one float4
+  static_assert(CPS >= 1 && CPS <= 16 && (16 % CPS) == 0, "unsupported geometry");
+  static_assert((RT * NT) % NW == 0, "bridge tiles must divide over the wavefronts");
+};
+
+// Effective CW x CW weight: the head's DHxDH matrix, or for DH == 8 the block-diagonal
+// diag(W, W) so that two heads share one 16-wide MFMA block.
+template <int DH>
+__device__ __forceinline__ float weff(const float* __restrict__ W, int k, int j) {
+  if constexpr (DH >= 16) {
+    return W[k * DH + j];
+  } else {
+    return ((k / DH) == (j / DH)) ? W[(k % DH) * DH + (j % DH)] : 0.0f;
+  }
+}
+
+// "T" fragment: A operand of  out[j] = sum_k W[k][j] v[k]   (forward maps):
+//   F[jb][kb][s] on lane (q, m=r)  = W_eff[16kb + 4q + s][16jb + r]
+template <int DH, int NB>
+__device__ __forceinline__ void load_frag_T(const float* __restrict__ W, int q, int r,
+                                            float (&F)[NB][NB][4]) {
+#pragma unroll
+  for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) F[jb][kb][s] = weff<DH>(W, 16 * kb + 4 * q + s, 16 * jb + r);
+}
+
+// "N" fragment: A operand of  out[k] = sum_j W[k][j] v[j]   (backward maps):
+//   F[kb][jb][s] on lane (q, m=r)  = W_eff[16kb + r][16jb + 4q + s]
+template <int DH, int NB>
+__device__ __forceinline__ void load_frag_N(const float* __restrict__ W, int q, int r,
+                                            float (&F)[NB][NB][4]) {
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) F[kb][jb][s] = weff<DH>(W, 16 * kb + r, 16 * jb + 4 * q + s);
+}
+
+// bias in C-layout: lane (q, .) reg i of block jb  <->  channel-in-column 16jb + 4q + i
+template <int DH, int NB>
+__device__ __forceinline__ void load_bias(const float* __restrict__ b, int q, f32x4 (&out)[NB]) {
+#pragma unroll
+  for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[jb][i] = b[(16 * jb + 4 * q + i) % DH];
+}
+
+// out = bias + F (x) v  in C-layout (see header comment)
+template <int NB>
+__device__ __forceinline__ void map_apply(const float (&F)[NB][NB][4], const f32x4 (&bias)[NB],
+                                          const f32x4 (&v)[NB], f32x4 (&out)[NB]) {
+#pragma unroll
+  for (int ob = 0; ob < NB; ++ob) {
+    f32x4 acc = bias[ob];
+#pragma unroll
+    for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = TLSAN_MFMA(F[ob][ib][s], v[ib][s], acc);
+    out[ob] = acc;
+  }
+}
+
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return __builtin_amdgcn_readfirstlane(v);
+}
+
+// sum over the lanes that own one sample: quarters (lane bits 4,5) and the CPS columns
+template <int CPS>
+__device__ __forceinline__ float sample_sum(float v) {
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+#pragma unroll
+  for (int o = 1; o < CPS; o <<= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__device__ __forceinline__ float dot4(f32x4 a, f32x4 b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+}
+
+// make LDS traffic of one wavefront visible to its own lanes (DS ops of a wave are
+// executed in order; this only stops the compiler from reordering across it)
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ------------------------------------------------------------------------------------------
+// Exact (order-independent) accumulation of fp32 values on a 2^-40 grid held in a double:
+//   t = (v + BIG) - BIG rounds v to a multiple of 2^-40 (BIG = 1.5 * 2^12, ulp 2^-40);
+//   sums of such t are exact in a double while |sum| < 2^12, so the result does not depend
+//   on the order in which contributions are added -> bitwise reproducible scatter-add
+//   without sorting the contribution lists.
+#define TLSAN_EXACT_BIG 6144.0
+__device__ __forceinline__ double exact_term(float v) {
+  double t = (double)v + TLSAN_EXACT_BIG;
+  return t - TLSAN_EXACT_BIG;
+}
+
+struct FwdArgs {
+  tlsan_params p;
+  tlsan_batch b;
+  tlsan_dense_layout lay;
+  int32_t Ls, di, dc;
+  int32_t S;        // contribution slots per sample: Ls + Sn + 2
+  int32_t ngroups;  // ceil(B / NSB)
+  float inv_B;
+  float* logits_i;
+  float* logits_j;
+  float* u_t;
+  // training only
+  float* G;         // [B*S, D] per-use gradient rows (item || cate halves)
+  float* GT;        // [B, Ls]  per-use usert_emb gradient rows
+  float* dlogit;    // [B]      per-use item_b gradients
+  float* gLong;     // [B, D]   long-term summaries (A operand of dK)
+  float* gDB;       // [B, D]   d loss / d bridge     (B operand of dK)
+  float* partials;  // [gridDim.x, NPB]
+};

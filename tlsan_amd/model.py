@@ -1,0 +1,377 @@
+"""`Model`: the reference's ``TLSAN/model.py`` call surface over the HIP library.
+
+Same constructor and methods as the reference class (model.py:13-313) so the reference's
+``train.py`` loop drives it unchanged apart from the TensorFlow session object:
+
+    Model(config, item_cate_list)
+    .train(sess, batch, lr, add_summary=False) -> float     model.py:208-234
+    .eval_auc(sess, batch) -> float                         model.py:237-263
+    .eval_prec(sess, batch) / .eval_recall(sess, batch)     model.py:265-299
+    .save(sess) / .restore(sess, path)                      model.py:302-313
+    .global_step / .global_epoch_step / .global_epoch_step_op  (objects with .eval())
+    .prec_1 ... .prec_50, .recall_1 ... .recall_50             (objects with .eval())
+    .train_writer / .eval_writer                               (objects with .add_summary())
+
+``sess`` is accepted and ignored (the reference passes a tf.Session).  ``batch`` is the 9-tuple
+of ``input.py``.  All arithmetic runs in libtlsan_hip.so on the GPU; torch is used only to own
+device memory and the stream.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+KS = (1, 10, 20, 30, 40, 50)  # model.py:144-156
+
+
+class _Var:
+    """Stand-in for the tf.Variable / tensor handles train.py calls .eval() on."""
+
+    def __init__(self, getter):
+        self._get = getter
+
+    def eval(self, session=None):  # noqa: A003 - name fixed by the reference
+        return self._get()
+
+
+class _Writer:
+    """tf.summary.FileWriter stand-in (model.py:18-19): keeps (tag, value, step) rows."""
+
+    def __init__(self, path):
+        self.path = path
+        self.rows = []
+
+    def add_summary(self, summary=None, global_step=None):
+        self.rows.append((global_step, summary))
+
+    def flush(self):
+        pass
+
+
+def glorot_uniform(rng, shape):
+    """TF-1.x default initializer of tf.get_variable (model.py:62-64,70-72,79-81,446)."""
+    limit = np.sqrt(6.0 / (shape[0] + shape[1]))
+    return rng.uniform(-limit, limit, size=shape).astype(np.float32)
+
+
+DENSE_KEYS = ("fwa1_W1", "fwa1_b1", "fwa1_W2", "fwa1_b2", "dense_K", "dense_b",
+              "fwa2_W1", "fwa2_b1", "fwa2_W2", "fwa2_b2", "gamma")
+TABLE_KEYS = ("item_emb", "item_b", "user_emb", "usert_emb", "cate_emb")
+
+
+class DeviceBatch:
+    """The placeholders of model.py:27-53 as int32 / fp32 device tensors + the C struct."""
+
+    def __init__(self, batch, device, is_test=False, Ls=None):
+        u, i, yj, hist_i, hist_i_new, hist_t, sl, new_sl, c = batch
+        t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(np.asarray(a)), dtype=dt).to(device, non_blocking=True)
+        self.B = int(len(u))
+        if self.B < 1:
+            raise ValueError("empty batch")
+        hist_i = np.asarray(hist_i)
+        hist_i_new = np.asarray(hist_i_new).reshape(self.B, -1)
+        if Ls is not None and hist_i.shape != (self.B, Ls):
+            raise ValueError("hist_i must be [B, Ls=%d], got %s" % (Ls, hist_i.shape))
+        self.Sn = int(hist_i_new.shape[1])
+        self.u = t(u, torch.int32)
+        self.i = t(i, torch.int32)
+        self.hist_i = t(hist_i, torch.int32)
+        self.hist_i_new = t(hist_i_new, torch.int32) if self.Sn > 0 else torch.zeros(1, dtype=torch.int32, device=device)
+        self.hist_t = t(hist_t, torch.float32)
+        self.sl = t(sl, torch.int32)
+        self.sl_new = t(new_sl, torch.int32)
+        self.u_cate = t(c, torch.int32)
+        self.j = t(yj, torch.int32) if is_test else None
+        self.y = None if is_test else t(yj, torch.float32)
+        self.c = self.struct()
+
+    def struct(self, use_j=True):
+        p = lambda x: None if x is None else x.data_ptr()
+        return L.Batch(self.B, self.Sn, p(self.u), p(self.i), p(self.j) if use_j else None, p(self.y),
+                       p(self.hist_i), p(self.hist_i_new), p(self.hist_t), p(self.sl), p(self.sl_new),
+                       p(self.u_cate))
+
+
+class Model(object):
+    def __init__(self, config, item_cate_list, device="cuda:0", seed=1234, norm_mode="tf18"):
+        self.config = config
+        self.lib = L.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("tlsan_amd.Model needs a GPU (no CPU fallback)")
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        if config.get("num_blocks", 1) != 1:
+            raise ValueError("num_blocks != 1 is degenerate in the reference (model.py:330-364) and unsupported")
+        if config.get("dropout", 0.0) != 0.0:
+            raise NotImplementedError("dropout > 0 (model.py:428-431) is not implemented")
+        if config.get("optimizer", "sgd") != "sgd":
+            raise NotImplementedError("only optimizer='sgd' (model.py:195) is implemented")
+        self.train_writer = _Writer(os.path.join(config.get("model_dir", "."), "train"))
+        self.eval_writer = _Writer(os.path.join(config.get("model_dir", "."), "eval"))
+        d = config["hidden_units"]
+        self.dims = L.Dims(config["user_count"], config["item_count"], config["cate_count"], d,
+                           config["itemid_embedding_size"], config["cateid_embedding_size"],
+                           config["num_heads"], config["Ls"])
+        if config["userid_embedding_size"] != config["itemid_embedding_size"]:
+            raise ValueError("userid_embedding_size must equal itemid_embedding_size (both + cate = hidden_units)")
+        self.lay = L.DenseLayout()
+        L.check(self.lib.tlsan_dense_layout_of(C.byref(self.dims), C.byref(self.lay)), "tlsan_dense_layout_of")
+        nbytes = self.lib.tlsan_state_bytes(C.byref(self.dims))
+        if nbytes == 0:
+            raise L.TlsanError("unsupported configuration: %s" % self.lib.tlsan_last_error().decode())
+        self.norm_mode = {"tf18": L.NORM_TF18, "dedup": L.NORM_DEDUP}[norm_mode]
+        icl = np.asarray(item_cate_list, np.int32)
+        if icl.shape != (config["item_count"],):
+            raise ValueError("item_cate_list must be [item_count]")
+        self.item_cate = torch.as_tensor(icl).to(self.device)
+        self._alloc_params()
+        self.set_params(self.init_params(config, seed))
+        self.state = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        self._ws = None
+        self._ws_key = (0, 0)
+        self._step = 0
+        self._epoch = 0
+        self.global_step = _Var(lambda: self._step)
+        self.global_epoch_step = _Var(lambda: self._epoch)
+        self.global_epoch_step_op = _Var(self._inc_epoch)
+        self._out = torch.zeros(2, dtype=torch.float32, device=self.device)  # loss, gnorm
+        self._hits_p = np.zeros(len(KS), np.int64)
+        self._hits_r = np.zeros(len(KS), np.int64)
+        self._n_p = 0
+        self._n_r = 0
+        for idx, k in enumerate(KS):
+            setattr(self, "prec_%d" % k, _Var(lambda idx=idx, k=k: self._hits_p[idx] / max(1, k * self._n_p)))
+            setattr(self, "recall_%d" % k, _Var(lambda idx=idx: self._hits_r[idx] / max(1, self._n_r)))
+        self._sync_state()
+
+    # ------------------------------------------------------------------ parameters
+    @staticmethod
+    def init_params(config, seed=1234):
+        """Variables of model.py:58-81, :443-450, :347 with the reference's initial values."""
+        rng = np.random.RandomState(seed)
+        I, U, Cc = config["item_count"], config["user_count"], config["cate_count"]
+        di, dc = config["itemid_embedding_size"], config["cateid_embedding_size"]
+        d, H, Ls = config["hidden_units"], config["num_heads"], config["Ls"]
+        dh = d // H
+        p = {
+            "gamma": np.ones((), np.float32),
+            "item_emb": glorot_uniform(rng, (I, di)),
+            "item_b": np.zeros(I, np.float32),
+            "user_emb": glorot_uniform(rng, (U, di)),
+            "usert_emb": -np.ones((U, Ls), np.float32),
+            "cate_emb": glorot_uniform(rng, (Cc, dc)),
+            "dense_K": glorot_uniform(rng, (d, d)),
+            "dense_b": np.zeros(d, np.float32),
+        }
+        for blk in ("fwa1", "fwa2"):
+            p[blk + "_W1"] = glorot_uniform(rng, (dh, dh))
+            p[blk + "_b1"] = np.zeros(dh, np.float32)
+            p[blk + "_W2"] = glorot_uniform(rng, (dh, dh))
+            p[blk + "_b2"] = np.zeros(dh, np.float32)
+        return p
+
+    def _alloc_params(self):
+        cfg, dev = self.config, self.device
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        self.item_emb = z(cfg["item_count"], cfg["itemid_embedding_size"])
+        self.item_b = z(cfg["item_count"])
+        self.user_emb = z(cfg["user_count"], cfg["itemid_embedding_size"])
+        self.usert_emb = z(cfg["user_count"], cfg["Ls"])
+        self.cate_emb = z(cfg["cate_count"], cfg["cateid_embedding_size"])
+        self.dense = z(self.lay.n_dense)
+        self.dense_KT = z(cfg["hidden_units"], cfg["hidden_units"])
+        self.cparams = L.Params(self.item_emb.data_ptr(), self.item_b.data_ptr(), self.user_emb.data_ptr(),
+                                self.usert_emb.data_ptr(), self.cate_emb.data_ptr(), self.dense.data_ptr(),
+                                self.dense_KT.data_ptr(), self.item_cate.data_ptr())
+
+    def _dense_slices(self):
+        lay, d = self.lay, self.config["hidden_units"]
+        dh = d // self.config["num_heads"]
+        return {
+            "fwa1_W1": (lay.f1_W1, (dh, dh)), "fwa1_b1": (lay.f1_b1, (dh,)),
+            "fwa1_W2": (lay.f1_W2, (dh, dh)), "fwa1_b2": (lay.f1_b2, (dh,)),
+            "dense_K": (lay.K, (d, d)), "dense_b": (lay.k0, (d,)),
+            "fwa2_W1": (lay.f2_W1, (dh, dh)), "fwa2_b1": (lay.f2_b1, (dh,)),
+            "fwa2_W2": (lay.f2_W2, (dh, dh)), "fwa2_b2": (lay.f2_b2, (dh,)),
+            "gamma": (lay.gamma, ()),
+        }
+
+    def pack_dense(self, p):
+        out = np.zeros(self.lay.n_dense, np.float32)
+        for k, (off, shape) in self._dense_slices().items():
+            n = int(np.prod(shape)) if shape else 1
+            out[off:off + n] = np.asarray(p[k], np.float32).reshape(-1)
+        return out
+
+    def unpack_dense(self, flat):
+        flat = np.asarray(flat)
+        out = {}
+        for k, (off, shape) in self._dense_slices().items():
+            n = int(np.prod(shape)) if shape else 1
+            out[k] = flat[off:off + n].reshape(shape).copy()
+        return out
+
+    def set_params(self, p):
+        """Load a dict of numpy arrays (names as in oracle / checkpoint) into device memory."""
+        for k in TABLE_KEYS:
+            t = getattr(self, k)
+            a = np.asarray(p[k], np.float32)
+            if tuple(a.shape) != tuple(t.shape):
+                raise ValueError("%s: shape %s != %s" % (k, a.shape, tuple(t.shape)))
+            t.copy_(torch.as_tensor(a))
+        self.dense.copy_(torch.as_tensor(self.pack_dense(p)))
+        if hasattr(self, "state"):
+            self._sync_state()
+
+    def get_params(self):
+        out = {k: getattr(self, k).detach().cpu().numpy().copy() for k in TABLE_KEYS}
+        out.update(self.unpack_dense(self.dense.detach().cpu().numpy()))
+        return out
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _sync_state(self):
+        L.check(self.lib.tlsan_state_init(C.byref(self.dims), C.byref(self.cparams), self.state.data_ptr(),
+                                          self._stream()), "tlsan_state_init")
+
+    def _workspace(self, B, Sn):
+        kB, kS = self._ws_key
+        if self._ws is None or B > kB or Sn > kS:
+            kB, kS = max(B, kB), max(Sn, kS)
+            n = self.lib.tlsan_workspace_bytes(C.byref(self.dims), kB, kS)
+            if n == 0:
+                raise L.TlsanError("tlsan_workspace_bytes: %s" % self.lib.tlsan_last_error().decode())
+            torch.cuda.synchronize(self.device)
+            self._ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+            self._ws_key = (kB, kS)
+        return self._ws
+
+    def _inc_epoch(self):
+        self._epoch += 1
+        return self._epoch
+
+    def hparams(self, lr):
+        return L.HParams(float(lr), float(self.config["regulation_rate"]), float(self.config["max_gradient_norm"]),
+                         self.norm_mode, L.L2_DENSE)
+
+    # ------------------------------------------------------------------ training
+    def device_batch(self, batch, is_test=False):
+        return batch if isinstance(batch, DeviceBatch) else DeviceBatch(batch, self.device, is_test, self.config["Ls"])
+
+    def train_async(self, batch, lr, logits=None):
+        """Enqueue one step (model.py:208-234) without reading the loss back."""
+        db = self.device_batch(batch)
+        ws = self._workspace(db.B, db.Sn)
+        out = L.StepOut(self._out.data_ptr(), self._out.data_ptr() + 4, None if logits is None else logits.data_ptr())
+        hp = self.hparams(lr)
+        L.check(self.lib.tlsan_train_step(C.byref(self.dims), C.byref(self.cparams), C.byref(db.c), C.byref(hp),
+                                          C.byref(out), self.state.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          self._stream()), "tlsan_train_step")
+        self._step += 1
+        return db
+
+    def train(self, sess, batch, lr, add_summary=False):
+        self.train_async(batch, lr)
+        loss = float(self._out[0].item())
+        if add_summary:
+            self.train_writer.add_summary(("Training Loss", loss), global_step=self._step)
+        return loss
+
+    def last_gnorm(self):
+        return float(self._out[1].item())
+
+    def grads(self, batch, lr=1.0):
+        """tf.gradients(loss, trainables) (model.py:198) as numpy arrays; test/diagnostic API."""
+        db = self.device_batch(batch)
+        ws = self._workspace(db.B, db.Sn)
+        g = {k: torch.zeros_like(getattr(self, k)) for k in TABLE_KEYS}
+        gd = torch.zeros_like(self.dense)
+        logits = torch.zeros(db.B, dtype=torch.float32, device=self.device)
+        go = L.GradsOut(g["item_emb"].data_ptr(), g["item_b"].data_ptr(), g["user_emb"].data_ptr(),
+                        g["usert_emb"].data_ptr(), g["cate_emb"].data_ptr(), gd.data_ptr())
+        out = L.StepOut(self._out.data_ptr(), self._out.data_ptr() + 4, logits.data_ptr())
+        hp = self.hparams(lr)
+        L.check(self.lib.tlsan_grads(C.byref(self.dims), C.byref(self.cparams), C.byref(db.c), C.byref(hp),
+                                     C.byref(go), C.byref(out), self.state.data_ptr(), ws.data_ptr(), ws.numel(),
+                                     self._stream()), "tlsan_grads")
+        res = {k: v.cpu().numpy() for k, v in g.items()}
+        res.update(self.unpack_dense(gd.cpu().numpy()))
+        o = self._out.cpu().numpy()
+        return dict(grads=res, loss=float(o[0]), gnorm=float(o[1]), logits=logits.cpu().numpy())
+
+    # ------------------------------------------------------------------ evaluation
+    def forward(self, batch, is_test=True, want_u_t=False):
+        """logits for candidate i (and j when the batch has one) -- `sess.run(self.logits)`."""
+        db = self.device_batch(batch, is_test)
+        li = torch.empty(db.B, dtype=torch.float32, device=self.device)
+        lj = torch.empty(db.B, dtype=torch.float32, device=self.device) if db.j is not None else None
+        ut = torch.empty(db.B, self.config["hidden_units"], dtype=torch.float32, device=self.device) if want_u_t else None
+        L.check(self.lib.tlsan_forward(C.byref(self.dims), C.byref(self.cparams), C.byref(db.c), li.data_ptr(),
+                                       None if lj is None else lj.data_ptr(), None if ut is None else ut.data_ptr(),
+                                       None, 0, self._stream()), "tlsan_forward")
+        return li, lj, ut, db
+
+    def eval_auc(self, sess, batch):
+        """mean(logit(pos) - logit(neg) > 0), ties wrong (model.py:237-263)."""
+        li, lj, _, _ = self.forward(batch, is_test=True)
+        return float(((li - lj) > 0).float().mean().item())
+
+    def label_ranks(self, batch):
+        """rank of the positive item among all items for each test row (model.py:140-156)."""
+        li, lj, ut, db = self.forward(batch, is_test=True, want_u_t=True)
+        ws = self._workspace(db.B, db.Sn)
+        ranks = torch.empty(db.B, dtype=torch.int32, device=self.device)
+        L.check(self.lib.tlsan_eval_ranks(C.byref(self.dims), C.byref(self.cparams), ut.data_ptr(), db.i.data_ptr(),
+                                          db.B, ranks.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
+                "tlsan_eval_ranks")
+        return ranks
+
+    def _hits(self, batch):
+        r = self.label_ranks(batch).cpu().numpy()
+        return np.array([(r < k).sum() for k in KS], np.int64), len(r)
+
+    def eval_prec(self, sess, batch):
+        """Streaming precision_at_k update ops (model.py:265-281); counters are cumulative over
+        every call, like the reference's never-reset local variables (train.py:75-76,82)."""
+        h, n = self._hits(batch)
+        self._hits_p += h
+        self._n_p += n
+        return [self._hits_p[i] / (k * self._n_p) for i, k in enumerate(KS)]
+
+    def eval_recall(self, sess, batch):
+        h, n = self._hits(batch)
+        self._hits_r += h
+        self._n_r += n
+        return [self._hits_r[i] / self._n_r for i in range(len(KS))]
+
+    def reset_metrics(self):
+        """Not in the reference (its counters are never reset); provided for per-round metrics."""
+        self._hits_p[:] = 0
+        self._hits_r[:] = 0
+        self._n_p = self._n_r = 0
+
+    # ------------------------------------------------------------------ checkpoint
+    def save(self, sess=None):
+        """model.py:302-307: parameters + config JSON next to them."""
+        os.makedirs(self.config["model_dir"], exist_ok=True)
+        base = os.path.join(self.config["model_dir"], "TLSAN")
+        path = "%s-%d.npz" % (base, self._step)
+        np.savez(path, global_step=self._step, global_epoch_step=self._epoch, **self.get_params())
+        json.dump(self.config, open("%s-%d.json" % (base, self._step), "w"), indent=2)
+        print("model saved at %s" % path, flush=True)
+        return path
+
+    def restore(self, sess, path):
+        """model.py:310-313."""
+        z = np.load(path)
+        self.set_params({k: z[k] for k in TABLE_KEYS + DENSE_KEYS})
+        self._step = int(z["global_step"])
+        self._epoch = int(z["global_epoch_step"])
+        print("model restored from %s" % path, flush=True)
