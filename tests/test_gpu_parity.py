@@ -68,7 +68,9 @@ def test_gradients(d, B, Sn):
     assert abs(out["loss"] - loss) < 1e-4 * max(1.0, abs(loss))
     for k in g:
         gk = np.asarray(out["grads"][k], np.float64).reshape(g[k].shape)
-        assert _relerr(gk, g[k]) < 2e-4, (k, _relerr(gk, g[k]))
+        # absolute floor: d/d b2 is identically 0 (softmax is shift invariant), fp32 leaves ~1e-9
+        err = np.abs(gk - g[k]).max()
+        assert err < 2e-4 * np.abs(g[k]).max() + 1e-6, (k, err, np.abs(g[k]).max())
     n18 = orc.global_norm(p, g, sparse, reg, "tf18")
     assert abs(out["gnorm"] - n18) < 2e-4 * n18
     m2 = _model(cfg, cat, p, norm_mode="dedup")
@@ -122,7 +124,8 @@ def test_multi_step_tracks_oracle_and_is_deterministic():
         ref_losses.append(l)
     assert np.allclose(runs[0][0], ref_losses, rtol=2e-4, atol=1e-5)
     for k in q:
-        assert _relerr(runs[0][1][k].reshape(q[k].shape), q[k]) < 5e-4, k
+        got = np.asarray(runs[0][1][k], np.float64).reshape(q[k].shape)
+        assert np.abs(got - q[k]).max() < 5e-4 * np.abs(q[k]).max() + 1e-6, k
 
 
 @pytest.mark.parametrize("name", ["clothing", "digital_music"])

@@ -62,6 +62,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own HIP runtime; import it first so this process has exactly one
+    # libamdhip64 (loading ours first leaves two runtimes and no visible device in one of them)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             "tlsan_amd: %s not found -- build it with `python -m tlsan_amd.build` "

@@ -158,7 +158,7 @@ __device__ __forceinline__ f32x4 gather_item4(const FwdArgs& a, int it, int c) {
 
 // Per-pass, per-wave gradient accumulators of one attention block, and their deterministic
 // reduction over the workgroup's wavefronts into the pass's partial record.
-// LDS staging: stage[wave][vec][lane*4 + i]; vec order: dW1[kb][jb], dW2[kb][jb], db1[kb],
+// LDS staging: stage[wave*WSCR + vec*256 + lane*4 + i]; vec order: dW1[kb][jb], dW2[kb][jb], db1[kb],
 // db2[kb], extra[kb] (extra = dk0 for block 2).
 template <int NB>
 struct AccSet {
@@ -173,11 +173,12 @@ struct AccSet {
   }
 };
 
+// `stage` is the wave's OWN scratch region (stride WSCR), so staging never touches the
+// transpose tiles another wavefront may still be using.
 template <int NB, int CPS, bool EXTRA>
 __device__ __forceinline__ void stage_accs(AccSet<NB>& A, f32x4 (&extra)[NB], float* __restrict__ stage,
-                                           int wave, int lane) {
-  constexpr int NV = 2 * NB * NB + 2 * NB + (EXTRA ? NB : 0);
-  float* base = stage + (size_t)wave * NV * 256 + lane * 4;
+                                           int lane) {
+  float* base = stage + lane * 4;
   int v = 0;
 #pragma unroll
   for (int kb = 0; kb < NB; ++kb)
@@ -232,7 +233,7 @@ __device__ __forceinline__ void reduce_staged(const float* __restrict__ stage, f
     const int q = ln >> 4, r = ln & 15;
     float s = 0.0f;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) s += stage[(size_t)w * NV * 256 + o];
+    for (int w = 0; w < NW; ++w) s += stage[(size_t)w * G::WSCR + o];
     if (v < 2 * NB * NB) {
       const int m = v % (NB * NB), kb = m / NB, jb = m % NB;
       const int idx = (16 * kb + 4 * q + i) * CW + 16 * jb + r;
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             }
           }
         }
-        stage_accs<NB, CPS, true>(acc, dk0, sT, wave, lane);
+        stage_accs<NB, CPS, true>(acc, dk0, T, lane);
       }
       __syncthreads();
       reduce_staged<G, true>(sT, prec, G::P_F2W1, G::P_F2B1, G::P_F2W2, G::P_F2B2, tid);
@@ -573,7 +574,10 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             }
           }
         }
-        stage_accs<NB, CPS, false>(acc, dummy, sT, wave, lane);
+        if (lead && vs) {  // padded slots: k_apply_rows sums all Ls entries of a use
+          for (int p = n_l; p < Ls; ++p) a.GT[(size_t)bidx * Ls + p] = 0.0f;
+        }
+        stage_accs<NB, CPS, false>(acc, dummy, T, lane);
       }
       // scalars of this pass: wave-reduce, stage, one thread sums the waves in fixed order
       {
