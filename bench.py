@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- user-sequences/s of the TLSAN train step (forward + backward + update) on the
+Electronics-scale synthetic workload (BASELINE.json configs[2] shapes; SURVEY.md 8d inputs).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]           (N>1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path over one batch of 4096 synthetic user-sequences that is
+already resident in HBM.  Rank 0 prints ONE JSON line with the whole-job throughput, the
+roofline record of the dominant kernel (k_fwd_bwd; HIP events on its own stream, inside the
+timed region) and the CPU baseline (the oracle's op-for-op torch port, timed on host cores
+on a bounded sample).  The oracle is only a baseline/checker here; the timed path is the HIP
+library (tlsan_amd/libtlsan_hip.so) and nothing else.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="electronics")
+    ap.add_argument("--batch", type=int, default=0, help="override the config's batch size")
+    ap.add_argument("--n-batches", type=int, default=16, help="distinct resident batches cycled through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--profile-level", type=int, default=1)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, icl, batch, seconds):
+    """oracle/tlsan_torch_ref.py: eager fp32 torch on host cores, dense L2 grads over whole
+    tables, global-norm clip, SGD -- the reference's step restated op for op (kind 'port':
+    TensorFlow 1.8 cannot run here or on the GPU box)."""
+    import torch
+    from oracle import tlsan_torch_ref as tref
+    from oracle import tlsan_oracle as orc
+    ncpu = os.cpu_count() or 1
+    p = tref.params_to_torch(orc.init_params(cfg, seed=1234, dtype=np.float32), dtype=torch.float32)
+    b = tref.batch_to_torch(orc.as_batch(batch), dtype=torch.float32)
+    B = len(batch[0])
+    # eager torch on many small ops does not scale with threads: probe a few counts, keep the best
+    best, cores = None, 1
+    for th in sorted({1, min(8, ncpu), min(32, ncpu)}):
+        torch.set_num_threads(th)
+        tref.train_step_(p, icl, b, cfg["num_heads"], cfg["regulation_rate"], 1.0)  # warm
+        t1 = time.perf_counter()
+        tref.train_step_(p, icl, b, cfg["num_heads"], cfg["regulation_rate"], 1.0)
+        dt1 = time.perf_counter() - t1
+        if best is None or dt1 < best:
+            best, cores = dt1, th
+    torch.set_num_threads(cores)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        tref.train_step_(p, icl, b, cfg["num_heads"], cfg["regulation_rate"], 1.0)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 200:
+            break
+    return dict(value=round(n * B / dt, 1), unit="user-sequences/s", cores=cores, kind="port",
+                sample="%d train steps of batch %d (same synthetic batch 0, fp32 eager torch, %.1f s)" % (n, B, dt))
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    from tlsan_amd import _lib as L
+    from tlsan_amd import synth
+    from tlsan_amd.model import DeviceBatch, Model
+
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    cfg = synth.make_config(args.workload)
+    B = args.batch or cfg["train_batch_size"]
+    icl = synth.item_cate_list(cfg)
+    # weak scaling: every rank trains its own batch of B sequences per step
+    host_batches = synth.make_batches(cfg, args.n_batches, B, seed=1234 + 1000 * rank)
+    if world == 1:
+        model = Model(cfg, icl, device=dev)
+        stepper = model
+    else:
+        from tlsan_amd.dist import ShardedModel
+        model = ShardedModel(cfg, icl, device=dev)
+        stepper = model
+    dbs = [stepper.device_batch(b) for b in host_batches]
+    lr = 1.0
+    lib = L.load()
+
+    def run(n, first):
+        for s in range(n):
+            stepper.train_async(dbs[(first + s) % len(dbs)], lr)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    run(args.warmup, 0)
+    fence()
+    lib.tlsan_profile_enable(args.profile_level)
+    t0 = time.perf_counter()
+    run(args.steps, args.warmup)
+    fence()
+    dt = time.perf_counter() - t0
+    nprof = min(args.steps, 4096)
+    buf = (ctypes.c_float * (nprof * 5))()
+    nrec = lib.tlsan_profile_collect(buf, nprof)
+    lib.tlsan_profile_enable(0)
+    seg = np.frombuffer(buf, dtype=np.float32)[: nrec * 5].reshape(nrec, 5) if nrec > 0 else np.zeros((0, 5))
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(model._out[0].item())
+    if not np.isfinite(loss):
+        raise SystemExit("bench.py: non-finite loss %r" % loss)
+
+    if rank == 0:
+        seqs = args.steps * B * world
+        ab = [synth.algorithmic_bytes(cfg, host_batches[(args.warmup + s) % len(host_batches)]) for s in range(args.steps)]
+        k_bytes = float(np.mean([a["fwd_bwd_kernel"] for a in ab]))
+        step_bytes = float(np.mean([a["train_step"] for a in ab])) + synth.dense_sweep_bytes(cfg)
+        k_ms = float(seg[:, 1].mean()) if nrec else float("nan")
+        achieved = k_bytes / (k_ms * 1e-3) / 1e9 if nrec else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_fwd_bwd_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "user-sequences/sec (train step: fwd+bwd+update), Electronics-scale",
+            "value": round(seqs / dt, 1),
+            "unit": "user-sequences/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "%s-scale synthetic (U=%d I=%d C=%d, d=%d, Ls=%d), batch %d/GPU, fp32 tables, "
+                                   "l2_mode=dense (every row updated every step, as the reference)"
+                                   % (args.workload, cfg["user_count"], cfg["item_count"], cfg["cate_count"],
+                                      cfg["hidden_units"], cfg["Ls"], B),
+                       "global_batch": B * world, "parallelism": "1 process/GPU, tables %s"
+                       % ("replicated" if world == 1 else "row-sharded, RCCL all-to-all")},
+            "roofline": {"bound": "hbm", "kernel": "k_fwd_bwd", "achieved": None if achieved is None else round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": traffic,
+                         "algorithmic_bytes_per_launch": round(k_bytes), "kernel_ms": round(k_ms, 5),
+                         "step_algorithmic_bytes": round(step_bytes),
+                         "step_frac": round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
+            "final_loss": round(loss, 6),
+        }
+        if nrec and args.profile_level >= 2:
+            out["segments_ms"] = {n: round(float(seg[:, i].mean()), 5) for i, n in enumerate(L.PROF_SEGMENTS)}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, icl, host_batches[0], args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -158,6 +158,16 @@ int tlsan_eval_ranks(const tlsan_dims* dims, const tlsan_params* p, const float*
                      const int32_t* labels, int32_t B, int32_t* ranks,
                      void* ws, size_t ws_bytes, void* stream);
 
+/* Profiling hooks (measurement only; no reference counterpart).  level 0 = off (default),
+ * 1 = HIP events around the fused forward/backward kernel of every train step,
+ * 2 = events at every kernel boundary of the step.  Events are recorded on the step's stream.
+ * tlsan_profile_collect waits for the recorded events and writes, per recorded step, 5 floats
+ * of milliseconds {index build, fwd+bwd kernel, dK partial, dense finalize, row apply}
+ * (level 1 fills only [1]); returns the number of steps written and clears the ring. */
+#define TLSAN_PROF_SEGMENTS 5
+int tlsan_profile_enable(int level);
+int tlsan_profile_collect(float* host_ms, int max_steps);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,8 +15,10 @@ L2_DENSE, L2_LAZY = 0, 1
 EXPORTS = [
     "tlsan_abi_version", "tlsan_last_error", "tlsan_dense_layout_of", "tlsan_workspace_bytes",
     "tlsan_state_bytes", "tlsan_state_init", "tlsan_sync_derived", "tlsan_forward",
-    "tlsan_train_step", "tlsan_grads", "tlsan_eval_ranks",
+    "tlsan_train_step", "tlsan_grads", "tlsan_eval_ranks", "tlsan_profile_enable",
+    "tlsan_profile_collect",
 ]
+PROF_SEGMENTS = ("index_build", "fwd_bwd", "dk_partial", "dense_finalize", "apply_rows")
 
 
 class Dims(C.Structure):
@@ -88,6 +90,10 @@ def load():
                                 C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.tlsan_eval_ranks.argtypes = [P(Dims), P(Params), C.c_void_p, C.c_void_p, C.c_int32,
                                      C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.tlsan_profile_enable.argtypes = [C.c_int]
+    lib.tlsan_profile_enable.restype = C.c_int
+    lib.tlsan_profile_collect.argtypes = [C.c_void_p, C.c_int]
+    lib.tlsan_profile_collect.restype = C.c_int
     for name in ("tlsan_dense_layout_of", "tlsan_state_init", "tlsan_sync_derived", "tlsan_forward",
                  "tlsan_train_step", "tlsan_grads", "tlsan_eval_ranks"):
         getattr(lib, name).restype = C.c_int

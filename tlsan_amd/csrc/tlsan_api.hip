@@ -3,6 +3,7 @@
 // caller's stream (so a whole step can be captured into a hipGraph).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "tlsan_common.h"
@@ -26,6 +27,33 @@ static int fail(int code, const char* fmt, ...) {
     hipError_t e_ = hipGetLastError();                                             \
     if (e_ != hipSuccess) return fail(TLSAN_E_LAUNCH, "%s: %s", what, hipGetErrorString(e_)); \
   } while (0)
+
+// ---- profiling ring (tlsan_profile_*): events at the kernel boundaries of a train step ----
+#define PROF_MAX_STEPS 4096
+#define PROF_MARKS 6
+static int g_prof_level = 0;
+static int g_prof_n = 0;
+static hipEvent_t* g_prof_ev = nullptr;  // [PROF_MAX_STEPS][PROF_MARKS], created on first enable
+static void prof_mark(int mark, hipStream_t hs) {
+  if (g_prof_level == 0 || g_prof_n >= PROF_MAX_STEPS) return;
+  if (g_prof_level == 1 && mark != 1 && mark != 2) return;
+  (void)hipEventRecord(g_prof_ev[g_prof_n * PROF_MARKS + mark], hs);
+}
+
+// ---- side stream: the inverted index only depends on the batch, so it is built concurrently
+// with the fused forward/backward kernel and joined before k_apply_rows (fork/join with events:
+// also valid under hipGraph stream capture)
+static hipStream_t g_side = nullptr;
+static hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr;
+static int g_use_side = 1;
+static bool side_ready() {
+  if (!g_use_side) return false;
+  if (g_side) return true;
+  if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) { g_side = nullptr; return false; }
+  if (hipEventCreateWithFlags(&g_ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&g_ev_join, hipEventDisableTiming) != hipSuccess) { g_side = nullptr; return false; }
+  return true;
+}
 
 static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -51,8 +79,6 @@ static int shape_of(const tlsan_dims* d, Shape* s) {
   return TLSAN_OK;
 }
 
-#define DK_CHUNK 64
-
 struct Ws {  // carve-up of the caller's scratch buffer
   float *G, *GT, *dlogit, *gLong, *gDB, *partials, *Kp, *gd, *sqd, *scal, *logits, *s_label;
   int32_t *off_item, *off_cate, *off_user, *cur_item, *cur_cate, *cur_user;
@@ -60,7 +86,7 @@ struct Ws {  // carve-up of the caller's scratch buffer
   double* rownorm_part;
   double* rownorm;
   size_t bytes;
-  int ngroups, nsplit, nfin;
+  int ngroups, nsplit, nfin, nbK, nbS;
 };
 
 static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base, Ws* w) {
@@ -71,7 +97,9 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
   tlsan_dense_layout_of(d, &L);
   w->ngroups = (B + s.NSB - 1) / s.NSB;
   w->nsplit = (B + DK_CHUNK - 1) / DK_CHUNK;
-  w->nfin = (L.n_dense + 255) / 256;
+  w->nbK = (s.D * s.D + 255) / 256;
+  w->nbS = (L.n_dense - s.D * s.D + 15) / 16;
+  w->nfin = w->nbK + w->nbS;
   w->G = (float*)take(sizeof(float) * B * S * D);
   w->GT = (float*)take(sizeof(float) * B * d->Ls);
   w->dlogit = (float*)take(sizeof(float) * B);
@@ -93,7 +121,7 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
   w->list_item = (int32_t*)take(4 * (size_t)B * S);
   w->list_cate = (int32_t*)take(4 * (size_t)B * S);
   w->list_user = (int32_t*)take(4 * (size_t)B);
-  const size_t nrowblk = (size_t)(d->item_count + 3) / 4 + (d->user_count + 3) / 4 + d->cate_count;
+  const size_t nrowblk = (size_t)(d->item_count + 15) / 16 + (d->user_count + 15) / 16 + d->cate_count;
   w->rownorm_part = (double*)take(8 * nrowblk);
   w->rownorm = (double*)take(8);
   w->bytes = o;
@@ -109,8 +137,8 @@ struct St {  // persistent state
 static void carve_state(const tlsan_dims* d, char* base, St* s) {
   size_t o = 0;
   auto take = [&](size_t n) { char* p = base ? base + o : nullptr; o += al(n); return p; };
-  s->nbI = (d->item_count + 3) / 4;
-  s->nbU = (d->user_count + 3) / 4;
+  s->nbI = (d->item_count + AP_ROWS_PB - 1) / AP_ROWS_PB;
+  s->nbU = (d->user_count + AP_ROWS_PB - 1) / AP_ROWS_PB;
   s->nbC = d->cate_count;
   s->cnt_item = (int32_t*)take(4 * (size_t)d->item_count);
   s->cnt_cate = (int32_t*)take(4 * (size_t)d->cate_count);
@@ -288,38 +316,61 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   ia.cur_item = w.cur_item; ia.cur_cate = w.cur_cate; ia.cur_user = w.cur_user;
   ia.list_item = w.list_item; ia.list_cate = w.list_cate; ia.list_user = w.list_user;
   const int nthr = b->B * S;
-  hipLaunchKernelGGL(k_index<false>, dim3((nthr + 255) / 256), dim3(256), 0, hs, ia);
+  prof_mark(0, hs);
+  const bool side = side_ready() && g_prof_level < 2;  // level-2 profiling serialises the stages
+  hipStream_t is = hs;
+  if (side) {
+    if (hipEventRecord(g_ev_fork, hs) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_fork, 0) != hipSuccess)
+      return fail(TLSAN_E_LAUNCH, "fork to side stream");
+    is = g_side;
+  }
+  hipLaunchKernelGGL(k_index<false>, dim3((nthr + 255) / 256), dim3(256), 0, is, ia);
   CHECK_LAUNCH("k_index<count>");
   ScanArgs sa;
   sa.cnt[0] = st.cnt_item; sa.cnt[1] = st.cnt_cate; sa.cnt[2] = st.cnt_user;
   sa.off[0] = w.off_item; sa.off[1] = w.off_cate; sa.off[2] = w.off_user;
   sa.cur[0] = w.cur_item; sa.cur[1] = w.cur_cate; sa.cur[2] = w.cur_user;
   sa.n[0] = d->item_count; sa.n[1] = d->cate_count; sa.n[2] = d->user_count;
-  hipLaunchKernelGGL(k_index_scan, dim3(3), dim3(1024), 0, hs, sa);
+  sa.blk0[0] = 0;
+  sa.blk0[1] = (sa.n[0] + 4095) / 4096;
+  sa.blk0[2] = sa.blk0[1] + (sa.n[1] + 4095) / 4096;
+  const int nscan = sa.blk0[2] + (sa.n[2] + 4095) / 4096;
+  hipLaunchKernelGGL(k_index_scan, dim3(nscan), dim3(1024), 0, is, sa);
   CHECK_LAUNCH("k_index_scan");
-  hipLaunchKernelGGL(k_index<true>, dim3((nthr + 255) / 256), dim3(256), 0, hs, ia);
+  hipLaunchKernelGGL(k_index<true>, dim3((nthr + 255) / 256), dim3(256), 0, is, ia);
   CHECK_LAUNCH("k_index<fill>");
+  if (side && hipEventRecord(g_ev_join, g_side) != hipSuccess) return fail(TLSAN_E_LAUNCH, "side stream join record");
   // --- fused forward + backward
   FwdArgs a;
   fill_fwd(a, d, s, p, b, w, L);
   a.logits_i = (out && out->logits) ? out->logits : w.logits;
   a.G = w.G; a.GT = w.GT; a.dlogit = w.dlogit; a.gLong = w.gLong; a.gDB = w.gDB; a.partials = w.partials;
+  prof_mark(1, hs);
   int rc = launch_fwd(s, true, a, hs);
   if (rc) return rc;
+  prof_mark(2, hs);
   // --- dense-parameter gradients
-  if (s.D == 64) hipLaunchKernelGGL(k_dk_partial<64>, dim3(w.nsplit), dim3(512), 0, hs, w.gLong, w.gDB, b->B, DK_CHUNK, w.Kp);
-  else if (s.D == 128) hipLaunchKernelGGL(k_dk_partial<128>, dim3(w.nsplit), dim3(512), 0, hs, w.gLong, w.gDB, b->B, DK_CHUNK, w.Kp);
-  else hipLaunchKernelGGL(k_dk_partial<256>, dim3(w.nsplit), dim3(512), 0, hs, w.gLong, w.gDB, b->B, DK_CHUNK, w.Kp);
+  {
+    const size_t smem = sizeof(float) * 2 * DK_CHUNK * (s.D + 4);
+    if (s.D == 64) { hipLaunchKernelGGL(k_dk_partial<64>, dim3(w.nsplit), dim3(512), smem, hs, w.gLong, w.gDB, b->B, w.Kp); }
+    else if (s.D == 128) { (void)hipFuncSetAttribute((const void*)k_dk_partial<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      hipLaunchKernelGGL(k_dk_partial<128>, dim3(w.nsplit), dim3(512), smem, hs, w.gLong, w.gDB, b->B, w.Kp); }
+    else { (void)hipFuncSetAttribute((const void*)k_dk_partial<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      hipLaunchKernelGGL(k_dk_partial<256>, dim3(w.nsplit), dim3(512), smem, hs, w.gLong, w.gDB, b->B, w.Kp); }
+  }
   CHECK_LAUNCH("k_dk_partial");
+  prof_mark(3, hs);
   FinArgs f;
   memset(&f, 0, sizeof(f));
   f.lay = L; f.partials = w.partials; f.nrec = w.ngroups; f.Kp = w.Kp; f.nsplit = w.nsplit;
   f.gd = w.gd; f.sqd = w.sqd; f.scal = w.scal;
   f.S_part = st.S_part; f.n_spart = st.nbI + st.nbU + st.nbC; f.S_total = st.S_total;
-  if (s.D == 64) hipLaunchKernelGGL((k_dense_finalize<64, 8>), dim3(w.nfin + 1), dim3(256), 0, hs, f);
-  else if (s.D == 128) hipLaunchKernelGGL((k_dense_finalize<128, 16>), dim3(w.nfin + 1), dim3(256), 0, hs, f);
-  else hipLaunchKernelGGL((k_dense_finalize<256, 32>), dim3(w.nfin + 1), dim3(256), 0, hs, f);
+  if (s.D == 64) hipLaunchKernelGGL((k_dense_finalize<64, 8>), dim3(w.nfin + 1), dim3(256), 0, hs, f, w.nbK, w.nbS);
+  else if (s.D == 128) hipLaunchKernelGGL((k_dense_finalize<128, 16>), dim3(w.nfin + 1), dim3(256), 0, hs, f, w.nbK, w.nbS);
+  else hipLaunchKernelGGL((k_dense_finalize<256, 32>), dim3(w.nfin + 1), dim3(256), 0, hs, f, w.nbK, w.nbS);
   CHECK_LAUNCH("k_dense_finalize");
+  if (side && hipStreamWaitEvent(hs, g_ev_join, 0) != hipSuccess) return fail(TLSAN_E_LAUNCH, "side stream join wait");
+  prof_mark(4, hs);
   return TLSAN_OK;
 }
 
@@ -363,6 +414,8 @@ int tlsan_train_step(const tlsan_dims* d, const tlsan_params* p, const tlsan_bat
   }
   hipLaunchKernelGGL(k_apply_rows<AP_UPDATE>, dim3(nrow + A.nbD), dim3(256), 0, hs, A);
   CHECK_LAUNCH("k_apply_rows<UPDATE>");
+  prof_mark(5, hs);
+  if (g_prof_level > 0 && g_prof_n < PROF_MAX_STEPS) ++g_prof_n;
   return TLSAN_OK;
 }
 
@@ -424,6 +477,37 @@ int tlsan_eval_ranks(const tlsan_dims* d, const tlsan_params* p, const float* u_
   else { hipLaunchKernelGGL(k_eval_label<256>, dim3(ut), dim3(64), 0, hs, e); hipLaunchKernelGGL(k_eval_rank<256>, dim3(ut, chunks), dim3(256), 0, hs, e); }
   CHECK_LAUNCH("k_eval");
   return TLSAN_OK;
+}
+
+int tlsan_profile_enable(int level) {
+  if (level < 0 || level > 2) return fail(TLSAN_E_BADARG, "profile level must be 0..2");
+  if (level > 0 && !g_prof_ev) {
+    g_prof_ev = (hipEvent_t*)malloc(sizeof(hipEvent_t) * PROF_MAX_STEPS * PROF_MARKS);
+    if (!g_prof_ev) return fail(TLSAN_E_WORKSPACE, "out of host memory");
+    for (int k = 0; k < PROF_MAX_STEPS * PROF_MARKS; ++k)
+      if (hipEventCreate(&g_prof_ev[k]) != hipSuccess) return fail(TLSAN_E_LAUNCH, "hipEventCreate");
+  }
+  g_prof_level = level;
+  g_prof_n = 0;
+  return TLSAN_OK;
+}
+
+int tlsan_profile_collect(float* host_ms, int max_steps) {
+  if (!host_ms || max_steps < 0) return fail(TLSAN_E_BADARG, "bad profile buffer");
+  int n = g_prof_n < max_steps ? g_prof_n : max_steps;
+  for (int k = 0; k < n; ++k) {
+    hipEvent_t* e = g_prof_ev + (size_t)k * PROF_MARKS;
+    for (int sgm = 0; sgm < TLSAN_PROF_SEGMENTS; ++sgm) {
+      float ms = 0.0f;
+      if (g_prof_level == 2 || sgm == 1) {
+        if (hipEventSynchronize(e[sgm + 1]) != hipSuccess || hipEventElapsedTime(&ms, e[sgm], e[sgm + 1]) != hipSuccess)
+          return fail(TLSAN_E_LAUNCH, "hipEventElapsedTime");
+      }
+      host_ms[k * TLSAN_PROF_SEGMENTS + sgm] = ms;
+    }
+  }
+  g_prof_n = 0;
+  return n;
 }
 
 }  // extern "C"

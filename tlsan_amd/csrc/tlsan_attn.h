@@ -156,6 +156,12 @@ __device__ __forceinline__ f32x4 gather_item4(const FwdArgs& a, int it, int c) {
   return *(const f32x4*)ptr;
 }
 
+__device__ __forceinline__ f32x4 gather_item4c(const FwdArgs& a, int it, int ct, int c) {
+  const float* ptr = (c < a.di) ? a.p.item_emb + (size_t)it * a.di + c
+                                : a.p.cate_emb + (size_t)ct * a.dc + (c - a.di);
+  return *(const f32x4*)ptr;
+}
+
 // Per-pass, per-wave gradient accumulators of one attention block, and their deterministic
 // reduction over the workgroup's wavefronts into the pass's partial record.
 // LDS staging: stage[wave*WSCR + vec*256 + lane*4 + i]; vec order: dW1[kb][jb], dW2[kb][jb], db1[kb],
@@ -259,7 +265,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   float* sA = smem;                   // [NSB][LSTR]  long -> dbridge
   float* sB = sA + NSB * LSTR;        // [NSB][LSTR]  bridge -> dlong
   float* sS = sB + NSB * LSTR;        // [NW][4] scalar staging
-  float* sT = sS + NW * 4;            // per-wave transpose scratch / accumulator staging
+  float* sH = sS + NW * 4;            // [NSB][2*LS] hist_t and usert*hist_t of the pass
+  float* sT = sH + NSB * 2 * LS;      // per-wave transpose scratch / accumulator staging
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int q = lane >> 4, r = lane & 15;
   const int s_loc = r / CPS, col = r % CPS;
@@ -294,6 +301,10 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       const float ht = vp ? a.b.hist_t[(size_t)bb * Ls + p] : 0.0f;
       const float ut = vp ? a.p.usert_emb[(size_t)uid * Ls + p] : 0.0f;
       sc1[p] = gamma * (ut * ht);  // model.py:100-102,109
+      if (TRAIN && lead) {
+        sH[srow * 2 * LS + p] = ht;
+        sH[srow * 2 * LS + LS + p] = ut * ht;
+      }
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb)
         e1[p][kb] = vp ? gather_item4(a, it, chb[kb]) : (f32x4)(0.0f);
@@ -363,12 +374,37 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         short4[kb] = xv[kb];
       }
     }
+    // session ids (and their categories) are fetched once, one per lane of the sample
+    // (lane k = q*CPS + col holds entry k of the current chunk of NL entries), then broadcast
+    // with a cross-lane read: no dependent index loads inside the position loops.
+    constexpr int NL = 4 * CPS;
+    const int kk = q * CPS + col;
+    int sid = 0, scat = 0;
+    auto load_chunk = [&](int base) {
+      const bool v = base + kk < n_s;
+      sid = v ? a.b.hist_i_new[(size_t)bb * Sn + base + kk] : 0;
+      scat = a.p.item_cate[sid];
+    };
+    auto fetch_row = [&](int t, f32x4 (&xr)[NB]) {  // row of session entry t (chunk must be loaded)
+      const int k = t % NL;
+      const int src = (k / CPS) * 16 + s_loc * CPS + (k % CPS);
+      const int it = __shfl(sid, src), ct = __shfl(scat, src);
+      const bool vt = t < n_s;
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) xr[kb] = vt ? gather_item4c(a, it, ct, chb[kb]) : (f32x4)(0.0f);
+    };
+    load_chunk(0);
+    f32x4 xnext[NB];
+    if (pmax2 > 1) fetch_row(0, xnext);
     for (int p = 1; p < pmax2; ++p) {  // wave-uniform trip count
       const bool vt = (p - 1) < n_s;
-      const int it = vt ? a.b.hist_i_new[(size_t)bb * Sn + (p - 1)] : 0;
       f32x4 xv[NB], z[NB], m2[NB];
 #pragma unroll
-      for (int kb = 0; kb < NB; ++kb) xv[kb] = vt ? gather_item4(a, it, chb[kb]) : (f32x4)(0.0f);
+      for (int kb = 0; kb < NB; ++kb) xv[kb] = xnext[kb];
+      if (p + 1 < pmax2) {  // prefetch the next row while this one is processed
+        if ((p % NL) == 0) load_chunk(p);
+        fetch_row(p, xnext);
+      }
       map_apply<NB>(FT1, b1, xv, z);
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb)
@@ -450,17 +486,18 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         load_frag_N<DH, NB>(dn + a.lay.f2_W2, q, r, FN2);
         AccSet<NB> acc;
         acc.zero();
+        if (pmax2 - 1 > NL) load_chunk(0);  // (wave-uniform) the forward loop moved past chunk 0
+        f32x4 xn2[NB];
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) xn2[kb] = *(const f32x4*)(sB + srow * LSTR + chb[kb]);
         for (int p = 0; p < pmax2; ++p) {  // wave-uniform trip count
           const bool vt = p < n_pos;
           f32x4 xv[NB], z1[NB], zr[NB], m2[NB], av[NB], dx[NB];
-          if (p == 0) {
 #pragma unroll
-            for (int kb = 0; kb < NB; ++kb) xv[kb] = *(const f32x4*)(sB + srow * LSTR + chb[kb]);
-          } else {
-            const int it = vt ? a.b.hist_i_new[(size_t)bb * Sn + (p - 1)] : 0;
-#pragma unroll
-            for (int kb = 0; kb < NB; ++kb)
-              xv[kb] = vt ? gather_item4(a, it, chb[kb]) : (f32x4)(0.0f);
+          for (int kb = 0; kb < NB; ++kb) xv[kb] = xn2[kb];
+          if (p + 1 < pmax2) {  // session entry t = p for the next position
+            if (p > 0 && (p % NL) == 0) load_chunk(p);
+            fetch_row(p, xn2);
           }
           map_apply<NB>(FT1, b1, xv, z1);
 #pragma unroll
@@ -534,9 +571,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         for (int p = 0; p < LS; ++p) {
           if (p < pmax1) {
             const bool vp = p < n_l;
-            const float ht = vp ? a.b.hist_t[(size_t)bb * Ls + p] : 0.0f;
-            const float ut = vp ? a.p.usert_emb[(size_t)uid * Ls + p] : 0.0f;
-            const float scp = gamma * (ut * ht);
+            const float ht = sH[srow * 2 * LS + p];
+            const float uth = sH[srow * 2 * LS + LS + p];
+            const float scp = gamma * uth;
             f32x4 xv[NB], z1[NB], zr[NB], m2[NB], av[NB], dx[NB];
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) xv[kb] = e1[p][kb] * scp;
@@ -569,7 +606,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
                 const float gt = ds * (gamma * ht);  // d / d usert_emb[u][p]
                 a.GT[(size_t)bidx * Ls + p] = gt;
                 sq_acc += gt * gt;
-                dgam += ds * (ut * ht);
+                dgam += ds * uth;
               }
             }
           }

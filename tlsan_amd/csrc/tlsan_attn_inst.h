@@ -6,7 +6,7 @@
 template <int D, int DH>
 static size_t fwd_smem_bytes() {
   using G = Geo<D, DH>;
-  return sizeof(float) * (2 * G::NSB * G::LSTR + G::NW * 4 + G::NW * G::WSCR);
+  return sizeof(float) * (2 * G::NSB * G::LSTR + G::NW * 4 + G::NSB * 2 * TLSAN_LS_MAX + G::NW * G::WSCR);
 }
 
 template <int D, int DH>

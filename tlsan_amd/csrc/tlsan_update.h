@@ -55,75 +55,103 @@ struct ScanArgs {
   int32_t* off[3];
   int32_t* cur[3];
   int32_t n[3];
+  int32_t blk0[3];  // first block of each table in the grid
 };
 
-// blockIdx.x selects the table; 1024 threads x 4 ids per iteration
+// Exclusive scan of the per-row counts, one launch: block j of a table owns ids
+// [4096 j, 4096 j + 4096); it first sums every count that precedes its chunk (coalesced
+// re-read of at most n ints from L2: cheaper than a second launch or a serial carry chain),
+// then scans its own chunk.
 __global__ __launch_bounds__(1024) void k_index_scan(ScanArgs a) {
   __shared__ int wsum[16];
-  __shared__ int carry;
-  const int which = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int32_t* cnt = a.cnt[which];
+  __shared__ int prefix;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int which = 0;
+  if ((int)blockIdx.x >= a.blk0[1]) which = 1;
+  if ((int)blockIdx.x >= a.blk0[2]) which = 2;
+  const int32_t* __restrict__ cnt = a.cnt[which];
+  const int n = a.n[which];
+  const int base = ((int)blockIdx.x - a.blk0[which]) * 4096;
+  // ---- sum of cnt[0, base)
+  int part = 0;
+  for (int k = tid * 4; k < base; k += 4096) {
+    const int4 v = *(const int4*)(cnt + k);  // base is a multiple of 4096 -> always in range
+    part += v.x + v.y + v.z + v.w;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
+  if (lane == 0) wsum[wave] = part;
+  __syncthreads();
+  if (tid == 0) {
+    int t = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += wsum[w];
+    prefix = t;
+  }
+  __syncthreads();
+  // ---- own chunk
+  const int i0 = base + tid * 4;
+  int v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = (i0 + k < n) ? cnt[i0 + k] : 0;
+  const int tsum = v[0] + v[1] + v[2] + v[3];
+  int inc = tsum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int run = prefix + inc - tsum;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) run += (w < wave) ? wsum[w] : 0;
   int32_t* off = a.off[which];
   int32_t* cur = a.cur[which];
-  const int n = a.n[which];
-  if (tid == 0) carry = 0;
-  __syncthreads();
-  for (int base = 0; base < n; base += 4096) {
-    const int i0 = base + tid * 4;
-    int v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = (i0 + k < n) ? cnt[i0 + k] : 0;
-    const int tsum = v[0] + v[1] + v[2] + v[3];
-    int inc = tsum;  // inclusive scan over the wave
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int t = __shfl_up(inc, o);
-      if (lane >= o) inc += t;
+  for (int k = 0; k < 4; ++k) {
+    if (i0 + k < n) {
+      off[i0 + k] = run;
+      cur[i0 + k] = run;
     }
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    int wbase = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) wbase += (w < wave) ? wsum[w] : 0;
-    int run = carry + wbase + inc - tsum;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (i0 + k < n) {
-        off[i0 + k] = run;
-        cur[i0 + k] = run;
-      }
-      run += v[k];
-    }
-    __syncthreads();
-    if (tid == 1023) carry = run;
-    __syncthreads();
+    run += v[k];
   }
 }
 
 // ------------------------------------------------------------------------------------------
 // dK[k][j] = sum_b long[b][k] * dbridge[b][j]  (gradient of tf.layers.dense's kernel,
-// model.py:347) for the samples [blockIdx.x*chunk, +chunk).  C[M=k][N=j], K-dim = samples.
+// model.py:347) for the DK_CHUNK samples of this workgroup.  C[M=k][N=j], K-dim = samples.
+// The chunk's rows are staged in LDS with one round of coalesced 16-B loads.
+#define DK_CHUNK 64
 template <int D>
 __global__ __launch_bounds__(512) void k_dk_partial(const float* __restrict__ gLong,
-                                                    const float* __restrict__ gDB, int B, int chunk,
+                                                    const float* __restrict__ gDB, int B,
                                                     float* __restrict__ Kp) {
-  constexpr int NT = D / 16;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, r = lane & 15;
-  const int b0 = blockIdx.x * chunk, b1 = min(B, b0 + chunk);
+  constexpr int NT = D / 16, STR = D + 4;  // rows 4 apart (lane quarters q, q+1) land 16 banks apart
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sL = smem;
+  float* sD = smem + DK_CHUNK * STR;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, r = lane & 15;
+  const int b0 = blockIdx.x * DK_CHUNK;
+  for (int o = tid; o < DK_CHUNK * (D / 4); o += 512) {
+    const int row = o / (D / 4), c4 = o % (D / 4);
+    const bool v = b0 + row < B;
+    const f32x4 z = (f32x4)(0.0f);
+    *(f32x4*)(sL + row * STR + 4 * c4) = v ? *(const f32x4*)(gLong + (size_t)(b0 + row) * D + 4 * c4) : z;
+    *(f32x4*)(sD + row * STR + 4 * c4) = v ? *(const f32x4*)(gDB + (size_t)(b0 + row) * D + 4 * c4) : z;
+  }
+  __syncthreads();
   float* out = Kp + (size_t)blockIdx.x * D * D;
   for (int tile = wave; tile < NT * NT; tile += 8) {
     const int kt = tile / NT, jt = tile % NT;
     f32x4 acc = (f32x4)(0.0f);
-    for (int bs = b0; bs < b1; bs += 16) {
+#pragma unroll
+    for (int st = 0; st < DK_CHUNK / 16; ++st)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const int bi = bs + 4 * q + s;
-        const bool v = bi < b1;
-        const float av = v ? gLong[(size_t)bi * D + 16 * kt + r] : 0.0f;
-        const float bv = v ? gDB[(size_t)bi * D + 16 * jt + r] : 0.0f;
-        acc = TLSAN_MFMA(av, bv, acc);
+        const int row = 16 * st + 4 * q + s;
+        acc = TLSAN_MFMA(sL[row * STR + 16 * kt + r], sD[row * STR + 16 * jt + r], acc);
       }
-    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) out[(size_t)(16 * kt + 4 * q + i) * D + 16 * jt + r] = acc[i];
   }
@@ -137,7 +165,7 @@ struct FinArgs {
   const float* Kp;        // [nsplit][D*D]
   int32_t nsplit;
   float* gd;              // [n_dense] reduced dense gradients
-  float* sqd;             // [gridDim.x - 1] per-block sum of gd^2
+  float* sqd;             // [nbK + nbS] per-block sum of gd^2
   float* scal;            // [0] = sum of per-sample BCE, [1] = sum of squares of per-use rows
   const double* S_part;   // per-row-block sums of squares of the regularised tables
   int32_t n_spart;
@@ -158,64 +186,93 @@ __device__ __forceinline__ double block_sum_double(const double* __restrict__ v,
   return sh[0];
 }
 
-// grid = ceil(n_dense/256) + 1; the last block reduces S_part -> S_total
+// Grid: [0, nbK) blocks reduce the D*D kernel gradient over the batch splits (one thread per
+// entry); [nbK, nbK+nbS) blocks reduce the small parameters over the per-pass partial records
+// with 16 lanes per parameter (lane l sums records l, l+16, ...; fixed xor tree after);
+// the last block reduces S_part -> S_total.  Every sum has a fixed order -> deterministic.
 template <int D, int DH>
-__global__ __launch_bounds__(256) void k_dense_finalize(FinArgs a) {
+__global__ __launch_bounds__(256) void k_dense_finalize(FinArgs a, int nbK, int nbS) {
   using G = Geo<D, DH>;
   constexpr int CW = G::CW, NPB = G::NPB, HPC = CW / DH;  // heads per 16-wide column block
   __shared__ double shd[256];
-  const int tid = threadIdx.x;
-  if (blockIdx.x == gridDim.x - 1) {
+  const int tid = threadIdx.x, blk = blockIdx.x;
+  const tlsan_dense_layout& L = a.lay;
+  if (blk == nbK + nbS) {
     const double s = block_sum_double(a.S_part, a.n_spart, shd);
     if (tid == 0) *a.S_total = s;
     return;
   }
-  const int n = blockIdx.x * 256 + tid;
-  const tlsan_dense_layout& L = a.lay;
   float g = 0.0f;
-  if (n < L.n_dense) {
-    if (n >= L.K && n < L.k0) {
-      const int idx = n - L.K;
-      for (int s = 0; s < a.nsplit; ++s) g += a.Kp[(size_t)s * D * D + idx];
-    } else {
+  bool owner = false;
+  if (blk < nbK) {
+    const int idx = blk * 256 + tid;
+    if (idx < D * D) {
+      float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f;
+      int sidx = 0;
+      for (; sidx + 3 < a.nsplit; sidx += 4) {
+        g0 += a.Kp[(size_t)(sidx + 0) * D * D + idx];
+        g1 += a.Kp[(size_t)(sidx + 1) * D * D + idx];
+        g2 += a.Kp[(size_t)(sidx + 2) * D * D + idx];
+        g3 += a.Kp[(size_t)(sidx + 3) * D * D + idx];
+      }
+      for (; sidx < a.nsplit; ++sidx) g0 += a.Kp[(size_t)sidx * D * D + idx];
+      g = (g0 + g1) + (g2 + g3);
+      a.gd[L.K + idx] = g;
+      owner = true;
+    }
+  } else {
+    const int m = (blk - nbK) * 16 + (tid >> 4), rl = tid & 15;
+    const int n_small = L.n_dense - D * D;
+    if (m < n_small) {
+      const int n = m < L.K ? m : m + D * D;
       // map the true parameter index to 1..HPC entries of the effective-layout record
       int e[2] = {-1, -1};
       const int wofs[4] = {L.f1_W1, L.f1_W2, L.f2_W1, L.f2_W2};
       const int bofs[4] = {L.f1_b1, L.f1_b2, L.f2_b1, L.f2_b2};
       const int pw[4] = {G::P_F1W1, G::P_F1W2, G::P_F2W1, G::P_F2W2};
       const int pb[4] = {G::P_F1B1, G::P_F1B2, G::P_F2B1, G::P_F2B2};
-      for (int m = 0; m < 4; ++m) {
-        if (n >= wofs[m] && n < wofs[m] + DH * DH) {
-          const int k = (n - wofs[m]) / DH, j = (n - wofs[m]) % DH;
-          for (int h = 0; h < HPC; ++h) e[h] = pw[m] + (h * DH + k) * CW + h * DH + j;
+      for (int mm = 0; mm < 4; ++mm) {
+        if (n >= wofs[mm] && n < wofs[mm] + DH * DH) {
+          const int k = (n - wofs[mm]) / DH, j = (n - wofs[mm]) % DH;
+          for (int h = 0; h < HPC; ++h) e[h] = pw[mm] + (h * DH + k) * CW + h * DH + j;
         }
-        if (n >= bofs[m] && n < bofs[m] + DH) {
-          const int j = n - bofs[m];
-          for (int h = 0; h < HPC; ++h) e[h] = pb[m] + h * DH + j;
+        if (n >= bofs[mm] && n < bofs[mm] + DH) {
+          const int j = n - bofs[mm];
+          for (int h = 0; h < HPC; ++h) e[h] = pb[mm] + h * DH + j;
         }
       }
       if (n >= L.k0 && n < L.k0 + D) e[0] = G::P_K0 + (n - L.k0);
       if (n == L.gamma) e[0] = G::P_GAMMA;
-      for (int rec = 0; rec < a.nrec; ++rec) {
+      float t = 0.0f;
+      for (int rec = rl; rec < a.nrec; rec += 16) {
         const float* p = a.partials + (size_t)rec * NPB;
-        float t = p[e[0]];
-        if (HPC > 1 && e[1] >= 0) t += p[e[1]];
-        g += t;
+        float v = p[e[0]];
+        if (HPC > 1 && e[1] >= 0) v += p[e[1]];
+        t += v;
+      }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) t += __shfl_xor(t, o);
+      g = t;
+      if (rl == 0) {
+        a.gd[n] = g;
+        owner = true;
       }
     }
-    a.gd[n] = g;
   }
-  shd[tid] = (double)g * (double)g;
+  shd[tid] = owner ? (double)g * (double)g : 0.0;
   __syncthreads();
   for (int o = 128; o >= 1; o >>= 1) {
     if (tid < o) shd[tid] += shd[tid + o];
     __syncthreads();
   }
-  if (tid == 0) a.sqd[blockIdx.x] = (float)shd[0];
-  if (blockIdx.x == 0 && tid < 2) {
-    float s = 0.0f;
-    for (int rec = 0; rec < a.nrec; ++rec) s += a.partials[(size_t)rec * NPB + G::P_LOSS + tid];
-    a.scal[tid] = s;
+  if (tid == 0) a.sqd[blk] = (float)shd[0];
+  if (blk == 0 && tid < 32) {  // loss sum and per-use square sum: 16 lanes each, fixed order
+    const int which = tid >> 4, rl = tid & 15;
+    float t = 0.0f;
+    for (int rec = rl; rec < a.nrec; rec += 16) t += a.partials[(size_t)rec * NPB + G::P_LOSS + which];
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) t += __shfl_xor(t, o);
+    if (rl == 0) a.scal[which] = t;
   }
 }
 
@@ -252,36 +309,47 @@ struct ApplyArgs {
   int32_t nbI, nbU, nbC, nbD;
 };
 
-// add the rows list[first], list[first+stride], ... (each: 4*W4 floats at G[c*D + colofs]) exactly
-__device__ __forceinline__ void accum_list(const int32_t* __restrict__ list, int n, int first,
+// add rows list[k], k = lo, lo+stride, ... < hi (each: 4*W4 floats at G[c*D + colofs]) exactly;
+// up to four independent rows in flight
+__device__ __forceinline__ void accum_list(const int32_t* __restrict__ list, int lo, int hi,
                                            int stride, const float* __restrict__ G, int D, int colofs,
                                            int W4, int l16, double (&acc)[2][4]) {
-  int k = first;
-  for (; k + stride < n; k += 2 * stride) {  // two independent rows in flight
-    const int c0 = list[k], c1 = list[k + stride];
+  for (int k = lo; k < hi; k += 4 * stride) {
+    int c[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) c[u] = (k + u * stride < hi) ? list[k + u * stride] : -1;
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch) {
       const int c4 = l16 + 16 * ch;
       if (c4 < W4) {
-        const f32x4 v0 = *(const f32x4*)(G + (size_t)c0 * D + colofs + 4 * c4);
-        const f32x4 v1 = *(const f32x4*)(G + (size_t)c1 * D + colofs + 4 * c4);
+        f32x4 v[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[ch][i] += exact_term(v0[i]) + exact_term(v1[i]);
+        for (int u = 0; u < 4; ++u)
+          v[u] = c[u] >= 0 ? *(const f32x4*)(G + (size_t)c[u] * D + colofs + 4 * c4) : (f32x4)(0.0f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[ch][i] += exact_term(v[u][i]);
       }
     }
   }
-  if (k < n) {
-    const int c0 = list[k];
-#pragma unroll
-    for (int ch = 0; ch < 2; ++ch) {
-      const int c4 = l16 + 16 * ch;
-      if (c4 < W4) {
-        const f32x4 v0 = *(const f32x4*)(G + (size_t)c0 * D + colofs + 4 * c4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[ch][i] += exact_term(v0[i]);
-      }
+}
+
+// the narrow companion of a row: item -> item_b gradient (lane 0, candidate-slot uses only),
+// user -> usert_emb gradient (lane p < Ls)
+__device__ __forceinline__ double accum_side(const ApplyArgs& a, bool is_item, const int32_t* __restrict__ list,
+                                             int lo, int hi, int stride, int l16) {
+  double sacc = 0.0;
+  for (int k = lo; k < hi; k += stride) {
+    const int c = list[k];
+    const int b = c / a.S;
+    if (is_item) {
+      if (l16 == 0 && (c - b * a.S) == a.Ls + a.Sn) sacc += exact_term(a.dlogit[b]);
+    } else if (l16 < a.Ls) {
+      sacc += exact_term(a.GT[(size_t)b * a.Ls + l16]);
     }
   }
+  return sacc;
 }
 
 // Apply one parameter row of width 4*W4 held by lanes l16 (chunks l16, l16+16):
@@ -322,6 +390,7 @@ __device__ __forceinline__ double apply_row(float* __restrict__ Wrow, float* __r
   return part;
 }
 
+// sum over the four 16-lane groups of a wavefront (exact doubles -> order irrelevant)
 __device__ __forceinline__ void combine_groups(double (&acc)[2][4]) {
 #pragma unroll
   for (int ch = 0; ch < 2; ++ch)
@@ -332,15 +401,19 @@ __device__ __forceinline__ void combine_groups(double (&acc)[2][4]) {
     }
 }
 
-// Block layout: [0,nbI) item rows (one row per wavefront), [nbI,nbI+nbU) user rows (user_emb +
-// usert_emb), then nbC category rows (one row per workgroup: long lists), then nbD blocks of
-// 256 dense parameters.
+#define AP_OWN 8        // uses a 16-lane group sums alone before the wavefront helps
+#define AP_ROWS_PB 16   // item / user rows per workgroup (4 wavefronts x 4 groups)
+
+// Block layout: [0,nbI) item rows, [nbI,nbI+nbU) user rows (user_emb + usert_emb): one row per
+// 16-lane group; the first AP_OWN uses of a row are summed by its group, longer lists (hot
+// items) by the whole wavefront.  Then nbC category rows (one row per workgroup: long lists),
+// then nbD blocks of 256 dense parameters.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_apply_rows(ApplyArgs a) {
   __shared__ double shd[4 * 16 * 8];
   __shared__ float sh_coef;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, grp = lane >> 4, l16 = lane & 15;
-  const int D = a.D, S = a.S;
+  const int D = a.D;
   float coef = 1.0f;
   if constexpr (MODE == AP_UPDATE || MODE == AP_GRADS) {
     if (tid == 0) {
@@ -367,62 +440,74 @@ __global__ __launch_bounds__(256) void k_apply_rows(ApplyArgs a) {
   const int blk = blockIdx.x;
   if (blk < a.nbI + a.nbU) {
     const bool is_item = blk < a.nbI;
-    const int row = is_item ? blk * 4 + wave : (blk - a.nbI) * 4 + wave;
+    const int row = (is_item ? blk : blk - a.nbI) * AP_ROWS_PB + wave * 4 + grp;
     const int nrows = is_item ? a.I : a.U;
-    if (row < nrows) {
-      double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-      double sacc = 0.0;  // item: bias gradient (lane 0 of each group); user: usert_emb[p = l16]
-      int n = 0;
-      if constexpr (MODE != AP_SUMSQ) {
-        int32_t* cntp = (is_item ? a.cnt_item : a.cnt_user) + row;
-        n = *cntp;
-        if (n > 0) {
-          const int32_t* list = (is_item ? a.list_item + a.off_item[row] : a.list_user + a.off_user[row]);
-          accum_list(list, n, grp, 4, a.G, D, 0, a.di / 4, l16, acc);
-          for (int k = grp; k < n; k += 4) {
-            const int c = list[k];
-            const int b = c / S;
-            if (is_item) {
-              if (l16 == 0 && (c - b * S) == a.Ls + a.Sn) sacc += exact_term(a.dlogit[b]);
-            } else if (l16 < a.Ls) {
-              sacc += exact_term(a.GT[(size_t)b * a.Ls + l16]);
-            }
-          }
-          combine_groups(acc);
-          sacc += __shfl_xor(sacc, 16);
-          sacc += __shfl_xor(sacc, 32);
-          if constexpr (MODE != AP_ROWNORM) {
-            if (lane == 0) *cntp = 0;  // counters are zero at rest
+    const bool vr = row < nrows;
+    double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    double sacc = 0.0;
+    int n = 0;
+    if constexpr (MODE != AP_SUMSQ) {
+      int32_t* cnt = is_item ? a.cnt_item : a.cnt_user;
+      const int32_t* lists = is_item ? a.list_item : a.list_user;
+      int off = 0;
+      if (vr) {
+        n = cnt[row];
+        off = (is_item ? a.off_item : a.off_user)[row];
+      }
+      const int n_own = min(n, AP_OWN);
+      accum_list(lists + off, 0, n_own, 1, a.G, D, 0, a.di / 4, l16, acc);
+      sacc = accum_side(a, is_item, lists + off, 0, n_own, 1, l16);
+      // long lists: the four groups of the wavefront split the rest of group g's list
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int ng = __shfl(n, g * 16);
+        if (ng > AP_OWN) {  // wave-uniform
+          const int og = __shfl(off, g * 16);
+          double t[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+          accum_list(lists + og, AP_OWN + grp, ng, 4, a.G, D, 0, a.di / 4, l16, t);
+          double ts = accum_side(a, is_item, lists + og, AP_OWN + grp, ng, 4, l16);
+          combine_groups(t);
+          ts += __shfl_xor(ts, 16);
+          ts += __shfl_xor(ts, 32);
+          if (grp == g) {
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc[ch][i] += t[ch][i];
+            sacc += ts;
           }
         }
       }
-      if (grp == 0) {
-        float* W = (is_item ? a.p.item_emb : a.p.user_emb) + (size_t)row * a.di;
-        float* Gr = nullptr;
-        if constexpr (MODE == AP_GRADS) Gr = (is_item ? a.go.item_emb : a.go.user_emb) + (size_t)row * a.di;
-        part += apply_row<MODE>(W, Gr, acc, a.di / 4, l16, a.reg, step);
-        // the narrow companions: item_b[row] (not regularised, model.py:164-169) / usert_emb[row]
-        if (is_item) {
-          if (l16 == 0) {
-            const float g = (float)sacc;
-            if constexpr (MODE == AP_GRADS) a.go.item_b[row] = g;
-            if constexpr (MODE == AP_ROWNORM) part += (double)g * (double)g;
-            if constexpr (MODE == AP_UPDATE) {
-              if (n > 0) a.p.item_b[row] -= step * g;
-            }
-          }
-        } else if (l16 < a.Ls) {
-          float* wp = a.p.usert_emb + (size_t)row * a.Ls + l16;
-          float w = *wp;
-          const float g = (float)sacc + a.reg * w;
-          if constexpr (MODE == AP_SUMSQ) part += (double)w * (double)w;
-          if constexpr (MODE == AP_GRADS) a.go.usert_emb[(size_t)row * a.Ls + l16] = g;
+      if constexpr (MODE != AP_ROWNORM) {
+        if (vr && n > 0 && l16 == 0) cnt[row] = 0;  // counters are zero at rest
+      }
+    }
+    if (vr) {
+      float* W = (is_item ? a.p.item_emb : a.p.user_emb) + (size_t)row * a.di;
+      float* Gr = nullptr;
+      if constexpr (MODE == AP_GRADS) Gr = (is_item ? a.go.item_emb : a.go.user_emb) + (size_t)row * a.di;
+      part += apply_row<MODE>(W, Gr, acc, a.di / 4, l16, a.reg, step);
+      // the narrow companions: item_b[row] (not regularised, model.py:164-169) / usert_emb[row]
+      if (is_item) {
+        if (l16 == 0) {
+          const float g = (float)sacc;
+          if constexpr (MODE == AP_GRADS) a.go.item_b[row] = g;
           if constexpr (MODE == AP_ROWNORM) part += (double)g * (double)g;
           if constexpr (MODE == AP_UPDATE) {
-            w -= step * g;
-            *wp = w;
-            part += (double)w * (double)w;
+            if (n > 0) a.p.item_b[row] -= step * g;
           }
+        }
+      } else if (l16 < a.Ls) {
+        float* wp = a.p.usert_emb + (size_t)row * a.Ls + l16;
+        float w = *wp;
+        const float g = (float)sacc + a.reg * w;
+        if constexpr (MODE == AP_SUMSQ) part += (double)w * (double)w;
+        if constexpr (MODE == AP_GRADS) a.go.usert_emb[(size_t)row * a.Ls + l16] = g;
+        if constexpr (MODE == AP_ROWNORM) part += (double)g * (double)g;
+        if constexpr (MODE == AP_UPDATE) {
+          w -= step * g;
+          *wp = w;
+          part += (double)w * (double)w;
         }
       }
     }
@@ -433,7 +518,7 @@ __global__ __launch_bounds__(256) void k_apply_rows(ApplyArgs a) {
     if constexpr (MODE != AP_SUMSQ) {
       n = a.cnt_cate[row];
       if (n > 0) {  // workgroup-uniform
-        accum_list(a.list_cate + a.off_cate[row], n, wave * 4 + grp, 16, a.G, D, a.di, a.dc / 4, l16, acc);
+        accum_list(a.list_cate + a.off_cate[row], wave * 4 + grp, n, 16, a.G, D, a.di, a.dc / 4, l16, acc);
         combine_groups(acc);
         if (grp == 0) {
 #pragma unroll
