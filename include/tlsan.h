@@ -168,6 +168,10 @@ int tlsan_eval_ranks(const tlsan_dims* dims, const tlsan_params* p, const float*
 int tlsan_profile_enable(int level);
 int tlsan_profile_collect(float* host_ms, int max_steps);
 
+/* Diagnostic: device buffer [blocks*8 waves][16] of s_memtime stamps written by the fused
+ * kernel at its phase boundaries (NULL = off, the default). */
+int tlsan_debug_stamps(void* device_buf);
+
 #ifdef __cplusplus
 }
 #endif

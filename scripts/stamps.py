@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase cycle shares of k_fwd_bwd from in-kernel s_memtime stamps."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tlsan_amd import _lib as L, synth
+from tlsan_amd.model import Model
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+cfg = synth.make_config("electronics")
+m = Model(cfg, synth.item_cate_list(cfg))
+lib = L.load()
+db = m.device_batch(synth.make_batches(cfg, 1, B, seed=7)[0])
+for _ in range(5):
+    m.train_async(db, 1.0)
+nblk = (B + 15) // 16
+st = torch.zeros(nblk * 8 * 16, dtype=torch.int64, device="cuda")
+lib.tlsan_debug_stamps(st.data_ptr())
+m.train_async(db, 1.0)
+torch.cuda.synchronize()
+lib.tlsan_debug_stamps(None)
+s = st.cpu().numpy().reshape(nblk, 8, 16)[:, :, :12].astype(np.float64)
+d = np.diff(s, axis=2)
+names = ["P1 gather+fwa1", "bar1", "P2 bridge", "bar2", "P3 fwd+logit", "P3 bwd", "bar3", "P4+reduce", "bar4", "P5 bwd long", "bar5+reduce"]
+tot = s[:, :, 11] - s[:, :, 0]
+print("ticks/wave (s_memtime, 100 MHz on gfx950?): mean %.0f max %.0f" % (tot.mean(), tot.max()))
+for i, n in enumerate(names):
+    print("%-16s mean %8.0f  p50 %8.0f  max %8.0f  (%.1f%%)" % (n, d[:, :, i].mean(), np.median(d[:, :, i]), d[:, :, i].max(), 100 * d[:, :, i].mean() / tot.mean()))
+f = st.cpu().numpy().reshape(nblk, 8, 16)[:, :, 12:16].astype(np.float64)
+fd = np.diff(f, axis=2)
+ok = (f[:, :, 0] > 0)
+for i, n in enumerate(["P5 pos1: maps+exp", "P5 pos1: bwd_compute", "P5 pos1: bwd_dw"]):
+    print("%-24s mean %8.0f p50 %8.0f max %8.0f" % (n, fd[:, :, i][ok].mean(), np.median(fd[:, :, i][ok]), fd[:, :, i][ok].max()))
+span = s[:, :, 11].max() - s[:, :, 0].min()
+print("kernel span (first start -> last end): %.0f ticks" % span)

@@ -16,7 +16,7 @@ EXPORTS = [
     "tlsan_abi_version", "tlsan_last_error", "tlsan_dense_layout_of", "tlsan_workspace_bytes",
     "tlsan_state_bytes", "tlsan_state_init", "tlsan_sync_derived", "tlsan_forward",
     "tlsan_train_step", "tlsan_grads", "tlsan_eval_ranks", "tlsan_profile_enable",
-    "tlsan_profile_collect",
+    "tlsan_profile_collect", "tlsan_debug_stamps",
 ]
 PROF_SEGMENTS = ("index_build", "fwd_bwd", "dk_partial", "dense_finalize", "apply_rows")
 
@@ -94,6 +94,8 @@ def load():
     lib.tlsan_profile_enable.restype = C.c_int
     lib.tlsan_profile_collect.argtypes = [C.c_void_p, C.c_int]
     lib.tlsan_profile_collect.restype = C.c_int
+    lib.tlsan_debug_stamps.argtypes = [C.c_void_p]
+    lib.tlsan_debug_stamps.restype = C.c_int
     for name in ("tlsan_dense_layout_of", "tlsan_state_init", "tlsan_sync_derived", "tlsan_forward",
                  "tlsan_train_step", "tlsan_grads", "tlsan_eval_ranks"):
         getattr(lib, name).restype = C.c_int

@@ -31,6 +31,7 @@ static int fail(int code, const char* fmt, ...) {
 // ---- profiling ring (tlsan_profile_*): events at the kernel boundaries of a train step ----
 #define PROF_MAX_STEPS 4096
 #define PROF_MARKS 6
+static unsigned long long* g_stamps = nullptr;
 static int g_prof_level = 0;
 static int g_prof_n = 0;
 static hipEvent_t* g_prof_ev = nullptr;  // [PROF_MAX_STEPS][PROF_MARKS], created on first enable
@@ -281,6 +282,7 @@ static void fill_fwd(FwdArgs& a, const tlsan_dims* d, const Shape& s, const tlsa
   a.S = d->Ls + b->Sn + 2;
   a.ngroups = (b->B + s.NSB - 1) / s.NSB;
   a.inv_B = 1.0f / (float)b->B;
+  a.stamps = g_stamps;
 }
 
 int tlsan_forward(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch* b, float* logits_i, float* logits_j,
@@ -476,6 +478,11 @@ int tlsan_eval_ranks(const tlsan_dims* d, const tlsan_params* p, const float* u_
   else if (s.D == 128) { hipLaunchKernelGGL(k_eval_label<128>, dim3(ut), dim3(64), 0, hs, e); hipLaunchKernelGGL(k_eval_rank<128>, dim3(ut, chunks), dim3(256), 0, hs, e); }
   else { hipLaunchKernelGGL(k_eval_label<256>, dim3(ut), dim3(64), 0, hs, e); hipLaunchKernelGGL(k_eval_rank<256>, dim3(ut, chunks), dim3(256), 0, hs, e); }
   CHECK_LAUNCH("k_eval");
+  return TLSAN_OK;
+}
+
+int tlsan_debug_stamps(void* device_buf) {
+  g_stamps = (unsigned long long*)device_buf;
   return TLSAN_OK;
 }
 

@@ -10,6 +10,13 @@
 //   P5  per wave   backward of block 1, per-use gradient rows, usert / gamma gradients
 // Per-use gradient rows are written once with plain 16-B stores into G[b*S + slot];
 // k_apply_rows sums them per destination row with exact (order-independent) arithmetic.
+//
+// The kernel is bound by the latency of ONE wavefront's dependent chain (4096 samples are
+// only 2 wavefronts per SIMD), so the code is organised to keep that chain short:
+// index/row loads are unconditional (clamped) and batched -- no per-lane branches around
+// loads; attention weights live in LDS; the dW products of position p are issued after the
+// map chain of position p+1 (double-buffered transpose scratch); cross-lane reductions are
+// batched after the loops.
 #pragma once
 #include "tlsan_common.h"
 
@@ -18,6 +25,7 @@
 // registers.  e[p] = raw rows, sc[p] = per-position scale.  Returns out = sum_p a[p] x[p]
 // plus the per-channel softmax statistics (mx = max score, Z = 1/sum exp) from which the
 // backward recomputes a[p] = exp(m2[p] - mx) * Z (exactly 0 on masked positions).
+// Positions are processed two per (wave-uniform) branch so their MFMA chains interleave.
 template <int NB, int NPOS>
 __device__ __forceinline__ void fwa_forward(const float (&FT1)[NB][NB][4], const f32x4 (&b1)[NB],
                                             const float (&FT2)[NB][NB][4], const f32x4 (&b2)[NB],
@@ -28,28 +36,33 @@ __device__ __forceinline__ void fwa_forward(const float (&FT1)[NB][NB][4], const
 #pragma unroll
   for (int kb = 0; kb < NB; ++kb) mx[kb] = (f32x4)(TLSAN_NEG);
 #pragma unroll
-  for (int p = 0; p < NPOS; ++p) {
-    if (p < pmax) {  // wave-uniform
-      f32x4 xv[NB], z[NB], m2[NB];
+  for (int p0 = 0; p0 < NPOS; p0 += 2) {
+    if (p0 < pmax) {  // wave-uniform
 #pragma unroll
-      for (int kb = 0; kb < NB; ++kb) xv[kb] = e[p][kb] * sc[p];
-      map_apply<NB>(FT1, b1, xv, z);  // model.py:380 (relu below)
+      for (int p = p0; p < p0 + 2 && p < NPOS; ++p) {
+        f32x4 xv[NB], z[NB], m2[NB];
 #pragma unroll
-      for (int kb = 0; kb < NB; ++kb)
+        for (int kb = 0; kb < NB; ++kb) xv[kb] = e[p][kb] * sc[p];
+        map_apply<NB>(FT1, b1, xv, z);  // model.py:380 (relu below)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) z[kb][i] = fmaxf(z[kb][i], 0.0f);
-      map_apply<NB>(FT2, b2, z, m2);  // model.py:382
-      const bool valid = p < n_valid;
+        for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
-      for (int kb = 0; kb < NB; ++kb) {
-        // model.py:384: m2 + (1-mask)*(-1e30) == -1e30 exactly in fp32
-        a[p][kb] = valid ? m2[kb] : (f32x4)(TLSAN_NEG);
+          for (int i = 0; i < 4; ++i) z[kb][i] = fmaxf(z[kb][i], 0.0f);
+        map_apply<NB>(FT2, b2, z, m2);  // model.py:382
+        const bool valid = p < n_valid;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) mx[kb][i] = fmaxf(mx[kb][i], a[p][kb][i]);
+        for (int kb = 0; kb < NB; ++kb) {
+          // model.py:384: m2 + (1-mask)*(-1e30) == -1e30 exactly in fp32
+          a[p][kb] = valid ? m2[kb] : (f32x4)(TLSAN_NEG);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) mx[kb][i] = fmaxf(mx[kb][i], a[p][kb][i]);
+        }
       }
     } else {
 #pragma unroll
-      for (int kb = 0; kb < NB; ++kb) a[p][kb] = (f32x4)(TLSAN_NEG);
+      for (int p = p0; p < p0 + 2 && p < NPOS; ++p)
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) a[p][kb] = (f32x4)(TLSAN_NEG);
     }
   }
 #pragma unroll
@@ -80,18 +93,17 @@ __device__ __forceinline__ void fwa_forward(const float (&FT1)[NB][NB][4], const
 }
 
 // ---------------------------------------------------------------------------------------
-// Backward of one position of feature_wise_attention.  Inputs in C-layout: x (scaled row),
-// z1 = x W1 + b1 (recomputed by the caller, bitwise equal to the forward), a (softmax
-// weight), outv (block output), dout (gradient of block output).
-// Produces dx (gradient w.r.t. x) and accumulates dW1, dW2 (MFMA over the tile's 16
-// (sample, head) columns, operands transposed through the wave's LDS scratch), db1, db2.
+// Backward of one position of feature_wise_attention, first half.  Inputs in C-layout:
+// x (scaled row), z1 = x W1 + b1 (recomputed by the caller, bitwise equal to the forward),
+// a (softmax weight), outv (block output), dout (gradient of block output).
+// Produces dx, accumulates db1 / db2, and writes the four 16x16 tiles (x, dz1, m1, dm2) of
+// this position transposed-ready into the LDS scratch `T` for bwd_dw.
 template <int NB, int TSTR>
-__device__ __forceinline__ void fwa_bwd_pos(const float (&FN2)[NB][NB][4],
+__device__ __forceinline__ void bwd_compute(const float (&FN2)[NB][NB][4],
                                             const float (&FN1)[NB][NB][4], const f32x4 (&xv)[NB],
                                             const f32x4 (&z1)[NB], const f32x4 (&av)[NB],
                                             const f32x4 (&outv)[NB], const f32x4 (&dout)[NB],
                                             float* __restrict__ T, int q, int r,
-                                            f32x4 (&dW1)[NB][NB], f32x4 (&dW2)[NB][NB],
                                             f32x4 (&db1)[NB], f32x4 (&db2)[NB], f32x4 (&dx)[NB]) {
   f32x4 m1[NB], dm2[NB], dm1[NB], dz1[NB], dxm[NB], zero[NB];
 #pragma unroll
@@ -113,7 +125,6 @@ __device__ __forceinline__ void fwa_bwd_pos(const float (&FN2)[NB][NB][4],
     db1[kb] += dz1[kb];
     db2[kb] += dm2[kb];
   }
-  // ---- dW1 += x^T dz1, dW2 += m1^T dm2 over the 16 columns of this tile ----
   // tiles in the scratch: [0,NB) x, [NB,2NB) dz1, [2NB,3NB) m1, [3NB,4NB) dm2; each [16][TSTR]
   const int wofs = r * TSTR + 4 * q;
 #pragma unroll
@@ -123,7 +134,16 @@ __device__ __forceinline__ void fwa_bwd_pos(const float (&FN2)[NB][NB][4],
     *(f32x4*)(T + (2 * NB + kb) * 16 * TSTR + wofs) = m1[kb];
     *(f32x4*)(T + (3 * NB + kb) * 16 * TSTR + wofs) = dm2[kb];
   }
-  wave_lds_fence();
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Second half: dW1 += x^T dz1, dW2 += m1^T dm2 over the 16 (sample, head) columns of the tile
+// staged in `T` (MFMA with the column index as the K dimension).  DS operations of a
+// wavefront execute in order, so reading what other lanes of the same wave wrote needs no
+// barrier, only program order.
+template <int NB, int TSTR>
+__device__ __forceinline__ void bwd_dw(const float* __restrict__ T, int q, int r,
+                                       f32x4 (&dW1)[NB][NB], f32x4 (&dW2)[NB][NB]) {
   float ax[NB][4], bz[NB][4], am[NB][4], bd[NB][4];
 #pragma unroll
   for (int kb = 0; kb < NB; ++kb)
@@ -144,7 +164,7 @@ __device__ __forceinline__ void fwa_bwd_pos(const float (&FN2)[NB][NB][4],
         dW1[kb][jb] = TLSAN_MFMA(ax[kb][s], bz[jb][s], dW1[kb][jb]);
         dW2[kb][jb] = TLSAN_MFMA(am[kb][s], bd[jb][s], dW2[kb][jb]);
       }
-  wave_lds_fence();
+  __builtin_amdgcn_wave_barrier();
 }
 
 // 16-B gather of channels [c, c+4) of the concatenated row [item_emb[it] || cate_emb[cat[it]]]
@@ -260,13 +280,18 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   using G = Geo<D, DH>;
   constexpr int NB = G::NB, CPS = G::CPS, SPW = G::SPW, NW = G::NW, NSB = G::NSB;
   constexpr int LS = TLSAN_LS_MAX, LSTR = G::LSTR, TSTR = G::TSTR, CW = G::CW;
+  constexpr int TB = G::TBUF;                 // floats of one transpose buffer
+  constexpr int NBUF = G::NBUF;               // 2: dW of position p overlaps position p+1
+  constexpr int WB = 2 * DH * DH + 2 * DH;    // floats of one attention block's weights
+  constexpr bool USE_SW = G::USE_SW;          // attention weights staged in LDS (when they fit)
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;                   // [NSB][LSTR]  long -> dbridge
   float* sB = sA + NSB * LSTR;        // [NSB][LSTR]  bridge -> dlong
   float* sS = sB + NSB * LSTR;        // [NW][4] scalar staging
   float* sH = sS + NW * 4;            // [NSB][2*LS] hist_t and usert*hist_t of the pass
-  float* sT = sH + NSB * 2 * LS;      // per-wave transpose scratch / accumulator staging
+  float* sW = sH + NSB * 2 * LS;      // [2][WB] attention weights (W1,b1,W2,b2) of both blocks
+  float* sT = sW + (USE_SW ? 2 * WB : 0);  // per-wave transpose scratch / accumulator staging
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int q = lane >> 4, r = lane & 15;
   const int s_loc = r / CPS, col = r % CPS;
@@ -280,83 +305,163 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   const float* dn = a.p.dense;
   const float gamma = dn[a.lay.gamma];
   const int Ls = a.Ls, Sn = a.b.Sn, B = a.b.B, S = a.S;
+  // attention weights -> LDS once per workgroup (both blocks are contiguous runs of `dense`)
+  if constexpr (USE_SW) {
+    for (int o = tid; o < 2 * WB; o += NW * 64)
+      sW[o] = (o < WB) ? dn[a.lay.f1_W1 + o] : dn[a.lay.f2_W1 + (o - WB)];
+    __syncthreads();
+  }
+  const float* wb1 = USE_SW ? sW : dn + a.lay.f1_W1;
+  const float* wb2 = USE_SW ? sW + WB : dn + a.lay.f2_W1;
+  const float *w1W1 = wb1, *w1b1 = wb1 + DH * DH, *w1W2 = w1b1 + DH, *w1b2 = w1W2 + DH * DH;
+  const float *w2W1 = wb2, *w2b1 = w2W1 + DH * DH, *w2W2 = w2b1 + DH, *w2b2 = w2W2 + DH * DH;
+
+#define TLSAN_STAMP(k)                                                                       \
+  do {                                                                                       \
+    if (a.stamps != nullptr && lane == 0)                                                    \
+      a.stamps[((size_t)blockIdx.x * NW + wave) * 16 + (k)] = __builtin_amdgcn_s_memtime();  \
+  } while (0)
 
   for (int g = blockIdx.x; g < a.ngroups; g += gridDim.x) {
+    TLSAN_STAMP(0);
     const int bidx = g * NSB + srow;
     const bool vs = bidx < B;
     const int bb = vs ? bidx : 0;
     const int uid = a.b.u[bb];
+    const int it_i = a.b.i[bb];
     int n_l = vs ? a.b.sl[bb] : 0;
     n_l = min(n_l, Ls);
+    int n_s = vs ? a.b.sl_new[bb] : 0;
+    n_s = min(n_s, Sn);
     float loss_acc = 0.0f, sq_acc = 0.0f, dgam = 0.0f;
     // ------------------------------------------------------------------ P1: long block
+    // All loads are unconditional on clamped (always valid) addresses so that they are issued
+    // back to back: three dependent round trips (ids -> categories -> rows) for all LS positions
+    // together; padding is applied afterwards by selects (padded slots contribute exactly 0).
     f32x4 e1[LS][NB], long4[NB], mx1[NB], iz1[NB];
     const int pmax1 = wave_max_i32(n_l);
     {
-    float sc1[LS];
+      float sc1[LS];
+      int its[LS];
 #pragma unroll
-    for (int p = 0; p < LS; ++p) {
-      const bool vp = p < n_l;
-      const int it = vp ? a.b.hist_i[(size_t)bb * Ls + p] : 0;
-      const float ht = vp ? a.b.hist_t[(size_t)bb * Ls + p] : 0.0f;
-      const float ut = vp ? a.p.usert_emb[(size_t)uid * Ls + p] : 0.0f;
-      sc1[p] = gamma * (ut * ht);  // model.py:100-102,109
-      if (TRAIN && lead) {
-        sH[srow * 2 * LS + p] = ht;
-        sH[srow * 2 * LS + LS + p] = ut * ht;
+      for (int p = 0; p < LS; ++p) {
+        const int pc = min(p, Ls - 1);
+        its[p] = a.b.hist_i[(size_t)bb * Ls + pc];
+        const float ht = a.b.hist_t[(size_t)bb * Ls + pc];
+        const float ut = a.p.usert_emb[(size_t)uid * Ls + pc];
+        const bool vp = p < n_l;
+        sc1[p] = vp ? gamma * (ut * ht) : 0.0f;  // model.py:100-102,109
+        if (TRAIN && lead) {
+          sH[srow * 2 * LS + p] = vp ? ht : 0.0f;
+          sH[srow * 2 * LS + LS + p] = vp ? ut * ht : 0.0f;
+        }
       }
 #pragma unroll
-      for (int kb = 0; kb < NB; ++kb)
-        e1[p][kb] = vp ? gather_item4(a, it, chb[kb]) : (f32x4)(0.0f);
-    }
-    {
+      for (int p = 0; p < LS; ++p) {
+        const int ct = a.p.item_cate[its[p]];
+        const bool vp = p < n_l;
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+          const f32x4 v = gather_item4c(a, its[p], ct, chb[kb]);
+          e1[p][kb] = vp ? v : (f32x4)(0.0f);
+        }
+      }
       float FT1[NB][NB][4], FT2[NB][NB][4];
       f32x4 b1[NB], b2[NB];
-      load_frag_T<DH, NB>(dn + a.lay.f1_W1, q, r, FT1);
-      load_frag_T<DH, NB>(dn + a.lay.f1_W2, q, r, FT2);
-      load_bias<DH, NB>(dn + a.lay.f1_b1, q, b1);
-      load_bias<DH, NB>(dn + a.lay.f1_b2, q, b2);
+      load_frag_T<DH, NB>(w1W1, q, r, FT1);
+      load_frag_T<DH, NB>(w1W2, q, r, FT2);
+      load_bias<DH, NB>(w1b1, q, b1);
+      load_bias<DH, NB>(w1b2, q, b2);
       fwa_forward<NB, LS>(FT1, b1, FT2, b2, e1, sc1, n_l, pmax1, mx1, iz1, long4);
-    }
     }
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
       *(f32x4*)(sA + srow * LSTR + chb[kb]) = long4[kb];
       if (TRAIN && vs) *(f32x4*)(a.gLong + (size_t)bidx * D + chb[kb]) = long4[kb];
     }
+    // rows the short block needs that depend only on ids: issue now, consume after P2
+    f32x4 uemb[NB], iemb[NB];
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+      const int c = chb[kb];
+      const float* up = (c < a.di) ? a.p.user_emb + (size_t)uid * a.di + c
+                                   : a.p.cate_emb + (size_t)a.b.u_cate[bb] * a.dc + (c - a.di);
+      uemb[kb] = *(const f32x4*)up;
+      iemb[kb] = gather_item4(a, it_i, c);
+    }
+    const float ib_i = a.p.item_b[it_i];
+    // B fragments of the bridge GEMM (K^T rows, L2-resident) do not depend on the barrier:
+    // fetch them first so their latency overlaps the wait for the slowest wavefront
+    f32x4 bfr[G::TPW][D / 16];
+#pragma unroll
+    for (int t = 0; t < G::TPW; ++t) {
+      const int ct = (wave * G::TPW + t) % G::NT;
+      const float* Brow = a.p.dense_KT + (size_t)(16 * ct + r) * D + 4 * q;
+#pragma unroll
+      for (int kc = 0; kc < D / 16; ++kc) bfr[t][kc] = *(const f32x4*)(Brow + 16 * kc);
+    }
+    TLSAN_STAMP(1);
     __syncthreads();
+    TLSAN_STAMP(2);
     // ------------------------------------------------------------------ P2: bridge GEMM
     // bridge[s][j] = sum_k long[s][k] K[k][j] + k0[j]   (tf.layers.dense, model.py:347)
 #pragma unroll
     for (int t = 0; t < G::TPW; ++t) {
       const int task = wave * G::TPW + t, rt = task / G::NT, ct = task % G::NT;
-      f32x4 acc = (f32x4)(dn[a.lay.k0 + 16 * ct + r]);
+      f32x4 acc0 = (f32x4)(dn[a.lay.k0 + 16 * ct + r]), acc1 = (f32x4)(0.0f);
       const float* Arow = sA + (16 * rt + r) * LSTR + 4 * q;
-      const float* Brow = a.p.dense_KT + (size_t)(16 * ct + r) * D + 4 * q;
-#pragma unroll 8
-      for (int kc = 0; kc < D / 16; ++kc) {
-        const f32x4 av = *(const f32x4*)(Arow + 16 * kc);
-        const f32x4 bv = *(const f32x4*)(Brow + 16 * kc);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc = TLSAN_MFMA(av[s], bv[s], acc);
+      for (int kc = 0; kc < D / 16; kc += 2) {
+        const f32x4 av0 = *(const f32x4*)(Arow + 16 * kc), av1 = *(const f32x4*)(Arow + 16 * kc + 16);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          acc0 = TLSAN_MFMA(av0[s], bfr[t][kc][s], acc0);
+          acc1 = TLSAN_MFMA(av1[s], bfr[t][kc + 1][s], acc1);
+        }
       }
+      acc0 += acc1;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) sB[(16 * rt + 4 * q + i) * LSTR + 16 * ct + r] = acc[i];
+      for (int i = 0; i < 4; ++i) sB[(16 * rt + 4 * q + i) * LSTR + 16 * ct + r] = acc0[i];
     }
+    TLSAN_STAMP(3);
     __syncthreads();
+    TLSAN_STAMP(4);
     // ------------------------------------------------------------------ P3: short block
     // positions: 0 = bridge, 1..n_s = session rows (model.py:350); streamed with an online
     // softmax so registers do not grow with the session length.
-    int n_s = vs ? a.b.sl_new[bb] : 0;
-    n_s = min(n_s, Sn);
     const int n_pos = n_s + 1;  // model.py:355: rep_length = sl_new + 1
     const int pmax2 = wave_max_i32(n_pos);
     float FT1[NB][NB][4], FT2[NB][NB][4];
     f32x4 b1[NB], b2[NB];
-    load_frag_T<DH, NB>(dn + a.lay.f2_W1, q, r, FT1);
-    load_frag_T<DH, NB>(dn + a.lay.f2_W2, q, r, FT2);
-    load_bias<DH, NB>(dn + a.lay.f2_b1, q, b1);
-    load_bias<DH, NB>(dn + a.lay.f2_b2, q, b2);
+    load_frag_T<DH, NB>(w2W1, q, r, FT1);
+    load_frag_T<DH, NB>(w2W2, q, r, FT2);
+    load_bias<DH, NB>(w2b1, q, b1);
+    load_bias<DH, NB>(w2b2, q, b2);
+    // session ids (and their categories) are fetched once, one per lane of the sample
+    // (lane k = q*CPS + col holds entry k of the current chunk of NL entries), then broadcast
+    // with a cross-lane read: no dependent index loads inside the position loops.
+    constexpr int NL = 4 * CPS;
+    const int kk = q * CPS + col;
+    int sid = 0, scat = 0;
+    auto load_chunk = [&](int base) {
+      const int t = min(base + kk, max(Sn - 1, 0));
+      sid = (Sn > 0) ? a.b.hist_i_new[(size_t)bb * Sn + t] : 0;
+      scat = a.p.item_cate[sid];
+    };
+    auto fetch_row = [&](int t, f32x4 (&xr)[NB]) {  // row of session entry t (chunk must be loaded)
+      const int k = t % NL;
+      const int src = (k / CPS) * 16 + s_loc * CPS + (k % CPS);
+      const int it = __shfl(sid, src), ct = __shfl(scat, src);
+      const bool vt = t < n_s;
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) {
+        const f32x4 v = gather_item4c(a, it, ct, chb[kb]);
+        xr[kb] = vt ? v : (f32x4)(0.0f);
+      }
+    };
+    load_chunk(0);
+    f32x4 xnext[NB];
+    if (pmax2 > 1) fetch_row(0, xnext);
     f32x4 mx[NB], Zs[NB], short4[NB];
     {
       f32x4 xv[NB], z[NB];
@@ -374,28 +479,6 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         short4[kb] = xv[kb];
       }
     }
-    // session ids (and their categories) are fetched once, one per lane of the sample
-    // (lane k = q*CPS + col holds entry k of the current chunk of NL entries), then broadcast
-    // with a cross-lane read: no dependent index loads inside the position loops.
-    constexpr int NL = 4 * CPS;
-    const int kk = q * CPS + col;
-    int sid = 0, scat = 0;
-    auto load_chunk = [&](int base) {
-      const bool v = base + kk < n_s;
-      sid = v ? a.b.hist_i_new[(size_t)bb * Sn + base + kk] : 0;
-      scat = a.p.item_cate[sid];
-    };
-    auto fetch_row = [&](int t, f32x4 (&xr)[NB]) {  // row of session entry t (chunk must be loaded)
-      const int k = t % NL;
-      const int src = (k / CPS) * 16 + s_loc * CPS + (k % CPS);
-      const int it = __shfl(sid, src), ct = __shfl(scat, src);
-      const bool vt = t < n_s;
-#pragma unroll
-      for (int kb = 0; kb < NB; ++kb) xr[kb] = vt ? gather_item4c(a, it, ct, chb[kb]) : (f32x4)(0.0f);
-    };
-    load_chunk(0);
-    f32x4 xnext[NB];
-    if (pmax2 > 1) fetch_row(0, xnext);
     for (int p = 1; p < pmax2; ++p) {  // wave-uniform trip count
       const bool vt = (p - 1) < n_s;
       f32x4 xv[NB], z[NB], m2[NB];
@@ -432,20 +515,15 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         short4[kb][i] *= Zs[kb][i];
       }
     // u_t = short + [user_emb[u] || cate_emb[u_cate]]   (model.py:93-95,135)
-    f32x4 ut4[NB], iemb[NB];
-    const int it_i = a.b.i[bb];
+    f32x4 ut4[NB];
     float part = 0.0f;
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
-      const int c = chb[kb];
-      const float* up = (c < a.di) ? a.p.user_emb + (size_t)uid * a.di + c
-                                   : a.p.cate_emb + (size_t)a.b.u_cate[bb] * a.dc + (c - a.di);
-      ut4[kb] = short4[kb] + *(const f32x4*)up;
-      iemb[kb] = gather_item4(a, it_i, c);
+      ut4[kb] = short4[kb] + uemb[kb];
       part += dot4(ut4[kb], iemb[kb]);
-      if (a.u_t != nullptr && vs) *(f32x4*)(a.u_t + (size_t)bidx * D + c) = ut4[kb];
+      if (a.u_t != nullptr && vs) *(f32x4*)(a.u_t + (size_t)bidx * D + chb[kb]) = ut4[kb];
     }
-    const float logit = sample_sum<CPS>(part) + a.p.item_b[it_i];  // model.py:137
+    const float logit = sample_sum<CPS>(part) + ib_i;  // model.py:137
     if (lead && vs && a.logits_i != nullptr) a.logits_i[bidx] = logit;
     if (a.b.j != nullptr && a.logits_j != nullptr) {  // second candidate (eval_auc's negative)
       const int it_j = a.b.j[bb];
@@ -455,12 +533,15 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       const float lj = sample_sum<CPS>(pj) + a.p.item_b[it_j];
       if (lead && vs) a.logits_j[bidx] = lj;
     }
+    TLSAN_STAMP(5);
     if constexpr (TRAIN) {
       float* prec = a.partials + (size_t)g * G::NPB;
       // BCE with logits, mean over the batch (model.py:171)
       const float yv = a.b.y[bb];
-      const float lb = fmaxf(logit, 0.0f) - logit * yv + log1pf(expf(-fabsf(logit)));
-      const float dl = vs ? (1.0f / (1.0f + expf(-logit)) - yv) * a.inv_B : 0.0f;
+      const float en = __expf(-fabsf(logit));
+      const float lb = fmaxf(logit, 0.0f) - logit * yv + __logf(1.0f + en);
+      const float sg = logit >= 0.0f ? 1.0f / (1.0f + en) : en / (1.0f + en);
+      const float dl = vs ? (sg - yv) * a.inv_B : 0.0f;
       if (lead && vs) {
         a.dlogit[bidx] = dl;
         loss_acc += lb;
@@ -482,8 +563,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       }
       {
         float FN1[NB][NB][4], FN2[NB][NB][4];
-        load_frag_N<DH, NB>(dn + a.lay.f2_W1, q, r, FN1);
-        load_frag_N<DH, NB>(dn + a.lay.f2_W2, q, r, FN2);
+        load_frag_N<DH, NB>(w2W1, q, r, FN1);
+        load_frag_N<DH, NB>(w2W2, q, r, FN2);
         AccSet<NB> acc;
         acc.zero();
         if (pmax2 - 1 > NL) load_chunk(0);  // (wave-uniform) the forward loop moved past chunk 0
@@ -510,8 +591,10 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
               av[kb][i] = vt ? __expf(m2[kb][i] - mx[kb][i]) * Zs[kb][i] : 0.0f;
-          fwa_bwd_pos<NB, TSTR>(FN2, FN1, xv, z1, av, short4, dout, T, q, r, acc.dW1, acc.dW2,
-                                acc.db1, acc.db2, dx);
+          float* Tp = T + (NBUF > 1 ? (p & 1) * TB : 0);
+          bwd_compute<NB, TSTR>(FN2, FN1, xv, z1, av, short4, dout, Tp, q, r, acc.db1, acc.db2, dx);
+          if (NBUF == 1) bwd_dw<NB, TSTR>(Tp, q, r, acc.dW1, acc.dW2);
+          else if (p > 0) bwd_dw<NB, TSTR>(T + ((p - 1) & 1) * TB, q, r, acc.dW1, acc.dW2);
           if (p == 0) {
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) {
@@ -530,53 +613,68 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             }
           }
         }
+        if (NBUF > 1) bwd_dw<NB, TSTR>(T + ((pmax2 - 1) & 1) * TB, q, r, acc.dW1, acc.dW2);
         stage_accs<NB, CPS, true>(acc, dk0, T, lane);
       }
+#pragma unroll
+      for (int t = 0; t < G::TPW; ++t) {  // B fragments of the dlong GEMM (K rows), before the barrier
+        const int kt = (wave * G::TPW + t) % G::NT;
+        const float* Brow = dn + a.lay.K + (size_t)(16 * kt + r) * D + 4 * q;
+#pragma unroll
+        for (int jc = 0; jc < D / 16; ++jc) bfr[t][jc] = *(const f32x4*)(Brow + 16 * jc);
+      }
+      TLSAN_STAMP(6);
       __syncthreads();
+      TLSAN_STAMP(7);
       reduce_staged<G, true>(sT, prec, G::P_F2W1, G::P_F2B1, G::P_F2W2, G::P_F2B2, tid);
       // ---------------------------------------------------------------- P4: dlong GEMM
       // dlong[s][k] = sum_j dbridge[s][j] K[k][j]
 #pragma unroll
       for (int t = 0; t < G::TPW; ++t) {
         const int task = wave * G::TPW + t, rt = task / G::NT, kt = task % G::NT;
-        f32x4 acc = (f32x4)(0.0f);
+        f32x4 acc0 = (f32x4)(0.0f), acc1 = (f32x4)(0.0f);
         const float* Arow = sA + (16 * rt + r) * LSTR + 4 * q;
-        const float* Brow = dn + a.lay.K + (size_t)(16 * kt + r) * D + 4 * q;
-#pragma unroll 8
-        for (int jc = 0; jc < D / 16; ++jc) {
-          const f32x4 av = *(const f32x4*)(Arow + 16 * jc);
-          const f32x4 bv = *(const f32x4*)(Brow + 16 * jc);
 #pragma unroll
-          for (int s = 0; s < 4; ++s) acc = TLSAN_MFMA(av[s], bv[s], acc);
+        for (int jc = 0; jc < D / 16; jc += 2) {
+          const f32x4 av0 = *(const f32x4*)(Arow + 16 * jc), av1 = *(const f32x4*)(Arow + 16 * jc + 16);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            acc0 = TLSAN_MFMA(av0[s], bfr[t][jc][s], acc0);
+            acc1 = TLSAN_MFMA(av1[s], bfr[t][jc + 1][s], acc1);
+          }
         }
+        acc0 += acc1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) sB[(16 * rt + 4 * q + i) * LSTR + 16 * kt + r] = acc[i];
+        for (int i = 0; i < 4; ++i) sB[(16 * rt + 4 * q + i) * LSTR + 16 * kt + r] = acc0[i];
       }
+      TLSAN_STAMP(8);
       __syncthreads();
+      TLSAN_STAMP(9);
       // ---------------------------------------------------------------- P5: long backward
       {
         f32x4 dlong[NB], dummy[NB];
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) dlong[kb] = *(const f32x4*)(sB + srow * LSTR + chb[kb]);
         float FN1[NB][NB][4], FN2[NB][NB][4];
-        load_frag_T<DH, NB>(dn + a.lay.f1_W1, q, r, FT1);
-        load_bias<DH, NB>(dn + a.lay.f1_b1, q, b1);
-        load_frag_T<DH, NB>(dn + a.lay.f1_W2, q, r, FT2);
-        load_bias<DH, NB>(dn + a.lay.f1_b2, q, b2);
-        load_frag_N<DH, NB>(dn + a.lay.f1_W1, q, r, FN1);
-        load_frag_N<DH, NB>(dn + a.lay.f1_W2, q, r, FN2);
+        load_frag_T<DH, NB>(w1W1, q, r, FT1);
+        load_bias<DH, NB>(w1b1, q, b1);
+        load_frag_T<DH, NB>(w1W2, q, r, FT2);
+        load_bias<DH, NB>(w1b2, q, b2);
+        load_frag_N<DH, NB>(w1W1, q, r, FN1);
+        load_frag_N<DH, NB>(w1W2, q, r, FN2);
         AccSet<NB> acc;
         acc.zero();
+        float dsp[LS];  // per-lane partials of d loss / d scale[p]; reduced after the loop
 #pragma unroll
         for (int p = 0; p < LS; ++p) {
+          dsp[p] = 0.0f;
           if (p < pmax1) {
             const bool vp = p < n_l;
-            const float ht = sH[srow * 2 * LS + p];
-            const float uth = sH[srow * 2 * LS + LS + p];
-            const float scp = gamma * uth;
+            const float scp = gamma * sH[srow * 2 * LS + LS + p];
             f32x4 xv[NB], z1[NB], zr[NB], m2[NB], av[NB], dx[NB];
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) xv[kb] = e1[p][kb] * scp;
+            if (p == 1) TLSAN_STAMP(12);
             map_apply<NB>(FT1, b1, xv, z1);
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb)
@@ -588,13 +686,16 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
               for (int i = 0; i < 4; ++i)
                 av[kb][i] = vp ? __expf(m2[kb][i] - mx1[kb][i]) * iz1[kb][i] : 0.0f;
-            fwa_bwd_pos<NB, TSTR>(FN2, FN1, xv, z1, av, long4, dlong, T, q, r, acc.dW1, acc.dW2,
-                                  acc.db1, acc.db2, dx);
-            float dsp = 0.0f;
+            if (p == 1) TLSAN_STAMP(13);
+            float* Tp = T + (NBUF > 1 ? (p & 1) * TB : 0);
+            bwd_compute<NB, TSTR>(FN2, FN1, xv, z1, av, long4, dlong, Tp, q, r, acc.db1, acc.db2, dx);
+            if (p == 1) TLSAN_STAMP(14);
+            if (NBUF == 1) bwd_dw<NB, TSTR>(Tp, q, r, acc.dW1, acc.dW2);
+            else if (p > 0) bwd_dw<NB, TSTR>(T + ((p - 1) & 1) * TB, q, r, acc.dW1, acc.dW2);
+            if (p == 1) TLSAN_STAMP(15);
 #pragma unroll
-            for (int kb = 0; kb < NB; ++kb) dsp += dot4(dx[kb], e1[p][kb]);
-            const float ds = sample_sum<CPS>(dsp);  // d loss / d scale[p]
-            if (vs && p < n_l) {
+            for (int kb = 0; kb < NB; ++kb) dsp[p] += dot4(dx[kb], e1[p][kb]);
+            if (vs && vp) {
               const size_t go = ((size_t)bidx * S + p) * D;
 #pragma unroll
               for (int kb = 0; kb < NB; ++kb) {
@@ -602,17 +703,21 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
                 *(f32x4*)(a.G + go + chb[kb]) = de;
                 sq_acc += dot4(de, de);
               }
-              if (lead) {
-                const float gt = ds * (gamma * ht);  // d / d usert_emb[u][p]
-                a.GT[(size_t)bidx * Ls + p] = gt;
-                sq_acc += gt * gt;
-                dgam += ds * uth;
-              }
             }
           }
         }
-        if (lead && vs) {  // padded slots: k_apply_rows sums all Ls entries of a use
-          for (int p = n_l; p < Ls; ++p) a.GT[(size_t)bidx * Ls + p] = 0.0f;
+        if (NBUF > 1 && pmax1 > 0) bwd_dw<NB, TSTR>(T + ((pmax1 - 1) & 1) * TB, q, r, acc.dW1, acc.dW2);
+        // usert_emb / gamma gradients: batched cross-lane reductions (independent chains)
+#pragma unroll
+        for (int p = 0; p < LS; ++p) {
+          const float ds = sample_sum<CPS>(dsp[p]);
+          if (lead && vs && p < Ls) {
+            const bool vp = p < n_l;
+            const float gt = vp ? ds * (gamma * sH[srow * 2 * LS + p]) : 0.0f;  // d / d usert_emb[u][p]
+            a.GT[(size_t)bidx * Ls + p] = gt;  // padded slots: 0 (k_apply_rows sums all Ls)
+            sq_acc += gt * gt;
+            dgam += vp ? ds * sH[srow * 2 * LS + LS + p] : 0.0f;
+          }
         }
         stage_accs<NB, CPS, false>(acc, dummy, T, lane);
       }
@@ -631,6 +736,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           sS[wave * 4 + 2] = s2;
         }
       }
+      TLSAN_STAMP(10);
       __syncthreads();
       reduce_staged<G, false>(sT, prec, G::P_F1W1, G::P_F1B1, G::P_F1W2, G::P_F1B2, tid);
       if (tid < 3) {
@@ -639,8 +745,10 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         for (int w = 0; w < NW; ++w) s += sS[w * 4 + tid];
         prec[G::P_GAMMA + tid] = s;
       }
+      TLSAN_STAMP(11);
     }
     // Next pass: sA is rewritten in P1 (last read in P4), sB in P2 (last read at the top of
-    // P5), sT/sS in P3/P5 (last read right above; P1->P2 barrier separates) -> no extra barrier.
+    // P5), sH rows are wave-private, sT/sS are rewritten in P3/P5 (last read right above; the
+    // P1->P2 barrier separates) -> no extra barrier.
   }
 }

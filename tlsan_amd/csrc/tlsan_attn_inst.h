@@ -6,7 +6,7 @@
 template <int D, int DH>
 static size_t fwd_smem_bytes() {
   using G = Geo<D, DH>;
-  return sizeof(float) * (2 * G::NSB * G::LSTR + G::NW * 4 + G::NSB * 2 * TLSAN_LS_MAX + G::NW * G::WSCR);
+  return sizeof(float) * (2 * G::NSB * G::LSTR + G::NW * 4 + G::NSB * 2 * TLSAN_LS_MAX + (G::USE_SW ? 2 * (2 * DH * DH + 2 * DH) : 0) + G::NW * G::WSCR);
 }
 
 template <int D, int DH>
@@ -14,11 +14,11 @@ static hipError_t launch_fwd_bwd_impl(bool train, const FwdArgs& a, int grid, hi
   const size_t smem = fwd_smem_bytes<D, DH>();
   if (train) {
     auto k = k_fwd_bwd<D, DH, true>;
-    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, st, a);
   } else {
     auto k = k_fwd_bwd<D, DH, false>;
-    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, st, a);
   }
   return hipGetLastError();

@@ -43,7 +43,10 @@ struct Geo {
   static constexpr int LSTR = D + 4;            // LDS row stride of [sample][channel] buffers
   static constexpr int TSTR = 20;               // LDS row stride of the 16x16 transpose tiles
   // per-wave LDS scratch (floats): 4*NB transpose tiles, or the staged gradient accumulators
-  static constexpr int WSCR_T = 4 * NB * 16 * TSTR;
+  static constexpr int TBUF = 4 * NB * 16 * TSTR;   // one buffer: x, dz1, m1, dm2 tiles
+  static constexpr int NBUF = NB == 1 ? 2 : 1;      // double-buffered when it fits the LDS
+  static constexpr bool USE_SW = NB == 1;           // attention weights in LDS when they fit
+  static constexpr int WSCR_T = NBUF * TBUF;
   static constexpr int WSCR_A = (2 * NB * NB + 3 * NB) * 256;
   static constexpr int WSCR = WSCR_T > WSCR_A ? WSCR_T : WSCR_A;
   // per-workgroup partial record (effective CWxCW layout), see k_dense_finalize
@@ -111,18 +114,23 @@ __device__ __forceinline__ void load_bias(const float* __restrict__ b, int q, f3
     for (int i = 0; i < 4; ++i) out[jb][i] = b[(16 * jb + 4 * q + i) % DH];
 }
 
-// out = bias + F (x) v  in C-layout (see header comment)
+// out = bias + F (x) v  in C-layout (see header comment).  Two accumulators per output block
+// (k-steps {0,1} and {2,3}) halve the dependent-MFMA chain: a lone wavefront stalls ~40 cycles
+// on every back-to-back dependent v_mfma_f32_16x16x4_f32.
 template <int NB>
 __device__ __forceinline__ void map_apply(const float (&F)[NB][NB][4], const f32x4 (&bias)[NB],
                                           const f32x4 (&v)[NB], f32x4 (&out)[NB]) {
 #pragma unroll
   for (int ob = 0; ob < NB; ++ob) {
-    f32x4 acc = bias[ob];
+    f32x4 acc0 = bias[ob], acc1 = (f32x4)(0.0f);
 #pragma unroll
-    for (int ib = 0; ib < NB; ++ib)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) acc = TLSAN_MFMA(F[ob][ib][s], v[ib][s], acc);
-    out[ob] = acc;
+    for (int ib = 0; ib < NB; ++ib) {
+      acc0 = TLSAN_MFMA(F[ob][ib][0], v[ib][0], acc0);
+      acc1 = TLSAN_MFMA(F[ob][ib][2], v[ib][2], acc1);
+      acc0 = TLSAN_MFMA(F[ob][ib][1], v[ib][1], acc0);
+      acc1 = TLSAN_MFMA(F[ob][ib][3], v[ib][3], acc1);
+    }
+    out[ob] = acc0 + acc1;
   }
 }
 
@@ -183,5 +191,6 @@ struct FwdArgs {
   float* dlogit;    // [B]      per-use item_b gradients
   float* gLong;     // [B, D]   long-term summaries (A operand of dK)
   float* gDB;       // [B, D]   d loss / d bridge     (B operand of dK)
-  float* partials;  // [gridDim.x, NPB]
+  float* partials;  // [ngroups, NPB]
+  unsigned long long* stamps;  // diagnostic only (NULL in production): [gridDim.x*8 waves][16]
 };
