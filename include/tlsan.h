@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TLSAN_ABI_VERSION 1
+#define TLSAN_ABI_VERSION 2
 
 enum {
   TLSAN_OK = 0,
@@ -60,6 +60,9 @@ typedef struct {
   float* dense;               /* [n_dense]   */
   float* dense_KT;            /* [d, d]      */
   const int32_t* item_cate;   /* [I] item -> category (model.py:85 graph constant) */
+  /* Row strides in floats; 0 = densely packed (d_item, 1, d_item, Ls).  Non-zero strides let
+   * the tables alias fused rows, e.g. [item_emb | item_b | pad] as exchanged between GPUs. */
+  int32_t ld_item, ld_itemb, ld_user, ld_usert;
 } tlsan_params;
 
 typedef struct {
@@ -102,6 +105,8 @@ typedef struct {
   float* loss;    /* [1]  mean BCE + reg * l2 (model.py:171-172), value BEFORE the update */
   float* gnorm;   /* [1]  global gradient norm used for clipping                           */
   float* logits;  /* [B]  model.py:137 (may be NULL)                                       */
+  float* sq_rows; /* [1]  sum of squares of every per-use embedding-gradient row (the sparse
+                     part of TF-1.8's global norm); may be NULL                              */
 } tlsan_step_out;
 
 int tlsan_abi_version(void);
@@ -156,6 +161,20 @@ int tlsan_grads(const tlsan_dims* dims, const tlsan_params* p, const tlsan_batch
  * The [B, I] score matrix is never materialised. */
 int tlsan_eval_ranks(const tlsan_dims* dims, const tlsan_params* p, const float* u_t,
                      const int32_t* labels, int32_t B, int32_t* ranks,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/* Deterministic scatter-apply on one row table (the owner-side half of the multi-GPU step, and
+ * the stand-alone form of the embedding update of model.py:198-205):
+ *   for every row r < nrows:  g = gscale * sum_{k: dest[k]==r} grows[k] (+ reg * W[r] on the
+ *   first reg_cols columns);   W[r] -= (*step_dev) * g
+ * Rows without contributions still decay (dense L2, as the reference).  The sum is exact
+ * (order independent) -> bitwise reproducible.  width % 4 == 0, width <= 192.
+ * sumsq_out (nullable, device double) receives sum over the first reg_cols columns of W_new^2.
+ * step_dev is a DEVICE float (lr * clip coefficient) so no host sync is needed. */
+size_t tlsan_rows_apply_workspace(int32_t nrows, int32_t n);
+int tlsan_rows_apply(float* W, int32_t ld, int32_t nrows, int32_t width, int32_t reg_cols,
+                     const float* grows, int32_t ldg, const int32_t* dest, int32_t n,
+                     float gscale, const float* step_dev, float reg, double* sumsq_out,
                      void* ws, size_t ws_bytes, void* stream);
 
 /* Profiling hooks (measurement only; no reference counterpart).  level 0 = off (default),

@@ -1,0 +1,131 @@
+"""GPU tests of the sharded multi-GPU step (tlsan_amd.dist.ShardedModel) against the oracle.
+Only one GPU is available to the tests, so world_size 2 runs as two processes that share
+cuda:0 and talk over gloo (host-staged all-to-all); the production path is RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import tlsan_oracle as orc
+from tests.helpers import make_config, random_batch, random_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _tuple(b):
+    return (b["u"], b["i"], b["y"], b["hist_i"], b["hist_i_new"], b["hist_t"], b["sl"], b["sl_new"], b["u_cate"])
+
+
+def _case(d=128):
+    cfg = make_config(U=61, I=83, C=9, d=d, regulation_rate=1e-3, max_gradient_norm=5.0)
+    p = {k: np.asarray(v, np.float32).astype(np.float64) for k, v in random_params(cfg, seed=17).items()}
+    _, cat = random_batch(cfg, B=4, Sn=2, seed=0)
+    return cfg, p, cat
+
+
+def _split_batches(cfg, world, steps, B):
+    out = []
+    for s in range(steps):
+        per = [random_batch(cfg, B=B, Sn=3, seed=1000 + 10 * s + r)[0] for r in range(world)]
+        out.append(per)
+    return out
+
+
+def _concat(per):
+    """the global batch all ranks train on together (pad session columns to a common width)"""
+    Sn = max(b["hist_i_new"].shape[1] for b in per)
+    out = {}
+    for k in per[0]:
+        if k == "hist_i_new":
+            out[k] = np.concatenate([np.pad(b[k], ((0, 0), (0, Sn - b[k].shape[1]))) for b in per], 0)
+        else:
+            out[k] = np.concatenate([b[k] for b in per], 0)
+    return out
+
+
+def _worker(rank, world, port, ret, d):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tlsan_amd.dist import ShardedModel
+        cfg, p, cat = _case(d)
+        m = ShardedModel(cfg, cat, device="cuda:0")
+        m.set_params({k: np.asarray(v, np.float32) for k, v in p.items()})
+        steps = _split_batches(cfg, world, 3, B=24)
+        losses = []
+        for per in steps:
+            losses.append(m.train(None, _tuple(per[rank]), 0.8))
+        got = m.gather_params()
+        auc = m.eval_auc(None, tuple(list(_tuple(steps[0][rank]))[:2] + [steps[0][rank]["i"][::-1].copy()] + list(_tuple(steps[0][rank]))[3:]))
+        if rank == 0:
+            q = dict(p)
+            ref = []
+            for per in steps:
+                l, q, info = orc.train_step(q, cat, _concat(per), 8, cfg["regulation_rate"], lr=0.8)
+                ref.append(l)
+            assert np.allclose(losses, ref, rtol=2e-4, atol=1e-5), (losses, ref)
+            for k in q:
+                g = np.asarray(got[k], np.float64).reshape(q[k].shape)
+                du, dr = g - p[k], q[k] - p[k]
+                assert np.abs(du - dr).max() < 5e-4 * (np.abs(dr).max() + 1e-9) + 5e-7, k
+        assert 0.0 <= auc <= 1.0
+        ret[rank] = "ok"
+    except Exception:
+        import traceback
+        ret[rank] = "FAIL: " + traceback.format_exc()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,d", [(1, 128), (2, 128), (2, 64)])
+def test_sharded_model_matches_oracle(world, d):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret, d), nprocs=world, join=True)
+    assert all(v == "ok" for v in dict(ret).values()) and len(ret) == world, dict(ret)
+
+
+def test_rows_apply_matches_numpy_and_is_deterministic():
+    import ctypes as C
+    from tlsan_amd import _lib as L
+    lib = L.load()
+    rng = np.random.RandomState(3)
+    nrows, width, ld, n = 300, 36, 40, 5000
+    W0 = rng.randn(nrows, ld).astype(np.float32)
+    G = rng.randn(n, width).astype(np.float32)
+    dest = np.minimum(rng.zipf(1.3, n) - 1, nrows - 1).astype(np.int32)   # skewed: long lists
+    step, reg, gscale, reg_cols = 0.37, 1e-2, 0.5, 32
+    outs = []
+    for rep in range(2):
+        W = torch.as_tensor(W0).cuda()
+        Gd, dd = torch.as_tensor(G).cuda(), torch.as_tensor(dest).cuda()
+        sd = torch.tensor([step], dtype=torch.float32, device="cuda")
+        ss = torch.zeros(1, dtype=torch.float64, device="cuda")
+        nb = lib.tlsan_rows_apply_workspace(nrows, n)
+        ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        L.check(lib.tlsan_rows_apply(W.data_ptr(), ld, nrows, width, reg_cols, Gd.data_ptr(), width, dd.data_ptr(), n,
+                                     gscale, sd.data_ptr(), reg, ss.data_ptr(), ws.data_ptr(), nb,
+                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)), "tlsan_rows_apply")
+        outs.append((W.cpu().numpy(), float(ss.item())))
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+    acc = np.zeros((nrows, width), np.float64)
+    np.add.at(acc, dest, G.astype(np.float64))
+    ref = W0.astype(np.float64).copy()
+    g = gscale * acc
+    g[:, :reg_cols] += reg * ref[:, :reg_cols]
+    ref[:, :width] -= step * g
+    assert np.abs(outs[0][0] - ref).max() < 2e-5
+    assert np.array_equal(outs[0][0][:, width:], W0[:, width:])           # padding columns untouched
+    assert abs(outs[0][1] - (ref[:, :reg_cols] ** 2).sum()) < 1e-3 * (ref[:, :reg_cols] ** 2).sum()

@@ -8,7 +8,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libtlsan_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 NORM_TF18, NORM_DEDUP = 0, 1
 L2_DENSE, L2_LAZY = 0, 1
 
@@ -16,7 +16,7 @@ EXPORTS = [
     "tlsan_abi_version", "tlsan_last_error", "tlsan_dense_layout_of", "tlsan_workspace_bytes",
     "tlsan_state_bytes", "tlsan_state_init", "tlsan_sync_derived", "tlsan_forward",
     "tlsan_train_step", "tlsan_grads", "tlsan_eval_ranks", "tlsan_profile_enable",
-    "tlsan_profile_collect", "tlsan_debug_stamps",
+    "tlsan_profile_collect", "tlsan_debug_stamps", "tlsan_rows_apply_workspace", "tlsan_rows_apply",
 ]
 PROF_SEGMENTS = ("index_build", "fwd_bwd", "dk_partial", "dense_finalize", "apply_rows")
 
@@ -28,7 +28,8 @@ class Dims(C.Structure):
 
 class Params(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
-                ("item_emb", "item_b", "user_emb", "usert_emb", "cate_emb", "dense", "dense_KT", "item_cate")]
+                ("item_emb", "item_b", "user_emb", "usert_emb", "cate_emb", "dense", "dense_KT", "item_cate")] + \
+               [(n, C.c_int32) for n in ("ld_item", "ld_itemb", "ld_user", "ld_usert")]
 
 
 class DenseLayout(C.Structure):
@@ -48,7 +49,7 @@ class HParams(C.Structure):
 
 
 class StepOut(C.Structure):
-    _fields_ = [("loss", C.c_void_p), ("gnorm", C.c_void_p), ("logits", C.c_void_p)]
+    _fields_ = [("loss", C.c_void_p), ("gnorm", C.c_void_p), ("logits", C.c_void_p), ("sq_rows", C.c_void_p)]
 
 
 class GradsOut(C.Structure):
@@ -94,6 +95,12 @@ def load():
     lib.tlsan_profile_enable.restype = C.c_int
     lib.tlsan_profile_collect.argtypes = [C.c_void_p, C.c_int]
     lib.tlsan_profile_collect.restype = C.c_int
+    lib.tlsan_rows_apply_workspace.argtypes = [C.c_int32, C.c_int32]
+    lib.tlsan_rows_apply_workspace.restype = C.c_size_t
+    lib.tlsan_rows_apply.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                     C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_float, C.c_void_p,
+                                     C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.tlsan_rows_apply.restype = C.c_int
     lib.tlsan_debug_stamps.argtypes = [C.c_void_p]
     lib.tlsan_debug_stamps.restype = C.c_int
     for name in ("tlsan_dense_layout_of", "tlsan_state_init", "tlsan_sync_derived", "tlsan_forward",

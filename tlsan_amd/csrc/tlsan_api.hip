@@ -9,6 +9,7 @@
 #include "tlsan_common.h"
 #include "tlsan_eval.h"
 #include "tlsan_update.h"
+#include "tlsan_rows.h"
 
 hipError_t tlsan_launch_fwd_bwd_d64(bool train, const FwdArgs& a, int grid, hipStream_t st);
 hipError_t tlsan_launch_fwd_bwd_d128(bool train, const FwdArgs& a, int grid, hipStream_t st);
@@ -196,6 +197,16 @@ static int check_params(const tlsan_params* p) {
   return TLSAN_OK;
 }
 
+// fill in the default (dense) row strides
+static tlsan_params norm_params(const tlsan_params* p, const tlsan_dims* d) {
+  tlsan_params q = *p;
+  if (q.ld_item == 0) q.ld_item = d->d_item;
+  if (q.ld_itemb == 0) q.ld_itemb = 1;
+  if (q.ld_user == 0) q.ld_user = d->d_item;
+  if (q.ld_usert == 0) q.ld_usert = d->Ls;
+  return q;
+}
+
 static int check_batch(const tlsan_dims* d, const tlsan_batch* b, bool train) {
   if (!b || b->B < 1 || b->Sn < 0) return fail(TLSAN_E_BADARG, "bad batch (B=%d, Sn=%d)", b ? b->B : -1, b ? b->Sn : -1);
   if (!b->u || !b->i || !b->hist_i || !b->hist_t || !b->sl || !b->sl_new || !b->u_cate || (b->Sn > 0 && !b->hist_i_new))
@@ -208,7 +219,7 @@ static int check_batch(const tlsan_dims* d, const tlsan_batch* b, bool train) {
 static void fill_apply(ApplyArgs& A, const tlsan_dims* d, const Shape& s, const tlsan_params* p, const tlsan_batch* b,
                        const tlsan_hparams* hp, const Ws& w, const St& st, const tlsan_dense_layout& L) {
   memset(&A, 0, sizeof(A));
-  A.p = *p;
+  A.p = norm_params(p, d);
   A.lay = L;
   A.I = d->item_count; A.U = d->user_count; A.C = d->cate_count; A.Ls = d->Ls; A.D = s.D;
   A.di = d->d_item; A.dc = d->d_cate;
@@ -275,7 +286,7 @@ static int launch_fwd(const Shape& s, bool train, const FwdArgs& a, hipStream_t 
 static void fill_fwd(FwdArgs& a, const tlsan_dims* d, const Shape& s, const tlsan_params* p, const tlsan_batch* b,
                      const Ws& w, const tlsan_dense_layout& L) {
   memset(&a, 0, sizeof(a));
-  a.p = *p;
+  a.p = norm_params(p, d);
   a.b = *b;
   a.lay = L;
   a.Ls = d->Ls; a.di = d->d_item; a.dc = d->d_cate;
@@ -405,6 +416,7 @@ int tlsan_train_step(const tlsan_dims* d, const tlsan_params* p, const tlsan_bat
   fill_apply(A, d, s, p, b, hp, w, st, L);
   A.out_loss = out ? out->loss : nullptr;
   A.out_gnorm = out ? out->gnorm : nullptr;
+  A.out_sq = out ? out->sq_rows : nullptr;
   const int nrow = st.nbI + st.nbU + st.nbC;
   if (hp->norm_mode == TLSAN_NORM_DEDUP) {
     ApplyArgs R = A;
@@ -437,6 +449,7 @@ int tlsan_grads(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch* b
   A.go = *g;
   A.out_loss = out ? out->loss : nullptr;
   A.out_gnorm = out ? out->gnorm : nullptr;
+  A.out_sq = out ? out->sq_rows : nullptr;
   const int nrow = st.nbI + st.nbU + st.nbC;
   if (hp->norm_mode == TLSAN_NORM_DEDUP) {
     ApplyArgs R = A;
@@ -465,7 +478,7 @@ int tlsan_eval_ranks(const tlsan_dims* d, const tlsan_params* p, const float* u_
   hipStream_t hs = (hipStream_t)stream;
   EvalArgs e;
   memset(&e, 0, sizeof(e));
-  e.p = *p; e.u_t = u_t; e.labels = labels; e.B = B; e.I = d->item_count; e.di = d->d_item; e.dc = d->d_cate;
+  e.p = norm_params(p, d); e.u_t = u_t; e.labels = labels; e.B = B; e.I = d->item_count; e.di = d->d_item; e.dc = d->d_cate;
   e.s_label = w.s_label; e.ranks = ranks;
   if (hipMemsetAsync(ranks, 0, sizeof(int32_t) * (size_t)B, hs) != hipSuccess) return fail(TLSAN_E_LAUNCH, "memset ranks");
   const int ut = (B + 15) / 16;
@@ -478,6 +491,64 @@ int tlsan_eval_ranks(const tlsan_dims* d, const tlsan_params* p, const float* u_
   else if (s.D == 128) { hipLaunchKernelGGL(k_eval_label<128>, dim3(ut), dim3(64), 0, hs, e); hipLaunchKernelGGL(k_eval_rank<128>, dim3(ut, chunks), dim3(256), 0, hs, e); }
   else { hipLaunchKernelGGL(k_eval_label<256>, dim3(ut), dim3(64), 0, hs, e); hipLaunchKernelGGL(k_eval_rank<256>, dim3(ut, chunks), dim3(256), 0, hs, e); }
   CHECK_LAUNCH("k_eval");
+  return TLSAN_OK;
+}
+
+struct RowsWs { int32_t *cnt, *off, *cur, *list; double* part; size_t bytes; int nblk; };
+static void carve_rows(int32_t nrows, int32_t n, char* base, RowsWs* w) {
+  size_t o = 0;
+  auto take = [&](size_t nb) { char* p = base ? base + o : nullptr; o += al(nb); return p; };
+  w->nblk = (nrows + AP_ROWS_PB - 1) / AP_ROWS_PB;
+  w->cnt = (int32_t*)take(4 * (size_t)nrows);
+  w->off = (int32_t*)take(4 * (size_t)nrows);
+  w->cur = (int32_t*)take(4 * (size_t)nrows);
+  w->list = (int32_t*)take(4 * (size_t)(n > 0 ? n : 1));
+  w->part = (double*)take(8 * (size_t)w->nblk);
+  w->bytes = o;
+}
+
+size_t tlsan_rows_apply_workspace(int32_t nrows, int32_t n) {
+  if (nrows < 1 || n < 0) return 0;
+  RowsWs w;
+  carve_rows(nrows, n, nullptr, &w);
+  return w.bytes;
+}
+
+int tlsan_rows_apply(float* W, int32_t ld, int32_t nrows, int32_t width, int32_t reg_cols, const float* grows,
+                     int32_t ldg, const int32_t* dest, int32_t n, float gscale, const float* step_dev, float reg,
+                     double* sumsq_out, void* ws, size_t ws_bytes, void* stream) {
+  if (!W || !step_dev || nrows < 1 || n < 0 || (n > 0 && (!grows || !dest)))
+    return fail(TLSAN_E_BADARG, "tlsan_rows_apply: bad pointer / size");
+  if (width < 4 || width % 4 || width > 16 * 4 * ROWS_NCH || ld < width || (n > 0 && ldg < width) || reg_cols < 0 || reg_cols > width)
+    return fail(TLSAN_E_UNSUPPORTED, "tlsan_rows_apply: width must be a multiple of 4 in 4..%d", 16 * 4 * ROWS_NCH);
+  if (ld % 4 || ldg % 4) return fail(TLSAN_E_UNSUPPORTED, "tlsan_rows_apply: row strides must be multiples of 4 floats");
+  if (!ws) return fail(TLSAN_E_WORKSPACE, "ws is NULL");
+  RowsWs w;
+  carve_rows(nrows, n, (char*)ws, &w);
+  if (w.bytes > ws_bytes) return fail(TLSAN_E_WORKSPACE, "workspace too small: need %zu have %zu", w.bytes, ws_bytes);
+  hipStream_t hs = (hipStream_t)stream;
+  if (hipMemsetAsync(w.cnt, 0, 4 * (size_t)nrows, hs) != hipSuccess) return fail(TLSAN_E_LAUNCH, "memset cnt");
+  GIdxArgs gi;
+  gi.dest = dest; gi.n = n; gi.nrows = nrows; gi.cnt = w.cnt; gi.cur = w.cur; gi.list = w.list;
+  if (n > 0) { hipLaunchKernelGGL(k_gidx<false>, dim3((n + 255) / 256), dim3(256), 0, hs, gi); CHECK_LAUNCH("k_gidx<count>"); }
+  ScanArgs sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.cnt[0] = w.cnt; sa.off[0] = w.off; sa.cur[0] = w.cur; sa.n[0] = nrows;
+  const int nscan = (nrows + 4095) / 4096;
+  sa.blk0[0] = 0; sa.blk0[1] = nscan; sa.blk0[2] = nscan;
+  hipLaunchKernelGGL(k_index_scan, dim3(nscan), dim3(1024), 0, hs, sa);
+  CHECK_LAUNCH("k_index_scan");
+  if (n > 0) { hipLaunchKernelGGL(k_gidx<true>, dim3((n + 255) / 256), dim3(256), 0, hs, gi); CHECK_LAUNCH("k_gidx<fill>"); }
+  RowsArgs ra;
+  ra.W = W; ra.ld = ld; ra.nrows = nrows; ra.width = width; ra.reg_cols = reg_cols; ra.G = grows; ra.ldg = ldg;
+  ra.cnt = w.cnt; ra.off = w.off; ra.list = w.list; ra.gscale = gscale; ra.step_dev = step_dev; ra.reg = reg;
+  ra.part_out = w.part;
+  hipLaunchKernelGGL(k_rows_apply, dim3(w.nblk), dim3(256), 0, hs, ra);
+  CHECK_LAUNCH("k_rows_apply");
+  if (sumsq_out) {
+    hipLaunchKernelGGL(k_reduce_double, dim3(1), dim3(256), 0, hs, w.part, w.nblk, sumsq_out);
+    CHECK_LAUNCH("k_reduce_double");
+  }
   return TLSAN_OK;
 }
 

@@ -171,13 +171,13 @@ __device__ __forceinline__ void bwd_dw(const float* __restrict__ T, int q, int r
 // (model.py:84-86,105-107,111-113)
 __device__ __forceinline__ f32x4 gather_item4(const FwdArgs& a, int it, int c) {
   const float* ptr = (c < a.di)
-                         ? a.p.item_emb + (size_t)it * a.di + c
+                         ? a.p.item_emb + (size_t)it * a.p.ld_item + c
                          : a.p.cate_emb + (size_t)a.p.item_cate[it] * a.dc + (c - a.di);
   return *(const f32x4*)ptr;
 }
 
 __device__ __forceinline__ f32x4 gather_item4c(const FwdArgs& a, int it, int ct, int c) {
-  const float* ptr = (c < a.di) ? a.p.item_emb + (size_t)it * a.di + c
+  const float* ptr = (c < a.di) ? a.p.item_emb + (size_t)it * a.p.ld_item + c
                                 : a.p.cate_emb + (size_t)ct * a.dc + (c - a.di);
   return *(const f32x4*)ptr;
 }
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         const int pc = min(p, Ls - 1);
         its[p] = a.b.hist_i[(size_t)bb * Ls + pc];
         const float ht = a.b.hist_t[(size_t)bb * Ls + pc];
-        const float ut = a.p.usert_emb[(size_t)uid * Ls + pc];
+        const float ut = a.p.usert_emb[(size_t)uid * a.p.ld_usert + pc];
         const bool vp = p < n_l;
         sc1[p] = vp ? gamma * (ut * ht) : 0.0f;  // model.py:100-102,109
         if (TRAIN && lead) {
@@ -384,12 +384,12 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
       const int c = chb[kb];
-      const float* up = (c < a.di) ? a.p.user_emb + (size_t)uid * a.di + c
+      const float* up = (c < a.di) ? a.p.user_emb + (size_t)uid * a.p.ld_user + c
                                    : a.p.cate_emb + (size_t)a.b.u_cate[bb] * a.dc + (c - a.di);
       uemb[kb] = *(const f32x4*)up;
       iemb[kb] = gather_item4(a, it_i, c);
     }
-    const float ib_i = a.p.item_b[it_i];
+    const float ib_i = a.p.item_b[(size_t)it_i * a.p.ld_itemb];
     // B fragments of the bridge GEMM (K^T rows, L2-resident) do not depend on the barrier:
     // fetch them first so their latency overlaps the wait for the slowest wavefront
     f32x4 bfr[G::TPW][D / 16];
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       float pj = 0.0f;
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb) pj += dot4(ut4[kb], gather_item4(a, it_j, chb[kb]));
-      const float lj = sample_sum<CPS>(pj) + a.p.item_b[it_j];
+      const float lj = sample_sum<CPS>(pj) + a.p.item_b[(size_t)it_j * a.p.ld_itemb];
       if (lead && vs) a.logits_j[bidx] = lj;
     }
     TLSAN_STAMP(5);

@@ -17,7 +17,7 @@ struct EvalArgs {
 };
 
 __device__ __forceinline__ f32x4 all_emb4(const EvalArgs& a, int it, int c) {
-  const float* ptr = (c < a.di) ? a.p.item_emb + (size_t)it * a.di + c
+  const float* ptr = (c < a.di) ? a.p.item_emb + (size_t)it * a.p.ld_item + c
                                 : a.p.cate_emb + (size_t)a.p.item_cate[it] * a.dc + (c - a.di);
   return *(const f32x4*)ptr;
 }
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(64) void k_eval_label(EvalArgs a) {
   const int u = u0 + r;
   const int item = (u < a.B) ? a.labels[u] : 0;
   const f32x4 acc = score_tile<D>(a, af, item, q);
-  const float bias = a.p.item_b[item];
+  const float bias = a.p.item_b[(size_t)item * a.p.ld_itemb];
   // diagonal: user (4q+i) == column r
   if (u < a.B && q == (r >> 2)) {
     float v = acc[0];
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_eval_rank(EvalArgs a) {
     const bool vn = n < a.I;
     const int item = vn ? n : a.I - 1;
     const f32x4 acc = score_tile<D>(a, af, item, q);
-    const float bias = a.p.item_b[item];
+    const float bias = a.p.item_b[(size_t)item * a.p.ld_itemb];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float s = acc[i] + bias;

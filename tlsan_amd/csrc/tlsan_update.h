@@ -305,7 +305,7 @@ struct ApplyArgs {
   const double* rownorm;   // dedup mode: sum over rows of |g_row|^2 (from the ROWNORM pass)
   float lr, reg, clip, inv_B;
   int32_t norm_mode;
-  float* out_loss; float* out_gnorm;
+  float* out_loss; float* out_gnorm; float* out_sq;
   int32_t nbI, nbU, nbC, nbD;
 };
 
@@ -430,6 +430,7 @@ __global__ __launch_bounds__(256) void k_apply_rows(ApplyArgs a) {
       if (blockIdx.x == 0) {
         if (a.out_gnorm) *a.out_gnorm = norm;
         if (a.out_loss) *a.out_loss = a.scal[0] * a.inv_B + a.reg * (float)(0.5 * St);
+        if (a.out_sq) *a.out_sq = a.scal[1];
       }
     }
     __syncthreads();
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(256) void k_apply_rows(ApplyArgs a) {
       }
     }
     if (vr) {
-      float* W = (is_item ? a.p.item_emb : a.p.user_emb) + (size_t)row * a.di;
+      float* W = is_item ? a.p.item_emb + (size_t)row * a.p.ld_item : a.p.user_emb + (size_t)row * a.p.ld_user;
       float* Gr = nullptr;
       if constexpr (MODE == AP_GRADS) Gr = (is_item ? a.go.item_emb : a.go.user_emb) + (size_t)row * a.di;
       part += apply_row<MODE>(W, Gr, acc, a.di / 4, l16, a.reg, step);
@@ -494,11 +495,11 @@ __global__ __launch_bounds__(256) void k_apply_rows(ApplyArgs a) {
           if constexpr (MODE == AP_GRADS) a.go.item_b[row] = g;
           if constexpr (MODE == AP_ROWNORM) part += (double)g * (double)g;
           if constexpr (MODE == AP_UPDATE) {
-            if (n > 0) a.p.item_b[row] -= step * g;
+            if (n > 0) a.p.item_b[(size_t)row * a.p.ld_itemb] -= step * g;
           }
         }
       } else if (l16 < a.Ls) {
-        float* wp = a.p.usert_emb + (size_t)row * a.Ls + l16;
+        float* wp = a.p.usert_emb + (size_t)row * a.p.ld_usert + l16;
         float w = *wp;
         const float g = (float)sacc + a.reg * w;
         if constexpr (MODE == AP_SUMSQ) part += (double)w * (double)w;

@@ -140,7 +140,7 @@ class Model(object):
         self.global_step = _Var(lambda: self._step)
         self.global_epoch_step = _Var(lambda: self._epoch)
         self.global_epoch_step_op = _Var(self._inc_epoch)
-        self._out = torch.zeros(2, dtype=torch.float32, device=self.device)  # loss, gnorm
+        self._out = torch.zeros(4, dtype=torch.float32, device=self.device)  # loss, gnorm, sq_rows
         self._hits_p = np.zeros(len(KS), np.int64)
         self._hits_r = np.zeros(len(KS), np.int64)
         self._n_p = 0
@@ -188,7 +188,7 @@ class Model(object):
         self.dense_KT = z(cfg["hidden_units"], cfg["hidden_units"])
         self.cparams = L.Params(self.item_emb.data_ptr(), self.item_b.data_ptr(), self.user_emb.data_ptr(),
                                 self.usert_emb.data_ptr(), self.cate_emb.data_ptr(), self.dense.data_ptr(),
-                                self.dense_KT.data_ptr(), self.item_cate.data_ptr())
+                                self.dense_KT.data_ptr(), self.item_cate.data_ptr(), 0, 0, 0, 0)
 
     def _dense_slices(self):
         lay, d = self.lay, self.config["hidden_units"]
@@ -269,7 +269,7 @@ class Model(object):
         """Enqueue one step (model.py:208-234) without reading the loss back."""
         db = self.device_batch(batch)
         ws = self._workspace(db.B, db.Sn)
-        out = L.StepOut(self._out.data_ptr(), self._out.data_ptr() + 4, None if logits is None else logits.data_ptr())
+        out = L.StepOut(self._out.data_ptr(), self._out.data_ptr() + 4, None if logits is None else logits.data_ptr(), None)
         hp = self.hparams(lr)
         L.check(self.lib.tlsan_train_step(C.byref(self.dims), C.byref(self.cparams), C.byref(db.c), C.byref(hp),
                                           C.byref(out), self.state.data_ptr(), ws.data_ptr(), ws.numel(),
@@ -296,7 +296,7 @@ class Model(object):
         logits = torch.zeros(db.B, dtype=torch.float32, device=self.device)
         go = L.GradsOut(g["item_emb"].data_ptr(), g["item_b"].data_ptr(), g["user_emb"].data_ptr(),
                         g["usert_emb"].data_ptr(), g["cate_emb"].data_ptr(), gd.data_ptr())
-        out = L.StepOut(self._out.data_ptr(), self._out.data_ptr() + 4, logits.data_ptr())
+        out = L.StepOut(self._out.data_ptr(), self._out.data_ptr() + 4, logits.data_ptr(), self._out.data_ptr() + 8)
         hp = self.hparams(lr)
         L.check(self.lib.tlsan_grads(C.byref(self.dims), C.byref(self.cparams), C.byref(db.c), C.byref(hp),
                                      C.byref(go), C.byref(out), self.state.data_ptr(), ws.data_ptr(), ws.numel(),
