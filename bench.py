@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--profile-level", type=int, default=1)
+    ap.add_argument("--force-sharded", action="store_true", help="run the sharded (multi-GPU) code path even at N=1")
     return ap.parse_args()
 
 
@@ -88,17 +89,19 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     dist = None
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
 
     cfg = synth.make_config(args.workload)
     B = args.batch or cfg["train_batch_size"]
     icl = synth.item_cate_list(cfg)
     # weak scaling: every rank trains its own batch of B sequences per step
     host_batches = synth.make_batches(cfg, args.n_batches, B, seed=1234 + 1000 * rank)
-    if world == 1:
+    if not sharded:
         model = Model(cfg, icl, device=dev)
         stepper = model
     else:
@@ -115,7 +118,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if dist is not None:
+        if dist is not None and world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -131,11 +134,11 @@ def main():
     nrec = lib.tlsan_profile_collect(buf, nprof)
     lib.tlsan_profile_enable(0)
     seg = np.frombuffer(buf, dtype=np.float32)[: nrec * 5].reshape(nrec, 5) if nrec > 0 else np.zeros((0, 5))
-    if dist is not None:
+    if dist is not None and world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    loss = float(model._out[0].item())
+    loss = float(model.last_loss.item()) if sharded else float(model._out[0].item())
     if not np.isfinite(loss):
         raise SystemExit("bench.py: non-finite loss %r" % loss)
 
@@ -171,7 +174,7 @@ def main():
                                    % (args.workload, cfg["user_count"], cfg["item_count"], cfg["cate_count"],
                                       cfg["hidden_units"], cfg["Ls"], B),
                        "global_batch": B * world, "parallelism": "1 process/GPU, tables %s"
-                       % ("replicated" if world == 1 else "row-sharded, RCCL all-to-all")},
+                       % ("on one GPU" if not sharded else "row-sharded (id %% N), RCCL all-to-all + one all-reduce")},
             "roofline": {"bound": "hbm", "kernel": "k_fwd_bwd", "achieved": None if achieved is None else round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),

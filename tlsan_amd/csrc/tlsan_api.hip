@@ -461,6 +461,8 @@ int tlsan_grads(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch* b
   }
   hipLaunchKernelGGL(k_apply_rows<AP_GRADS>, dim3(nrow + A.nbD), dim3(256), 0, hs, A);
   CHECK_LAUNCH("k_apply_rows<GRADS>");
+  prof_mark(5, hs);
+  if (g_prof_level > 0 && g_prof_n < PROF_MAX_STEPS) ++g_prof_n;
   return TLSAN_OK;
 }
 
