@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--profile-level", type=int, default=1)
+    ap.add_argument("--graph", type=int, default=1, help="replay hipGraph-captured steps (single-GPU path)")
+    ap.add_argument("--event-every", type=int, default=8,
+                    help="with --graph: every Nth timed step runs eagerly so HIP events can bracket k_fwd_bwd")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded (multi-GPU) code path even at N=1")
     return ap.parse_args()
 
@@ -112,9 +115,16 @@ def main():
     lr = 1.0
     lib = L.load()
 
-    def run(n, first):
+    use_graph = bool(args.graph) and not sharded
+    graphs = [model.capture_step(db, lr) for db in dbs] if use_graph else None
+
+    def run(n, first, timed=False):
         for s in range(n):
-            stepper.train_async(dbs[(first + s) % len(dbs)], lr)
+            k = (first + s) % len(dbs)
+            if use_graph and not (timed and args.profile_level > 0 and s % args.event_every == 0):
+                model.replay(graphs[k])
+            else:
+                stepper.train_async(dbs[k], lr)
 
     def fence():
         torch.cuda.synchronize()
@@ -126,7 +136,7 @@ def main():
     fence()
     lib.tlsan_profile_enable(args.profile_level)
     t0 = time.perf_counter()
-    run(args.steps, args.warmup)
+    run(args.steps, args.warmup, timed=True)
     fence()
     dt = time.perf_counter() - t0
     nprof = min(args.steps, 4096)
@@ -182,6 +192,8 @@ def main():
                          "algorithmic_bytes_per_launch": round(k_bytes), "kernel_ms": round(k_ms, 5),
                          "step_algorithmic_bytes": round(step_bytes),
                          "step_frac": round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
+            "launch": ("hipGraph replay (1 graph/step; every %dth step eager for the HIP-event kernel timing)" % args.event_every)
+                      if use_graph else "eager (7 kernel launches/step)",
             "final_loss": round(loss, 6),
         }
         if nrec and args.profile_level >= 2:

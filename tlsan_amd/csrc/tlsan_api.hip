@@ -49,6 +49,12 @@ static hipStream_t g_side = nullptr;
 static hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr;
 static int g_use_side = 1;
 static bool side_ready() {
+  static int env_checked = 0;
+  if (!env_checked) {
+    env_checked = 1;
+    const char* e = getenv("TLSAN_SIDE_STREAM");
+    if (e) g_use_side = atoi(e);
+  }
   if (!g_use_side) return false;
   if (g_side) return true;
   if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) { g_side = nullptr; return false; }

@@ -277,6 +277,26 @@ class Model(object):
         self._step += 1
         return db
 
+    def capture_step(self, batch, lr):
+        """Capture one training step on `batch` into a hipGraph (fork/join of the index-build
+        side stream included) and return the graph: `g.replay()` re-runs the step on the same
+        device buffers.  lr is baked in (re-capture when it changes, train.py:232-233)."""
+        db = self.device_batch(batch)
+        self._workspace(db.B, db.Sn)
+        self.train_async(db, lr)          # warm: lazy one-time initialisation happens outside capture
+        self._step -= 1
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.train_async(db, lr)
+        self._step -= 1
+        g._tlsan_batch = db               # keep the captured buffers alive
+        return g
+
+    def replay(self, g):
+        g.replay()
+        self._step += 1
+
     def train(self, sess, batch, lr, add_summary=False):
         self.train_async(batch, lr)
         loss = float(self._out[0].item())

@@ -1,0 +1,127 @@
+"""Driver: counterpart of the reference's ``TLSAN/train.py`` (flags :26-54, loop :121-249).
+
+    python -m tlsan_amd.train --dataset tests/golden/packed_clothing.npz [--flag=value ...]
+
+Same flag names and defaults as the reference (``tf.app.flags`` -> argparse), same flow:
+initial AUC / P@k / R@k, ``max_epochs`` epochs of shuffled batches, evaluation every
+``eval_freq`` steps, learning rate 1.0 -> 0.1 at step 150000, save when the test AUC improves
+(> 0.8).  ``--dataset`` takes either a ``dataset.pkl`` written by the reference's
+``build_dataset.py`` (train.py:131-135) or a ``packed_<name>.npz`` export (tests/golden/).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import pickle
+import time
+
+import numpy as np
+
+from .input import DataInput, DataInputTest, PackedSet, load_packed
+from .model import KS, Model
+
+FLAGS = [  # (name, type, default)  -- train.py:26-54
+    ("hidden_units", int, 64), ("num_blocks", int, 1), ("num_heads", int, 8), ("Ls", int, 10),
+    ("dropout", float, 0.0), ("regulation_rate", float, 0.00005),
+    ("itemid_embedding_size", int, 32), ("userid_embedding_size", int, 32), ("cateid_embedding_size", int, 32),
+    ("model_dir", str, "save_path"), ("optimizer", str, "sgd"), ("learning_rate", float, 1.0),
+    ("max_gradient_norm", float, 5.0), ("train_batch_size", int, 32), ("test_batch_size", int, 128),
+    ("max_epochs", int, 20), ("display_freq", int, 100), ("eval_freq", int, 1000),
+]
+
+
+def parse(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    for name, typ, default in FLAGS:
+        ap.add_argument("--" + name, type=typ, default=default)
+    ap.add_argument("--from_scratch", type=lambda s: s.lower() != "false", default=True)
+    ap.add_argument("--dataset", required=True)
+    ap.add_argument("--device", default="cuda:0")
+    ap.add_argument("--max_steps", type=int, default=0, help="stop early (0 = run max_epochs)")
+    ap.add_argument("--norm_mode", default="tf18", choices=["tf18", "dedup"])
+    ap.add_argument("--quiet", action="store_true")
+    return ap.parse_args(argv)
+
+
+def load_dataset(path):
+    if path.endswith(".npz"):
+        return load_packed(path)
+    with open(path, "rb") as f:  # train.py:131-135
+        train_set = pickle.load(f)
+        test_set = pickle.load(f)
+        counts = pickle.load(f)
+        icl = pickle.load(f)
+    return PackedSet.from_samples(train_set), PackedSet.from_samples(test_set), tuple(counts), np.asarray(icl, np.int32)
+
+
+def eval_auc(model, test_set, config):
+    """train.py:86-96: batch AUCs weighted by batch length."""
+    s = 0.0
+    for _, batch in DataInputTest(test_set, config["test_batch_size"], config["Ls"]):
+        s += model.eval_auc(None, batch) * len(batch[0])
+    return s / len(test_set)
+
+
+def eval_prec_recall(model, test_set, config):
+    """train.py:98-118 (cumulative counters, as the reference)."""
+    for _, batch in DataInputTest(test_set, config["test_batch_size"], config["Ls"]):
+        model.eval_prec(None, batch)
+        model.eval_recall(None, batch)
+    return ([getattr(model, "prec_%d" % k).eval() for k in KS], [getattr(model, "recall_%d" % k).eval() for k in KS])
+
+
+def train(args):
+    say = (lambda *a, **k: None) if args.quiet else print
+    train_set, test_set, (U, I, Cc), icl = load_dataset(args.dataset)
+    config = {name: getattr(args, name) for name, _, _ in FLAGS}
+    config.update(user_count=U, item_count=I, cate_count=Cc, from_scratch=args.from_scratch)
+    say(json.dumps(config, indent=4), flush=True)
+    model = Model(config, icl, device=args.device, norm_mode=args.norm_mode)
+    t0 = time.time()
+    init_auc = eval_auc(model, test_set, config)
+    say("Init AUC: %.4f" % init_auc)
+    lr = args.learning_rate
+    rng = np.random.RandomState(1234)  # train.py:15-16 seeds; the shuffle stream itself differs from CPython's
+    best_auc, avg_loss, history = 0.0, 0.0, []
+    done = False
+    for _ in range(args.max_epochs):
+        train_set.shuffle(rng)  # train.py:191
+        for _, batch in DataInput(train_set, args.train_batch_size, config["Ls"]):
+            add_summary = model.global_step.eval() % args.display_freq == 0
+            avg_loss += model.train(None, batch, lr, add_summary)
+            step = model.global_step.eval()
+            if step % args.eval_freq == 0:
+                auc = eval_auc(model, test_set, config)
+                history.append((step, time.time() - t0, auc))
+                say("Epoch %d Global_step %d\tTrain_loss: %.4f\tEval_auc: %.4f" %
+                    (model.global_epoch_step.eval(), step, avg_loss / args.eval_freq, auc), flush=True)
+                avg_loss = 0.0
+                if auc > 0.8 and auc > best_auc:  # train.py:228-230
+                    best_auc = auc
+                    model.save(None)
+                best_auc = max(best_auc, auc)
+            if step == 150000:  # train.py:232-233
+                lr = 0.1
+            if args.max_steps and step >= args.max_steps:
+                done = True
+                break
+        model.global_epoch_step_op.eval()
+        if done:
+            break
+    prec, recall = eval_prec_recall(model, test_set, config)
+    final_auc = eval_auc(model, test_set, config)
+    best_auc = max(best_auc, final_auc)
+    say("Best test_auc:", best_auc)
+    say("P@k:", " ".join("@%d=%.4f" % (k, p) for k, p in zip(KS, prec)))
+    say("R@k:", " ".join("@%d=%.4f" % (k, r) for k, r in zip(KS, recall)))
+    return dict(init_auc=init_auc, best_auc=best_auc, final_auc=final_auc, steps=model.global_step.eval(),
+                seconds=time.time() - t0, history=history, prec=prec, recall=recall)
+
+
+def main(argv=None):
+    res = train(parse(argv))
+    print(json.dumps({k: v for k, v in res.items() if k != "history"}))
+
+
+if __name__ == "__main__":
+    main()
