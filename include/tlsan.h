@@ -125,6 +125,10 @@ size_t tlsan_state_bytes(const tlsan_dims* dims);
  * after creating / restoring / externally modifying parameters. */
 int tlsan_state_init(const tlsan_dims* dims, const tlsan_params* p, void* state, void* stream);
 
+/* Clear the use counters and rebuild the static category->items index for p->item_cate without
+ * touching the sums of squares (used by callers whose item table changes every step). */
+int tlsan_state_reindex(const tlsan_dims* dims, const tlsan_params* p, void* state, void* stream);
+
 /* Refresh derived copies (dense_KT) after the caller wrote p->dense. */
 int tlsan_sync_derived(const tlsan_dims* dims, const tlsan_params* p, void* stream);
 

@@ -14,7 +14,7 @@ L2_DENSE, L2_LAZY = 0, 1
 
 EXPORTS = [
     "tlsan_abi_version", "tlsan_last_error", "tlsan_dense_layout_of", "tlsan_workspace_bytes",
-    "tlsan_state_bytes", "tlsan_state_init", "tlsan_sync_derived", "tlsan_forward",
+    "tlsan_state_bytes", "tlsan_state_init", "tlsan_state_reindex", "tlsan_sync_derived", "tlsan_forward",
     "tlsan_train_step", "tlsan_grads", "tlsan_eval_ranks", "tlsan_profile_enable",
     "tlsan_profile_collect", "tlsan_debug_stamps", "tlsan_rows_apply_workspace", "tlsan_rows_apply",
 ]
@@ -83,6 +83,8 @@ def load():
     lib.tlsan_state_bytes.restype = C.c_size_t
     lib.tlsan_state_init.argtypes = [P(Dims), P(Params), C.c_void_p, C.c_void_p]
     lib.tlsan_sync_derived.argtypes = [P(Dims), P(Params), C.c_void_p]
+    lib.tlsan_state_reindex.argtypes = [P(Dims), P(Params), C.c_void_p, C.c_void_p]
+    lib.tlsan_state_reindex.restype = C.c_int
     lib.tlsan_forward.argtypes = [P(Dims), P(Params), P(Batch), C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_size_t, C.c_void_p]
     lib.tlsan_train_step.argtypes = [P(Dims), P(Params), P(Batch), P(HParams), P(StepOut),

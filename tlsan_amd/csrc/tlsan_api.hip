@@ -42,27 +42,6 @@ static void prof_mark(int mark, hipStream_t hs) {
   (void)hipEventRecord(g_prof_ev[g_prof_n * PROF_MARKS + mark], hs);
 }
 
-// ---- side stream: the inverted index only depends on the batch, so it is built concurrently
-// with the fused forward/backward kernel and joined before k_apply_rows (fork/join with events:
-// also valid under hipGraph stream capture)
-static hipStream_t g_side = nullptr;
-static hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr;
-static int g_use_side = 1;
-static bool side_ready() {
-  static int env_checked = 0;
-  if (!env_checked) {
-    env_checked = 1;
-    const char* e = getenv("TLSAN_SIDE_STREAM");
-    if (e) g_use_side = atoi(e);
-  }
-  if (!g_use_side) return false;
-  if (g_side) return true;
-  if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) { g_side = nullptr; return false; }
-  if (hipEventCreateWithFlags(&g_ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&g_ev_join, hipEventDisableTiming) != hipSuccess) { g_side = nullptr; return false; }
-  return true;
-}
-
 static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Shape {  // derived geometry of the supported (d, heads) combinations
@@ -88,29 +67,33 @@ static int shape_of(const tlsan_dims* d, Shape* s) {
 }
 
 struct Ws {  // carve-up of the caller's scratch buffer
-  float *G, *GT, *dlogit, *gLong, *gDB, *partials, *Kp, *gd, *sqd, *scal, *logits, *s_label;
-  int32_t *off_item, *off_cate, *off_user, *cur_item, *cur_cate, *cur_user;
-  int32_t *list_item, *list_cate, *list_user;
+  float *Gi, *Gb, *Gu, *Gc, *Pc, *gLong, *gDB, *partials, *Kp, *gd, *sqd, *scal, *logits, *s_label;
+  int32_t *off_item, *off_uc, *off_user, *cur_item, *cur_uc, *cur_user;
   double* rownorm_part;
   double* rownorm;
   size_t bytes;
-  int ngroups, nsplit, nfin, nbK, nbS;
+  int ngroups, nsplit, nfin, nbK, nbS, WU;
 };
+
+static int ru4(int x) { return (x + 3) / 4 * 4; }
 
 static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base, Ws* w) {
   size_t o = 0;
   auto take = [&](size_t n) { char* p = base ? base + o : nullptr; o += al(n); return p; };
-  const size_t S = (size_t)d->Ls + Sn + 2, D = s.D;
+  const size_t NI = (size_t)B * (d->Ls + Sn + 1), D = s.D;
   tlsan_dense_layout L;
   tlsan_dense_layout_of(d, &L);
+  w->WU = ru4(d->d_item + d->Ls);
   w->ngroups = (B + s.NSB - 1) / s.NSB;
   w->nsplit = (B + DK_CHUNK - 1) / DK_CHUNK;
   w->nbK = (s.D * s.D + 255) / 256;
   w->nbS = (L.n_dense - s.D * s.D + 15) / 16;
   w->nfin = w->nbK + w->nbS;
-  w->G = (float*)take(sizeof(float) * B * S * D);
-  w->GT = (float*)take(sizeof(float) * B * d->Ls);
-  w->dlogit = (float*)take(sizeof(float) * B);
+  w->Gi = (float*)take(sizeof(float) * NI * D);
+  w->Gb = (float*)take(sizeof(float) * NI);
+  w->Gu = (float*)take(sizeof(float) * (size_t)B * w->WU);
+  w->Gc = (float*)take(sizeof(float) * (size_t)B * d->d_cate);
+  w->Pc = (float*)take(sizeof(float) * (size_t)d->item_count * d->d_cate);
   w->gLong = (float*)take(sizeof(float) * B * D);
   w->gDB = (float*)take(sizeof(float) * B * D);
   w->partials = (float*)take(sizeof(float) * w->ngroups * s.NPB);
@@ -121,14 +104,11 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
   w->logits = (float*)take(sizeof(float) * B);
   w->s_label = (float*)take(sizeof(float) * B);
   w->off_item = (int32_t*)take(4 * (size_t)d->item_count);
-  w->off_cate = (int32_t*)take(4 * (size_t)d->cate_count);
+  w->off_uc = (int32_t*)take(4 * (size_t)d->cate_count);
   w->off_user = (int32_t*)take(4 * (size_t)d->user_count);
   w->cur_item = (int32_t*)take(4 * (size_t)d->item_count);
-  w->cur_cate = (int32_t*)take(4 * (size_t)d->cate_count);
+  w->cur_uc = (int32_t*)take(4 * (size_t)d->cate_count);
   w->cur_user = (int32_t*)take(4 * (size_t)d->user_count);
-  w->list_item = (int32_t*)take(4 * (size_t)B * S);
-  w->list_cate = (int32_t*)take(4 * (size_t)B * S);
-  w->list_user = (int32_t*)take(4 * (size_t)B);
   const size_t nrowblk = (size_t)(d->item_count + 15) / 16 + (d->user_count + 15) / 16 + d->cate_count;
   w->rownorm_part = (double*)take(8 * nrowblk);
   w->rownorm = (double*)take(8);
@@ -136,7 +116,8 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
 }
 
 struct St {  // persistent state
-  int32_t *cnt_item, *cnt_cate, *cnt_user;
+  int32_t *cnt_item, *cnt_uc, *cnt_user;                  // use counters, zero at rest
+  int32_t *cate_off, *cate_cnt, *cate_cur, *cate_items;   // static CSR category -> items
   double *S_part, *S_total;
   size_t bytes;
   int nbI, nbU, nbC;
@@ -149,8 +130,12 @@ static void carve_state(const tlsan_dims* d, char* base, St* s) {
   s->nbU = (d->user_count + AP_ROWS_PB - 1) / AP_ROWS_PB;
   s->nbC = d->cate_count;
   s->cnt_item = (int32_t*)take(4 * (size_t)d->item_count);
-  s->cnt_cate = (int32_t*)take(4 * (size_t)d->cate_count);
+  s->cnt_uc = (int32_t*)take(4 * (size_t)d->cate_count);
   s->cnt_user = (int32_t*)take(4 * (size_t)d->user_count);
+  s->cate_off = (int32_t*)take(4 * (size_t)d->cate_count);
+  s->cate_cnt = (int32_t*)take(4 * (size_t)d->cate_count);
+  s->cate_cur = (int32_t*)take(4 * (size_t)d->cate_count);
+  s->cate_items = (int32_t*)take(4 * (size_t)d->item_count);
   s->S_part = (double*)take(8 * (size_t)(s->nbI + s->nbU + s->nbC));
   s->S_total = (double*)take(8);
   s->bytes = o;
@@ -219,6 +204,7 @@ static int check_batch(const tlsan_dims* d, const tlsan_batch* b, bool train) {
     return fail(TLSAN_E_BADARG, "NULL batch pointer");
   if (train && !b->y) return fail(TLSAN_E_BADARG, "training needs labels y");
   if ((size_t)b->B * (d->Ls + b->Sn + 2) >= ((size_t)1 << 31)) return fail(TLSAN_E_UNSUPPORTED, "B*S overflows int32");
+  if (train && b->Sn > TLSAN_SN_CAP) return fail(TLSAN_E_UNSUPPORTED, "training supports sessions up to %d items (got Sn=%d)", TLSAN_SN_CAP, b->Sn);
   return TLSAN_OK;
 }
 
@@ -228,18 +214,61 @@ static void fill_apply(ApplyArgs& A, const tlsan_dims* d, const Shape& s, const 
   A.p = norm_params(p, d);
   A.lay = L;
   A.I = d->item_count; A.U = d->user_count; A.C = d->cate_count; A.Ls = d->Ls; A.D = s.D;
-  A.di = d->d_item; A.dc = d->d_cate;
-  A.Sn = b ? b->Sn : 0;
-  A.S = d->Ls + A.Sn + 2;
-  A.G = w.G; A.GT = w.GT; A.dlogit = w.dlogit;
-  A.cnt_item = st.cnt_item; A.cnt_cate = st.cnt_cate; A.cnt_user = st.cnt_user;
-  A.off_item = w.off_item; A.off_cate = w.off_cate; A.off_user = w.off_user;
-  A.list_item = w.list_item; A.list_cate = w.list_cate; A.list_user = w.list_user;
+  A.di = d->d_item; A.dc = d->d_cate; A.WU = ru4(d->d_item + d->Ls);
+  A.Gi = w.Gi; A.Gb = w.Gb; A.Gu = w.Gu; A.Gc = w.Gc; A.Pc = w.Pc;
+  A.cnt_item = st.cnt_item; A.cnt_uc = st.cnt_uc; A.cnt_user = st.cnt_user;
+  A.off_item = w.off_item; A.off_uc = w.off_uc; A.off_user = w.off_user;
+  A.cate_off = st.cate_off; A.cate_cnt = st.cate_cnt; A.cate_items = st.cate_items;
   A.gd = w.gd; A.sqd = w.sqd; A.nsqd = w.nfin; A.scal = w.scal;
   A.part_out = st.S_part; A.S_total = st.S_total; A.rownorm = w.rownorm;
   if (hp) { A.lr = hp->lr; A.reg = hp->reg; A.clip = hp->clip; A.norm_mode = hp->norm_mode; }
   A.inv_B = b ? 1.0f / (float)b->B : 0.0f;
   A.nbI = st.nbI; A.nbU = st.nbU; A.nbC = st.nbC; A.nbD = (L.n_dense + 255) / 256;
+}
+
+// the two launches of one apply pass: item/user rows (+ dense parameters), then category rows
+static int launch_apply(int mode, const ApplyArgs& A, bool with_dense, hipStream_t hs) {
+  const dim3 g1(A.nbI + A.nbU + (with_dense ? A.nbD : 0)), g2(A.nbC), blk(256);
+  switch (mode) {
+    case AP_UPDATE:
+      hipLaunchKernelGGL(k_apply_rows<AP_UPDATE>, g1, blk, 0, hs, A);
+      hipLaunchKernelGGL(k_apply_cates<AP_UPDATE>, g2, blk, 0, hs, A);
+      break;
+    case AP_GRADS:
+      hipLaunchKernelGGL(k_apply_rows<AP_GRADS>, g1, blk, 0, hs, A);
+      hipLaunchKernelGGL(k_apply_cates<AP_GRADS>, g2, blk, 0, hs, A);
+      break;
+    case AP_SUMSQ:
+      hipLaunchKernelGGL(k_apply_rows<AP_SUMSQ>, g1, blk, 0, hs, A);
+      hipLaunchKernelGGL(k_apply_cates<AP_SUMSQ>, g2, blk, 0, hs, A);
+      break;
+    default:
+      hipLaunchKernelGGL(k_apply_rows<AP_ROWNORM>, g1, blk, 0, hs, A);
+      hipLaunchKernelGGL(k_apply_cates<AP_ROWNORM>, g2, blk, 0, hs, A);
+      break;
+  }
+  CHECK_LAUNCH("k_apply_rows / k_apply_cates");
+  return TLSAN_OK;
+}
+
+// static CSR category -> items from p->item_cate (counting sort with the generic index kernels)
+static int build_cate_csr(const tlsan_dims* d, const tlsan_params* p, const St& st, hipStream_t hs) {
+  const int I = d->item_count, C = d->cate_count;
+  if (hipMemsetAsync(st.cate_cnt, 0, 4 * (size_t)C, hs) != hipSuccess) return fail(TLSAN_E_LAUNCH, "memset cate_cnt");
+  GIdxArgs gi;
+  gi.dest = p->item_cate; gi.n = I; gi.nrows = C; gi.cnt = st.cate_cnt; gi.cur = st.cate_cur; gi.list = st.cate_items;
+  hipLaunchKernelGGL(k_gidx<false>, dim3((I + 255) / 256), dim3(256), 0, hs, gi);
+  CHECK_LAUNCH("k_gidx<count>");
+  ScanArgs sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.cnt[0] = st.cate_cnt; sa.off[0] = st.cate_off; sa.cur[0] = st.cate_cur; sa.n[0] = C;
+  const int nscan = (C + 4095) / 4096;
+  sa.blk0[0] = 0; sa.blk0[1] = nscan; sa.blk0[2] = nscan;
+  hipLaunchKernelGGL(k_index_scan, dim3(nscan), dim3(1024), 0, hs, sa);
+  CHECK_LAUNCH("k_index_scan");
+  hipLaunchKernelGGL(k_gidx<true>, dim3((I + 255) / 256), dim3(256), 0, hs, gi);
+  CHECK_LAUNCH("k_gidx<fill>");
+  return TLSAN_OK;
 }
 
 int tlsan_sync_derived(const tlsan_dims* d, const tlsan_params* p, void* stream) {
@@ -272,11 +301,24 @@ int tlsan_state_init(const tlsan_dims* d, const tlsan_params* p, void* state, vo
   memset(&w, 0, sizeof(w));
   ApplyArgs A;
   fill_apply(A, d, s, p, nullptr, nullptr, w, st, L);
-  hipLaunchKernelGGL(k_apply_rows<AP_SUMSQ>, dim3(st.nbI + st.nbU + st.nbC), dim3(256), 0, hs, A);
-  CHECK_LAUNCH("k_apply_rows<SUMSQ>");
+  if ((rc = build_cate_csr(d, p, st, hs))) return rc;
+  if ((rc = launch_apply(AP_SUMSQ, A, false, hs))) return rc;
   hipLaunchKernelGGL(k_reduce_double, dim3(1), dim3(256), 0, hs, st.S_part, st.nbI + st.nbU + st.nbC, st.S_total);
   CHECK_LAUNCH("k_reduce_double");
   return TLSAN_OK;
+}
+
+int tlsan_state_reindex(const tlsan_dims* d, const tlsan_params* p, void* state, void* stream) {
+  Shape s;
+  int rc = shape_of(d, &s);
+  if (rc) return rc;
+  if ((rc = check_params(p))) return rc;
+  if (!state) return fail(TLSAN_E_WORKSPACE, "state is NULL");
+  St st;
+  carve_state(d, (char*)state, &st);
+  hipStream_t hs = (hipStream_t)stream;
+  if (hipMemsetAsync(state, 0, st.bytes, hs) != hipSuccess) return fail(TLSAN_E_LAUNCH, "memset state");
+  return build_cate_csr(d, p, st, hs);
 }
 
 static int launch_fwd(const Shape& s, bool train, const FwdArgs& a, hipStream_t hs) {
@@ -296,7 +338,6 @@ static void fill_fwd(FwdArgs& a, const tlsan_dims* d, const Shape& s, const tlsa
   a.b = *b;
   a.lay = L;
   a.Ls = d->Ls; a.di = d->d_item; a.dc = d->d_cate;
-  a.S = d->Ls + b->Sn + 2;
   a.ngroups = (b->B + s.NSB - 1) / s.NSB;
   a.inv_B = 1.0f / (float)b->B;
   a.stamps = g_stamps;
@@ -326,44 +367,33 @@ int tlsan_forward(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch*
 static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params* p, const tlsan_batch* b,
                         const tlsan_step_out* out, const Ws& w, const St& st, const tlsan_dense_layout& L,
                         hipStream_t hs) {
-  const int S = d->Ls + b->Sn + 2;
-  // --- inverted index: counts -> offsets -> lists
-  IdxArgs ia;
-  memset(&ia, 0, sizeof(ia));
-  ia.b = *b; ia.item_cate = p->item_cate; ia.Ls = d->Ls; ia.S = S;
-  ia.cnt_item = st.cnt_item; ia.cnt_cate = st.cnt_cate; ia.cnt_user = st.cnt_user;
-  ia.cur_item = w.cur_item; ia.cur_cate = w.cur_cate; ia.cur_user = w.cur_user;
-  ia.list_item = w.list_item; ia.list_cate = w.list_cate; ia.list_user = w.list_user;
-  const int nthr = b->B * S;
+  // --- use counts per destination row -> first sorted position of every row
+  CountArgs ca;
+  memset(&ca, 0, sizeof(ca));
+  ca.b = *b; ca.Ls = d->Ls;
+  ca.cnt_item = st.cnt_item; ca.cnt_user = st.cnt_user; ca.cnt_uc = st.cnt_uc;
+  const int nthr = b->B * (d->Ls + b->Sn + 2);
   prof_mark(0, hs);
-  const bool side = side_ready() && g_prof_level < 2;  // level-2 profiling serialises the stages
-  hipStream_t is = hs;
-  if (side) {
-    if (hipEventRecord(g_ev_fork, hs) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_fork, 0) != hipSuccess)
-      return fail(TLSAN_E_LAUNCH, "fork to side stream");
-    is = g_side;
-  }
-  hipLaunchKernelGGL(k_index<false>, dim3((nthr + 255) / 256), dim3(256), 0, is, ia);
-  CHECK_LAUNCH("k_index<count>");
+  hipLaunchKernelGGL(k_count, dim3((nthr + 255) / 256), dim3(256), 0, hs, ca);
+  CHECK_LAUNCH("k_count");
   ScanArgs sa;
-  sa.cnt[0] = st.cnt_item; sa.cnt[1] = st.cnt_cate; sa.cnt[2] = st.cnt_user;
-  sa.off[0] = w.off_item; sa.off[1] = w.off_cate; sa.off[2] = w.off_user;
-  sa.cur[0] = w.cur_item; sa.cur[1] = w.cur_cate; sa.cur[2] = w.cur_user;
+  sa.cnt[0] = st.cnt_item; sa.cnt[1] = st.cnt_uc; sa.cnt[2] = st.cnt_user;
+  sa.off[0] = w.off_item; sa.off[1] = w.off_uc; sa.off[2] = w.off_user;
+  sa.cur[0] = w.cur_item; sa.cur[1] = w.cur_uc; sa.cur[2] = w.cur_user;
   sa.n[0] = d->item_count; sa.n[1] = d->cate_count; sa.n[2] = d->user_count;
   sa.blk0[0] = 0;
   sa.blk0[1] = (sa.n[0] + 4095) / 4096;
   sa.blk0[2] = sa.blk0[1] + (sa.n[1] + 4095) / 4096;
   const int nscan = sa.blk0[2] + (sa.n[2] + 4095) / 4096;
-  hipLaunchKernelGGL(k_index_scan, dim3(nscan), dim3(1024), 0, is, sa);
+  hipLaunchKernelGGL(k_index_scan, dim3(nscan), dim3(1024), 0, hs, sa);
   CHECK_LAUNCH("k_index_scan");
-  hipLaunchKernelGGL(k_index<true>, dim3((nthr + 255) / 256), dim3(256), 0, is, ia);
-  CHECK_LAUNCH("k_index<fill>");
-  if (side && hipEventRecord(g_ev_join, g_side) != hipSuccess) return fail(TLSAN_E_LAUNCH, "side stream join record");
   // --- fused forward + backward
   FwdArgs a;
   fill_fwd(a, d, s, p, b, w, L);
   a.logits_i = (out && out->logits) ? out->logits : w.logits;
-  a.G = w.G; a.GT = w.GT; a.dlogit = w.dlogit; a.gLong = w.gLong; a.gDB = w.gDB; a.partials = w.partials;
+  a.Gi = w.Gi; a.Gb = w.Gb; a.Gu = w.Gu; a.Gc = w.Gc; a.WU = w.WU;
+  a.cur_item = w.cur_item; a.cur_user = w.cur_user; a.cur_uc = w.cur_uc;
+  a.gLong = w.gLong; a.gDB = w.gDB; a.partials = w.partials;
   prof_mark(1, hs);
   int rc = launch_fwd(s, true, a, hs);
   if (rc) return rc;
@@ -388,7 +418,6 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   else if (s.D == 128) hipLaunchKernelGGL((k_dense_finalize<128, 16>), dim3(w.nfin + 1), dim3(256), 0, hs, f, w.nbK, w.nbS);
   else hipLaunchKernelGGL((k_dense_finalize<256, 32>), dim3(w.nfin + 1), dim3(256), 0, hs, f, w.nbK, w.nbS);
   CHECK_LAUNCH("k_dense_finalize");
-  if (side && hipStreamWaitEvent(hs, g_ev_join, 0) != hipSuccess) return fail(TLSAN_E_LAUNCH, "side stream join wait");
   prof_mark(4, hs);
   return TLSAN_OK;
 }
@@ -427,13 +456,11 @@ int tlsan_train_step(const tlsan_dims* d, const tlsan_params* p, const tlsan_bat
   if (hp->norm_mode == TLSAN_NORM_DEDUP) {
     ApplyArgs R = A;
     R.part_out = w.rownorm_part;
-    hipLaunchKernelGGL(k_apply_rows<AP_ROWNORM>, dim3(nrow), dim3(256), 0, hs, R);
-    CHECK_LAUNCH("k_apply_rows<ROWNORM>");
+    if ((rc = launch_apply(AP_ROWNORM, R, false, hs))) return rc;
     hipLaunchKernelGGL(k_reduce_double, dim3(1), dim3(256), 0, hs, w.rownorm_part, nrow, w.rownorm);
     CHECK_LAUNCH("k_reduce_double");
   }
-  hipLaunchKernelGGL(k_apply_rows<AP_UPDATE>, dim3(nrow + A.nbD), dim3(256), 0, hs, A);
-  CHECK_LAUNCH("k_apply_rows<UPDATE>");
+  if ((rc = launch_apply(AP_UPDATE, A, true, hs))) return rc;
   prof_mark(5, hs);
   if (g_prof_level > 0 && g_prof_n < PROF_MAX_STEPS) ++g_prof_n;
   return TLSAN_OK;
@@ -460,13 +487,11 @@ int tlsan_grads(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch* b
   if (hp->norm_mode == TLSAN_NORM_DEDUP) {
     ApplyArgs R = A;
     R.part_out = w.rownorm_part;
-    hipLaunchKernelGGL(k_apply_rows<AP_ROWNORM>, dim3(nrow), dim3(256), 0, hs, R);
-    CHECK_LAUNCH("k_apply_rows<ROWNORM>");
+    if ((rc = launch_apply(AP_ROWNORM, R, false, hs))) return rc;
     hipLaunchKernelGGL(k_reduce_double, dim3(1), dim3(256), 0, hs, w.rownorm_part, nrow, w.rownorm);
     CHECK_LAUNCH("k_reduce_double");
   }
-  hipLaunchKernelGGL(k_apply_rows<AP_GRADS>, dim3(nrow + A.nbD), dim3(256), 0, hs, A);
-  CHECK_LAUNCH("k_apply_rows<GRADS>");
+  if ((rc = launch_apply(AP_GRADS, A, true, hs))) return rc;
   prof_mark(5, hs);
   if (g_prof_level > 0 && g_prof_n < PROF_MAX_STEPS) ++g_prof_n;
   return TLSAN_OK;

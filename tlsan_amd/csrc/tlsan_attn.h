@@ -8,8 +8,9 @@
 //   P3  per wave   gather session rows, FWA block 2, logit, BCE, backward of block 2
 //   P4  workgroup  dlong = dbridge . K^T           (MFMA, B = K rows)
 //   P5  per wave   backward of block 1, per-use gradient rows, usert / gamma gradients
-// Per-use gradient rows are written once with plain 16-B stores into G[b*S + slot];
-// k_apply_rows sums them per destination row with exact (order-independent) arithmetic.
+// Per-use gradient rows are written once with plain 16-B stores at destination-sorted
+// positions (drawn from the fill cursors of the inverted index with one returning integer
+// atomic per use); k_apply_* sum each row's contiguous segment with exact arithmetic.
 //
 // The kernel is bound by the latency of ONE wavefront's dependent chain (4096 samples are
 // only 2 wavefronts per SIMD), so the code is organised to keep that chain short:
@@ -284,6 +285,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   constexpr int NBUF = G::NBUF;               // 2: dW of position p overlaps position p+1
   constexpr int WB = 2 * DH * DH + 2 * DH;    // floats of one attention block's weights
   constexpr bool USE_SW = G::USE_SW;          // attention weights staged in LDS (when they fit)
+  constexpr int PSTR = G::PSTR;               // per-sample position slots: LS long, SN_CAP session, 3 singles
+  constexpr int P_TGT = LS + TLSAN_SN_CAP, P_USR = P_TGT + 1, P_UC = P_TGT + 2;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;                   // [NSB][LSTR]  long -> dbridge
@@ -291,7 +294,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   float* sS = sB + NSB * LSTR;        // [NW][4] scalar staging
   float* sH = sS + NW * 4;            // [NSB][2*LS] hist_t and usert*hist_t of the pass
   float* sW = sH + NSB * 2 * LS;      // [2][WB] attention weights (W1,b1,W2,b2) of both blocks
-  float* sT = sW + (USE_SW ? 2 * WB : 0);  // per-wave transpose scratch / accumulator staging
+  int* sP = (int*)(sW + (USE_SW ? 2 * WB : 0));  // [NSB][PSTR] destination-sorted row of every use
+  float* sT = (float*)(sP + (TRAIN ? NSB * PSTR : 0));  // per-wave transpose scratch / staging
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int q = lane >> 4, r = lane & 15;
   const int s_loc = r / CPS, col = r % CPS;
@@ -304,7 +308,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 
   const float* dn = a.p.dense;
   const float gamma = dn[a.lay.gamma];
-  const int Ls = a.Ls, Sn = a.b.Sn, B = a.b.B, S = a.S;
+  const int Ls = a.Ls, Sn = a.b.Sn, B = a.b.B;
   // attention weights -> LDS once per workgroup (both blocks are contiguous runs of `dense`)
   if constexpr (USE_SW) {
     for (int o = tid; o < 2 * WB; o += NW * 64)
@@ -356,6 +360,23 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           sH[srow * 2 * LS + LS + p] = vp ? ut * ht : 0.0f;
         }
       }
+      if constexpr (TRAIN) {
+        // destination-sorted row of every long use: issue all the returning atomics first, read
+        // their results afterwards (no wait inside the per-position predicates)
+        int posv[LS];
+#pragma unroll
+        for (int p = 0; p < LS; ++p) posv[p] = (lead && p < n_l) ? atomicAdd(&a.cur_item[its[p]], 1) : 0;
+        const int pt = (lead && vs) ? atomicAdd(&a.cur_item[it_i], 1) : 0;
+        const int pu = (lead && vs) ? atomicAdd(&a.cur_user[uid], 1) : 0;
+        const int pc = (lead && vs) ? atomicAdd(&a.cur_uc[a.b.u_cate[bb]], 1) : 0;
+        if (lead) {
+#pragma unroll
+          for (int p = 0; p < LS; ++p) sP[srow * PSTR + p] = posv[p];
+          sP[srow * PSTR + P_TGT] = pt;
+          sP[srow * PSTR + P_USR] = pu;
+          sP[srow * PSTR + P_UC] = pc;
+        }
+      }
 #pragma unroll
       for (int p = 0; p < LS; ++p) {
         const int ct = a.p.item_cate[its[p]];
@@ -390,6 +411,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       iemb[kb] = gather_item4(a, it_i, c);
     }
     const float ib_i = a.p.item_b[(size_t)it_i * a.p.ld_itemb];
+
     // B fragments of the bridge GEMM (K^T rows, L2-resident) do not depend on the barrier:
     // fetch them first so their latency overlaps the wait for the slowest wavefront
     f32x4 bfr[G::TPW][D / 16];
@@ -459,6 +481,12 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         xr[kb] = vt ? v : (f32x4)(0.0f);
       }
     };
+    if constexpr (TRAIN) {  // positions of the session uses: one returning atomic per use
+      for (int base = 0; base < pmax2 - 1; base += NL) {
+        const int t = base + kk;
+        if (vs && t < n_s) sP[srow * PSTR + LS + t] = atomicAdd(&a.cur_item[a.b.hist_i_new[(size_t)bb * Sn + t]], 1);
+      }
+    }
     load_chunk(0);
     f32x4 xnext[NB];
     if (pmax2 > 1) fetch_row(0, xnext);
@@ -542,22 +570,24 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       const float lb = fmaxf(logit, 0.0f) - logit * yv + __logf(1.0f + en);
       const float sg = logit >= 0.0f ? 1.0f / (1.0f + en) : en / (1.0f + en);
       const float dl = vs ? (sg - yv) * a.inv_B : 0.0f;
+      const int pos_t = sP[srow * PSTR + P_TGT], pos_u = sP[srow * PSTR + P_USR], pos_c = sP[srow * PSTR + P_UC];
       if (lead && vs) {
-        a.dlogit[bidx] = dl;
+        a.Gb[pos_t] = dl;  // per-use item_b gradient
         loss_acc += lb;
-        sq_acc += dl * dl;  // per-use item_b gradient
+        sq_acc += dl * dl;
       }
       f32x4 dout[NB], dk0[NB];
-      const size_t gU = ((size_t)bidx * S + Ls + Sn + 1) * D;  // user slot: [user || u_cate]
-      const size_t gI = ((size_t)bidx * S + Ls + Sn) * D;      // candidate slot
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb) {
         dout[kb] = iemb[kb] * dl;  // d loss / d u_t
         dk0[kb] = (f32x4)(0.0f);
         const f32x4 gi = ut4[kb] * dl;
         if (vs) {
-          *(f32x4*)(a.G + gU + chb[kb]) = dout[kb];
-          *(f32x4*)(a.G + gI + chb[kb]) = gi;
+          const int c = chb[kb];
+          // user use: [user_emb half] -> Gu (grouped by user), [u_cate half] -> Gc (grouped by category)
+          float* up = (c < a.di) ? a.Gu + (size_t)pos_u * a.WU + c : a.Gc + (size_t)pos_c * a.dc + (c - a.di);
+          *(f32x4*)up = dout[kb];
+          *(f32x4*)(a.Gi + (size_t)pos_t * D + c) = gi;  // candidate use
           sq_acc += dot4(dout[kb], dout[kb]) + dot4(gi, gi);
         }
       }
@@ -605,10 +635,11 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
               }
             }
           } else if (vs && vt) {
-            const size_t go = ((size_t)bidx * S + Ls + (p - 1)) * D;
+            const int pos = sP[srow * PSTR + LS + (p - 1)];
+            if (lead) a.Gb[pos] = 0.0f;
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) {
-              *(f32x4*)(a.G + go + chb[kb]) = dx[kb];
+              *(f32x4*)(a.Gi + (size_t)pos * D + chb[kb]) = dx[kb];
               sq_acc += dot4(dx[kb], dx[kb]);
             }
           }
@@ -696,11 +727,12 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) dsp[p] += dot4(dx[kb], e1[p][kb]);
             if (vs && vp) {
-              const size_t go = ((size_t)bidx * S + p) * D;
+              const int pos = sP[srow * PSTR + p];
+              if (lead) a.Gb[pos] = 0.0f;
 #pragma unroll
               for (int kb = 0; kb < NB; ++kb) {
                 const f32x4 de = dx[kb] * scp;
-                *(f32x4*)(a.G + go + chb[kb]) = de;
+                *(f32x4*)(a.Gi + (size_t)pos * D + chb[kb]) = de;
                 sq_acc += dot4(de, de);
               }
             }
@@ -714,11 +746,13 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           if (lead && vs && p < Ls) {
             const bool vp = p < n_l;
             const float gt = vp ? ds * (gamma * sH[srow * 2 * LS + p]) : 0.0f;  // d / d usert_emb[u][p]
-            a.GT[(size_t)bidx * Ls + p] = gt;  // padded slots: 0 (k_apply_rows sums all Ls)
+            a.Gu[(size_t)sP[srow * PSTR + P_USR] * a.WU + a.di + p] = gt;  // padded slots: 0
             sq_acc += gt * gt;
             dgam += vp ? ds * sH[srow * 2 * LS + LS + p] : 0.0f;
           }
         }
+        if (lead && vs)
+          for (int p = a.di + Ls; p < a.WU; ++p) a.Gu[(size_t)sP[srow * PSTR + P_USR] * a.WU + p] = 0.0f;
         stage_accs<NB, CPS, false>(acc, dummy, T, lane);
       }
       // scalars of this pass: wave-reduce, stage, one thread sums the waves in fixed order

@@ -46,6 +46,7 @@ struct Geo {
   static constexpr int TBUF = 4 * NB * 16 * TSTR;   // one buffer: x, dz1, m1, dm2 tiles
   static constexpr int NBUF = NB == 1 ? 2 : 1;      // double-buffered when it fits the LDS
   static constexpr bool USE_SW = NB == 1;           // attention weights in LDS when they fit
+  static constexpr int PSTR = 10 + 96 + 4;          // TLSAN_LS_MAX + TLSAN_SN_CAP + 3 singles (+1 pad)
   static constexpr int WSCR_T = NBUF * TBUF;
   static constexpr int WSCR_A = (2 * NB * NB + 3 * NB) * 256;
   static constexpr int WSCR = WSCR_T > WSCR_A ? WSCR_T : WSCR_A;
@@ -174,21 +175,27 @@ __device__ __forceinline__ double exact_term(float v) {
   return t - TLSAN_EXACT_BIG;
 }
 
+#define TLSAN_SN_CAP 96  // longest session the training kernel keeps positions for (reference: <= 90)
+
 struct FwdArgs {
   tlsan_params p;
   tlsan_batch b;
   tlsan_dense_layout lay;
   int32_t Ls, di, dc;
-  int32_t S;        // contribution slots per sample: Ls + Sn + 2
+  int32_t WU;       // floats per row of Gu: roundup4(di + Ls)
   int32_t ngroups;  // ceil(B / NSB)
   float inv_B;
   float* logits_i;
   float* logits_j;
   float* u_t;
-  // training only
-  float* G;         // [B*S, D] per-use gradient rows (item || cate halves)
-  float* GT;        // [B, Ls]  per-use usert_emb gradient rows
-  float* dlogit;    // [B]      per-use item_b gradients
+  // training only.  Per-use gradient rows are written at DESTINATION-SORTED positions: the
+  // kernel draws the position of each use from the fill cursor of its destination row
+  // (cursor = exclusive scan of the per-row use counts), so k_apply_* read contiguous segments.
+  float* Gi;        // [n_item_uses, D]  [item half | cate half] rows, grouped by item id
+  float* Gb;        // [n_item_uses]     item_b gradients (same positions; 0 for non-candidate uses)
+  float* Gu;        // [B, WU]           [user_emb | usert_emb | pad] rows, grouped by user id
+  float* Gc;        // [B, dc]           u_cate rows, grouped by category
+  int32_t* cur_item; int32_t* cur_user; int32_t* cur_uc;
   float* gLong;     // [B, D]   long-term summaries (A operand of dK)
   float* gDB;       // [B, D]   d loss / d bridge     (B operand of dK)
   float* partials;  // [ngroups, NPB]

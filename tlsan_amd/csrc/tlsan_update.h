@@ -1,52 +1,42 @@
 // tlsan_update.h -- everything after the fused forward/backward kernel:
-//   k_index<FILL>     inverted index (destination row -> list of per-use gradient rows)
-//   k_index_scan      exclusive scan of the per-row counts
+//   k_count           uses per destination row (integer atomics)
+//   k_index_scan      exclusive scan of the counts = first sorted position of every row; the
+//                     fused kernel then draws one position per use from these cursors
 //   k_dk_partial      dK = long^T . dbridge  (split over the batch, f32 MFMA)
 //   k_dense_finalize  fixed-order reduction of all dense-parameter gradient partials
-//   k_apply_rows      exact segment-sum of the per-use rows + clip + SGD (model.py:198-205)
+//   k_apply_rows      item / user rows: exact sum of the row's contiguous segment of per-use
+//                     gradient rows + clip + SGD (model.py:198-205); per-item category partials
+//   k_apply_cates     category rows: two-level (items of the category, then u_cate uses)
 // Determinism: integer atomics only build *which* rows belong to a destination; the float
 // sums are order-independent (exact_term) or in a fixed order, so two runs are bitwise equal.
 #pragma once
 #include "tlsan_common.h"
 
-struct IdxArgs {
+struct CountArgs {
   tlsan_batch b;
-  const int32_t* item_cate;
-  int32_t Ls, S;
-  int32_t* cnt_item; int32_t* cnt_cate; int32_t* cnt_user;   // persistent, zero at rest
-  int32_t* cur_item; int32_t* cur_cate; int32_t* cur_user;   // fill cursors (start = offsets)
-  int32_t* list_item; int32_t* list_cate; int32_t* list_user;
+  int32_t Ls;
+  int32_t* cnt_item; int32_t* cnt_user; int32_t* cnt_uc;  // persistent, zero at rest
 };
 
-// one thread per (sample, slot); slot order: [0,Ls) long, [Ls,Ls+Sn) session, Ls+Sn candidate,
-// Ls+Sn+1 user.  The contribution code stored in the lists is c = b*S + slot = the row of G.
-template <bool FILL>
-__global__ void k_index(IdxArgs a) {
+// Use counts per destination row: one thread per (sample, slot); slots [0,Ls) long positions,
+// [Ls,Ls+Sn) session positions, Ls+Sn candidate, Ls+Sn+1 the user use (user row + u_cate row).
+// Category rows get their item-side gradients through the items (two-level reduction, see
+// k_apply_cates), so only the u_cate uses are counted per category.
+__global__ void k_count(CountArgs a) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int B = a.b.B, S = a.S, Ls = a.Ls, Sn = a.b.Sn;
+  const int B = a.b.B, Ls = a.Ls, Sn = a.b.Sn, S = Ls + Sn + 2;
   if (t >= B * S) return;
   const int b = t / S, slot = t - b * S;
-  int item = -1, cate = -1, user = -1;
   if (slot < Ls) {
-    if (slot < min(a.b.sl[b], Ls)) item = a.b.hist_i[(size_t)b * Ls + slot];
+    if (slot < min(a.b.sl[b], Ls)) atomicAdd(&a.cnt_item[a.b.hist_i[(size_t)b * Ls + slot]], 1);
   } else if (slot < Ls + Sn) {
     const int k = slot - Ls;
-    if (k < min(a.b.sl_new[b], Sn)) item = a.b.hist_i_new[(size_t)b * Sn + k];
+    if (k < min(a.b.sl_new[b], Sn)) atomicAdd(&a.cnt_item[a.b.hist_i_new[(size_t)b * Sn + k]], 1);
   } else if (slot == Ls + Sn) {
-    item = a.b.i[b];
+    atomicAdd(&a.cnt_item[a.b.i[b]], 1);
   } else {
-    user = a.b.u[b];
-    cate = a.b.u_cate[b];
-  }
-  if (item >= 0) cate = a.item_cate[item];
-  if constexpr (!FILL) {
-    if (item >= 0) atomicAdd(&a.cnt_item[item], 1);
-    if (cate >= 0) atomicAdd(&a.cnt_cate[cate], 1);
-    if (user >= 0) atomicAdd(&a.cnt_user[user], 1);
-  } else {
-    if (item >= 0) a.list_item[atomicAdd(&a.cur_item[item], 1)] = t;
-    if (cate >= 0) a.list_cate[atomicAdd(&a.cur_cate[cate], 1)] = t;
-    if (user >= 0) a.list_user[atomicAdd(&a.cur_user[user], 1)] = t;
+    atomicAdd(&a.cnt_user[a.b.u[b]], 1);
+    atomicAdd(&a.cnt_uc[a.b.u_cate[b]], 1);
   }
 }
 
@@ -294,11 +284,12 @@ struct ApplyArgs {
   tlsan_params p;
   tlsan_grads_out go;
   tlsan_dense_layout lay;
-  int32_t I, U, C, Ls, D, di, dc, S, Sn;
-  const float* G; const float* GT; const float* dlogit;
-  int32_t* cnt_item; int32_t* cnt_cate; int32_t* cnt_user;
-  const int32_t* off_item; const int32_t* off_cate; const int32_t* off_user;
-  const int32_t* list_item; const int32_t* list_cate; const int32_t* list_user;
+  int32_t I, U, C, Ls, D, di, dc, WU;
+  const float* Gi; const float* Gb; const float* Gu; const float* Gc;
+  float* Pc;                                   // [I, dc] per-item sums of the category halves
+  int32_t* cnt_item; int32_t* cnt_user; int32_t* cnt_uc;
+  const int32_t* off_item; const int32_t* off_user; const int32_t* off_uc;
+  const int32_t* cate_off; const int32_t* cate_cnt; const int32_t* cate_items;  // static CSR
   const float* gd; const float* sqd; int32_t nsqd; const float* scal;
   double* part_out;        // UPDATE/SUMSQ: new sums of squares per row block; ROWNORM: sum g^2
   const double* S_total;   // sum of squares of the four regularised tables (current params)
@@ -309,23 +300,22 @@ struct ApplyArgs {
   int32_t nbI, nbU, nbC, nbD;
 };
 
-// add rows list[k], k = lo, lo+stride, ... < hi (each: 4*W4 floats at G[c*D + colofs]) exactly;
-// up to four independent rows in flight
-__device__ __forceinline__ void accum_list(const int32_t* __restrict__ list, int lo, int hi,
-                                           int stride, const float* __restrict__ G, int D, int colofs,
-                                           int W4, int l16, double (&acc)[2][4]) {
+#define AP_OWN 8        // uses a 16-lane group sums alone before the wavefront helps
+#define AP_ROWS_PB 16   // item / user rows per workgroup (4 wavefronts x 4 groups)
+#define AP_NCH 4        // 16 lanes x 4 chunks x 4 floats = up to 256 columns (d = 256 item rows)
+
+// exact sum of rows lo, lo+stride, ... < hi of a [.., ld] buffer (columns 4*c4..), 4 in flight
+__device__ __forceinline__ void seg_accum(const float* __restrict__ Gs, int ld, int lo, int hi, int stride,
+                                          int W4, int l16, double (&acc)[AP_NCH][4]) {
   for (int k = lo; k < hi; k += 4 * stride) {
-    int c[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) c[u] = (k + u * stride < hi) ? list[k + u * stride] : -1;
-#pragma unroll
-    for (int ch = 0; ch < 2; ++ch) {
+    for (int ch = 0; ch < AP_NCH; ++ch) {
       const int c4 = l16 + 16 * ch;
       if (c4 < W4) {
         f32x4 v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-          v[u] = c[u] >= 0 ? *(const f32x4*)(G + (size_t)c[u] * D + colofs + 4 * c4) : (f32x4)(0.0f);
+          v[u] = (k + u * stride < hi) ? *(const f32x4*)(Gs + (size_t)(k + u * stride) * ld + 4 * c4) : (f32x4)(0.0f);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -335,65 +325,17 @@ __device__ __forceinline__ void accum_list(const int32_t* __restrict__ list, int
   }
 }
 
-// the narrow companion of a row: item -> item_b gradient (lane 0, candidate-slot uses only),
-// user -> usert_emb gradient (lane p < Ls)
-__device__ __forceinline__ double accum_side(const ApplyArgs& a, bool is_item, const int32_t* __restrict__ list,
-                                             int lo, int hi, int stride, int l16) {
-  double sacc = 0.0;
-  for (int k = lo; k < hi; k += stride) {
-    const int c = list[k];
-    const int b = c / a.S;
-    if (is_item) {
-      if (l16 == 0 && (c - b * a.S) == a.Ls + a.Sn) sacc += exact_term(a.dlogit[b]);
-    } else if (l16 < a.Ls) {
-      sacc += exact_term(a.GT[(size_t)b * a.Ls + l16]);
-    }
-  }
-  return sacc;
-}
-
-// Apply one parameter row of width 4*W4 held by lanes l16 (chunks l16, l16+16):
-//   g = (float)acc + reg*w;  UPDATE: w -= lr*coef*g.  Returns this lane's partial for part_out.
-template <int MODE>
-__device__ __forceinline__ double apply_row(float* __restrict__ Wrow, float* __restrict__ Grow,
-                                            const double (&acc)[2][4], int W4, int l16, float reg,
-                                            float step) {
-  double part = 0.0;
+__device__ __forceinline__ void zero_acc(double (&acc)[AP_NCH][4]) {
 #pragma unroll
-  for (int ch = 0; ch < 2; ++ch) {
-    const int c4 = l16 + 16 * ch;
-    if (c4 < W4) {
-      f32x4 w = *(const f32x4*)(Wrow + 4 * c4);
-      if constexpr (MODE == AP_SUMSQ) {
+  for (int ch = 0; ch < AP_NCH; ++ch)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) part += (double)w[i] * (double)w[i];
-      } else {
-        f32x4 g;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) g[i] = (float)acc[ch][i] + reg * w[i];
-        if constexpr (MODE == AP_GRADS) *(f32x4*)(Grow + 4 * c4) = g;
-        if constexpr (MODE == AP_ROWNORM) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) part += (double)g[i] * (double)g[i];
-        }
-        if constexpr (MODE == AP_UPDATE) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            w[i] -= step * g[i];
-            part += (double)w[i] * (double)w[i];
-          }
-          *(f32x4*)(Wrow + 4 * c4) = w;
-        }
-      }
-    }
-  }
-  return part;
+    for (int i = 0; i < 4; ++i) acc[ch][i] = 0.0;
 }
 
 // sum over the four 16-lane groups of a wavefront (exact doubles -> order irrelevant)
-__device__ __forceinline__ void combine_groups(double (&acc)[2][4]) {
+__device__ __forceinline__ void combine_groups(double (&acc)[AP_NCH][4]) {
 #pragma unroll
-  for (int ch = 0; ch < 2; ++ch)
+  for (int ch = 0; ch < AP_NCH; ++ch)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       acc[ch][i] += __shfl_xor(acc[ch][i], 16);
@@ -401,23 +343,12 @@ __device__ __forceinline__ void combine_groups(double (&acc)[2][4]) {
     }
 }
 
-#define AP_OWN 8        // uses a 16-lane group sums alone before the wavefront helps
-#define AP_ROWS_PB 16   // item / user rows per workgroup (4 wavefronts x 4 groups)
-
-// Block layout: [0,nbI) item rows, [nbI,nbI+nbU) user rows (user_emb + usert_emb): one row per
-// 16-lane group; the first AP_OWN uses of a row are summed by its group, longer lists (hot
-// items) by the whole wavefront.  Then nbC category rows (one row per workgroup: long lists),
-// then nbD blocks of 256 dense parameters.
+// the global-norm clip coefficient (model.py:201), identical in every workgroup
 template <int MODE>
-__global__ __launch_bounds__(256) void k_apply_rows(ApplyArgs a) {
-  __shared__ double shd[4 * 16 * 8];
-  __shared__ float sh_coef;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, grp = lane >> 4, l16 = lane & 15;
-  const int D = a.D;
-  float coef = 1.0f;
+__device__ __forceinline__ float clip_coef(const ApplyArgs& a, float* sh_coef, bool writer) {
   if constexpr (MODE == AP_UPDATE || MODE == AP_GRADS) {
-    if (tid == 0) {
-      // global norm (model.py:201).  tf18: per-use rows + (reg*W)^2 + dense; dedup: summed rows.
+    if (threadIdx.x == 0) {
+      // tf18: per-use rows + (reg*W)^2 + dense; dedup: summed rows + dense
       double sq = 0.0;
       for (int k = 0; k < a.nsqd; ++k) sq += (double)a.sqd[k];
       const double St = *a.S_total;
@@ -426,133 +357,46 @@ __global__ __launch_bounds__(256) void k_apply_rows(ApplyArgs a) {
       else
         sq += *a.rownorm;
       const float norm = (float)sqrt(sq);
-      sh_coef = a.clip / fmaxf(norm, a.clip);
-      if (blockIdx.x == 0) {
+      *sh_coef = a.clip / fmaxf(norm, a.clip);
+      if (writer) {
         if (a.out_gnorm) *a.out_gnorm = norm;
         if (a.out_loss) *a.out_loss = a.scal[0] * a.inv_B + a.reg * (float)(0.5 * St);
         if (a.out_sq) *a.out_sq = a.scal[1];
       }
     }
     __syncthreads();
-    coef = sh_coef;
+    return *sh_coef;
   }
+  return 1.0f;
+}
+
+__device__ __forceinline__ void block_part_store(double part, double* shd, double* dst) {
+  __syncthreads();
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) part += __shfl_xor(part, o);
+  if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) *dst = shd[0] + shd[1] + shd[2] + shd[3];
+}
+
+// Block layout: [0,nbI) item rows, [nbI,nbI+nbU) user rows (user_emb + usert_emb): one row per
+// 16-lane group; the first AP_OWN uses of a row are summed by its group, longer segments (hot
+// items) by the whole wavefront.  Then nbD blocks of 256 dense parameters.
+// Item rows carry [item half | cate half]: the item half updates item_emb, the cate half is
+// written to Pc[item] for k_apply_cates.  User rows are [user_emb | usert_emb | pad].
+template <int MODE>
+__global__ __launch_bounds__(256) void k_apply_rows(ApplyArgs a) {
+  __shared__ double shd[4];
+  __shared__ float sh_coef;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, grp = lane >> 4, l16 = lane & 15;
+  const int D = a.D;
+  const float coef = clip_coef<MODE>(a, &sh_coef, blockIdx.x == 0);
   const float step = a.lr * coef;
   double part = 0.0;
   const int blk = blockIdx.x;
-  if (blk < a.nbI + a.nbU) {
-    const bool is_item = blk < a.nbI;
-    const int row = (is_item ? blk : blk - a.nbI) * AP_ROWS_PB + wave * 4 + grp;
-    const int nrows = is_item ? a.I : a.U;
-    const bool vr = row < nrows;
-    double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    double sacc = 0.0;
-    int n = 0;
-    if constexpr (MODE != AP_SUMSQ) {
-      int32_t* cnt = is_item ? a.cnt_item : a.cnt_user;
-      const int32_t* lists = is_item ? a.list_item : a.list_user;
-      int off = 0;
-      if (vr) {
-        n = cnt[row];
-        off = (is_item ? a.off_item : a.off_user)[row];
-      }
-      const int n_own = min(n, AP_OWN);
-      accum_list(lists + off, 0, n_own, 1, a.G, D, 0, a.di / 4, l16, acc);
-      sacc = accum_side(a, is_item, lists + off, 0, n_own, 1, l16);
-      // long lists: the four groups of the wavefront split the rest of group g's list
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int ng = __shfl(n, g * 16);
-        if (ng > AP_OWN) {  // wave-uniform
-          const int og = __shfl(off, g * 16);
-          double t[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-          accum_list(lists + og, AP_OWN + grp, ng, 4, a.G, D, 0, a.di / 4, l16, t);
-          double ts = accum_side(a, is_item, lists + og, AP_OWN + grp, ng, 4, l16);
-          combine_groups(t);
-          ts += __shfl_xor(ts, 16);
-          ts += __shfl_xor(ts, 32);
-          if (grp == g) {
-#pragma unroll
-            for (int ch = 0; ch < 2; ++ch)
-#pragma unroll
-              for (int i = 0; i < 4; ++i) acc[ch][i] += t[ch][i];
-            sacc += ts;
-          }
-        }
-      }
-      if constexpr (MODE != AP_ROWNORM) {
-        if (vr && n > 0 && l16 == 0) cnt[row] = 0;  // counters are zero at rest
-      }
-    }
-    if (vr) {
-      float* W = is_item ? a.p.item_emb + (size_t)row * a.p.ld_item : a.p.user_emb + (size_t)row * a.p.ld_user;
-      float* Gr = nullptr;
-      if constexpr (MODE == AP_GRADS) Gr = (is_item ? a.go.item_emb : a.go.user_emb) + (size_t)row * a.di;
-      part += apply_row<MODE>(W, Gr, acc, a.di / 4, l16, a.reg, step);
-      // the narrow companions: item_b[row] (not regularised, model.py:164-169) / usert_emb[row]
-      if (is_item) {
-        if (l16 == 0) {
-          const float g = (float)sacc;
-          if constexpr (MODE == AP_GRADS) a.go.item_b[row] = g;
-          if constexpr (MODE == AP_ROWNORM) part += (double)g * (double)g;
-          if constexpr (MODE == AP_UPDATE) {
-            if (n > 0) a.p.item_b[(size_t)row * a.p.ld_itemb] -= step * g;
-          }
-        }
-      } else if (l16 < a.Ls) {
-        float* wp = a.p.usert_emb + (size_t)row * a.p.ld_usert + l16;
-        float w = *wp;
-        const float g = (float)sacc + a.reg * w;
-        if constexpr (MODE == AP_SUMSQ) part += (double)w * (double)w;
-        if constexpr (MODE == AP_GRADS) a.go.usert_emb[(size_t)row * a.Ls + l16] = g;
-        if constexpr (MODE == AP_ROWNORM) part += (double)g * (double)g;
-        if constexpr (MODE == AP_UPDATE) {
-          w -= step * g;
-          *wp = w;
-          part += (double)w * (double)w;
-        }
-      }
-    }
-  } else if (blk < a.nbI + a.nbU + a.nbC) {
-    const int row = blk - a.nbI - a.nbU;
-    double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    int n = 0;
-    if constexpr (MODE != AP_SUMSQ) {
-      n = a.cnt_cate[row];
-      if (n > 0) {  // workgroup-uniform
-        accum_list(a.list_cate + a.off_cate[row], wave * 4 + grp, n, 16, a.G, D, a.di, a.dc / 4, l16, acc);
-        combine_groups(acc);
-        if (grp == 0) {
-#pragma unroll
-          for (int ch = 0; ch < 2; ++ch)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) shd[((wave * 16 + l16) * 2 + ch) * 4 + i] = acc[ch][i];
-        }
-        __syncthreads();
-        if (wave == 0 && grp == 0) {
-#pragma unroll
-          for (int ch = 0; ch < 2; ++ch)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              double s = 0.0;
-              for (int w = 0; w < 4; ++w) s += shd[((w * 16 + l16) * 2 + ch) * 4 + i];
-              acc[ch][i] = s;
-            }
-        }
-        __syncthreads();
-        if constexpr (MODE != AP_ROWNORM) {
-          if (tid == 0) a.cnt_cate[row] = 0;
-        }
-      }
-    }
-    if (wave == 0 && grp == 0) {
-      float* W = a.p.cate_emb + (size_t)row * a.dc;
-      float* Gr = nullptr;
-      if constexpr (MODE == AP_GRADS) Gr = a.go.cate_emb + (size_t)row * a.dc;
-      part += apply_row<MODE>(W, Gr, acc, a.dc / 4, l16, a.reg, step);
-    }
-  } else {
+  if (blk >= a.nbI + a.nbU) {
     if constexpr (MODE == AP_UPDATE || MODE == AP_GRADS) {
-      const int n = (blk - a.nbI - a.nbU - a.nbC) * 256 + tid;
+      const int n = (blk - a.nbI - a.nbU) * 256 + tid;
       if (n < a.lay.n_dense) {
         const float g = a.gd[n];
         if constexpr (MODE == AP_GRADS) {
@@ -569,13 +413,225 @@ __global__ __launch_bounds__(256) void k_apply_rows(ApplyArgs a) {
     }
     return;
   }
-  if constexpr (MODE != AP_GRADS) {
-    // per-workgroup partial (fixed order): lanes -> waves -> block
-    __syncthreads();
+  const bool is_item = blk < a.nbI;
+  const int row = (is_item ? blk : blk - a.nbI) * AP_ROWS_PB + wave * 4 + grp;
+  const bool vr = row < (is_item ? a.I : a.U);
+  const float* Gs = is_item ? a.Gi : a.Gu;
+  const int ld = is_item ? D : a.WU;
+  const int W4 = ld / 4;
+  double acc[AP_NCH][4];
+  zero_acc(acc);
+  double bacc = 0.0;  // item_b gradient of the row (item rows)
+  int n = 0, off = 0;
+  if constexpr (MODE != AP_SUMSQ) {
+    if (vr) {
+      n = (is_item ? a.cnt_item : a.cnt_user)[row];
+      off = (is_item ? a.off_item : a.off_user)[row];
+    }
+    const int n_own = min(n, AP_OWN);
+    seg_accum(Gs, ld, off, off + n_own, 1, W4, l16, acc);
+    if (is_item)
+      for (int k = off + l16; k < off + n_own; k += 16) bacc += exact_term(a.Gb[k]);
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) part += __shfl_xor(part, o);
-    if (lane == 0) shd[wave] = part;
-    __syncthreads();
-    if (tid == 0) a.part_out[blk] = shd[0] + shd[1] + shd[2] + shd[3];
+    for (int g = 0; g < 4; ++g) {
+      const int ng = __shfl(n, g * 16);
+      if (ng > AP_OWN) {  // wave-uniform: the four groups split the rest of group g's segment
+        const int og = __shfl(off, g * 16);
+        double t[AP_NCH][4];
+        zero_acc(t);
+        seg_accum(Gs, ld, og + AP_OWN + grp, og + ng, 4, W4, l16, t);
+        double tb = 0.0;
+        if (is_item)
+          for (int k = og + AP_OWN + lane; k < og + ng; k += 64) tb += exact_term(a.Gb[k]);
+        combine_groups(t);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) tb += __shfl_xor(tb, o);
+        if (grp == g) {
+#pragma unroll
+          for (int ch = 0; ch < AP_NCH; ++ch)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[ch][i] += t[ch][i];
+          if (l16 == 0) bacc += tb;
+        }
+      }
+    }
+    if (is_item) {  // fold the group's 16 partial bias sums (exact doubles: any order)
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) bacc += __shfl_xor(bacc, o);
+    }
+    if constexpr (MODE != AP_ROWNORM) {
+      if (!is_item && vr && n > 0 && l16 == 0) a.cnt_user[row] = 0;  // counters are zero at rest
+      // (cnt_item is read as the "touched" flag and reset by k_apply_cates)
+    }
   }
+  if (vr) {
+    // column c of the fused row -> parameter element
+    //   item rows: c < di -> item_emb[row][c];  di <= c < di+dc -> Pc[row][c-di] (not a parameter)
+    //   user rows: c < di -> user_emb[row][c];  di <= c < di+Ls -> usert_emb[row][c-di]
+#pragma unroll
+    for (int ch = 0; ch < AP_NCH; ++ch) {
+      const int c = 4 * (l16 + 16 * ch);
+      if (c >= ld) continue;
+      if (is_item && c >= a.di) {
+        if constexpr (MODE != AP_SUMSQ) {
+          if (n > 0) {
+            f32x4 pc;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pc[i] = (float)acc[ch][i];
+            *(f32x4*)(a.Pc + (size_t)row * a.dc + (c - a.di)) = pc;
+          }
+        }
+        continue;
+      }
+      if (c < a.di) {
+        float* Wp = is_item ? a.p.item_emb + (size_t)row * a.p.ld_item + c : a.p.user_emb + (size_t)row * a.p.ld_user + c;
+        f32x4 w = *(const f32x4*)Wp;
+        if constexpr (MODE == AP_SUMSQ) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) part += (double)w[i] * (double)w[i];
+        } else {
+          f32x4 g;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) g[i] = (float)acc[ch][i] + a.reg * w[i];
+          if constexpr (MODE == AP_GRADS)
+            *(f32x4*)((is_item ? a.go.item_emb : a.go.user_emb) + (size_t)row * a.di + c) = g;
+          if constexpr (MODE == AP_ROWNORM) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) part += (double)g[i] * (double)g[i];
+          }
+          if constexpr (MODE == AP_UPDATE) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              w[i] -= step * g[i];
+              part += (double)w[i] * (double)w[i];
+            }
+            *(f32x4*)Wp = w;
+          }
+        }
+      } else {  // user rows, usert_emb columns (scalar: Ls need not be a multiple of 4)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int p = c + i - a.di;
+          if (p < a.Ls) {
+            float* wp = a.p.usert_emb + (size_t)row * a.p.ld_usert + p;
+            float w = *wp;
+            const float g = (float)acc[ch][i] + a.reg * w;
+            if constexpr (MODE == AP_SUMSQ) part += (double)w * (double)w;
+            if constexpr (MODE == AP_GRADS) a.go.usert_emb[(size_t)row * a.Ls + p] = g;
+            if constexpr (MODE == AP_ROWNORM) part += (double)g * (double)g;
+            if constexpr (MODE == AP_UPDATE) {
+              w -= step * g;
+              *wp = w;
+              part += (double)w * (double)w;
+            }
+          }
+        }
+      }
+    }
+    if (is_item && l16 == 0) {  // item_b[row]: not regularised (model.py:164-169)
+      const float g = (float)bacc;
+      if constexpr (MODE == AP_GRADS) a.go.item_b[row] = g;
+      if constexpr (MODE == AP_ROWNORM) part += (double)g * (double)g;
+      if constexpr (MODE == AP_UPDATE) {
+        if (n > 0) a.p.item_b[(size_t)row * a.p.ld_itemb] -= step * g;
+      }
+    }
+  }
+  if constexpr (MODE != AP_GRADS) block_part_store(part, shd, &a.part_out[blk]);
+}
+
+// Category rows, one per workgroup, after k_apply_rows of the same step:
+//   g[c] = sum over the items i of category c that were used this step of Pc[i]
+//        + sum of the u_cate uses of c (contiguous segment of Gc)            (+ reg * W)
+// The item lists are the static CSR of item_cate (built by tlsan_state_init).  Resets the item
+// and u_cate use counters (every item belongs to exactly one category).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_apply_cates(ApplyArgs a) {
+  __shared__ double shd[4 * 16 * AP_NCH * 4];
+  __shared__ double shp[4];
+  __shared__ float sh_coef;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, grp = lane >> 4, l16 = lane & 15;
+  const int gid = wave * 4 + grp;  // 16 groups
+  const float coef = clip_coef<MODE>(a, &sh_coef, false);
+  const float step = a.lr * coef;
+  const int row = blockIdx.x;
+  const int W4 = a.dc / 4;
+  double acc[AP_NCH][4];
+  zero_acc(acc);
+  if constexpr (MODE != AP_SUMSQ) {
+    const int i0 = a.cate_off[row], ni = a.cate_cnt[row];
+    for (int k = gid; k < ni; k += 16) {
+      const int item = a.cate_items[i0 + k];
+      if (a.cnt_item[item] > 0) {
+#pragma unroll
+        for (int ch = 0; ch < AP_NCH; ++ch) {
+          const int c4 = l16 + 16 * ch;
+          if (c4 < W4) {
+            const f32x4 v = *(const f32x4*)(a.Pc + (size_t)item * a.dc + 4 * c4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[ch][i] += exact_term(v[i]);
+          }
+        }
+        if constexpr (MODE != AP_ROWNORM) {
+          if (l16 == 0) a.cnt_item[item] = 0;
+        }
+      }
+    }
+    const int nu = a.cnt_uc[row], ou = a.off_uc[row];
+    seg_accum(a.Gc, a.dc, ou + gid, ou + nu, 16, W4, l16, acc);
+    combine_groups(acc);
+    if (grp == 0) {
+#pragma unroll
+      for (int ch = 0; ch < AP_NCH; ++ch)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) shd[((wave * 16 + l16) * AP_NCH + ch) * 4 + i] = acc[ch][i];
+    }
+    __syncthreads();
+    if (wave == 0 && grp == 0) {
+#pragma unroll
+      for (int ch = 0; ch < AP_NCH; ++ch)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          double s = 0.0;
+          for (int w = 0; w < 4; ++w) s += shd[((w * 16 + l16) * AP_NCH + ch) * 4 + i];
+          acc[ch][i] = s;
+        }
+    }
+    if constexpr (MODE != AP_ROWNORM) {
+      if (tid == 0 && nu > 0) a.cnt_uc[row] = 0;
+    }
+  }
+  double part = 0.0;
+  if (wave == 0 && grp == 0) {
+#pragma unroll
+    for (int ch = 0; ch < AP_NCH; ++ch) {
+      const int c4 = l16 + 16 * ch;
+      if (c4 < W4) {
+        float* Wp = a.p.cate_emb + (size_t)row * a.dc + 4 * c4;
+        f32x4 w = *(const f32x4*)Wp;
+        if constexpr (MODE == AP_SUMSQ) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) part += (double)w[i] * (double)w[i];
+        } else {
+          f32x4 g;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) g[i] = (float)acc[ch][i] + a.reg * w[i];
+          if constexpr (MODE == AP_GRADS) *(f32x4*)(a.go.cate_emb + (size_t)row * a.dc + 4 * c4) = g;
+          if constexpr (MODE == AP_ROWNORM) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) part += (double)g[i] * (double)g[i];
+          }
+          if constexpr (MODE == AP_UPDATE) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              w[i] -= step * g[i];
+              part += (double)w[i] * (double)w[i];
+            }
+            *(f32x4*)Wp = w;
+          }
+        }
+      }
+    }
+  }
+  if constexpr (MODE != AP_GRADS) block_part_store(part, shp, &a.part_out[a.nbI + a.nbU + row]);
 }

@@ -224,15 +224,17 @@ class ShardedModel:
     def device_batch(self, batch, is_test=False):
         return batch if isinstance(batch, DeviceBatch) else DeviceBatch(batch, self.device, is_test, self.Ls)
 
-    def _buffers(self, dims, B, Sn, n_rows_max):
+    def _buffers(self, dims, cp, B, Sn, n_rows_max):
         nst = self.lib.tlsan_state_bytes(C.byref(dims))
         nws = self.lib.tlsan_workspace_bytes(C.byref(dims), B, Sn)
         if nst == 0 or nws == 0:
             raise L.TlsanError(self.lib.tlsan_last_error().decode())
         if self._state is None or self._state.numel() < nst:
             self._state = torch.zeros(int(nst * 1.5), dtype=torch.uint8, device=self.device)
-        else:
-            self._state.zero_()   # compact-table shapes change every step: keep counters zero at rest
+        # the compact item table (and its item -> category map) changes every step: clear the
+        # use counters and rebuild the category -> items index for it
+        L.check(self.lib.tlsan_state_reindex(C.byref(dims), C.byref(cp), self._state.data_ptr(), self._stream()),
+                "tlsan_state_reindex")
         if self._ws is None or self._ws.numel() < nws:
             self._ws = torch.empty(int(nws * 1.25), dtype=torch.uint8, device=self.device)
         nr = self.lib.tlsan_rows_apply_workspace(max(self.item_shard.shape[0], self.user_shard.shape[0],
@@ -278,7 +280,7 @@ class ShardedModel:
         G = self.world
         dims, cp, cb, plan_i, plan_u, keep = self._compact(db, with_j=False)
         n_i, n_u, Cc = dims.item_count, dims.user_count, dims.cate_count
-        self._buffers(dims, db.B, db.Sn, max(sum(plan_i.recv_counts), sum(plan_u.recv_counts), Cc))
+        self._buffers(dims, cp, db.B, db.Sn, max(sum(plan_i.recv_counts), sum(plan_u.recv_counts), Cc))
         dev = self.device
         g_item = torch.empty(n_i, self.di, dtype=torch.float32, device=dev)
         g_itemb = torch.empty(n_i, dtype=torch.float32, device=dev)
