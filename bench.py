@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--profile-level", type=int, default=1)
+    ap.add_argument("--l2-mode", default="lazy", choices=["lazy", "dense"],
+                    help="lazy: W = P*W_stored, only used rows touched (same update as the reference's dense L2); "
+                         "dense: every row decayed every step")
     ap.add_argument("--graph", type=int, default=1, help="replay hipGraph-captured steps (single-GPU path)")
     ap.add_argument("--event-every", type=int, default=8,
                     help="with --graph: every Nth timed step runs eagerly so HIP events can bracket k_fwd_bwd")
@@ -105,7 +108,7 @@ def main():
     # weak scaling: every rank trains its own batch of B sequences per step
     host_batches = synth.make_batches(cfg, args.n_batches, B, seed=1234 + 1000 * rank)
     if not sharded:
-        model = Model(cfg, icl, device=dev)
+        model = Model(cfg, icl, device=dev, l2_mode=args.l2_mode)
         stepper = model
     else:
         from tlsan_amd.dist import ShardedModel
@@ -156,7 +159,8 @@ def main():
         seqs = args.steps * B * world
         ab = [synth.algorithmic_bytes(cfg, host_batches[(args.warmup + s) % len(host_batches)]) for s in range(args.steps)]
         k_bytes = float(np.mean([a["fwd_bwd_kernel"] for a in ab]))
-        step_bytes = float(np.mean([a["train_step"] for a in ab])) + synth.dense_sweep_bytes(cfg)
+        l2 = "dense" if sharded else args.l2_mode
+        step_bytes = float(np.mean([a["train_step"] for a in ab])) + (synth.dense_sweep_bytes(cfg) if l2 == "dense" else 0)
         k_ms = float(seg[:, 1].mean()) if nrec else float("nan")
         achieved = k_bytes / (k_ms * 1e-3) / 1e9 if nrec else None
         traffic = None
@@ -180,9 +184,11 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "%s-scale synthetic (U=%d I=%d C=%d, d=%d, Ls=%d), batch %d/GPU, fp32 tables, "
-                                   "l2_mode=dense (every row updated every step, as the reference)"
+                                   "l2_mode=%s"
                                    % (args.workload, cfg["user_count"], cfg["item_count"], cfg["cate_count"],
-                                      cfg["hidden_units"], cfg["Ls"], B),
+                                      cfg["hidden_units"], cfg["Ls"], B,
+                                      "dense (every row decayed every step, as the reference)" if l2 == "dense" else
+                                      "lazy (reference's dense-L2 update as W = P*W_stored; only used rows touched)"),
                        "global_batch": B * world, "parallelism": "1 process/GPU, tables %s"
                        % ("on one GPU" if not sharded else "row-sharded (id %% N), RCCL all-to-all + one all-reduce")},
             "roofline": {"bound": "hbm", "kernel": "k_fwd_bwd", "achieved": None if achieved is None else round(achieved, 1),

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TLSAN_ABI_VERSION 2
+#define TLSAN_ABI_VERSION 3
 
 enum {
   TLSAN_OK = 0,
@@ -63,6 +63,11 @@ typedef struct {
   /* Row strides in floats; 0 = densely packed (d_item, 1, d_item, Ls).  Non-zero strides let
    * the tables alias fused rows, e.g. [item_emb | item_b | pad] as exchanged between GPUs. */
   int32_t ld_item, ld_itemb, ld_user, ld_usert;
+  /* Optional DEVICE scalar P (NULL = 1): the four L2-regularised tables hold W / P, i.e. the
+   * true parameters are P * stored (item_b and `dense` are never scaled).  With
+   * TLSAN_L2_LAZY the library keeps P = prod_t (1 - lr_t c_t reg) here instead of decaying
+   * every row every step; point it at tlsan_state_scale(state). */
+  const float* scale;
 } tlsan_params;
 
 typedef struct {
@@ -88,6 +93,12 @@ typedef struct {
 } tlsan_batch;
 
 enum { TLSAN_NORM_TF18 = 0, TLSAN_NORM_DEDUP = 1 };
+/* L2 term of model.py:164-172.  DENSE: every row of the four tables is decayed every step, as the
+ * reference's dense gradient does.  LAZY: algebraically the same update,
+ *   W <- (1 - lr c reg) W - lr c G_sparse,
+ * kept as W = P * W_stored with one global scale P, so only rows that received a gradient are
+ * read and written (identical up to fp32 rounding; required for tables that do not fit a
+ * per-step sweep). */
 enum { TLSAN_L2_DENSE = 0, TLSAN_L2_LAZY = 1 };
 
 /* Hyper-parameters of one step: model.py:172 (regulation_rate), :201 (max_gradient_norm),
@@ -124,6 +135,13 @@ size_t tlsan_state_bytes(const tlsan_dims* dims);
 /* (Re)initialise `state` from the current parameters and refresh dense_KT.  Call once
  * after creating / restoring / externally modifying parameters. */
 int tlsan_state_init(const tlsan_dims* dims, const tlsan_params* p, void* state, void* stream);
+
+/* Address (inside `state`) of the table scale P maintained by TLSAN_L2_LAZY steps. */
+const float* tlsan_state_scale(const void* state);
+
+/* Fold the scale into the tables (stored *= P, P = 1).  Call before reading the tables as plain
+ * parameters (checkpoint) or when P gets small (long lazy runs: P ~ exp(-sum lr c reg)). */
+int tlsan_state_renorm(const tlsan_dims* dims, const tlsan_params* p, void* state, void* stream);
 
 /* Clear the use counters and rebuild the static category->items index for p->item_cate without
  * touching the sums of squares (used by callers whose item table changes every step). */

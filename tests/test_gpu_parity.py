@@ -222,3 +222,58 @@ def test_errors():
     bad = list(_tuple(b)); bad[3] = bad[3][:, :5]
     with pytest.raises(ValueError):
         m.train(None, tuple(bad), 1.0)
+
+
+@pytest.mark.parametrize("clip", [5.0, 0.02])
+def test_lazy_l2_matches_dense_oracle(clip):
+    """l2_mode='lazy' (scaled representation, only used rows touched) is the reference's dense-L2
+    update up to fp32 rounding: several steps against the (dense) oracle, clip active and not."""
+    cfg = make_config(U=300, I=200, C=9, d=128, max_gradient_norm=clip, regulation_rate=2e-2)  # big reg: decay visible
+    p = _p32(random_params(cfg, seed=51))
+    _, cat = random_batch(cfg, B=8, Sn=3, seed=0)
+    batches = [random_batch(cfg, B=24, Sn=1 + s % 3, seed=300 + s)[0] for s in range(5)]
+    m = _model(cfg, cat, p, l2_mode="lazy")
+    q = dict(p)
+    for b in batches:
+        l = m.train(None, _tuple(b), 0.9)
+        lo, q, info = orc.train_step(q, cat, b, 8, cfg["regulation_rate"], lr=0.9, clip=clip)
+        assert abs(l - lo) < 2e-4 * max(1.0, abs(lo))
+        assert abs(m.last_gnorm() - info["norm"]) < 3e-4 * info["norm"]
+    P = m.table_scale()
+    assert P < (0.95 if clip > 1 else 1.0)  # the decay really lives in the scale
+    # evaluation uses the scale on the fly
+    tb, _ = random_batch(cfg, B=20, Sn=2, seed=99, test=True)
+    li, lj, ut, _ = m.forward(_tuple(tb, True), is_test=True, want_u_t=True)
+    ref = orc.forward(q, cat, tb, 8)
+    assert np.abs(li.cpu().numpy() - ref["logits"]).max() < 3e-4
+    ranks = m.label_ranks(_tuple(tb, True)).cpu().numpy()
+    rr = orc.label_ranks(orc.all_item_scores(q, cat, ref["u_t"]), tb["i"])
+    assert np.abs(ranks - rr).max() <= 2
+    got = m.get_params()  # folds the scale
+    assert m.table_scale() == 1.0
+    for k in q:
+        g = np.asarray(got[k], np.float64).reshape(q[k].shape)
+        assert np.abs(g - q[k]).max() < 5e-4 * np.abs(q[k]).max() + 1e-6, k
+    # training continues correctly after the fold
+    b = batches[0]
+    l = m.train(None, _tuple(b), 0.9)
+    lo, q, _ = orc.train_step(q, cat, b, 8, cfg["regulation_rate"], lr=0.9, clip=clip)
+    assert abs(l - lo) < 2e-4 * max(1.0, abs(lo))
+
+
+def test_lazy_is_deterministic_and_untouched_rows_are_not_written():
+    cfg = make_config(U=400, I=300, C=7, d=64, regulation_rate=1e-3)
+    p = _p32(random_params(cfg, seed=61))
+    b, cat = random_batch(cfg, B=16, Sn=2, seed=62)
+    outs = []
+    for rep in range(2):
+        m = _model(cfg, cat, p, l2_mode="lazy")
+        before = m.user_emb.clone()
+        m.train(None, _tuple(b), 1.0)
+        touched = np.zeros(cfg["user_count"], bool)
+        touched[b["u"]] = True
+        same = (m.user_emb == before).all(dim=1).cpu().numpy()
+        assert same[~touched].all() and not same[touched].any()
+        outs.append(m.get_params())
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k

@@ -8,13 +8,14 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libtlsan_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 NORM_TF18, NORM_DEDUP = 0, 1
 L2_DENSE, L2_LAZY = 0, 1
 
 EXPORTS = [
     "tlsan_abi_version", "tlsan_last_error", "tlsan_dense_layout_of", "tlsan_workspace_bytes",
-    "tlsan_state_bytes", "tlsan_state_init", "tlsan_state_reindex", "tlsan_sync_derived", "tlsan_forward",
+    "tlsan_state_bytes", "tlsan_state_init", "tlsan_state_reindex", "tlsan_state_scale",
+    "tlsan_state_renorm", "tlsan_sync_derived", "tlsan_forward",
     "tlsan_train_step", "tlsan_grads", "tlsan_eval_ranks", "tlsan_profile_enable",
     "tlsan_profile_collect", "tlsan_debug_stamps", "tlsan_rows_apply_workspace", "tlsan_rows_apply",
 ]
@@ -29,7 +30,7 @@ class Dims(C.Structure):
 class Params(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
                 ("item_emb", "item_b", "user_emb", "usert_emb", "cate_emb", "dense", "dense_KT", "item_cate")] + \
-               [(n, C.c_int32) for n in ("ld_item", "ld_itemb", "ld_user", "ld_usert")]
+               [(n, C.c_int32) for n in ("ld_item", "ld_itemb", "ld_user", "ld_usert")] + [("scale", C.c_void_p)]
 
 
 class DenseLayout(C.Structure):
@@ -85,6 +86,10 @@ def load():
     lib.tlsan_sync_derived.argtypes = [P(Dims), P(Params), C.c_void_p]
     lib.tlsan_state_reindex.argtypes = [P(Dims), P(Params), C.c_void_p, C.c_void_p]
     lib.tlsan_state_reindex.restype = C.c_int
+    lib.tlsan_state_scale.argtypes = [C.c_void_p]
+    lib.tlsan_state_scale.restype = C.c_void_p
+    lib.tlsan_state_renorm.argtypes = [P(Dims), P(Params), C.c_void_p, C.c_void_p]
+    lib.tlsan_state_renorm.restype = C.c_int
     lib.tlsan_forward.argtypes = [P(Dims), P(Params), P(Batch), C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_size_t, C.c_void_p]
     lib.tlsan_train_step.argtypes = [P(Dims), P(Params), P(Batch), P(HParams), P(StepOut),

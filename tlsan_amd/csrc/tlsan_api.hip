@@ -68,7 +68,7 @@ static int shape_of(const tlsan_dims* d, Shape* s) {
 
 struct Ws {  // carve-up of the caller's scratch buffer
   float *Gi, *Gb, *Gu, *Gc, *Pc, *gLong, *gDB, *partials, *Kp, *gd, *sqd, *scal, *logits, *s_label;
-  int32_t *off_item, *off_uc, *off_user, *cur_item, *cur_uc, *cur_user;
+  int32_t *off_item, *off_uc, *off_user, *cur_item, *cur_uc, *cur_user, *uniq_item, *uniq_user;
   double* rownorm_part;
   double* rownorm;
   size_t bytes;
@@ -109,6 +109,8 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
   w->cur_item = (int32_t*)take(4 * (size_t)d->item_count);
   w->cur_uc = (int32_t*)take(4 * (size_t)d->cate_count);
   w->cur_user = (int32_t*)take(4 * (size_t)d->user_count);
+  w->uniq_item = (int32_t*)take(4 * (size_t)d->item_count);
+  w->uniq_user = (int32_t*)take(4 * (size_t)d->user_count);
   const size_t nrowblk = (size_t)(d->item_count + 15) / 16 + (d->user_count + 15) / 16 + d->cate_count;
   w->rownorm_part = (double*)take(8 * nrowblk);
   w->rownorm = (double*)take(8);
@@ -118,6 +120,7 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
 struct St {  // persistent state
   int32_t *cnt_item, *cnt_uc, *cnt_user;                  // use counters, zero at rest
   int32_t *cate_off, *cate_cnt, *cate_cur, *cate_items;   // static CSR category -> items
+  StateHdr* hdr;
   double *S_part, *S_total;
   size_t bytes;
   int nbI, nbU, nbC;
@@ -129,6 +132,7 @@ static void carve_state(const tlsan_dims* d, char* base, St* s) {
   s->nbI = (d->item_count + AP_ROWS_PB - 1) / AP_ROWS_PB;
   s->nbU = (d->user_count + AP_ROWS_PB - 1) / AP_ROWS_PB;
   s->nbC = d->cate_count;
+  s->hdr = (StateHdr*)take(sizeof(StateHdr));  // must stay first: tlsan_state_scale(state) == state
   s->cnt_item = (int32_t*)take(4 * (size_t)d->item_count);
   s->cnt_uc = (int32_t*)take(4 * (size_t)d->cate_count);
   s->cnt_user = (int32_t*)take(4 * (size_t)d->user_count);
@@ -137,7 +141,7 @@ static void carve_state(const tlsan_dims* d, char* base, St* s) {
   s->cate_cur = (int32_t*)take(4 * (size_t)d->cate_count);
   s->cate_items = (int32_t*)take(4 * (size_t)d->item_count);
   s->S_part = (double*)take(8 * (size_t)(s->nbI + s->nbU + s->nbC));
-  s->S_total = (double*)take(8);
+  s->S_total = base ? &s->hdr->St : nullptr;
   s->bytes = o;
 }
 
@@ -220,33 +224,43 @@ static void fill_apply(ApplyArgs& A, const tlsan_dims* d, const Shape& s, const 
   A.off_item = w.off_item; A.off_uc = w.off_uc; A.off_user = w.off_user;
   A.cate_off = st.cate_off; A.cate_cnt = st.cate_cnt; A.cate_items = st.cate_items;
   A.gd = w.gd; A.sqd = w.sqd; A.nsqd = w.nfin; A.scal = w.scal;
-  A.part_out = st.S_part; A.S_total = st.S_total; A.rownorm = w.rownorm;
+  A.part_out = st.S_part; A.hdr = st.hdr; A.rownorm = w.rownorm;
+  A.uniq_item = w.uniq_item; A.uniq_user = w.uniq_user;
   if (hp) { A.lr = hp->lr; A.reg = hp->reg; A.clip = hp->clip; A.norm_mode = hp->norm_mode; }
   A.inv_B = b ? 1.0f / (float)b->B : 0.0f;
   A.nbI = st.nbI; A.nbU = st.nbU; A.nbC = st.nbC; A.nbD = (L.n_dense + 255) / 256;
 }
 
-// the two launches of one apply pass: item/user rows (+ dense parameters), then category rows
-static int launch_apply(int mode, const ApplyArgs& A, bool with_dense, hipStream_t hs) {
+// the two launches of one apply pass: item/user rows (+ dense parameters), then category rows.
+// lazy (UPDATE only): the row blocks walk the compacted lists of used rows.
+static int launch_apply(int mode, bool lazy, ApplyArgs A, bool with_dense, int B, int Sn, hipStream_t hs) {
+  if (lazy) {  // at most min(rows, uses) rows were used
+    const long ni = (long)B * (A.Ls + Sn + 1);
+    A.nbI = (int)(((ni < A.I ? ni : A.I) + AP_ROWS_PB - 1) / AP_ROWS_PB);
+    A.nbU = ((B < A.U ? B : A.U) + AP_ROWS_PB - 1) / AP_ROWS_PB;
+  }
   const dim3 g1(A.nbI + A.nbU + (with_dense ? A.nbD : 0)), g2(A.nbC), blk(256);
+  const bool wide = A.D > 128 || A.WU > 128;  // float4 chunks per lane: 2 (<= 128 columns) or 4
+#define AP_LAUNCH(M, LZ)                                                                   \
+  do {                                                                                     \
+    if (wide) {                                                                            \
+      hipLaunchKernelGGL((k_apply_rows<M, LZ, 4>), g1, blk, 0, hs, A);                     \
+      hipLaunchKernelGGL((k_apply_cates<M, LZ, 4>), g2, blk, 0, hs, A);                    \
+    } else {                                                                               \
+      hipLaunchKernelGGL((k_apply_rows<M, LZ, 2>), g1, blk, 0, hs, A);                     \
+      hipLaunchKernelGGL((k_apply_cates<M, LZ, 2>), g2, blk, 0, hs, A);                    \
+    }                                                                                      \
+  } while (0)
   switch (mode) {
     case AP_UPDATE:
-      hipLaunchKernelGGL(k_apply_rows<AP_UPDATE>, g1, blk, 0, hs, A);
-      hipLaunchKernelGGL(k_apply_cates<AP_UPDATE>, g2, blk, 0, hs, A);
+      if (lazy) AP_LAUNCH(AP_UPDATE, true);
+      else AP_LAUNCH(AP_UPDATE, false);
       break;
-    case AP_GRADS:
-      hipLaunchKernelGGL(k_apply_rows<AP_GRADS>, g1, blk, 0, hs, A);
-      hipLaunchKernelGGL(k_apply_cates<AP_GRADS>, g2, blk, 0, hs, A);
-      break;
-    case AP_SUMSQ:
-      hipLaunchKernelGGL(k_apply_rows<AP_SUMSQ>, g1, blk, 0, hs, A);
-      hipLaunchKernelGGL(k_apply_cates<AP_SUMSQ>, g2, blk, 0, hs, A);
-      break;
-    default:
-      hipLaunchKernelGGL(k_apply_rows<AP_ROWNORM>, g1, blk, 0, hs, A);
-      hipLaunchKernelGGL(k_apply_cates<AP_ROWNORM>, g2, blk, 0, hs, A);
-      break;
+    case AP_GRADS: AP_LAUNCH(AP_GRADS, false); break;
+    case AP_SUMSQ: AP_LAUNCH(AP_SUMSQ, false); break;
+    default: AP_LAUNCH(AP_ROWNORM, false); break;
   }
+#undef AP_LAUNCH
   CHECK_LAUNCH("k_apply_rows / k_apply_cates");
   return TLSAN_OK;
 }
@@ -301,10 +315,35 @@ int tlsan_state_init(const tlsan_dims* d, const tlsan_params* p, void* state, vo
   memset(&w, 0, sizeof(w));
   ApplyArgs A;
   fill_apply(A, d, s, p, nullptr, nullptr, w, st, L);
+  static const float one = 1.0f;  // table scale P = 1
+  if (hipMemcpyAsync(&st.hdr->P, &one, sizeof(float), hipMemcpyHostToDevice, hs) != hipSuccess) return fail(TLSAN_E_LAUNCH, "init P");
   if ((rc = build_cate_csr(d, p, st, hs))) return rc;
-  if ((rc = launch_apply(AP_SUMSQ, A, false, hs))) return rc;
+  if ((rc = launch_apply(AP_SUMSQ, false, A, false, 0, 0, hs))) return rc;
   hipLaunchKernelGGL(k_reduce_double, dim3(1), dim3(256), 0, hs, st.S_part, st.nbI + st.nbU + st.nbC, st.S_total);
   CHECK_LAUNCH("k_reduce_double");
+  // from here on S_part carries per-step CHANGES (consumed and cleared by k_dense_finalize)
+  if (hipMemsetAsync(st.S_part, 0, 8 * (size_t)(st.nbI + st.nbU + st.nbC), hs) != hipSuccess) return fail(TLSAN_E_LAUNCH, "memset S_part");
+  return TLSAN_OK;
+}
+
+const float* tlsan_state_scale(const void* state) { return (const float*)state; }
+
+int tlsan_state_renorm(const tlsan_dims* d, const tlsan_params* p, void* state, void* stream) {
+  Shape s;
+  int rc = shape_of(d, &s);
+  if (rc) return rc;
+  if ((rc = check_params(p))) return rc;
+  if (!state) return fail(TLSAN_E_WORKSPACE, "state is NULL");
+  St st;
+  carve_state(d, (char*)state, &st);
+  const tlsan_params q = norm_params(p, d);
+  hipStream_t hs = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_scale_table, dim3(1024), dim3(256), 0, hs, q.item_emb, d->item_count, d->d_item, q.ld_item, st.hdr);
+  hipLaunchKernelGGL(k_scale_table, dim3(1024), dim3(256), 0, hs, q.user_emb, d->user_count, d->d_item, q.ld_user, st.hdr);
+  hipLaunchKernelGGL(k_scale_table, dim3(256), dim3(256), 0, hs, q.usert_emb, d->user_count, d->Ls, q.ld_usert, st.hdr);
+  hipLaunchKernelGGL(k_scale_table, dim3(64), dim3(256), 0, hs, q.cate_emb, d->cate_count, d->d_cate, d->d_cate, st.hdr);
+  hipLaunchKernelGGL(k_renorm_commit, dim3(1), dim3(1), 0, hs, st.hdr);
+  CHECK_LAUNCH("tlsan_state_renorm");
   return TLSAN_OK;
 }
 
@@ -317,7 +356,8 @@ int tlsan_state_reindex(const tlsan_dims* d, const tlsan_params* p, void* state,
   St st;
   carve_state(d, (char*)state, &st);
   hipStream_t hs = (hipStream_t)stream;
-  if (hipMemsetAsync(state, 0, st.bytes, hs) != hipSuccess) return fail(TLSAN_E_LAUNCH, "memset state");
+  const size_t skip = al(sizeof(StateHdr));  // keep P / St
+  if (hipMemsetAsync((char*)state + skip, 0, st.bytes - skip, hs) != hipSuccess) return fail(TLSAN_E_LAUNCH, "memset state");
   return build_cate_csr(d, p, st, hs);
 }
 
@@ -377,6 +417,7 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   hipLaunchKernelGGL(k_count, dim3((nthr + 255) / 256), dim3(256), 0, hs, ca);
   CHECK_LAUNCH("k_count");
   ScanArgs sa;
+  memset(&sa, 0, sizeof(sa));
   sa.cnt[0] = st.cnt_item; sa.cnt[1] = st.cnt_uc; sa.cnt[2] = st.cnt_user;
   sa.off[0] = w.off_item; sa.off[1] = w.off_uc; sa.off[2] = w.off_user;
   sa.cur[0] = w.cur_item; sa.cur[1] = w.cur_uc; sa.cur[2] = w.cur_user;
@@ -385,6 +426,8 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   sa.blk0[1] = (sa.n[0] + 4095) / 4096;
   sa.blk0[2] = sa.blk0[1] + (sa.n[1] + 4095) / 4096;
   const int nscan = sa.blk0[2] + (sa.n[2] + 4095) / 4096;
+  sa.uniq[0] = w.uniq_item; sa.uniq[1] = nullptr; sa.uniq[2] = w.uniq_user;
+  sa.n_uniq[0] = &st.hdr->n_uniq_item; sa.n_uniq[1] = nullptr; sa.n_uniq[2] = &st.hdr->n_uniq_user;
   hipLaunchKernelGGL(k_index_scan, dim3(nscan), dim3(1024), 0, hs, sa);
   CHECK_LAUNCH("k_index_scan");
   // --- fused forward + backward
@@ -429,7 +472,11 @@ static int prep_step(const tlsan_dims* d, Shape* s, const tlsan_params* p, const
   if ((rc = check_params(p))) return rc;
   if ((rc = check_batch(d, b, true))) return rc;
   if (!hp) return fail(TLSAN_E_BADARG, "hparams is NULL");
-  if (hp->l2_mode != TLSAN_L2_DENSE) return fail(TLSAN_E_UNSUPPORTED, "l2_mode: only TLSAN_L2_DENSE in this build");
+  if (hp->l2_mode != TLSAN_L2_DENSE && hp->l2_mode != TLSAN_L2_LAZY) return fail(TLSAN_E_BADARG, "l2_mode");
+  if (hp->l2_mode == TLSAN_L2_LAZY) {
+    if (hp->norm_mode != TLSAN_NORM_TF18) return fail(TLSAN_E_UNSUPPORTED, "TLSAN_L2_LAZY supports norm_mode TF18 only");
+    if (p->scale != tlsan_state_scale(state)) return fail(TLSAN_E_BADARG, "TLSAN_L2_LAZY needs params->scale == tlsan_state_scale(state)");
+  }
   if (hp->norm_mode != TLSAN_NORM_TF18 && hp->norm_mode != TLSAN_NORM_DEDUP) return fail(TLSAN_E_BADARG, "norm_mode");
   if (!state || !ws) return fail(TLSAN_E_WORKSPACE, "state / ws is NULL");
   carve(d, *s, b->B, b->Sn, (char*)ws, w);
@@ -456,11 +503,11 @@ int tlsan_train_step(const tlsan_dims* d, const tlsan_params* p, const tlsan_bat
   if (hp->norm_mode == TLSAN_NORM_DEDUP) {
     ApplyArgs R = A;
     R.part_out = w.rownorm_part;
-    if ((rc = launch_apply(AP_ROWNORM, R, false, hs))) return rc;
+    if ((rc = launch_apply(AP_ROWNORM, false, R, false, b->B, b->Sn, hs))) return rc;
     hipLaunchKernelGGL(k_reduce_double, dim3(1), dim3(256), 0, hs, w.rownorm_part, nrow, w.rownorm);
     CHECK_LAUNCH("k_reduce_double");
   }
-  if ((rc = launch_apply(AP_UPDATE, A, true, hs))) return rc;
+  if ((rc = launch_apply(AP_UPDATE, hp->l2_mode == TLSAN_L2_LAZY, A, true, b->B, b->Sn, hs))) return rc;
   prof_mark(5, hs);
   if (g_prof_level > 0 && g_prof_n < PROF_MAX_STEPS) ++g_prof_n;
   return TLSAN_OK;
@@ -487,11 +534,11 @@ int tlsan_grads(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch* b
   if (hp->norm_mode == TLSAN_NORM_DEDUP) {
     ApplyArgs R = A;
     R.part_out = w.rownorm_part;
-    if ((rc = launch_apply(AP_ROWNORM, R, false, hs))) return rc;
+    if ((rc = launch_apply(AP_ROWNORM, false, R, false, b->B, b->Sn, hs))) return rc;
     hipLaunchKernelGGL(k_reduce_double, dim3(1), dim3(256), 0, hs, w.rownorm_part, nrow, w.rownorm);
     CHECK_LAUNCH("k_reduce_double");
   }
-  if ((rc = launch_apply(AP_GRADS, A, true, hs))) return rc;
+  if ((rc = launch_apply(AP_GRADS, false, A, true, b->B, b->Sn, hs))) return rc;
   prof_mark(5, hs);
   if (g_prof_level > 0 && g_prof_n < PROF_MAX_STEPS) ++g_prof_n;
   return TLSAN_OK;

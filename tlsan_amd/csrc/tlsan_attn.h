@@ -308,6 +308,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 
   const float* dn = a.p.dense;
   const float gamma = dn[a.lay.gamma];
+  const float P = a.p.scale ? *a.p.scale : 1.0f;  // tables hold W / P (lazy L2 decay)
   const int Ls = a.Ls, Sn = a.b.Sn, B = a.b.B;
   // attention weights -> LDS once per workgroup (both blocks are contiguous runs of `dense`)
   if constexpr (USE_SW) {
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         const float ht = a.b.hist_t[(size_t)bb * Ls + pc];
         const float ut = a.p.usert_emb[(size_t)uid * a.p.ld_usert + pc];
         const bool vp = p < n_l;
-        sc1[p] = vp ? gamma * (ut * ht) : 0.0f;  // model.py:100-102,109
+        sc1[p] = vp ? (gamma * P * P) * (ut * ht) : 0.0f;  // model.py:100-102,109 (e1 and ut are stored / P)
         if (TRAIN && lead) {
           sH[srow * 2 * LS + p] = vp ? ht : 0.0f;
           sH[srow * 2 * LS + LS + p] = vp ? ut * ht : 0.0f;
@@ -407,8 +408,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       const int c = chb[kb];
       const float* up = (c < a.di) ? a.p.user_emb + (size_t)uid * a.p.ld_user + c
                                    : a.p.cate_emb + (size_t)a.b.u_cate[bb] * a.dc + (c - a.di);
-      uemb[kb] = *(const f32x4*)up;
-      iemb[kb] = gather_item4(a, it_i, c);
+      uemb[kb] = *(const f32x4*)up * P;
+      iemb[kb] = gather_item4(a, it_i, c) * P;
     }
     const float ib_i = a.p.item_b[(size_t)it_i * a.p.ld_itemb];
 
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       const bool vt = t < n_s;
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb) {
-        const f32x4 v = gather_item4c(a, it, ct, chb[kb]);
+        const f32x4 v = gather_item4c(a, it, ct, chb[kb]) * P;
         xr[kb] = vt ? v : (f32x4)(0.0f);
       }
     };
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       const int it_j = a.b.j[bb];
       float pj = 0.0f;
 #pragma unroll
-      for (int kb = 0; kb < NB; ++kb) pj += dot4(ut4[kb], gather_item4(a, it_j, chb[kb]));
+      for (int kb = 0; kb < NB; ++kb) pj += dot4(ut4[kb], gather_item4(a, it_j, chb[kb]) * P);
       const float lj = sample_sum<CPS>(pj) + a.p.item_b[(size_t)it_j * a.p.ld_itemb];
       if (lead && vs) a.logits_j[bidx] = lj;
     }
@@ -701,7 +702,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           dsp[p] = 0.0f;
           if (p < pmax1) {
             const bool vp = p < n_l;
-            const float scp = gamma * sH[srow * 2 * LS + LS + p];
+            const float uth = sH[srow * 2 * LS + LS + p];
+            const float scp = (gamma * P * P) * uth;  // x = e_stored * scp
+            const float sce = (gamma * P) * uth;      // d x / d e_true
             f32x4 xv[NB], z1[NB], zr[NB], m2[NB], av[NB], dx[NB];
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) xv[kb] = e1[p][kb] * scp;
@@ -731,7 +734,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
               if (lead) a.Gb[pos] = 0.0f;
 #pragma unroll
               for (int kb = 0; kb < NB; ++kb) {
-                const f32x4 de = dx[kb] * scp;
+                const f32x4 de = dx[kb] * sce;
                 *(f32x4*)(a.Gi + (size_t)pos * D + chb[kb]) = de;
                 sq_acc += dot4(de, de);
               }
@@ -742,13 +745,13 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         // usert_emb / gamma gradients: batched cross-lane reductions (independent chains)
 #pragma unroll
         for (int p = 0; p < LS; ++p) {
-          const float ds = sample_sum<CPS>(dsp[p]);
+          const float ds = sample_sum<CPS>(dsp[p]) * P;  // d loss / d scale[p] (e_true = P * e_stored)
           if (lead && vs && p < Ls) {
             const bool vp = p < n_l;
             const float gt = vp ? ds * (gamma * sH[srow * 2 * LS + p]) : 0.0f;  // d / d usert_emb[u][p]
             a.Gu[(size_t)sP[srow * PSTR + P_USR] * a.WU + a.di + p] = gt;  // padded slots: 0
             sq_acc += gt * gt;
-            dgam += vp ? ds * sH[srow * 2 * LS + LS + p] : 0.0f;
+            dgam += vp ? ds * (P * sH[srow * 2 * LS + LS + p]) : 0.0f;
           }
         }
         if (lead && vs)

@@ -53,7 +53,8 @@ __global__ __launch_bounds__(64) void k_eval_label(EvalArgs a) {
   load_user_frag<D>(a, u0, q, r, af);
   const int u = u0 + r;
   const int item = (u < a.B) ? a.labels[u] : 0;
-  const f32x4 acc = score_tile<D>(a, af, item, q);
+  const float P = a.p.scale ? *a.p.scale : 1.0f;
+  const f32x4 acc = score_tile<D>(a, af, item, q) * P;
   const float bias = a.p.item_b[(size_t)item * a.p.ld_itemb];
   // diagonal: user (4q+i) == column r
   if (u < a.B && q == (r >> 2)) {
@@ -81,12 +82,13 @@ __global__ __launch_bounds__(256) void k_eval_rank(EvalArgs a) {
     lab[i] = (u < a.B) ? a.labels[u] : -1;
     cnt[i] = 0;
   }
+  const float P = a.p.scale ? *a.p.scale : 1.0f;
   const int ntiles = (a.I + 15) / 16;
   for (int t = blockIdx.y * 4 + wave; t < ntiles; t += gridDim.y * 4) {
     const int n = t * 16 + r;
     const bool vn = n < a.I;
     const int item = vn ? n : a.I - 1;
-    const f32x4 acc = score_tile<D>(a, af, item, q);
+    const f32x4 acc = score_tile<D>(a, af, item, q) * P;
     const float bias = a.p.item_b[(size_t)item * a.p.ld_itemb];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

@@ -12,6 +12,17 @@
 #pragma once
 #include "tlsan_common.h"
 
+// first bytes of the persistent state buffer
+struct StateHdr {
+  float P;                 // scale of the four regularised tables: W_true = P * W_stored (1 unless lazy L2)
+  float pad0;
+  int32_t n_uniq_item;     // rows that received a gradient in the current step (k_index_scan)
+  int32_t n_uniq_user;
+  int32_t ticket;          // arrival counter of k_apply_cates: the last workgroup commits P
+  int32_t pad1;
+  double St;               // sum of squares of the four STORED tables (true value: P^2 * St)
+};
+
 struct CountArgs {
   tlsan_batch b;
   int32_t Ls;
@@ -45,16 +56,19 @@ struct ScanArgs {
   int32_t* off[3];
   int32_t* cur[3];
   int32_t n[3];
-  int32_t blk0[3];  // first block of each table in the grid
+  int32_t blk0[3];     // first block of each table in the grid
+  int32_t* uniq[3];    // optional: ids with cnt > 0, ascending (lazy L2: rows to update)
+  int32_t* n_uniq[3];  // optional: how many
 };
 
 // Exclusive scan of the per-row counts, one launch: block j of a table owns ids
 // [4096 j, 4096 j + 4096); it first sums every count that precedes its chunk (coalesced
 // re-read of at most n ints from L2: cheaper than a second launch or a serial carry chain),
-// then scans its own chunk.
+// then scans its own chunk.  The number of non-zero counts is scanned alongside (high 32 bits
+// of a packed 64-bit sum) to compact the list of used rows.
 __global__ __launch_bounds__(1024) void k_index_scan(ScanArgs a) {
-  __shared__ int wsum[16];
-  __shared__ int prefix;
+  __shared__ long long wsum[16];
+  __shared__ long long prefix;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int which = 0;
   if ((int)blockIdx.x >= a.blk0[1]) which = 1;
@@ -62,49 +76,55 @@ __global__ __launch_bounds__(1024) void k_index_scan(ScanArgs a) {
   const int32_t* __restrict__ cnt = a.cnt[which];
   const int n = a.n[which];
   const int base = ((int)blockIdx.x - a.blk0[which]) * 4096;
-  // ---- sum of cnt[0, base)
-  int part = 0;
+  auto pack = [](int c) { return (long long)c + ((long long)(c > 0) << 32); };
+  // ---- packed sum over cnt[0, base)
+  long long part = 0;
   for (int k = tid * 4; k < base; k += 4096) {
     const int4 v = *(const int4*)(cnt + k);  // base is a multiple of 4096 -> always in range
-    part += v.x + v.y + v.z + v.w;
+    part += pack(v.x) + pack(v.y) + pack(v.z) + pack(v.w);
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
   if (lane == 0) wsum[wave] = part;
   __syncthreads();
   if (tid == 0) {
-    int t = 0;
+    long long t = 0;
 #pragma unroll
     for (int w = 0; w < 16; ++w) t += wsum[w];
     prefix = t;
   }
+  __syncthreads();
+  const long long pre = prefix;
   __syncthreads();
   // ---- own chunk
   const int i0 = base + tid * 4;
   int v[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) v[k] = (i0 + k < n) ? cnt[i0 + k] : 0;
-  const int tsum = v[0] + v[1] + v[2] + v[3];
-  int inc = tsum;
+  const long long tsum = pack(v[0]) + pack(v[1]) + pack(v[2]) + pack(v[3]);
+  long long inc = tsum;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(inc, o);
+    const long long t = __shfl_up(inc, o);
     if (lane >= o) inc += t;
   }
   if (lane == 63) wsum[wave] = inc;
   __syncthreads();
-  int run = prefix + inc - tsum;
+  long long run = pre + inc - tsum;
 #pragma unroll
   for (int w = 0; w < 16; ++w) run += (w < wave) ? wsum[w] : 0;
   int32_t* off = a.off[which];
   int32_t* cur = a.cur[which];
+  int32_t* uniq = a.uniq[which];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     if (i0 + k < n) {
-      off[i0 + k] = run;
-      cur[i0 + k] = run;
+      off[i0 + k] = (int)(run & 0xffffffffLL);
+      cur[i0 + k] = (int)(run & 0xffffffffLL);
+      if (uniq && v[k] > 0) uniq[(int)(run >> 32)] = i0 + k;
+      run += pack(v[k]);
+      if (i0 + k == n - 1 && a.n_uniq[which]) *a.n_uniq[which] = (int)(run >> 32);
     }
-    run += v[k];
   }
 }
 
@@ -157,7 +177,7 @@ struct FinArgs {
   float* gd;              // [n_dense] reduced dense gradients
   float* sqd;             // [nbK + nbS] per-block sum of gd^2
   float* scal;            // [0] = sum of per-sample BCE, [1] = sum of squares of per-use rows
-  const double* S_part;   // per-row-block sums of squares of the regularised tables
+  double* S_part;         // per-row-block changes of the regularised tables' sum of squares
   int32_t n_spart;
   double* S_total;
 };
@@ -188,8 +208,11 @@ __global__ __launch_bounds__(256) void k_dense_finalize(FinArgs a, int nbK, int 
   const int tid = threadIdx.x, blk = blockIdx.x;
   const tlsan_dense_layout& L = a.lay;
   if (blk == nbK + nbS) {
+    // the apply kernels leave per-workgroup CHANGES of the tables' sum of squares: fold them in
+    // and clear them (consumed exactly once)
     const double s = block_sum_double(a.S_part, a.n_spart, shd);
-    if (tid == 0) *a.S_total = s;
+    for (int k = tid; k < a.n_spart; k += 256) a.S_part[k] = 0.0;
+    if (tid == 0) *a.S_total += s;
     return;
   }
   float g = 0.0f;
@@ -289,10 +312,12 @@ struct ApplyArgs {
   float* Pc;                                   // [I, dc] per-item sums of the category halves
   int32_t* cnt_item; int32_t* cnt_user; int32_t* cnt_uc;
   const int32_t* off_item; const int32_t* off_user; const int32_t* off_uc;
+  const int32_t* uniq_item; const int32_t* uniq_user;   // lazy L2: rows used this step
   const int32_t* cate_off; const int32_t* cate_cnt; const int32_t* cate_items;  // static CSR
   const float* gd; const float* sqd; int32_t nsqd; const float* scal;
-  double* part_out;        // UPDATE/SUMSQ: new sums of squares per row block; ROWNORM: sum g^2
-  const double* S_total;   // sum of squares of the four regularised tables (current params)
+  double* part_out;        // UPDATE: change of the stored tables' sum of squares per workgroup;
+                           // SUMSQ: sum of squares; ROWNORM: sum g^2
+  StateHdr* hdr;           // P, St, n_uniq_*, ticket
   const double* rownorm;   // dedup mode: sum over rows of |g_row|^2 (from the ROWNORM pass)
   float lr, reg, clip, inv_B;
   int32_t norm_mode;
@@ -302,14 +327,14 @@ struct ApplyArgs {
 
 #define AP_OWN 8        // uses a 16-lane group sums alone before the wavefront helps
 #define AP_ROWS_PB 16   // item / user rows per workgroup (4 wavefronts x 4 groups)
-#define AP_NCH 4        // 16 lanes x 4 chunks x 4 floats = up to 256 columns (d = 256 item rows)
 
 // exact sum of rows lo, lo+stride, ... < hi of a [.., ld] buffer (columns 4*c4..), 4 in flight
+template <int NCH>
 __device__ __forceinline__ void seg_accum(const float* __restrict__ Gs, int ld, int lo, int hi, int stride,
-                                          int W4, int l16, double (&acc)[AP_NCH][4]) {
+                                          int W4, int l16, double (&acc)[NCH][4]) {
   for (int k = lo; k < hi; k += 4 * stride) {
 #pragma unroll
-    for (int ch = 0; ch < AP_NCH; ++ch) {
+    for (int ch = 0; ch < NCH; ++ch) {
       const int c4 = l16 + 16 * ch;
       if (c4 < W4) {
         f32x4 v[4];
@@ -325,17 +350,19 @@ __device__ __forceinline__ void seg_accum(const float* __restrict__ Gs, int ld, 
   }
 }
 
-__device__ __forceinline__ void zero_acc(double (&acc)[AP_NCH][4]) {
+template <int NCH>
+__device__ __forceinline__ void zero_acc(double (&acc)[NCH][4]) {
 #pragma unroll
-  for (int ch = 0; ch < AP_NCH; ++ch)
+  for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[ch][i] = 0.0;
 }
 
 // sum over the four 16-lane groups of a wavefront (exact doubles -> order irrelevant)
-__device__ __forceinline__ void combine_groups(double (&acc)[AP_NCH][4]) {
+template <int NCH>
+__device__ __forceinline__ void combine_groups(double (&acc)[NCH][4]) {
 #pragma unroll
-  for (int ch = 0; ch < AP_NCH; ++ch)
+  for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       acc[ch][i] += __shfl_xor(acc[ch][i], 16);
@@ -345,13 +372,13 @@ __device__ __forceinline__ void combine_groups(double (&acc)[AP_NCH][4]) {
 
 // the global-norm clip coefficient (model.py:201), identical in every workgroup
 template <int MODE>
-__device__ __forceinline__ float clip_coef(const ApplyArgs& a, float* sh_coef, bool writer) {
+__device__ __forceinline__ float clip_coef(const ApplyArgs& a, float P, float* sh_coef, bool writer) {
   if constexpr (MODE == AP_UPDATE || MODE == AP_GRADS) {
     if (threadIdx.x == 0) {
       // tf18: per-use rows + (reg*W)^2 + dense; dedup: summed rows + dense
       double sq = 0.0;
       for (int k = 0; k < a.nsqd; ++k) sq += (double)a.sqd[k];
-      const double St = *a.S_total;
+      const double St = a.hdr->St * (double)P * (double)P;  // true tables = P * stored
       if (a.norm_mode == TLSAN_NORM_TF18)
         sq += (double)a.scal[1] + (double)a.reg * (double)a.reg * St;
       else
@@ -379,19 +406,43 @@ __device__ __forceinline__ void block_part_store(double part, double* shd, doubl
   if (threadIdx.x == 0) *dst = shd[0] + shd[1] + shd[2] + shd[3];
 }
 
+// One parameter element of a regularised table under the update of model.py:198-205.
+// Stored value w (true parameter P*w), exact gradient sum gs of the TRUE parameter.
+//   dense : w <- w - step * (gs / P + reg * w)            (every row, every step)
+//   lazy  : w <- w - (step / P_new) * gs, P_new = P (1 - step reg), P committed once per step
+// Returns the gradient (GRADS / ROWNORM) and accumulates the block partial.
+template <int MODE, bool LAZY>
+__device__ __forceinline__ float apply_elem(float& w, float gs, float P, float invP, float reg, float step,
+                                            float lazy_scale, double& part) {
+  const float g = gs + reg * (P * w);  // gradient of the true parameter
+  if constexpr (MODE == AP_SUMSQ) part += (double)w * (double)w;
+  if constexpr (MODE == AP_ROWNORM) part += (double)g * (double)g;
+  if constexpr (MODE == AP_UPDATE) {
+    const float w0 = w;
+    if constexpr (LAZY) w = w0 - lazy_scale * gs;
+    else w = w0 - step * (gs * invP + reg * w0);
+    part += (double)w * (double)w - (double)w0 * (double)w0;
+  }
+  return g;
+}
+
 // Block layout: [0,nbI) item rows, [nbI,nbI+nbU) user rows (user_emb + usert_emb): one row per
 // 16-lane group; the first AP_OWN uses of a row are summed by its group, longer segments (hot
 // items) by the whole wavefront.  Then nbD blocks of 256 dense parameters.
 // Item rows carry [item half | cate half]: the item half updates item_emb, the cate half is
 // written to Pc[item] for k_apply_cates.  User rows are [user_emb | usert_emb | pad].
-template <int MODE>
+// LAZY: the row blocks walk the compacted lists of used rows instead of every row.
+// NCH = float4 chunks per lane: 16 lanes x NCH x 4 floats >= the widest fused row (d, WU)
+template <int MODE, bool LAZY, int NCH>
 __global__ __launch_bounds__(256) void k_apply_rows(ApplyArgs a) {
   __shared__ double shd[4];
   __shared__ float sh_coef;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, grp = lane >> 4, l16 = lane & 15;
   const int D = a.D;
-  const float coef = clip_coef<MODE>(a, &sh_coef, blockIdx.x == 0);
+  const float P = a.hdr->P, invP = 1.0f / P;
+  const float coef = clip_coef<MODE>(a, P, &sh_coef, blockIdx.x == 0);
   const float step = a.lr * coef;
+  const float lazy_scale = step / (P * (1.0f - step * a.reg));
   double part = 0.0;
   const int blk = blockIdx.x;
   if (blk >= a.nbI + a.nbU) {
@@ -414,12 +465,19 @@ __global__ __launch_bounds__(256) void k_apply_rows(ApplyArgs a) {
     return;
   }
   const bool is_item = blk < a.nbI;
-  const int row = (is_item ? blk : blk - a.nbI) * AP_ROWS_PB + wave * 4 + grp;
-  const bool vr = row < (is_item ? a.I : a.U);
+  const int slot = (is_item ? blk : blk - a.nbI) * AP_ROWS_PB + wave * 4 + grp;
+  int row = slot;
+  bool vr;
+  if constexpr (LAZY) {
+    vr = slot < (is_item ? a.hdr->n_uniq_item : a.hdr->n_uniq_user);
+    row = vr ? (is_item ? a.uniq_item : a.uniq_user)[slot] : 0;
+  } else {
+    vr = row < (is_item ? a.I : a.U);
+  }
   const float* Gs = is_item ? a.Gi : a.Gu;
   const int ld = is_item ? D : a.WU;
   const int W4 = ld / 4;
-  double acc[AP_NCH][4];
+  double acc[NCH][4];
   zero_acc(acc);
   double bacc = 0.0;  // item_b gradient of the row (item rows)
   int n = 0, off = 0;
@@ -437,7 +495,7 @@ __global__ __launch_bounds__(256) void k_apply_rows(ApplyArgs a) {
       const int ng = __shfl(n, g * 16);
       if (ng > AP_OWN) {  // wave-uniform: the four groups split the rest of group g's segment
         const int og = __shfl(off, g * 16);
-        double t[AP_NCH][4];
+        double t[NCH][4];
         zero_acc(t);
         seg_accum(Gs, ld, og + AP_OWN + grp, og + ng, 4, W4, l16, t);
         double tb = 0.0;
@@ -448,7 +506,7 @@ __global__ __launch_bounds__(256) void k_apply_rows(ApplyArgs a) {
         for (int o = 1; o < 64; o <<= 1) tb += __shfl_xor(tb, o);
         if (grp == g) {
 #pragma unroll
-          for (int ch = 0; ch < AP_NCH; ++ch)
+          for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[ch][i] += t[ch][i];
           if (l16 == 0) bacc += tb;
@@ -461,7 +519,7 @@ __global__ __launch_bounds__(256) void k_apply_rows(ApplyArgs a) {
     }
     if constexpr (MODE != AP_ROWNORM) {
       if (!is_item && vr && n > 0 && l16 == 0) a.cnt_user[row] = 0;  // counters are zero at rest
-      // (cnt_item is read as the "touched" flag and reset by k_apply_cates)
+      // (cnt_item is read as the "used" flag and reset by k_apply_cates)
     }
   }
   if (vr) {
@@ -469,7 +527,7 @@ __global__ __launch_bounds__(256) void k_apply_rows(ApplyArgs a) {
     //   item rows: c < di -> item_emb[row][c];  di <= c < di+dc -> Pc[row][c-di] (not a parameter)
     //   user rows: c < di -> user_emb[row][c];  di <= c < di+Ls -> usert_emb[row][c-di]
 #pragma unroll
-    for (int ch = 0; ch < AP_NCH; ++ch) {
+    for (int ch = 0; ch < NCH; ++ch) {
       const int c = 4 * (l16 + 16 * ch);
       if (c >= ld) continue;
       if (is_item && c >= a.di) {
@@ -485,29 +543,16 @@ __global__ __launch_bounds__(256) void k_apply_rows(ApplyArgs a) {
       }
       if (c < a.di) {
         float* Wp = is_item ? a.p.item_emb + (size_t)row * a.p.ld_item + c : a.p.user_emb + (size_t)row * a.p.ld_user + c;
-        f32x4 w = *(const f32x4*)Wp;
-        if constexpr (MODE == AP_SUMSQ) {
+        f32x4 w = *(const f32x4*)Wp, g;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) part += (double)w[i] * (double)w[i];
-        } else {
-          f32x4 g;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) g[i] = (float)acc[ch][i] + a.reg * w[i];
-          if constexpr (MODE == AP_GRADS)
-            *(f32x4*)((is_item ? a.go.item_emb : a.go.user_emb) + (size_t)row * a.di + c) = g;
-          if constexpr (MODE == AP_ROWNORM) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) part += (double)g[i] * (double)g[i];
-          }
-          if constexpr (MODE == AP_UPDATE) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              w[i] -= step * g[i];
-              part += (double)w[i] * (double)w[i];
-            }
-            *(f32x4*)Wp = w;
-          }
+        for (int i = 0; i < 4; ++i) {
+          float wi = w[i];
+          g[i] = apply_elem<MODE, LAZY>(wi, (float)acc[ch][i], P, invP, a.reg, step, lazy_scale, part);
+          w[i] = wi;
         }
+        if constexpr (MODE == AP_GRADS)
+          *(f32x4*)((is_item ? a.go.item_emb : a.go.user_emb) + (size_t)row * a.di + c) = g;
+        if constexpr (MODE == AP_UPDATE) *(f32x4*)Wp = w;
       } else {  // user rows, usert_emb columns (scalar: Ls need not be a multiple of 4)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -515,20 +560,14 @@ __global__ __launch_bounds__(256) void k_apply_rows(ApplyArgs a) {
           if (p < a.Ls) {
             float* wp = a.p.usert_emb + (size_t)row * a.p.ld_usert + p;
             float w = *wp;
-            const float g = (float)acc[ch][i] + a.reg * w;
-            if constexpr (MODE == AP_SUMSQ) part += (double)w * (double)w;
+            const float g = apply_elem<MODE, LAZY>(w, (float)acc[ch][i], P, invP, a.reg, step, lazy_scale, part);
             if constexpr (MODE == AP_GRADS) a.go.usert_emb[(size_t)row * a.Ls + p] = g;
-            if constexpr (MODE == AP_ROWNORM) part += (double)g * (double)g;
-            if constexpr (MODE == AP_UPDATE) {
-              w -= step * g;
-              *wp = w;
-              part += (double)w * (double)w;
-            }
+            if constexpr (MODE == AP_UPDATE) *wp = w;
           }
         }
       }
     }
-    if (is_item && l16 == 0) {  // item_b[row]: not regularised (model.py:164-169)
+    if (is_item && l16 == 0) {  // item_b[row]: not regularised (model.py:164-169), never scaled
       const float g = (float)bacc;
       if constexpr (MODE == AP_GRADS) a.go.item_b[row] = g;
       if constexpr (MODE == AP_ROWNORM) part += (double)g * (double)g;
@@ -544,19 +583,23 @@ __global__ __launch_bounds__(256) void k_apply_rows(ApplyArgs a) {
 //   g[c] = sum over the items i of category c that were used this step of Pc[i]
 //        + sum of the u_cate uses of c (contiguous segment of Gc)            (+ reg * W)
 // The item lists are the static CSR of item_cate (built by tlsan_state_init).  Resets the item
-// and u_cate use counters (every item belongs to exactly one category).
-template <int MODE>
+// and u_cate use counters (every item belongs to exactly one category).  LAZY UPDATE: the last
+// workgroup to arrive commits the new table scale P (every other reader of P has finished).
+template <int MODE, bool LAZY, int NCH>
 __global__ __launch_bounds__(256) void k_apply_cates(ApplyArgs a) {
-  __shared__ double shd[4 * 16 * AP_NCH * 4];
+  __shared__ double shd[4 * 16 * NCH * 4];
   __shared__ double shp[4];
   __shared__ float sh_coef;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, grp = lane >> 4, l16 = lane & 15;
   const int gid = wave * 4 + grp;  // 16 groups
-  const float coef = clip_coef<MODE>(a, &sh_coef, false);
+  const float P = a.hdr->P, invP = 1.0f / P;
+  const float coef = clip_coef<MODE>(a, P, &sh_coef, false);
   const float step = a.lr * coef;
+  const float Pn = P * (1.0f - step * a.reg);
+  const float lazy_scale = step / Pn;
   const int row = blockIdx.x;
   const int W4 = a.dc / 4;
-  double acc[AP_NCH][4];
+  double acc[NCH][4];
   zero_acc(acc);
   if constexpr (MODE != AP_SUMSQ) {
     const int i0 = a.cate_off[row], ni = a.cate_cnt[row];
@@ -564,7 +607,7 @@ __global__ __launch_bounds__(256) void k_apply_cates(ApplyArgs a) {
       const int item = a.cate_items[i0 + k];
       if (a.cnt_item[item] > 0) {
 #pragma unroll
-        for (int ch = 0; ch < AP_NCH; ++ch) {
+        for (int ch = 0; ch < NCH; ++ch) {
           const int c4 = l16 + 16 * ch;
           if (c4 < W4) {
             const f32x4 v = *(const f32x4*)(a.Pc + (size_t)item * a.dc + 4 * c4);
@@ -582,18 +625,18 @@ __global__ __launch_bounds__(256) void k_apply_cates(ApplyArgs a) {
     combine_groups(acc);
     if (grp == 0) {
 #pragma unroll
-      for (int ch = 0; ch < AP_NCH; ++ch)
+      for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) shd[((wave * 16 + l16) * AP_NCH + ch) * 4 + i] = acc[ch][i];
+        for (int i = 0; i < 4; ++i) shd[((wave * 16 + l16) * NCH + ch) * 4 + i] = acc[ch][i];
     }
     __syncthreads();
     if (wave == 0 && grp == 0) {
 #pragma unroll
-      for (int ch = 0; ch < AP_NCH; ++ch)
+      for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           double s = 0.0;
-          for (int w = 0; w < 4; ++w) s += shd[((w * 16 + l16) * AP_NCH + ch) * 4 + i];
+          for (int w = 0; w < 4; ++w) s += shd[((w * 16 + l16) * NCH + ch) * 4 + i];
           acc[ch][i] = s;
         }
     }
@@ -604,34 +647,48 @@ __global__ __launch_bounds__(256) void k_apply_cates(ApplyArgs a) {
   double part = 0.0;
   if (wave == 0 && grp == 0) {
 #pragma unroll
-    for (int ch = 0; ch < AP_NCH; ++ch) {
+    for (int ch = 0; ch < NCH; ++ch) {
       const int c4 = l16 + 16 * ch;
       if (c4 < W4) {
         float* Wp = a.p.cate_emb + (size_t)row * a.dc + 4 * c4;
-        f32x4 w = *(const f32x4*)Wp;
-        if constexpr (MODE == AP_SUMSQ) {
+        f32x4 w = *(const f32x4*)Wp, g;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) part += (double)w[i] * (double)w[i];
-        } else {
-          f32x4 g;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) g[i] = (float)acc[ch][i] + a.reg * w[i];
-          if constexpr (MODE == AP_GRADS) *(f32x4*)(a.go.cate_emb + (size_t)row * a.dc + 4 * c4) = g;
-          if constexpr (MODE == AP_ROWNORM) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) part += (double)g[i] * (double)g[i];
-          }
-          if constexpr (MODE == AP_UPDATE) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              w[i] -= step * g[i];
-              part += (double)w[i] * (double)w[i];
-            }
-            *(f32x4*)Wp = w;
-          }
+        for (int i = 0; i < 4; ++i) {
+          float wi = w[i];
+          g[i] = apply_elem<MODE, LAZY>(wi, (float)acc[ch][i], P, invP, a.reg, step, lazy_scale, part);
+          w[i] = wi;
         }
+        if constexpr (MODE == AP_GRADS) *(f32x4*)(a.go.cate_emb + (size_t)row * a.dc + 4 * c4) = g;
+        if constexpr (MODE == AP_UPDATE) *(f32x4*)Wp = w;
       }
     }
   }
   if constexpr (MODE != AP_GRADS) block_part_store(part, shp, &a.part_out[a.nbI + a.nbU + row]);
+  if constexpr (MODE == AP_UPDATE && LAZY) {
+    // every workgroup read P before arriving here; the last one to arrive publishes P_new for the
+    // next kernel (kernel boundary = visibility)
+    if (tid == 0) {
+      const int t = atomicAdd(&a.hdr->ticket, 1);
+      if (t == (int)gridDim.x - 1) {
+        a.hdr->P = Pn;
+        a.hdr->ticket = 0;
+      }
+    }
+  }
+}
+
+// stored *= P for one table (tlsan_state_renorm)
+__global__ void k_scale_table(float* W, int rows, int width, int ld, const StateHdr* hdr) {
+  const float P = hdr->P;
+  const size_t n = (size_t)rows * width;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = t / width, c = t % width;
+    W[r * ld + c] *= P;
+  }
+}
+
+__global__ void k_renorm_commit(StateHdr* hdr) {
+  const double P = hdr->P;
+  hdr->St *= P * P;
+  hdr->P = 1.0f;
 }

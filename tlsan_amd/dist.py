@@ -269,7 +269,7 @@ class ShardedModel:
                      ptr(db.sl), ptr(db.sl_new), ptr(db.u_cate))
         cp = L.Params(item_c.data_ptr(), item_c.data_ptr() + 4 * self.di, user_c.data_ptr(),
                       user_c.data_ptr() + 4 * self.di, self.cate_emb.data_ptr(), self.dense.data_ptr(),
-                      self.dense_KT.data_ptr(), cate_c.data_ptr(), self.WI, self.WI, self.WU, self.WU)
+                      self.dense_KT.data_ptr(), cate_c.data_ptr(), self.WI, self.WI, self.WU, self.WU, None)
         dims = L.Dims(int(uniq_u.numel()), int(uniq_i.numel()), self.config["cate_count"], self.d, self.di, self.dc,
                       self.H, self.Ls)
         return dims, cp, cb, plan_i, plan_u, keep

@@ -99,7 +99,7 @@ class DeviceBatch:
 
 
 class Model(object):
-    def __init__(self, config, item_cate_list, device="cuda:0", seed=1234, norm_mode="tf18"):
+    def __init__(self, config, item_cate_list, device="cuda:0", seed=1234, norm_mode="tf18", l2_mode="dense"):
         self.config = config
         self.lib = L.load()
         if not torch.cuda.is_available():
@@ -126,6 +126,12 @@ class Model(object):
         if nbytes == 0:
             raise L.TlsanError("unsupported configuration: %s" % self.lib.tlsan_last_error().decode())
         self.norm_mode = {"tf18": L.NORM_TF18, "dedup": L.NORM_DEDUP}[norm_mode]
+        # l2_mode: "dense" decays every row every step like the reference's dense L2 gradient
+        # (model.py:164-172); "lazy" is the same update kept as W = P * W_stored (one global scale),
+        # touching only rows that received a gradient -- identical up to fp32 rounding.
+        self.l2_mode = {"dense": L.L2_DENSE, "lazy": L.L2_LAZY}[l2_mode]
+        if self.l2_mode == L.L2_LAZY and self.norm_mode != L.NORM_TF18:
+            raise NotImplementedError("l2_mode='lazy' supports norm_mode='tf18' only")
         icl = np.asarray(item_cate_list, np.int32)
         if icl.shape != (config["item_count"],):
             raise ValueError("item_cate_list must be [item_count]")
@@ -133,6 +139,8 @@ class Model(object):
         self._alloc_params()
         self.set_params(self.init_params(config, seed))
         self.state = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        if self.l2_mode == L.L2_LAZY:
+            self.cparams.scale = self.lib.tlsan_state_scale(self.state.data_ptr())
         self._ws = None
         self._ws_key = (0, 0)
         self._step = 0
@@ -188,7 +196,7 @@ class Model(object):
         self.dense_KT = z(cfg["hidden_units"], cfg["hidden_units"])
         self.cparams = L.Params(self.item_emb.data_ptr(), self.item_b.data_ptr(), self.user_emb.data_ptr(),
                                 self.usert_emb.data_ptr(), self.cate_emb.data_ptr(), self.dense.data_ptr(),
-                                self.dense_KT.data_ptr(), self.item_cate.data_ptr(), 0, 0, 0, 0)
+                                self.dense_KT.data_ptr(), self.item_cate.data_ptr(), 0, 0, 0, 0, None)
 
     def _dense_slices(self):
         lay, d = self.lay, self.config["hidden_units"]
@@ -229,7 +237,17 @@ class Model(object):
         if hasattr(self, "state"):
             self._sync_state()
 
+    def fold_scale(self):
+        """lazy L2: fold the table scale P into the stored tables (P = 1 afterwards)."""
+        if self.l2_mode == L.L2_LAZY:
+            L.check(self.lib.tlsan_state_renorm(C.byref(self.dims), C.byref(self.cparams), self.state.data_ptr(),
+                                                self._stream()), "tlsan_state_renorm")
+
+    def table_scale(self):
+        return float(self.state[:4].view(torch.float32).item())
+
     def get_params(self):
+        self.fold_scale()
         out = {k: getattr(self, k).detach().cpu().numpy().copy() for k in TABLE_KEYS}
         out.update(self.unpack_dense(self.dense.detach().cpu().numpy()))
         return out
@@ -259,7 +277,7 @@ class Model(object):
 
     def hparams(self, lr):
         return L.HParams(float(lr), float(self.config["regulation_rate"]), float(self.config["max_gradient_norm"]),
-                         self.norm_mode, L.L2_DENSE)
+                         self.norm_mode, self.l2_mode)
 
     # ------------------------------------------------------------------ training
     def device_batch(self, batch, is_test=False):
