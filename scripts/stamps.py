@@ -33,3 +33,13 @@ for i, n in enumerate(["P5 pos1: maps+exp", "P5 pos1: bwd_compute", "P5 pos1: bw
     print("%-24s mean %8.0f p50 %8.0f max %8.0f" % (n, fd[:, :, i][ok].mean(), np.median(fd[:, :, i][ok]), fd[:, :, i][ok].max()))
 span = s[:, :, 11].max() - s[:, :, 0].min()
 print("kernel span (first start -> last end): %.0f ticks" % span)
+p1 = d[:, :, 0]
+print("P1 percentiles:", np.percentile(p1, [1, 10, 25, 50, 75, 90, 99, 100]).astype(int))
+print("P1 mean by XCD (block%8):", [int(p1[x::8].mean()) for x in range(8)])
+print("P1 mean by wave:", [int(p1[:, w].mean()) for w in range(8)])
+blk = p1.mean(1)
+print("P1 block-mean percentiles:", np.percentile(blk, [0, 10, 50, 90, 100]).astype(int))
+start = s[:, :, 0] - s[:, :, 0].min()
+print("wave start-time percentiles (ticks after first):", np.percentile(start, [0, 10, 50, 90, 100]).astype(int))
+end = s[:, :, 11] - s[:, :, 0].min()
+print("wave end-time percentiles:", np.percentile(end, [0, 10, 50, 90, 100]).astype(int))

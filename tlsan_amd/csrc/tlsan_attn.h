@@ -344,49 +344,49 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     // back to back: three dependent round trips (ids -> categories -> rows) for all LS positions
     // together; padding is applied afterwards by selects (padded slots contribute exactly 0).
     f32x4 e1[LS][NB], long4[NB], mx1[NB], iz1[NB];
+    int posv[TRAIN ? LS + 3 : 1];
     const int pmax1 = wave_max_i32(n_l);
     {
-      float sc1[LS];
-      int its[LS];
+      // Three explicit load stages (ids/scales -> categories -> rows); sched_barrier keeps the
+      // compiler from interleaving a stage's loads with their first uses, which otherwise
+      // serialises them into one round trip per position.
+      float sc1[LS], hts[LS], uts[LS];
+      int its[LS], cts[LS];
 #pragma unroll
       for (int p = 0; p < LS; ++p) {
         const int pc = min(p, Ls - 1);
         its[p] = a.b.hist_i[(size_t)bb * Ls + pc];
-        const float ht = a.b.hist_t[(size_t)bb * Ls + pc];
-        const float ut = a.p.usert_emb[(size_t)uid * a.p.ld_usert + pc];
-        const bool vp = p < n_l;
-        sc1[p] = vp ? (gamma * P * P) * (ut * ht) : 0.0f;  // model.py:100-102,109 (e1 and ut are stored / P)
-        if (TRAIN && lead) {
-          sH[srow * 2 * LS + p] = vp ? ht : 0.0f;
-          sH[srow * 2 * LS + LS + p] = vp ? ut * ht : 0.0f;
-        }
+        hts[p] = a.b.hist_t[(size_t)bb * Ls + pc];
+        uts[p] = a.p.usert_emb[(size_t)uid * a.p.ld_usert + pc];
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int p = 0; p < LS; ++p) cts[p] = a.p.item_cate[its[p]];
       if constexpr (TRAIN) {
-        // destination-sorted row of every long use: issue all the returning atomics first, read
-        // their results afterwards (no wait inside the per-position predicates)
-        int posv[LS];
+        // destination-sorted row of every long use: issue all the returning atomics now; their
+        // results are only published to LDS after the bridge GEMM (nothing waits on them here)
 #pragma unroll
         for (int p = 0; p < LS; ++p) posv[p] = (lead && p < n_l) ? atomicAdd(&a.cur_item[its[p]], 1) : 0;
-        const int pt = (lead && vs) ? atomicAdd(&a.cur_item[it_i], 1) : 0;
-        const int pu = (lead && vs) ? atomicAdd(&a.cur_user[uid], 1) : 0;
-        const int pc = (lead && vs) ? atomicAdd(&a.cur_uc[a.b.u_cate[bb]], 1) : 0;
-        if (lead) {
-#pragma unroll
-          for (int p = 0; p < LS; ++p) sP[srow * PSTR + p] = posv[p];
-          sP[srow * PSTR + P_TGT] = pt;
-          sP[srow * PSTR + P_USR] = pu;
-          sP[srow * PSTR + P_UC] = pc;
-        }
+        posv[LS] = (lead && vs) ? atomicAdd(&a.cur_item[it_i], 1) : 0;
+        posv[LS + 1] = (lead && vs) ? atomicAdd(&a.cur_user[uid], 1) : 0;
+        posv[LS + 2] = (lead && vs) ? atomicAdd(&a.cur_uc[a.b.u_cate[bb]], 1) : 0;
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int p = 0; p < LS; ++p)
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) e1[p][kb] = gather_item4c(a, its[p], cts[p], chb[kb]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int p = 0; p < LS; ++p) {
-        const int ct = a.p.item_cate[its[p]];
         const bool vp = p < n_l;
-#pragma unroll
-        for (int kb = 0; kb < NB; ++kb) {
-          const f32x4 v = gather_item4c(a, its[p], ct, chb[kb]);
-          e1[p][kb] = vp ? v : (f32x4)(0.0f);
+        sc1[p] = vp ? (gamma * P * P) * (uts[p] * hts[p]) : 0.0f;  // model.py:100-102,109 (e1, ut stored / P)
+        if (TRAIN && lead) {
+          sH[srow * 2 * LS + p] = vp ? hts[p] : 0.0f;
+          sH[srow * 2 * LS + LS + p] = vp ? uts[p] * hts[p] : 0.0f;
         }
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) e1[p][kb] = vp ? e1[p][kb] : (f32x4)(0.0f);
       }
       float FT1[NB][NB][4], FT2[NB][NB][4];
       f32x4 b1[NB], b2[NB];
@@ -454,6 +454,15 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     // softmax so registers do not grow with the session length.
     const int n_pos = n_s + 1;  // model.py:355: rep_length = sl_new + 1
     const int pmax2 = wave_max_i32(n_pos);
+    if constexpr (TRAIN) {
+      if (lead) {
+#pragma unroll
+        for (int p = 0; p < LS; ++p) sP[srow * PSTR + p] = posv[p];
+        sP[srow * PSTR + P_TGT] = posv[LS];
+        sP[srow * PSTR + P_USR] = posv[LS + 1];
+        sP[srow * PSTR + P_UC] = posv[LS + 2];
+      }
+    }
     float FT1[NB][NB][4], FT2[NB][NB][4];
     f32x4 b1[NB], b2[NB];
     load_frag_T<DH, NB>(w2W1, q, r, FT1);
@@ -482,13 +491,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         xr[kb] = vt ? v : (f32x4)(0.0f);
       }
     };
-    if constexpr (TRAIN) {  // positions of the session uses: one returning atomic per use
-      for (int base = 0; base < pmax2 - 1; base += NL) {
-        const int t = base + kk;
-        if (vs && t < n_s) sP[srow * PSTR + LS + t] = atomicAdd(&a.cur_item[a.b.hist_i_new[(size_t)bb * Sn + t]], 1);
-      }
-    }
     load_chunk(0);
+    int spos0 = 0;  // position of session use kk (first chunk): one returning atomic per use
+    if constexpr (TRAIN) spos0 = (vs && kk < n_s) ? atomicAdd(&a.cur_item[sid], 1) : 0;
     f32x4 xnext[NB];
     if (pmax2 > 1) fetch_row(0, xnext);
     f32x4 mx[NB], Zs[NB], short4[NB];
@@ -543,6 +548,13 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         Zs[kb][i] = 1.0f / Zs[kb][i];
         short4[kb][i] *= Zs[kb][i];
       }
+    if constexpr (TRAIN) {  // publish the session positions (the atomics are long back by now)
+      if (vs && kk < n_s) sP[srow * PSTR + LS + kk] = spos0;
+      for (int base = NL; base < pmax2 - 1; base += NL) {  // sessions longer than one chunk (rare)
+        const int t = base + kk;
+        if (vs && t < n_s) sP[srow * PSTR + LS + t] = atomicAdd(&a.cur_item[a.b.hist_i_new[(size_t)bb * Sn + t]], 1);
+      }
+    }
     // u_t = short + [user_emb[u] || cate_emb[u_cate]]   (model.py:93-95,135)
     f32x4 ut4[NB];
     float part = 0.0f;

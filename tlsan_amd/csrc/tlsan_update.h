@@ -370,14 +370,22 @@ __device__ __forceinline__ void combine_groups(double (&acc)[NCH][4]) {
     }
 }
 
-// the global-norm clip coefficient (model.py:201), identical in every workgroup
+// the global-norm clip coefficient (model.py:201), identical in every workgroup: the per-block
+// squares of the dense gradients are summed by the whole workgroup (one load per thread, fixed
+// shuffle tree) instead of a serial loop on one lane
 template <int MODE>
 __device__ __forceinline__ float clip_coef(const ApplyArgs& a, float P, float* sh_coef, bool writer) {
   if constexpr (MODE == AP_UPDATE || MODE == AP_GRADS) {
+    __shared__ double sh_sq[4];
+    double sq = 0.0;
+    for (int k = threadIdx.x; k < a.nsqd; k += 256) sq += (double)a.sqd[k];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) sq += __shfl_xor(sq, o);
+    if ((threadIdx.x & 63) == 0) sh_sq[threadIdx.x >> 6] = sq;
+    __syncthreads();
     if (threadIdx.x == 0) {
       // tf18: per-use rows + (reg*W)^2 + dense; dedup: summed rows + dense
-      double sq = 0.0;
-      for (int k = 0; k < a.nsqd; ++k) sq += (double)a.sqd[k];
+      sq = (sh_sq[0] + sh_sq[1]) + (sh_sq[2] + sh_sq[3]);
       const double St = a.hdr->St * (double)P * (double)P;  // true tables = P * stored
       if (a.norm_mode == TLSAN_NORM_TF18)
         sq += (double)a.scal[1] + (double)a.reg * (double)a.reg * St;
