@@ -277,3 +277,90 @@ def test_lazy_is_deterministic_and_untouched_rows_are_not_written():
         outs.append(m.get_params())
     for k in outs[0]:
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+def test_long_sessions_and_short_window():
+    """Sessions longer than one prefetch chunk (32 ids at d=128, 16 at d=64) and Ls < 10."""
+    for d, Ls, Sn in ((128, 6, 40), (64, 4, 37), (128, 10, 70)):
+        cfg = make_config(U=40, I=120, C=6, d=d, Ls=Ls)
+        p = _p32(random_params(cfg, seed=d + Sn))
+        b, cat = random_batch(cfg, B=19, Sn=Sn, seed=Sn)
+        b["sl_new"][:3] = [Sn, Sn - 1, 33 if Sn > 33 else Sn]
+        ar = np.arange(Sn)[None, :]
+        rng = np.random.RandomState(1)
+        b["hist_i_new"] = np.where(ar < b["sl_new"][:, None], rng.randint(0, 120, (19, Sn)), 0)
+        loss, newp, info = orc.train_step(p, cat, b, 8, cfg["regulation_rate"], lr=0.5)
+        for l2 in ("dense", "lazy"):
+            m = _model(cfg, cat, p, l2_mode=l2)
+            l = m.train(None, _tuple(b), 0.5)
+            assert abs(l - loss) < 2e-4 * max(1.0, abs(loss)), (d, Ls, Sn, l2)
+            got = m.get_params()
+            for k in newp:
+                du = np.asarray(got[k], np.float64).reshape(p[k].shape) - p[k]
+                dr = newp[k] - p[k]
+                assert np.abs(du - dr).max() < 3e-4 * (np.abs(dr).max() + 1e-9) + 5e-7, (k, d, Ls, Sn, l2)
+    # sessions beyond the documented cap are rejected, not mis-computed
+    from tlsan_amd._lib import TlsanError
+    cfg = make_config(U=10, I=20, C=3, d=64)
+    b, cat = random_batch(cfg, B=4, Sn=100, seed=1)
+    m = _model(cfg, cat)
+    with pytest.raises(TlsanError):
+        m.train(None, _tuple(b), 1.0)
+
+
+def test_graph_replay_equals_eager():
+    cfg = make_config(U=200, I=150, C=9, d=128)
+    p = _p32(random_params(cfg, seed=71))
+    _, cat = random_batch(cfg, B=8, Sn=3, seed=0)
+    batches = [random_batch(cfg, B=64, Sn=3, seed=400 + s)[0] for s in range(3)]
+    outs = []
+    for mode in ("eager", "graph"):
+        m = _model(cfg, cat, p, l2_mode="lazy")
+        if mode == "graph":
+            graphs = [m.capture_step(_tuple(b), 0.7) for b in batches]
+            # capture_step runs one warm step per batch: rebuild the same starting point
+            m.set_params({k: np.asarray(v, np.float32) for k, v in p.items()})
+            for rep in range(2):
+                for g in graphs:
+                    m.replay(g)
+        else:
+            for rep in range(2):
+                for b in batches:
+                    m.train_async(_tuple(b), 0.7)
+        outs.append(m.get_params())
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+def test_full_size_batch_matches_oracle():
+    """One step at the bench shape class (B=4096 -> 256 workgroup passes, hot rows, hot categories)."""
+    from tlsan_amd import synth
+    cfg = synth.make_config("electronics", user_count=3000, item_count=2000, cate_count=40)
+    icl = synth.item_cate_list(cfg)
+    batch = synth.make_batches(cfg, 1, 4096, seed=5)[0]
+    m = _model(cfg, icl, l2_mode="lazy")
+    p = {k: np.asarray(v, np.float64) for k, v in m.get_params().items()}
+    b = orc.as_batch(batch)
+    loss, newp, info = orc.train_step(p, icl, b, 8, cfg["regulation_rate"], lr=1.0)
+    l = m.train(None, batch, 1.0)
+    assert abs(l - loss) < 1e-4 * max(1.0, abs(loss))
+    assert abs(m.last_gnorm() - info["norm"]) < 2e-4 * info["norm"]
+    got = m.get_params()
+    for k in newp:
+        du = np.asarray(got[k], np.float64).reshape(p[k].shape) - p[k]
+        dr = newp[k] - p[k]
+        assert np.abs(du - dr).max() < 3e-4 * (np.abs(dr).max() + 1e-9) + 5e-7, k
+
+
+def test_train_driver_on_real_clothing(tmp_path):
+    """tlsan_amd.train (the reference's train.py flow) on the real Clothing tuples: AUC must rise
+    from its initial value within 600 steps at the reference's hyper-parameters."""
+    import os
+    from tlsan_amd import train as T
+    ds = os.path.join(os.path.dirname(__file__), "golden", "packed_clothing.npz")
+    res = T.train(T.parse(["--dataset", ds, "--max_steps", "600", "--eval_freq", "300", "--quiet",
+                           "--model_dir", str(tmp_path / "ckpt")]))
+    assert res["steps"] == 600
+    assert 0.80 < res["init_auc"] < 0.90          # the README leak quirk: ~0.86 at random init
+    assert res["final_auc"] > res["init_auc"] + 0.003
+    assert len(res["prec"]) == 6 and 0.0 <= res["recall"][-1] <= 1.0
