@@ -42,7 +42,7 @@ typedef struct {
   int32_t d_item;     /* itemid_embedding_size (== userid_embedding_size)                        */
   int32_t d_cate;     /* cateid_embedding_size                                                  */
   int32_t num_heads;  /* 8 in every config; d/num_heads in {8,16,32}                             */
-  int32_t Ls;         /* long-term window (columns of hist_i / usert_emb), <= 10 in this build   */
+  int32_t Ls;         /* long-term window (columns of hist_i / usert_emb), <= 96 (reference max_length = 90) */
 } tlsan_dims;
 
 /* Trainable variables of model.py:58-81 + attention/dense weights, fp32, row-major.

@@ -42,7 +42,9 @@ def test_dense_layout_and_sizes():
     bad = L.Dims(100, 200, 10, 96, 48, 48, 8, 10)
     assert lib.tlsan_state_bytes(C.byref(bad)) == 0
     assert b"unsupported" in lib.tlsan_last_error()
-    bad = L.Dims(100, 200, 10, 128, 64, 64, 8, 90)
+    ok90 = L.Dims(100, 200, 10, 128, 64, 64, 8, 90)   # reference max_length: streamed long block
+    assert lib.tlsan_workspace_bytes(C.byref(ok90), 32, 4) > 0
+    bad = L.Dims(100, 200, 10, 128, 64, 64, 8, 97)
     assert lib.tlsan_workspace_bytes(C.byref(bad), 32, 4) == 0
 
 

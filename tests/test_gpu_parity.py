@@ -364,3 +364,38 @@ def test_train_driver_on_real_clothing(tmp_path):
     assert 0.80 < res["init_auc"] < 0.90          # the README leak quirk: ~0.86 at random init
     assert res["final_auc"] > res["init_auc"] + 0.003
     assert len(res["prec"]) == 6 and 0.0 <= res["recall"][-1] <= 1.0
+
+
+@pytest.mark.parametrize("d,Ls,Sn,B", [(128, 20, 3, 37), (128, 90, 5, 21), (64, 33, 2, 50), (256, 16, 2, 9)])
+def test_long_windows_streamed(d, Ls, Sn, B):
+    """Ls > 10 (BASELINE configs 3/4: seq <= 90): the long block is streamed with an online
+    softmax; forward, one training step (dense and lazy L2) and eval against the oracle."""
+    cfg = make_config(U=50, I=150, C=8, d=d, Ls=Ls, regulation_rate=1e-3)
+    p = _p32(random_params(cfg, seed=Ls + d))
+    b, cat = random_batch(cfg, B=B, Sn=Sn, seed=Ls)
+    b["sl"][:4] = [Ls, 1, Ls - 1, min(Ls, 11)]
+    ar = np.arange(Ls)[None, :]
+    b["hist_i"] = np.where(ar < b["sl"][:, None], np.random.RandomState(2).randint(0, 150, (B, Ls)), 0)
+    b["hist_t"] = np.where(ar < b["sl"][:, None], (1.0 / np.random.RandomState(3).randint(1, 13, (B, Ls))), 0).astype(np.float32)
+    ref = orc.forward(p, cat, b, 8)
+    m0 = _model(cfg, cat, p)
+    tb = dict(b); tb["j"] = b["i"][::-1].copy()
+    li, lj, ut, _ = m0.forward(_tuple(tb, True), is_test=True, want_u_t=True)
+    assert np.abs(li.cpu().numpy() - ref["logits"]).max() < LOGIT_TOL
+    assert np.abs(ut.cpu().numpy() - ref["u_t"]).max() < LOGIT_TOL
+    loss, newp, info = orc.train_step(p, cat, b, 8, cfg["regulation_rate"], lr=0.6)
+    if d == 256:  # documented limit of this build: forward/eval only for d=256 with a streamed window
+        from tlsan_amd._lib import TlsanError
+        with pytest.raises(TlsanError):
+            _model(cfg, cat, p).train(None, _tuple(b), 0.6)
+        return
+    for l2 in ("dense", "lazy"):
+        m = _model(cfg, cat, p, l2_mode=l2)
+        l = m.train(None, _tuple(b), 0.6)
+        assert abs(l - loss) < 2e-4 * max(1.0, abs(loss)), l2
+        assert abs(m.last_gnorm() - info["norm"]) < 3e-4 * info["norm"], l2
+        got = m.get_params()
+        for k in newp:
+            du = np.asarray(got[k], np.float64).reshape(p[k].shape) - p[k]
+            dr = newp[k] - p[k]
+            assert np.abs(du - dr).max() < 3e-4 * (np.abs(dr).max() + 1e-9) + 5e-7, (k, l2)

@@ -11,9 +11,9 @@
 #include "tlsan_update.h"
 #include "tlsan_rows.h"
 
-hipError_t tlsan_launch_fwd_bwd_d64(bool train, const FwdArgs& a, int grid, hipStream_t st);
-hipError_t tlsan_launch_fwd_bwd_d128(bool train, const FwdArgs& a, int grid, hipStream_t st);
-hipError_t tlsan_launch_fwd_bwd_d256(bool train, const FwdArgs& a, int grid, hipStream_t st);
+hipError_t tlsan_launch_fwd_bwd_d64(bool train, bool lstream, const FwdArgs& a, int grid, hipStream_t st);
+hipError_t tlsan_launch_fwd_bwd_d128(bool train, bool lstream, const FwdArgs& a, int grid, hipStream_t st);
+hipError_t tlsan_launch_fwd_bwd_d256(bool train, bool lstream, const FwdArgs& a, int grid, hipStream_t st);
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, ...) {
@@ -55,7 +55,7 @@ static int shape_of(const tlsan_dims* d, Shape* s) {
   if (d->d_item + d->d_cate != D) return fail(TLSAN_E_BADARG, "d_item + d_cate != d (model.py:100-109)");
   if (d->d_item % 4 || d->d_cate % 4 || d->d_item > 128 || d->d_cate > 128)
     return fail(TLSAN_E_UNSUPPORTED, "embedding widths must be multiples of 4 and <= 128");
-  if (d->Ls < 1 || d->Ls > TLSAN_LS_MAX) return fail(TLSAN_E_UNSUPPORTED, "Ls must be in 1..%d", TLSAN_LS_MAX);
+  if (d->Ls < 1 || d->Ls > TLSAN_LS_CAP) return fail(TLSAN_E_UNSUPPORTED, "Ls must be in 1..%d", TLSAN_LS_CAP);
   if (d->user_count < 1 || d->item_count < 1 || d->cate_count < 1) return fail(TLSAN_E_BADARG, "empty table");
   s->D = D;
   s->DH = DH;
@@ -364,9 +364,12 @@ int tlsan_state_reindex(const tlsan_dims* d, const tlsan_params* p, void* state,
 static int launch_fwd(const Shape& s, bool train, const FwdArgs& a, hipStream_t hs) {
   int grid = a.ngroups < 4096 ? a.ngroups : 4096;
   hipError_t e;
-  if (s.D == 64) e = tlsan_launch_fwd_bwd_d64(train, a, grid, hs);
-  else if (s.D == 128) e = tlsan_launch_fwd_bwd_d128(train, a, grid, hs);
-  else e = tlsan_launch_fwd_bwd_d256(train, a, grid, hs);
+  const bool lstream = a.Ls > TLSAN_LS_MAX;  // long windows are streamed, short ones stay in registers
+  if (train && lstream && s.D == 256)
+    return fail(TLSAN_E_UNSUPPORTED, "training with hidden_units=256 and Ls > %d needs more LDS than one CU has in this build", TLSAN_LS_MAX);
+  if (s.D == 64) e = tlsan_launch_fwd_bwd_d64(train, lstream, a, grid, hs);
+  else if (s.D == 128) e = tlsan_launch_fwd_bwd_d128(train, lstream, a, grid, hs);
+  else e = tlsan_launch_fwd_bwd_d256(train, lstream, a, grid, hs);
   if (e != hipSuccess) return fail(TLSAN_E_LAUNCH, "k_fwd_bwd: %s", hipGetErrorString(e));
   return TLSAN_OK;
 }

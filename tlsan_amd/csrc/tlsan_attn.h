@@ -276,24 +276,44 @@ __device__ __forceinline__ void reduce_staged(const float* __restrict__ stage, f
   }
 }
 
-template <int D, int DH, bool TRAIN>
+// one online-softmax step of a streamed attention block (running max mx, sum Z, weighted sum N)
+template <int NB>
+__device__ __forceinline__ void online_step(f32x4 (&mx)[NB], f32x4 (&Z)[NB], f32x4 (&N)[NB],
+                                            const f32x4 (&m2)[NB], const f32x4 (&xv)[NB]) {
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float mn = fmaxf(mx[kb][i], m2[kb][i]);
+      const float so = __expf(mx[kb][i] - mn), ev = __expf(m2[kb][i] - mn);
+      Z[kb][i] = Z[kb][i] * so + ev;
+      N[kb][i] = N[kb][i] * so + ev * xv[kb][i];
+      mx[kb][i] = mn;
+    }
+}
+
+// LSTREAM: the long block is streamed like the short one (any Ls <= TLSAN_LS_CAP); otherwise its
+// Ls <= TLSAN_LS_MAX positions stay in registers between forward and backward.
+template <int D, int DH, bool TRAIN, bool LSTREAM>
 __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   using G = Geo<D, DH>;
   constexpr int NB = G::NB, CPS = G::CPS, SPW = G::SPW, NW = G::NW, NSB = G::NSB;
-  constexpr int LS = TLSAN_LS_MAX, LSTR = G::LSTR, TSTR = G::TSTR, CW = G::CW;
+  constexpr int LS = LSTREAM ? 1 : TLSAN_LS_MAX;             // positions held in registers
+  constexpr int LSC = LSTREAM ? TLSAN_LS_CAP : TLSAN_LS_MAX;  // position slots in the LDS tables
+  constexpr int LSTR = G::LSTR, TSTR = G::TSTR, CW = G::CW;
   constexpr int TB = G::TBUF;                 // floats of one transpose buffer
   constexpr int NBUF = G::NBUF;               // 2: dW of position p overlaps position p+1
   constexpr int WB = 2 * DH * DH + 2 * DH;    // floats of one attention block's weights
   constexpr bool USE_SW = G::USE_SW;          // attention weights staged in LDS (when they fit)
-  constexpr int PSTR = G::PSTR;               // per-sample position slots: LS long, SN_CAP session, 3 singles
-  constexpr int P_TGT = LS + TLSAN_SN_CAP, P_USR = P_TGT + 1, P_UC = P_TGT + 2;
+  constexpr int PSTR = LSC + TLSAN_SN_CAP + 4;  // per-sample position slots: long, session, 3 singles
+  constexpr int P_TGT = LSC + TLSAN_SN_CAP, P_USR = P_TGT + 1, P_UC = P_TGT + 2;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;                   // [NSB][LSTR]  long -> dbridge
   float* sB = sA + NSB * LSTR;        // [NSB][LSTR]  bridge -> dlong
   float* sS = sB + NSB * LSTR;        // [NW][4] scalar staging
   float* sH = sS + NW * 4;            // [NSB][2*LS] hist_t and usert*hist_t of the pass
-  float* sW = sH + NSB * 2 * LS;      // [2][WB] attention weights (W1,b1,W2,b2) of both blocks
+  float* sW = sH + NSB * 2 * LSC;     // [2][WB] attention weights (W1,b1,W2,b2) of both blocks
   int* sP = (int*)(sW + (USE_SW ? 2 * WB : 0));  // [NSB][PSTR] destination-sorted row of every use
   float* sT = (float*)(sP + (TRAIN ? NSB * PSTR : 0));  // per-wave transpose scratch / staging
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -346,6 +366,83 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     f32x4 e1[LS][NB], long4[NB], mx1[NB], iz1[NB];
     int posv[TRAIN ? LS + 3 : 1];
     const int pmax1 = wave_max_i32(n_l);
+    // ---- streamed long block (LSTREAM): ids, scales and positions live one per lane of the sample
+    // (lane kk = entry base + kk of the current chunk) and are broadcast with cross-lane reads
+    constexpr int NLc = 4 * CPS;
+    const int kkl = q * CPS + col;
+    int lid = 0, lct = 0;
+    float lht = 0.0f, lut = 0.0f;
+    auto load_lchunk = [&](int base) {
+      const int t = min(base + kkl, Ls - 1);
+      lid = a.b.hist_i[(size_t)bb * Ls + t];
+      lht = a.b.hist_t[(size_t)bb * Ls + t];
+      lut = a.p.usert_emb[(size_t)uid * a.p.ld_usert + t];
+      lct = a.p.item_cate[lid];
+    };
+    auto fetch_lrow = [&](int p, f32x4 (&xr)[NB], float& scx, float& sce) {  // position p of the loaded chunk
+      const int k = p % NLc;
+      const int src = (k / CPS) * 16 + s_loc * CPS + (k % CPS);
+      const int it = __shfl(lid, src), ct = __shfl(lct, src);
+      const float uth = __shfl(lut, src) * __shfl(lht, src);
+      scx = (gamma * P * P) * uth;  // x = e_stored * scx
+      sce = (gamma * P) * uth;      // d x / d e_true
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) xr[kb] = gather_item4c(a, it, ct, chb[kb]);
+    };
+    if constexpr (LSTREAM) {
+      float FT1[NB][NB][4], FT2[NB][NB][4];
+      f32x4 b1[NB], b2[NB], Zl[NB];
+      load_frag_T<DH, NB>(w1W1, q, r, FT1);
+      load_frag_T<DH, NB>(w1W2, q, r, FT2);
+      load_bias<DH, NB>(w1b1, q, b1);
+      load_bias<DH, NB>(w1b2, q, b2);
+      if constexpr (TRAIN) {
+        posv[LS] = (lead && vs) ? atomicAdd(&a.cur_item[it_i], 1) : 0;
+        posv[LS + 1] = (lead && vs) ? atomicAdd(&a.cur_user[uid], 1) : 0;
+        posv[LS + 2] = (lead && vs) ? atomicAdd(&a.cur_uc[a.b.u_cate[bb]], 1) : 0;
+      }
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) {
+        mx1[kb] = (f32x4)(TLSAN_NEG);
+        Zl[kb] = (f32x4)(0.0f);
+        long4[kb] = (f32x4)(0.0f);
+      }
+      for (int base = 0; base < pmax1; base += NLc) {  // wave-uniform
+        load_lchunk(base);
+        if constexpr (TRAIN) {
+          const int t = base + kkl;
+          if (t < Ls) {
+            const bool vt = vs && t < n_l;
+            sP[srow * PSTR + t] = vt ? atomicAdd(&a.cur_item[lid], 1) : 0;
+            sH[srow * 2 * LSC + t] = vt ? lht : 0.0f;
+            sH[srow * 2 * LSC + LSC + t] = vt ? lut * lht : 0.0f;
+          }
+        }
+        const int pend = min(base + NLc, pmax1);
+        for (int p = base; p < pend; ++p) {
+          f32x4 xv[NB], z[NB], m2[NB];
+          float scx, sce;
+          fetch_lrow(p, xv, scx, sce);
+          const bool vp = p < n_l;
+#pragma unroll
+          for (int kb = 0; kb < NB; ++kb) xv[kb] = vp ? xv[kb] * scx : (f32x4)(0.0f);
+          map_apply<NB>(FT1, b1, xv, z);
+#pragma unroll
+          for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) z[kb][i] = fmaxf(z[kb][i], 0.0f);
+          map_apply<NB>(FT2, b2, z, m2);
+          if (vp) online_step<NB>(mx1, Zl, long4, m2, xv);
+        }
+      }
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          iz1[kb][i] = Zl[kb][i] > 0.0f ? 1.0f / Zl[kb][i] : 0.0f;  // samples past the batch: no position
+          long4[kb][i] *= iz1[kb][i];
+        }
+    } else
     {
       // Three explicit load stages (ids/scales -> categories -> rows); sched_barrier keeps the
       // compiler from interleaving a stage's loads with their first uses, which otherwise
@@ -382,8 +479,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         const bool vp = p < n_l;
         sc1[p] = vp ? (gamma * P * P) * (uts[p] * hts[p]) : 0.0f;  // model.py:100-102,109 (e1, ut stored / P)
         if (TRAIN && lead) {
-          sH[srow * 2 * LS + p] = vp ? hts[p] : 0.0f;
-          sH[srow * 2 * LS + LS + p] = vp ? uts[p] * hts[p] : 0.0f;
+          sH[srow * 2 * LSC + p] = vp ? hts[p] : 0.0f;
+          sH[srow * 2 * LSC + LSC + p] = vp ? uts[p] * hts[p] : 0.0f;
         }
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) e1[p][kb] = vp ? e1[p][kb] : (f32x4)(0.0f);
@@ -456,8 +553,10 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     const int pmax2 = wave_max_i32(n_pos);
     if constexpr (TRAIN) {
       if (lead) {
+        if constexpr (!LSTREAM) {
 #pragma unroll
-        for (int p = 0; p < LS; ++p) sP[srow * PSTR + p] = posv[p];
+          for (int p = 0; p < LS; ++p) sP[srow * PSTR + p] = posv[p];
+        }
         sP[srow * PSTR + P_TGT] = posv[LS];
         sP[srow * PSTR + P_USR] = posv[LS + 1];
         sP[srow * PSTR + P_UC] = posv[LS + 2];
@@ -549,10 +648,10 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         short4[kb][i] *= Zs[kb][i];
       }
     if constexpr (TRAIN) {  // publish the session positions (the atomics are long back by now)
-      if (vs && kk < n_s) sP[srow * PSTR + LS + kk] = spos0;
+      if (vs && kk < n_s) sP[srow * PSTR + LSC + kk] = spos0;
       for (int base = NL; base < pmax2 - 1; base += NL) {  // sessions longer than one chunk (rare)
         const int t = base + kk;
-        if (vs && t < n_s) sP[srow * PSTR + LS + t] = atomicAdd(&a.cur_item[a.b.hist_i_new[(size_t)bb * Sn + t]], 1);
+        if (vs && t < n_s) sP[srow * PSTR + LSC + t] = atomicAdd(&a.cur_item[a.b.hist_i_new[(size_t)bb * Sn + t]], 1);
       }
     }
     // u_t = short + [user_emb[u] || cate_emb[u_cate]]   (model.py:93-95,135)
@@ -648,7 +747,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
               }
             }
           } else if (vs && vt) {
-            const int pos = sP[srow * PSTR + LS + (p - 1)];
+            const int pos = sP[srow * PSTR + LSC + (p - 1)];
             if (lead) a.Gb[pos] = 0.0f;
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) {
@@ -706,6 +805,61 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         load_bias<DH, NB>(w1b2, q, b2);
         load_frag_N<DH, NB>(w1W1, q, r, FN1);
         load_frag_N<DH, NB>(w1W2, q, r, FN2);
+        if constexpr (LSTREAM) {
+          AccSet<NB> acc;
+          acc.zero();
+          for (int base = 0; base < pmax1; base += NLc) {  // wave-uniform
+            load_lchunk(base);
+            const int pend = min(base + NLc, pmax1);
+            for (int p = base; p < pend; ++p) {
+              const bool vp = p < n_l;
+              f32x4 ev[NB], xv[NB], z1[NB], zr[NB], m2[NB], av[NB], dx[NB];
+              float scx, sce;
+              fetch_lrow(p, ev, scx, sce);
+#pragma unroll
+              for (int kb = 0; kb < NB; ++kb) {
+                ev[kb] = vp ? ev[kb] : (f32x4)(0.0f);
+                xv[kb] = ev[kb] * scx;
+              }
+              map_apply<NB>(FT1, b1, xv, z1);
+#pragma unroll
+              for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) zr[kb][i] = fmaxf(z1[kb][i], 0.0f);
+              map_apply<NB>(FT2, b2, zr, m2);
+#pragma unroll
+              for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                  av[kb][i] = vp ? __expf(m2[kb][i] - mx1[kb][i]) * iz1[kb][i] : 0.0f;
+              bwd_compute<NB, TSTR>(FN2, FN1, xv, z1, av, long4, dlong, T, q, r, acc.db1, acc.db2, dx);
+              bwd_dw<NB, TSTR>(T, q, r, acc.dW1, acc.dW2);
+              float dsp = 0.0f;
+#pragma unroll
+              for (int kb = 0; kb < NB; ++kb) dsp += dot4(dx[kb], ev[kb]);
+              const float ds = sample_sum<CPS>(dsp) * P;  // d loss / d scale[p]
+              if (vs && vp) {
+                const int pos = sP[srow * PSTR + p];
+                if (lead) a.Gb[pos] = 0.0f;
+#pragma unroll
+                for (int kb = 0; kb < NB; ++kb) {
+                  const f32x4 de = dx[kb] * sce;
+                  *(f32x4*)(a.Gi + (size_t)pos * D + chb[kb]) = de;
+                  sq_acc += dot4(de, de);
+                }
+                if (lead) {
+                  const float gt = ds * (gamma * sH[srow * 2 * LSC + p]);  // d / d usert_emb[u][p]
+                  a.Gu[(size_t)sP[srow * PSTR + P_USR] * a.WU + a.di + p] = gt;
+                  sq_acc += gt * gt;
+                  dgam += ds * (P * sH[srow * 2 * LSC + LSC + p]);
+                }
+              }
+            }
+          }
+          if (lead && vs)  // padded long slots and the row's alignment padding
+            for (int p = a.di + n_l; p < a.WU; ++p) a.Gu[(size_t)sP[srow * PSTR + P_USR] * a.WU + p] = 0.0f;
+          stage_accs<NB, CPS, false>(acc, dummy, T, lane);
+        } else {
         AccSet<NB> acc;
         acc.zero();
         float dsp[LS];  // per-lane partials of d loss / d scale[p]; reduced after the loop
@@ -714,7 +868,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           dsp[p] = 0.0f;
           if (p < pmax1) {
             const bool vp = p < n_l;
-            const float uth = sH[srow * 2 * LS + LS + p];
+            const float uth = sH[srow * 2 * LSC + LSC + p];
             const float scp = (gamma * P * P) * uth;  // x = e_stored * scp
             const float sce = (gamma * P) * uth;      // d x / d e_true
             f32x4 xv[NB], z1[NB], zr[NB], m2[NB], av[NB], dx[NB];
@@ -760,15 +914,16 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           const float ds = sample_sum<CPS>(dsp[p]) * P;  // d loss / d scale[p] (e_true = P * e_stored)
           if (lead && vs && p < Ls) {
             const bool vp = p < n_l;
-            const float gt = vp ? ds * (gamma * sH[srow * 2 * LS + p]) : 0.0f;  // d / d usert_emb[u][p]
+            const float gt = vp ? ds * (gamma * sH[srow * 2 * LSC + p]) : 0.0f;  // d / d usert_emb[u][p]
             a.Gu[(size_t)sP[srow * PSTR + P_USR] * a.WU + a.di + p] = gt;  // padded slots: 0
             sq_acc += gt * gt;
-            dgam += vp ? ds * (P * sH[srow * 2 * LS + LS + p]) : 0.0f;
+            dgam += vp ? ds * (P * sH[srow * 2 * LSC + LSC + p]) : 0.0f;
           }
         }
         if (lead && vs)
           for (int p = a.di + Ls; p < a.WU; ++p) a.Gu[(size_t)sP[srow * PSTR + P_USR] * a.WU + p] = 0.0f;
         stage_accs<NB, CPS, false>(acc, dummy, T, lane);
+        }
       }
       // scalars of this pass: wave-reduce, stage, one thread sums the waves in fixed order
       {

@@ -4,23 +4,23 @@
 #include "tlsan_attn.h"
 
 template <int D, int DH>
-static size_t fwd_smem_bytes(bool train) {
+static size_t fwd_smem_bytes(bool train, bool lstream) {
   using G = Geo<D, DH>;
-  return sizeof(float) * ((train ? G::NSB * G::PSTR : 0) + 2 * G::NSB * G::LSTR + G::NW * 4 + G::NSB * 2 * TLSAN_LS_MAX + (G::USE_SW ? 2 * (2 * DH * DH + 2 * DH) : 0) + G::NW * G::WSCR);
+  const int lsc = lstream ? TLSAN_LS_CAP : TLSAN_LS_MAX;
+  return sizeof(float) * ((train ? G::NSB * (lsc + TLSAN_SN_CAP + 4) : 0) + 2 * G::NSB * G::LSTR + G::NW * 4 + G::NSB * 2 * lsc + (G::USE_SW ? 2 * (2 * DH * DH + 2 * DH) : 0) + G::NW * G::WSCR);
 }
 
-template <int D, int DH>
-static hipError_t launch_fwd_bwd_impl(bool train, const FwdArgs& a, int grid, hipStream_t st) {
-  const size_t smem = fwd_smem_bytes<D, DH>(train);
-  if (train) {
-    auto k = k_fwd_bwd<D, DH, true>;
-    if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, st, a);
-  } else {
-    auto k = k_fwd_bwd<D, DH, false>;
-    if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, st, a);
-  }
+template <int D, int DH, bool TRAIN, bool LSTREAM>
+static hipError_t launch_variant(const FwdArgs& a, int grid, hipStream_t st) {
+  const size_t smem = fwd_smem_bytes<D, DH>(TRAIN, LSTREAM);
+  auto k = k_fwd_bwd<D, DH, TRAIN, LSTREAM>;
+  if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, st, a);
   return hipGetLastError();
 }
 
+template <int D, int DH>
+static hipError_t launch_fwd_bwd_impl(bool train, bool lstream, const FwdArgs& a, int grid, hipStream_t st) {
+  if (train) return lstream ? launch_variant<D, DH, true, true>(a, grid, st) : launch_variant<D, DH, true, false>(a, grid, st);
+  return lstream ? launch_variant<D, DH, false, true>(a, grid, st) : launch_variant<D, DH, false, false>(a, grid, st);
+}

@@ -25,7 +25,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define TLSAN_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #define TLSAN_NEG (-1e30f)  // VERY_NEGATIVE_NUMBER, reference TLSAN/model.py:10-11
 
-#define TLSAN_LS_MAX 10  // static bound on the long-term window (reference default Ls = 10)
+#define TLSAN_LS_MAX 10  // long-term windows up to this size stay in registers (reference default Ls = 10)
+#define TLSAN_LS_CAP 96  // larger windows (up to the reference's max_length = 90) are streamed
 
 template <int D_, int DH_>
 struct Geo {
@@ -46,7 +47,6 @@ struct Geo {
   static constexpr int TBUF = 4 * NB * 16 * TSTR;   // one buffer: x, dz1, m1, dm2 tiles
   static constexpr int NBUF = NB == 1 ? 2 : 1;      // double-buffered when it fits the LDS
   static constexpr bool USE_SW = NB == 1;           // attention weights in LDS when they fit
-  static constexpr int PSTR = 10 + 96 + 4;          // TLSAN_LS_MAX + TLSAN_SN_CAP + 3 singles (+1 pad)
   static constexpr int WSCR_T = NBUF * TBUF;
   static constexpr int WSCR_A = (2 * NB * NB + 3 * NB) * 256;
   static constexpr int WSCR = WSCR_T > WSCR_A ? WSCR_T : WSCR_A;
