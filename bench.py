@@ -206,9 +206,19 @@ def main():
             out["segments_ms"] = {n: round(float(seg[:, i].mean()), 5) for i, n in enumerate(L.PROF_SEGMENTS)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, icl, host_batches[0], args.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        result = json.dumps(out)
+    else:
+        result = None
     if dist is not None:
         dist.destroy_process_group()
+    if result is not None:
+        # RCCL prints its version banner through C stdio; flush that first so the JSON line is
+        # the last line on stdout
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(result, flush=True)
 
 
 if __name__ == "__main__":

@@ -199,6 +199,14 @@ int tlsan_rows_apply(float* W, int32_t ld, int32_t nrows, int32_t width, int32_t
                      float gscale, const float* step_dev, float reg, double* sumsq_out,
                      void* ws, size_t ws_bytes, void* stream);
 
+/* Exclusive prefix sum + compaction of a device int32 array (the id-routing step of the sharded
+ * path): prefix[k] = sum(cnt[0..k)), uniq = ascending list of k with cnt[k] > 0 and
+ * prefix_nz[k]... see below.  For 0/1 flags, prefix[k] is the compact index of k.
+ *   prefix  [n]  exclusive prefix of cnt
+ *   uniq    [n]  (nullable) indices with cnt > 0, ascending
+ *   n_uniq  [1]  (nullable) how many */
+int tlsan_scan_compact(const int32_t* cnt, int32_t n, int32_t* prefix, int32_t* uniq, int32_t* n_uniq, void* stream);
+
 /* Profiling hooks (measurement only; no reference counterpart).  level 0 = off (default),
  * 1 = HIP events around the fused forward/backward kernel of every train step,
  * 2 = events at every kernel boundary of the step.  Events are recorded on the step's stream.

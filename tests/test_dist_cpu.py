@@ -82,3 +82,53 @@ def test_mod_partition():
     ids = torch.arange(10)
     assert torch.equal(p.owner(ids), ids % 4) and torch.equal(p.local_row(ids), ids // 4)
     assert p.global_ids(1).tolist() == [1, 5, 9]
+
+
+def _worker_router(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tlsan_amd.dist import KeyRouter, torch_scan
+        I, U, W = 23, 17, 5
+        rng = np.random.RandomState(0)
+        items = rng.randn(I, W).astype(np.float32)
+        users = rng.randn(U, W).astype(np.float32)
+        r = KeyRouter(I, U, world, rank)
+        shard = np.zeros((r.R, W), np.float32)
+        gi, gu = np.arange(rank, I, world), np.arange(rank, U, world)
+        shard[:len(gi)] = items[gi]
+        shard[r.cI:r.cI + len(gu)] = users[gu]
+        shard_t = torch.as_tensor(shard)
+        rs = np.random.RandomState(10 + rank)
+        it = torch.as_tensor(rs.randint(0, I, 40))
+        us = torch.as_tensor(rs.randint(0, U, 9))
+        keys = torch.cat([r.item_keys(it), r.user_keys(us)])
+        plan = r.plan(keys, torch_scan)
+        table = r.fetch(plan, shard_t).numpy()
+        comp = plan["prefix"][keys].numpy()
+        # every id of the batch finds its own row in the compact table
+        assert np.array_equal(table[comp[:40]], items[it.numpy()])
+        assert np.array_equal(table[comp[40:]], users[us.numpy()])
+        assert plan["n"] == len(np.unique(keys.numpy()))
+        # push: per-row values come back to their owners exactly once per requesting rank
+        vals = torch.as_tensor(np.arange(plan["n"], dtype=np.float32)[:, None] + 100.0 * rank + np.zeros((1, 2), np.float32))
+        rows, recv = r.push(plan, vals)
+        all_keys = [None] * world
+        dist.all_gather_object(all_keys, plan["uniq"].numpy())
+        exp_rows = np.concatenate([k[k // r.R == rank] % r.R for k in all_keys])
+        assert np.array_equal(rows.numpy(), exp_rows)              # source-rank order
+        assert recv.shape[0] == len(exp_rows)
+        ret[rank] = "ok"
+    except Exception:
+        import traceback
+        ret[rank] = "FAIL: " + traceback.format_exc()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_key_router_world2():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_router, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: "ok", 1: "ok"}, dict(ret)

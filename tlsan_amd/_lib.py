@@ -17,7 +17,7 @@ EXPORTS = [
     "tlsan_state_bytes", "tlsan_state_init", "tlsan_state_reindex", "tlsan_state_scale",
     "tlsan_state_renorm", "tlsan_sync_derived", "tlsan_forward",
     "tlsan_train_step", "tlsan_grads", "tlsan_eval_ranks", "tlsan_profile_enable",
-    "tlsan_profile_collect", "tlsan_debug_stamps", "tlsan_rows_apply_workspace", "tlsan_rows_apply",
+    "tlsan_profile_collect", "tlsan_debug_stamps", "tlsan_rows_apply_workspace", "tlsan_rows_apply", "tlsan_scan_compact",
 ]
 PROF_SEGMENTS = ("index_build", "fwd_bwd", "dk_partial", "dense_finalize", "apply_rows")
 
@@ -108,6 +108,8 @@ def load():
                                      C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_float, C.c_void_p,
                                      C.c_void_p, C.c_size_t, C.c_void_p]
     lib.tlsan_rows_apply.restype = C.c_int
+    lib.tlsan_scan_compact.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.tlsan_scan_compact.restype = C.c_int
     lib.tlsan_debug_stamps.argtypes = [C.c_void_p]
     lib.tlsan_debug_stamps.restype = C.c_int
     for name in ("tlsan_dense_layout_of", "tlsan_state_init", "tlsan_sync_derived", "tlsan_forward",

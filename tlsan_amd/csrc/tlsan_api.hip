@@ -635,6 +635,19 @@ int tlsan_rows_apply(float* W, int32_t ld, int32_t nrows, int32_t width, int32_t
   return TLSAN_OK;
 }
 
+int tlsan_scan_compact(const int32_t* cnt, int32_t n, int32_t* prefix, int32_t* uniq, int32_t* n_uniq, void* stream) {
+  if (!cnt || !prefix || n < 1) return fail(TLSAN_E_BADARG, "tlsan_scan_compact: bad arguments");
+  ScanArgs sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.cnt[0] = cnt; sa.off[0] = prefix; sa.cur[0] = nullptr; sa.n[0] = n;
+  sa.uniq[0] = uniq; sa.n_uniq[0] = n_uniq;
+  const int nscan = (n + 4095) / 4096;
+  sa.blk0[0] = 0; sa.blk0[1] = nscan; sa.blk0[2] = nscan;
+  hipLaunchKernelGGL(k_index_scan, dim3(nscan), dim3(1024), 0, (hipStream_t)stream, sa);
+  CHECK_LAUNCH("k_index_scan");
+  return TLSAN_OK;
+}
+
 int tlsan_debug_stamps(void* device_buf) {
   g_stamps = (unsigned long long*)device_buf;
   return TLSAN_OK;

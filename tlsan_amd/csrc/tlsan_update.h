@@ -120,7 +120,7 @@ __global__ __launch_bounds__(1024) void k_index_scan(ScanArgs a) {
   for (int k = 0; k < 4; ++k) {
     if (i0 + k < n) {
       off[i0 + k] = (int)(run & 0xffffffffLL);
-      cur[i0 + k] = (int)(run & 0xffffffffLL);
+      if (cur) cur[i0 + k] = (int)(run & 0xffffffffLL);
       if (uniq && v[k] > 0) uniq[(int)(run >> 32)] = i0 + k;
       run += pack(v[k]);
       if (i0 + k == n - 1 && a.n_uniq[which]) *a.n_uniq[which] = (int)(run >> 32);

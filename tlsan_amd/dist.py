@@ -10,15 +10,18 @@ SURVEY.md section 8e.  Samples are independent units: every rank trains its own 
     mod-G spreads the Zipf-hot items);
   * ``cate_emb`` (<= 5 MB), ``item_cate_list`` and the dense attention weights: replicated.
 
-One step = (1) de-duplicate the ids the local batch touches, (2) all-to-all ids -> owners,
-(3) all-to-all rows back into a compact per-step table the HIP kernels run on in place (row
-strides, tlsan_params.ld_*), (4) fused forward/backward + exact per-row gradient sums
-(tlsan_grads), (5) ONE all-reduce of [dense grads | cate grads | loss | norm terms],
-(6) all-to-all of the per-row gradients back to the owners, (7) owners apply them with the
-deterministic tlsan_rows_apply (dense L2 decay of every local row, as the reference).
+One step = (1) mark the rows the local batch touches in an owner-major key space and compact the
+marks (one HIP scan: distinct rows already in all-to-all order + the id -> compact-row map),
+(2) all-to-all of the per-owner counts and local row numbers, (3) all-to-all of the rows back
+into a compact per-step table the HIP kernels run on in place (row strides,
+tlsan_params.ld_*), (4) fused forward/backward + exact per-row gradient sums (tlsan_grads),
+(5) ONE all-reduce of [dense grads | cate grads | loss | norm terms], (6) all-to-all of the
+per-row gradients back to the owners, (7) owners apply them with the deterministic
+tlsan_rows_apply (dense L2 decay of every local row, as the reference).  Items and users share
+one fused shard table and one exchange each way; one host sync per step (split sizes).
 
-``RowExchange`` is device-agnostic torch + torch.distributed plumbing (runs on CPU/gloo in the
-tests); all arithmetic on rows is in libtlsan_hip.so.
+``KeyRouter`` / ``RowExchange`` are device-agnostic torch + torch.distributed plumbing (run on
+CPU/gloo in the tests); all arithmetic on rows is in libtlsan_hip.so.
 """
 from __future__ import annotations
 
@@ -141,6 +144,87 @@ def _ru4(x):
     return (x + 3) // 4 * 4
 
 
+class KeyRouter:
+    """Owner-major key space for the fused shard table of one rank group.
+
+    Every rank owns R = cI + cU rows: its items (id % G == rank) at local rows [0, cI) and its
+    users at [cI, R).  A global id maps to key = owner * R + local_row, so
+      * marking the keys a batch touches and compacting the marks (one scan) yields the distinct
+        rows it needs ALREADY grouped by owner, i.e. in all-to-all send order, and the exclusive
+        prefix is the id -> compact-row map of the per-step table;
+      * what is sent to an owner are its local row numbers (key - owner * R).
+    One plan / fetch / push serves both tables: one collective each way instead of two, and no
+    sort / unique / bincount kernels."""
+
+    def __init__(self, n_items, n_users, world, rank, group=None):
+        self.G, self.rank, self.group = int(world), int(rank), group
+        self.cI = (int(n_items) + self.G - 1) // self.G
+        self.cU = (int(n_users) + self.G - 1) // self.G
+        self.R = self.cI + self.cU
+        self.nkeys = self.G * self.R
+
+    def item_keys(self, ids):
+        return (ids % self.G) * self.R + torch.div(ids, self.G, rounding_mode="floor")
+
+    def user_keys(self, ids):
+        return (ids % self.G) * self.R + self.cI + torch.div(ids, self.G, rounding_mode="floor")
+
+    def plan(self, keys, scan):
+        """keys: int64 tensor of every key the batch touches (duplicates fine).  `scan(flags)` ->
+        (prefix, uniq, n_uniq_tensor) is the exclusive-scan + compaction primitive
+        (tlsan_scan_compact on the GPU).  Returns a dict describing the exchange."""
+        dev = keys.device
+        flags = torch.zeros(self.nkeys, dtype=torch.int32, device=dev)
+        flags[keys] = 1
+        prefix, uniq, n_uniq = scan(flags)
+        bnd = torch.arange(0, self.nkeys, self.R, device=dev)
+        starts = torch.cat([prefix[bnd], n_uniq.reshape(1)])
+        sc = (starts[1:] - starts[:-1]).to(torch.int64)
+        if self.G > 1:
+            rc = torch.empty_like(sc)
+            a2a(rc, sc, None, None, self.group)
+            both = torch.stack([sc, rc]).cpu()          # the step's single host sync
+            send_counts, recv_counts = both[0].tolist(), both[1].tolist()
+        else:
+            send_counts = recv_counts = sc.cpu().tolist()
+        n = int(sum(send_counts))
+        uniq = uniq[:n]
+        local_rows = (uniq.to(torch.int64) % self.R)
+        if self.G > 1:
+            recv_rows = torch.empty(sum(recv_counts), dtype=torch.int64, device=dev)
+            a2a(recv_rows, local_rows, recv_counts, send_counts, self.group)
+        else:
+            recv_rows = local_rows
+        return dict(prefix=prefix, uniq=uniq, n=n, send_counts=send_counts, recv_counts=recv_counts,
+                    recv_rows=recv_rows)
+
+    def fetch(self, plan, shard):
+        """compact per-step table: row k = the shard row of plan['uniq'][k]"""
+        rows = shard[plan["recv_rows"]]
+        if self.G == 1:
+            return rows
+        out = torch.empty((plan["n"], shard.shape[1]), dtype=shard.dtype, device=shard.device)
+        a2a(out, rows, plan["send_counts"], plan["recv_counts"], self.group)
+        return out
+
+    def push(self, plan, values):
+        """one value row per compact row back to its owner: (local_rows, rows) in source-rank order"""
+        if self.G == 1:
+            return plan["recv_rows"], values
+        got = torch.empty((sum(plan["recv_counts"]), values.shape[1]), dtype=values.dtype, device=values.device)
+        a2a(got, values, plan["recv_counts"], plan["send_counts"], self.group)
+        return plan["recv_rows"], got
+
+
+def torch_scan(flags):
+    """scan + compaction with torch ops (CPU tests of the routing; the GPU path uses the HIP scan)"""
+    inc = torch.cumsum(flags, 0, dtype=torch.int32)
+    prefix = inc - flags
+    uniq = torch.nonzero(flags, as_tuple=False).reshape(-1).to(torch.int32)
+    pad = torch.zeros(flags.numel() - uniq.numel(), dtype=torch.int32, device=flags.device)
+    return prefix, torch.cat([uniq, pad]), inc[-1:].clone()
+
+
 class ShardedModel:
     """Model surface (train / eval_auc / ...) over row-sharded tables; see module docstring."""
 
@@ -157,57 +241,50 @@ class ShardedModel:
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         U, I, Cc = config["user_count"], config["item_count"], config["cate_count"]
+        self.U, self.I, self.C = U, I, Cc
         self.di, self.dc, self.Ls = config["itemid_embedding_size"], config["cateid_embedding_size"], config["Ls"]
         self.d, self.H = config["hidden_units"], config["num_heads"]
-        self.WI = self.di + 4                    # [item_emb | item_b | pad x3]
-        self.WU = _ru4(self.di + self.Ls)        # [user_emb | usert_emb | pad]
-        self.part_i, self.part_u = ModPartition(I, self.world), ModPartition(U, self.world)
-        self.xi, self.xu = RowExchange(self.part_i, group), RowExchange(self.part_u, group)
-        p = Model.init_params(config, seed)      # identical on every rank (numpy, seeded)
+        # fused rows: items [item_emb | item_b | pad], users [user_emb | usert_emb | pad], one width
+        self.W = max(self.di + 4, _ru4(self.di + self.Ls))
+        self.router = KeyRouter(I, U, self.world, self.rank, group)
+        self.cI, self.cU = self.router.cI, self.router.cU
         dev = self.device
-        gi = np.arange(self.rank, I, self.world)
-        gu = np.arange(self.rank, U, self.world)
-        item = np.zeros((len(gi), self.WI), np.float32)
-        item[:, :self.di] = p["item_emb"][gi]
-        item[:, self.di] = p["item_b"][gi]
-        user = np.zeros((len(gu), self.WU), np.float32)
-        user[:, :self.di] = p["user_emb"][gu]
-        user[:, self.di:self.di + self.Ls] = p["usert_emb"][gu]
-        self.item_shard = torch.as_tensor(item).to(dev)
-        self.user_shard = torch.as_tensor(user).to(dev)
-        self.cate_emb = torch.as_tensor(p["cate_emb"]).to(dev)
-        self.item_cate = torch.as_tensor(np.asarray(item_cate_list, np.int32)).to(dev)
-        # dims of the full problem only to obtain the dense layout
+        self.shard = torch.zeros(self.router.R, self.W, dtype=torch.float32, device=dev)
+        self.cate_emb = torch.zeros(Cc, self.dc, dtype=torch.float32, device=dev)
+        icl = np.asarray(item_cate_list, np.int32)
+        # item -> category in key space (user keys: 0), so the compact table's map is one gather
+        ck = np.zeros(self.router.nkeys, np.int32)
+        ids = np.arange(I)
+        ck[(ids % self.world) * self.router.R + ids // self.world] = icl
+        self.cate_by_key = torch.as_tensor(ck).to(dev)
         dims_full = L.Dims(U, I, Cc, self.d, self.di, self.dc, self.H, self.Ls)
+        self.dims_full = dims_full
         self.lay = L.DenseLayout()
         L.check(self.lib.tlsan_dense_layout_of(C.byref(dims_full), C.byref(self.lay)), "tlsan_dense_layout_of")
         self.dense = torch.zeros(self.lay.n_dense, dtype=torch.float32, device=dev)
         self.dense_KT = torch.zeros(self.d, self.d, dtype=torch.float32, device=dev)
-        self._pack_dense(p)
         self.reg = float(config["regulation_rate"])
         self.clip = float(config["max_gradient_norm"])
-        # running sums of squares of the regularised tables (tf.nn.l2_loss terms, model.py:164-169)
-        self.S_local = (self.item_shard[:, :self.di].double().pow(2).sum()
-                        + self.user_shard[:, :self.di + self.Ls].double().pow(2).sum()).reshape(1)
-        self.S_cate = self.cate_emb.double().pow(2).sum().reshape(1)
         self._sq = torch.zeros(3, dtype=torch.float64, device=dev)   # rows_apply sumsq outputs
         self._out = torch.zeros(4, dtype=torch.float32, device=dev)  # loss, gnorm, sq_rows (local)
         self._step_dev = torch.zeros(1, dtype=torch.float32, device=dev)
         self.last_loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self.last_gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
-        self._state = None
-        self._ws = None
-        self._rws = None
+        self._state = self._ws = self._rws = None
+        self._scan_prefix = torch.empty(self.router.nkeys, dtype=torch.int32, device=dev)
+        self._scan_uniq = torch.empty(self.router.nkeys, dtype=torch.int32, device=dev)
+        self._scan_n = torch.zeros(1, dtype=torch.int32, device=dev)
         self._step = 0
         self._epoch = 0
         self.global_step = _Var(lambda: self._step)
         self.global_epoch_step = _Var(lambda: self._epoch)
         self.train_writer, self.eval_writer = _Writer("train"), _Writer("eval")
         self._cate_ids = torch.arange(Cc, dtype=torch.int32, device=dev)
+        self.set_params(Model.init_params(config, seed))   # identical on every rank (numpy, seeded)
 
     # ------------------------------------------------------------------ helpers
     def _pack_dense(self, p):
-        d, dh = self.d, self.d // self.H
+        d = self.d
         lay = self.lay
         flat = np.zeros(lay.n_dense, np.float32)
         for k, off in (("fwa1_W1", lay.f1_W1), ("fwa1_b1", lay.f1_b1), ("fwa1_W2", lay.f1_W2), ("fwa1_b2", lay.f1_b2),
@@ -221,8 +298,25 @@ class ShardedModel:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _scan(self, flags):
+        L.check(self.lib.tlsan_scan_compact(flags.data_ptr(), flags.numel(), self._scan_prefix.data_ptr(),
+                                            self._scan_uniq.data_ptr(), self._scan_n.data_ptr(), self._stream()),
+                "tlsan_scan_compact")
+        return self._scan_prefix, self._scan_uniq, self._scan_n
+
     def device_batch(self, batch, is_test=False):
-        return batch if isinstance(batch, DeviceBatch) else DeviceBatch(batch, self.device, is_test, self.Ls)
+        """Upload the batch and map its ids into the router's key space (elementwise, once)."""
+        db = batch if isinstance(batch, DeviceBatch) else DeviceBatch(batch, self.device, is_test, self.Ls)
+        if not hasattr(db, "keys"):
+            r = self.router
+            parts = [r.item_keys(db.i.long()), r.item_keys(db.hist_i.reshape(-1).long())]
+            if db.Sn > 0:
+                parts.append(r.item_keys(db.hist_i_new.reshape(-1).long()))
+            if db.j is not None:
+                parts.append(r.item_keys(db.j.long()))
+            parts.append(r.user_keys(db.u.long()))
+            db.keys = torch.cat(parts)
+        return db
 
     def _buffers(self, dims, cp, B, Sn, n_rows_max):
         nst = self.lib.tlsan_state_bytes(C.byref(dims))
@@ -231,67 +325,62 @@ class ShardedModel:
             raise L.TlsanError(self.lib.tlsan_last_error().decode())
         if self._state is None or self._state.numel() < nst:
             self._state = torch.zeros(int(nst * 1.5), dtype=torch.uint8, device=self.device)
-        # the compact item table (and its item -> category map) changes every step: clear the
-        # use counters and rebuild the category -> items index for it
-        L.check(self.lib.tlsan_state_reindex(C.byref(dims), C.byref(cp), self._state.data_ptr(), self._stream()),
-                "tlsan_state_reindex")
         if self._ws is None or self._ws.numel() < nws:
             self._ws = torch.empty(int(nws * 1.25), dtype=torch.uint8, device=self.device)
-        nr = self.lib.tlsan_rows_apply_workspace(max(self.item_shard.shape[0], self.user_shard.shape[0],
-                                                     self.cate_emb.shape[0]), n_rows_max)
+        # the compact table (and its item -> category map) changes every step: clear the use
+        # counters and rebuild the category -> items index for it; P = 1 (owners apply the decay)
+        self._state[:4].view(torch.float32).fill_(1.0)
+        L.check(self.lib.tlsan_state_reindex(C.byref(dims), C.byref(cp), self._state.data_ptr(), self._stream()),
+                "tlsan_state_reindex")
+        nr = self.lib.tlsan_rows_apply_workspace(max(self.router.R, self.C), max(n_rows_max, 1))
         if self._rws is None or self._rws.numel() < nr:
             self._rws = torch.empty(int(nr * 1.25), dtype=torch.uint8, device=self.device)
 
-    def _compact(self, db, with_j):
-        """De-duplicate ids, fetch their rows, build the compact batch + parameter structs."""
+    def _compact(self, db):
+        """Route: distinct rows the batch touches -> compact per-step table + remapped batch."""
         B, Ls, Sn = db.B, self.Ls, db.Sn
-        parts = [db.i.long(), db.hist_i.reshape(-1).long()]
-        if Sn > 0:
-            parts.append(db.hist_i_new.reshape(-1).long())
-        if with_j and db.j is not None:
-            parts.append(db.j.long())
-        uniq_i, inv_i = torch.unique(torch.cat(parts), sorted=True, return_inverse=True)
-        uniq_u, inv_u = torch.unique(db.u.long(), sorted=True, return_inverse=True)
-        plan_i, plan_u = self.xi.plan(uniq_i), self.xu.plan(uniq_u)
-        item_c = self.xi.fetch(plan_i, self.item_shard)     # [n_i, WI]
-        user_c = self.xu.fetch(plan_u, self.user_shard)     # [n_u, WU]
-        inv_i = inv_i.int()
+        plan = self.router.plan(db.keys, self._scan)
+        table = self.router.fetch(plan, self.shard)              # [n, W], rows in key order
+        comp = plan["prefix"][db.keys]                            # compact row of every id of the batch
         o = 0
-        i_c = inv_i[o:o + B].contiguous(); o += B
-        hist_c = inv_i[o:o + B * Ls].contiguous(); o += B * Ls
-        new_c = inv_i[o:o + B * Sn].contiguous() if Sn > 0 else db.hist_i_new; o += B * Sn
-        j_c = inv_i[o:o + B].contiguous() if (with_j and db.j is not None) else None
-        u_c = inv_u.int().contiguous()
-        cate_c = self.item_cate[uniq_i].contiguous()
-        keep = (item_c, user_c, i_c, hist_c, new_c, j_c, u_c, cate_c)
+        i_c = comp[o:o + B]; o += B
+        hist_c = comp[o:o + B * Ls]; o += B * Ls
+        new_c = comp[o:o + B * Sn] if Sn > 0 else db.hist_i_new; o += B * Sn
+        j_c = None
+        if db.j is not None:
+            j_c = comp[o:o + B]; o += B
+        u_c = comp[o:o + B]
+        cate_c = self.cate_by_key[plan["uniq"].long()]
+        keep = (table, comp, cate_c)
         ptr = lambda t: None if t is None else t.data_ptr()
         cb = L.Batch(B, Sn, ptr(u_c), ptr(i_c), ptr(j_c), ptr(db.y), ptr(hist_c), ptr(new_c), ptr(db.hist_t),
                      ptr(db.sl), ptr(db.sl_new), ptr(db.u_cate))
-        cp = L.Params(item_c.data_ptr(), item_c.data_ptr() + 4 * self.di, user_c.data_ptr(),
-                      user_c.data_ptr() + 4 * self.di, self.cate_emb.data_ptr(), self.dense.data_ptr(),
-                      self.dense_KT.data_ptr(), cate_c.data_ptr(), self.WI, self.WI, self.WU, self.WU, None)
-        dims = L.Dims(int(uniq_u.numel()), int(uniq_i.numel()), self.config["cate_count"], self.d, self.di, self.dc,
-                      self.H, self.Ls)
-        return dims, cp, cb, plan_i, plan_u, keep
+        base = table.data_ptr()
+        cp = L.Params(base, base + 4 * self.di, base, base + 4 * self.di, self.cate_emb.data_ptr(),
+                      self.dense.data_ptr(), self.dense_KT.data_ptr(), cate_c.data_ptr(),
+                      self.W, self.W, self.W, self.W, None)
+        n = max(plan["n"], 1)
+        dims = L.Dims(n, n, self.C, self.d, self.di, self.dc, self.H, self.Ls)
+        return dims, cp, cb, plan, keep
 
     # ------------------------------------------------------------------ training
     def train_async(self, batch, lr):
         db = self.device_batch(batch)
         G = self.world
-        dims, cp, cb, plan_i, plan_u, keep = self._compact(db, with_j=False)
-        n_i, n_u, Cc = dims.item_count, dims.user_count, dims.cate_count
-        self._buffers(dims, cp, db.B, db.Sn, max(sum(plan_i.recv_counts), sum(plan_u.recv_counts), Cc))
+        dims, cp, cb, plan, keep = self._compact(db)
+        n, Cc, di, Ls, W = dims.item_count, self.C, self.di, self.Ls, self.W
+        self._buffers(dims, cp, db.B, db.Sn, max(int(plan["recv_rows"].numel()), Cc))
         dev = self.device
-        g_item = torch.empty(n_i, self.di, dtype=torch.float32, device=dev)
-        g_itemb = torch.empty(n_i, dtype=torch.float32, device=dev)
-        g_user = torch.empty(n_u, self.di, dtype=torch.float32, device=dev)
-        g_usert = torch.empty(n_u, self.Ls, dtype=torch.float32, device=dev)
+        g_item = torch.empty(n, di, dtype=torch.float32, device=dev)
+        g_itemb = torch.empty(n, dtype=torch.float32, device=dev)
+        g_user = torch.empty(n, di, dtype=torch.float32, device=dev)
+        g_usert = torch.empty(n, Ls, dtype=torch.float32, device=dev)
         n_dense = self.lay.n_dense
         flat = torch.zeros(n_dense + Cc * self.dc + 4, dtype=torch.float32, device=dev)
         go = L.GradsOut(g_item.data_ptr(), g_itemb.data_ptr(), g_user.data_ptr(), g_usert.data_ptr(),
                         flat.data_ptr() + 4 * n_dense, flat.data_ptr())
         out = L.StepOut(self._out.data_ptr(), self._out.data_ptr() + 4, None, self._out.data_ptr() + 8)
-        hp = L.HParams(float(lr), 0.0, self.clip, L.NORM_TF18, L.L2_DENSE)   # reg applied by the owners
+        hp = L.HParams(float(lr), 0.0, self.clip, L.NORM_TF18, L.L2_DENSE)   # reg is applied by the owners
         st = self._stream()
         L.check(self.lib.tlsan_grads(C.byref(dims), C.byref(cp), C.byref(cb), C.byref(hp), C.byref(go), C.byref(out),
                                      self._state.data_ptr(), self._ws.data_ptr(), self._ws.numel(), st), "tlsan_grads")
@@ -311,35 +400,34 @@ class ShardedModel:
         self._step_dev.copy_((coef * float(lr)).reshape(1))
         self.last_gnorm.copy_(norm.reshape(1))
         self.last_loss.copy_((tail[0] * inv_g + self.reg * 0.5 * S_tot.float()).reshape(1))
-        # ---- route the per-row gradients to their owners and apply (deterministic, dense L2)
-        gi_f = torch.zeros(n_i, self.WI, dtype=torch.float32, device=dev)
-        gi_f[:, :self.di] = g_item
-        gi_f[:, self.di] = g_itemb
-        gu_f = torch.zeros(n_u, self.WU, dtype=torch.float32, device=dev)
-        gu_f[:, :self.di] = g_user
-        gu_f[:, self.di:self.di + self.Ls] = g_usert
-        rows_i, vals_i = self.xi.push(plan_i, gi_f)
-        rows_u, vals_u = self.xu.push(plan_u, gu_f)
-        self._rows_apply(self.item_shard, self.WI, self.di, vals_i, rows_i, inv_g, 0)
-        self._rows_apply(self.user_shard, self.WU, self.di + self.Ls, vals_u, rows_u, inv_g, 1)
+        # ---- per-row gradients in the fused layout (rows of the other kind are exactly zero)
+        gf = torch.zeros(n, W, dtype=torch.float32, device=dev)
+        gf[:, :di] = g_item + g_user
+        gf[:, di:di + Ls] = g_usert
+        gf[:, di] += g_itemb
+        rows, vals = self.router.push(plan, gf)
+        rows32 = rows.to(torch.int32)
+        # owners: deterministic scatter-apply with dense L2 decay of every local row; destinations
+        # outside a view's range (the other table's rows) are ignored by tlsan_rows_apply
+        self._rows_apply(self.shard[:self.cI], di, vals, rows32, inv_g, 0)
+        self._rows_apply(self.shard[self.cI:], di + Ls, vals, rows32 - self.cI, inv_g, 1)
         g_cate = flat[n_dense:n_dense + Cc * self.dc].view(Cc, self.dc)
-        self._rows_apply(self.cate_emb, self.dc, self.dc, g_cate, self._cate_ids, inv_g, 2)
+        self._rows_apply(self.cate_emb, self.dc, g_cate, self._cate_ids, inv_g, 2)
         self.S_local = (self._sq[0] + self._sq[1]).reshape(1).clone()
         self.S_cate = self._sq[2].reshape(1).clone()
         # dense attention weights: replicated, identical update on every rank
         self.dense.sub_(gd * self._step_dev)
-        dims_full = L.Dims(self.config["user_count"], self.config["item_count"], Cc, self.d, self.di, self.dc, self.H, self.Ls)
-        L.check(self.lib.tlsan_sync_derived(C.byref(dims_full), C.byref(cp), st), "tlsan_sync_derived")
+        L.check(self.lib.tlsan_sync_derived(C.byref(self.dims_full), C.byref(cp), st), "tlsan_sync_derived")
         self._step += 1
-        self._keep = (keep, flat, gi_f, gu_f, vals_i, vals_u, rows_i, rows_u, g_item, g_itemb, g_user, g_usert)
+        self._keep = (keep, flat, gf, vals, rows32, g_item, g_itemb, g_user, g_usert)
         return db
 
-    def _rows_apply(self, W, width, reg_cols, vals, rows, gscale, slot):
-        n = int(rows.numel())
-        rows32 = rows.int().contiguous() if rows.dtype != torch.int32 else rows
+    def _rows_apply(self, Wt, reg_cols, vals, rows32, gscale, slot):
+        n = int(rows32.numel())
+        rows32 = rows32.contiguous()
         vals = vals.contiguous()
-        L.check(self.lib.tlsan_rows_apply(W.data_ptr(), W.shape[1], W.shape[0], width, reg_cols,
-                                          vals.data_ptr() if n else None, vals.shape[1] if n else width,
+        L.check(self.lib.tlsan_rows_apply(Wt.data_ptr(), Wt.stride(0), Wt.shape[0], Wt.shape[1], reg_cols,
+                                          vals.data_ptr() if n else None, vals.stride(0) if n else Wt.shape[1],
                                           rows32.data_ptr() if n else None, n, float(gscale),
                                           self._step_dev.data_ptr(), self.reg, self._sq.data_ptr() + 8 * slot,
                                           self._rws.data_ptr(), self._rws.numel(), self._stream()), "tlsan_rows_apply")
@@ -352,7 +440,7 @@ class ShardedModel:
     # ------------------------------------------------------------------ evaluation
     def forward(self, batch, is_test=True):
         db = self.device_batch(batch, is_test)
-        dims, cp, cb, _, _, keep = self._compact(db, with_j=True)
+        dims, cp, cb, _, keep = self._compact(db)
         li = torch.empty(db.B, dtype=torch.float32, device=self.device)
         lj = torch.empty(db.B, dtype=torch.float32, device=self.device) if db.j is not None else None
         L.check(self.lib.tlsan_forward(C.byref(dims), C.byref(cp), C.byref(cb), li.data_ptr(),
@@ -366,27 +454,27 @@ class ShardedModel:
         return float(((li - lj) > 0).float().mean().item())
 
     # ------------------------------------------------------------------ inspection
+    def _table_views(self):
+        return self.shard[:self.cI], self.shard[self.cI:]
+
     def gather_params(self):
         """Full (un-sharded) parameters on every rank, as numpy (tests / checkpoints)."""
-        def allgather_rows(shard, part):
-            n_max = part.local_count(0)
-            pad = torch.zeros(n_max, shard.shape[1], dtype=shard.dtype, device=shard.device)
-            pad[:shard.shape[0]] = shard
-            if self.world > 1:
-                host = pad.cpu()
-                outs = [torch.empty_like(host) for _ in range(self.world)]
-                dist.all_gather(outs, host, group=self.group)
-                outs = [o.to(shard.device) for o in outs]
-            else:
-                outs = [pad]
-            full = torch.zeros(part.n, shard.shape[1], dtype=shard.dtype, device=shard.device)
-            for r in range(self.world):
-                full[r::self.world] = outs[r][:part.local_count(r)]
-            return full.cpu().numpy()
-        item = allgather_rows(self.item_shard, self.part_i)
-        user = allgather_rows(self.user_shard, self.part_u)
-        out = dict(item_emb=item[:, :self.di].copy(), item_b=item[:, self.di].copy(),
-                   user_emb=user[:, :self.di].copy(), usert_emb=user[:, self.di:self.di + self.Ls].copy(),
+        host = self.shard.cpu()
+        if self.world > 1:
+            outs = [torch.empty_like(host) for _ in range(self.world)]
+            dist.all_gather(outs, host, group=self.group)
+        else:
+            outs = [host]
+        I, U, G, di, Ls = self.I, self.U, self.world, self.di, self.Ls
+        item = np.zeros((I, self.W), np.float32)
+        user = np.zeros((U, self.W), np.float32)
+        for r in range(G):
+            t = outs[r].numpy()
+            ni, nu = len(range(r, I, G)), len(range(r, U, G))
+            item[r::G] = t[:ni]
+            user[r::G] = t[self.cI:self.cI + nu]
+        out = dict(item_emb=item[:, :di].copy(), item_b=item[:, di].copy(),
+                   user_emb=user[:, :di].copy(), usert_emb=user[:, di:di + Ls].copy(),
                    cate_emb=self.cate_emb.cpu().numpy())
         flat = self.dense.cpu().numpy()
         d, dh, lay = self.d, self.d // self.H, self.lay
@@ -401,18 +489,18 @@ class ShardedModel:
 
     def set_params(self, p):
         """Load full parameters (dict of numpy arrays); every rank keeps its own rows."""
-        gi = np.arange(self.rank, self.part_i.n, self.world)
-        gu = np.arange(self.rank, self.part_u.n, self.world)
-        item = np.zeros(tuple(self.item_shard.shape), np.float32)
-        item[:, :self.di] = np.asarray(p["item_emb"], np.float32)[gi]
-        item[:, self.di] = np.asarray(p["item_b"], np.float32)[gi]
-        user = np.zeros(tuple(self.user_shard.shape), np.float32)
-        user[:, :self.di] = np.asarray(p["user_emb"], np.float32)[gu]
-        user[:, self.di:self.di + self.Ls] = np.asarray(p["usert_emb"], np.float32)[gu]
-        self.item_shard.copy_(torch.as_tensor(item))
-        self.user_shard.copy_(torch.as_tensor(user))
+        G, r, di, Ls = self.world, self.rank, self.di, self.Ls
+        gi = np.arange(r, self.I, G)
+        gu = np.arange(r, self.U, G)
+        t = np.zeros(tuple(self.shard.shape), np.float32)
+        t[:len(gi), :di] = np.asarray(p["item_emb"], np.float32)[gi]
+        t[:len(gi), di] = np.asarray(p["item_b"], np.float32)[gi]
+        t[self.cI:self.cI + len(gu), :di] = np.asarray(p["user_emb"], np.float32)[gu]
+        t[self.cI:self.cI + len(gu), di:di + Ls] = np.asarray(p["usert_emb"], np.float32)[gu]
+        self.shard.copy_(torch.as_tensor(t))
         self.cate_emb.copy_(torch.as_tensor(np.asarray(p["cate_emb"], np.float32)))
         self._pack_dense(p)
-        self.S_local = (self.item_shard[:, :self.di].double().pow(2).sum()
-                        + self.user_shard[:, :self.di + self.Ls].double().pow(2).sum()).reshape(1)
+        it, us = self._table_views()
+        # running sums of squares of the regularised tables (tf.nn.l2_loss terms, model.py:164-169)
+        self.S_local = (it[:, :di].double().pow(2).sum() + us[:, :di + Ls].double().pow(2).sum()).reshape(1)
         self.S_cate = self.cate_emb.double().pow(2).sum().reshape(1)
