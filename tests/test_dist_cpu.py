@@ -116,7 +116,7 @@ def _worker_router(rank, world, port, ret):
         all_keys = [None] * world
         dist.all_gather_object(all_keys, plan["uniq"].numpy())
         exp_rows = np.concatenate([k[k // r.R == rank] % r.R for k in all_keys])
-        assert np.array_equal(rows.numpy(), exp_rows)              # source-rank order
+        assert np.array_equal(rows.numpy().astype(np.int64), exp_rows.astype(np.int64))   # source-rank order
         assert recv.shape[0] == len(exp_rows)
         ret[rank] = "ok"
     except Exception:

@@ -189,9 +189,9 @@ class KeyRouter:
             send_counts = recv_counts = sc.cpu().tolist()
         n = int(sum(send_counts))
         uniq = uniq[:n]
-        local_rows = (uniq.to(torch.int64) % self.R)
+        local_rows = uniq % self.R                      # int32 row numbers inside the owner's shard
         if self.G > 1:
-            recv_rows = torch.empty(sum(recv_counts), dtype=torch.int64, device=dev)
+            recv_rows = torch.empty(sum(recv_counts), dtype=torch.int32, device=dev)
             a2a(recv_rows, local_rows, recv_counts, send_counts, self.group)
         else:
             recv_rows = local_rows
@@ -200,7 +200,7 @@ class KeyRouter:
 
     def fetch(self, plan, shard):
         """compact per-step table: row k = the shard row of plan['uniq'][k]"""
-        rows = shard[plan["recv_rows"]]
+        rows = shard[plan["recv_rows"].long()]
         if self.G == 1:
             return rows
         out = torch.empty((plan["n"], shard.shape[1]), dtype=shard.dtype, device=shard.device)
@@ -252,8 +252,9 @@ class ShardedModel:
         self.shard = torch.zeros(self.router.R, self.W, dtype=torch.float32, device=dev)
         self.cate_emb = torch.zeros(Cc, self.dc, dtype=torch.float32, device=dev)
         icl = np.asarray(item_cate_list, np.int32)
-        # item -> category in key space (user keys: 0), so the compact table's map is one gather
-        ck = np.zeros(self.router.nkeys, np.int32)
+        # item -> category in key space (user / padding keys: -1 = in no category), so the compact
+        # table's map is one gather
+        ck = np.full(self.router.nkeys, -1, np.int32)
         ids = np.arange(I)
         ck[(ids % self.world) * self.router.R + ids // self.world] = icl
         self.cate_by_key = torch.as_tensor(ck).to(dev)
@@ -405,8 +406,7 @@ class ShardedModel:
         gf[:, :di] = g_item + g_user
         gf[:, di:di + Ls] = g_usert
         gf[:, di] += g_itemb
-        rows, vals = self.router.push(plan, gf)
-        rows32 = rows.to(torch.int32)
+        rows32, vals = self.router.push(plan, gf)
         # owners: deterministic scatter-apply with dense L2 decay of every local row; destinations
         # outside a view's range (the other table's rows) are ignored by tlsan_rows_apply
         self._rows_apply(self.shard[:self.cI], di, vals, rows32, inv_g, 0)
