@@ -32,7 +32,7 @@ __device__ __forceinline__ void fwa_forward(const float (&FT1)[NB][NB][4], const
                                             const float (&FT2)[NB][NB][4], const f32x4 (&b2)[NB],
                                             const f32x4 (&e)[NPOS][NB], const float (&sc)[NPOS],
                                             int n_valid, int pmax, f32x4 (&mx)[NB],
-                                            f32x4 (&Z)[NB], f32x4 (&out)[NB]) {
+                                            f32x4 (&Z)[NB], f32x4 (&out)[NB], float* __restrict__ sAw) {
   f32x4 a[NPOS][NB];
 #pragma unroll
   for (int kb = 0; kb < NB; ++kb) mx[kb] = (f32x4)(TLSAN_NEG);
@@ -90,6 +90,7 @@ __device__ __forceinline__ void fwa_forward(const float (&FT1)[NB][NB][4], const
     for (int kb = 0; kb < NB; ++kb) {
       a[p][kb] = a[p][kb] * Z[kb];
       out[kb] += a[p][kb] * (e[p][kb] * sc[p]);  // model.py:387
+      if (sAw != nullptr) *(f32x4*)(sAw + (p * NB + kb) * 256) = a[p][kb];  // [position][lane] float4s
     }
 }
 
@@ -316,11 +317,13 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   float* sW = sH + NSB * 2 * LSC;     // [2][WB] attention weights (W1,b1,W2,b2) of both blocks
   int* sP = (int*)(sW + (USE_SW ? 2 * WB : 0));  // [NSB][PSTR] destination-sorted row of every use
   float* sT = (float*)(sP + (TRAIN ? NSB * PSTR : 0));  // per-wave transpose scratch / staging
+  constexpr bool KEEP_A = G::KEEP_A && TRAIN && !LSTREAM;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int q = lane >> 4, r = lane & 15;
   const int s_loc = r / CPS, col = r % CPS;
   const int srow = wave * SPW + s_loc;  // sample row inside the workgroup pass
   float* T = sT + wave * G::WSCR;
+  float* sAw = sT + NW * G::WSCR + wave * (LS * NB * 256) + lane * 4;  // this lane's slot of the kept softmax weights
   int chb[NB];
 #pragma unroll
   for (int kb = 0; kb < NB; ++kb) chb[kb] = col * CW + 16 * kb + 4 * q;
@@ -491,7 +494,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       load_frag_T<DH, NB>(w1W2, q, r, FT2);
       load_bias<DH, NB>(w1b1, q, b1);
       load_bias<DH, NB>(w1b2, q, b2);
-      fwa_forward<NB, LS>(FT1, b1, FT2, b2, e1, sc1, n_l, pmax1, mx1, iz1, long4);
+      fwa_forward<NB, LS>(FT1, b1, FT2, b2, e1, sc1, n_l, pmax1, mx1, iz1, long4, KEEP_A ? sAw : nullptr);
     }
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
@@ -876,16 +879,21 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             for (int kb = 0; kb < NB; ++kb) xv[kb] = e1[p][kb] * scp;
             if (p == 1) TLSAN_STAMP(12);
             map_apply<NB>(FT1, b1, xv, z1);
+            if constexpr (KEEP_A) {
 #pragma unroll
-            for (int kb = 0; kb < NB; ++kb)
+              for (int kb = 0; kb < NB; ++kb) av[kb] = *(const f32x4*)(sAw + (p * NB + kb) * 256);
+            } else {
 #pragma unroll
-              for (int i = 0; i < 4; ++i) zr[kb][i] = fmaxf(z1[kb][i], 0.0f);
-            map_apply<NB>(FT2, b2, zr, m2);
+              for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
-            for (int kb = 0; kb < NB; ++kb)
+                for (int i = 0; i < 4; ++i) zr[kb][i] = fmaxf(z1[kb][i], 0.0f);
+              map_apply<NB>(FT2, b2, zr, m2);
 #pragma unroll
-              for (int i = 0; i < 4; ++i)
-                av[kb][i] = vp ? __expf(m2[kb][i] - mx1[kb][i]) * iz1[kb][i] : 0.0f;
+              for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                  av[kb][i] = vp ? __expf(m2[kb][i] - mx1[kb][i]) * iz1[kb][i] : 0.0f;
+            }
             if (p == 1) TLSAN_STAMP(13);
             float* Tp = T + (NBUF > 1 ? (p & 1) * TB : 0);
             bwd_compute<NB, TSTR>(FN2, FN1, xv, z1, av, long4, dlong, Tp, q, r, acc.db1, acc.db2, dx);

@@ -45,7 +45,8 @@ struct Geo {
   static constexpr int TSTR = 20;               // LDS row stride of the 16x16 transpose tiles
   // per-wave LDS scratch (floats): 4*NB transpose tiles, or the staged gradient accumulators
   static constexpr int TBUF = 4 * NB * 16 * TSTR;   // one buffer: x, dz1, m1, dm2 tiles
-  static constexpr int NBUF = NB == 1 ? 2 : 1;      // double-buffered when it fits the LDS
+  static constexpr int NBUF = 1;                    // (double-buffering the tiles bought nothing measurable)
+  static constexpr bool KEEP_A = NB == 1;           // long block's softmax weights kept in LDS for the backward
   static constexpr bool USE_SW = NB == 1;           // attention weights in LDS when they fit
   static constexpr int WSCR_T = NBUF * TBUF;
   static constexpr int WSCR_A = (2 * NB * NB + 3 * NB) * 256;
