@@ -217,8 +217,9 @@ int tlsan_scan_compact(const int32_t* cnt, int32_t n, int32_t* prefix, int32_t* 
 int tlsan_profile_enable(int level);
 int tlsan_profile_collect(float* host_ms, int max_steps);
 
-/* Diagnostic: device buffer [blocks*8 waves][16] of s_memtime stamps written by the fused
- * kernel at its phase boundaries (NULL = off, the default). */
+/* Diagnostic: device buffer of s_memtime stamps (NULL = off, the default): entries
+ * [blocks*8 waves][16] written by the fused kernel at its phase boundaries and, from entry
+ * 2^20 on, [workgroups][8] written by k_apply (the buffer must hold 2^20 + 8*grid entries). */
 int tlsan_debug_stamps(void* device_buf);
 
 #ifdef __cplusplus

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-workgroup s_memtime stamps of k_apply (start times, phase durations per block type)."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tlsan_amd import _lib as L, synth
+from tlsan_amd.model import Model
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+cfg = synth.make_config("electronics")
+m = Model(cfg, synth.item_cate_list(cfg), l2_mode="lazy")
+lib = L.load()
+hb = synth.make_batches(cfg, 1, B, seed=7)[0]
+db = m.device_batch(hb)
+for _ in range(5):
+    m.train_async(db, 1.0)
+OFF = 1 << 20
+NBLK = 8192
+st = torch.zeros(OFF + NBLK * 8, dtype=torch.int64, device="cuda")
+lib.tlsan_debug_stamps(st.data_ptr())
+m.train_async(db, 1.0)
+torch.cuda.synchronize()
+lib.tlsan_debug_stamps(None)
+s = st.cpu().numpy()[OFF:].reshape(NBLK, 8).astype(np.float64)
+used = s[:, 0] > 0
+n = int(used.sum())
+s = s[:n]
+t0 = s[:, 0].min()
+C = cfg["cate_count"]
+Sn = db.Sn
+ni = min(cfg["item_count"], B * (cfg["Ls"] + Sn + 1))
+nbI = (ni + 15) // 16
+nbU = (min(B, cfg["user_count"]) + 15) // 16
+print("blocks %d: cate %d, item %d, user %d, dense %d; span %.0f ticks (100 MHz -> %.1f us)" % (n, C, nbI, nbU, n - C - nbI - nbU, s[:, 6].max() - t0, (s[:, 6].max() - t0) / 100))
+def show(name, lo, hi):
+    x = s[lo:hi]
+    if len(x) == 0:
+        return
+    print("%-6s start p0/50/100 %5.0f %5.0f %5.0f | end p50/100 %5.0f %5.0f | dur p50 %5.0f max %5.0f" % (
+        name, *(np.percentile(x[:, 0] - t0, [0, 50, 100])), *(np.percentile(x[:, 6] - t0, [50, 100])),
+        np.median(x[:, 6] - x[:, 0]), (x[:, 6] - x[:, 0]).max()))
+    d = np.diff(x[:, :7], axis=1)
+    ok = (x[:, 1:7] > 0).all(1)
+    if ok.any():
+        print("        phases (median ticks): " + " ".join("%d:%.0f" % (i, np.median(d[ok, i])) for i in range(6)))
+show("cate", 0, C)
+show("item", C, C + nbI)
+show("user", C + nbI, C + nbI + nbU)
+show("dense", C + nbI + nbU, n)

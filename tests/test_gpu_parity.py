@@ -332,13 +332,16 @@ def test_graph_replay_equals_eager():
         assert np.array_equal(outs[0][k], outs[1][k]), k
 
 
-def test_full_size_batch_matches_oracle():
-    """One step at the bench shape class (B=4096 -> 256 workgroup passes, hot rows, hot categories)."""
+@pytest.mark.parametrize("C,l2_mode", [(40, "lazy"), (3, "lazy"), (3, "dense")])
+def test_full_size_batch_matches_oracle(C, l2_mode):
+    """One step at the bench shape class (B=4096 -> 256 workgroup passes, hot rows, hot categories).
+    C=3: ~13k uses and ~670 items per category -> the category blocks of k_apply take several
+    256-item passes and the segment-by-segment path (use list larger than AP_CAP)."""
     from tlsan_amd import synth
-    cfg = synth.make_config("electronics", user_count=3000, item_count=2000, cate_count=40)
+    cfg = synth.make_config("electronics", user_count=3000, item_count=2000, cate_count=C)
     icl = synth.item_cate_list(cfg)
     batch = synth.make_batches(cfg, 1, 4096, seed=5)[0]
-    m = _model(cfg, icl, l2_mode="lazy")
+    m = _model(cfg, icl, l2_mode=l2_mode)
     p = {k: np.asarray(v, np.float64) for k, v in m.get_params().items()}
     b = orc.as_batch(batch)
     loss, newp, info = orc.train_step(p, icl, b, 8, cfg["regulation_rate"], lr=1.0)

@@ -33,6 +33,7 @@ static int fail(int code, const char* fmt, ...) {
 #define PROF_MAX_STEPS 4096
 #define PROF_MARKS 6
 static unsigned long long* g_stamps = nullptr;
+#define TLSAN_APPLY_STAMP_OFF (1 << 20)  // k_apply's stamps start this many entries into the debug buffer
 static int g_prof_level = 0;
 static int g_prof_n = 0;
 static hipEvent_t* g_prof_ev = nullptr;  // [PROF_MAX_STEPS][PROF_MARKS], created on first enable
@@ -67,8 +68,9 @@ static int shape_of(const tlsan_dims* d, Shape* s) {
 }
 
 struct Ws {  // carve-up of the caller's scratch buffer
-  float *Gi, *Gb, *Gu, *Gc, *Pc, *gLong, *gDB, *partials, *Kp, *gd, *sqd, *scal, *logits, *s_label;
-  int32_t *off_item, *off_uc, *off_user, *cur_item, *cur_uc, *cur_user, *uniq_item, *uniq_user;
+  float *Gi, *Gb, *Gu, *Gc, *gLong, *gDB, *partials, *Kp, *gd, *sqd, *scal, *logits, *s_label;
+  int32_t *off_item, *off_uc, *off_user, *cur_item, *cur_uc, *cur_user;
+  int4 *urec_item, *urec_user;
   double* rownorm_part;
   double* rownorm;
   size_t bytes;
@@ -89,11 +91,11 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
   w->nbK = (s.D * s.D + 255) / 256;
   w->nbS = (L.n_dense - s.D * s.D + 15) / 16;
   w->nfin = w->nbK + w->nbS;
-  w->Gi = (float*)take(sizeof(float) * NI * D);
-  w->Gb = (float*)take(sizeof(float) * NI);
-  w->Gu = (float*)take(sizeof(float) * (size_t)B * w->WU);
-  w->Gc = (float*)take(sizeof(float) * (size_t)B * d->d_cate);
-  w->Pc = (float*)take(sizeof(float) * (size_t)d->item_count * d->d_cate);
+  // (+1 row: k_apply reads clamped addresses instead of branching, see AP_OWN)
+  w->Gi = (float*)take(sizeof(float) * (NI + 1) * D);
+  w->Gb = (float*)take(sizeof(float) * (NI + 1));
+  w->Gu = (float*)take(sizeof(float) * (size_t)(B + 1) * w->WU);
+  w->Gc = (float*)take(sizeof(float) * (size_t)(B + 1) * d->d_cate);
   w->gLong = (float*)take(sizeof(float) * B * D);
   w->gDB = (float*)take(sizeof(float) * B * D);
   w->partials = (float*)take(sizeof(float) * w->ngroups * s.NPB);
@@ -103,14 +105,14 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
   w->scal = (float*)take(sizeof(float) * 4);
   w->logits = (float*)take(sizeof(float) * B);
   w->s_label = (float*)take(sizeof(float) * B);
-  w->off_item = (int32_t*)take(4 * (size_t)d->item_count);
-  w->off_uc = (int32_t*)take(4 * (size_t)d->cate_count);
-  w->off_user = (int32_t*)take(4 * (size_t)d->user_count);
+  w->off_item = (int32_t*)take(4 * ((size_t)d->item_count + 1));
+  w->off_uc = (int32_t*)take(4 * ((size_t)d->cate_count + 1));
+  w->off_user = (int32_t*)take(4 * ((size_t)d->user_count + 1));
   w->cur_item = (int32_t*)take(4 * (size_t)d->item_count);
   w->cur_uc = (int32_t*)take(4 * (size_t)d->cate_count);
   w->cur_user = (int32_t*)take(4 * (size_t)d->user_count);
-  w->uniq_item = (int32_t*)take(4 * (size_t)d->item_count);
-  w->uniq_user = (int32_t*)take(4 * (size_t)d->user_count);
+  w->urec_item = (int4*)take(16 * ((size_t)d->item_count + AP_ROWS_PB));
+  w->urec_user = (int4*)take(16 * ((size_t)d->user_count + AP_ROWS_PB));
   const size_t nrowblk = (size_t)(d->item_count + 15) / 16 + (d->user_count + 15) / 16 + d->cate_count;
   w->rownorm_part = (double*)take(8 * nrowblk);
   w->rownorm = (double*)take(8);
@@ -219,37 +221,32 @@ static void fill_apply(ApplyArgs& A, const tlsan_dims* d, const Shape& s, const 
   A.lay = L;
   A.I = d->item_count; A.U = d->user_count; A.C = d->cate_count; A.Ls = d->Ls; A.D = s.D;
   A.di = d->d_item; A.dc = d->d_cate; A.WU = ru4(d->d_item + d->Ls);
-  A.Gi = w.Gi; A.Gb = w.Gb; A.Gu = w.Gu; A.Gc = w.Gc; A.Pc = w.Pc;
+  A.Gi = w.Gi; A.Gb = w.Gb; A.Gu = w.Gu; A.Gc = w.Gc;
   A.cnt_item = st.cnt_item; A.cnt_uc = st.cnt_uc; A.cnt_user = st.cnt_user;
   A.off_item = w.off_item; A.off_uc = w.off_uc; A.off_user = w.off_user;
   A.cate_off = st.cate_off; A.cate_cnt = st.cate_cnt; A.cate_items = st.cate_items;
-  A.gd = w.gd; A.sqd = w.sqd; A.nsqd = w.nfin; A.scal = w.scal;
-  A.part_out = st.S_part; A.hdr = st.hdr; A.rownorm = w.rownorm;
-  A.uniq_item = w.uniq_item; A.uniq_user = w.uniq_user;
-  if (hp) { A.lr = hp->lr; A.reg = hp->reg; A.clip = hp->clip; A.norm_mode = hp->norm_mode; }
-  A.inv_B = b ? 1.0f / (float)b->B : 0.0f;
+  A.gd = w.gd;
+  A.part_out = st.S_part; A.hdr = st.hdr;
+  A.urec_item = w.urec_item; A.urec_user = w.urec_user;
+  if (hp) { A.lr = hp->lr; A.reg = hp->reg; }
   A.nbI = st.nbI; A.nbU = st.nbU; A.nbC = st.nbC; A.nbD = (L.n_dense + 255) / 256;
+  A.stamps = g_stamps ? g_stamps + TLSAN_APPLY_STAMP_OFF : nullptr;
 }
 
-// the two launches of one apply pass: item/user rows (+ dense parameters), then category rows.
-// lazy (UPDATE only): the row blocks walk the compacted lists of used rows.
+// one apply pass = one launch: category rows, item/user rows (+ dense parameters).
+// lazy (UPDATE only): the row blocks walk the compacted records of used rows.
 static int launch_apply(int mode, bool lazy, ApplyArgs A, bool with_dense, int B, int Sn, hipStream_t hs) {
   if (lazy) {  // at most min(rows, uses) rows were used
     const long ni = (long)B * (A.Ls + Sn + 1);
     A.nbI = (int)(((ni < A.I ? ni : A.I) + AP_ROWS_PB - 1) / AP_ROWS_PB);
     A.nbU = ((B < A.U ? B : A.U) + AP_ROWS_PB - 1) / AP_ROWS_PB;
   }
-  const dim3 g1(A.nbI + A.nbU + (with_dense ? A.nbD : 0)), g2(A.nbC), blk(256);
-  const bool wide = A.D > 128 || A.WU > 128;  // float4 chunks per lane: 2 (<= 128 columns) or 4
+  const dim3 g1(A.nbC + A.nbI + A.nbU + (with_dense ? A.nbD : 0)), blk(256);
+  const bool wide = A.WU > 128;  // float4 chunks per lane: 2 (rows of <= 128 columns) or 4
 #define AP_LAUNCH(M, LZ)                                                                   \
   do {                                                                                     \
-    if (wide) {                                                                            \
-      hipLaunchKernelGGL((k_apply_rows<M, LZ, 4>), g1, blk, 0, hs, A);                     \
-      hipLaunchKernelGGL((k_apply_cates<M, LZ, 4>), g2, blk, 0, hs, A);                    \
-    } else {                                                                               \
-      hipLaunchKernelGGL((k_apply_rows<M, LZ, 2>), g1, blk, 0, hs, A);                     \
-      hipLaunchKernelGGL((k_apply_cates<M, LZ, 2>), g2, blk, 0, hs, A);                    \
-    }                                                                                      \
+    if (wide) hipLaunchKernelGGL((k_apply<M, LZ, 4>), g1, blk, 0, hs, A);                  \
+    else hipLaunchKernelGGL((k_apply<M, LZ, 2>), g1, blk, 0, hs, A);                       \
   } while (0)
   switch (mode) {
     case AP_UPDATE:
@@ -261,7 +258,7 @@ static int launch_apply(int mode, bool lazy, ApplyArgs A, bool with_dense, int B
     default: AP_LAUNCH(AP_ROWNORM, false); break;
   }
 #undef AP_LAUNCH
-  CHECK_LAUNCH("k_apply_rows / k_apply_cates");
+  CHECK_LAUNCH("k_apply");
   return TLSAN_OK;
 }
 
@@ -408,8 +405,8 @@ int tlsan_forward(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch*
 
 // shared front half of train_step / grads: index build, fused fwd+bwd, dense-grad reduction
 static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params* p, const tlsan_batch* b,
-                        const tlsan_step_out* out, const Ws& w, const St& st, const tlsan_dense_layout& L,
-                        hipStream_t hs) {
+                        const tlsan_hparams* hp, bool commit, const tlsan_step_out* out, const Ws& w, const St& st,
+                        const tlsan_dense_layout& L, hipStream_t hs) {
   // --- use counts per destination row -> first sorted position of every row
   CountArgs ca;
   memset(&ca, 0, sizeof(ca));
@@ -429,7 +426,8 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   sa.blk0[1] = (sa.n[0] + 4095) / 4096;
   sa.blk0[2] = sa.blk0[1] + (sa.n[1] + 4095) / 4096;
   const int nscan = sa.blk0[2] + (sa.n[2] + 4095) / 4096;
-  sa.uniq[0] = w.uniq_item; sa.uniq[1] = nullptr; sa.uniq[2] = w.uniq_user;
+  sa.urec[0] = w.urec_item; sa.urec[2] = w.urec_user;
+  sa.total[0] = sa.total[1] = sa.total[2] = 1;
   sa.n_uniq[0] = &st.hdr->n_uniq_item; sa.n_uniq[1] = nullptr; sa.n_uniq[2] = &st.hdr->n_uniq_user;
   hipLaunchKernelGGL(k_index_scan, dim3(nscan), dim3(1024), 0, hs, sa);
   CHECK_LAUNCH("k_index_scan");
@@ -460,6 +458,11 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   f.lay = L; f.partials = w.partials; f.nrec = w.ngroups; f.Kp = w.Kp; f.nsplit = w.nsplit;
   f.gd = w.gd; f.sqd = w.sqd; f.scal = w.scal;
   f.S_part = st.S_part; f.n_spart = st.nbI + st.nbU + st.nbC; f.S_total = st.S_total;
+  f.hdr = st.hdr; f.lr = hp->lr; f.reg = hp->reg; f.clip = hp->clip; f.inv_B = 1.0f / (float)b->B;
+  f.norm_mode = hp->norm_mode; f.commit = commit ? 1 : 0;
+  f.out_loss = out ? out->loss : nullptr;
+  f.out_gnorm = out ? out->gnorm : nullptr;
+  f.out_sq = out ? out->sq_rows : nullptr;
   if (s.D == 64) hipLaunchKernelGGL((k_dense_finalize<64, 8>), dim3(w.nfin + 1), dim3(256), 0, hs, f, w.nbK, w.nbS);
   else if (s.D == 128) hipLaunchKernelGGL((k_dense_finalize<128, 16>), dim3(w.nfin + 1), dim3(256), 0, hs, f, w.nbK, w.nbS);
   else hipLaunchKernelGGL((k_dense_finalize<256, 32>), dim3(w.nfin + 1), dim3(256), 0, hs, f, w.nbK, w.nbS);
@@ -488,6 +491,19 @@ static int prep_step(const tlsan_dims* d, Shape* s, const tlsan_params* p, const
   return TLSAN_OK;
 }
 
+// dedup-norm mode: per-row squared norms of the SUMMED gradients (ROWNORM pass), then the coefficient
+static int clip_dedup(const ApplyArgs& A, const tlsan_hparams* hp, const tlsan_step_out* out, const Ws& w,
+                      const St& st, const tlsan_batch* b, hipStream_t hs) {
+  ApplyArgs R = A;
+  R.part_out = w.rownorm_part;
+  int rc = launch_apply(AP_ROWNORM, false, R, false, b->B, b->Sn, hs);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_clip_dedup, dim3(1), dim3(256), 0, hs, w.rownorm_part, st.nbI + st.nbU + st.nbC, w.sqd, w.nfin,
+                     st.hdr, hp->clip, out ? out->gnorm : nullptr);
+  CHECK_LAUNCH("k_clip_dedup");
+  return TLSAN_OK;
+}
+
 int tlsan_train_step(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch* b, const tlsan_hparams* hp,
                      const tlsan_step_out* out, void* state, void* ws, size_t ws_bytes, void* stream) {
   Shape s; Ws w; St st;
@@ -496,20 +512,10 @@ int tlsan_train_step(const tlsan_dims* d, const tlsan_params* p, const tlsan_bat
   hipStream_t hs = (hipStream_t)stream;
   tlsan_dense_layout L;
   tlsan_dense_layout_of(d, &L);
-  if ((rc = run_backward(d, s, p, b, out, w, st, L, hs))) return rc;
+  if ((rc = run_backward(d, s, p, b, hp, hp->l2_mode == TLSAN_L2_LAZY, out, w, st, L, hs))) return rc;
   ApplyArgs A;
   fill_apply(A, d, s, p, b, hp, w, st, L);
-  A.out_loss = out ? out->loss : nullptr;
-  A.out_gnorm = out ? out->gnorm : nullptr;
-  A.out_sq = out ? out->sq_rows : nullptr;
-  const int nrow = st.nbI + st.nbU + st.nbC;
-  if (hp->norm_mode == TLSAN_NORM_DEDUP) {
-    ApplyArgs R = A;
-    R.part_out = w.rownorm_part;
-    if ((rc = launch_apply(AP_ROWNORM, false, R, false, b->B, b->Sn, hs))) return rc;
-    hipLaunchKernelGGL(k_reduce_double, dim3(1), dim3(256), 0, hs, w.rownorm_part, nrow, w.rownorm);
-    CHECK_LAUNCH("k_reduce_double");
-  }
+  if (hp->norm_mode == TLSAN_NORM_DEDUP && (rc = clip_dedup(A, hp, out, w, st, b, hs))) return rc;
   if ((rc = launch_apply(AP_UPDATE, hp->l2_mode == TLSAN_L2_LAZY, A, true, b->B, b->Sn, hs))) return rc;
   prof_mark(5, hs);
   if (g_prof_level > 0 && g_prof_n < PROF_MAX_STEPS) ++g_prof_n;
@@ -526,21 +532,11 @@ int tlsan_grads(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch* b
   hipStream_t hs = (hipStream_t)stream;
   tlsan_dense_layout L;
   tlsan_dense_layout_of(d, &L);
-  if ((rc = run_backward(d, s, p, b, out, w, st, L, hs))) return rc;
+  if ((rc = run_backward(d, s, p, b, hp, false, out, w, st, L, hs))) return rc;
   ApplyArgs A;
   fill_apply(A, d, s, p, b, hp, w, st, L);
   A.go = *g;
-  A.out_loss = out ? out->loss : nullptr;
-  A.out_gnorm = out ? out->gnorm : nullptr;
-  A.out_sq = out ? out->sq_rows : nullptr;
-  const int nrow = st.nbI + st.nbU + st.nbC;
-  if (hp->norm_mode == TLSAN_NORM_DEDUP) {
-    ApplyArgs R = A;
-    R.part_out = w.rownorm_part;
-    if ((rc = launch_apply(AP_ROWNORM, false, R, false, b->B, b->Sn, hs))) return rc;
-    hipLaunchKernelGGL(k_reduce_double, dim3(1), dim3(256), 0, hs, w.rownorm_part, nrow, w.rownorm);
-    CHECK_LAUNCH("k_reduce_double");
-  }
+  if (hp->norm_mode == TLSAN_NORM_DEDUP && (rc = clip_dedup(A, hp, out, w, st, b, hs))) return rc;
   if ((rc = launch_apply(AP_GRADS, false, A, true, b->B, b->Sn, hs))) return rc;
   prof_mark(5, hs);
   if (g_prof_level > 0 && g_prof_n < PROF_MAX_STEPS) ++g_prof_n;

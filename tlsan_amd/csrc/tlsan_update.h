@@ -4,9 +4,8 @@
 //                     fused kernel then draws one position per use from these cursors
 //   k_dk_partial      dK = long^T . dbridge  (split over the batch, f32 MFMA)
 //   k_dense_finalize  fixed-order reduction of all dense-parameter gradient partials
-//   k_apply_rows      item / user rows: exact sum of the row's contiguous segment of per-use
-//                     gradient rows + clip + SGD (model.py:198-205); per-item category partials
-//   k_apply_cates     category rows: two-level (items of the category, then u_cate uses)
+//   k_apply           one launch for all tables: exact sum of every destination row's contiguous
+//                     segment(s) of per-use gradient rows + clip + SGD (model.py:198-205)
 // Determinism: integer atomics only build *which* rows belong to a destination; the float
 // sums are order-independent (exact_term) or in a fixed order, so two runs are bitwise equal.
 #pragma once
@@ -14,14 +13,19 @@
 
 // first bytes of the persistent state buffer
 struct StateHdr {
+  // ---- read-mostly line
   float P;                 // scale of the four regularised tables: W_true = P * W_stored (1 unless lazy L2)
-  float pad0;
+  float P_prev;            // P before the current step's commit: what k_apply scales with
   int32_t n_uniq_item;     // rows that received a gradient in the current step (k_index_scan)
   int32_t n_uniq_user;
-  int32_t ticket;          // arrival counter of k_apply_cates: the last workgroup commits P
-  int32_t pad1;
   double St;               // sum of squares of the four STORED tables (true value: P^2 * St)
+  float coef;              // global-norm clip coefficient of the current step (model.py:201)
+  float pad0[25];
+  // ---- its own 128-B line: hammered by atomics, must not share a line with anything that is read
+  int32_t ticket;          // arrival counter of k_dense_finalize: the last workgroup writes the step summary
+  int32_t pad1[31];
 };
+static_assert(sizeof(StateHdr) == 256, "StateHdr layout");
 
 struct CountArgs {
   tlsan_batch b;
@@ -31,8 +35,8 @@ struct CountArgs {
 
 // Use counts per destination row: one thread per (sample, slot); slots [0,Ls) long positions,
 // [Ls,Ls+Sn) session positions, Ls+Sn candidate, Ls+Sn+1 the user use (user row + u_cate row).
-// Category rows get their item-side gradients through the items (two-level reduction, see
-// k_apply_cates), so only the u_cate uses are counted per category.
+// Category rows find their item-side gradients through the segments of their items (see k_apply),
+// so only the u_cate uses are counted per category.
 __global__ void k_count(CountArgs a) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int B = a.b.B, Ls = a.Ls, Sn = a.b.Sn, S = Ls + Sn + 2;
@@ -57,8 +61,10 @@ struct ScanArgs {
   int32_t* cur[3];
   int32_t n[3];
   int32_t blk0[3];     // first block of each table in the grid
-  int32_t* uniq[3];    // optional: ids with cnt > 0, ascending (lazy L2: rows to update)
+  int32_t* uniq[3];    // optional: ids with cnt > 0, ascending
   int32_t* n_uniq[3];  // optional: how many
+  int4* urec[3];       // optional: (id, first position, count) of the ids with cnt > 0 (lazy L2: rows to update)
+  int32_t total[3];    // != 0: off has n+1 entries, off[n] = sum of all counts
 };
 
 // Exclusive scan of the per-row counts, one launch: block j of a table owns ids
@@ -116,14 +122,20 @@ __global__ __launch_bounds__(1024) void k_index_scan(ScanArgs a) {
   int32_t* off = a.off[which];
   int32_t* cur = a.cur[which];
   int32_t* uniq = a.uniq[which];
+  int4* urec = a.urec[which];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     if (i0 + k < n) {
-      off[i0 + k] = (int)(run & 0xffffffffLL);
-      if (cur) cur[i0 + k] = (int)(run & 0xffffffffLL);
+      const int o = (int)(run & 0xffffffffLL);
+      off[i0 + k] = o;
+      if (cur) cur[i0 + k] = o;
       if (uniq && v[k] > 0) uniq[(int)(run >> 32)] = i0 + k;
+      if (urec && v[k] > 0) urec[(int)(run >> 32)] = make_int4(i0 + k, o, v[k], 0);
       run += pack(v[k]);
-      if (i0 + k == n - 1 && a.n_uniq[which]) *a.n_uniq[which] = (int)(run >> 32);
+      if (i0 + k == n - 1) {
+        if (a.n_uniq[which]) *a.n_uniq[which] = (int)(run >> 32);
+        if (a.total[which]) off[n] = (int)(run & 0xffffffffLL);
+      }
     }
   }
 }
@@ -180,7 +192,64 @@ struct FinArgs {
   double* S_part;         // per-row-block changes of the regularised tables' sum of squares
   int32_t n_spart;
   double* S_total;
+  // step summary (written by the last workgroup to arrive)
+  StateHdr* hdr;
+  float lr, reg, clip, inv_B;
+  int32_t norm_mode;
+  int32_t commit;          // lazy L2 update: advance the table scale P (P_prev keeps the old value)
+  float* out_loss; float* out_gnorm; float* out_sq;
 };
+
+// The step's scalars, computed once by the last workgroup of k_dense_finalize instead of by every
+// workgroup of k_apply: global norm (tf18: per-use rows + (reg*W)^2 + dense; model.py:198-201),
+// clip coefficient, loss with the L2 term (model.py:181-196), and the new table scale for lazy L2.
+// Dedup-norm mode finishes the coefficient in k_clip_dedup (it needs the per-row sums first).
+//
+// Hand-over without a device-wide fence (a release fence would write back the whole L2, which
+// holds the step's gradient rows): the few scalars other workgroups produced are published with
+// returning device-scope atomics (pub_*; the wait for the returned value orders them before the
+// ticket) and read back here with device-scope atomic loads.
+__device__ __forceinline__ void pub_f32(float* p, float v) {
+  const float old = atomicExch(p, v);
+  asm volatile("" ::"v"(old));  // wait for the return: the exchange has been performed
+}
+__device__ __forceinline__ void pub_f64(double* p, double v) {
+  const unsigned long long old = atomicExch((unsigned long long*)p, (unsigned long long)__double_as_longlong(v));
+  asm volatile("" ::"v"(old));
+}
+__device__ __forceinline__ float acq_f32(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double acq_f64(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void step_summary(const FinArgs& a, int nsqd, double* shd) {
+  const int tid = threadIdx.x;
+  double sq = 0.0;
+  for (int k = tid; k < nsqd; k += 256) sq += (double)acq_f32(a.sqd + k);
+  shd[tid] = sq;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (tid < o) shd[tid] += shd[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const float P = a.hdr->P;
+    const double St = acq_f64(a.S_total) * (double)P * (double)P;  // true tables = P * stored
+    const float sc0 = acq_f32(a.scal + 0), sc1 = acq_f32(a.scal + 1);
+    sq = shd[0] + (double)sc1 + (double)a.reg * (double)a.reg * St;
+    const float norm = (float)sqrt(sq);
+    const float coef = a.clip / fmaxf(norm, a.clip);
+    a.hdr->coef = coef;
+    a.hdr->P_prev = P;
+    if (a.commit) a.hdr->P = P * (1.0f - a.lr * coef * a.reg);
+    if (a.norm_mode == TLSAN_NORM_TF18 && a.out_gnorm) *a.out_gnorm = norm;
+    if (a.out_loss) *a.out_loss = sc0 * a.inv_B + a.reg * (float)(0.5 * St);
+    if (a.out_sq) *a.out_sq = sc1;
+    a.hdr->ticket = 0;
+  }
+}
 
 // fixed-order sum of doubles by one 256-thread block
 __device__ __forceinline__ double block_sum_double(const double* __restrict__ v, int n, double* sh) {
@@ -212,12 +281,13 @@ __global__ __launch_bounds__(256) void k_dense_finalize(FinArgs a, int nbK, int 
     // and clear them (consumed exactly once)
     const double s = block_sum_double(a.S_part, a.n_spart, shd);
     for (int k = tid; k < a.n_spart; k += 256) a.S_part[k] = 0.0;
-    if (tid == 0) *a.S_total += s;
-    return;
+    if (tid == 0) pub_f64(a.S_total, *a.S_total + s);
+    __syncthreads();  // shd is reused below
   }
   float g = 0.0f;
   bool owner = false;
-  if (blk < nbK) {
+  if (blk == nbK + nbS) {
+  } else if (blk < nbK) {
     const int idx = blk * 256 + tid;
     if (idx < D * D) {
       float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f;
@@ -278,14 +348,42 @@ __global__ __launch_bounds__(256) void k_dense_finalize(FinArgs a, int nbK, int 
     if (tid < o) shd[tid] += shd[tid + o];
     __syncthreads();
   }
-  if (tid == 0) a.sqd[blk] = (float)shd[0];
+  if (tid == 0 && blk < nbK + nbS) pub_f32(a.sqd + blk, (float)shd[0]);
   if (blk == 0 && tid < 32) {  // loss sum and per-use square sum: 16 lanes each, fixed order
     const int which = tid >> 4, rl = tid & 15;
     float t = 0.0f;
     for (int rec = rl; rec < a.nrec; rec += 16) t += a.partials[(size_t)rec * NPB + G::P_LOSS + which];
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) t += __shfl_xor(t, o);
-    if (rl == 0) a.scal[which] = t;
+    if (rl == 0) pub_f32(a.scal + which, t);
+  }
+  // ---- the last workgroup to arrive sees every other one's results and writes the step summary
+  __shared__ int sh_last;
+  __syncthreads();
+  if (tid == 0) sh_last = atomicAdd(&a.hdr->ticket, 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (sh_last) step_summary(a, nbK + nbS, shd);
+}
+
+// dedup-norm mode: norm^2 = sum over destination rows of |summed row gradient|^2 (ROWNORM pass)
+// + dense gradients; overrides the coefficient / norm of the step summary
+__global__ __launch_bounds__(256) void k_clip_dedup(const double* rown_part, int nrow, const float* sqd, int nsqd,
+                                                    StateHdr* hdr, float clip, float* out_gnorm) {
+  __shared__ double shd[256];
+  const int tid = threadIdx.x;
+  double s = 0.0;
+  for (int k = tid; k < nrow; k += 256) s += rown_part[k];
+  for (int k = tid; k < nsqd; k += 256) s += (double)sqd[k];
+  shd[tid] = s;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (tid < o) shd[tid] += shd[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const float norm = (float)sqrt(shd[0]);
+    hdr->coef = clip / fmaxf(norm, clip);
+    if (out_gnorm) *out_gnorm = norm;
   }
 }
 
@@ -309,20 +407,17 @@ struct ApplyArgs {
   tlsan_dense_layout lay;
   int32_t I, U, C, Ls, D, di, dc, WU;
   const float* Gi; const float* Gb; const float* Gu; const float* Gc;
-  float* Pc;                                   // [I, dc] per-item sums of the category halves
   int32_t* cnt_item; int32_t* cnt_user; int32_t* cnt_uc;
-  const int32_t* off_item; const int32_t* off_user; const int32_t* off_uc;
-  const int32_t* uniq_item; const int32_t* uniq_user;   // lazy L2: rows used this step
+  const int32_t* off_item; const int32_t* off_user; const int32_t* off_uc;   // n+1 entries each
+  const int4* urec_item; const int4* urec_user;   // lazy L2: (row, first position, uses) of the rows used this step
   const int32_t* cate_off; const int32_t* cate_cnt; const int32_t* cate_items;  // static CSR
-  const float* gd; const float* sqd; int32_t nsqd; const float* scal;
+  const float* gd;
   double* part_out;        // UPDATE: change of the stored tables' sum of squares per workgroup;
                            // SUMSQ: sum of squares; ROWNORM: sum g^2
-  StateHdr* hdr;           // P, St, n_uniq_*, ticket
-  const double* rownorm;   // dedup mode: sum over rows of |g_row|^2 (from the ROWNORM pass)
-  float lr, reg, clip, inv_B;
-  int32_t norm_mode;
-  float* out_loss; float* out_gnorm; float* out_sq;
+  const StateHdr* hdr;     // P, P_prev, coef, n_uniq_*
+  float lr, reg;
   int32_t nbI, nbU, nbC, nbD;
+  unsigned long long* stamps;  // debug: 8 s_memtime stamps per workgroup (tlsan_debug_stamps)
 };
 
 #define AP_OWN 8        // uses a 16-lane group sums alone before the wavefront helps
@@ -370,41 +465,6 @@ __device__ __forceinline__ void combine_groups(double (&acc)[NCH][4]) {
     }
 }
 
-// the global-norm clip coefficient (model.py:201), identical in every workgroup: the per-block
-// squares of the dense gradients are summed by the whole workgroup (one load per thread, fixed
-// shuffle tree) instead of a serial loop on one lane
-template <int MODE>
-__device__ __forceinline__ float clip_coef(const ApplyArgs& a, float P, float* sh_coef, bool writer) {
-  if constexpr (MODE == AP_UPDATE || MODE == AP_GRADS) {
-    __shared__ double sh_sq[4];
-    double sq = 0.0;
-    for (int k = threadIdx.x; k < a.nsqd; k += 256) sq += (double)a.sqd[k];
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) sq += __shfl_xor(sq, o);
-    if ((threadIdx.x & 63) == 0) sh_sq[threadIdx.x >> 6] = sq;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      // tf18: per-use rows + (reg*W)^2 + dense; dedup: summed rows + dense
-      sq = (sh_sq[0] + sh_sq[1]) + (sh_sq[2] + sh_sq[3]);
-      const double St = a.hdr->St * (double)P * (double)P;  // true tables = P * stored
-      if (a.norm_mode == TLSAN_NORM_TF18)
-        sq += (double)a.scal[1] + (double)a.reg * (double)a.reg * St;
-      else
-        sq += *a.rownorm;
-      const float norm = (float)sqrt(sq);
-      *sh_coef = a.clip / fmaxf(norm, a.clip);
-      if (writer) {
-        if (a.out_gnorm) *a.out_gnorm = norm;
-        if (a.out_loss) *a.out_loss = a.scal[0] * a.inv_B + a.reg * (float)(0.5 * St);
-        if (a.out_sq) *a.out_sq = a.scal[1];
-      }
-    }
-    __syncthreads();
-    return *sh_coef;
-  }
-  return 1.0f;
-}
-
 __device__ __forceinline__ void block_part_store(double part, double* shd, double* dst) {
   __syncthreads();
 #pragma unroll
@@ -434,256 +494,350 @@ __device__ __forceinline__ float apply_elem(float& w, float gs, float P, float i
   return g;
 }
 
-// Block layout: [0,nbI) item rows, [nbI,nbI+nbU) user rows (user_emb + usert_emb): one row per
-// 16-lane group; the first AP_OWN uses of a row are summed by its group, longer segments (hot
-// items) by the whole wavefront.  Then nbD blocks of 256 dense parameters.
-// Item rows carry [item half | cate half]: the item half updates item_emb, the cate half is
-// written to Pc[item] for k_apply_cates.  User rows are [user_emb | usert_emb | pad].
-// LAZY: the row blocks walk the compacted lists of used rows instead of every row.
-// NCH = float4 chunks per lane: 16 lanes x NCH x 4 floats >= the widest fused row (d, WU)
-template <int MODE, bool LAZY, int NCH>
-__global__ __launch_bounds__(256) void k_apply_rows(ApplyArgs a) {
-  __shared__ double shd[4];
-  __shared__ float sh_coef;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, grp = lane >> 4, l16 = lane & 15;
-  const int D = a.D;
-  const float P = a.hdr->P, invP = 1.0f / P;
-  const float coef = clip_coef<MODE>(a, P, &sh_coef, blockIdx.x == 0);
-  const float step = a.lr * coef;
-  const float lazy_scale = step / (P * (1.0f - step * a.reg));
-  double part = 0.0;
-  const int blk = blockIdx.x;
-  if (blk >= a.nbI + a.nbU) {
-    if constexpr (MODE == AP_UPDATE || MODE == AP_GRADS) {
-      const int n = (blk - a.nbI - a.nbU) * 256 + tid;
-      if (n < a.lay.n_dense) {
-        const float g = a.gd[n];
-        if constexpr (MODE == AP_GRADS) {
-          a.go.dense[n] = g;
-        } else {
-          const float w = a.p.dense[n] - step * g;
-          a.p.dense[n] = w;
-          if (n >= a.lay.K && n < a.lay.k0) {
-            const int idx = n - a.lay.K;
-            a.p.dense_KT[(size_t)(idx % D) * D + idx / D] = w;
-          }
-        }
-      }
-    }
-    return;
-  }
-  const bool is_item = blk < a.nbI;
-  const int slot = (is_item ? blk : blk - a.nbI) * AP_ROWS_PB + wave * 4 + grp;
-  int row = slot;
-  bool vr;
-  if constexpr (LAZY) {
-    vr = slot < (is_item ? a.hdr->n_uniq_item : a.hdr->n_uniq_user);
-    row = vr ? (is_item ? a.uniq_item : a.uniq_user)[slot] : 0;
-  } else {
-    vr = row < (is_item ? a.I : a.U);
-  }
-  const float* Gs = is_item ? a.Gi : a.Gu;
-  const int ld = is_item ? D : a.WU;
-  const int W4 = ld / 4;
-  double acc[NCH][4];
-  zero_acc(acc);
-  double bacc = 0.0;  // item_b gradient of the row (item rows)
-  int n = 0, off = 0;
-  if constexpr (MODE != AP_SUMSQ) {
-    if (vr) {
-      n = (is_item ? a.cnt_item : a.cnt_user)[row];
-      off = (is_item ? a.off_item : a.off_user)[row];
-    }
-    const int n_own = min(n, AP_OWN);
-    seg_accum(Gs, ld, off, off + n_own, 1, W4, l16, acc);
-    if (is_item)
-      for (int k = off + l16; k < off + n_own; k += 16) bacc += exact_term(a.Gb[k]);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int ng = __shfl(n, g * 16);
-      if (ng > AP_OWN) {  // wave-uniform: the four groups split the rest of group g's segment
-        const int og = __shfl(off, g * 16);
-        double t[NCH][4];
-        zero_acc(t);
-        seg_accum(Gs, ld, og + AP_OWN + grp, og + ng, 4, W4, l16, t);
-        double tb = 0.0;
-        if (is_item)
-          for (int k = og + AP_OWN + lane; k < og + ng; k += 64) tb += exact_term(a.Gb[k]);
-        combine_groups(t);
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) tb += __shfl_xor(tb, o);
-        if (grp == g) {
-#pragma unroll
-          for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[ch][i] += t[ch][i];
-          if (l16 == 0) bacc += tb;
-        }
-      }
-    }
-    if (is_item) {  // fold the group's 16 partial bias sums (exact doubles: any order)
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) bacc += __shfl_xor(bacc, o);
-    }
-    if constexpr (MODE != AP_ROWNORM) {
-      if (!is_item && vr && n > 0 && l16 == 0) a.cnt_user[row] = 0;  // counters are zero at rest
-      // (cnt_item is read as the "used" flag and reset by k_apply_cates)
-    }
-  }
-  if (vr) {
-    // column c of the fused row -> parameter element
-    //   item rows: c < di -> item_emb[row][c];  di <= c < di+dc -> Pc[row][c-di] (not a parameter)
-    //   user rows: c < di -> user_emb[row][c];  di <= c < di+Ls -> usert_emb[row][c-di]
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-      const int c = 4 * (l16 + 16 * ch);
-      if (c >= ld) continue;
-      if (is_item && c >= a.di) {
-        if constexpr (MODE != AP_SUMSQ) {
-          if (n > 0) {
-            f32x4 pc;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) pc[i] = (float)acc[ch][i];
-            *(f32x4*)(a.Pc + (size_t)row * a.dc + (c - a.di)) = pc;
-          }
-        }
-        continue;
-      }
-      if (c < a.di) {
-        float* Wp = is_item ? a.p.item_emb + (size_t)row * a.p.ld_item + c : a.p.user_emb + (size_t)row * a.p.ld_user + c;
-        f32x4 w = *(const f32x4*)Wp, g;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float wi = w[i];
-          g[i] = apply_elem<MODE, LAZY>(wi, (float)acc[ch][i], P, invP, a.reg, step, lazy_scale, part);
-          w[i] = wi;
-        }
-        if constexpr (MODE == AP_GRADS)
-          *(f32x4*)((is_item ? a.go.item_emb : a.go.user_emb) + (size_t)row * a.di + c) = g;
-        if constexpr (MODE == AP_UPDATE) *(f32x4*)Wp = w;
-      } else {  // user rows, usert_emb columns (scalar: Ls need not be a multiple of 4)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int p = c + i - a.di;
-          if (p < a.Ls) {
-            float* wp = a.p.usert_emb + (size_t)row * a.p.ld_usert + p;
-            float w = *wp;
-            const float g = apply_elem<MODE, LAZY>(w, (float)acc[ch][i], P, invP, a.reg, step, lazy_scale, part);
-            if constexpr (MODE == AP_GRADS) a.go.usert_emb[(size_t)row * a.Ls + p] = g;
-            if constexpr (MODE == AP_UPDATE) *wp = w;
-          }
-        }
-      }
-    }
-    if (is_item && l16 == 0) {  // item_b[row]: not regularised (model.py:164-169), never scaled
-      const float g = (float)bacc;
-      if constexpr (MODE == AP_GRADS) a.go.item_b[row] = g;
-      if constexpr (MODE == AP_ROWNORM) part += (double)g * (double)g;
-      if constexpr (MODE == AP_UPDATE) {
-        if (n > 0) a.p.item_b[(size_t)row * a.p.ld_itemb] -= step * g;
-      }
-    }
-  }
-  if constexpr (MODE != AP_GRADS) block_part_store(part, shd, &a.part_out[blk]);
-}
+// ------------------------------------------------------------------------------------------
+// k_apply: ONE launch applies the step to every embedding table and the dense parameters.
+// Block layout: [0,nbC) one category row per workgroup, then nbI blocks of item rows and nbU
+// blocks of user rows (user_emb + usert_emb; one row per 16-lane group), then nbD blocks of 256
+// dense parameters.  Category blocks come first: they have the longest dependent chain.
+//
+// Item uses are stored destination-sorted as rows [item half | cate half] of Gi: the item
+// blocks sum the item halves of their row's contiguous segment, the category blocks sum the
+// cate halves of the segments of all items of the category (static CSR of item_cate) plus the
+// category's u_cate uses (segment of Gc).  Nothing is passed between blocks, so rows and
+// categories need no second launch.  Every sum is exact (exact_term) -> order-free, bitwise
+// reproducible.
+//
+// The kernel is a chain of dependent memory round trips, so every load that does not depend
+// on another is issued up front: used-row records, clip-norm partials, the parameter row, and
+// the first AP_OWN gradient rows of a segment in one batch (clamped addresses instead of
+// branches, which the compiler would serialise).
+// LAZY: the row blocks walk the compacted records of used rows (k_index_scan) instead of every row.
+// NCH = float4 chunks per lane: 16 lanes x NCH x 4 floats >= the widest row (d_item, WU, d_cate).
+#define AP_CAP 2048  // LDS list of use positions of one category pass
 
-// Category rows, one per workgroup, after k_apply_rows of the same step:
-//   g[c] = sum over the items i of category c that were used this step of Pc[i]
-//        + sum of the u_cate uses of c (contiguous segment of Gc)            (+ reg * W)
-// The item lists are the static CSR of item_cate (built by tlsan_state_init).  Resets the item
-// and u_cate use counters (every item belongs to exactly one category).  LAZY UPDATE: the last
-// workgroup to arrive commits the new table scale P (every other reader of P has finished).
-template <int MODE, bool LAZY, int NCH>
-__global__ __launch_bounds__(256) void k_apply_cates(ApplyArgs a) {
-  __shared__ double shd[4 * 16 * NCH * 4];
-  __shared__ double shp[4];
-  __shared__ float sh_coef;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, grp = lane >> 4, l16 = lane & 15;
-  const int gid = wave * 4 + grp;  // 16 groups
-  const float P = a.hdr->P, invP = 1.0f / P;
-  const float coef = clip_coef<MODE>(a, P, &sh_coef, false);
-  const float step = a.lr * coef;
-  const float Pn = P * (1.0f - step * a.reg);
-  const float lazy_scale = step / Pn;
-  const int row = blockIdx.x;
-  const int W4 = a.dc / 4;
-  double acc[NCH][4];
-  zero_acc(acc);
-  if constexpr (MODE != AP_SUMSQ) {
-    const int i0 = a.cate_off[row], ni = a.cate_cnt[row];
-    for (int k = gid; k < ni; k += 16) {
-      const int item = a.cate_items[i0 + k];
-      if (a.cnt_item[item] > 0) {
+// exact sum of the rows listed in sh_pos[0, T): >= 0 -> cate half of Gi[pos], < 0 -> Gc[~pos];
+// the 16 groups of the workgroup stride over the list, AP_OWN rows in flight per group
+template <int NCH>
+__device__ __forceinline__ void list_accum(const ApplyArgs& a, const int* sh_pos, int T, int gid, int l16, int W4,
+                                           double (&acc)[NCH][4]) {
+  for (int k = gid; k < T; k += 16 * AP_OWN) {
+    f32x4 v[AP_OWN][NCH];
+#pragma unroll
+    for (int u = 0; u < AP_OWN; ++u) {
+      const int kk = k + 16 * u;
+      const int pos = sh_pos[kk < T ? kk : k];
+      const float* src = pos >= 0 ? a.Gi + (size_t)pos * a.D + a.di : a.Gc + (size_t)(~pos) * a.dc;
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        const int c4 = l16 + 16 * ch;
+        if (c4 < W4) v[u][ch] = *(const f32x4*)(src + 4 * c4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < AP_OWN; ++u) {
+      if (k + 16 * u < T) {
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
-          const int c4 = l16 + 16 * ch;
-          if (c4 < W4) {
-            const f32x4 v = *(const f32x4*)(a.Pc + (size_t)item * a.dc + 4 * c4);
+          if (l16 + 16 * ch < W4) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[ch][i] += exact_term(v[i]);
+            for (int i = 0; i < 4; ++i) acc[ch][i] += exact_term(v[u][ch][i]);
           }
         }
-        if constexpr (MODE != AP_ROWNORM) {
-          if (l16 == 0) a.cnt_item[item] = 0;
-        }
-      }
-    }
-    const int nu = a.cnt_uc[row], ou = a.off_uc[row];
-    seg_accum(a.Gc, a.dc, ou + gid, ou + nu, 16, W4, l16, acc);
-    combine_groups(acc);
-    if (grp == 0) {
-#pragma unroll
-      for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) shd[((wave * 16 + l16) * NCH + ch) * 4 + i] = acc[ch][i];
-    }
-    __syncthreads();
-    if (wave == 0 && grp == 0) {
-#pragma unroll
-      for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          double s = 0.0;
-          for (int w = 0; w < 4; ++w) s += shd[((w * 16 + l16) * NCH + ch) * 4 + i];
-          acc[ch][i] = s;
-        }
-    }
-    if constexpr (MODE != AP_ROWNORM) {
-      if (tid == 0 && nu > 0) a.cnt_uc[row] = 0;
-    }
-  }
-  double part = 0.0;
-  if (wave == 0 && grp == 0) {
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-      const int c4 = l16 + 16 * ch;
-      if (c4 < W4) {
-        float* Wp = a.p.cate_emb + (size_t)row * a.dc + 4 * c4;
-        f32x4 w = *(const f32x4*)Wp, g;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float wi = w[i];
-          g[i] = apply_elem<MODE, LAZY>(wi, (float)acc[ch][i], P, invP, a.reg, step, lazy_scale, part);
-          w[i] = wi;
-        }
-        if constexpr (MODE == AP_GRADS) *(f32x4*)(a.go.cate_emb + (size_t)row * a.dc + 4 * c4) = g;
-        if constexpr (MODE == AP_UPDATE) *(f32x4*)Wp = w;
-      }
-    }
-  }
-  if constexpr (MODE != AP_GRADS) block_part_store(part, shp, &a.part_out[a.nbI + a.nbU + row]);
-  if constexpr (MODE == AP_UPDATE && LAZY) {
-    // every workgroup read P before arriving here; the last one to arrive publishes P_new for the
-    // next kernel (kernel boundary = visibility)
-    if (tid == 0) {
-      const int t = atomicAdd(&a.hdr->ticket, 1);
-      if (t == (int)gridDim.x - 1) {
-        a.hdr->P = Pn;
-        a.hdr->ticket = 0;
       }
     }
   }
 }
+
+template <int MODE, bool LAZY, int NCH>
+__global__ __launch_bounds__(256) void k_apply(ApplyArgs a) {
+  __shared__ double shd[4 * 16 * NCH * 4];
+  __shared__ double shp[4];
+  __shared__ int sh_pos[AP_CAP];
+  __shared__ int sh_lo[256], sh_n[256];
+  __shared__ int sh_wtot[4];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, grp = lane >> 4, l16 = lane & 15;
+  const int gid = wave * 4 + grp;  // 16 groups
+  const int D = a.D;
+  const int blk = blockIdx.x;
+  constexpr bool RESET = MODE == AP_UPDATE || MODE == AP_GRADS;  // counters are zero at rest
+#define AP_STAMP(k)                                                                    \
+  do {                                                                                 \
+    if (a.stamps != nullptr && tid == 0) a.stamps[(size_t)blk * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+  AP_STAMP(0);
+  // ---- loads nothing else depends on
+  // (the step summary of k_dense_finalize already advanced hdr->P for a lazy update)
+  const float P = (MODE == AP_UPDATE && LAZY) ? a.hdr->P_prev : a.hdr->P, invP = 1.0f / P;
+  const float step = MODE == AP_UPDATE ? a.lr * a.hdr->coef : 0.0f;
+  const float lazy_scale = step / (P * (1.0f - step * a.reg));
+  double part = 0.0;
+  if (blk < a.nbC) {
+    // ================= one category row =================
+    const int c = blk;
+    const int W4 = a.dc / 4;
+    float* Wrow = a.p.cate_emb + (size_t)c * a.dc;
+    f32x4 w[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+      if (l16 + 16 * ch < W4) w[ch] = *(const f32x4*)(Wrow + 4 * (l16 + 16 * ch));
+    double acc[NCH][4];
+    zero_acc(acc);
+    int nu = 0;
+    if constexpr (MODE != AP_SUMSQ) {
+      const int i0 = a.cate_off[c], ni = a.cate_cnt[c];
+      const int ou = a.off_uc[c];
+      nu = a.off_uc[c + 1] - ou;
+      for (int p0 = 0; p0 == 0 || p0 < ni; p0 += 256) {
+        int lo = 0, n = 0;
+        if (p0 + tid < ni) {
+          const int item = a.cate_items[i0 + p0 + tid];
+          lo = a.off_item[item];
+          n = a.off_item[item + 1] - lo;
+        }
+        int inc = n;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int t = __shfl_up(inc, o);
+          if (lane >= o) inc += t;
+        }
+        if (lane == 63) sh_wtot[wave] = inc;
+        __syncthreads();
+        int pre = inc - n;
+#pragma unroll
+        for (int w_ = 0; w_ < 4; ++w_) pre += (w_ < wave) ? sh_wtot[w_] : 0;
+        const int T = (sh_wtot[0] + sh_wtot[1]) + (sh_wtot[2] + sh_wtot[3]);
+        const bool last = p0 + 256 >= ni;
+        const int extra = last ? nu : 0;  // the u_cate uses ride along with the last pass
+        if (T + extra <= AP_CAP) {
+          for (int j = 0; j < n; ++j) sh_pos[pre + j] = lo + j;
+          for (int j = tid; j < extra; j += 256) sh_pos[T + j] = ~(ou + j);
+          __syncthreads();
+          AP_STAMP(1);
+          list_accum<NCH>(a, sh_pos, T + extra, gid, l16, W4, acc);
+          AP_STAMP(2);
+        } else {  // very hot category: segment after segment, the 16 groups striding over each
+          sh_lo[tid] = lo;
+          sh_n[tid] = n;
+          __syncthreads();
+          const int cnt = min(256, ni - p0);
+          for (int t = 0; t < cnt; ++t) {
+            const int nt = sh_n[t], lt = sh_lo[t];
+            if (nt > 0) seg_accum<NCH>(a.Gi + a.di, D, lt + gid, lt + nt, 16, W4, l16, acc);
+          }
+          if (last) seg_accum<NCH>(a.Gc, a.dc, ou + gid, ou + nu, 16, W4, l16, acc);
+        }
+        __syncthreads();  // sh_pos / sh_wtot are rewritten by the next pass
+      }
+      combine_groups(acc);
+      if (grp == 0) {
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) shd[((wave * 16 + l16) * NCH + ch) * 4 + i] = acc[ch][i];
+      }
+      __syncthreads();
+      if (wave == 0 && grp == 0) {
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            double s = 0.0;
+            for (int w_ = 0; w_ < 4; ++w_) s += shd[((w_ * 16 + l16) * NCH + ch) * 4 + i];
+            acc[ch][i] = s;
+          }
+      }
+    }
+    AP_STAMP(3);
+    if (wave == 0 && grp == 0) {
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        const int c4 = l16 + 16 * ch;
+        if (c4 < W4) {
+          f32x4 g;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float wi = w[ch][i];
+            g[i] = apply_elem<MODE, LAZY>(wi, (float)acc[ch][i], P, invP, a.reg, step, lazy_scale, part);
+            w[ch][i] = wi;
+          }
+          if constexpr (MODE == AP_GRADS) *(f32x4*)(a.go.cate_emb + (size_t)c * a.dc + 4 * c4) = g;
+          if constexpr (MODE == AP_UPDATE) *(f32x4*)(Wrow + 4 * c4) = w[ch];
+        }
+      }
+    }
+    if constexpr (RESET) {
+      if (tid == 0 && nu > 0) a.cnt_uc[c] = 0;
+    }
+    if constexpr (MODE != AP_GRADS) block_part_store(part, shp, &a.part_out[blk]);
+  } else if (blk < a.nbC + a.nbI + a.nbU) {
+    // ================= 16 item or user rows =================
+    const bool is_item = blk < a.nbC + a.nbI;
+    const int slot = (blk - a.nbC - (is_item ? 0 : a.nbI)) * AP_ROWS_PB + gid;
+    int row = 0, off = 0, n = 0;
+    bool vr;
+    if constexpr (LAZY) {
+      const int nuq = is_item ? a.hdr->n_uniq_item : a.hdr->n_uniq_user;
+      const int4 r = (is_item ? a.urec_item : a.urec_user)[slot];  // (row, first position, uses)
+      vr = slot < nuq;
+      if (vr) { row = r.x; off = r.y; n = r.z; }
+    } else {
+      vr = slot < (is_item ? a.I : a.U);
+      if (vr) row = slot;
+      if constexpr (MODE != AP_SUMSQ) {
+        const int32_t* o = is_item ? a.off_item : a.off_user;
+        off = o[row];
+        n = vr ? o[row + 1] - off : 0;
+      }
+    }
+    AP_STAMP(1);
+    const float* Gs = is_item ? a.Gi : a.Gu;
+    const int ld = is_item ? D : a.WU;
+    const int W4 = (is_item ? a.di : a.WU) / 4;  // item rows: the item half only
+    // ---- the parameter row
+    float* Wrow = is_item ? a.p.item_emb + (size_t)row * a.p.ld_item : a.p.user_emb + (size_t)row * a.p.ld_user;
+    float* Trow = a.p.usert_emb + (size_t)row * a.p.ld_usert;
+    f32x4 w[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int cc = 4 * (l16 + 16 * ch);
+      if (cc < a.di) {
+        w[ch] = *(const f32x4*)(Wrow + cc);
+      } else if (!is_item) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[ch][i] = (cc + i - a.di < a.Ls) ? Trow[cc + i - a.di] : 0.0f;
+      }
+    }
+    float wb = 0.0f;
+    if (is_item && l16 == 0) wb = a.p.item_b[(size_t)row * a.p.ld_itemb];
+    // ---- exact sum of the row's segment
+    double acc[NCH][4];
+    zero_acc(acc);
+    double bacc = 0.0;  // item_b gradient of the row (item rows)
+    if constexpr (MODE != AP_SUMSQ) {
+      const int n_own = min(n, AP_OWN);
+      {
+        f32x4 v[AP_OWN][NCH];
+        const int last = max(n_own - 1, 0);
+#pragma unroll
+        for (int u = 0; u < AP_OWN; ++u) {
+          const float* src = Gs + (size_t)(off + min(u, last)) * ld;  // (buffers carry a pad row)
+#pragma unroll
+          for (int ch = 0; ch < NCH; ++ch)
+            if (l16 + 16 * ch < W4) v[u][ch] = *(const f32x4*)(src + 4 * (l16 + 16 * ch));
+        }
+        float gb = 0.0f;
+        if (is_item) gb = a.Gb[off + min(l16, last)];
+#pragma unroll
+        for (int u = 0; u < AP_OWN; ++u) {
+          if (u < n_own) {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+              if (l16 + 16 * ch < W4) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[ch][i] += exact_term(v[u][ch][i]);
+              }
+          }
+        }
+        if (is_item && l16 < n_own) bacc = exact_term(gb);
+      }
+      AP_STAMP(2);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int ng = __shfl(n, g * 16);
+        if (ng > AP_OWN) {  // wave-uniform: the four groups split the rest of group g's segment
+          const int og = __shfl(off, g * 16);
+          double t[NCH][4];
+          zero_acc(t);
+          seg_accum<NCH>(Gs, ld, og + AP_OWN + grp, og + ng, 4, W4, l16, t);
+          double tb = 0.0;
+          if (is_item)
+            for (int k = og + AP_OWN + lane; k < og + ng; k += 64) tb += exact_term(a.Gb[k]);
+          combine_groups(t);
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) tb += __shfl_xor(tb, o);
+          if (grp == g) {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc[ch][i] += t[ch][i];
+            if (l16 == 0) bacc += tb;
+          }
+        }
+      }
+      if (is_item) {  // fold the group's 16 partial bias sums (exact doubles: any order)
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) bacc += __shfl_xor(bacc, o);
+      }
+    }
+    AP_STAMP(3);
+    if (vr) {
+      // column cc of the row: cc < di -> item_emb / user_emb;  user rows, di <= cc < di+Ls -> usert_emb
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        const int cc = 4 * (l16 + 16 * ch);
+        if (cc >= 4 * W4) continue;
+        f32x4 g;
+        if (cc < a.di) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float wi = w[ch][i];
+            g[i] = apply_elem<MODE, LAZY>(wi, (float)acc[ch][i], P, invP, a.reg, step, lazy_scale, part);
+            w[ch][i] = wi;
+          }
+          if constexpr (MODE == AP_GRADS)
+            *(f32x4*)((is_item ? a.go.item_emb : a.go.user_emb) + (size_t)row * a.di + cc) = g;
+          if constexpr (MODE == AP_UPDATE) *(f32x4*)(Wrow + cc) = w[ch];
+        } else {  // usert_emb columns (scalar: Ls need not be a multiple of 4)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int p = cc + i - a.di;
+            if (p < a.Ls) {
+              float wi = w[ch][i];
+              const float gg = apply_elem<MODE, LAZY>(wi, (float)acc[ch][i], P, invP, a.reg, step, lazy_scale, part);
+              if constexpr (MODE == AP_GRADS) a.go.usert_emb[(size_t)row * a.Ls + p] = gg;
+              if constexpr (MODE == AP_UPDATE) Trow[p] = wi;
+            }
+          }
+        }
+      }
+      if (is_item && l16 == 0) {  // item_b[row]: not regularised (model.py:164-169), never scaled
+        const float g = (float)bacc;
+        if constexpr (MODE == AP_GRADS) a.go.item_b[row] = g;
+        if constexpr (MODE == AP_ROWNORM) part += (double)g * (double)g;
+        if constexpr (MODE == AP_UPDATE) {
+          if (n > 0) a.p.item_b[(size_t)row * a.p.ld_itemb] = wb - step * g;
+        }
+      }
+      if constexpr (RESET) {
+        if (n > 0 && l16 == 0) (is_item ? a.cnt_item : a.cnt_user)[row] = 0;
+      }
+    }
+    if constexpr (MODE != AP_GRADS) block_part_store(part, shp, &a.part_out[blk]);
+  } else {
+    // ================= 256 dense parameters =================
+    const int nd = (blk - a.nbC - a.nbI - a.nbU) * 256 + tid;
+    if constexpr (MODE == AP_UPDATE || MODE == AP_GRADS) {
+      if (nd < a.lay.n_dense) {
+        const float g = a.gd[nd];
+        float w0 = 0.0f;
+        if constexpr (MODE == AP_UPDATE) w0 = a.p.dense[nd];
+        if constexpr (MODE == AP_GRADS) {
+          a.go.dense[nd] = g;
+        } else {
+          const float wn = w0 - step * g;
+          a.p.dense[nd] = wn;
+          if (nd >= a.lay.K && nd < a.lay.k0) {
+            const int idx = nd - a.lay.K;
+            a.p.dense_KT[(size_t)(idx % D) * D + idx / D] = wn;
+          }
+        }
+      }
+    }
+  }
+  AP_STAMP(6);
+#undef AP_STAMP
+}
+
 
 // stored *= P for one table (tlsan_state_renorm)
 __global__ void k_scale_table(float* W, int rows, int width, int ld, const StateHdr* hdr) {
