@@ -39,10 +39,12 @@ def show(name, lo, hi):
     print("%-6s start p0/50/100 %5.0f %5.0f %5.0f | end p50/100 %5.0f %5.0f | dur p50 %5.0f max %5.0f" % (
         name, *(np.percentile(x[:, 0] - t0, [0, 50, 100])), *(np.percentile(x[:, 6] - t0, [50, 100])),
         np.median(x[:, 6] - x[:, 0]), (x[:, 6] - x[:, 0]).max()))
-    d = np.diff(x[:, :7], axis=1)
-    ok = (x[:, 1:7] > 0).all(1)
+    cols = [0, 1, 2, 3, 6]
+    y = x[:, cols]
+    ok = (y > 0).all(1)
     if ok.any():
-        print("        phases (median ticks): " + " ".join("%d:%.0f" % (i, np.median(d[ok, i])) for i in range(6)))
+        d = np.diff(y[ok], axis=1)
+        print("        phases (median / p90 ticks): " + " ".join("%d-%d: %.0f/%.0f" % (cols[i], cols[i + 1], np.median(d[:, i]), np.percentile(d[:, i], 90)) for i in range(4)))
 show("cate", 0, C)
 show("item", C, C + nbI)
 show("user", C + nbI, C + nbI + nbU)

@@ -87,7 +87,7 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
   tlsan_dense_layout_of(d, &L);
   w->WU = ru4(d->d_item + d->Ls);
   w->ngroups = (B + s.NSB - 1) / s.NSB;
-  w->nsplit = (B + DK_CHUNK - 1) / DK_CHUNK;
+  w->nsplit = dk_nsplit(B);
   w->nbK = (s.D * s.D + 255) / 256;
   w->nbS = (L.n_dense - s.D * s.D + 15) / 16;
   w->nfin = w->nbK + w->nbS;
@@ -242,11 +242,11 @@ static int launch_apply(int mode, bool lazy, ApplyArgs A, bool with_dense, int B
     A.nbU = ((B < A.U ? B : A.U) + AP_ROWS_PB - 1) / AP_ROWS_PB;
   }
   const dim3 g1(A.nbC + A.nbI + A.nbU + (with_dense ? A.nbD : 0)), blk(256);
-  const bool wide = A.WU > 128;  // float4 chunks per lane: 2 (rows of <= 128 columns) or 4
+  const bool wide = A.di > 64 || A.dc > 64 || A.WU > 128;  // more float4 chunks per lane
 #define AP_LAUNCH(M, LZ)                                                                   \
   do {                                                                                     \
-    if (wide) hipLaunchKernelGGL((k_apply<M, LZ, 4>), g1, blk, 0, hs, A);                  \
-    else hipLaunchKernelGGL((k_apply<M, LZ, 2>), g1, blk, 0, hs, A);                       \
+    if (wide) hipLaunchKernelGGL((k_apply<M, LZ, true>), g1, blk, 0, hs, A);               \
+    else hipLaunchKernelGGL((k_apply<M, LZ, false>), g1, blk, 0, hs, A);                   \
   } while (0)
   switch (mode) {
     case AP_UPDATE:
@@ -444,12 +444,17 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   prof_mark(2, hs);
   // --- dense-parameter gradients
   {
-    const size_t smem = sizeof(float) * 2 * DK_CHUNK * (s.D + 4);
-    if (s.D == 64) { hipLaunchKernelGGL(k_dk_partial<64>, dim3(w.nsplit), dim3(512), smem, hs, w.gLong, w.gDB, b->B, w.Kp); }
-    else if (s.D == 128) { (void)hipFuncSetAttribute((const void*)k_dk_partial<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      hipLaunchKernelGGL(k_dk_partial<128>, dim3(w.nsplit), dim3(512), smem, hs, w.gLong, w.gDB, b->B, w.Kp); }
-    else { (void)hipFuncSetAttribute((const void*)k_dk_partial<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      hipLaunchKernelGGL(k_dk_partial<256>, dim3(w.nsplit), dim3(512), smem, hs, w.gLong, w.gDB, b->B, w.Kp); }
+    const int spw = dk_spw(b->B), nq = (s.D / 64) * (s.D / 64);
+    const dim3 grid(nq * w.nsplit), blk(512);
+#define DK_LAUNCH(DD)                                                                                           \
+  do {                                                                                                          \
+    (void)hipFuncSetAttribute((const void*)k_dk_partial<DD>, hipFuncAttributeMaxDynamicSharedMemorySize, DK_SMEM_BYTES); \
+    hipLaunchKernelGGL(k_dk_partial<DD>, grid, blk, DK_SMEM_BYTES, hs, w.gLong, w.gDB, b->B, spw, w.Kp);        \
+  } while (0)
+    if (s.D == 64) DK_LAUNCH(64);
+    else if (s.D == 128) DK_LAUNCH(128);
+    else DK_LAUNCH(256);
+#undef DK_LAUNCH
   }
   CHECK_LAUNCH("k_dk_partial");
   prof_mark(3, hs);

@@ -142,40 +142,70 @@ __global__ __launch_bounds__(1024) void k_index_scan(ScanArgs a) {
 
 // ------------------------------------------------------------------------------------------
 // dK[k][j] = sum_b long[b][k] * dbridge[b][j]  (gradient of tf.layers.dense's kernel,
-// model.py:347) for the DK_CHUNK samples of this workgroup.  C[M=k][N=j], K-dim = samples.
-// The chunk's rows are staged in LDS with one round of coalesced 16-B loads.
-#define DK_CHUNK 64
+// model.py:347): C[M=k][N=j], K-dim = samples, f32 MFMA.
+// Grid: (D/64)^2 output quadrants of 64x64 x nsplit batch splits; a workgroup is 8 wavefronts and
+// wavefront w of split s owns the samples [(8s+w)*spw, +spw).  A wavefront computes a whole 64x64
+// quadrant for its samples from two coalesced 16-B loads per MFMA k-step: lane (q, r) reads
+// channels 4r..4r+3 of sample s0+q from both operands, and float t of the load feeds MFMA tile t,
+// i.e. tile ta x tb covers rows 4m+ta, columns 4n+tb -- 16 independent accumulators per k-step
+// and the float4 write-out is contiguous again.  The 8 wavefronts are summed through LDS in a
+// fixed order, so a launch leaves nsplit (<= DK_SPLITS_MAX) partial matrices for k_dense_finalize.
+#define DK_SPLITS_MAX 32
+static inline int dk_nsplit(int B) { const int n = (B + 127) / 128; return n < DK_SPLITS_MAX ? n : DK_SPLITS_MAX; }
+static inline int dk_spw(int B) { const int per = (B + dk_nsplit(B) * 8 - 1) / (dk_nsplit(B) * 8); return (per + 3) / 4 * 4; }
+#define DK_SMEM_BYTES (8 * 64 * 64 * 4)
 template <int D>
 __global__ __launch_bounds__(512) void k_dk_partial(const float* __restrict__ gLong,
-                                                    const float* __restrict__ gDB, int B,
+                                                    const float* __restrict__ gDB, int B, int spw,
                                                     float* __restrict__ Kp) {
-  constexpr int NT = D / 16, STR = D + 4;  // rows 4 apart (lane quarters q, q+1) land 16 banks apart
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sL = smem;
-  float* sD = smem + DK_CHUNK * STR;
+  constexpr int NQ = D / 64;
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [8 wavefronts][64][64]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, r = lane & 15;
-  const int b0 = blockIdx.x * DK_CHUNK;
-  for (int o = tid; o < DK_CHUNK * (D / 4); o += 512) {
-    const int row = o / (D / 4), c4 = o % (D / 4);
-    const bool v = b0 + row < B;
-    const f32x4 z = (f32x4)(0.0f);
-    *(f32x4*)(sL + row * STR + 4 * c4) = v ? *(const f32x4*)(gLong + (size_t)(b0 + row) * D + 4 * c4) : z;
-    *(f32x4*)(sD + row * STR + 4 * c4) = v ? *(const f32x4*)(gDB + (size_t)(b0 + row) * D + 4 * c4) : z;
+  const int quad = blockIdx.x % (NQ * NQ), split = blockIdx.x / (NQ * NQ);
+  const int M0 = (quad / NQ) * 64, N0 = (quad % NQ) * 64;
+  const int s_begin = (split * 8 + wave) * spw, s_end = min(s_begin + spw, B);
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = (f32x4)(0.0f);
+  for (int s0 = s_begin; s0 < s_end; s0 += 16) {
+    f32x4 va[4], vb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // k-step j: samples s0 + 4j + q (clamped address, zeroed past the end)
+      const int sm = s0 + 4 * j + q;
+      const int sc = sm < s_end ? sm : s_begin;
+      va[j] = *(const f32x4*)(gLong + (size_t)sc * D + M0 + 4 * r);
+      vb[j] = *(const f32x4*)(gDB + (size_t)sc * D + N0 + 4 * r);
+      if (sm >= s_end) va[j] = (f32x4)(0.0f);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = TLSAN_MFMA(va[j][ta], vb[j][tb], acc[ta][tb]);
   }
+  // acc[ta][tb][i] = C[M0 + 4 (4q + i) + ta][N0 + 4 r + tb]
+  float* W = smem + wave * 4096;
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x4 v;
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb) v[tb] = acc[ta][tb][i];
+      *(f32x4*)(W + (16 * q + 4 * i + ta) * 64 + 4 * r) = v;
+    }
   __syncthreads();
-  float* out = Kp + (size_t)blockIdx.x * D * D;
-  for (int tile = wave; tile < NT * NT; tile += 8) {
-    const int kt = tile / NT, jt = tile % NT;
-    f32x4 acc = (f32x4)(0.0f);
+  float* out = Kp + (size_t)split * D * D;
 #pragma unroll
-    for (int st = 0; st < DK_CHUNK / 16; ++st)
+  for (int k = 0; k < 2; ++k) {
+    const int f = tid + 512 * k;  // float4 index inside the 64x64 quadrant
+    f32x4 v = *(const f32x4*)(smem + 4 * f);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int row = 16 * st + 4 * q + s;
-        acc = TLSAN_MFMA(sL[row * STR + 16 * kt + r], sD[row * STR + 16 * jt + r], acc);
-      }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) out[(size_t)(16 * kt + 4 * q + i) * D + 16 * jt + r] = acc[i];
+    for (int w_ = 1; w_ < 8; ++w_) v += *(const f32x4*)(smem + w_ * 4096 + 4 * f);
+    *(f32x4*)(out + (size_t)(M0 + f / 16) * D + N0 + 4 * (f % 16)) = v;
   }
 }
 
@@ -255,7 +285,13 @@ __device__ __forceinline__ void step_summary(const FinArgs& a, int nsqd, double*
 __device__ __forceinline__ double block_sum_double(const double* __restrict__ v, int n, double* sh) {
   const int tid = threadIdx.x;
   double s = 0.0;
-  for (int k = tid; k < n; k += 256) s += v[k];
+  for (int k0 = tid; k0 < n; k0 += 256 * 8) {  // 8 loads in flight (clamped addresses, masked sum)
+    double t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = v[k0 + 256 * u < n ? k0 + 256 * u : k0];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += k0 + 256 * u < n ? t[u] : 0.0;
+  }
   sh[tid] = s;
   __syncthreads();
   for (int o = 128; o >= 1; o >>= 1) {
@@ -290,15 +326,19 @@ __global__ __launch_bounds__(256) void k_dense_finalize(FinArgs a, int nbK, int 
   } else if (blk < nbK) {
     const int idx = blk * 256 + tid;
     if (idx < D * D) {
+      // all split partials in flight at once (clamped addresses, masked sum), fixed order
+      float v[DK_SPLITS_MAX];
+#pragma unroll
+      for (int sidx = 0; sidx < DK_SPLITS_MAX; ++sidx)
+        v[sidx] = a.Kp[(size_t)min(sidx, a.nsplit - 1) * D * D + idx];
       float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f;
-      int sidx = 0;
-      for (; sidx + 3 < a.nsplit; sidx += 4) {
-        g0 += a.Kp[(size_t)(sidx + 0) * D * D + idx];
-        g1 += a.Kp[(size_t)(sidx + 1) * D * D + idx];
-        g2 += a.Kp[(size_t)(sidx + 2) * D * D + idx];
-        g3 += a.Kp[(size_t)(sidx + 3) * D * D + idx];
+#pragma unroll
+      for (int sidx = 0; sidx < DK_SPLITS_MAX; sidx += 4) {
+        g0 += sidx + 0 < a.nsplit ? v[sidx + 0] : 0.0f;
+        g1 += sidx + 1 < a.nsplit ? v[sidx + 1] : 0.0f;
+        g2 += sidx + 2 < a.nsplit ? v[sidx + 2] : 0.0f;
+        g3 += sidx + 3 < a.nsplit ? v[sidx + 3] : 0.0f;
       }
-      for (; sidx < a.nsplit; ++sidx) g0 += a.Kp[(size_t)sidx * D * D + idx];
       g = (g0 + g1) + (g2 + g3);
       a.gd[L.K + idx] = g;
       owner = true;
@@ -327,11 +367,19 @@ __global__ __launch_bounds__(256) void k_dense_finalize(FinArgs a, int nbK, int 
       if (n >= L.k0 && n < L.k0 + D) e[0] = G::P_K0 + (n - L.k0);
       if (n == L.gamma) e[0] = G::P_GAMMA;
       float t = 0.0f;
-      for (int rec = rl; rec < a.nrec; rec += 16) {
-        const float* p = a.partials + (size_t)rec * NPB;
-        float v = p[e[0]];
-        if (HPC > 1 && e[1] >= 0) v += p[e[1]];
-        t += v;
+      const bool two = HPC > 1 && e[1] >= 0;
+      const int e1 = two ? e[1] : e[0];
+      for (int r0 = rl; r0 < a.nrec; r0 += 16 * 8) {  // 8 records in flight per lane, fixed order
+        float v0[8], v1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float* p = a.partials + (size_t)(r0 + 16 * u < a.nrec ? r0 + 16 * u : r0) * NPB;
+          v0[u] = p[e[0]];
+          v1[u] = p[e1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (r0 + 16 * u < a.nrec) t += two ? v0[u] + v1[u] : v0[u];
       }
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1) t += __shfl_xor(t, o);
@@ -352,7 +400,15 @@ __global__ __launch_bounds__(256) void k_dense_finalize(FinArgs a, int nbK, int 
   if (blk == 0 && tid < 32) {  // loss sum and per-use square sum: 16 lanes each, fixed order
     const int which = tid >> 4, rl = tid & 15;
     float t = 0.0f;
-    for (int rec = rl; rec < a.nrec; rec += 16) t += a.partials[(size_t)rec * NPB + G::P_LOSS + which];
+    for (int r0 = rl; r0 < a.nrec; r0 += 16 * 8) {
+      float v0[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        v0[u] = a.partials[(size_t)(r0 + 16 * u < a.nrec ? r0 + 16 * u : r0) * NPB + G::P_LOSS + which];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (r0 + 16 * u < a.nrec) t += v0[u];
+    }
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) t += __shfl_xor(t, o);
     if (rl == 0) pub_f32(a.scal + which, t);
@@ -548,274 +604,302 @@ __device__ __forceinline__ void list_accum(const ApplyArgs& a, const int* sh_pos
   }
 }
 
+struct ApCtx {
+  int tid, wave, lane, grp, l16, gid, blk;
+  float P, invP, step, lazy_scale;
+};
+
+#define AP_STAMP(k)                                                                      \
+  do {                                                                                   \
+    if (a.stamps != nullptr && x.tid == 0) a.stamps[(size_t)x.blk * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+
+// ================= one category row per workgroup =================
 template <int MODE, bool LAZY, int NCH>
+__device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx& x, double* shd, double* shp,
+                                                 int* sh_pos, int* sh_lo, int* sh_n, int* sh_wtot) {
+  constexpr bool RESET = MODE == AP_UPDATE || MODE == AP_GRADS;  // counters are zero at rest
+  const int tid = x.tid, wave = x.wave, lane = x.lane, grp = x.grp, l16 = x.l16, gid = x.gid;
+  const int c = x.blk;
+  const int W4 = a.dc / 4;
+  float* Wrow = a.p.cate_emb + (size_t)c * a.dc;
+  f32x4 w[NCH];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch)
+    if (l16 + 16 * ch < W4) w[ch] = *(const f32x4*)(Wrow + 4 * (l16 + 16 * ch));
+  double acc[NCH][4];
+  zero_acc(acc);
+  double part = 0.0;
+  int nu = 0;
+  if constexpr (MODE != AP_SUMSQ) {
+    const int i0 = a.cate_off[c], ni = a.cate_cnt[c];
+    const int ou = a.off_uc[c];
+    nu = a.off_uc[c + 1] - ou;
+    for (int p0 = 0; p0 == 0 || p0 < ni; p0 += 256) {
+      int lo = 0, n = 0;
+      if (p0 + tid < ni) {
+        const int item = a.cate_items[i0 + p0 + tid];
+        lo = a.off_item[item];
+        n = a.off_item[item + 1] - lo;
+      }
+      int inc = n;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+      }
+      if (lane == 63) sh_wtot[wave] = inc;
+      __syncthreads();
+      int pre = inc - n;
+#pragma unroll
+      for (int w_ = 0; w_ < 4; ++w_) pre += (w_ < wave) ? sh_wtot[w_] : 0;
+      const int T = (sh_wtot[0] + sh_wtot[1]) + (sh_wtot[2] + sh_wtot[3]);
+      const bool last = p0 + 256 >= ni;
+      const int extra = last ? nu : 0;  // the u_cate uses ride along with the last pass
+      if (T + extra <= AP_CAP) {
+        for (int j = 0; j < n; ++j) sh_pos[pre + j] = lo + j;
+        for (int j = tid; j < extra; j += 256) sh_pos[T + j] = ~(ou + j);
+        __syncthreads();
+        AP_STAMP(1);
+        list_accum<NCH>(a, sh_pos, T + extra, gid, l16, W4, acc);
+        AP_STAMP(2);
+      } else {  // very hot category: segment after segment, the 16 groups striding over each
+        sh_lo[tid] = lo;
+        sh_n[tid] = n;
+        __syncthreads();
+        const int cnt = min(256, ni - p0);
+        for (int t = 0; t < cnt; ++t) {
+          const int nt = sh_n[t], lt = sh_lo[t];
+          if (nt > 0) seg_accum<NCH>(a.Gi + a.di, a.D, lt + gid, lt + nt, 16, W4, l16, acc);
+        }
+        if (last) seg_accum<NCH>(a.Gc, a.dc, ou + gid, ou + nu, 16, W4, l16, acc);
+      }
+      __syncthreads();  // sh_pos / sh_wtot are rewritten by the next pass
+    }
+    combine_groups(acc);
+    if (grp == 0) {
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) shd[((wave * 16 + l16) * NCH + ch) * 4 + i] = acc[ch][i];
+    }
+    __syncthreads();
+    if (wave == 0 && grp == 0) {
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          double s = 0.0;
+          for (int w_ = 0; w_ < 4; ++w_) s += shd[((w_ * 16 + l16) * NCH + ch) * 4 + i];
+          acc[ch][i] = s;
+        }
+    }
+  }
+  AP_STAMP(3);
+  if (wave == 0 && grp == 0) {
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int c4 = l16 + 16 * ch;
+      if (c4 < W4) {
+        f32x4 g;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float wi = w[ch][i];
+          g[i] = apply_elem<MODE, LAZY>(wi, (float)acc[ch][i], x.P, x.invP, a.reg, x.step, x.lazy_scale, part);
+          w[ch][i] = wi;
+        }
+        if constexpr (MODE == AP_GRADS) *(f32x4*)(a.go.cate_emb + (size_t)c * a.dc + 4 * c4) = g;
+        if constexpr (MODE == AP_UPDATE) *(f32x4*)(Wrow + 4 * c4) = w[ch];
+      }
+    }
+  }
+  if constexpr (RESET) {
+    if (tid == 0 && nu > 0) a.cnt_uc[c] = 0;
+  }
+  if constexpr (MODE != AP_GRADS) block_part_store(part, shp, &a.part_out[x.blk]);
+}
+
+// ================= 16 item rows or 16 user rows per workgroup (one row per 16-lane group) =========
+// NCH float4 chunks per lane cover the row (item rows: the item half only), OWN gradient rows are
+// in flight per group; longer segments are finished by the whole wavefront.
+template <int MODE, bool LAZY, bool IS_ITEM, int NCH, int OWN>
+__device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx& x, int slot0, double* shp) {
+  constexpr bool RESET = MODE == AP_UPDATE || MODE == AP_GRADS;
+  const int lane = x.lane, grp = x.grp, l16 = x.l16;
+  const int slot = slot0 + x.gid;
+  int row = 0, off = 0, n = 0;
+  bool vr;
+  double part = 0.0;
+  if constexpr (LAZY) {
+    const int nuq = IS_ITEM ? a.hdr->n_uniq_item : a.hdr->n_uniq_user;
+    if (slot0 >= nuq) return;  // (workgroup-uniform) nothing left: lazy rows past the used ones leave no partial
+    const int4 r = (IS_ITEM ? a.urec_item : a.urec_user)[slot];  // (row, first position, uses)
+    vr = slot < nuq;
+    if (vr) { row = r.x; off = r.y; n = r.z; }
+  } else {
+    vr = slot < (IS_ITEM ? a.I : a.U);
+    if (vr) row = slot;
+    if constexpr (MODE != AP_SUMSQ) {
+      const int32_t* o = IS_ITEM ? a.off_item : a.off_user;
+      off = o[row];
+      n = vr ? o[row + 1] - off : 0;
+    }
+  }
+  AP_STAMP(1);
+  const float* Gs = IS_ITEM ? a.Gi : a.Gu;
+  const int ld = IS_ITEM ? a.D : a.WU;
+  const int W4 = (IS_ITEM ? a.di : a.WU) / 4;
+  // ---- the parameter row
+  float* Wrow = IS_ITEM ? a.p.item_emb + (size_t)row * a.p.ld_item : a.p.user_emb + (size_t)row * a.p.ld_user;
+  float* Trow = a.p.usert_emb + (size_t)row * a.p.ld_usert;
+  f32x4 w[NCH];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int cc = 4 * (l16 + 16 * ch);
+    if (cc < a.di) {
+      w[ch] = *(const f32x4*)(Wrow + cc);
+    } else if (!IS_ITEM) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w[ch][i] = (cc + i - a.di < a.Ls) ? Trow[cc + i - a.di] : 0.0f;
+    }
+  }
+  float wb = 0.0f;
+  if (IS_ITEM && l16 == 0) wb = a.p.item_b[(size_t)row * a.p.ld_itemb];
+  // ---- exact sum of the row's segment
+  double acc[NCH][4];
+  zero_acc(acc);
+  double bacc = 0.0;  // item_b gradient of the row (item rows)
+  if constexpr (MODE != AP_SUMSQ) {
+    const int n_own = min(n, OWN);
+    {
+      f32x4 v[OWN][NCH];
+      const int last = max(n_own - 1, 0);
+#pragma unroll
+      for (int u = 0; u < OWN; ++u) {
+        const float* src = Gs + (size_t)(off + min(u, last)) * ld;  // (buffers carry a pad row)
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+          if (l16 + 16 * ch < W4) v[u][ch] = *(const f32x4*)(src + 4 * (l16 + 16 * ch));
+      }
+      float gb = 0.0f;
+      if (IS_ITEM) gb = a.Gb[off + min(l16, last)];
+#pragma unroll
+      for (int u = 0; u < OWN; ++u) {
+        if (u < n_own) {
+#pragma unroll
+          for (int ch = 0; ch < NCH; ++ch)
+            if (l16 + 16 * ch < W4) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc[ch][i] += exact_term(v[u][ch][i]);
+            }
+        }
+      }
+      if (IS_ITEM && l16 < n_own) bacc = exact_term(gb);
+    }
+    AP_STAMP(2);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int ng = __shfl(n, g * 16);
+      if (ng > OWN) {  // wave-uniform: the four groups split the rest of group g's segment
+        const int og = __shfl(off, g * 16);
+        double t[NCH][4];
+        zero_acc(t);
+        seg_accum<NCH>(Gs, ld, og + OWN + grp, og + ng, 4, W4, l16, t);
+        double tb = 0.0;
+        if (IS_ITEM)
+          for (int k = og + OWN + lane; k < og + ng; k += 64) tb += exact_term(a.Gb[k]);
+        combine_groups(t);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) tb += __shfl_xor(tb, o);
+        if (grp == g) {
+#pragma unroll
+          for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[ch][i] += t[ch][i];
+          if (l16 == 0) bacc += tb;
+        }
+      }
+    }
+    if (IS_ITEM) {  // fold the group's 16 partial bias sums (exact doubles: any order)
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) bacc += __shfl_xor(bacc, o);
+    }
+  }
+  AP_STAMP(3);
+  if (vr) {
+    // column cc of the row: cc < di -> item_emb / user_emb;  user rows, di <= cc < di+Ls -> usert_emb
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int cc = 4 * (l16 + 16 * ch);
+      if (cc >= 4 * W4) continue;
+      f32x4 g;
+      if (cc < a.di) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float wi = w[ch][i];
+          g[i] = apply_elem<MODE, LAZY>(wi, (float)acc[ch][i], x.P, x.invP, a.reg, x.step, x.lazy_scale, part);
+          w[ch][i] = wi;
+        }
+        if constexpr (MODE == AP_GRADS)
+          *(f32x4*)((IS_ITEM ? a.go.item_emb : a.go.user_emb) + (size_t)row * a.di + cc) = g;
+        if constexpr (MODE == AP_UPDATE) *(f32x4*)(Wrow + cc) = w[ch];
+      } else if (!IS_ITEM) {  // usert_emb columns (scalar: Ls need not be a multiple of 4)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int p = cc + i - a.di;
+          if (p < a.Ls) {
+            float wi = w[ch][i];
+            const float gg = apply_elem<MODE, LAZY>(wi, (float)acc[ch][i], x.P, x.invP, a.reg, x.step, x.lazy_scale, part);
+            if constexpr (MODE == AP_GRADS) a.go.usert_emb[(size_t)row * a.Ls + p] = gg;
+            if constexpr (MODE == AP_UPDATE) Trow[p] = wi;
+          }
+        }
+      }
+    }
+    if (IS_ITEM && l16 == 0) {  // item_b[row]: not regularised (model.py:164-169), never scaled
+      const float g = (float)bacc;
+      if constexpr (MODE == AP_GRADS) a.go.item_b[row] = g;
+      if constexpr (MODE == AP_ROWNORM) part += (double)g * (double)g;
+      if constexpr (MODE == AP_UPDATE) {
+        if (n > 0) a.p.item_b[(size_t)row * a.p.ld_itemb] = wb - x.step * g;
+      }
+    }
+    if constexpr (RESET) {
+      if (n > 0 && l16 == 0) (IS_ITEM ? a.cnt_item : a.cnt_user)[row] = 0;
+    }
+  }
+  if constexpr (MODE != AP_GRADS) block_part_store(part, shp, &a.part_out[x.blk]);
+}
+
+// WIDE: d_item / d_cate above 64 or d_item + Ls above 128 columns (more float4 chunks per lane)
+template <int MODE, bool LAZY, bool WIDE>
 __global__ __launch_bounds__(256) void k_apply(ApplyArgs a) {
-  __shared__ double shd[4 * 16 * NCH * 4];
+  constexpr int NC = WIDE ? 2 : 1, NI = WIDE ? 2 : 1, NU = WIDE ? 4 : 2;
+  __shared__ double shd[4 * 16 * NC * 4];
   __shared__ double shp[4];
   __shared__ int sh_pos[AP_CAP];
   __shared__ int sh_lo[256], sh_n[256];
   __shared__ int sh_wtot[4];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, grp = lane >> 4, l16 = lane & 15;
-  const int gid = wave * 4 + grp;  // 16 groups
-  const int D = a.D;
-  const int blk = blockIdx.x;
-  constexpr bool RESET = MODE == AP_UPDATE || MODE == AP_GRADS;  // counters are zero at rest
-#define AP_STAMP(k)                                                                    \
-  do {                                                                                 \
-    if (a.stamps != nullptr && tid == 0) a.stamps[(size_t)blk * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
-  } while (0)
+  ApCtx x;
+  x.tid = threadIdx.x; x.wave = x.tid >> 6; x.lane = x.tid & 63; x.grp = x.lane >> 4; x.l16 = x.lane & 15;
+  x.gid = x.wave * 4 + x.grp;  // 16 groups
+  x.blk = blockIdx.x;
   AP_STAMP(0);
-  // ---- loads nothing else depends on
   // (the step summary of k_dense_finalize already advanced hdr->P for a lazy update)
-  const float P = (MODE == AP_UPDATE && LAZY) ? a.hdr->P_prev : a.hdr->P, invP = 1.0f / P;
-  const float step = MODE == AP_UPDATE ? a.lr * a.hdr->coef : 0.0f;
-  const float lazy_scale = step / (P * (1.0f - step * a.reg));
-  double part = 0.0;
+  x.P = (MODE == AP_UPDATE && LAZY) ? a.hdr->P_prev : a.hdr->P;
+  x.invP = 1.0f / x.P;
+  x.step = MODE == AP_UPDATE ? a.lr * a.hdr->coef : 0.0f;
+  x.lazy_scale = x.step / (x.P * (1.0f - x.step * a.reg));
+  const int blk = x.blk;
   if (blk < a.nbC) {
-    // ================= one category row =================
-    const int c = blk;
-    const int W4 = a.dc / 4;
-    float* Wrow = a.p.cate_emb + (size_t)c * a.dc;
-    f32x4 w[NCH];
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch)
-      if (l16 + 16 * ch < W4) w[ch] = *(const f32x4*)(Wrow + 4 * (l16 + 16 * ch));
-    double acc[NCH][4];
-    zero_acc(acc);
-    int nu = 0;
-    if constexpr (MODE != AP_SUMSQ) {
-      const int i0 = a.cate_off[c], ni = a.cate_cnt[c];
-      const int ou = a.off_uc[c];
-      nu = a.off_uc[c + 1] - ou;
-      for (int p0 = 0; p0 == 0 || p0 < ni; p0 += 256) {
-        int lo = 0, n = 0;
-        if (p0 + tid < ni) {
-          const int item = a.cate_items[i0 + p0 + tid];
-          lo = a.off_item[item];
-          n = a.off_item[item + 1] - lo;
-        }
-        int inc = n;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const int t = __shfl_up(inc, o);
-          if (lane >= o) inc += t;
-        }
-        if (lane == 63) sh_wtot[wave] = inc;
-        __syncthreads();
-        int pre = inc - n;
-#pragma unroll
-        for (int w_ = 0; w_ < 4; ++w_) pre += (w_ < wave) ? sh_wtot[w_] : 0;
-        const int T = (sh_wtot[0] + sh_wtot[1]) + (sh_wtot[2] + sh_wtot[3]);
-        const bool last = p0 + 256 >= ni;
-        const int extra = last ? nu : 0;  // the u_cate uses ride along with the last pass
-        if (T + extra <= AP_CAP) {
-          for (int j = 0; j < n; ++j) sh_pos[pre + j] = lo + j;
-          for (int j = tid; j < extra; j += 256) sh_pos[T + j] = ~(ou + j);
-          __syncthreads();
-          AP_STAMP(1);
-          list_accum<NCH>(a, sh_pos, T + extra, gid, l16, W4, acc);
-          AP_STAMP(2);
-        } else {  // very hot category: segment after segment, the 16 groups striding over each
-          sh_lo[tid] = lo;
-          sh_n[tid] = n;
-          __syncthreads();
-          const int cnt = min(256, ni - p0);
-          for (int t = 0; t < cnt; ++t) {
-            const int nt = sh_n[t], lt = sh_lo[t];
-            if (nt > 0) seg_accum<NCH>(a.Gi + a.di, D, lt + gid, lt + nt, 16, W4, l16, acc);
-          }
-          if (last) seg_accum<NCH>(a.Gc, a.dc, ou + gid, ou + nu, 16, W4, l16, acc);
-        }
-        __syncthreads();  // sh_pos / sh_wtot are rewritten by the next pass
-      }
-      combine_groups(acc);
-      if (grp == 0) {
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) shd[((wave * 16 + l16) * NCH + ch) * 4 + i] = acc[ch][i];
-      }
-      __syncthreads();
-      if (wave == 0 && grp == 0) {
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            double s = 0.0;
-            for (int w_ = 0; w_ < 4; ++w_) s += shd[((w_ * 16 + l16) * NCH + ch) * 4 + i];
-            acc[ch][i] = s;
-          }
-      }
-    }
-    AP_STAMP(3);
-    if (wave == 0 && grp == 0) {
-#pragma unroll
-      for (int ch = 0; ch < NCH; ++ch) {
-        const int c4 = l16 + 16 * ch;
-        if (c4 < W4) {
-          f32x4 g;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            float wi = w[ch][i];
-            g[i] = apply_elem<MODE, LAZY>(wi, (float)acc[ch][i], P, invP, a.reg, step, lazy_scale, part);
-            w[ch][i] = wi;
-          }
-          if constexpr (MODE == AP_GRADS) *(f32x4*)(a.go.cate_emb + (size_t)c * a.dc + 4 * c4) = g;
-          if constexpr (MODE == AP_UPDATE) *(f32x4*)(Wrow + 4 * c4) = w[ch];
-        }
-      }
-    }
-    if constexpr (RESET) {
-      if (tid == 0 && nu > 0) a.cnt_uc[c] = 0;
-    }
-    if constexpr (MODE != AP_GRADS) block_part_store(part, shp, &a.part_out[blk]);
+    apply_cate_block<MODE, LAZY, NC>(a, x, shd, shp, sh_pos, sh_lo, sh_n, sh_wtot);
+  } else if (blk < a.nbC + a.nbI) {
+    apply_rows_block<MODE, LAZY, true, NI, AP_OWN>(a, x, (blk - a.nbC) * AP_ROWS_PB, shp);
   } else if (blk < a.nbC + a.nbI + a.nbU) {
-    // ================= 16 item or user rows =================
-    const bool is_item = blk < a.nbC + a.nbI;
-    const int slot = (blk - a.nbC - (is_item ? 0 : a.nbI)) * AP_ROWS_PB + gid;
-    int row = 0, off = 0, n = 0;
-    bool vr;
-    if constexpr (LAZY) {
-      const int nuq = is_item ? a.hdr->n_uniq_item : a.hdr->n_uniq_user;
-      const int4 r = (is_item ? a.urec_item : a.urec_user)[slot];  // (row, first position, uses)
-      vr = slot < nuq;
-      if (vr) { row = r.x; off = r.y; n = r.z; }
-    } else {
-      vr = slot < (is_item ? a.I : a.U);
-      if (vr) row = slot;
-      if constexpr (MODE != AP_SUMSQ) {
-        const int32_t* o = is_item ? a.off_item : a.off_user;
-        off = o[row];
-        n = vr ? o[row + 1] - off : 0;
-      }
-    }
-    AP_STAMP(1);
-    const float* Gs = is_item ? a.Gi : a.Gu;
-    const int ld = is_item ? D : a.WU;
-    const int W4 = (is_item ? a.di : a.WU) / 4;  // item rows: the item half only
-    // ---- the parameter row
-    float* Wrow = is_item ? a.p.item_emb + (size_t)row * a.p.ld_item : a.p.user_emb + (size_t)row * a.p.ld_user;
-    float* Trow = a.p.usert_emb + (size_t)row * a.p.ld_usert;
-    f32x4 w[NCH];
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-      const int cc = 4 * (l16 + 16 * ch);
-      if (cc < a.di) {
-        w[ch] = *(const f32x4*)(Wrow + cc);
-      } else if (!is_item) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) w[ch][i] = (cc + i - a.di < a.Ls) ? Trow[cc + i - a.di] : 0.0f;
-      }
-    }
-    float wb = 0.0f;
-    if (is_item && l16 == 0) wb = a.p.item_b[(size_t)row * a.p.ld_itemb];
-    // ---- exact sum of the row's segment
-    double acc[NCH][4];
-    zero_acc(acc);
-    double bacc = 0.0;  // item_b gradient of the row (item rows)
-    if constexpr (MODE != AP_SUMSQ) {
-      const int n_own = min(n, AP_OWN);
-      {
-        f32x4 v[AP_OWN][NCH];
-        const int last = max(n_own - 1, 0);
-#pragma unroll
-        for (int u = 0; u < AP_OWN; ++u) {
-          const float* src = Gs + (size_t)(off + min(u, last)) * ld;  // (buffers carry a pad row)
-#pragma unroll
-          for (int ch = 0; ch < NCH; ++ch)
-            if (l16 + 16 * ch < W4) v[u][ch] = *(const f32x4*)(src + 4 * (l16 + 16 * ch));
-        }
-        float gb = 0.0f;
-        if (is_item) gb = a.Gb[off + min(l16, last)];
-#pragma unroll
-        for (int u = 0; u < AP_OWN; ++u) {
-          if (u < n_own) {
-#pragma unroll
-            for (int ch = 0; ch < NCH; ++ch)
-              if (l16 + 16 * ch < W4) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[ch][i] += exact_term(v[u][ch][i]);
-              }
-          }
-        }
-        if (is_item && l16 < n_own) bacc = exact_term(gb);
-      }
-      AP_STAMP(2);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int ng = __shfl(n, g * 16);
-        if (ng > AP_OWN) {  // wave-uniform: the four groups split the rest of group g's segment
-          const int og = __shfl(off, g * 16);
-          double t[NCH][4];
-          zero_acc(t);
-          seg_accum<NCH>(Gs, ld, og + AP_OWN + grp, og + ng, 4, W4, l16, t);
-          double tb = 0.0;
-          if (is_item)
-            for (int k = og + AP_OWN + lane; k < og + ng; k += 64) tb += exact_term(a.Gb[k]);
-          combine_groups(t);
-#pragma unroll
-          for (int o = 1; o < 64; o <<= 1) tb += __shfl_xor(tb, o);
-          if (grp == g) {
-#pragma unroll
-            for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-              for (int i = 0; i < 4; ++i) acc[ch][i] += t[ch][i];
-            if (l16 == 0) bacc += tb;
-          }
-        }
-      }
-      if (is_item) {  // fold the group's 16 partial bias sums (exact doubles: any order)
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) bacc += __shfl_xor(bacc, o);
-      }
-    }
-    AP_STAMP(3);
-    if (vr) {
-      // column cc of the row: cc < di -> item_emb / user_emb;  user rows, di <= cc < di+Ls -> usert_emb
-#pragma unroll
-      for (int ch = 0; ch < NCH; ++ch) {
-        const int cc = 4 * (l16 + 16 * ch);
-        if (cc >= 4 * W4) continue;
-        f32x4 g;
-        if (cc < a.di) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            float wi = w[ch][i];
-            g[i] = apply_elem<MODE, LAZY>(wi, (float)acc[ch][i], P, invP, a.reg, step, lazy_scale, part);
-            w[ch][i] = wi;
-          }
-          if constexpr (MODE == AP_GRADS)
-            *(f32x4*)((is_item ? a.go.item_emb : a.go.user_emb) + (size_t)row * a.di + cc) = g;
-          if constexpr (MODE == AP_UPDATE) *(f32x4*)(Wrow + cc) = w[ch];
-        } else {  // usert_emb columns (scalar: Ls need not be a multiple of 4)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int p = cc + i - a.di;
-            if (p < a.Ls) {
-              float wi = w[ch][i];
-              const float gg = apply_elem<MODE, LAZY>(wi, (float)acc[ch][i], P, invP, a.reg, step, lazy_scale, part);
-              if constexpr (MODE == AP_GRADS) a.go.usert_emb[(size_t)row * a.Ls + p] = gg;
-              if constexpr (MODE == AP_UPDATE) Trow[p] = wi;
-            }
-          }
-        }
-      }
-      if (is_item && l16 == 0) {  // item_b[row]: not regularised (model.py:164-169), never scaled
-        const float g = (float)bacc;
-        if constexpr (MODE == AP_GRADS) a.go.item_b[row] = g;
-        if constexpr (MODE == AP_ROWNORM) part += (double)g * (double)g;
-        if constexpr (MODE == AP_UPDATE) {
-          if (n > 0) a.p.item_b[(size_t)row * a.p.ld_itemb] = wb - step * g;
-        }
-      }
-      if constexpr (RESET) {
-        if (n > 0 && l16 == 0) (is_item ? a.cnt_item : a.cnt_user)[row] = 0;
-      }
-    }
-    if constexpr (MODE != AP_GRADS) block_part_store(part, shp, &a.part_out[blk]);
+    apply_rows_block<MODE, LAZY, false, NU, AP_OWN / 2>(a, x, (blk - a.nbC - a.nbI) * AP_ROWS_PB, shp);
   } else {
     // ================= 256 dense parameters =================
-    const int nd = (blk - a.nbC - a.nbI - a.nbU) * 256 + tid;
+    const int nd = (blk - a.nbC - a.nbI - a.nbU) * 256 + x.tid;
     if constexpr (MODE == AP_UPDATE || MODE == AP_GRADS) {
       if (nd < a.lay.n_dense) {
         const float g = a.gd[nd];
@@ -824,19 +908,19 @@ __global__ __launch_bounds__(256) void k_apply(ApplyArgs a) {
         if constexpr (MODE == AP_GRADS) {
           a.go.dense[nd] = g;
         } else {
-          const float wn = w0 - step * g;
+          const float wn = w0 - x.step * g;
           a.p.dense[nd] = wn;
           if (nd >= a.lay.K && nd < a.lay.k0) {
             const int idx = nd - a.lay.K;
-            a.p.dense_KT[(size_t)(idx % D) * D + idx / D] = wn;
+            a.p.dense_KT[(size_t)(idx % a.D) * a.D + idx / a.D] = wn;
           }
         }
       }
     }
   }
   AP_STAMP(6);
-#undef AP_STAMP
 }
+#undef AP_STAMP
 
 
 // stored *= P for one table (tlsan_state_renorm)
