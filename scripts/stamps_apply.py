@@ -49,3 +49,14 @@ show("cate", 0, C)
 show("item", C, C + nbI)
 show("user", C + nbI, C + nbI + nbU)
 show("dense", C + nbI + nbU, n)
+
+# timeline on the device-wide 100 MHz clock (slots 4/5)
+r0 = s[:, 4].min()
+print("timeline (us after the first workgroup start; 100 MHz s_memrealtime): kernel span %.2f us" % ((s[:, 5].max() - r0) / 100))
+for nm, lo, hi in [("cate", 0, C), ("item", C, C + nbI), ("user", C + nbI, C + nbI + nbU), ("dense", C + nbI + nbU, n)]:
+    x = s[lo:hi]
+    if len(x):
+        st, en = (x[:, 4] - r0) / 100, (x[:, 5] - r0) / 100
+        print("  %-5s start p0/10/50/90/100 %s | end p50/90/100 %s | dur p50 %.2f" % (
+            nm, " ".join("%5.2f" % v for v in np.percentile(st, [0, 10, 50, 90, 100])),
+            " ".join("%5.2f" % v for v in np.percentile(en, [50, 90, 100])), np.median(en - st)))

@@ -885,6 +885,7 @@ __global__ __launch_bounds__(256) void k_apply(ApplyArgs a) {
   x.gid = x.wave * 4 + x.grp;  // 16 groups
   x.blk = blockIdx.x;
   AP_STAMP(0);
+  if (a.stamps != nullptr && x.tid == 0) a.stamps[(size_t)x.blk * 8 + 4] = __builtin_amdgcn_s_memrealtime();
   // (the step summary of k_dense_finalize already advanced hdr->P for a lazy update)
   x.P = (MODE == AP_UPDATE && LAZY) ? a.hdr->P_prev : a.hdr->P;
   x.invP = 1.0f / x.P;
@@ -919,6 +920,8 @@ __global__ __launch_bounds__(256) void k_apply(ApplyArgs a) {
     }
   }
   AP_STAMP(6);
+  // (slots 4/5: the device-wide 100 MHz clock at start/end; s_memtime is not synchronised across the chip)
+  if (a.stamps != nullptr && x.tid == 0) a.stamps[(size_t)x.blk * 8 + 5] = __builtin_amdgcn_s_memrealtime();
 }
 #undef AP_STAMP
 
