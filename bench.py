@@ -126,6 +126,9 @@ def main():
             k = (first + s) % len(dbs)
             if use_graph and not (timed and args.profile_level > 0 and s % args.event_every == 0):
                 model.replay(graphs[k])
+            elif sharded:
+                # the next batch is known (as in any input pipeline): its routing plan is queued a step ahead
+                stepper.train_async(dbs[k], lr, next_batch=dbs[(k + 1) % len(dbs)])
             else:
                 stepper.train_async(dbs[k], lr)
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TLSAN_ABI_VERSION 3
+#define TLSAN_ABI_VERSION 4
 
 enum {
   TLSAN_OK = 0,
@@ -171,6 +171,12 @@ int tlsan_train_step(const tlsan_dims* dims, const tlsan_params* p, const tlsan_
 typedef struct {
   float* item_emb; float* item_b; float* user_emb; float* usert_emb; float* cate_emb;
   float* dense;    /* [n_dense] */
+  /* row strides in floats of the four row outputs; 0 = packed (d_item, 1, d_item, Ls) */
+  int32_t ld_item, ld_itemb, ld_user, ld_usert;
+  /* != 0: rows that received no gradient are not written (the caller zeroed the buffers).  With
+   * strides this lets item and user gradients land in ONE fused [rows, W] buffer when a row is
+   * only ever used as one kind (the compact per-step table of the sharded path). */
+  int32_t sparse;
 } tlsan_grads_out;
 int tlsan_grads(const tlsan_dims* dims, const tlsan_params* p, const tlsan_batch* b,
                 const tlsan_hparams* hp, const tlsan_grads_out* g, const tlsan_step_out* out,
@@ -198,6 +204,49 @@ int tlsan_rows_apply(float* W, int32_t ld, int32_t nrows, int32_t width, int32_t
                      const float* grows, int32_t ldg, const int32_t* dest, int32_t n,
                      float gscale, const float* step_dev, float reg, double* sumsq_out,
                      void* ws, size_t ws_bytes, void* stream);
+
+/* ---- device side of the row-sharded multi-GPU step (tlsan_amd/dist.py; no reference counterpart:
+ * the reference is single-GPU, train.py:53,146).  Key space: G owners x R rows, key = owner*R + row.
+ *
+ * tlsan_route_plan: distinct rows a batch touches, grouped by owner (= all-to-all send order):
+ *   keys [n_keys] (duplicates fine) -> rank[G*R] compact index of every key, uniq[<=n_keys]
+ *   distinct keys ascending, n_uniq[1], cate_c[n_uniq] = cate_by_key[uniq], comp[n_keys] = rank[keys],
+ *   sendbuf [G][1 + cap] = per owner {count, row numbers inside the owner's shard ...}: the payload of
+ *   ONE equal-split all-to-all (cap >= min(R, n_keys)).  flags[G*R] is scratch. */
+int tlsan_route_plan(const int32_t* keys, int32_t n_keys, int32_t R, int32_t G, const int32_t* cate_by_key,
+                     int32_t* flags, int32_t* rank, int32_t* uniq, int32_t* n_uniq, int32_t* sendbuf, int32_t cap,
+                     int32_t* cate_c, int32_t* comp, void* stream);
+
+/* tlsan_shard_gather: owner side of the row fetch.  recvbuf [G][1 + cap] as received from the G
+ * ranks; n_recv = sum of the counts (host value).  rows_out [n_recv, W] = the requested rows of
+ * shard [R, ld] in source-rank order (the all-to-all send order), recv_rows [n_recv] = their row
+ * numbers (input of tlsan_shard_apply). */
+int tlsan_shard_gather(const float* shard, int32_t ld, int32_t R, int32_t W, const int32_t* recvbuf, int32_t cap,
+                       int32_t G, int32_t n_recv, float* rows_out, int32_t* recv_rows, void* stream);
+
+/* tlsan_shard_summary: after the all-reduce (sum over G ranks) of
+ *   flat = [dense grads n_dense | cate grads n_cate | mean BCE | per-use row squares | table squares | pad]:
+ * global norm (tf18 rule), clip coefficient (model.py:201), loss (model.py:164-172), the device
+ * step size lr*coef, and the SGD update of the replicated dense parameters (+ K^T copy). */
+int tlsan_shard_summary(const float* flat, int32_t n_dense, int32_t n_cate, int32_t G, float lr, float reg, float clip,
+                        const double* S_cate, float* dense, float* dense_KT, const tlsan_dims* dims,
+                        float* step_dev, float* loss_out, float* gnorm_out, void* stream);
+
+/* tlsan_shard_apply: owner-side update of the fused shard table [R, W] (rows [0,cI) items with
+ * reg_item regularised columns, rows [cI,R) users with reg_user) from the row gradients received
+ * from every rank (vals[n_recv, ldv] for local rows `rows`, concatenated in source-rank order,
+ * src_off[G+1] host array of the per-source offsets; rows of one source are distinct), and of the
+ * replicated category table from g_cate [C, dc]:  W -= step * (gscale * sum + reg * W) on every
+ * row (dense L2, as the reference).  Fixed summation order -> bitwise reproducible.
+ * slots: int32 [R*G] device scratch that must be zero on entry and is zero again on exit.
+ * sumsq_out[2] (device doubles): sums of squares of the regularised columns of shard / cate_emb
+ * after the update; sumsq_f32 (nullable) receives (float)sumsq_out[0]. */
+size_t tlsan_shard_apply_workspace(int32_t R, int32_t C);
+int tlsan_shard_apply(float* shard, int32_t ld, int32_t cI, int32_t R, int32_t W, int32_t reg_item, int32_t reg_user,
+                      const float* vals, int32_t ldv, const int32_t* rows, int32_t n_recv, const int32_t* src_off,
+                      int32_t G, int32_t* slots, float gscale, const float* step_dev, float reg,
+                      float* cate_emb, int32_t C, int32_t dc, const float* g_cate,
+                      double* sumsq_out, float* sumsq_f32, void* ws, size_t ws_bytes, void* stream);
 
 /* Exclusive prefix sum + compaction of a device int32 array (the id-routing step of the sharded
  * path): prefix[k] = sum(cnt[0..k)), uniq = ascending list of k with cnt[k] > 0 and

@@ -8,7 +8,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libtlsan_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 NORM_TF18, NORM_DEDUP = 0, 1
 L2_DENSE, L2_LAZY = 0, 1
 
@@ -18,6 +18,7 @@ EXPORTS = [
     "tlsan_state_renorm", "tlsan_sync_derived", "tlsan_forward",
     "tlsan_train_step", "tlsan_grads", "tlsan_eval_ranks", "tlsan_profile_enable",
     "tlsan_profile_collect", "tlsan_debug_stamps", "tlsan_rows_apply_workspace", "tlsan_rows_apply", "tlsan_scan_compact",
+    "tlsan_route_plan", "tlsan_shard_gather", "tlsan_shard_summary", "tlsan_shard_apply_workspace", "tlsan_shard_apply",
 ]
 PROF_SEGMENTS = ("index_build", "fwd_bwd", "dk_partial", "dense_finalize", "apply_rows")
 
@@ -55,7 +56,8 @@ class StepOut(C.Structure):
 
 class GradsOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
-                ("item_emb", "item_b", "user_emb", "usert_emb", "cate_emb", "dense")]
+                ("item_emb", "item_b", "user_emb", "usert_emb", "cate_emb", "dense")] + \
+               [(n, C.c_int32) for n in ("ld_item", "ld_itemb", "ld_user", "ld_usert", "sparse")]
 
 
 _lib = None
@@ -110,6 +112,23 @@ def load():
     lib.tlsan_rows_apply.restype = C.c_int
     lib.tlsan_scan_compact.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.tlsan_scan_compact.restype = C.c_int
+    lib.tlsan_route_plan.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 6 + \
+                                    [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.tlsan_shard_gather.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
+                                       C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.tlsan_shard_gather.restype = C.c_int
+    lib.tlsan_route_plan.restype = C.c_int
+    lib.tlsan_shard_summary.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, P(Dims), C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]
+    lib.tlsan_shard_summary.restype = C.c_int
+    lib.tlsan_shard_apply_workspace.argtypes = [C.c_int32, C.c_int32]
+    lib.tlsan_shard_apply_workspace.restype = C.c_size_t
+    lib.tlsan_shard_apply.argtypes = [C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                      P(C.c_int32), C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_float,
+                                      C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.tlsan_shard_apply.restype = C.c_int
     lib.tlsan_debug_stamps.argtypes = [C.c_void_p]
     lib.tlsan_debug_stamps.restype = C.c_int
     for name in ("tlsan_dense_layout_of", "tlsan_state_init", "tlsan_sync_derived", "tlsan_forward",

@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libtlsan_hip.so")
 SOURCES = ["tlsan_api.hip", "tlsan_attn_d64.hip", "tlsan_attn_d128.hip", "tlsan_attn_d256.hip"]
-HEADERS = ["tlsan_common.h", "tlsan_attn.h", "tlsan_attn_inst.h", "tlsan_update.h", "tlsan_eval.h", "tlsan_rows.h"]
+HEADERS = ["tlsan_common.h", "tlsan_attn.h", "tlsan_attn_inst.h", "tlsan_update.h", "tlsan_eval.h", "tlsan_rows.h", "tlsan_shard.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC]
 
 

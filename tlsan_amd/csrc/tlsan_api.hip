@@ -9,7 +9,7 @@
 #include "tlsan_common.h"
 #include "tlsan_eval.h"
 #include "tlsan_update.h"
-#include "tlsan_rows.h"
+#include "tlsan_shard.h"
 
 hipError_t tlsan_launch_fwd_bwd_d64(bool train, bool lstream, const FwdArgs& a, int grid, hipStream_t st);
 hipError_t tlsan_launch_fwd_bwd_d128(bool train, bool lstream, const FwdArgs& a, int grid, hipStream_t st);
@@ -541,6 +541,11 @@ int tlsan_grads(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch* b
   ApplyArgs A;
   fill_apply(A, d, s, p, b, hp, w, st, L);
   A.go = *g;
+  if (A.go.ld_item == 0) A.go.ld_item = d->d_item;
+  if (A.go.ld_itemb == 0) A.go.ld_itemb = 1;
+  if (A.go.ld_user == 0) A.go.ld_user = d->d_item;
+  if (A.go.ld_usert == 0) A.go.ld_usert = d->Ls;
+  if (A.go.ld_item % 4 || A.go.ld_user % 4) return fail(TLSAN_E_UNSUPPORTED, "gradient row strides must be multiples of 4 floats");
   if (hp->norm_mode == TLSAN_NORM_DEDUP && (rc = clip_dedup(A, hp, out, w, st, b, hs))) return rc;
   if ((rc = launch_apply(AP_GRADS, false, A, true, b->B, b->Sn, hs))) return rc;
   prof_mark(5, hs);
@@ -633,6 +638,104 @@ int tlsan_rows_apply(float* W, int32_t ld, int32_t nrows, int32_t width, int32_t
     hipLaunchKernelGGL(k_reduce_double, dim3(1), dim3(256), 0, hs, w.part, w.nblk, sumsq_out);
     CHECK_LAUNCH("k_reduce_double");
   }
+  return TLSAN_OK;
+}
+
+int tlsan_route_plan(const int32_t* keys, int32_t n_keys, int32_t R, int32_t G, const int32_t* cate_by_key,
+                     int32_t* flags, int32_t* rank, int32_t* uniq, int32_t* n_uniq, int32_t* sendbuf, int32_t cap,
+                     int32_t* cate_c, int32_t* comp, void* stream) {
+  if (!keys || !cate_by_key || !flags || !rank || !uniq || !n_uniq || !sendbuf || !cate_c || !comp)
+    return fail(TLSAN_E_BADARG, "tlsan_route_plan: NULL pointer");
+  if (n_keys < 1 || R < 1 || G < 1 || (long long)R * G >= (1LL << 31)) return fail(TLSAN_E_BADARG, "tlsan_route_plan: bad sizes");
+  if (cap < (R < n_keys ? R : n_keys)) return fail(TLSAN_E_BADARG, "tlsan_route_plan: cap must be >= min(R, n_keys)");
+  hipStream_t hs = (hipStream_t)stream;
+  const int nkeys = R * G;
+  if (hipMemsetAsync(flags, 0, 4 * (size_t)nkeys, hs) != hipSuccess) return fail(TLSAN_E_LAUNCH, "memset flags");
+  RouteArgs a;
+  memset(&a, 0, sizeof(a));
+  a.keys = keys; a.n_keys = n_keys; a.R = R; a.G = G; a.prefix = rank; a.uniq = uniq; a.n_uniq = n_uniq;
+  a.cate_by_key = cate_by_key; a.flags = flags; a.sendbuf = sendbuf; a.cap = cap;
+  a.cate_c = cate_c; a.comp = comp;
+  const int nt = n_keys > G ? n_keys : G;
+  hipLaunchKernelGGL(k_route_mark, dim3((n_keys + 255) / 256), dim3(256), 0, hs, a);
+  CHECK_LAUNCH("k_route_mark");
+  int rc = tlsan_scan_compact(flags, nkeys, rank, uniq, n_uniq, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_route_finish, dim3((nt + 255) / 256), dim3(256), 0, hs, a);
+  CHECK_LAUNCH("k_route_finish");
+  return TLSAN_OK;
+}
+
+int tlsan_shard_gather(const float* shard, int32_t ld, int32_t R, int32_t W, const int32_t* recvbuf, int32_t cap,
+                       int32_t G, int32_t n_recv, float* rows_out, int32_t* recv_rows, void* stream) {
+  if (!shard || !recvbuf || n_recv < 0 || (n_recv > 0 && (!rows_out || !recv_rows)) || G < 1 || R < 1 || cap < 1)
+    return fail(TLSAN_E_BADARG, "tlsan_shard_gather: bad arguments");
+  if (W < 4 || W % 4 || ld < W || ld % 4) return fail(TLSAN_E_UNSUPPORTED, "tlsan_shard_gather: W, ld must be multiples of 4");
+  if (n_recv == 0) return TLSAN_OK;
+  GatherArgs a;
+  a.shard = shard; a.ld = ld; a.W = W; a.recvbuf = recvbuf; a.cap = cap; a.G = G; a.n_recv = n_recv; a.R = R;
+  a.rows_out = rows_out; a.recv_rows = recv_rows;
+  hipLaunchKernelGGL(k_shard_gather, dim3((n_recv + 15) / 16), dim3(256), 0, (hipStream_t)stream, a);
+  CHECK_LAUNCH("k_shard_gather");
+  return TLSAN_OK;
+}
+
+int tlsan_shard_summary(const float* flat, int32_t n_dense, int32_t n_cate, int32_t G, float lr, float reg, float clip,
+                        const double* S_cate, float* dense, float* dense_KT, const tlsan_dims* d,
+                        float* step_dev, float* loss_out, float* gnorm_out, void* stream) {
+  if (!flat || !S_cate || !dense || !dense_KT || !d || !step_dev || !loss_out || !gnorm_out || G < 1)
+    return fail(TLSAN_E_BADARG, "tlsan_shard_summary: bad arguments");
+  tlsan_dense_layout L;
+  int rc = tlsan_dense_layout_of(d, &L);
+  if (rc) return rc;
+  if (n_dense != L.n_dense) return fail(TLSAN_E_BADARG, "tlsan_shard_summary: n_dense does not match dims");
+  SummaryArgs a;
+  a.flat = flat; a.n_dense = n_dense; a.n_cate = n_cate; a.G = G; a.lr = lr; a.reg = reg; a.clip = clip;
+  a.S_cate = S_cate; a.dense = dense; a.dense_KT = dense_KT; a.D = d->d; a.K_off = L.K; a.k0_off = L.k0;
+  a.step_dev = step_dev; a.loss_out = loss_out; a.gnorm_out = gnorm_out;
+  hipLaunchKernelGGL(k_shard_summary, dim3((n_dense + 1023) / 1024), dim3(1024), 0, (hipStream_t)stream, a);
+  CHECK_LAUNCH("k_shard_summary");
+  return TLSAN_OK;
+}
+
+size_t tlsan_shard_apply_workspace(int32_t R, int32_t C) {
+  if (R < 1 || C < 1) return 0;
+  return al(8 * (size_t)((R + AP_ROWS_PB - 1) / AP_ROWS_PB + (C + AP_ROWS_PB - 1) / AP_ROWS_PB));
+}
+
+int tlsan_shard_apply(float* shard, int32_t ld, int32_t cI, int32_t R, int32_t W, int32_t reg_item, int32_t reg_user,
+                      const float* vals, int32_t ldv, const int32_t* rows, int32_t n_recv, const int32_t* src_off,
+                      int32_t G, int32_t* slots, float gscale, const float* step_dev, float reg,
+                      float* cate_emb, int32_t C, int32_t dc, const float* g_cate,
+                      double* sumsq_out, float* sumsq_f32, void* ws, size_t ws_bytes, void* stream) {
+  if (!shard || !slots || !step_dev || !cate_emb || !g_cate || !sumsq_out || !src_off || n_recv < 0 ||
+      (n_recv > 0 && (!vals || !rows)))
+    return fail(TLSAN_E_BADARG, "tlsan_shard_apply: bad pointer / size");
+  if (G < 1 || G > SHARD_GMAX) return fail(TLSAN_E_UNSUPPORTED, "tlsan_shard_apply: 1..%d ranks", SHARD_GMAX);
+  if (W < 4 || W % 4 || W > 16 * 4 * SHARD_NCH || dc % 4 || dc > 16 * 4 * SHARD_NCH || ld < W || ld % 4 ||
+      (n_recv > 0 && (ldv < W || ldv % 4)) || cI < 0 || cI > R || reg_item > W || reg_user > W)
+    return fail(TLSAN_E_UNSUPPORTED, "tlsan_shard_apply: widths must be multiples of 4 up to %d", 16 * 4 * SHARD_NCH);
+  if (!ws || ws_bytes < tlsan_shard_apply_workspace(R, C)) return fail(TLSAN_E_WORKSPACE, "tlsan_shard_apply: workspace too small");
+  ShardApplyArgs a;
+  memset(&a, 0, sizeof(a));
+  a.shard = shard; a.ld = ld; a.cI = cI; a.R = R; a.W = W; a.reg_item = reg_item; a.reg_user = reg_user;
+  a.vals = vals ? vals : shard; a.ldv = vals ? ldv : ld; a.rows = rows; a.n_recv = n_recv; a.G = G;
+  for (int s = 0; s <= G; ++s) a.src_off[s] = src_off[s];
+  if (a.src_off[0] != 0 || a.src_off[G] != n_recv) return fail(TLSAN_E_BADARG, "tlsan_shard_apply: src_off must run from 0 to n_recv");
+  a.slots = slots; a.gscale = gscale; a.step_dev = step_dev; a.reg = reg;
+  a.cate_emb = cate_emb; a.C = C; a.dc = dc; a.g_cate = g_cate;
+  a.part_out = (double*)ws;
+  a.nb_rows = (R + AP_ROWS_PB - 1) / AP_ROWS_PB;
+  a.nb_cate = (C + AP_ROWS_PB - 1) / AP_ROWS_PB;
+  hipStream_t hs = (hipStream_t)stream;
+  if (n_recv > 0) {
+    hipLaunchKernelGGL(k_slot_mark, dim3((n_recv + 255) / 256), dim3(256), 0, hs, a);
+    CHECK_LAUNCH("k_slot_mark");
+  }
+  hipLaunchKernelGGL(k_shard_apply, dim3(a.nb_rows + a.nb_cate), dim3(256), 0, hs, a);
+  CHECK_LAUNCH("k_shard_apply");
+  hipLaunchKernelGGL(k_reduce_double2, dim3(2), dim3(256), 0, hs, a.part_out, a.nb_rows, a.nb_cate, sumsq_out, sumsq_f32);
+  CHECK_LAUNCH("k_reduce_double2");
   return TLSAN_OK;
 }
 

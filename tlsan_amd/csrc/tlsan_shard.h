@@ -1,0 +1,249 @@
+// tlsan_shard.h -- device side of the row-sharded multi-GPU step (tlsan_amd/dist.py): routing plan
+// of a batch in the owner-major key space, the step's scalar summary after the all-reduce, and the
+// owner-side deterministic apply of the row gradients received from every rank.  No reference
+// counterpart (the reference is single-GPU, train.py:53,146); the arithmetic is the update of
+// model.py:198-205 on the rows a rank owns.
+#pragma once
+#include "tlsan_rows.h"
+
+struct RouteArgs {
+  const int32_t* keys;      // [n_keys] key of every id the batch touches (duplicates fine)
+  int32_t n_keys, R, G;     // R rows per owner, G owners: key = owner * R + local row
+  const int32_t* prefix;    // [G*R] compact index of every key (exclusive scan of the flags)
+  const int32_t* uniq;      // distinct keys, ascending (= grouped by owner: all-to-all send order)
+  const int32_t* n_uniq;
+  const int32_t* cate_by_key;  // category of an item key, -1 for user keys
+  int32_t* flags;
+  int32_t* sendbuf;         // [G][1 + cap]: per owner {count, row numbers inside the owner's shard ...}:
+  int32_t cap;              //   equal-split all-to-all payload (count and ids travel together)
+  int32_t* cate_c;          // [n_uniq] item -> category map of the compact table
+  int32_t* comp;            // [n_keys] compact row of every id of the batch
+};
+
+__global__ void k_route_mark(RouteArgs a) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < a.n_keys) a.flags[a.keys[t]] = 1;
+}
+
+__global__ void k_route_finish(RouteArgs a) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nu = *a.n_uniq;
+  if (t < a.n_keys) a.comp[t] = a.prefix[a.keys[t]];
+  if (t < nu) {
+    const int k = a.uniq[t], g = k / a.R;
+    a.sendbuf[(size_t)g * (1 + a.cap) + 1 + (t - a.prefix[(size_t)g * a.R])] = k - g * a.R;
+    a.cate_c[t] = a.cate_by_key[k];
+  }
+  if (t < a.G)
+    a.sendbuf[(size_t)t * (1 + a.cap)] = (t + 1 < a.G ? a.prefix[(size_t)(t + 1) * a.R] : nu) - a.prefix[(size_t)t * a.R];
+}
+
+// Owner side of the row fetch: the rows the G ranks asked for (recvbuf [G][1 + cap] as received:
+// {count, local row numbers}) copied contiguously in source-rank order (= all-to-all send order),
+// plus the flat list of those row numbers for the gradient apply.  One 16-lane group per row.
+struct GatherArgs {
+  const float* shard; int32_t ld, W;
+  const int32_t* recvbuf; int32_t cap, G, n_recv, R;
+  float* rows_out; int32_t* recv_rows;
+};
+__global__ __launch_bounds__(256) void k_shard_gather(GatherArgs a) {
+  const int e = blockIdx.x * 16 + (threadIdx.x >> 4), l16 = threadIdx.x & 15;
+  if (e >= a.n_recv) return;
+  int s = 0, j = e;
+  for (;;) {  // source rank of entry e (G <= 16 counts, L2-resident)
+    const int c = a.recvbuf[(size_t)s * (1 + a.cap)];
+    if (j < c || s + 1 >= a.G) break;
+    j -= c;
+    ++s;
+  }
+  int r = a.recvbuf[(size_t)s * (1 + a.cap) + 1 + j];
+  r = min(max(r, 0), a.R - 1);
+  if (l16 == 0) a.recv_rows[e] = r;
+  const float* src = a.shard + (size_t)r * a.ld;
+  float* dst = a.rows_out + (size_t)e * a.W;
+  for (int c4 = l16; c4 < a.W / 4; c4 += 16) *(f32x4*)(dst + 4 * c4) = *(const f32x4*)(src + 4 * c4);
+}
+
+// ------------------------------------------------------------------------------------------
+// After the all-reduce of flat = [dense grads | cate grads | loss | per-use squares | table squares]
+// (sums over the G ranks of per-rank MEANS over their own batches): global norm, clip coefficient,
+// loss, step size (device scalar for the owners' apply) and the SGD update of the replicated dense
+// parameters + the K^T copy.  Every rank computes identical bits.
+struct SummaryArgs {
+  const float* flat; int32_t n_dense, n_cate, G;
+  float lr, reg, clip;
+  const double* S_cate;   // sum of squares of the (replicated) category table
+  float* dense; float* dense_KT; int32_t D, K_off, k0_off;
+  float* step_dev; float* loss_out; float* gnorm_out;
+};
+
+// Every workgroup recomputes the norm (n_dense L2-resident floats, same fixed tree -> same bits)
+// and then updates its own 1024-element slice: no second launch, no cross-workgroup hand-over.
+__global__ __launch_bounds__(1024) void k_shard_summary(SummaryArgs a) {
+  __shared__ double sh[1024];
+  __shared__ float sh_step;
+  const int tid = threadIdx.x;
+  const float inv_g = 1.0f / (float)a.G;
+  double s = 0.0;
+  for (int k0 = tid; k0 < a.n_dense; k0 += 1024 * 8) {  // 8 loads in flight
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = a.flat[k0 + 1024 * u < a.n_dense ? k0 + 1024 * u : k0];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (k0 + 1024 * u < a.n_dense) {
+        const double g = (double)(v[u] * inv_g);
+        s += g * g;
+      }
+  }
+  sh[tid] = s;
+  __syncthreads();
+  for (int o = 512; o >= 1; o >>= 1) {
+    if (tid < o) sh[tid] += sh[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const float* tail = a.flat + a.n_dense + a.n_cate;
+    const double S_tot = (double)tail[2] + *a.S_cate;
+    const double sq = (double)tail[1] * (double)(inv_g * inv_g) + (double)a.reg * (double)a.reg * S_tot + sh[0];
+    const float norm = (float)sqrt(sq);
+    const float coef = a.clip / fmaxf(norm, a.clip);  // clip_by_global_norm (model.py:201)
+    sh_step = coef * a.lr;
+    if (blockIdx.x == 0) {
+      *a.step_dev = sh_step;
+      *a.gnorm_out = norm;
+      *a.loss_out = tail[0] * inv_g + a.reg * 0.5f * (float)S_tot;
+    }
+  }
+  __syncthreads();
+  const float step = sh_step;
+  const int k = blockIdx.x * 1024 + tid;
+  if (k < a.n_dense) {
+    const float w = a.dense[k] - step * (a.flat[k] * inv_g);
+    a.dense[k] = w;
+    if (k >= a.K_off && k < a.k0_off) {
+      const int idx = k - a.K_off;
+      a.dense_KT[(size_t)(idx % a.D) * a.D + idx / a.D] = w;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Owner-side apply.  The rows received from source rank s are distinct, so a destination row has at
+// most one contribution per source: k_slot_mark files entry e of source s under slots[row][s]
+// (plain stores, no counting sort), k_shard_apply sums a row's contributions in source order
+// (fixed order -> bitwise reproducible), applies the dense-L2 SGD update to EVERY local row
+// (model.py:164-169,198-205) and clears the slots.  Category rows (replicated table, gradient
+// already summed by the all-reduce) are the trailing workgroups.
+#define SHARD_GMAX 16
+#define SHARD_NCH 4  // 16 lanes x 4 chunks x 4 floats = 256 columns max
+struct ShardApplyArgs {
+  float* shard; int32_t ld, cI, R, W, reg_item, reg_user;
+  const float* vals; int32_t ldv; const int32_t* rows; int32_t n_recv;
+  int32_t src_off[SHARD_GMAX + 1]; int32_t G;
+  int32_t* slots;  // [R][G], zero at rest
+  float gscale; const float* step_dev; float reg;
+  float* cate_emb; int32_t C, dc; const float* g_cate;
+  double* part_out; int32_t nb_rows, nb_cate;
+};
+
+__global__ void k_slot_mark(ShardApplyArgs a) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= a.n_recv) return;
+  int s = 0;
+  while (s + 1 < a.G && e >= a.src_off[s + 1]) ++s;
+  const int r = a.rows[e];
+  if (r >= 0 && r < a.R) a.slots[(size_t)r * a.G + s] = e + 1;
+}
+
+__global__ __launch_bounds__(256) void k_shard_apply(ShardApplyArgs a) {
+  __shared__ double shd[4];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, grp = lane >> 4, l16 = lane & 15;
+  const int blk = blockIdx.x;
+  const bool is_cate = blk >= a.nb_rows;
+  const int row = (is_cate ? blk - a.nb_rows : blk) * AP_ROWS_PB + wave * 4 + grp;
+  const bool vr = row < (is_cate ? a.C : a.R);
+  const int rc = vr ? row : 0;
+  const int width = is_cate ? a.dc : a.W;
+  const int W4 = width / 4;
+  const int reg_cols = is_cate ? a.dc : (rc < a.cI ? a.reg_item : a.reg_user);
+  float* Wr = is_cate ? a.cate_emb + (size_t)rc * a.dc : a.shard + (size_t)rc * a.ld;
+  const float step = *a.step_dev;
+  f32x4 w[SHARD_NCH];
+#pragma unroll
+  for (int ch = 0; ch < SHARD_NCH; ++ch)
+    if (l16 + 16 * ch < W4) w[ch] = *(const f32x4*)(Wr + 4 * (l16 + 16 * ch));
+  double acc[SHARD_NCH][4];
+#pragma unroll
+  for (int ch = 0; ch < SHARD_NCH; ++ch)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[ch][i] = 0.0;
+  if (is_cate) {
+#pragma unroll
+    for (int ch = 0; ch < SHARD_NCH; ++ch)
+      if (l16 + 16 * ch < W4) {
+        const f32x4 v = *(const f32x4*)(a.g_cate + (size_t)rc * a.dc + 4 * (l16 + 16 * ch));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[ch][i] = (double)v[i];
+      }
+  } else {
+    int32_t* sl = a.slots + (size_t)rc * a.G;
+    for (int s0 = 0; s0 < a.G; s0 += 4) {  // 4 sources in flight (clamped addresses, masked sum)
+      int e[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) e[u] = (s0 + u < a.G && vr) ? sl[s0 + u] : 0;
+      f32x4 v[4][SHARD_NCH];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* src = a.vals + (size_t)(e[u] > 0 ? e[u] - 1 : 0) * a.ldv;
+#pragma unroll
+        for (int ch = 0; ch < SHARD_NCH; ++ch)
+          if (l16 + 16 * ch < W4) v[u][ch] = *(const f32x4*)(src + 4 * (l16 + 16 * ch));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (e[u] > 0) {
+#pragma unroll
+          for (int ch = 0; ch < SHARD_NCH; ++ch)
+            if (l16 + 16 * ch < W4) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc[ch][i] += (double)v[u][ch][i];
+            }
+          if (l16 == 0) sl[s0 + u] = 0;
+        }
+    }
+  }
+  double part = 0.0;
+  if (vr) {
+#pragma unroll
+    for (int ch = 0; ch < SHARD_NCH; ++ch) {
+      const int c4 = l16 + 16 * ch;
+      if (c4 < W4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bool rg = 4 * c4 + i < reg_cols;
+          const float g = a.gscale * (float)acc[ch][i] + (rg ? a.reg * w[ch][i] : 0.0f);
+          w[ch][i] -= step * g;
+          if (rg) part += (double)w[ch][i] * (double)w[ch][i];
+        }
+        *(f32x4*)(Wr + 4 * c4) = w[ch];
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) part += __shfl_xor(part, o);
+  if (lane == 0) shd[wave] = part;
+  __syncthreads();
+  if (tid == 0) a.part_out[blk] = shd[0] + shd[1] + shd[2] + shd[3];
+}
+
+// out[0] = sum(part[0, n0)), out[1] = sum(part[n0, n0+n1)); sq_f32 (nullable) = (float)out[0]
+__global__ __launch_bounds__(256) void k_reduce_double2(const double* part, int n0, int n1, double* out, float* sq_f32) {
+  __shared__ double shd[256];
+  const int b = blockIdx.x;
+  const double s = block_sum_double(part + (b ? n0 : 0), b ? n1 : n0, shd);
+  if (threadIdx.x == 0) {
+    out[b] = s;
+    if (b == 0 && sq_f32) *sq_f32 = (float)s;
+  }
+}

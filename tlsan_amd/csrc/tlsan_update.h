@@ -840,8 +840,10 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
           g[i] = apply_elem<MODE, LAZY>(wi, (float)acc[ch][i], x.P, x.invP, a.reg, x.step, x.lazy_scale, part);
           w[ch][i] = wi;
         }
-        if constexpr (MODE == AP_GRADS)
-          *(f32x4*)((IS_ITEM ? a.go.item_emb : a.go.user_emb) + (size_t)row * a.di + cc) = g;
+        if constexpr (MODE == AP_GRADS) {
+          if (!a.go.sparse || n > 0)
+            *(f32x4*)((IS_ITEM ? a.go.item_emb + (size_t)row * a.go.ld_item : a.go.user_emb + (size_t)row * a.go.ld_user) + cc) = g;
+        }
         if constexpr (MODE == AP_UPDATE) *(f32x4*)(Wrow + cc) = w[ch];
       } else if (!IS_ITEM) {  // usert_emb columns (scalar: Ls need not be a multiple of 4)
 #pragma unroll
@@ -850,7 +852,9 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
           if (p < a.Ls) {
             float wi = w[ch][i];
             const float gg = apply_elem<MODE, LAZY>(wi, (float)acc[ch][i], x.P, x.invP, a.reg, x.step, x.lazy_scale, part);
-            if constexpr (MODE == AP_GRADS) a.go.usert_emb[(size_t)row * a.Ls + p] = gg;
+            if constexpr (MODE == AP_GRADS) {
+              if (!a.go.sparse || n > 0) a.go.usert_emb[(size_t)row * a.go.ld_usert + p] = gg;
+            }
             if constexpr (MODE == AP_UPDATE) Trow[p] = wi;
           }
         }
@@ -858,7 +862,9 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
     }
     if (IS_ITEM && l16 == 0) {  // item_b[row]: not regularised (model.py:164-169), never scaled
       const float g = (float)bacc;
-      if constexpr (MODE == AP_GRADS) a.go.item_b[row] = g;
+      if constexpr (MODE == AP_GRADS) {
+        if (!a.go.sparse || n > 0) a.go.item_b[(size_t)row * a.go.ld_itemb] = g;
+      }
       if constexpr (MODE == AP_ROWNORM) part += (double)g * (double)g;
       if constexpr (MODE == AP_UPDATE) {
         if (n > 0) a.p.item_b[(size_t)row * a.p.ld_itemb] = wb - x.step * g;

@@ -10,15 +10,28 @@ SURVEY.md section 8e.  Samples are independent units: every rank trains its own 
     mod-G spreads the Zipf-hot items);
   * ``cate_emb`` (<= 5 MB), ``item_cate_list`` and the dense attention weights: replicated.
 
-One step = (1) mark the rows the local batch touches in an owner-major key space and compact the
-marks (one HIP scan: distinct rows already in all-to-all order + the id -> compact-row map),
-(2) all-to-all of the per-owner counts and local row numbers, (3) all-to-all of the rows back
-into a compact per-step table the HIP kernels run on in place (row strides,
-tlsan_params.ld_*), (4) fused forward/backward + exact per-row gradient sums (tlsan_grads),
-(5) ONE all-reduce of [dense grads | cate grads | loss | norm terms], (6) all-to-all of the
-per-row gradients back to the owners, (7) owners apply them with the deterministic
-tlsan_rows_apply (dense L2 decay of every local row, as the reference).  Items and users share
-one fused shard table and one exchange each way; one host sync per step (split sizes).
+One step on the main stream, in this order on every rank (four collectives, all on one
+communicator in program order):
+
+  plan, stage 1 (tlsan_route_plan; normally queued one step AHEAD for the next batch): mark the
+      rows the batch touches in an owner-major key space, compact the marks with one HIP scan
+      (distinct rows already in all-to-all order + the id -> compact-row map), and tell every
+      owner which of its rows are wanted with ONE equal-split all-to-all that carries counts and
+      row numbers together; the counts are copied to pinned host memory behind an event;
+  plan, stage 2: the host reads the counts (the only host wait of a step; free when stage 1 ran a
+      step ahead);
+  (1) owners gather the wanted rows (tlsan_shard_gather), all-to-all of the rows into a compact
+      per-step table the HIP kernels run on in place (row strides, tlsan_params.ld_*);
+  (2) fused forward/backward + exact per-row gradient sums written straight into the fused
+      [rows, W] layout (tlsan_grads with strides / sparse rows);
+  (3) ONE all-reduce of [dense grads | cate grads | loss | norm terms];
+  (4) tlsan_shard_summary: global norm, clip coefficient, loss, dense update (one launch);
+  (5) all-to-all of the per-row gradients back to the owners;
+  (6) tlsan_shard_apply: the owners file each received row under (row, source rank) -- rows of one
+      source are distinct, so no counting sort -- and apply the update with dense L2 decay to every
+      local row in fixed source order (bitwise reproducible), category table included.
+
+Items and users share one fused shard table and one exchange each way.
 
 ``KeyRouter`` / ``RowExchange`` are device-agnostic torch + torch.distributed plumbing (run on
 CPU/gloo in the tests); all arithmetic on rows is in libtlsan_hip.so.
@@ -266,21 +279,26 @@ class ShardedModel:
         self.dense_KT = torch.zeros(self.d, self.d, dtype=torch.float32, device=dev)
         self.reg = float(config["regulation_rate"])
         self.clip = float(config["max_gradient_norm"])
-        self._sq = torch.zeros(3, dtype=torch.float64, device=dev)   # rows_apply sumsq outputs
-        self._out = torch.zeros(4, dtype=torch.float32, device=dev)  # loss, gnorm, sq_rows (local)
+        if self.W > 256 or self.world > 16:
+            raise NotImplementedError("fused shard rows up to 256 floats, up to 16 ranks")
+        self._sq = torch.zeros(2, dtype=torch.float64, device=dev)   # sums of squares: local shard rows, cate_emb
+        # all-reduced vector: dense grads | cate grads | mean BCE | per-use squares | local table squares | pad
+        self._flat = torch.zeros(self.lay.n_dense + Cc * self.dc + 4, dtype=torch.float32, device=dev)
+        self._gn_local = torch.zeros(1, dtype=torch.float32, device=dev)
         self._step_dev = torch.zeros(1, dtype=torch.float32, device=dev)
         self.last_loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self.last_gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
-        self._state = self._ws = self._rws = None
-        self._scan_prefix = torch.empty(self.router.nkeys, dtype=torch.int32, device=dev)
-        self._scan_uniq = torch.empty(self.router.nkeys, dtype=torch.int32, device=dev)
-        self._scan_n = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._ws = None
+        self._flags = torch.empty(self.router.nkeys, dtype=torch.int32, device=dev)
+        self._slots = [None, None]          # routing plans: current / prefetched
+        self._next_slot = 0
+        self._slots_buf = torch.zeros(self.router.R * self.world, dtype=torch.int32, device=dev)  # zero at rest
+        self._aws = torch.empty(int(self.lib.tlsan_shard_apply_workspace(self.router.R, Cc)), dtype=torch.uint8, device=dev)
         self._step = 0
         self._epoch = 0
         self.global_step = _Var(lambda: self._step)
         self.global_epoch_step = _Var(lambda: self._epoch)
         self.train_writer, self.eval_writer = _Writer("train"), _Writer("eval")
-        self._cate_ids = torch.arange(Cc, dtype=torch.int32, device=dev)
         self.set_params(Model.init_params(config, seed))   # identical on every rank (numpy, seeded)
 
     # ------------------------------------------------------------------ helpers
@@ -299,12 +317,6 @@ class ShardedModel:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def _scan(self, flags):
-        L.check(self.lib.tlsan_scan_compact(flags.data_ptr(), flags.numel(), self._scan_prefix.data_ptr(),
-                                            self._scan_uniq.data_ptr(), self._scan_n.data_ptr(), self._stream()),
-                "tlsan_scan_compact")
-        return self._scan_prefix, self._scan_uniq, self._scan_n
-
     def device_batch(self, batch, is_test=False):
         """Upload the batch and map its ids into the router's key space (elementwise, once)."""
         db = batch if isinstance(batch, DeviceBatch) else DeviceBatch(batch, self.device, is_test, self.Ls)
@@ -316,122 +328,182 @@ class ShardedModel:
             if db.j is not None:
                 parts.append(r.item_keys(db.j.long()))
             parts.append(r.user_keys(db.u.long()))
-            db.keys = torch.cat(parts)
+            db.keys = torch.cat(parts).to(torch.int32)
         return db
 
-    def _buffers(self, dims, cp, B, Sn, n_rows_max):
+    # ------------------------------------------------------------------ routing plan (two stages)
+    def _slot(self, k, n_keys):
+        """Per-slot routing buffers (two slots: the plan of the next batch is built while the
+        current one is in use)."""
+        sl = self._slots[k]
+        if sl is None or sl["cap"] < n_keys:
+            dev, G, nk = self.device, self.world, self.router.nkeys
+            cap = int(n_keys * 1.25) + 16
+            pcap = min(self.router.R, cap)   # distinct rows one owner can be asked for
+            sl = dict(cap=cap, pcap=pcap, rank=torch.empty(nk, dtype=torch.int32, device=dev),
+                      uniq=torch.empty(nk, dtype=torch.int32, device=dev),
+                      n_uniq=torch.zeros(1, dtype=torch.int32, device=dev),
+                      # per peer {count, local row numbers ...}: ONE equal-split all-to-all carries both
+                      sendbuf=torch.zeros(G, 1 + pcap, dtype=torch.int32, device=dev),
+                      recvbuf=torch.zeros(G, 1 + pcap, dtype=torch.int32, device=dev),
+                      cnts=torch.zeros(2, G, dtype=torch.int32, device=dev),       # [send | recv] per peer
+                      cate_c=torch.empty(cap, dtype=torch.int32, device=dev),
+                      comp=torch.empty(cap, dtype=torch.int32, device=dev),
+                      host=torch.zeros(2, G, dtype=torch.int32).pin_memory(),
+                      event=torch.cuda.Event(), state=None)
+            self._slots[k] = sl
+        return sl
+
+    def _plan_stage1(self, db, k):
+        """Device-only half: distinct rows grouped by owner, compact ids, and ONE all-to-all that
+        tells every owner which of its rows are wanted (counts + row numbers); the copy of the
+        counts to the host is queued, nothing waits."""
+        nk = int(db.keys.numel())
+        sl = self._slot(k, nk)
+        r = self.router
+        L.check(self.lib.tlsan_route_plan(db.keys.data_ptr(), nk, r.R, r.G, self.cate_by_key.data_ptr(),
+                                          self._flags.data_ptr(), sl["rank"].data_ptr(), sl["uniq"].data_ptr(),
+                                          sl["n_uniq"].data_ptr(), sl["sendbuf"].data_ptr(), sl["pcap"],
+                                          sl["cate_c"].data_ptr(), sl["comp"].data_ptr(), self._stream()),
+                "tlsan_route_plan")
+        if self.world > 1:
+            a2a(sl["recvbuf"].view(-1), sl["sendbuf"].view(-1), None, None, self.group)
+            rb = sl["recvbuf"]
+        else:
+            rb = sl["sendbuf"]
+        sl["rb"] = rb
+        sl["cnts"][0].copy_(sl["sendbuf"][:, 0])
+        sl["cnts"][1].copy_(rb[:, 0])
+        sl["host"].copy_(sl["cnts"], non_blocking=True)
+        sl["event"].record(torch.cuda.current_stream(self.device))
+        sl["db"] = db
+        return sl
+
+    def _plan_stage2(self, sl):
+        """Host half: read the exchange sizes (the step's only host wait; free when stage 1 was
+        queued a step ahead)."""
+        sl["event"].synchronize()
+        h = sl["host"]
+        send, recv = h[0].tolist(), h[1].tolist()
+        n, n_recv = int(sum(send)), int(sum(recv))
+        recv_rows = torch.empty(max(n_recv, 1), dtype=torch.int32, device=self.device)
+        off = [0]
+        for c in recv:
+            off.append(off[-1] + int(c))
+        sl.update(send=send, recv=recv, n=n, n_recv=n_recv, recv_rows=recv_rows,
+                  src_off=(C.c_int32 * (self.world + 1))(*off))
+        return sl
+
+    def _plan(self, db):
+        """The plan of `db`: prefetched (train_async(..., next_batch=)) or built now."""
+        k = self._next_slot
+        sl = self._slots[k]
+        if sl is None or sl.get("db") is not db:
+            sl = self._plan_stage1(db, k)
+        self._next_slot = 1 - k
+        return self._plan_stage2(sl)
+
+    def _fetch(self, sl):
+        """compact per-step table: row k = the owner's shard row of the k-th distinct key"""
+        rows = torch.empty((max(sl["n_recv"], 1), self.W), dtype=torch.float32, device=self.device)
+        L.check(self.lib.tlsan_shard_gather(self.shard.data_ptr(), self.W, self.router.R, self.W, sl["rb"].data_ptr(),
+                                            sl["pcap"], self.world, sl["n_recv"], rows.data_ptr(),
+                                            sl["recv_rows"].data_ptr(), self._stream()), "tlsan_shard_gather")
+        if self.world == 1:
+            return rows
+        table = torch.empty((max(sl["n"], 1), self.W), dtype=torch.float32, device=self.device)
+        a2a(table[:sl["n"]], rows[:sl["n_recv"]], sl["send"], sl["recv"], self.group)
+        return table
+
+    def _compact(self, db, sl, table):
+        B, Ls, Sn = db.B, self.Ls, db.Sn
+        comp = sl["comp"]
+        esz = 4
+        base_c = comp.data_ptr()
+        o = 0
+        p_i = base_c + esz * o; o += B
+        p_hist = base_c + esz * o; o += B * Ls
+        p_new = base_c + esz * o if Sn > 0 else db.hist_i_new.data_ptr(); o += B * Sn
+        p_j = None
+        if db.j is not None:
+            p_j = base_c + esz * o; o += B
+        p_u = base_c + esz * o
+        ptr = lambda t: None if t is None else t.data_ptr()
+        cb = L.Batch(B, Sn, p_u, p_i, p_j, ptr(db.y), p_hist, p_new, ptr(db.hist_t),
+                     ptr(db.sl), ptr(db.sl_new), ptr(db.u_cate))
+        base = table.data_ptr()
+        cp = L.Params(base, base + 4 * self.di, base, base + 4 * self.di, self.cate_emb.data_ptr(),
+                      self.dense.data_ptr(), self.dense_KT.data_ptr(), sl["cate_c"].data_ptr(),
+                      self.W, self.W, self.W, self.W, None)
+        n = max(sl["n"], 1)
+        dims = L.Dims(n, n, self.C, self.d, self.di, self.dc, self.H, self.Ls)
+        return dims, cp, cb
+
+    def _buffers(self, sl, dims, cp, B, Sn):
         nst = self.lib.tlsan_state_bytes(C.byref(dims))
         nws = self.lib.tlsan_workspace_bytes(C.byref(dims), B, Sn)
         if nst == 0 or nws == 0:
             raise L.TlsanError(self.lib.tlsan_last_error().decode())
-        if self._state is None or self._state.numel() < nst:
-            self._state = torch.zeros(int(nst * 1.5), dtype=torch.uint8, device=self.device)
+        if sl["state"] is None or sl["state"].numel() < nst:
+            sl["state"] = torch.zeros(int(nst * 1.5), dtype=torch.uint8, device=self.device)
+            sl["state"][:4].view(torch.float32).fill_(1.0)   # table scale P = 1 (the owners apply the decay)
         if self._ws is None or self._ws.numel() < nws:
             self._ws = torch.empty(int(nws * 1.25), dtype=torch.uint8, device=self.device)
         # the compact table (and its item -> category map) changes every step: clear the use
-        # counters and rebuild the category -> items index for it; P = 1 (owners apply the decay)
-        self._state[:4].view(torch.float32).fill_(1.0)
-        L.check(self.lib.tlsan_state_reindex(C.byref(dims), C.byref(cp), self._state.data_ptr(), self._stream()),
+        # counters and rebuild the category -> items index for it
+        L.check(self.lib.tlsan_state_reindex(C.byref(dims), C.byref(cp), sl["state"].data_ptr(), self._stream()),
                 "tlsan_state_reindex")
-        nr = self.lib.tlsan_rows_apply_workspace(max(self.router.R, self.C), max(n_rows_max, 1))
-        if self._rws is None or self._rws.numel() < nr:
-            self._rws = torch.empty(int(nr * 1.25), dtype=torch.uint8, device=self.device)
-
-    def _compact(self, db):
-        """Route: distinct rows the batch touches -> compact per-step table + remapped batch."""
-        B, Ls, Sn = db.B, self.Ls, db.Sn
-        plan = self.router.plan(db.keys, self._scan)
-        table = self.router.fetch(plan, self.shard)              # [n, W], rows in key order
-        comp = plan["prefix"][db.keys]                            # compact row of every id of the batch
-        o = 0
-        i_c = comp[o:o + B]; o += B
-        hist_c = comp[o:o + B * Ls]; o += B * Ls
-        new_c = comp[o:o + B * Sn] if Sn > 0 else db.hist_i_new; o += B * Sn
-        j_c = None
-        if db.j is not None:
-            j_c = comp[o:o + B]; o += B
-        u_c = comp[o:o + B]
-        cate_c = self.cate_by_key[plan["uniq"].long()]
-        keep = (table, comp, cate_c)
-        ptr = lambda t: None if t is None else t.data_ptr()
-        cb = L.Batch(B, Sn, ptr(u_c), ptr(i_c), ptr(j_c), ptr(db.y), ptr(hist_c), ptr(new_c), ptr(db.hist_t),
-                     ptr(db.sl), ptr(db.sl_new), ptr(db.u_cate))
-        base = table.data_ptr()
-        cp = L.Params(base, base + 4 * self.di, base, base + 4 * self.di, self.cate_emb.data_ptr(),
-                      self.dense.data_ptr(), self.dense_KT.data_ptr(), cate_c.data_ptr(),
-                      self.W, self.W, self.W, self.W, None)
-        n = max(plan["n"], 1)
-        dims = L.Dims(n, n, self.C, self.d, self.di, self.dc, self.H, self.Ls)
-        return dims, cp, cb, plan, keep
 
     # ------------------------------------------------------------------ training
-    def train_async(self, batch, lr):
+    def train_async(self, batch, lr, next_batch=None):
+        """One step.  `next_batch` (optional): its routing plan is queued before this step's heavy
+        kernels, so that the next step's host wait for the exchange sizes costs nothing."""
         db = self.device_batch(batch)
         G = self.world
-        dims, cp, cb, plan, keep = self._compact(db)
+        sl = self._plan(db)
+        if next_batch is not None:
+            self._plan_stage1(self.device_batch(next_batch), self._next_slot)
+        table = self._fetch(sl)
+        dims, cp, cb = self._compact(db, sl, table)
+        self._buffers(sl, dims, cp, db.B, db.Sn)
         n, Cc, di, Ls, W = dims.item_count, self.C, self.di, self.Ls, self.W
-        self._buffers(dims, cp, db.B, db.Sn, max(int(plan["recv_rows"].numel()), Cc))
         dev = self.device
-        g_item = torch.empty(n, di, dtype=torch.float32, device=dev)
-        g_itemb = torch.empty(n, dtype=torch.float32, device=dev)
-        g_user = torch.empty(n, di, dtype=torch.float32, device=dev)
-        g_usert = torch.empty(n, Ls, dtype=torch.float32, device=dev)
-        n_dense = self.lay.n_dense
-        flat = torch.zeros(n_dense + Cc * self.dc + 4, dtype=torch.float32, device=dev)
-        go = L.GradsOut(g_item.data_ptr(), g_itemb.data_ptr(), g_user.data_ptr(), g_usert.data_ptr(),
-                        flat.data_ptr() + 4 * n_dense, flat.data_ptr())
-        out = L.StepOut(self._out.data_ptr(), self._out.data_ptr() + 4, None, self._out.data_ptr() + 8)
+        n_dense, n_cate = self.lay.n_dense, Cc * self.dc
+        flat = self._flat
+        fp = flat.data_ptr()
+        # per-row gradients land directly in the fused layout (a compact row is an item or a user)
+        gf = torch.zeros(n, W, dtype=torch.float32, device=dev)
+        g0 = gf.data_ptr()
+        go = L.GradsOut(g0, g0 + 4 * di, g0, g0 + 4 * di, fp + 4 * n_dense, fp, W, W, W, W, 1)
+        tail = fp + 4 * (n_dense + n_cate)
+        out = L.StepOut(tail, self._gn_local.data_ptr(), None, tail + 4)
         hp = L.HParams(float(lr), 0.0, self.clip, L.NORM_TF18, L.L2_DENSE)   # reg is applied by the owners
         st = self._stream()
         L.check(self.lib.tlsan_grads(C.byref(dims), C.byref(cp), C.byref(cb), C.byref(hp), C.byref(go), C.byref(out),
-                                     self._state.data_ptr(), self._ws.data_ptr(), self._ws.numel(), st), "tlsan_grads")
+                                     sl["state"].data_ptr(), self._ws.data_ptr(), self._ws.numel(), st), "tlsan_grads")
         # ---- one all-reduce: dense grads | cate grads | loss | per-use squares | local table squares
-        tail = flat[n_dense + Cc * self.dc:]
-        tail[0] = self._out[0]
-        tail[1] = self._out[2]
-        tail[2] = self.S_local[0].float()
         if G > 1:
             allreduce_sum(flat, self.group)
-        inv_g = 1.0 / G
-        gd = flat[:n_dense] * inv_g
-        S_tot = tail[2].double() + self.S_cate[0]
-        sq = (tail[1].double() * (inv_g * inv_g) + (self.reg * self.reg) * S_tot + gd.double().pow(2).sum())
-        norm = sq.sqrt().float()
-        coef = self.clip / torch.clamp(norm, min=self.clip)          # clip_by_global_norm (model.py:201)
-        self._step_dev.copy_((coef * float(lr)).reshape(1))
-        self.last_gnorm.copy_(norm.reshape(1))
-        self.last_loss.copy_((tail[0] * inv_g + self.reg * 0.5 * S_tot.float()).reshape(1))
-        # ---- per-row gradients in the fused layout (rows of the other kind are exactly zero)
-        gf = torch.zeros(n, W, dtype=torch.float32, device=dev)
-        gf[:, :di] = g_item + g_user
-        gf[:, di:di + Ls] = g_usert
-        gf[:, di] += g_itemb
-        rows32, vals = self.router.push(plan, gf)
-        # owners: deterministic scatter-apply with dense L2 decay of every local row; destinations
-        # outside a view's range (the other table's rows) are ignored by tlsan_rows_apply
-        self._rows_apply(self.shard[:self.cI], di, vals, rows32, inv_g, 0)
-        self._rows_apply(self.shard[self.cI:], di + Ls, vals, rows32 - self.cI, inv_g, 1)
-        g_cate = flat[n_dense:n_dense + Cc * self.dc].view(Cc, self.dc)
-        self._rows_apply(self.cate_emb, self.dc, g_cate, self._cate_ids, inv_g, 2)
-        self.S_local = (self._sq[0] + self._sq[1]).reshape(1).clone()
-        self.S_cate = self._sq[2].reshape(1).clone()
-        # dense attention weights: replicated, identical update on every rank
-        self.dense.sub_(gd * self._step_dev)
-        L.check(self.lib.tlsan_sync_derived(C.byref(self.dims_full), C.byref(cp), st), "tlsan_sync_derived")
+        L.check(self.lib.tlsan_shard_summary(fp, n_dense, n_cate, G, float(lr), self.reg, self.clip,
+                                             self._sq.data_ptr() + 8, self.dense.data_ptr(), self.dense_KT.data_ptr(),
+                                             C.byref(self.dims_full), self._step_dev.data_ptr(),
+                                             self.last_loss.data_ptr(), self.last_gnorm.data_ptr(), st),
+                "tlsan_shard_summary")
+        # ---- row gradients back to the owners, deterministic apply with dense L2 decay of every row
+        if G > 1:
+            vals = torch.empty((max(sl["n_recv"], 1), W), dtype=torch.float32, device=dev)
+            a2a(vals[:sl["n_recv"]], gf[:sl["n"]], sl["recv"], sl["send"], self.group)
+        else:
+            vals = gf
+        L.check(self.lib.tlsan_shard_apply(self.shard.data_ptr(), W, self.cI, self.router.R, W, di, di + Ls,
+                                           vals.data_ptr(), W, sl["recv_rows"].data_ptr(), sl["n_recv"], sl["src_off"],
+                                           G, self._slots_buf.data_ptr(), 1.0 / G, self._step_dev.data_ptr(), self.reg,
+                                           self.cate_emb.data_ptr(), Cc, self.dc, fp + 4 * n_dense,
+                                           self._sq.data_ptr(), tail + 8, self._aws.data_ptr(), self._aws.numel(), st),
+                "tlsan_shard_apply")
         self._step += 1
-        self._keep = (keep, flat, gf, vals, rows32, g_item, g_itemb, g_user, g_usert)
+        self._keep = (table, gf, vals, sl["recv_rows"])
         return db
-
-    def _rows_apply(self, Wt, reg_cols, vals, rows32, gscale, slot):
-        n = int(rows32.numel())
-        rows32 = rows32.contiguous()
-        vals = vals.contiguous()
-        L.check(self.lib.tlsan_rows_apply(Wt.data_ptr(), Wt.stride(0), Wt.shape[0], Wt.shape[1], reg_cols,
-                                          vals.data_ptr() if n else None, vals.stride(0) if n else Wt.shape[1],
-                                          rows32.data_ptr() if n else None, n, float(gscale),
-                                          self._step_dev.data_ptr(), self.reg, self._sq.data_ptr() + 8 * slot,
-                                          self._rws.data_ptr(), self._rws.numel(), self._stream()), "tlsan_rows_apply")
-        self._keep_rows = getattr(self, "_keep_rows", [])[-6:] + [(rows32, vals)]
 
     def train(self, sess, batch, lr, add_summary=False):
         self.train_async(batch, lr)
@@ -440,13 +512,15 @@ class ShardedModel:
     # ------------------------------------------------------------------ evaluation
     def forward(self, batch, is_test=True):
         db = self.device_batch(batch, is_test)
-        dims, cp, cb, _, keep = self._compact(db)
+        sl = self._plan(db)
+        table = self._fetch(sl)
+        dims, cp, cb = self._compact(db, sl, table)
         li = torch.empty(db.B, dtype=torch.float32, device=self.device)
         lj = torch.empty(db.B, dtype=torch.float32, device=self.device) if db.j is not None else None
         L.check(self.lib.tlsan_forward(C.byref(dims), C.byref(cp), C.byref(cb), li.data_ptr(),
                                        None if lj is None else lj.data_ptr(), None, None, 0, self._stream()),
                 "tlsan_forward")
-        torch.cuda.current_stream(self.device).synchronize()   # `keep` tensors stay alive until done
+        torch.cuda.current_stream(self.device).synchronize()   # `table` stays alive until done
         return li, lj
 
     def eval_auc(self, sess, batch):
@@ -502,5 +576,6 @@ class ShardedModel:
         self._pack_dense(p)
         it, us = self._table_views()
         # running sums of squares of the regularised tables (tf.nn.l2_loss terms, model.py:164-169)
-        self.S_local = (it[:, :di].double().pow(2).sum() + us[:, :di + Ls].double().pow(2).sum()).reshape(1)
-        self.S_cate = self.cate_emb.double().pow(2).sum().reshape(1)
+        self._sq[0] = it[:, :di].double().pow(2).sum() + us[:, :di + Ls].double().pow(2).sum()
+        self._sq[1] = self.cate_emb.double().pow(2).sum()
+        self._flat[self.lay.n_dense + self.C * self.dc + 2] = self._sq[0].float()   # rides in the all-reduce
