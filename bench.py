@@ -40,9 +40,11 @@ def parse():
     ap.add_argument("--l2-mode", default="lazy", choices=["lazy", "dense"],
                     help="lazy: W = P*W_stored, only used rows touched (same update as the reference's dense L2); "
                          "dense: every row decayed every step")
-    ap.add_argument("--graph", type=int, default=1, help="replay hipGraph-captured steps (single-GPU path)")
+    ap.add_argument("--graph", type=int, default=0, help="replay hipGraph-captured steps instead of eager launches (single-GPU path)")
+    ap.add_argument("--prefetch", type=int, default=1,
+                    help="eager mode: build the next batch's destination index on a second stream during the step")
     ap.add_argument("--event-every", type=int, default=8,
-                    help="with --graph: every Nth timed step runs eagerly so HIP events can bracket k_fwd_bwd")
+                    help="every Nth timed step carries the HIP events that bracket k_fwd_bwd (graph mode: runs eagerly)")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded (multi-GPU) code path even at N=1")
     return ap.parse_args()
 
@@ -124,10 +126,14 @@ def main():
     def run(n, first, timed=False):
         for s in range(n):
             k = (first + s) % len(dbs)
-            if use_graph and not (timed and args.profile_level > 0 and s % args.event_every == 0):
-                model.replay(graphs[k])
-            elif sharded:
-                # the next batch is known (as in any input pipeline): its routing plan is queued a step ahead
+            if use_graph:
+                if timed and args.profile_level > 0 and s % args.event_every == 0:
+                    stepper.train_async(dbs[k], lr)
+                else:
+                    model.replay(graphs[k])
+            elif sharded or args.prefetch:
+                # the next batch is known (as in any input pipeline): its routing plan (sharded) /
+                # destination index (single GPU) is queued while this step computes
                 stepper.train_async(dbs[k], lr, next_batch=dbs[(k + 1) % len(dbs)])
             else:
                 stepper.train_async(dbs[k], lr)
@@ -140,6 +146,7 @@ def main():
 
     run(args.warmup, 0)
     fence()
+    lib.tlsan_profile_stride(1 if use_graph else args.event_every)   # graph mode: only the eager steps reach the marks
     lib.tlsan_profile_enable(args.profile_level)
     t0 = time.perf_counter()
     run(args.steps, args.warmup, timed=True)
@@ -202,7 +209,8 @@ def main():
                          "step_algorithmic_bytes": round(step_bytes),
                          "step_frac": round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
             "launch": ("hipGraph replay (1 graph/step; every %dth step eager for the HIP-event kernel timing)" % args.event_every)
-                      if use_graph else "eager (7 kernel launches/step)",
+                      if use_graph else ("eager, 4 launches/step on the main stream + the next batch's index (2 launches) "
+                                         "on a second stream" if (args.prefetch and not sharded) else "eager"),
             "final_loss": round(loss, 6),
         }
         if nrec and args.profile_level >= 2:

@@ -109,6 +109,12 @@ typedef struct {
   float clip;
   int32_t norm_mode;  /* TLSAN_NORM_*: how clip_by_global_norm's norm treats repeated ids */
   int32_t l2_mode;    /* TLSAN_L2_*                                                       */
+  /* The destination index of a batch (use counts, segment offsets, used-row records) depends only on
+   * the batch's ids.  The state holds two index slots: index_slot picks the one this
+   * step uses; index_prebuilt != 0 says tlsan_batch_index already built it (e.g. on a second stream
+   * while the previous step ran), otherwise the step builds it itself.  Defaults 0, 0. */
+  int32_t index_slot;
+  int32_t index_prebuilt;
 } tlsan_hparams;
 
 /* Device-side results of a train step (all optional except loss). */
@@ -164,6 +170,12 @@ int tlsan_forward(const tlsan_dims* dims, const tlsan_params* p, const tlsan_bat
 int tlsan_train_step(const tlsan_dims* dims, const tlsan_params* p, const tlsan_batch* b,
                      const tlsan_hparams* hp, const tlsan_step_out* out,
                      void* state, void* ws, size_t ws_bytes, void* stream);
+
+/* Build the destination index of batch `b` into index slot `slot` (0 or 1) of the state: the two
+ * launches a step otherwise starts with.  Independent of the parameters, so an input pipeline can
+ * run it for the NEXT batch on another stream while the current step computes; the caller orders
+ * it after the last step that used the same slot and before the step that consumes it. */
+int tlsan_batch_index(const tlsan_dims* dims, const tlsan_batch* b, void* state, int32_t slot, void* stream);
 
 /* Gradients only (no update) -- what `tf.gradients(self.loss, trainables)` (model.py:198)
  * returns, with duplicate ids summed and reg*W added for the four regularised tables.
@@ -264,6 +276,8 @@ int tlsan_scan_compact(const int32_t* cnt, int32_t n, int32_t* prefix, int32_t* 
  * (level 1 fills only [1]); returns the number of steps written and clears the ring. */
 #define TLSAN_PROF_SEGMENTS 5
 int tlsan_profile_enable(int level);
+/* record only every `every`-th step (default 1): timing events perturb a latency-bound pipeline */
+int tlsan_profile_stride(int every);
 int tlsan_profile_collect(float* host_ms, int max_steps);
 
 /* Diagnostic: device buffer of s_memtime stamps (NULL = off, the default): entries

@@ -16,7 +16,7 @@ EXPORTS = [
     "tlsan_abi_version", "tlsan_last_error", "tlsan_dense_layout_of", "tlsan_workspace_bytes",
     "tlsan_state_bytes", "tlsan_state_init", "tlsan_state_reindex", "tlsan_state_scale",
     "tlsan_state_renorm", "tlsan_sync_derived", "tlsan_forward",
-    "tlsan_train_step", "tlsan_grads", "tlsan_eval_ranks", "tlsan_profile_enable",
+    "tlsan_train_step", "tlsan_batch_index", "tlsan_grads", "tlsan_eval_ranks", "tlsan_profile_enable", "tlsan_profile_stride",
     "tlsan_profile_collect", "tlsan_debug_stamps", "tlsan_rows_apply_workspace", "tlsan_rows_apply", "tlsan_scan_compact",
     "tlsan_route_plan", "tlsan_shard_gather", "tlsan_shard_summary", "tlsan_shard_apply_workspace", "tlsan_shard_apply",
 ]
@@ -47,7 +47,7 @@ class Batch(C.Structure):
 
 class HParams(C.Structure):
     _fields_ = [("lr", C.c_float), ("reg", C.c_float), ("clip", C.c_float),
-                ("norm_mode", C.c_int32), ("l2_mode", C.c_int32)]
+                ("norm_mode", C.c_int32), ("l2_mode", C.c_int32), ("index_slot", C.c_int32), ("index_prebuilt", C.c_int32)]
 
 
 class StepOut(C.Structure):
@@ -96,12 +96,16 @@ def load():
                                   C.c_void_p, C.c_size_t, C.c_void_p]
     lib.tlsan_train_step.argtypes = [P(Dims), P(Params), P(Batch), P(HParams), P(StepOut),
                                      C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.tlsan_batch_index.argtypes = [P(Dims), P(Batch), C.c_void_p, C.c_int32, C.c_void_p]
+    lib.tlsan_batch_index.restype = C.c_int
     lib.tlsan_grads.argtypes = [P(Dims), P(Params), P(Batch), P(HParams), P(GradsOut), P(StepOut),
                                 C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.tlsan_eval_ranks.argtypes = [P(Dims), P(Params), C.c_void_p, C.c_void_p, C.c_int32,
                                      C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.tlsan_profile_enable.argtypes = [C.c_int]
     lib.tlsan_profile_enable.restype = C.c_int
+    lib.tlsan_profile_stride.argtypes = [C.c_int]
+    lib.tlsan_profile_stride.restype = C.c_int
     lib.tlsan_profile_collect.argtypes = [C.c_void_p, C.c_int]
     lib.tlsan_profile_collect.restype = C.c_int
     lib.tlsan_rows_apply_workspace.argtypes = [C.c_int32, C.c_int32]

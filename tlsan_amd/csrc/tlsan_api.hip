@@ -36,11 +36,19 @@ static unsigned long long* g_stamps = nullptr;
 #define TLSAN_APPLY_STAMP_OFF (1 << 20)  // k_apply's stamps start this many entries into the debug buffer
 static int g_prof_level = 0;
 static int g_prof_n = 0;
+static int g_prof_stride = 1;  // record every g_prof_stride-th step (tlsan_profile_stride)
+static int g_prof_tick = 0;    // steps seen since the ring was enabled
 static hipEvent_t* g_prof_ev = nullptr;  // [PROF_MAX_STEPS][PROF_MARKS], created on first enable
 static void prof_mark(int mark, hipStream_t hs) {
-  if (g_prof_level == 0 || g_prof_n >= PROF_MAX_STEPS) return;
+  if (g_prof_level == 0 || g_prof_n >= PROF_MAX_STEPS || (g_prof_tick % g_prof_stride) != 0) return;
   if (g_prof_level == 1 && mark != 1 && mark != 2) return;
   (void)hipEventRecord(g_prof_ev[g_prof_n * PROF_MARKS + mark], hs);
+}
+
+static void prof_step_done() {
+  if (g_prof_level == 0) return;
+  if ((g_prof_tick % g_prof_stride) == 0 && g_prof_n < PROF_MAX_STEPS) ++g_prof_n;
+  ++g_prof_tick;
 }
 
 static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -69,8 +77,6 @@ static int shape_of(const tlsan_dims* d, Shape* s) {
 
 struct Ws {  // carve-up of the caller's scratch buffer
   float *Gi, *Gb, *Gu, *Gc, *gLong, *gDB, *partials, *Kp, *gd, *sqd, *scal, *logits, *s_label;
-  int32_t *off_item, *off_uc, *off_user, *cur_item, *cur_uc, *cur_user;
-  int4 *urec_item, *urec_user;
   double* rownorm_part;
   double* rownorm;
   size_t bytes;
@@ -105,14 +111,6 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
   w->scal = (float*)take(sizeof(float) * 4);
   w->logits = (float*)take(sizeof(float) * B);
   w->s_label = (float*)take(sizeof(float) * B);
-  w->off_item = (int32_t*)take(4 * ((size_t)d->item_count + 1));
-  w->off_uc = (int32_t*)take(4 * ((size_t)d->cate_count + 1));
-  w->off_user = (int32_t*)take(4 * ((size_t)d->user_count + 1));
-  w->cur_item = (int32_t*)take(4 * (size_t)d->item_count);
-  w->cur_uc = (int32_t*)take(4 * (size_t)d->cate_count);
-  w->cur_user = (int32_t*)take(4 * (size_t)d->user_count);
-  w->urec_item = (int4*)take(16 * ((size_t)d->item_count + AP_ROWS_PB));
-  w->urec_user = (int4*)take(16 * ((size_t)d->user_count + AP_ROWS_PB));
   const size_t nrowblk = (size_t)(d->item_count + 15) / 16 + (d->user_count + 15) / 16 + d->cate_count;
   w->rownorm_part = (double*)take(8 * nrowblk);
   w->rownorm = (double*)take(8);
@@ -120,7 +118,12 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
 }
 
 struct St {  // persistent state
-  int32_t *cnt_item, *cnt_uc, *cnt_user;                  // use counters, zero at rest
+  // two index slots (a batch's destination index depends only on its ids, so it lives with the
+  // state, not in the per-call workspace whose layout follows the batch shape):
+  int32_t *cnt_item[2], *cnt_uc[2], *cnt_user[2];         // use counters, zero at rest
+  int32_t *off_item[2], *off_uc[2], *off_user[2];         // segment offsets (n+1 entries)
+  int32_t *cur_item[2], *cur_uc[2], *cur_user[2];         // fill cursors
+  int4 *urec_item[2], *urec_user[2];                      // (row, first position, uses) of the used rows
   int32_t *cate_off, *cate_cnt, *cate_cur, *cate_items;   // static CSR category -> items
   StateHdr* hdr;
   double *S_part, *S_total;
@@ -135,9 +138,19 @@ static void carve_state(const tlsan_dims* d, char* base, St* s) {
   s->nbU = (d->user_count + AP_ROWS_PB - 1) / AP_ROWS_PB;
   s->nbC = d->cate_count;
   s->hdr = (StateHdr*)take(sizeof(StateHdr));  // must stay first: tlsan_state_scale(state) == state
-  s->cnt_item = (int32_t*)take(4 * (size_t)d->item_count);
-  s->cnt_uc = (int32_t*)take(4 * (size_t)d->cate_count);
-  s->cnt_user = (int32_t*)take(4 * (size_t)d->user_count);
+  for (int k = 0; k < 2; ++k) {
+    s->cnt_item[k] = (int32_t*)take(4 * (size_t)d->item_count);
+    s->cnt_uc[k] = (int32_t*)take(4 * (size_t)d->cate_count);
+    s->cnt_user[k] = (int32_t*)take(4 * (size_t)d->user_count);
+    s->off_item[k] = (int32_t*)take(4 * ((size_t)d->item_count + 1));
+    s->off_uc[k] = (int32_t*)take(4 * ((size_t)d->cate_count + 1));
+    s->off_user[k] = (int32_t*)take(4 * ((size_t)d->user_count + 1));
+    s->cur_item[k] = (int32_t*)take(4 * (size_t)d->item_count);
+    s->cur_uc[k] = (int32_t*)take(4 * (size_t)d->cate_count);
+    s->cur_user[k] = (int32_t*)take(4 * (size_t)d->user_count);
+    s->urec_item[k] = (int4*)take(16 * ((size_t)d->item_count + AP_ROWS_PB));
+    s->urec_user[k] = (int4*)take(16 * ((size_t)d->user_count + AP_ROWS_PB));
+  }
   s->cate_off = (int32_t*)take(4 * (size_t)d->cate_count);
   s->cate_cnt = (int32_t*)take(4 * (size_t)d->cate_count);
   s->cate_cur = (int32_t*)take(4 * (size_t)d->cate_count);
@@ -216,18 +229,20 @@ static int check_batch(const tlsan_dims* d, const tlsan_batch* b, bool train) {
 
 static void fill_apply(ApplyArgs& A, const tlsan_dims* d, const Shape& s, const tlsan_params* p, const tlsan_batch* b,
                        const tlsan_hparams* hp, const Ws& w, const St& st, const tlsan_dense_layout& L) {
+  const int k = hp ? hp->index_slot : 0;
   memset(&A, 0, sizeof(A));
   A.p = norm_params(p, d);
   A.lay = L;
   A.I = d->item_count; A.U = d->user_count; A.C = d->cate_count; A.Ls = d->Ls; A.D = s.D;
   A.di = d->d_item; A.dc = d->d_cate; A.WU = ru4(d->d_item + d->Ls);
   A.Gi = w.Gi; A.Gb = w.Gb; A.Gu = w.Gu; A.Gc = w.Gc;
-  A.cnt_item = st.cnt_item; A.cnt_uc = st.cnt_uc; A.cnt_user = st.cnt_user;
-  A.off_item = w.off_item; A.off_uc = w.off_uc; A.off_user = w.off_user;
+  A.cnt_item = st.cnt_item[k]; A.cnt_uc = st.cnt_uc[k]; A.cnt_user = st.cnt_user[k];
+  A.off_item = st.off_item[k]; A.off_uc = st.off_uc[k]; A.off_user = st.off_user[k];
+  A.n_uniq_item = st.hdr ? &st.hdr->n_uniq[k][0] : nullptr; A.n_uniq_user = st.hdr ? &st.hdr->n_uniq[k][1] : nullptr;
   A.cate_off = st.cate_off; A.cate_cnt = st.cate_cnt; A.cate_items = st.cate_items;
   A.gd = w.gd;
   A.part_out = st.S_part; A.hdr = st.hdr;
-  A.urec_item = w.urec_item; A.urec_user = w.urec_user;
+  A.urec_item = st.urec_item[k]; A.urec_user = st.urec_user[k];
   if (hp) { A.lr = hp->lr; A.reg = hp->reg; }
   A.nbI = st.nbI; A.nbU = st.nbU; A.nbC = st.nbC; A.nbD = (L.n_dense + 255) / 256;
   A.stamps = g_stamps ? g_stamps + TLSAN_APPLY_STAMP_OFF : nullptr;
@@ -403,44 +418,51 @@ int tlsan_forward(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch*
   return launch_fwd(s, false, a, (hipStream_t)stream);
 }
 
-// shared front half of train_step / grads: index build, fused fwd+bwd, dense-grad reduction
-static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params* p, const tlsan_batch* b,
-                        const tlsan_hparams* hp, bool commit, const tlsan_step_out* out, const Ws& w, const St& st,
-                        const tlsan_dense_layout& L, hipStream_t hs) {
-  // --- use counts per destination row -> first sorted position of every row
+// destination index of a batch into slot k: use counts per destination row -> first sorted position
+// of every row (+ records of the used rows)
+static int build_index(const tlsan_dims* d, const tlsan_batch* b, const St& st, int k, hipStream_t hs) {
   CountArgs ca;
   memset(&ca, 0, sizeof(ca));
   ca.b = *b; ca.Ls = d->Ls;
-  ca.cnt_item = st.cnt_item; ca.cnt_user = st.cnt_user; ca.cnt_uc = st.cnt_uc;
+  ca.cnt_item = st.cnt_item[k]; ca.cnt_user = st.cnt_user[k]; ca.cnt_uc = st.cnt_uc[k];
   const int nthr = b->B * (d->Ls + b->Sn + 2);
-  prof_mark(0, hs);
   hipLaunchKernelGGL(k_count, dim3((nthr + 255) / 256), dim3(256), 0, hs, ca);
   CHECK_LAUNCH("k_count");
   ScanArgs sa;
   memset(&sa, 0, sizeof(sa));
-  sa.cnt[0] = st.cnt_item; sa.cnt[1] = st.cnt_uc; sa.cnt[2] = st.cnt_user;
-  sa.off[0] = w.off_item; sa.off[1] = w.off_uc; sa.off[2] = w.off_user;
-  sa.cur[0] = w.cur_item; sa.cur[1] = w.cur_uc; sa.cur[2] = w.cur_user;
+  sa.cnt[0] = st.cnt_item[k]; sa.cnt[1] = st.cnt_uc[k]; sa.cnt[2] = st.cnt_user[k];
+  sa.off[0] = st.off_item[k]; sa.off[1] = st.off_uc[k]; sa.off[2] = st.off_user[k];
+  sa.cur[0] = st.cur_item[k]; sa.cur[1] = st.cur_uc[k]; sa.cur[2] = st.cur_user[k];
   sa.n[0] = d->item_count; sa.n[1] = d->cate_count; sa.n[2] = d->user_count;
   sa.blk0[0] = 0;
   sa.blk0[1] = (sa.n[0] + 4095) / 4096;
   sa.blk0[2] = sa.blk0[1] + (sa.n[1] + 4095) / 4096;
   const int nscan = sa.blk0[2] + (sa.n[2] + 4095) / 4096;
-  sa.urec[0] = w.urec_item; sa.urec[2] = w.urec_user;
+  sa.urec[0] = st.urec_item[k]; sa.urec[2] = st.urec_user[k];
   sa.total[0] = sa.total[1] = sa.total[2] = 1;
-  sa.n_uniq[0] = &st.hdr->n_uniq_item; sa.n_uniq[1] = nullptr; sa.n_uniq[2] = &st.hdr->n_uniq_user;
+  sa.n_uniq[0] = &st.hdr->n_uniq[k][0]; sa.n_uniq[1] = nullptr; sa.n_uniq[2] = &st.hdr->n_uniq[k][1];
   hipLaunchKernelGGL(k_index_scan, dim3(nscan), dim3(1024), 0, hs, sa);
   CHECK_LAUNCH("k_index_scan");
+  return TLSAN_OK;
+}
+
+// shared front half of train_step / grads: index build, fused fwd+bwd, dense-grad reduction
+static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params* p, const tlsan_batch* b,
+                        const tlsan_hparams* hp, bool commit, const tlsan_step_out* out, const Ws& w, const St& st,
+                        const tlsan_dense_layout& L, hipStream_t hs) {
+  const int k = hp->index_slot;
+  int rc;
+  prof_mark(0, hs);
+  if (!hp->index_prebuilt && (rc = build_index(d, b, st, k, hs))) return rc;
   // --- fused forward + backward
   FwdArgs a;
   fill_fwd(a, d, s, p, b, w, L);
   a.logits_i = (out && out->logits) ? out->logits : w.logits;
   a.Gi = w.Gi; a.Gb = w.Gb; a.Gu = w.Gu; a.Gc = w.Gc; a.WU = w.WU;
-  a.cur_item = w.cur_item; a.cur_user = w.cur_user; a.cur_uc = w.cur_uc;
+  a.cur_item = st.cur_item[k]; a.cur_user = st.cur_user[k]; a.cur_uc = st.cur_uc[k];
   a.gLong = w.gLong; a.gDB = w.gDB; a.partials = w.partials;
   prof_mark(1, hs);
-  int rc = launch_fwd(s, true, a, hs);
-  if (rc) return rc;
+  if ((rc = launch_fwd(s, true, a, hs))) return rc;
   prof_mark(2, hs);
   // --- dense-parameter gradients
   {
@@ -484,6 +506,7 @@ static int prep_step(const tlsan_dims* d, Shape* s, const tlsan_params* p, const
   if ((rc = check_batch(d, b, true))) return rc;
   if (!hp) return fail(TLSAN_E_BADARG, "hparams is NULL");
   if (hp->l2_mode != TLSAN_L2_DENSE && hp->l2_mode != TLSAN_L2_LAZY) return fail(TLSAN_E_BADARG, "l2_mode");
+  if (hp->index_slot < 0 || hp->index_slot > 1) return fail(TLSAN_E_BADARG, "index_slot must be 0 or 1");
   if (hp->l2_mode == TLSAN_L2_LAZY) {
     if (hp->norm_mode != TLSAN_NORM_TF18) return fail(TLSAN_E_UNSUPPORTED, "TLSAN_L2_LAZY supports norm_mode TF18 only");
     if (p->scale != tlsan_state_scale(state)) return fail(TLSAN_E_BADARG, "TLSAN_L2_LAZY needs params->scale == tlsan_state_scale(state)");
@@ -509,6 +532,17 @@ static int clip_dedup(const ApplyArgs& A, const tlsan_hparams* hp, const tlsan_s
   return TLSAN_OK;
 }
 
+int tlsan_batch_index(const tlsan_dims* d, const tlsan_batch* b, void* state, int32_t slot, void* stream) {
+  Shape s; St st;
+  int rc = shape_of(d, &s);
+  if (rc) return rc;
+  if ((rc = check_batch(d, b, true))) return rc;
+  if (slot < 0 || slot > 1) return fail(TLSAN_E_BADARG, "index slot must be 0 or 1");
+  if (!state) return fail(TLSAN_E_WORKSPACE, "state is NULL");
+  carve_state(d, (char*)state, &st);
+  return build_index(d, b, st, slot, (hipStream_t)stream);
+}
+
 int tlsan_train_step(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch* b, const tlsan_hparams* hp,
                      const tlsan_step_out* out, void* state, void* ws, size_t ws_bytes, void* stream) {
   Shape s; Ws w; St st;
@@ -523,7 +557,7 @@ int tlsan_train_step(const tlsan_dims* d, const tlsan_params* p, const tlsan_bat
   if (hp->norm_mode == TLSAN_NORM_DEDUP && (rc = clip_dedup(A, hp, out, w, st, b, hs))) return rc;
   if ((rc = launch_apply(AP_UPDATE, hp->l2_mode == TLSAN_L2_LAZY, A, true, b->B, b->Sn, hs))) return rc;
   prof_mark(5, hs);
-  if (g_prof_level > 0 && g_prof_n < PROF_MAX_STEPS) ++g_prof_n;
+  prof_step_done();
   return TLSAN_OK;
 }
 
@@ -549,7 +583,7 @@ int tlsan_grads(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch* b
   if (hp->norm_mode == TLSAN_NORM_DEDUP && (rc = clip_dedup(A, hp, out, w, st, b, hs))) return rc;
   if ((rc = launch_apply(AP_GRADS, false, A, true, b->B, b->Sn, hs))) return rc;
   prof_mark(5, hs);
-  if (g_prof_level > 0 && g_prof_n < PROF_MAX_STEPS) ++g_prof_n;
+  prof_step_done();
   return TLSAN_OK;
 }
 
@@ -757,6 +791,12 @@ int tlsan_debug_stamps(void* device_buf) {
   return TLSAN_OK;
 }
 
+int tlsan_profile_stride(int every) {
+  if (every < 1) return fail(TLSAN_E_BADARG, "profile stride must be >= 1");
+  g_prof_stride = every;
+  return TLSAN_OK;
+}
+
 int tlsan_profile_enable(int level) {
   if (level < 0 || level > 2) return fail(TLSAN_E_BADARG, "profile level must be 0..2");
   if (level > 0 && !g_prof_ev) {
@@ -767,6 +807,7 @@ int tlsan_profile_enable(int level) {
   }
   g_prof_level = level;
   g_prof_n = 0;
+  g_prof_tick = 0;
   return TLSAN_OK;
 }
 

@@ -16,11 +16,10 @@ struct StateHdr {
   // ---- read-mostly line
   float P;                 // scale of the four regularised tables: W_true = P * W_stored (1 unless lazy L2)
   float P_prev;            // P before the current step's commit: what k_apply scales with
-  int32_t n_uniq_item;     // rows that received a gradient in the current step (k_index_scan)
-  int32_t n_uniq_user;
+  int32_t n_uniq[2][2];    // [index slot][item, user]: rows that received a gradient (k_index_scan)
   double St;               // sum of squares of the four STORED tables (true value: P^2 * St)
   float coef;              // global-norm clip coefficient of the current step (model.py:201)
-  float pad0[25];
+  float pad0[23];
   // ---- its own 128-B line: hammered by atomics, must not share a line with anything that is read
   int32_t ticket;          // arrival counter of k_dense_finalize: the last workgroup writes the step summary
   int32_t pad1[31];
@@ -470,7 +469,8 @@ struct ApplyArgs {
   const float* gd;
   double* part_out;        // UPDATE: change of the stored tables' sum of squares per workgroup;
                            // SUMSQ: sum of squares; ROWNORM: sum g^2
-  const StateHdr* hdr;     // P, P_prev, coef, n_uniq_*
+  const StateHdr* hdr;     // P, P_prev, coef
+  const int32_t* n_uniq_item; const int32_t* n_uniq_user;   // used-row counts of this step's index slot
   float lr, reg;
   int32_t nbI, nbU, nbC, nbD;
   unsigned long long* stamps;  // debug: 8 s_memtime stamps per workgroup (tlsan_debug_stamps)
@@ -731,7 +731,7 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
   bool vr;
   double part = 0.0;
   if constexpr (LAZY) {
-    const int nuq = IS_ITEM ? a.hdr->n_uniq_item : a.hdr->n_uniq_user;
+    const int nuq = IS_ITEM ? *a.n_uniq_item : *a.n_uniq_user;
     if (slot0 >= nuq) return;  // (workgroup-uniform) nothing left: lazy rows past the used ones leave no partial
     const int4 r = (IS_ITEM ? a.urec_item : a.urec_user)[slot];  // (row, first position, uses)
     vr = slot < nuq;

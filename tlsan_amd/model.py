@@ -143,6 +143,12 @@ class Model(object):
             self.cparams.scale = self.lib.tlsan_state_scale(self.state.data_ptr())
         self._ws = None
         self._ws_key = (0, 0)
+        # two destination-index slots: the current step's and the one being built for the next batch
+        self._idx_slot = 0
+        self._idx_ready = [None, None]
+        self._idx_event = [torch.cuda.Event(), torch.cuda.Event()]
+        self._step_event = [None, None]
+        self._side = None
         self._step = 0
         self._epoch = 0
         self.global_step = _Var(lambda: self._step)
@@ -275,23 +281,59 @@ class Model(object):
         self._epoch += 1
         return self._epoch
 
-    def hparams(self, lr):
+    def hparams(self, lr, index_slot=0, index_prebuilt=0):
         return L.HParams(float(lr), float(self.config["regulation_rate"]), float(self.config["max_gradient_norm"]),
-                         self.norm_mode, self.l2_mode)
+                         self.norm_mode, self.l2_mode, index_slot, index_prebuilt)
 
     # ------------------------------------------------------------------ training
     def device_batch(self, batch, is_test=False):
         return batch if isinstance(batch, DeviceBatch) else DeviceBatch(batch, self.device, is_test, self.config["Ls"])
 
-    def train_async(self, batch, lr, logits=None):
-        """Enqueue one step (model.py:208-234) without reading the loss back."""
+    def train_async(self, batch, lr, logits=None, next_batch=None):
+        """Enqueue one step (model.py:208-234) without reading the loss back.
+
+        next_batch (optional, what an input pipeline knows anyway): its destination index (use
+        counts, segment offsets -- a function of the ids only) is built on a second stream while
+        this step computes, so the next step starts directly with the fused kernel.  The two
+        streams are ordered by HOST waits on events that are complete by the time they are
+        needed (device-side event waits between queues cost more than the work they would hide)."""
         db = self.device_batch(batch)
         ws = self._workspace(db.B, db.Sn)
         out = L.StepOut(self._out.data_ptr(), self._out.data_ptr() + 4, None if logits is None else logits.data_ptr(), None)
-        hp = self.hparams(lr)
+        if torch.cuda.is_current_stream_capturing():   # hipGraph capture: one self-contained step
+            hp = self.hparams(lr)
+            L.check(self.lib.tlsan_train_step(C.byref(self.dims), C.byref(self.cparams), C.byref(db.c), C.byref(hp),
+                                              C.byref(out), self.state.data_ptr(), ws.data_ptr(), ws.numel(),
+                                              self._stream()), "tlsan_train_step")
+            self._step += 1
+            return db
+        k = self._idx_slot
+        if self._idx_ready[k] is not None and self._idx_ready[k] is not db:
+            raise RuntimeError("train_async: the batch announced as next_batch must be the next one trained "
+                               "(its destination index is already counted into the state)")
+        pre = self._idx_ready[k] is db
+        if pre:
+            self._idx_event[k].synchronize()       # the side stream finished this batch's index
+        self._idx_ready[k] = None
+        hp = self.hparams(lr, k, 1 if pre else 0)
         L.check(self.lib.tlsan_train_step(C.byref(self.dims), C.byref(self.cparams), C.byref(db.c), C.byref(hp),
                                           C.byref(out), self.state.data_ptr(), ws.data_ptr(), ws.numel(),
                                           self._stream()), "tlsan_train_step")
+        main = torch.cuda.current_stream(self.device)
+        if next_batch is not None:
+            ndb = self.device_batch(next_batch)
+            if self._side is None:
+                self._side = torch.cuda.Stream(self.device)
+            if self._step_event[1 - k] is not None:
+                self._step_event[1 - k].synchronize()   # the last step that used slot 1-k has finished with it
+            L.check(self.lib.tlsan_batch_index(C.byref(self.dims), C.byref(ndb.c), self.state.data_ptr(), 1 - k,
+                                               C.c_void_p(self._side.cuda_stream)), "tlsan_batch_index")
+            self._idx_event[1 - k].record(self._side)
+            self._idx_ready[1 - k] = ndb
+        if self._step_event[k] is None:
+            self._step_event[k] = torch.cuda.Event()
+        self._step_event[k].record(main)
+        self._idx_slot = 1 - k
         self._step += 1
         return db
 
