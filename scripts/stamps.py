@@ -14,21 +14,28 @@ db = m.device_batch(synth.make_batches(cfg, 1, B, seed=7)[0])
 for _ in range(5):
     m.train_async(db, 1.0)
 nblk = (B + 15) // 16
+NWV = 8 if os.environ.get('TLSAN_FWD_V2') == '0' else 16   # wavefronts per workgroup of the kernel that runs
 st = torch.zeros((1 << 20) + 8 * 8192, dtype=torch.int64, device="cuda")   # k_apply stamps live from entry 2^20 on
 lib.tlsan_debug_stamps(st.data_ptr())
 m.train_async(db, 1.0)
 torch.cuda.synchronize()
 lib.tlsan_debug_stamps(None)
-s = st.cpu().numpy()[:nblk * 8 * 16].reshape(nblk, 8, 16)[:, :, :12].astype(np.float64)
+s = st.cpu().numpy()[:nblk * NWV * 16].reshape(nblk, NWV, 16)[:, :, :12].astype(np.float64)
 d = np.diff(s, axis=2)
 names = ["P1 gather+fwa1", "bar1", "P2 bridge", "bar2", "P3 fwd+logit", "P3 bwd", "bar3", "P4+reduce", "bar4", "P5 bwd long", "bar5+reduce"]
 tot = s[:, :, 11] - s[:, :, 0]
 print("ticks/wave (s_memtime, 100 MHz on gfx950?): mean %.0f max %.0f" % (tot.mean(), tot.max()))
 for i, n in enumerate(names):
     print("%-16s mean %8.0f  p50 %8.0f  max %8.0f  (%.1f%%)" % (n, d[:, :, i].mean(), np.median(d[:, :, i]), d[:, :, i].max(), 100 * d[:, :, i].mean() / tot.mean()))
-f = st.cpu().numpy()[:nblk * 8 * 16].reshape(nblk, 8, 16)[:, :, 12:16].astype(np.float64)
+f = st.cpu().numpy()[:nblk * NWV * 16].reshape(nblk, NWV, 16)[:, :, 12:16].astype(np.float64)
 fd = np.diff(f, axis=2)
 ok = (f[:, :, 0] > 0)
+if NWV == 16:   # k_fwd_bwd2: slots 12..14 split P1 (after the gathers, after the maps, after the softmax combine)
+    g = st.cpu().numpy()[:nblk * NWV * 16].reshape(nblk, NWV, 16).astype(np.float64)
+    for nm, lo, hi in (("P1: loads -> rows in registers", 0, 12), ("P1: maps of the lane's positions", 12, 13), ("P1: softmax combine + sum", 13, 14), ("P1: publish, LDS writes", 14, 1)):
+        dd = g[:, :, hi] - g[:, :, lo]
+        print("%-34s mean %8.0f p50 %8.0f max %8.0f" % (nm, dd.mean(), np.median(dd), dd.max()))
+    sys.exit(0)
 for i, n in enumerate(["P5 pos1: maps+exp", "P5 pos1: bwd_compute", "P5 pos1: bwd_dw"]):
     print("%-24s mean %8.0f p50 %8.0f max %8.0f" % (n, fd[:, :, i][ok].mean(), np.median(fd[:, :, i][ok]), fd[:, :, i][ok].max()))
 span = s[:, :, 11].max() - s[:, :, 0].min()

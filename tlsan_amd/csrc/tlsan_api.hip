@@ -14,6 +14,7 @@
 hipError_t tlsan_launch_fwd_bwd_d64(bool train, bool lstream, const FwdArgs& a, int grid, hipStream_t st);
 hipError_t tlsan_launch_fwd_bwd_d128(bool train, bool lstream, const FwdArgs& a, int grid, hipStream_t st);
 hipError_t tlsan_launch_fwd_bwd_d256(bool train, bool lstream, const FwdArgs& a, int grid, hipStream_t st);
+hipError_t tlsan_launch_fwd_bwd2(int D, const FwdArgs& a, int grid, hipStream_t st);  // one sample per wavefront (training, d <= 128, Ls <= 10)
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, ...) {
@@ -92,7 +93,7 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
   tlsan_dense_layout L;
   tlsan_dense_layout_of(d, &L);
   w->WU = ru4(d->d_item + d->Ls);
-  w->ngroups = (B + s.NSB - 1) / s.NSB;
+  w->ngroups = (B + 15) / 16;  // partial records: one per workgroup pass (16 samples with k_fwd_bwd2, NSB otherwise)
   w->nsplit = dk_nsplit(B);
   w->nbK = (s.D * s.D + 255) / 256;
   w->nbS = (L.n_dense - s.D * s.D + 15) / 16;
@@ -373,13 +374,29 @@ int tlsan_state_reindex(const tlsan_dims* d, const tlsan_params* p, void* state,
   return build_cate_csr(d, p, st, hs);
 }
 
-static int launch_fwd(const Shape& s, bool train, const FwdArgs& a, hipStream_t hs) {
+// which fused kernel runs: k_fwd_bwd (default), or with TLSAN_FWD_V2=1 the experimental k_fwd_bwd2
+// (one sample per wavefront, 16 wavefronts per workgroup; training at d <= 128 with the long window
+// in registers and every table / gradient buffer below 4 GiB).  Measured slower at the bench shape
+// (57 vs 46 us), kept selectable and tested because it documents that the kernel is
+// bound by the fp32 matrix pipe and the per-sample length imbalance, not by occupancy.
+static bool fwd_v2(const Shape& s, bool train, const tlsan_dims* d, const tlsan_params& q, const tlsan_batch* b) {
+  static const int on = [] { const char* v = getenv("TLSAN_FWD_V2"); return v ? atoi(v) : 0; }();
+  if (!on || !train || d->Ls > TLSAN_LS_MAX || s.D > 128) return false;
+  const size_t lim = (size_t)1 << 32;  // it addresses with 32-bit byte offsets from the table bases
+  const size_t uses = (size_t)b->B * (d->Ls + b->Sn + 1);
+  return (size_t)d->item_count * q.ld_item * 4 < lim && (size_t)d->user_count * q.ld_user * 4 < lim &&
+         (size_t)d->user_count * q.ld_usert * 4 < lim && (size_t)d->item_count * q.ld_itemb * 4 < lim &&
+         (uses + 1) * s.D * 4 < lim && (size_t)b->B * (s.D + 4 * ((d->d_item + d->Ls + 3) / 4)) * 4 < lim;
+}
+
+static int launch_fwd(const Shape& s, bool train, bool v2, const FwdArgs& a, hipStream_t hs) {
   int grid = a.ngroups < 4096 ? a.ngroups : 4096;
   hipError_t e;
   const bool lstream = a.Ls > TLSAN_LS_MAX;  // long windows are streamed, short ones stay in registers
   if (train && lstream && s.D == 256)
     return fail(TLSAN_E_UNSUPPORTED, "training with hidden_units=256 and Ls > %d needs more LDS than one CU has in this build", TLSAN_LS_MAX);
-  if (s.D == 64) e = tlsan_launch_fwd_bwd_d64(train, lstream, a, grid, hs);
+  if (v2) e = tlsan_launch_fwd_bwd2(s.D, a, grid, hs);
+  else if (s.D == 64) e = tlsan_launch_fwd_bwd_d64(train, lstream, a, grid, hs);
   else if (s.D == 128) e = tlsan_launch_fwd_bwd_d128(train, lstream, a, grid, hs);
   else e = tlsan_launch_fwd_bwd_d256(train, lstream, a, grid, hs);
   if (e != hipSuccess) return fail(TLSAN_E_LAUNCH, "k_fwd_bwd: %s", hipGetErrorString(e));
@@ -393,7 +410,7 @@ static void fill_fwd(FwdArgs& a, const tlsan_dims* d, const Shape& s, const tlsa
   a.b = *b;
   a.lay = L;
   a.Ls = d->Ls; a.di = d->d_item; a.dc = d->d_cate;
-  a.ngroups = (b->B + s.NSB - 1) / s.NSB;
+  a.ngroups = (b->B + s.NSB - 1) / s.NSB;  // (training: overridden by run_backward)
   a.inv_B = 1.0f / (float)b->B;
   a.stamps = g_stamps;
 }
@@ -415,7 +432,7 @@ int tlsan_forward(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch*
   a.logits_i = logits_i;
   a.logits_j = logits_j;
   a.u_t = u_t;
-  return launch_fwd(s, false, a, (hipStream_t)stream);
+  return launch_fwd(s, false, false, a, (hipStream_t)stream);
 }
 
 // destination index of a batch into slot k: use counts per destination row -> first sorted position
@@ -461,8 +478,11 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   a.Gi = w.Gi; a.Gb = w.Gb; a.Gu = w.Gu; a.Gc = w.Gc; a.WU = w.WU;
   a.cur_item = st.cur_item[k]; a.cur_user = st.cur_user[k]; a.cur_uc = st.cur_uc[k];
   a.gLong = w.gLong; a.gDB = w.gDB; a.partials = w.partials;
+  const bool v2 = fwd_v2(s, true, d, a.p, b);
+  const int grp = v2 ? 16 : s.NSB;  // samples per workgroup pass of the kernel that runs (= per partial record)
+  a.ngroups = (b->B + grp - 1) / grp;
   prof_mark(1, hs);
-  if ((rc = launch_fwd(s, true, a, hs))) return rc;
+  if ((rc = launch_fwd(s, true, v2, a, hs))) return rc;
   prof_mark(2, hs);
   // --- dense-parameter gradients
   {
@@ -482,7 +502,7 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   prof_mark(3, hs);
   FinArgs f;
   memset(&f, 0, sizeof(f));
-  f.lay = L; f.partials = w.partials; f.nrec = w.ngroups; f.Kp = w.Kp; f.nsplit = w.nsplit;
+  f.lay = L; f.partials = w.partials; f.nrec = (b->B + grp - 1) / grp; f.Kp = w.Kp; f.nsplit = w.nsplit;
   f.gd = w.gd; f.sqd = w.sqd; f.scal = w.scal;
   f.S_part = st.S_part; f.n_spart = st.nbI + st.nbU + st.nbC; f.S_total = st.S_total;
   f.hdr = st.hdr; f.lr = hp->lr; f.reg = hp->reg; f.clip = hp->clip; f.inv_B = 1.0f / (float)b->B;
