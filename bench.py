@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+F32_MFMA_PEAK_TFLOPS = 157.3  # same guide: peak FP32 (matrix), v_mfma_f32_16x16x4_f32, exact f32
 
 
 def parse():
@@ -171,6 +172,7 @@ def main():
         k_bytes = float(np.mean([a["fwd_bwd_kernel"] for a in ab]))
         l2 = "dense" if sharded else args.l2_mode
         step_bytes = float(np.mean([a["train_step"] for a in ab])) + (synth.dense_sweep_bytes(cfg) if l2 == "dense" else 0)
+        k_flops = float(np.mean([synth.algorithmic_flops(cfg, host_batches[(args.warmup + s) % len(host_batches)]) for s in range(args.steps)]))
         k_ms = float(seg[:, 1].mean()) if nrec else float("nan")
         achieved = k_bytes / (k_ms * 1e-3) / 1e9 if nrec else None
         traffic = None
@@ -208,6 +210,13 @@ def main():
                          "algorithmic_bytes_per_launch": round(k_bytes), "kernel_ms": round(k_ms, 5),
                          "step_algorithmic_bytes": round(step_bytes),
                          "step_frac": round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
+            # the designated roofline is HBM (north_star); at d=128 in exact fp32 the same kernel's maps
+            # are also 1.4 GFLOP on the fp32 matrix pipe (SURVEY 8d "compute co-bound"): reported beside it
+            "roofline_mfma": {"bound": "mfma", "kernel": "k_fwd_bwd", "dtype": "f32",
+                              "achieved": None if not nrec else round(k_flops / (k_ms * 1e-3) / 1e12, 2),
+                              "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": None if not nrec else round(k_flops / (k_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                              "algorithmic_flops_per_launch": round(k_flops)},
             "launch": ("hipGraph replay (1 graph/step; every %dth step eager for the HIP-event kernel timing)" % args.event_every)
                       if use_graph else ("eager, 4 launches/step on the main stream + the next batch's index (2 launches) "
                                          "on a second stream" if (args.prefetch and not sharded) else "eager"),

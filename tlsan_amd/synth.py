@@ -91,6 +91,16 @@ def algorithmic_bytes(cfg, batch, elem_bytes=4):
                 fwd_bwd_kernel=int(2 * S_rows + S_idx), train_step=int(3 * S_rows + S_idx))
 
 
+def algorithmic_flops(cfg, batch):
+    """train FLOPs of the fused kernel = 3 * (4*d*dh*P + 2*d^2) per sequence with
+    P = n_l + n_s + 1 positions (two dh x dh maps per head per position + the d x d bridge; x3
+    for forward, dX and dW), valid positions only, no recomputation counted."""
+    u, i, yj, hist_i, hist_i_new, hist_t, sl, sl_new, c = batch
+    d, dh = cfg["hidden_units"], cfg["hidden_units"] // cfg["num_heads"]
+    Pn = np.asarray(sl, np.int64) + np.asarray(sl_new, np.int64) + 1
+    return int((3 * (4 * d * dh * Pn + 2 * d * d)).sum())
+
+
 def dense_sweep_bytes(cfg, elem_bytes=4):
     """The reference's full-table read+write per step in l2_mode=dense."""
     U, I, C = cfg["user_count"], cfg["item_count"], cfg["cate_count"]
