@@ -171,6 +171,29 @@ int tlsan_train_step(const tlsan_dims* dims, const tlsan_params* p, const tlsan_
                      const tlsan_hparams* hp, const tlsan_step_out* out,
                      void* state, void* ws, size_t ws_bytes, void* stream);
 
+/* Device-resident batcher.  A sample set packed as CSR, every pointer a DEVICE
+ * pointer (counterpart of the python lists `dataset.pkl` holds, build_dataset.py:58-59,71):
+ * sample s has history hist[hist_off[s] .. hist_off[s+1]) with weights hist_t (same indexing),
+ * current session sess[sess_off[s] .. sess_off[s+1]), user u[s], category cate[s],
+ * target[s] = the candidate (train) / positive (test) item, second[s] = the 0/1 label (train) /
+ * the negative item (test). */
+typedef struct {
+  int32_t n;
+  const int32_t* u; const int32_t* cate;
+  const int32_t* hist_off; const int32_t* hist; const float* hist_t;
+  const int32_t* sess_off; const int32_t* sess;
+  const int32_t* target; const int32_t* second;
+} tlsan_packed;
+
+/* tlsan_batch_pack -- replaces DataInput.__next__ / DataInputTest.__next__ (TLSAN/input.py:17-54,
+ * 70-107) without touching the host: assemble samples order[lo .. lo + out->B) of `set` into the
+ * caller-allocated device arrays of `out` (u, i, y (train) or j (test), hist_i [B,Ls],
+ * hist_i_new [B,Sn], hist_t [B,Ls], sl, sl_new, u_cate).  out->Sn must be >= the longest session
+ * of the batch (the reference pads to exactly the longest; pass that for identical shapes).
+ * Bit-identical to the reference's arrays on the committed fixtures. */
+int tlsan_batch_pack(const tlsan_packed* set, const int32_t* order, int32_t lo, const tlsan_batch* out,
+                     int32_t Ls, int32_t is_test, void* stream);
+
 /* Build the destination index of batch `b` into index slot `slot` (0 or 1) of the state: the two
  * launches a step otherwise starts with.  Independent of the parameters, so an input pipeline can
  * run it for the NEXT batch on another stream while the current step computes; the caller orders

@@ -16,7 +16,7 @@ EXPORTS = [
     "tlsan_abi_version", "tlsan_last_error", "tlsan_dense_layout_of", "tlsan_workspace_bytes",
     "tlsan_state_bytes", "tlsan_state_init", "tlsan_state_reindex", "tlsan_state_scale",
     "tlsan_state_renorm", "tlsan_sync_derived", "tlsan_forward",
-    "tlsan_train_step", "tlsan_batch_index", "tlsan_grads", "tlsan_eval_ranks", "tlsan_profile_enable", "tlsan_profile_stride",
+    "tlsan_train_step", "tlsan_batch_pack", "tlsan_batch_index", "tlsan_grads", "tlsan_eval_ranks", "tlsan_profile_enable", "tlsan_profile_stride",
     "tlsan_profile_collect", "tlsan_debug_stamps", "tlsan_rows_apply_workspace", "tlsan_rows_apply", "tlsan_scan_compact",
     "tlsan_route_plan", "tlsan_shard_gather", "tlsan_shard_summary", "tlsan_shard_apply_workspace", "tlsan_shard_apply",
 ]
@@ -43,6 +43,11 @@ class DenseLayout(C.Structure):
 class Batch(C.Structure):
     _fields_ = [("B", C.c_int32), ("Sn", C.c_int32)] + [(n, C.c_void_p) for n in
                 ("u", "i", "j", "y", "hist_i", "hist_i_new", "hist_t", "sl", "sl_new", "u_cate")]
+
+
+class Packed(C.Structure):
+    _fields_ = [("n", C.c_int32)] + [(n, C.c_void_p) for n in
+                ("u", "cate", "hist_off", "hist", "hist_t", "sess_off", "sess", "target", "second")]
 
 
 class HParams(C.Structure):
@@ -96,6 +101,8 @@ def load():
                                   C.c_void_p, C.c_size_t, C.c_void_p]
     lib.tlsan_train_step.argtypes = [P(Dims), P(Params), P(Batch), P(HParams), P(StepOut),
                                      C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.tlsan_batch_pack.argtypes = [P(Packed), C.c_void_p, C.c_int32, P(Batch), C.c_int32, C.c_int32, C.c_void_p]
+    lib.tlsan_batch_pack.restype = C.c_int
     lib.tlsan_batch_index.argtypes = [P(Dims), P(Batch), C.c_void_p, C.c_int32, C.c_void_p]
     lib.tlsan_batch_index.restype = C.c_int
     lib.tlsan_grads.argtypes = [P(Dims), P(Params), P(Batch), P(HParams), P(GradsOut), P(StepOut),

@@ -552,6 +552,25 @@ static int clip_dedup(const ApplyArgs& A, const tlsan_hparams* hp, const tlsan_s
   return TLSAN_OK;
 }
 
+int tlsan_batch_pack(const tlsan_packed* set, const int32_t* order, int32_t lo, const tlsan_batch* out, int32_t Ls,
+                     int32_t is_test, void* stream) {
+  if (!set || !order || !out) return fail(TLSAN_E_BADARG, "tlsan_batch_pack: NULL argument");
+  if (!set->u || !set->cate || !set->hist_off || !set->sess_off || !set->target || !set->second)
+    return fail(TLSAN_E_BADARG, "tlsan_batch_pack: NULL pointer in the packed set");
+  if (out->B < 1 || out->Sn < 0 || Ls < 1 || lo < 0 || lo + out->B > set->n)
+    return fail(TLSAN_E_BADARG, "tlsan_batch_pack: samples [%d, %d) outside the set of %d", lo, lo + out->B, set->n);
+  if (!out->u || !out->i || !out->hist_i || !out->hist_t || !out->sl || !out->sl_new || !out->u_cate ||
+      (out->Sn > 0 && !out->hist_i_new) || (is_test ? !out->j : !out->y))
+    return fail(TLSAN_E_BADARG, "tlsan_batch_pack: NULL output array");
+  if ((size_t)out->B * (Ls + out->Sn + 1) >= ((size_t)1 << 31)) return fail(TLSAN_E_UNSUPPORTED, "B*S overflows int32");
+  PackArgs a;
+  a.set = *set; a.order = order; a.lo = lo; a.Ls = Ls; a.is_test = is_test ? 1 : 0; a.out = *out;
+  const int nthr = out->B * (Ls + out->Sn + 1);
+  hipLaunchKernelGGL(k_batch_pack, dim3((nthr + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+  CHECK_LAUNCH("k_batch_pack");
+  return TLSAN_OK;
+}
+
 int tlsan_batch_index(const tlsan_dims* d, const tlsan_batch* b, void* state, int32_t slot, void* stream) {
   Shape s; St st;
   int rc = shape_of(d, &s);

@@ -54,6 +54,47 @@ __global__ void k_count(CountArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Device-resident batcher: the reference's DataInput.__next__ / DataInputTest.__next__
+// (TLSAN/input.py:17-54, 70-107) over a sample set packed as CSR (tlsan_amd/input.py PackedSet).
+// One thread per (sample, slot): slots [0,Ls) the long window -- sl = min(len, Ls), the LAST Ls
+// items when the history is longer (input.py:41-45), left-aligned otherwise (:47-49), zeros past
+// sl -- slots [Ls, Ls+Sn) the current session padded with zeros, slot Ls+Sn the scalars.
+struct PackArgs {
+  tlsan_packed set;
+  const int32_t* order;  // sample permutation of the epoch (train.py:191 shuffles the list)
+  int32_t lo, Ls, is_test;
+  tlsan_batch out;
+};
+
+__global__ void k_batch_pack(PackArgs a) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int B = a.out.B, Sn = a.out.Sn, Ls = a.Ls, S = Ls + Sn + 1;
+  if (t >= B * S) return;
+  const int b = t / S, slot = t - b * S;
+  const int smp = a.order[a.lo + b];
+  if (slot < Ls) {
+    const int h0 = a.set.hist_off[smp], len = a.set.hist_off[smp + 1] - h0;
+    const int sl = min(len, Ls), src = h0 + max(len - Ls, 0) + slot;
+    const bool v = slot < sl;
+    const_cast<int32_t*>(a.out.hist_i)[(size_t)b * Ls + slot] = v ? a.set.hist[src] : 0;
+    const_cast<float*>(a.out.hist_t)[(size_t)b * Ls + slot] = v ? a.set.hist_t[src] : 0.0f;
+  } else if (slot < Ls + Sn) {
+    const int k = slot - Ls;
+    const int s0 = a.set.sess_off[smp], n = a.set.sess_off[smp + 1] - s0;
+    const_cast<int32_t*>(a.out.hist_i_new)[(size_t)b * Sn + k] = k < n ? a.set.sess[s0 + k] : 0;
+  } else {
+    const int len = a.set.hist_off[smp + 1] - a.set.hist_off[smp];
+    const_cast<int32_t*>(a.out.u)[b] = a.set.u[smp];
+    const_cast<int32_t*>(a.out.u_cate)[b] = a.set.cate[smp];
+    const_cast<int32_t*>(a.out.sl)[b] = min(len, Ls);                                   // input.py:31
+    const_cast<int32_t*>(a.out.sl_new)[b] = a.set.sess_off[smp + 1] - a.set.sess_off[smp];  // :32
+    const_cast<int32_t*>(a.out.i)[b] = a.set.target[smp];
+    if (a.is_test) const_cast<int32_t*>(a.out.j)[b] = a.set.second[smp];
+    else const_cast<float*>(a.out.y)[b] = (float)a.set.second[smp];
+  }
+}
+
 struct ScanArgs {
   const int32_t* cnt[3];
   int32_t* off[3];

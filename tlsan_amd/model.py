@@ -91,6 +91,33 @@ class DeviceBatch:
         self.y = None if is_test else t(yj, torch.float32)
         self.c = self.struct()
 
+    @classmethod
+    def allocate(cls, B, Sn, Ls, device, is_test=False):
+        """Uninitialised device arrays of a [B, Ls] / [B, Sn] batch (filled by tlsan_batch_pack)."""
+        self = cls.__new__(cls)
+        e = lambda shape, dt: torch.empty(shape, dtype=dt, device=device)
+        self.B, self.Sn = int(B), int(Sn)
+        self.u, self.i = e(B, torch.int32), e(B, torch.int32)
+        self.hist_i = e((B, Ls), torch.int32)
+        self.hist_i_new = e((B, Sn), torch.int32) if Sn > 0 else torch.zeros(1, dtype=torch.int32, device=device)
+        self.hist_t = e((B, Ls), torch.float32)
+        self.sl, self.sl_new, self.u_cate = e(B, torch.int32), e(B, torch.int32), e(B, torch.int32)
+        self.j = e(B, torch.int32) if is_test else None
+        self.y = None if is_test else e(B, torch.float32)
+        self.c = self.struct()
+        return self
+
+    def to_host(self):
+        """The reference's 9-tuple (input.py:54 / :107) as numpy arrays."""
+        n = lambda t: t.cpu().numpy()
+        third = n(self.j).astype(np.int64) if self.j is not None else n(self.y).astype(np.int64)
+        hin = n(self.hist_i_new).astype(np.int64).reshape(self.B, self.Sn) if self.Sn > 0 else np.zeros((self.B, 0), np.int64)
+        return (n(self.u).astype(np.int64), n(self.i).astype(np.int64), third, n(self.hist_i).astype(np.int64), hin,
+                n(self.hist_t), n(self.sl).astype(np.int64), n(self.sl_new).astype(np.int64), n(self.u_cate).astype(np.int64))
+
+    def __len__(self):
+        return self.B
+
     def struct(self, use_j=True):
         p = lambda x: None if x is None else x.data_ptr()
         return L.Batch(self.B, self.Sn, p(self.u), p(self.i), p(self.j) if use_j else None, p(self.y),
@@ -147,7 +174,7 @@ class Model(object):
         self._idx_slot = 0
         self._idx_ready = [None, None]
         self._idx_event = [torch.cuda.Event(), torch.cuda.Event()]
-        self._step_event = [None, None]
+        self._pre_event = torch.cuda.Event()
         self._side = None
         self._step = 0
         self._epoch = 0
@@ -315,24 +342,25 @@ class Model(object):
         if pre:
             self._idx_event[k].synchronize()       # the side stream finished this batch's index
         self._idx_ready[k] = None
+        main = torch.cuda.current_stream(self.device)
+        ndb = None
+        if next_batch is not None:
+            # everything queued so far -- the previous step (last user of the other index slot) and
+            # whatever produced the next batch's arrays -- must be done before the side stream reads them
+            ndb = self.device_batch(next_batch)
+            self._pre_event.record(main)
         hp = self.hparams(lr, k, 1 if pre else 0)
         L.check(self.lib.tlsan_train_step(C.byref(self.dims), C.byref(self.cparams), C.byref(db.c), C.byref(hp),
                                           C.byref(out), self.state.data_ptr(), ws.data_ptr(), ws.numel(),
                                           self._stream()), "tlsan_train_step")
-        main = torch.cuda.current_stream(self.device)
-        if next_batch is not None:
-            ndb = self.device_batch(next_batch)
+        if ndb is not None:
             if self._side is None:
                 self._side = torch.cuda.Stream(self.device)
-            if self._step_event[1 - k] is not None:
-                self._step_event[1 - k].synchronize()   # the last step that used slot 1-k has finished with it
+            self._pre_event.synchronize()
             L.check(self.lib.tlsan_batch_index(C.byref(self.dims), C.byref(ndb.c), self.state.data_ptr(), 1 - k,
                                                C.c_void_p(self._side.cuda_stream)), "tlsan_batch_index")
             self._idx_event[1 - k].record(self._side)
             self._idx_ready[1 - k] = ndb
-        if self._step_event[k] is None:
-            self._step_event[k] = torch.cuda.Event()
-        self._step_event[k].record(main)
         self._idx_slot = 1 - k
         self._step += 1
         return db

@@ -40,6 +40,9 @@ def parse(argv=None):
     ap.add_argument("--max_steps", type=int, default=0, help="stop early (0 = run max_epochs)")
     ap.add_argument("--norm_mode", default="tf18", choices=["tf18", "dedup"])
     ap.add_argument("--quiet", action="store_true")
+    ap.add_argument("--device_input", type=int, default=1,
+                    help="1: keep the sample sets in HBM and assemble batches on the device (tlsan_amd.device_input); "
+                         "0: the host batcher (tlsan_amd.input), one upload per batch")
     return ap.parse_args(argv)
 
 
@@ -54,20 +57,41 @@ def load_dataset(path):
     return PackedSet.from_samples(train_set), PackedSet.from_samples(test_set), tuple(counts), np.asarray(icl, np.int32)
 
 
+def _test_batches(test_set, config):
+    if isinstance(test_set, PackedSet):
+        return DataInputTest(test_set, config["test_batch_size"], config["Ls"])
+    from .device_input import DeviceDataInputTest
+    return DeviceDataInputTest(test_set, config["test_batch_size"], config["Ls"])
+
+
 def eval_auc(model, test_set, config):
     """train.py:86-96: batch AUCs weighted by batch length."""
     s = 0.0
-    for _, batch in DataInputTest(test_set, config["test_batch_size"], config["Ls"]):
-        s += model.eval_auc(None, batch) * len(batch[0])
+    for _, batch in _test_batches(test_set, config):
+        s += model.eval_auc(None, batch) * len(batch[0] if isinstance(batch, tuple) else batch)
     return s / len(test_set)
 
 
 def eval_prec_recall(model, test_set, config):
     """train.py:98-118 (cumulative counters, as the reference)."""
-    for _, batch in DataInputTest(test_set, config["test_batch_size"], config["Ls"]):
+    for _, batch in _test_batches(test_set, config):
         model.eval_prec(None, batch)
         model.eval_recall(None, batch)
     return ([getattr(model, "prec_%d" % k).eval() for k in KS], [getattr(model, "recall_%d" % k).eval() for k in KS])
+
+
+def _lookahead(it):
+    """(item, next_item_or_None) pairs: the step is told its successor so the successor's
+    destination index can be built while it runs (Model.train_async(next_batch=))."""
+    it = iter(it)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return
+    for nxt in it:
+        yield cur, nxt
+        cur = nxt
+    yield cur, None
 
 
 def train(args):
@@ -77,25 +101,36 @@ def train(args):
     config.update(user_count=U, item_count=I, cate_count=Cc, from_scratch=args.from_scratch)
     say(json.dumps(config, indent=4), flush=True)
     model = Model(config, icl, device=args.device, norm_mode=args.norm_mode)
+    if args.device_input:
+        from .device_input import DeviceDataInput, DevicePackedSet
+        train_set, test_set = DevicePackedSet(train_set, args.device), DevicePackedSet(test_set, args.device)
+        train_batches = lambda: DeviceDataInput(train_set, args.train_batch_size, config["Ls"])
+    else:
+        train_batches = lambda: DataInput(train_set, args.train_batch_size, config["Ls"])
     t0 = time.time()
     init_auc = eval_auc(model, test_set, config)
     say("Init AUC: %.4f" % init_auc)
     lr = args.learning_rate
     rng = np.random.RandomState(1234)  # train.py:15-16 seeds; the shuffle stream itself differs from CPython's
-    best_auc, avg_loss, history = 0.0, 0.0, []
+    best_auc, history = 0.0, []
+    import torch
+    loss_sum = torch.zeros((), dtype=torch.float32, device=args.device)
     done = False
     for _ in range(args.max_epochs):
         train_set.shuffle(rng)  # train.py:191
-        for _, batch in DataInput(train_set, args.train_batch_size, config["Ls"]):
-            add_summary = model.global_step.eval() % args.display_freq == 0
-            avg_loss += model.train(None, batch, lr, add_summary)
+        for batch, nxt in _lookahead(model.device_batch(b) for _, b in train_batches()):
+            # the reference reads the loss back every step (model.py:229-234); the sum is all the driver
+            # uses, so it is accumulated on the device and read at the evaluation points only
+            last = nxt is None or (args.max_steps and model.global_step.eval() + 1 >= args.max_steps)
+            model.train_async(batch, lr, next_batch=None if last else nxt)
+            loss_sum += model._out[0]
             step = model.global_step.eval()
             if step % args.eval_freq == 0:
                 auc = eval_auc(model, test_set, config)
                 history.append((step, time.time() - t0, auc))
                 say("Epoch %d Global_step %d\tTrain_loss: %.4f\tEval_auc: %.4f" %
-                    (model.global_epoch_step.eval(), step, avg_loss / args.eval_freq, auc), flush=True)
-                avg_loss = 0.0
+                    (model.global_epoch_step.eval(), step, float(loss_sum.item()) / args.eval_freq, auc), flush=True)
+                loss_sum.zero_()
                 if auc > 0.8 and auc > best_auc:  # train.py:228-230
                     best_auc = auc
                     model.save(None)
