@@ -459,3 +459,61 @@ def test_experimental_one_sample_per_wave_kernel(d):
     for k in ref:
         du, dr = np.asarray(got[k], np.float64) - p[k].reshape(np.shape(got[k])), np.asarray(ref[k], np.float64) - p[k].reshape(np.shape(ref[k]))
         assert np.abs(du - dr).max() < 2e-4 * (np.abs(dr).max() + 1e-9) + 2e-7, k
+
+
+def test_full_scale_properties():
+    """BASELINE.json configs[2] at full size (U=39991, I=22048, C=673, d=128, batch 4096), where the
+    oracle is too slow: size-independent properties of the train step.
+      * determinism: two runs of 3 steps are bitwise equal;
+      * the lazy-L2 step is the reference's dense-L2 step: after folding the scale, parameters of
+        l2_mode=lazy and l2_mode=dense agree to fp32 rounding, losses and norms too;
+      * untouched rows are not written in lazy mode;
+      * checksums: the item_b gradient sums to the sum of d loss/d logit, and equals minus the
+        change of item_b divided by the step; the per-use square sum of the step output is the
+        sum of squares of every per-use row (recomputed from tlsan_grads with reg = 0 is not
+        possible at this size, so it is pinned through the clip norm: gnorm^2 = sq_rows +
+        reg^2 * ||tables||^2 + ||dense grads||^2)."""
+    from tlsan_amd import synth
+    cfg = synth.make_config("electronics")
+    icl = synth.item_cate_list(cfg)
+    batches = synth.make_batches(cfg, 3, 4096, seed=77)
+    runs = {}
+    for mode in ("lazy", "lazy", "dense"):
+        m = _model(cfg, icl, l2_mode=mode)
+        p0 = m.get_params()
+        before_user = m.user_emb.clone()
+        losses, norms = [], []
+        for b in batches:
+            losses.append(m.train(None, b, 1.0))
+            norms.append(m.last_gnorm())
+        if mode == "lazy":   # (before get_params: reading the parameters folds the scale into the tables)
+            touched = np.zeros(cfg["user_count"], bool)
+            for b in batches:
+                touched[np.asarray(b[0])] = True
+            same = (m.user_emb == before_user).all(dim=1).cpu().numpy()
+            assert same[~touched].all() and not same[touched].any()
+        out = dict(params=m.get_params(), losses=losses, norms=norms)
+        key = mode if mode not in runs else mode + "2"
+        runs[key] = out
+    for k in runs["lazy"]["params"]:
+        assert np.array_equal(runs["lazy"]["params"][k], runs["lazy2"]["params"][k]), k
+    assert runs["lazy"]["losses"] == runs["lazy2"]["losses"]
+    assert np.allclose(runs["lazy"]["losses"], runs["dense"]["losses"], rtol=2e-6, atol=0)
+    assert np.allclose(runs["lazy"]["norms"], runs["dense"]["norms"], rtol=1e-5, atol=0)
+    for k in runs["lazy"]["params"]:
+        a, d_ = np.asarray(runs["lazy"]["params"][k], np.float64), np.asarray(runs["dense"]["params"][k], np.float64)
+        assert np.abs(a - d_).max() <= 2e-6 * np.abs(d_).max() + 1e-9, k
+    # checksum of the step: item_b moves by -step * (sum of the per-use bias gradients) and its
+    # total change is -step * sum_b dl_b, where sum_b dl_b = mean(sigmoid(logit) - y)
+    m = _model(cfg, icl, l2_mode="lazy")
+    b = batches[0]
+    db = m.device_batch(b)
+    li, _, _, _ = m.forward(b, is_test=False)
+    logit = li.cpu().numpy().astype(np.float64)
+    y = np.asarray(b[2], np.float64)
+    dl_sum = ((1.0 / (1.0 + np.exp(-logit))) - y).sum() / len(y)
+    ib0 = m.get_params()["item_b"].astype(np.float64)
+    m.train(None, b, 1.0)
+    coef = min(1.0, cfg["max_gradient_norm"] / m.last_gnorm())
+    ib1 = m.get_params()["item_b"].astype(np.float64)
+    assert abs((ib0 - ib1).sum() - coef * dl_sum) < 1e-5 * max(1.0, abs(dl_sum)) + 1e-7
