@@ -76,8 +76,10 @@ static int shape_of(const tlsan_dims* d, Shape* s) {
   return TLSAN_OK;
 }
 
+#define EVAL_DENSE_MAX ((size_t)256 << 20)  // all-items scoring materialises all_emb (model.py:89-90) up to this size
 struct Ws {  // carve-up of the caller's scratch buffer
   float *Gi, *Gb, *Gu, *Gc, *gLong, *gDB, *partials, *Kp, *gd, *sqd, *scal, *logits, *s_label;
+  float* all_emb;  // evaluation: dense [I, D] item matrix (NULL when it would exceed EVAL_DENSE_MAX bytes)
   double* rownorm_part;
   double* rownorm;
   size_t bytes;
@@ -112,6 +114,10 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
   w->scal = (float*)take(sizeof(float) * 4);
   w->logits = (float*)take(sizeof(float) * B);
   w->s_label = (float*)take(sizeof(float) * B);
+  {
+    const size_t ae = sizeof(float) * (size_t)d->item_count * D;
+    w->all_emb = ae <= EVAL_DENSE_MAX ? (float*)take(ae) : nullptr;
+  }
   const size_t nrowblk = (size_t)(d->item_count + 15) / 16 + (d->user_count + 15) / 16 + d->cate_count;
   w->rownorm_part = (double*)take(8 * nrowblk);
   w->rownorm = (double*)take(8);
@@ -641,7 +647,7 @@ int tlsan_eval_ranks(const tlsan_dims* d, const tlsan_params* p, const float* u_
   EvalArgs e;
   memset(&e, 0, sizeof(e));
   e.p = norm_params(p, d); e.u_t = u_t; e.labels = labels; e.B = B; e.I = d->item_count; e.di = d->d_item; e.dc = d->d_cate;
-  e.s_label = w.s_label; e.ranks = ranks;
+  e.s_label = w.s_label; e.ranks = ranks; e.all_emb = w.all_emb;
   if (hipMemsetAsync(ranks, 0, sizeof(int32_t) * (size_t)B, hs) != hipSuccess) return fail(TLSAN_E_LAUNCH, "memset ranks");
   const int ut = (B + 15) / 16;
   const int ntiles = (d->item_count + 15) / 16;
@@ -649,9 +655,23 @@ int tlsan_eval_ranks(const tlsan_dims* d, const tlsan_params* p, const float* u_
   const int want = (2048 + ut - 1) / ut;  // enough workgroups to fill the chip
   if (chunks > want) chunks = want;
   if (chunks < 1) chunks = 1;
-  if (s.D == 64) { hipLaunchKernelGGL(k_eval_label<64>, dim3(ut), dim3(64), 0, hs, e); hipLaunchKernelGGL(k_eval_rank<64>, dim3(ut, chunks), dim3(256), 0, hs, e); }
-  else if (s.D == 128) { hipLaunchKernelGGL(k_eval_label<128>, dim3(ut), dim3(64), 0, hs, e); hipLaunchKernelGGL(k_eval_rank<128>, dim3(ut, chunks), dim3(256), 0, hs, e); }
-  else { hipLaunchKernelGGL(k_eval_label<256>, dim3(ut), dim3(64), 0, hs, e); hipLaunchKernelGGL(k_eval_rank<256>, dim3(ut, chunks), dim3(256), 0, hs, e); }
+  const int nae = (d->item_count * (s.D / 4) + 255) / 256;
+  int ngrp = ((d->item_count + 63) / 64 + 3) / 4;  // workgroups (4 wavefronts x 64 items) along the items
+  if (ngrp > want) ngrp = want;
+#define EVAL_LAUNCH(DD)                                                                                  \
+  do {                                                                                                   \
+    hipLaunchKernelGGL(k_eval_label<DD>, dim3(ut), dim3(64), 0, hs, e);                                  \
+    if (e.all_emb) {                                                                                     \
+      hipLaunchKernelGGL(k_all_emb<DD>, dim3(nae), dim3(256), 0, hs, e);                                 \
+      hipLaunchKernelGGL(k_eval_rank_dense<DD>, dim3(ut, ngrp), dim3(256), 0, hs, e);                    \
+    } else {                                                                                             \
+      hipLaunchKernelGGL(k_eval_rank<DD>, dim3(ut, chunks), dim3(256), 0, hs, e);                        \
+    }                                                                                                    \
+  } while (0)
+  if (s.D == 64) EVAL_LAUNCH(64);
+  else if (s.D == 128) EVAL_LAUNCH(128);
+  else EVAL_LAUNCH(256);
+#undef EVAL_LAUNCH
   CHECK_LAUNCH("k_eval");
   return TLSAN_OK;
 }
