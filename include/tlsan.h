@@ -153,6 +153,11 @@ int tlsan_state_renorm(const tlsan_dims* dims, const tlsan_params* p, void* stat
  * touching the sums of squares (used by callers whose item table changes every step). */
 int tlsan_state_reindex(const tlsan_dims* dims, const tlsan_params* p, void* state, void* stream);
 
+/* Rebuild only the category->items index for p->item_cate (same dims as before, use counters
+ * untouched -- they are zero between steps): for callers whose item -> category map changes every
+ * step while the table shape stays (the padded compact table of the sharded path). */
+int tlsan_state_recategorize(const tlsan_dims* dims, const tlsan_params* p, void* state, void* stream);
+
 /* Refresh derived copies (dense_KT) after the caller wrote p->dense. */
 int tlsan_sync_derived(const tlsan_dims* dims, const tlsan_params* p, void* stream);
 
@@ -247,10 +252,12 @@ int tlsan_rows_apply(float* W, int32_t ld, int32_t nrows, int32_t width, int32_t
  *   keys [n_keys] (duplicates fine) -> rank[G*R] compact index of every key, uniq[<=n_keys]
  *   distinct keys ascending, n_uniq[1], cate_c[n_uniq] = cate_by_key[uniq], comp[n_keys] = rank[keys],
  *   sendbuf [G][1 + cap] = per owner {count, row numbers inside the owner's shard ...}: the payload of
- *   ONE equal-split all-to-all (cap >= min(R, n_keys)).  flags[G*R] is scratch. */
+ *   ONE equal-split all-to-all (cap >= min(R, n_keys)).  cate_c entries [n_uniq, cate_pad) are set
+ *   to -1 (a compact table padded to a fixed row count).  flags[G*R] is scratch that must be zero
+ *   on entry and is zero again on exit. */
 int tlsan_route_plan(const int32_t* keys, int32_t n_keys, int32_t R, int32_t G, const int32_t* cate_by_key,
                      int32_t* flags, int32_t* rank, int32_t* uniq, int32_t* n_uniq, int32_t* sendbuf, int32_t cap,
-                     int32_t* cate_c, int32_t* comp, void* stream);
+                     int32_t* cate_c, int32_t cate_pad, int32_t* comp, void* stream);
 
 /* tlsan_shard_gather: owner side of the row fetch.  recvbuf [G][1 + cap] as received from the G
  * ranks; n_recv = sum of the counts (host value).  rows_out [n_recv, W] = the requested rows of

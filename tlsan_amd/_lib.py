@@ -14,7 +14,7 @@ L2_DENSE, L2_LAZY = 0, 1
 
 EXPORTS = [
     "tlsan_abi_version", "tlsan_last_error", "tlsan_dense_layout_of", "tlsan_workspace_bytes",
-    "tlsan_state_bytes", "tlsan_state_init", "tlsan_state_reindex", "tlsan_state_scale",
+    "tlsan_state_bytes", "tlsan_state_init", "tlsan_state_reindex", "tlsan_state_recategorize", "tlsan_state_scale",
     "tlsan_state_renorm", "tlsan_sync_derived", "tlsan_forward",
     "tlsan_train_step", "tlsan_batch_pack", "tlsan_batch_index", "tlsan_grads", "tlsan_eval_ranks", "tlsan_profile_enable", "tlsan_profile_stride",
     "tlsan_profile_collect", "tlsan_debug_stamps", "tlsan_rows_apply_workspace", "tlsan_rows_apply", "tlsan_scan_compact",
@@ -93,6 +93,8 @@ def load():
     lib.tlsan_sync_derived.argtypes = [P(Dims), P(Params), C.c_void_p]
     lib.tlsan_state_reindex.argtypes = [P(Dims), P(Params), C.c_void_p, C.c_void_p]
     lib.tlsan_state_reindex.restype = C.c_int
+    lib.tlsan_state_recategorize.argtypes = [P(Dims), P(Params), C.c_void_p, C.c_void_p]
+    lib.tlsan_state_recategorize.restype = C.c_int
     lib.tlsan_state_scale.argtypes = [C.c_void_p]
     lib.tlsan_state_scale.restype = C.c_void_p
     lib.tlsan_state_renorm.argtypes = [P(Dims), P(Params), C.c_void_p, C.c_void_p]
@@ -124,7 +126,7 @@ def load():
     lib.tlsan_scan_compact.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.tlsan_scan_compact.restype = C.c_int
     lib.tlsan_route_plan.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 6 + \
-                                    [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+                                    [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.tlsan_shard_gather.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
                                        C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.tlsan_shard_gather.restype = C.c_int

@@ -395,6 +395,17 @@ static bool fwd_v2(const Shape& s, bool train, const tlsan_dims* d, const tlsan_
          (uses + 1) * s.D * 4 < lim && (size_t)b->B * (s.D + 4 * ((d->d_item + d->Ls + 3) / 4)) * 4 < lim;
 }
 
+int tlsan_state_recategorize(const tlsan_dims* d, const tlsan_params* p, void* state, void* stream) {
+  Shape s;
+  int rc = shape_of(d, &s);
+  if (rc) return rc;
+  if ((rc = check_params(p))) return rc;
+  if (!state) return fail(TLSAN_E_WORKSPACE, "state is NULL");
+  St st;
+  carve_state(d, (char*)state, &st);
+  return build_cate_csr(d, p, st, (hipStream_t)stream);
+}
+
 static int launch_fwd(const Shape& s, bool train, bool v2, const FwdArgs& a, hipStream_t hs) {
   int grid = a.ngroups < 4096 ? a.ngroups : 4096;
   hipError_t e;
@@ -736,20 +747,21 @@ int tlsan_rows_apply(float* W, int32_t ld, int32_t nrows, int32_t width, int32_t
 
 int tlsan_route_plan(const int32_t* keys, int32_t n_keys, int32_t R, int32_t G, const int32_t* cate_by_key,
                      int32_t* flags, int32_t* rank, int32_t* uniq, int32_t* n_uniq, int32_t* sendbuf, int32_t cap,
-                     int32_t* cate_c, int32_t* comp, void* stream) {
+                     int32_t* cate_c, int32_t cate_pad, int32_t* comp, void* stream) {
   if (!keys || !cate_by_key || !flags || !rank || !uniq || !n_uniq || !sendbuf || !cate_c || !comp)
     return fail(TLSAN_E_BADARG, "tlsan_route_plan: NULL pointer");
   if (n_keys < 1 || R < 1 || G < 1 || (long long)R * G >= (1LL << 31)) return fail(TLSAN_E_BADARG, "tlsan_route_plan: bad sizes");
   if (cap < (R < n_keys ? R : n_keys)) return fail(TLSAN_E_BADARG, "tlsan_route_plan: cap must be >= min(R, n_keys)");
   hipStream_t hs = (hipStream_t)stream;
   const int nkeys = R * G;
-  if (hipMemsetAsync(flags, 0, 4 * (size_t)nkeys, hs) != hipSuccess) return fail(TLSAN_E_LAUNCH, "memset flags");
+  if (cate_pad < 0) return fail(TLSAN_E_BADARG, "tlsan_route_plan: cate_pad < 0");
   RouteArgs a;
   memset(&a, 0, sizeof(a));
   a.keys = keys; a.n_keys = n_keys; a.R = R; a.G = G; a.prefix = rank; a.uniq = uniq; a.n_uniq = n_uniq;
   a.cate_by_key = cate_by_key; a.flags = flags; a.sendbuf = sendbuf; a.cap = cap;
-  a.cate_c = cate_c; a.comp = comp;
-  const int nt = n_keys > G ? n_keys : G;
+  a.cate_c = cate_c; a.cate_pad = cate_pad; a.comp = comp;
+  int nt = n_keys > G ? n_keys : G;
+  if (cate_pad > nt) nt = cate_pad;
   hipLaunchKernelGGL(k_route_mark, dim3((n_keys + 255) / 256), dim3(256), 0, hs, a);
   CHECK_LAUNCH("k_route_mark");
   int rc = tlsan_scan_compact(flags, nkeys, rank, uniq, n_uniq, stream);

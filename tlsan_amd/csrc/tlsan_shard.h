@@ -16,7 +16,8 @@ struct RouteArgs {
   int32_t* flags;
   int32_t* sendbuf;         // [G][1 + cap]: per owner {count, row numbers inside the owner's shard ...}:
   int32_t cap;              //   equal-split all-to-all payload (count and ids travel together)
-  int32_t* cate_c;          // [n_uniq] item -> category map of the compact table
+  int32_t* cate_c;          // [cate_pad] item -> category map of the compact table (-1 past n_uniq)
+  int32_t cate_pad;
   int32_t* comp;            // [n_keys] compact row of every id of the batch
 };
 
@@ -33,6 +34,9 @@ __global__ void k_route_finish(RouteArgs a) {
     const int k = a.uniq[t], g = k / a.R;
     a.sendbuf[(size_t)g * (1 + a.cap) + 1 + (t - a.prefix[(size_t)g * a.R])] = k - g * a.R;
     a.cate_c[t] = a.cate_by_key[k];
+    a.flags[k] = 0;  // the marks are zero at rest: no memset per step
+  } else if (t < a.cate_pad) {
+    a.cate_c[t] = -1;  // rows of the (padded) compact table that are not in use: in no category
   }
   if (t < a.G)
     a.sendbuf[(size_t)t * (1 + a.cap)] = (t + 1 < a.G ? a.prefix[(size_t)(t + 1) * a.R] : nu) - a.prefix[(size_t)t * a.R];

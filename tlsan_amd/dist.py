@@ -289,7 +289,8 @@ class ShardedModel:
         self.last_loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self.last_gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
         self._ws = None
-        self._flags = torch.empty(self.router.nkeys, dtype=torch.int32, device=dev)
+        self._flags = torch.zeros(self.router.nkeys, dtype=torch.int32, device=dev)   # zero at rest
+        self._rows_pad = 4096     # compact-table rows are padded (grow-only): the kernels' state layout is stable
         self._slots = [None, None]          # routing plans: current / prefetched
         self._next_slot = 0
         self._slots_buf = torch.zeros(self.router.R * self.world, dtype=torch.int32, device=dev)  # zero at rest
@@ -364,7 +365,8 @@ class ShardedModel:
         L.check(self.lib.tlsan_route_plan(db.keys.data_ptr(), nk, r.R, r.G, self.cate_by_key.data_ptr(),
                                           self._flags.data_ptr(), sl["rank"].data_ptr(), sl["uniq"].data_ptr(),
                                           sl["n_uniq"].data_ptr(), sl["sendbuf"].data_ptr(), sl["pcap"],
-                                          sl["cate_c"].data_ptr(), sl["comp"].data_ptr(), self._stream()),
+                                          sl["cate_c"].data_ptr(), min(self._rows_pad, sl["cap"]), sl["comp"].data_ptr(),
+                                          self._stream()),
                 "tlsan_route_plan")
         if self.world > 1:
             a2a(sl["recvbuf"].view(-1), sl["sendbuf"].view(-1), None, None, self.group)
@@ -405,13 +407,16 @@ class ShardedModel:
 
     def _fetch(self, sl):
         """compact per-step table: row k = the owner's shard row of the k-th distinct key"""
-        rows = torch.empty((max(sl["n_recv"], 1), self.W), dtype=torch.float32, device=self.device)
+        if self._rows_pad < sl["n"]:        # compact-table rows, padded (grow-only) so the state layout is stable
+            self._rows_pad = (sl["n"] + sl["n"] // 16 + 4095) // 4096 * 4096
+        rows = torch.empty((max(sl["n_recv"], self._rows_pad if self.world == 1 else 1), self.W), dtype=torch.float32,
+                           device=self.device)
         L.check(self.lib.tlsan_shard_gather(self.shard.data_ptr(), self.W, self.router.R, self.W, sl["rb"].data_ptr(),
                                             sl["pcap"], self.world, sl["n_recv"], rows.data_ptr(),
                                             sl["recv_rows"].data_ptr(), self._stream()), "tlsan_shard_gather")
         if self.world == 1:
             return rows
-        table = torch.empty((max(sl["n"], 1), self.W), dtype=torch.float32, device=self.device)
+        table = torch.empty((self._rows_pad, self.W), dtype=torch.float32, device=self.device)
         a2a(table[:sl["n"]], rows[:sl["n_recv"]], sl["send"], sl["recv"], self.group)
         return table
 
@@ -435,7 +440,8 @@ class ShardedModel:
         cp = L.Params(base, base + 4 * self.di, base, base + 4 * self.di, self.cate_emb.data_ptr(),
                       self.dense.data_ptr(), self.dense_KT.data_ptr(), sl["cate_c"].data_ptr(),
                       self.W, self.W, self.W, self.W, None)
-        n = max(sl["n"], 1)
+        # rows [n, pad) of the padded table are never referenced (no use, category -1)
+        n = self._rows_pad
         dims = L.Dims(n, n, self.C, self.d, self.di, self.dc, self.H, self.Ls)
         return dims, cp, cb
 
@@ -444,15 +450,22 @@ class ShardedModel:
         nws = self.lib.tlsan_workspace_bytes(C.byref(dims), B, Sn)
         if nst == 0 or nws == 0:
             raise L.TlsanError(self.lib.tlsan_last_error().decode())
-        if sl["state"] is None or sl["state"].numel() < nst:
+        fresh = sl["state"] is None or sl["state"].numel() < nst
+        if fresh:
             sl["state"] = torch.zeros(int(nst * 1.5), dtype=torch.uint8, device=self.device)
             sl["state"][:4].view(torch.float32).fill_(1.0)   # table scale P = 1 (the owners apply the decay)
         if self._ws is None or self._ws.numel() < nws:
             self._ws = torch.empty(int(nws * 1.25), dtype=torch.uint8, device=self.device)
-        # the compact table (and its item -> category map) changes every step: clear the use
-        # counters and rebuild the category -> items index for it
-        L.check(self.lib.tlsan_state_reindex(C.byref(dims), C.byref(cp), sl["state"].data_ptr(), self._stream()),
-                "tlsan_state_reindex")
+        # the compact table's item -> category map changes every step: rebuild the category -> items
+        # index for it; the use counters are zero between steps unless the (padded) shape changed
+        key = (dims.item_count, dims.cate_count)
+        if fresh or sl.get("dims_key") != key:
+            sl["dims_key"] = key
+            L.check(self.lib.tlsan_state_reindex(C.byref(dims), C.byref(cp), sl["state"].data_ptr(), self._stream()),
+                    "tlsan_state_reindex")
+        else:
+            L.check(self.lib.tlsan_state_recategorize(C.byref(dims), C.byref(cp), sl["state"].data_ptr(), self._stream()),
+                    "tlsan_state_recategorize")
 
     # ------------------------------------------------------------------ training
     def train_async(self, batch, lr, next_batch=None):
