@@ -291,6 +291,7 @@ class ShardedModel:
         self._ws = None
         self._flags = torch.zeros(self.router.nkeys, dtype=torch.int32, device=dev)   # zero at rest
         self._rows_pad = 4096     # compact-table rows are padded (grow-only): the kernels' state layout is stable
+        self._side = None
         self._slots = [None, None]          # routing plans: current / prefetched
         self._next_slot = 0
         self._slots_buf = torch.zeros(self.router.R * self.world, dtype=torch.int32, device=dev)  # zero at rest
@@ -379,11 +380,14 @@ class ShardedModel:
         sl["host"].copy_(sl["cnts"], non_blocking=True)
         sl["event"].record(torch.cuda.current_stream(self.device))
         sl["db"] = db
+        sl["prepared"] = False
         return sl
 
     def _plan_stage2(self, sl):
         """Host half: read the exchange sizes (the step's only host wait; free when stage 1 was
         queued a step ahead)."""
+        if sl.get("stage2") is sl["db"]:
+            return sl
         sl["event"].synchronize()
         h = sl["host"]
         send, recv = h[0].tolist(), h[1].tolist()
@@ -393,7 +397,7 @@ class ShardedModel:
         for c in recv:
             off.append(off[-1] + int(c))
         sl.update(send=send, recv=recv, n=n, n_recv=n_recv, recv_rows=recv_rows,
-                  src_off=(C.c_int32 * (self.world + 1))(*off))
+                  src_off=(C.c_int32 * (self.world + 1))(*off), stage2=sl["db"])
         return sl
 
     def _plan(self, db):
@@ -436,7 +440,7 @@ class ShardedModel:
         ptr = lambda t: None if t is None else t.data_ptr()
         cb = L.Batch(B, Sn, p_u, p_i, p_j, ptr(db.y), p_hist, p_new, ptr(db.hist_t),
                      ptr(db.sl), ptr(db.sl_new), ptr(db.u_cate))
-        base = table.data_ptr()
+        base = (self.shard if table is None else table).data_ptr()   # (None: only item_cate is looked at)
         cp = L.Params(base, base + 4 * self.di, base, base + 4 * self.di, self.cate_emb.data_ptr(),
                       self.dense.data_ptr(), self.dense_KT.data_ptr(), sl["cate_c"].data_ptr(),
                       self.W, self.W, self.W, self.W, None)
@@ -445,7 +449,26 @@ class ShardedModel:
         dims = L.Dims(n, n, self.C, self.d, self.di, self.dc, self.H, self.Ls)
         return dims, cp, cb
 
-    def _buffers(self, sl, dims, cp, B, Sn):
+    def _prepare_side(self, ndb, nsl):
+        """While the current step runs: on a second stream, rebuild the category index of the next
+        step's compact table and build its destination index (both functions of the routing plan
+        only).  Ordered by host waits on events that are already complete; no collective here."""
+        st8 = nsl.get("state")
+        if st8 is None or nsl["n"] > self._rows_pad or nsl.get("dims_key") != (self._rows_pad, self.C) or self._ws is None:
+            return   # first use of the slot or the padded shape grows: the step does it inline
+        dims, cp, cb = self._compact(ndb, nsl, None)
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+            self._side_event = [torch.cuda.Event(), torch.cuda.Event()]
+        sst = C.c_void_p(self._side.cuda_stream)
+        L.check(self.lib.tlsan_state_recategorize(C.byref(dims), C.byref(cp), st8.data_ptr(), sst), "tlsan_state_recategorize")
+        L.check(self.lib.tlsan_batch_index(C.byref(dims), C.byref(cb), st8.data_ptr(), 0, sst), "tlsan_batch_index")
+        ev = self._side_event[self._next_slot]
+        ev.record(self._side)
+        nsl["prep_event"] = ev
+        nsl["prepared"] = True
+
+    def _buffers(self, sl, dims, cp, B, Sn, prepared=False):
         nst = self.lib.tlsan_state_bytes(C.byref(dims))
         nws = self.lib.tlsan_workspace_bytes(C.byref(dims), B, Sn)
         if nst == 0 or nws == 0:
@@ -459,6 +482,8 @@ class ShardedModel:
         # the compact table's item -> category map changes every step: rebuild the category -> items
         # index for it; the use counters are zero between steps unless the (padded) shape changed
         key = (dims.item_count, dims.cate_count)
+        if prepared and not fresh and sl.get("dims_key") == key:
+            return
         if fresh or sl.get("dims_key") != key:
             sl["dims_key"] = key
             L.check(self.lib.tlsan_state_reindex(C.byref(dims), C.byref(cp), sl["state"].data_ptr(), self._stream()),
@@ -474,11 +499,17 @@ class ShardedModel:
         db = self.device_batch(batch)
         G = self.world
         sl = self._plan(db)
+        ndb = None
         if next_batch is not None:
-            self._plan_stage1(self.device_batch(next_batch), self._next_slot)
+            ndb = self.device_batch(next_batch)
+            self._plan_stage1(ndb, self._next_slot)
+        prepared = bool(sl.get("prepared")) and sl["n"] <= self._rows_pad
+        sl["prepared"] = False
+        if prepared:
+            sl["prep_event"].synchronize()      # the side stream finished this batch's indices
         table = self._fetch(sl)
         dims, cp, cb = self._compact(db, sl, table)
-        self._buffers(sl, dims, cp, db.B, db.Sn)
+        self._buffers(sl, dims, cp, db.B, db.Sn, prepared)
         n, Cc, di, Ls, W = dims.item_count, self.C, self.di, self.Ls, self.W
         dev = self.device
         n_dense, n_cate = self.lay.n_dense, Cc * self.dc
@@ -490,7 +521,7 @@ class ShardedModel:
         go = L.GradsOut(g0, g0 + 4 * di, g0, g0 + 4 * di, fp + 4 * n_dense, fp, W, W, W, W, 1)
         tail = fp + 4 * (n_dense + n_cate)
         out = L.StepOut(tail, self._gn_local.data_ptr(), None, tail + 4)
-        hp = L.HParams(float(lr), 0.0, self.clip, L.NORM_TF18, L.L2_DENSE)   # reg is applied by the owners
+        hp = L.HParams(float(lr), 0.0, self.clip, L.NORM_TF18, L.L2_DENSE, 0, 1 if prepared else 0)   # reg: applied by the owners
         st = self._stream()
         L.check(self.lib.tlsan_grads(C.byref(dims), C.byref(cp), C.byref(cb), C.byref(hp), C.byref(go), C.byref(out),
                                      sl["state"].data_ptr(), self._ws.data_ptr(), self._ws.numel(), st), "tlsan_grads")
@@ -516,6 +547,9 @@ class ShardedModel:
                 "tlsan_shard_apply")
         self._step += 1
         self._keep = (table, gf, vals, sl["recv_rows"])
+        if ndb is not None:
+            nsl = self._plan_stage2(self._slots[self._next_slot])   # its counts arrived long ago
+            self._prepare_side(ndb, nsl)
         return db
 
     def train(self, sess, batch, lr, add_summary=False):
