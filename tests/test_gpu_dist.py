@@ -55,7 +55,7 @@ def _concat(per):
     return out
 
 
-def _worker(rank, world, port, ret, d):
+def _worker(rank, world, port, ret, d, prefetch):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -63,10 +63,16 @@ def _worker(rank, world, port, ret, d):
         cfg, p, cat = _case(d)
         m = ShardedModel(cfg, cat, device="cuda:0")
         m.set_params({k: np.asarray(v, np.float32) for k, v in p.items()})
-        steps = _split_batches(cfg, world, 3, B=24)
+        steps = _split_batches(cfg, world, 4, B=24)
         losses = []
-        for per in steps:
-            losses.append(m.train(None, _tuple(per[rank]), 0.8))
+        if prefetch:   # every step is told its successor: routing plan + indices are built a step ahead
+            dbs = [m.device_batch(_tuple(per[rank])) for per in steps]
+            for k, db in enumerate(dbs):
+                m.train_async(db, 0.8, next_batch=dbs[k + 1] if k + 1 < len(dbs) else None)
+                losses.append(float(m.last_loss.item()))
+        else:
+            for per in steps:
+                losses.append(m.train(None, _tuple(per[rank]), 0.8))
         got = m.gather_params()
         auc = m.eval_auc(None, tuple(list(_tuple(steps[0][rank]))[:2] + [steps[0][rank]["i"][::-1].copy()] + list(_tuple(steps[0][rank]))[3:]))
         if rank == 0:
@@ -79,7 +85,7 @@ def _worker(rank, world, port, ret, d):
             for k in q:
                 g = np.asarray(got[k], np.float64).reshape(q[k].shape)
                 du, dr = g - p[k], q[k] - p[k]
-                assert np.abs(du - dr).max() < 5e-4 * (np.abs(dr).max() + 1e-9) + 5e-7, k
+                assert np.abs(du - dr).max() < 5e-4 * (np.abs(dr).max() + 1e-9) + 5e-7, (k, float(np.abs(du - dr).max()), float(np.abs(dr).max()))
         assert 0.0 <= auc <= 1.0
         ret[rank] = "ok"
     except Exception:
@@ -89,11 +95,11 @@ def _worker(rank, world, port, ret, d):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,d", [(1, 128), (2, 128), (2, 64)])
-def test_sharded_model_matches_oracle(world, d):
+@pytest.mark.parametrize("world,d,prefetch", [(1, 128, False), (2, 128, False), (2, 64, False), (1, 128, True), (2, 128, True)])
+def test_sharded_model_matches_oracle(world, d, prefetch):
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), ret, d), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), ret, d, prefetch), nprocs=world, join=True)
     assert all(v == "ok" for v in dict(ret).values()) and len(ret) == world, dict(ret)
 
 
@@ -129,3 +135,44 @@ def test_rows_apply_matches_numpy_and_is_deterministic():
     assert np.abs(outs[0][0] - ref).max() < 2e-5
     assert np.array_equal(outs[0][0][:, width:], W0[:, width:])           # padding columns untouched
     assert abs(outs[0][1] - (ref[:, :reg_cols] ** 2).sum()) < 1e-3 * (ref[:, :reg_cols] ** 2).sum()
+
+
+def test_route_plan_matches_key_router():
+    """tlsan_route_plan (the GPU routing of the sharded step) against KeyRouter.plan with the torch
+    scan (what tests/test_dist_cpu.py checks over gloo): same distinct rows, same per-owner counts,
+    same local row numbers in all-to-all order, same compact ids, same category map."""
+    import ctypes as C
+    from tlsan_amd import _lib as L
+    from tlsan_amd.dist import KeyRouter
+    lib = L.load()
+    G, n_items, n_users = 4, 203, 117
+    r = KeyRouter(n_items, n_users, G, 0)
+    rng = np.random.RandomState(11)
+    items, users = rng.randint(0, n_items, 700), rng.randint(0, n_users, 64)
+    keys = torch.cat([r.item_keys(torch.as_tensor(items)), r.user_keys(torch.as_tensor(users))]).to(torch.int32).cuda()
+    cbk = torch.full((r.nkeys,), -1, dtype=torch.int32)
+    ids = np.arange(n_items)
+    cbk[(ids % G) * r.R + ids // G] = torch.as_tensor(rng.randint(0, 9, n_items).astype(np.int32))
+    cbk = cbk.cuda()
+    nk, cap, pad = int(keys.numel()), r.R, 1024
+    z = lambda n: torch.zeros(n, dtype=torch.int32, device="cuda")
+    flags, rank, uniq, n_uniq, sendbuf, cate_c, comp = z(r.nkeys), z(r.nkeys), z(r.nkeys), z(1), z(G * (1 + cap)), z(pad), z(nk)
+    L.check(lib.tlsan_route_plan(keys.data_ptr(), nk, r.R, G, cbk.data_ptr(), flags.data_ptr(), rank.data_ptr(), uniq.data_ptr(),
+                                 n_uniq.data_ptr(), sendbuf.data_ptr(), cap, cate_c.data_ptr(), pad, comp.data_ptr(),
+                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)), "tlsan_route_plan")
+    # reference: the same quantities KeyRouter.plan derives (checked over gloo in tests/test_dist_cpu.py)
+    kn = keys.cpu().numpy().astype(np.int64)
+    u_ref = np.unique(kn)                                   # distinct keys, ascending = grouped by owner
+    n = len(u_ref)
+    counts = [int(((u_ref >= g * r.R) & (u_ref < (g + 1) * r.R)).sum()) for g in range(G)]
+    assert int(n_uniq.item()) == n
+    assert np.array_equal(uniq[:n].cpu().numpy(), u_ref)
+    sb = sendbuf.view(G, 1 + cap).cpu().numpy()
+    assert sb[:, 0].tolist() == counts
+    rows = np.concatenate([sb[g, 1:1 + counts[g]] for g in range(G)])
+    assert np.array_equal(rows, u_ref % r.R)                # local row numbers in all-to-all send order
+    assert np.array_equal(comp.cpu().numpy(), np.searchsorted(u_ref, kn))
+    assert np.array_equal(cate_c[:n].cpu().numpy(), cbk.cpu().numpy()[u_ref])
+    assert (cate_c[n:pad] == -1).all() and int(flags.abs().sum().item()) == 0     # pads marked, marks cleared
+    # and the python router agrees on the key space
+    assert np.array_equal(r.item_keys(torch.as_tensor(items)).numpy(), (items % G) * r.R + items // G)

@@ -349,7 +349,7 @@ class ShardedModel:
                       sendbuf=torch.zeros(G, 1 + pcap, dtype=torch.int32, device=dev),
                       recvbuf=torch.zeros(G, 1 + pcap, dtype=torch.int32, device=dev),
                       cnts=torch.zeros(2, G, dtype=torch.int32, device=dev),       # [send | recv] per peer
-                      cate_c=torch.empty(cap, dtype=torch.int32, device=dev),
+                      cate_c=torch.empty(max(cap, self._rows_pad), dtype=torch.int32, device=dev),
                       comp=torch.empty(cap, dtype=torch.int32, device=dev),
                       host=torch.zeros(2, G, dtype=torch.int32).pin_memory(),
                       event=torch.cuda.Event(), state=None)
@@ -362,11 +362,14 @@ class ShardedModel:
         counts to the host is queued, nothing waits."""
         nk = int(db.keys.numel())
         sl = self._slot(k, nk)
+        if sl["cate_c"].numel() < self._rows_pad:    # the padded table grew since the slot was made
+            sl["cate_c"] = torch.empty(self._rows_pad, dtype=torch.int32, device=self.device)
+        sl["cate_pad"] = self._rows_pad               # category map entries [n_uniq, cate_pad) are set to -1
         r = self.router
         L.check(self.lib.tlsan_route_plan(db.keys.data_ptr(), nk, r.R, r.G, self.cate_by_key.data_ptr(),
                                           self._flags.data_ptr(), sl["rank"].data_ptr(), sl["uniq"].data_ptr(),
                                           sl["n_uniq"].data_ptr(), sl["sendbuf"].data_ptr(), sl["pcap"],
-                                          sl["cate_c"].data_ptr(), min(self._rows_pad, sl["cap"]), sl["comp"].data_ptr(),
+                                          sl["cate_c"].data_ptr(), sl["cate_pad"], sl["comp"].data_ptr(),
                                           self._stream()),
                 "tlsan_route_plan")
         if self.world > 1:
@@ -413,6 +416,10 @@ class ShardedModel:
         """compact per-step table: row k = the owner's shard row of the k-th distinct key"""
         if self._rows_pad < sl["n"]:        # compact-table rows, padded (grow-only) so the state layout is stable
             self._rows_pad = (sl["n"] + sl["n"] // 16 + 4095) // 4096 * 4096
+        if sl["cate_pad"] < self._rows_pad:  # (rare) the table grew after this plan's category map was written
+            cc = torch.full((self._rows_pad,), -1, dtype=torch.int32, device=self.device)
+            cc[:sl["n"]] = sl["cate_c"][:sl["n"]]
+            sl["cate_c"], sl["cate_pad"] = cc, self._rows_pad
         rows = torch.empty((max(sl["n_recv"], self._rows_pad if self.world == 1 else 1), self.W), dtype=torch.float32,
                            device=self.device)
         L.check(self.lib.tlsan_shard_gather(self.shard.data_ptr(), self.W, self.router.R, self.W, sl["rb"].data_ptr(),
