@@ -517,3 +517,28 @@ def test_full_scale_properties():
     coef = min(1.0, cfg["max_gradient_norm"] / m.last_gnorm())
     ib1 = m.get_params()["item_b"].astype(np.float64)
     assert abs((ib0 - ib1).sum() - coef * dl_sum) < 1e-5 * max(1.0, abs(dl_sum)) + 1e-7
+
+
+def test_periodic_scale_fold_in_long_lazy_runs():
+    """lazy L2 folds the table scale into the tables on a fixed schedule (Model.renorm_every) so that
+    P never underflows; folding must not change what is trained."""
+    cfg = make_config(U=40, I=60, C=9, d=64, regulation_rate=2e-2)
+    p = _p32(random_params(cfg, seed=71))
+    _, cat = random_batch(cfg, B=8, Sn=2, seed=0)
+    batches = [random_batch(cfg, B=30, Sn=3, seed=700 + s)[0] for s in range(7)]
+    q = dict(p)
+    for b in batches:
+        _, q, _ = orc.train_step(q, cat, b, 8, cfg["regulation_rate"], lr=1.0)
+    for every in (0, 3):
+        m = _model(cfg, cat, p, l2_mode="lazy")
+        m.renorm_every = every
+        for b in batches:
+            m.train_async(_tuple(b), 1.0)
+        if every:
+            assert m.table_scale() > 0.97     # folded at step 6, one step since
+        else:
+            assert m.table_scale() < 0.9      # 7 steps of (1 - lr c reg)
+        got = m.get_params()
+        for k in q:
+            g = np.asarray(got[k], np.float64).reshape(q[k].shape)
+            assert np.abs(g - q[k]).max() < 5e-4 * np.abs(q[k]).max() + 1e-6, (every, k)

@@ -170,6 +170,7 @@ class Model(object):
             self.cparams.scale = self.lib.tlsan_state_scale(self.state.data_ptr())
         self._ws = None
         self._ws_key = (0, 0)
+        self.renorm_every = 4096   # lazy L2: fold the table scale into the tables every so many steps (0 = never)
         # two destination-index slots: the current step's and the one being built for the next batch
         self._idx_slot = 0
         self._idx_ready = [None, None]
@@ -334,6 +335,10 @@ class Model(object):
                                               self._stream()), "tlsan_train_step")
             self._step += 1
             return db
+        if self.l2_mode == L.L2_LAZY and self.renorm_every and self._step and self._step % self.renorm_every == 0:
+            # keep the table scale P = prod(1 - lr c reg) away from fp32 underflow in very long runs
+            # (a fixed schedule, so runs stay bitwise reproducible); one sweep of the tables
+            self.fold_scale()
         k = self._idx_slot
         if self._idx_ready[k] is not None and self._idx_ready[k] is not db:
             raise RuntimeError("train_async: the batch announced as next_batch must be the next one trained "
