@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--l2-mode", default="lazy", choices=["lazy", "dense"],
                     help="lazy: W = P*W_stored, only used rows touched (same update as the reference's dense L2); "
                          "dense: every row decayed every step")
+    ap.add_argument("--table-dtype", default="f32", choices=["f32", "bf16"],
+                    help="storage of the item/user/category tables (arithmetic is fp32 either way)")
     ap.add_argument("--graph", type=int, default=0, help="replay hipGraph-captured steps instead of eager launches (single-GPU path)")
     ap.add_argument("--prefetch", type=int, default=1,
                     help="eager mode: build the next batch's destination index on a second stream during the step")
@@ -111,7 +113,7 @@ def main():
     # weak scaling: every rank trains its own batch of B sequences per step
     host_batches = synth.make_batches(cfg, args.n_batches, B, seed=1234 + 1000 * rank)
     if not sharded:
-        model = Model(cfg, icl, device=dev, l2_mode=args.l2_mode)
+        model = Model(cfg, icl, device=dev, l2_mode=args.l2_mode, table_dtype=args.table_dtype)
         stepper = model
     else:
         from tlsan_amd.dist import ShardedModel
@@ -168,7 +170,8 @@ def main():
 
     if rank == 0:
         seqs = args.steps * B * world
-        ab = [synth.algorithmic_bytes(cfg, host_batches[(args.warmup + s) % len(host_batches)]) for s in range(args.steps)]
+        eb = 2 if (args.table_dtype == "bf16" and not sharded) else 4   # e = bytes per table element
+        ab = [synth.algorithmic_bytes(cfg, host_batches[(args.warmup + s) % len(host_batches)], eb) for s in range(args.steps)]
         k_bytes = float(np.mean([a["fwd_bwd_kernel"] for a in ab]))
         l2 = "dense" if sharded else args.l2_mode
         step_bytes = float(np.mean([a["train_step"] for a in ab])) + (synth.dense_sweep_bytes(cfg) if l2 == "dense" else 0)
@@ -195,10 +198,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "%s-scale synthetic (U=%d I=%d C=%d, d=%d, Ls=%d), batch %d/GPU, fp32 tables, "
+            "config": {"workload": "%s-scale synthetic (U=%d I=%d C=%d, d=%d, Ls=%d), batch %d/GPU, %s tables, "
                                    "l2_mode=%s"
                                    % (args.workload, cfg["user_count"], cfg["item_count"], cfg["cate_count"],
                                       cfg["hidden_units"], cfg["Ls"], B,
+                                      "bf16 (fp32 arithmetic, stochastic rounding on update)" if eb == 2 else "fp32",
                                       "dense (every row decayed every step, as the reference)" if l2 == "dense" else
                                       "lazy (reference's dense-L2 update as W = P*W_stored; only used rows touched)"),
                        "global_batch": B * world, "parallelism": "1 process/GPU, tables %s"

@@ -68,7 +68,15 @@ typedef struct {
    * TLSAN_L2_LAZY the library keeps P = prod_t (1 - lr_t c_t reg) here instead of decaying
    * every row every step; point it at tlsan_state_scale(state). */
   const float* scale;
+  /* Storage type of item_emb, user_emb and cate_emb: TLSAN_TABLE_F32 (0) or TLSAN_TABLE_BF16 (1).
+   * With bf16 the three pointers address uint16 elements (row strides still in ELEMENTS); all
+   * arithmetic stays fp32, updates are written back with stochastic rounding (deterministic: a
+   * hash of step, table and element).  usert_emb, item_b and dense are always fp32.  A build
+   * extension: the reference is fp32 throughout. */
+  int32_t table_dtype;
 } tlsan_params;
+#define TLSAN_TABLE_F32 0
+#define TLSAN_TABLE_BF16 1
 
 typedef struct {
   int32_t n_dense;

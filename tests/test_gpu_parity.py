@@ -542,3 +542,73 @@ def test_periodic_scale_fold_in_long_lazy_runs():
         for k in q:
             g = np.asarray(got[k], np.float64).reshape(q[k].shape)
             assert np.abs(g - q[k]).max() < 5e-4 * np.abs(q[k]).max() + 1e-6, (every, k)
+
+
+def _bf16_round(a):
+    """round-to-nearest-even to bfloat16, back to float32 (what Model.set_params stores)"""
+    import torch
+    return torch.as_tensor(np.asarray(a, np.float32)).to(torch.bfloat16).float().numpy()
+
+
+BF16_TABLES = ("item_emb", "user_emb", "cate_emb")
+
+
+@pytest.mark.parametrize("l2_mode", ["dense", "lazy"])
+def test_bf16_tables(l2_mode):
+    """table_dtype='bf16' (BASELINE.json configs[2] names bf16 tables; a build extension, the reference
+    is fp32): item_emb / user_emb / cate_emb are stored as bfloat16, arithmetic stays fp32.
+      * forward and gradients equal the fp64 oracle evaluated on the stored (rounded) parameters;
+      * after a step every bf16 element is one of the two bf16 neighbours of the exact update
+        (stochastic rounding), the fp32 parameters match the oracle as usual;
+      * the rounding is unbiased on average and deterministic (same bits on a second run);
+      * the L2 / clip-norm bookkeeping follows the STORED values (loss of the next step matches the
+        oracle evaluated on the stored parameters)."""
+    cfg = make_config(U=60, I=90, C=9, d=128, regulation_rate=1e-3)
+    p = _p32(random_params(cfg, seed=81))
+    for k in BF16_TABLES:
+        p[k] = _bf16_round(p[k]).astype(np.float64)
+    b, cat = random_batch(cfg, B=64, Sn=4, seed=82)
+    b2, _ = random_batch(cfg, B=64, Sn=3, seed=83)
+    m = _model(cfg, cat, p, l2_mode=l2_mode, table_dtype="bf16")
+    got0 = m.get_params()
+    for k in p:
+        assert np.array_equal(np.asarray(got0[k], np.float64).reshape(p[k].shape), p[k]), k   # stored exactly
+    # forward + gradients on the stored parameters
+    out = orc.forward(p, cat, b, 8)
+    li, _, _, _ = m.forward(_tuple(b), is_test=False)
+    assert np.abs(li.cpu().numpy() - out["logits"]).max() < 1e-4
+    g = m.grads(_tuple(b))
+    _, _, ref_g, _ = orc.backward(p, cat, b, 8, cfg["regulation_rate"])
+    for k in ref_g:
+        a, r = np.asarray(g["grads"][k], np.float64).reshape(ref_g[k].shape), ref_g[k]
+        assert np.abs(a - r).max() < 2e-4 * np.abs(r).max() + 1e-6, k
+    # one step: stochastic rounding lands on a bf16 neighbour of the exact update
+    loss, q, info = orc.train_step(p, cat, b, 8, cfg["regulation_rate"], lr=0.7)
+    runs = []
+    for rep in range(2):
+        mm = _model(cfg, cat, p, l2_mode=l2_mode, table_dtype="bf16")
+        l = mm.train(None, _tuple(b), 0.7)
+        assert abs(l - loss) < 1e-4 * max(1.0, abs(loss))
+        l2 = mm.train(None, _tuple(b2), 0.7)           # second step: its loss carries the L2 term of the STORED tables
+        runs.append((mm.get_params(), l2))
+        if rep == 0:
+            m1 = _model(cfg, cat, p, l2_mode=l2_mode, table_dtype="bf16")
+            m1.train(None, _tuple(b), 0.7)
+            stored = {k: np.asarray(v, np.float64) for k, v in m1.get_params().items()}
+            for k in q:
+                a, r = stored[k].reshape(q[k].shape), q[k]
+                if k in BF16_TABLES:
+                    ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(r), 1e-30))) - 7)
+                    # (lazy: reading the parameters folds the table scale in, a second stochastic rounding)
+                    assert (np.abs(a - r) <= ulp * ((2 if l2_mode == "lazy" else 1) + 1e-3) + 1e-12).all(), k
+                    assert np.array_equal(a.astype(np.float32), _bf16_round(a)), k        # representable in bf16
+                    bias = ((a - r) / ulp).mean()
+                    assert abs(bias) < 0.06, (k, bias)                                    # unbiased: E[stored] = exact
+                else:
+                    du, dr = a - p[k], r - p[k]
+                    assert np.abs(du - dr).max() < 2e-4 * (np.abs(dr).max() + 1e-9) + 2e-7, k
+            ref_l2 = orc.train_step(stored, cat, b2, 8, cfg["regulation_rate"], lr=0.7)[0]
+            assert abs(l2 - ref_l2) < 1e-4 * max(1.0, abs(ref_l2))
+    for k in runs[0][0]:
+        assert np.array_equal(runs[0][0][k], runs[1][0][k]), k
+    assert runs[0][1] == runs[1][1]

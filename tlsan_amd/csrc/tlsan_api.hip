@@ -211,6 +211,9 @@ static int check_params(const tlsan_params* p) {
   if (!p || !p->item_emb || !p->item_b || !p->user_emb || !p->usert_emb || !p->cate_emb || !p->dense ||
       !p->dense_KT || !p->item_cate)
     return fail(TLSAN_E_BADARG, "NULL parameter pointer");
+  if (p->table_dtype != TLSAN_TABLE_F32 && p->table_dtype != TLSAN_TABLE_BF16) return fail(TLSAN_E_BADARG, "table_dtype");
+  if (p->table_dtype == TLSAN_TABLE_BF16 && ((p->ld_item | p->ld_user) % 4))
+    return fail(TLSAN_E_UNSUPPORTED, "bf16 tables need row strides that are multiples of 4 elements");
   return TLSAN_OK;
 }
 
@@ -265,10 +268,16 @@ static int launch_apply(int mode, bool lazy, ApplyArgs A, bool with_dense, int B
   }
   const dim3 g1(A.nbC + A.nbI + A.nbU + (with_dense ? A.nbD : 0)), blk(256);
   const bool wide = A.di > 64 || A.dc > 64 || A.WU > 128;  // more float4 chunks per lane
-#define AP_LAUNCH(M, LZ)                                                                   \
-  do {                                                                                     \
-    if (wide) hipLaunchKernelGGL((k_apply<M, LZ, true>), g1, blk, 0, hs, A);               \
-    else hipLaunchKernelGGL((k_apply<M, LZ, false>), g1, blk, 0, hs, A);                   \
+  const bool bf16 = A.p.table_dtype == TLSAN_TABLE_BF16;
+#define AP_LAUNCH(M, LZ)                                                                                     \
+  do {                                                                                                       \
+    if (bf16) {                                                                                              \
+      if (wide) hipLaunchKernelGGL((k_apply<M, LZ, true, TLSAN_TABLE_BF16>), g1, blk, 0, hs, A);             \
+      else hipLaunchKernelGGL((k_apply<M, LZ, false, TLSAN_TABLE_BF16>), g1, blk, 0, hs, A);                 \
+    } else {                                                                                                 \
+      if (wide) hipLaunchKernelGGL((k_apply<M, LZ, true>), g1, blk, 0, hs, A);                               \
+      else hipLaunchKernelGGL((k_apply<M, LZ, false>), g1, blk, 0, hs, A);                                   \
+    }                                                                                                        \
   } while (0)
   switch (mode) {
     case AP_UPDATE:
@@ -357,12 +366,27 @@ int tlsan_state_renorm(const tlsan_dims* d, const tlsan_params* p, void* state, 
   carve_state(d, (char*)state, &st);
   const tlsan_params q = norm_params(p, d);
   hipStream_t hs = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_scale_table, dim3(1024), dim3(256), 0, hs, q.item_emb, d->item_count, d->d_item, q.ld_item, st.hdr);
-  hipLaunchKernelGGL(k_scale_table, dim3(1024), dim3(256), 0, hs, q.user_emb, d->user_count, d->d_item, q.ld_user, st.hdr);
-  hipLaunchKernelGGL(k_scale_table, dim3(256), dim3(256), 0, hs, q.usert_emb, d->user_count, d->Ls, q.ld_usert, st.hdr);
-  hipLaunchKernelGGL(k_scale_table, dim3(64), dim3(256), 0, hs, q.cate_emb, d->cate_count, d->d_cate, d->d_cate, st.hdr);
+  const int dt = q.table_dtype;
+  hipLaunchKernelGGL(k_scale_table, dim3(1024), dim3(256), 0, hs, q.item_emb, d->item_count, d->d_item, q.ld_item, st.hdr, dt, 0x1b873593u);
+  hipLaunchKernelGGL(k_scale_table, dim3(1024), dim3(256), 0, hs, q.user_emb, d->user_count, d->d_item, q.ld_user, st.hdr, dt, 0xcc9e2d51u);
+  hipLaunchKernelGGL(k_scale_table, dim3(256), dim3(256), 0, hs, q.usert_emb, d->user_count, d->Ls, q.ld_usert, st.hdr, TLSAN_TABLE_F32, 0u);
+  hipLaunchKernelGGL(k_scale_table, dim3(64), dim3(256), 0, hs, q.cate_emb, d->cate_count, d->d_cate, d->d_cate, st.hdr, dt, 0xe6546b64u);
   hipLaunchKernelGGL(k_renorm_commit, dim3(1), dim3(1), 0, hs, st.hdr);
   CHECK_LAUNCH("tlsan_state_renorm");
+  if (dt != TLSAN_TABLE_F32) {
+    // the rounded values no longer scale exactly with P: take the sum of squares from what is stored
+    tlsan_dense_layout L;
+    tlsan_dense_layout_of(d, &L);
+    Ws w;
+    memset(&w, 0, sizeof(w));
+    ApplyArgs A;
+    fill_apply(A, d, s, p, nullptr, nullptr, w, st, L);
+    // (per-step changes still pending in S_part are already part of the stored values: overwritten)
+    if ((rc = launch_apply(AP_SUMSQ, false, A, false, 0, 0, hs))) return rc;
+    hipLaunchKernelGGL(k_reduce_double, dim3(1), dim3(256), 0, hs, st.S_part, st.nbI + st.nbU + st.nbC, st.S_total);
+    CHECK_LAUNCH("k_reduce_double");
+    if (hipMemsetAsync(st.S_part, 0, 8 * (size_t)(st.nbI + st.nbU + st.nbC), hs) != hipSuccess) return fail(TLSAN_E_LAUNCH, "memset S_part");
+  }
   return TLSAN_OK;
 }
 
@@ -387,7 +411,7 @@ int tlsan_state_reindex(const tlsan_dims* d, const tlsan_params* p, void* state,
 // bound by the fp32 matrix pipe and the per-sample length imbalance, not by occupancy.
 static bool fwd_v2(const Shape& s, bool train, const tlsan_dims* d, const tlsan_params& q, const tlsan_batch* b) {
   static const int on = [] { const char* v = getenv("TLSAN_FWD_V2"); return v ? atoi(v) : 0; }();
-  if (!on || !train || d->Ls > TLSAN_LS_MAX || s.D > 128) return false;
+  if (!on || !train || d->Ls > TLSAN_LS_MAX || s.D > 128 || q.table_dtype != TLSAN_TABLE_F32) return false;
   const size_t lim = (size_t)1 << 32;  // it addresses with 32-bit byte offsets from the table bases
   const size_t uses = (size_t)b->B * (d->Ls + b->Sn + 1);
   return (size_t)d->item_count * q.ld_item * 4 < lim && (size_t)d->user_count * q.ld_user * 4 < lim &&
@@ -416,6 +440,7 @@ static int launch_fwd(const Shape& s, bool train, bool v2, const FwdArgs& a, hip
   else if (s.D == 64) e = tlsan_launch_fwd_bwd_d64(train, lstream, a, grid, hs);
   else if (s.D == 128) e = tlsan_launch_fwd_bwd_d128(train, lstream, a, grid, hs);
   else e = tlsan_launch_fwd_bwd_d256(train, lstream, a, grid, hs);
+  if (e == hipErrorNotSupported) return fail(TLSAN_E_UNSUPPORTED, "bf16 tables with a streamed window (Ls > %d) are not built", TLSAN_LS_MAX);
   if (e != hipSuccess) return fail(TLSAN_E_LAUNCH, "k_fwd_bwd: %s", hipGetErrorString(e));
   return TLSAN_OK;
 }
@@ -482,8 +507,9 @@ static int build_index(const tlsan_dims* d, const tlsan_batch* b, const St& st, 
 
 // shared front half of train_step / grads: index build, fused fwd+bwd, dense-grad reduction
 static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params* p, const tlsan_batch* b,
-                        const tlsan_hparams* hp, bool commit, const tlsan_step_out* out, const Ws& w, const St& st,
+                        const tlsan_hparams* hp, bool update, const tlsan_step_out* out, const Ws& w, const St& st,
                         const tlsan_dense_layout& L, hipStream_t hs) {
+  const bool commit = update && hp->l2_mode == TLSAN_L2_LAZY;
   const int k = hp->index_slot;
   int rc;
   prof_mark(0, hs);
@@ -523,7 +549,7 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   f.gd = w.gd; f.sqd = w.sqd; f.scal = w.scal;
   f.S_part = st.S_part; f.n_spart = st.nbI + st.nbU + st.nbC; f.S_total = st.S_total;
   f.hdr = st.hdr; f.lr = hp->lr; f.reg = hp->reg; f.clip = hp->clip; f.inv_B = 1.0f / (float)b->B;
-  f.norm_mode = hp->norm_mode; f.commit = commit ? 1 : 0;
+  f.norm_mode = hp->norm_mode; f.commit = commit ? 1 : 0; f.count_step = update ? 1 : 0;
   f.out_loss = out ? out->loss : nullptr;
   f.out_gnorm = out ? out->gnorm : nullptr;
   f.out_sq = out ? out->sq_rows : nullptr;
@@ -607,7 +633,7 @@ int tlsan_train_step(const tlsan_dims* d, const tlsan_params* p, const tlsan_bat
   hipStream_t hs = (hipStream_t)stream;
   tlsan_dense_layout L;
   tlsan_dense_layout_of(d, &L);
-  if ((rc = run_backward(d, s, p, b, hp, hp->l2_mode == TLSAN_L2_LAZY, out, w, st, L, hs))) return rc;
+  if ((rc = run_backward(d, s, p, b, hp, true, out, w, st, L, hs))) return rc;
   ApplyArgs A;
   fill_apply(A, d, s, p, b, hp, w, st, L);
   if (hp->norm_mode == TLSAN_NORM_DEDUP && (rc = clip_dedup(A, hp, out, w, st, b, hs))) return rc;

@@ -171,17 +171,16 @@ __device__ __forceinline__ void bwd_dw(const float* __restrict__ T, int q, int r
 
 // 16-B gather of channels [c, c+4) of the concatenated row [item_emb[it] || cate_emb[cat[it]]]
 // (model.py:84-86,105-107,111-113)
+template <int DT = TLSAN_TABLE_F32>
 __device__ __forceinline__ f32x4 gather_item4(const FwdArgs& a, int it, int c) {
-  const float* ptr = (c < a.di)
-                         ? a.p.item_emb + (size_t)it * a.p.ld_item + c
-                         : a.p.cate_emb + (size_t)a.p.item_cate[it] * a.dc + (c - a.di);
-  return *(const f32x4*)ptr;
+  return (c < a.di) ? tbl_ld4<DT>(a.p.item_emb, (size_t)it * a.p.ld_item + c)
+                    : tbl_ld4<DT>(a.p.cate_emb, (size_t)a.p.item_cate[it] * a.dc + (c - a.di));
 }
 
+template <int DT = TLSAN_TABLE_F32>
 __device__ __forceinline__ f32x4 gather_item4c(const FwdArgs& a, int it, int ct, int c) {
-  const float* ptr = (c < a.di) ? a.p.item_emb + (size_t)it * a.p.ld_item + c
-                                : a.p.cate_emb + (size_t)ct * a.dc + (c - a.di);
-  return *(const f32x4*)ptr;
+  return (c < a.di) ? tbl_ld4<DT>(a.p.item_emb, (size_t)it * a.p.ld_item + c)
+                    : tbl_ld4<DT>(a.p.cate_emb, (size_t)ct * a.dc + (c - a.di));
 }
 
 // Per-pass, per-wave gradient accumulators of one attention block, and their deterministic
@@ -295,7 +294,7 @@ __device__ __forceinline__ void online_step(f32x4 (&mx)[NB], f32x4 (&Z)[NB], f32
 
 // LSTREAM: the long block is streamed like the short one (any Ls <= TLSAN_LS_CAP); otherwise its
 // Ls <= TLSAN_LS_MAX positions stay in registers between forward and backward.
-template <int D, int DH, bool TRAIN, bool LSTREAM>
+template <int D, int DH, bool TRAIN, bool LSTREAM, int DT = TLSAN_TABLE_F32>
 __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   using G = Geo<D, DH>;
   constexpr int NB = G::NB, CPS = G::CPS, SPW = G::SPW, NW = G::NW, NSB = G::NSB;
@@ -390,7 +389,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       scx = (gamma * P * P) * uth;  // x = e_stored * scx
       sce = (gamma * P) * uth;      // d x / d e_true
 #pragma unroll
-      for (int kb = 0; kb < NB; ++kb) xr[kb] = gather_item4c(a, it, ct, chb[kb]);
+      for (int kb = 0; kb < NB; ++kb) xr[kb] = gather_item4c<DT>(a, it, ct, chb[kb]);
     };
     if constexpr (LSTREAM) {
       float FT1[NB][NB][4], FT2[NB][NB][4];
@@ -475,7 +474,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
       for (int p = 0; p < LS; ++p)
 #pragma unroll
-        for (int kb = 0; kb < NB; ++kb) e1[p][kb] = gather_item4c(a, its[p], cts[p], chb[kb]);
+        for (int kb = 0; kb < NB; ++kb) e1[p][kb] = gather_item4c<DT>(a, its[p], cts[p], chb[kb]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int p = 0; p < LS; ++p) {
@@ -506,10 +505,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
       const int c = chb[kb];
-      const float* up = (c < a.di) ? a.p.user_emb + (size_t)uid * a.p.ld_user + c
-                                   : a.p.cate_emb + (size_t)a.b.u_cate[bb] * a.dc + (c - a.di);
-      uemb[kb] = *(const f32x4*)up * P;
-      iemb[kb] = gather_item4(a, it_i, c) * P;
+      uemb[kb] = ((c < a.di) ? tbl_ld4<DT>(a.p.user_emb, (size_t)uid * a.p.ld_user + c)
+                             : tbl_ld4<DT>(a.p.cate_emb, (size_t)a.b.u_cate[bb] * a.dc + (c - a.di))) * P;
+      iemb[kb] = gather_item4<DT>(a, it_i, c) * P;
     }
     const float ib_i = a.p.item_b[(size_t)it_i * a.p.ld_itemb];
 
@@ -589,7 +587,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       const bool vt = t < n_s;
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb) {
-        const f32x4 v = gather_item4c(a, it, ct, chb[kb]) * P;
+        const f32x4 v = gather_item4c<DT>(a, it, ct, chb[kb]) * P;
         xr[kb] = vt ? v : (f32x4)(0.0f);
       }
     };
@@ -672,7 +670,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       const int it_j = a.b.j[bb];
       float pj = 0.0f;
 #pragma unroll
-      for (int kb = 0; kb < NB; ++kb) pj += dot4(ut4[kb], gather_item4(a, it_j, chb[kb]) * P);
+      for (int kb = 0; kb < NB; ++kb) pj += dot4(ut4[kb], gather_item4<DT>(a, it_j, chb[kb]) * P);
       const float lj = sample_sum<CPS>(pj) + a.p.item_b[(size_t)it_j * a.p.ld_itemb];
       if (lead && vs) a.logits_j[bidx] = lj;
     }

@@ -11,13 +11,23 @@ static size_t fwd_smem_bytes(bool train, bool lstream) {
                           ((G::KEEP_A && train && !lstream) ? G::NW * TLSAN_LS_MAX * G::NB * 256 : 0));
 }
 
-template <int D, int DH, bool TRAIN, bool LSTREAM>
-static hipError_t launch_variant(const FwdArgs& a, int grid, hipStream_t st) {
+template <int D, int DH, bool TRAIN, bool LSTREAM, int DT>
+static hipError_t launch_variant_dt(const FwdArgs& a, int grid, hipStream_t st) {
   const size_t smem = fwd_smem_bytes<D, DH>(TRAIN, LSTREAM);
-  auto k = k_fwd_bwd<D, DH, TRAIN, LSTREAM>;
+  auto k = k_fwd_bwd<D, DH, TRAIN, LSTREAM, DT>;
   if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, st, a);
   return hipGetLastError();
+}
+
+// bf16 table storage: the common variants only (window in registers); streamed windows stay fp32
+template <int D, int DH, bool TRAIN, bool LSTREAM>
+static hipError_t launch_variant(const FwdArgs& a, int grid, hipStream_t st) {
+  if (a.p.table_dtype == TLSAN_TABLE_BF16) {
+    if constexpr (!LSTREAM) return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_BF16>(a, grid, st);
+    else return hipErrorNotSupported;
+  }
+  return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_F32>(a, grid, st);
 }
 
 template <int D, int DH>

@@ -28,6 +28,52 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define TLSAN_LS_MAX 10  // long-term windows up to this size stay in registers (reference default Ls = 10)
 #define TLSAN_LS_CAP 96  // larger windows (up to the reference's max_length = 90) are streamed
 
+// ---- table storage: fp32, or bf16 (upper half of the fp32 pattern) ---------------------------
+// 4 consecutive elements at element index idx of a table.  The storage type is a COMPILE-TIME
+// parameter of the kernels (a run-time branch around the loads makes the compiler serialise the
+// gathers: +7 us on the fused kernel).
+template <int DT>
+__device__ __forceinline__ f32x4 tbl_ld4(const float* __restrict__ base, size_t idx) {
+  if constexpr (DT == TLSAN_TABLE_F32) return *(const f32x4*)(base + idx);
+  const uint2 v = *(const uint2*)((const uint16_t*)base + idx);
+  f32x4 r;
+  r[0] = __uint_as_float(v.x << 16);
+  r[1] = __uint_as_float(v.x & 0xffff0000u);
+  r[2] = __uint_as_float(v.y << 16);
+  r[3] = __uint_as_float(v.y & 0xffff0000u);
+  return r;
+}
+// 32 well-mixed bits from (element index, stream): the random bits of the stochastic rounding
+__device__ __forceinline__ uint32_t tbl_hash(uint32_t x, uint32_t stream) {
+  x ^= stream * 0x9e3779b9u;
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+// store 4 elements; bf16: stochastic rounding -- add 16 random bits below the kept half, truncate:
+// E[stored] = value, so updates smaller than one bf16 ulp still move the parameter on average.
+// `stream` = a per-step, per-table salt (deterministic).  w receives the values actually stored.
+template <int DT>
+__device__ __forceinline__ void tbl_st4(float* __restrict__ base, size_t idx, f32x4& w, uint32_t stream) {
+  if constexpr (DT == TLSAN_TABLE_F32) {
+    *(f32x4*)(base + idx) = w;
+    return;
+  }
+  const uint32_t h0 = tbl_hash((uint32_t)idx, stream), h1 = tbl_hash((uint32_t)idx + 0x68bc21ebu, stream ^ 0x2545f491u);
+  uint32_t b[4];
+  b[0] = (__float_as_uint(w[0]) + (h0 & 0xffffu)) & 0xffff0000u;
+  b[1] = (__float_as_uint(w[1]) + (h0 >> 16)) & 0xffff0000u;
+  b[2] = (__float_as_uint(w[2]) + (h1 & 0xffffu)) & 0xffff0000u;
+  b[3] = (__float_as_uint(w[3]) + (h1 >> 16)) & 0xffff0000u;
+  uint2 v;
+  v.x = (b[0] >> 16) | b[1];
+  v.y = (b[2] >> 16) | b[3];
+  *(uint2*)((uint16_t*)base + idx) = v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = __uint_as_float(b[i]);
+}
+
 template <int D_, int DH_>
 struct Geo {
   static constexpr int D = D_;

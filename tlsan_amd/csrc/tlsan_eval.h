@@ -18,9 +18,11 @@ struct EvalArgs {
 };
 
 __device__ __forceinline__ f32x4 all_emb4(const EvalArgs& a, int it, int c) {
-  const float* ptr = (c < a.di) ? a.p.item_emb + (size_t)it * a.p.ld_item + c
-                                : a.p.cate_emb + (size_t)a.p.item_cate[it] * a.dc + (c - a.di);
-  return *(const f32x4*)ptr;
+  if (a.p.table_dtype == TLSAN_TABLE_BF16)   // (evaluation: a run-time switch is good enough here)
+    return (c < a.di) ? tbl_ld4<TLSAN_TABLE_BF16>(a.p.item_emb, (size_t)it * a.p.ld_item + c)
+                      : tbl_ld4<TLSAN_TABLE_BF16>(a.p.cate_emb, (size_t)a.p.item_cate[it] * a.dc + (c - a.di));
+  return (c < a.di) ? tbl_ld4<TLSAN_TABLE_F32>(a.p.item_emb, (size_t)it * a.p.ld_item + c)
+                    : tbl_ld4<TLSAN_TABLE_F32>(a.p.cate_emb, (size_t)a.p.item_cate[it] * a.dc + (c - a.di));
 }
 
 template <int D>

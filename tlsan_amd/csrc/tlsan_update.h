@@ -19,7 +19,8 @@ struct StateHdr {
   int32_t n_uniq[2][2];    // [index slot][item, user]: rows that received a gradient (k_index_scan)
   double St;               // sum of squares of the four STORED tables (true value: P^2 * St)
   float coef;              // global-norm clip coefficient of the current step (model.py:201)
-  float pad0[23];
+  uint32_t nstep;          // update steps taken (salt of the stochastic rounding of bf16 tables)
+  float pad0[22];
   // ---- its own 128-B line: hammered by atomics, must not share a line with anything that is read
   int32_t ticket;          // arrival counter of k_dense_finalize: the last workgroup writes the step summary
   int32_t pad1[31];
@@ -267,6 +268,7 @@ struct FinArgs {
   float lr, reg, clip, inv_B;
   int32_t norm_mode;
   int32_t commit;          // lazy L2 update: advance the table scale P (P_prev keeps the old value)
+  int32_t count_step;      // an update follows (train step, not tlsan_grads): advance hdr->nstep
   float* out_loss; float* out_gnorm; float* out_sq;
 };
 
@@ -313,6 +315,7 @@ __device__ __forceinline__ void step_summary(const FinArgs& a, int nsqd, double*
     const float coef = a.clip / fmaxf(norm, a.clip);
     a.hdr->coef = coef;
     a.hdr->P_prev = P;
+    if (a.count_step) a.hdr->nstep += 1;
     if (a.commit) a.hdr->P = P * (1.0f - a.lr * coef * a.reg);
     if (a.norm_mode == TLSAN_NORM_TF18 && a.out_gnorm) *a.out_gnorm = norm;
     if (a.out_loss) *a.out_loss = sc0 * a.inv_B + a.reg * (float)(0.5 * St);
@@ -648,6 +651,7 @@ __device__ __forceinline__ void list_accum(const ApplyArgs& a, const int* sh_pos
 struct ApCtx {
   int tid, wave, lane, grp, l16, gid, blk;
   float P, invP, step, lazy_scale;
+  uint32_t salt;      // per-step salt of the stochastic rounding (bf16 tables)
 };
 
 #define AP_STAMP(k)                                                                      \
@@ -656,18 +660,18 @@ struct ApCtx {
   } while (0)
 
 // ================= one category row per workgroup =================
-template <int MODE, bool LAZY, int NCH>
+template <int MODE, bool LAZY, int NCH, int DT>
 __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx& x, double* shd, double* shp,
                                                  int* sh_pos, int* sh_lo, int* sh_n, int* sh_wtot) {
   constexpr bool RESET = MODE == AP_UPDATE || MODE == AP_GRADS;  // counters are zero at rest
   const int tid = x.tid, wave = x.wave, lane = x.lane, grp = x.grp, l16 = x.l16, gid = x.gid;
   const int c = x.blk;
   const int W4 = a.dc / 4;
-  float* Wrow = a.p.cate_emb + (size_t)c * a.dc;
+  const size_t wrow = (size_t)c * a.dc;  // element index of the row in cate_emb
   f32x4 w[NCH];
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch)
-    if (l16 + 16 * ch < W4) w[ch] = *(const f32x4*)(Wrow + 4 * (l16 + 16 * ch));
+    if (l16 + 16 * ch < W4) w[ch] = tbl_ld4<DT>(a.p.cate_emb, wrow + 4 * (l16 + 16 * ch));
   double acc[NCH][4];
   zero_acc(acc);
   double part = 0.0;
@@ -743,14 +747,22 @@ __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx
       const int c4 = l16 + 16 * ch;
       if (c4 < W4) {
         f32x4 g;
+        const f32x4 w0 = w[ch];
+        double pe = 0.0;  // (UPDATE: the change of the sum of squares is taken from the values actually stored)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float wi = w[ch][i];
-          g[i] = apply_elem<MODE, LAZY>(wi, (float)acc[ch][i], x.P, x.invP, a.reg, x.step, x.lazy_scale, part);
+          g[i] = apply_elem<MODE, LAZY>(wi, (float)acc[ch][i], x.P, x.invP, a.reg, x.step, x.lazy_scale, pe);
           w[ch][i] = wi;
         }
         if constexpr (MODE == AP_GRADS) *(f32x4*)(a.go.cate_emb + (size_t)c * a.dc + 4 * c4) = g;
-        if constexpr (MODE == AP_UPDATE) *(f32x4*)(Wrow + 4 * c4) = w[ch];
+        if constexpr (MODE == AP_UPDATE) {
+          tbl_st4<DT>(a.p.cate_emb, wrow + 4 * c4, w[ch], x.salt ^ 0x3c6ef372u);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) part += (double)w[ch][i] * (double)w[ch][i] - (double)w0[i] * (double)w0[i];
+        } else {
+          part += pe;
+        }
       }
     }
   }
@@ -763,7 +775,7 @@ __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx
 // ================= 16 item rows or 16 user rows per workgroup (one row per 16-lane group) =========
 // NCH float4 chunks per lane cover the row (item rows: the item half only), OWN gradient rows are
 // in flight per group; longer segments are finished by the whole wavefront.
-template <int MODE, bool LAZY, bool IS_ITEM, int NCH, int OWN>
+template <int MODE, bool LAZY, bool IS_ITEM, int NCH, int OWN, int DT>
 __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx& x, int slot0, double* shp) {
   constexpr bool RESET = MODE == AP_UPDATE || MODE == AP_GRADS;
   const int lane = x.lane, grp = x.grp, l16 = x.l16;
@@ -791,14 +803,15 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
   const int ld = IS_ITEM ? a.D : a.WU;
   const int W4 = (IS_ITEM ? a.di : a.WU) / 4;
   // ---- the parameter row
-  float* Wrow = IS_ITEM ? a.p.item_emb + (size_t)row * a.p.ld_item : a.p.user_emb + (size_t)row * a.p.ld_user;
+  float* Wtab = IS_ITEM ? a.p.item_emb : a.p.user_emb;
+  const size_t wrow = IS_ITEM ? (size_t)row * a.p.ld_item : (size_t)row * a.p.ld_user;  // element index of the row
   float* Trow = a.p.usert_emb + (size_t)row * a.p.ld_usert;
   f32x4 w[NCH];
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
     const int cc = 4 * (l16 + 16 * ch);
     if (cc < a.di) {
-      w[ch] = *(const f32x4*)(Wrow + cc);
+      w[ch] = tbl_ld4<DT>(Wtab, wrow + cc);
     } else if (!IS_ITEM) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) w[ch][i] = (cc + i - a.di < a.Ls) ? Trow[cc + i - a.di] : 0.0f;
@@ -875,17 +888,25 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
       if (cc >= 4 * W4) continue;
       f32x4 g;
       if (cc < a.di) {
+        const f32x4 w0 = w[ch];
+        double pe = 0.0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float wi = w[ch][i];
-          g[i] = apply_elem<MODE, LAZY>(wi, (float)acc[ch][i], x.P, x.invP, a.reg, x.step, x.lazy_scale, part);
+          g[i] = apply_elem<MODE, LAZY>(wi, (float)acc[ch][i], x.P, x.invP, a.reg, x.step, x.lazy_scale, pe);
           w[ch][i] = wi;
         }
         if constexpr (MODE == AP_GRADS) {
           if (!a.go.sparse || n > 0)
             *(f32x4*)((IS_ITEM ? a.go.item_emb + (size_t)row * a.go.ld_item : a.go.user_emb + (size_t)row * a.go.ld_user) + cc) = g;
         }
-        if constexpr (MODE == AP_UPDATE) *(f32x4*)(Wrow + cc) = w[ch];
+        if constexpr (MODE == AP_UPDATE) {
+          tbl_st4<DT>(Wtab, wrow + cc, w[ch], x.salt ^ (IS_ITEM ? 0x85ebca6bu : 0xc2b2ae35u));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) part += (double)w[ch][i] * (double)w[ch][i] - (double)w0[i] * (double)w0[i];
+        } else {
+          part += pe;
+        }
       } else if (!IS_ITEM) {  // usert_emb columns (scalar: Ls need not be a multiple of 4)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -919,7 +940,7 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
 }
 
 // WIDE: d_item / d_cate above 64 or d_item + Ls above 128 columns (more float4 chunks per lane)
-template <int MODE, bool LAZY, bool WIDE>
+template <int MODE, bool LAZY, bool WIDE, int DT = TLSAN_TABLE_F32>
 __global__ __launch_bounds__(256) void k_apply(ApplyArgs a) {
   constexpr int NC = WIDE ? 2 : 1, NI = WIDE ? 2 : 1, NU = WIDE ? 4 : 2;
   __shared__ double shd[4 * 16 * NC * 4];
@@ -938,13 +959,14 @@ __global__ __launch_bounds__(256) void k_apply(ApplyArgs a) {
   x.invP = 1.0f / x.P;
   x.step = MODE == AP_UPDATE ? a.lr * a.hdr->coef : 0.0f;
   x.lazy_scale = x.step / (x.P * (1.0f - x.step * a.reg));
+  x.salt = a.hdr->nstep;
   const int blk = x.blk;
   if (blk < a.nbC) {
-    apply_cate_block<MODE, LAZY, NC>(a, x, shd, shp, sh_pos, sh_lo, sh_n, sh_wtot);
+    apply_cate_block<MODE, LAZY, NC, DT>(a, x, shd, shp, sh_pos, sh_lo, sh_n, sh_wtot);
   } else if (blk < a.nbC + a.nbI) {
-    apply_rows_block<MODE, LAZY, true, NI, AP_OWN>(a, x, (blk - a.nbC) * AP_ROWS_PB, shp);
+    apply_rows_block<MODE, LAZY, true, NI, AP_OWN, DT>(a, x, (blk - a.nbC) * AP_ROWS_PB, shp);
   } else if (blk < a.nbC + a.nbI + a.nbU) {
-    apply_rows_block<MODE, LAZY, false, NU, AP_OWN / 2>(a, x, (blk - a.nbC - a.nbI) * AP_ROWS_PB, shp);
+    apply_rows_block<MODE, LAZY, false, NU, AP_OWN / 2, DT>(a, x, (blk - a.nbC - a.nbI) * AP_ROWS_PB, shp);
   } else {
     // ================= 256 dense parameters =================
     const int nd = (blk - a.nbC - a.nbI - a.nbU) * 256 + x.tid;
@@ -974,12 +996,22 @@ __global__ __launch_bounds__(256) void k_apply(ApplyArgs a) {
 
 
 // stored *= P for one table (tlsan_state_renorm)
-__global__ void k_scale_table(float* W, int rows, int width, int ld, const StateHdr* hdr) {
+// (dt: storage type of the table; width % 4 == 0 for bf16 tables; bf16 values are rounded stochastically)
+__global__ void k_scale_table(float* W, int rows, int width, int ld, const StateHdr* hdr, int dt, uint32_t salt) {
   const float P = hdr->P;
-  const size_t n = (size_t)rows * width;
-  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
-    const size_t r = t / width, c = t % width;
-    W[r * ld + c] *= P;
+  if (dt == TLSAN_TABLE_F32) {
+    const size_t n = (size_t)rows * width;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+      const size_t r = t / width, c = t % width;
+      W[r * ld + c] *= P;
+    }
+    return;
+  }
+  const size_t n4 = (size_t)rows * (width / 4);
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = t / (width / 4), c = 4 * (t % (width / 4));
+    f32x4 w = tbl_ld4<TLSAN_TABLE_BF16>(W, r * ld + c) * P;
+    tbl_st4<TLSAN_TABLE_BF16>(W, r * ld + c, w, salt ^ hdr->nstep);
   }
 }
 

@@ -126,7 +126,14 @@ class DeviceBatch:
 
 
 class Model(object):
-    def __init__(self, config, item_cate_list, device="cuda:0", seed=1234, norm_mode="tf18", l2_mode="dense"):
+    def __init__(self, config, item_cate_list, device="cuda:0", seed=1234, norm_mode="tf18", l2_mode="dense",
+                 table_dtype="f32"):
+        """table_dtype: "f32" (the reference's precision) or "bf16" -- item_emb / user_emb / cate_emb stored
+        as bfloat16 (BASELINE.json configs[2]), arithmetic in fp32, updates written back with
+        deterministic stochastic rounding; usert_emb, item_b and the dense weights stay fp32."""
+        if table_dtype not in ("f32", "bf16"):
+            raise ValueError("table_dtype must be 'f32' or 'bf16'")
+        self.table_dtype = table_dtype
         self.config = config
         self.lib = L.load()
         if not torch.cuda.is_available():
@@ -221,16 +228,19 @@ class Model(object):
     def _alloc_params(self):
         cfg, dev = self.config, self.device
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
-        self.item_emb = z(cfg["item_count"], cfg["itemid_embedding_size"])
+        tdt = torch.bfloat16 if self.table_dtype == "bf16" else torch.float32
+        zt = lambda *s: torch.zeros(*s, dtype=tdt, device=dev)
+        self.item_emb = zt(cfg["item_count"], cfg["itemid_embedding_size"])
         self.item_b = z(cfg["item_count"])
-        self.user_emb = z(cfg["user_count"], cfg["itemid_embedding_size"])
+        self.user_emb = zt(cfg["user_count"], cfg["itemid_embedding_size"])
         self.usert_emb = z(cfg["user_count"], cfg["Ls"])
-        self.cate_emb = z(cfg["cate_count"], cfg["cateid_embedding_size"])
+        self.cate_emb = zt(cfg["cate_count"], cfg["cateid_embedding_size"])
         self.dense = z(self.lay.n_dense)
         self.dense_KT = z(cfg["hidden_units"], cfg["hidden_units"])
         self.cparams = L.Params(self.item_emb.data_ptr(), self.item_b.data_ptr(), self.user_emb.data_ptr(),
                                 self.usert_emb.data_ptr(), self.cate_emb.data_ptr(), self.dense.data_ptr(),
-                                self.dense_KT.data_ptr(), self.item_cate.data_ptr(), 0, 0, 0, 0, None)
+                                self.dense_KT.data_ptr(), self.item_cate.data_ptr(), 0, 0, 0, 0, None,
+                                L.TABLE_BF16 if self.table_dtype == "bf16" else L.TABLE_F32)
 
     def _dense_slices(self):
         lay, d = self.lay, self.config["hidden_units"]
@@ -266,7 +276,7 @@ class Model(object):
             a = np.asarray(p[k], np.float32)
             if tuple(a.shape) != tuple(t.shape):
                 raise ValueError("%s: shape %s != %s" % (k, a.shape, tuple(t.shape)))
-            t.copy_(torch.as_tensor(a))
+            t.copy_(torch.as_tensor(a))      # (bf16 tables: round to nearest even on load)
         self.dense.copy_(torch.as_tensor(self.pack_dense(p)))
         if hasattr(self, "state"):
             self._sync_state()
@@ -282,7 +292,7 @@ class Model(object):
 
     def get_params(self):
         self.fold_scale()
-        out = {k: getattr(self, k).detach().cpu().numpy().copy() for k in TABLE_KEYS}
+        out = {k: getattr(self, k).detach().float().cpu().numpy().copy() for k in TABLE_KEYS}
         out.update(self.unpack_dense(self.dense.detach().cpu().numpy()))
         return out
 
@@ -404,7 +414,7 @@ class Model(object):
         """tf.gradients(loss, trainables) (model.py:198) as numpy arrays; test/diagnostic API."""
         db = self.device_batch(batch)
         ws = self._workspace(db.B, db.Sn)
-        g = {k: torch.zeros_like(getattr(self, k)) for k in TABLE_KEYS}
+        g = {k: torch.zeros_like(getattr(self, k), dtype=torch.float32) for k in TABLE_KEYS}
         gd = torch.zeros_like(self.dense)
         logits = torch.zeros(db.B, dtype=torch.float32, device=self.device)
         go = L.GradsOut(g["item_emb"].data_ptr(), g["item_b"].data_ptr(), g["user_emb"].data_ptr(),

@@ -40,6 +40,9 @@ def parse(argv=None):
     ap.add_argument("--max_steps", type=int, default=0, help="stop early (0 = run max_epochs)")
     ap.add_argument("--norm_mode", default="tf18", choices=["tf18", "dedup"])
     ap.add_argument("--quiet", action="store_true")
+    ap.add_argument("--table_dtype", default="f32", choices=["f32", "bf16"],
+                    help="storage of item/user/category tables (bf16: fp32 arithmetic, stochastic rounding on update)")
+    ap.add_argument("--l2_mode", default="dense", choices=["dense", "lazy"])
     ap.add_argument("--device_input", type=int, default=1,
                     help="1: keep the sample sets in HBM and assemble batches on the device (tlsan_amd.device_input); "
                          "0: the host batcher (tlsan_amd.input), one upload per batch")
@@ -100,7 +103,7 @@ def train(args):
     config = {name: getattr(args, name) for name, _, _ in FLAGS}
     config.update(user_count=U, item_count=I, cate_count=Cc, from_scratch=args.from_scratch)
     say(json.dumps(config, indent=4), flush=True)
-    model = Model(config, icl, device=args.device, norm_mode=args.norm_mode)
+    model = Model(config, icl, device=args.device, norm_mode=args.norm_mode, l2_mode=args.l2_mode, table_dtype=args.table_dtype)
     if args.device_input:
         from .device_input import DeviceDataInput, DevicePackedSet
         train_set, test_set = DevicePackedSet(train_set, args.device), DevicePackedSet(test_set, args.device)
