@@ -43,6 +43,9 @@ def parse():
                          "dense: every row decayed every step")
     ap.add_argument("--table-dtype", default="f32", choices=["f32", "bf16"],
                     help="storage of the item/user/category tables (arithmetic is fp32 either way)")
+    ap.add_argument("--also-bf16", type=int, default=1,
+                    help="single GPU, fp32 run: also time the same steps with bf16 tables (BASELINE.json configs[2] names "
+                         "bf16 storage) and report them under 'bf16_tables'")
     ap.add_argument("--graph", type=int, default=0, help="replay hipGraph-captured steps instead of eager launches (single-GPU path)")
     ap.add_argument("--prefetch", type=int, default=1,
                     help="eager mode: build the next batch's destination index on a second stream during the step")
@@ -165,6 +168,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss = float(model.last_loss.item()) if sharded else float(model._out[0].item())
+    also = None
+    if args.also_bf16 and not sharded and args.table_dtype == "f32" and not use_graph:
+        # same batches, same step count, tables stored as bf16 (the storage BASELINE.json configs[2] names)
+        m16 = Model(cfg, icl, device=dev, l2_mode=args.l2_mode, table_dtype="bf16")
+        for s in range(args.warmup):
+            m16.train_async(dbs[s % len(dbs)], lr, next_batch=dbs[(s + 1) % len(dbs)])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for s in range(args.steps):
+            k = (args.warmup + s) % len(dbs)
+            m16.train_async(dbs[k], lr, next_batch=dbs[(k + 1) % len(dbs)])
+        torch.cuda.synchronize()
+        dt16 = time.perf_counter() - t1
+        ab16 = float(np.mean([synth.algorithmic_bytes(cfg, host_batches[(args.warmup + s) % len(host_batches)], 2)["train_step"]
+                              for s in range(args.steps)]))
+        also = {"value": round(args.steps * B / dt16, 1), "unit": "user-sequences/s", "ms_per_step": round(dt16 / args.steps * 1e3, 4),
+                "storage": "item/user/category tables bf16, fp32 arithmetic, stochastic rounding on update",
+                "step_algorithmic_bytes": round(ab16), "step_frac": round(ab16 / (dt16 / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                "final_loss": round(float(m16._out[0].item()), 6)}
+        del m16
     if not np.isfinite(loss):
         raise SystemExit("bench.py: non-finite loss %r" % loss)
 
@@ -226,6 +249,8 @@ def main():
                                          "on a second stream" if (args.prefetch and not sharded) else "eager"),
             "final_loss": round(loss, 6),
         }
+        if also is not None:
+            out["bf16_tables"] = also
         if nrec and args.profile_level >= 2:
             out["segments_ms"] = {n: round(float(seg[:, i].mean()), 5) for i, n in enumerate(L.PROF_SEGMENTS)}
         if not args.no_cpu_baseline and world == 1:
