@@ -434,8 +434,6 @@ static int launch_fwd(const Shape& s, bool train, bool v2, const FwdArgs& a, hip
   int grid = a.ngroups < 4096 ? a.ngroups : 4096;
   hipError_t e;
   const bool lstream = a.Ls > TLSAN_LS_MAX;  // long windows are streamed, short ones stay in registers
-  if (train && lstream && s.D == 256)
-    return fail(TLSAN_E_UNSUPPORTED, "training with hidden_units=256 and Ls > %d needs more LDS than one CU has in this build", TLSAN_LS_MAX);
   if (v2) e = tlsan_launch_fwd_bwd2(s.D, a, grid, hs);
   else if (s.D == 64) e = tlsan_launch_fwd_bwd_d64(train, lstream, a, grid, hs);
   else if (s.D == 128) e = tlsan_launch_fwd_bwd_d128(train, lstream, a, grid, hs);

@@ -248,6 +248,62 @@ __device__ __forceinline__ void stage_accs(AccSet<NB>& A, f32x4 (&extra)[NB], fl
   }
 }
 
+// Half of the above (Geo::SPLIT): PART 0 = {dW1, db1, extra}, PART 1 = {dW2, db2}.
+template <int NB, int CPS, bool EXTRA, int PART>
+__device__ __forceinline__ void stage_part(AccSet<NB>& A, f32x4 (&extra)[NB], float* __restrict__ stage, int lane) {
+  float* base = stage + lane * 4;
+  int v = 0;
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb) *(f32x4*)(base + (v++) * 256) = PART == 0 ? A.dW1[kb][jb] : A.dW2[kb][jb];
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb) {
+    f32x4 t = PART == 0 ? A.db1[kb] : A.db2[kb];
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) t[i] += __shfl_xor(t[i], o);
+    *(f32x4*)(base + (v++) * 256) = t;
+  }
+  if constexpr (EXTRA && PART == 0) {
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+      f32x4 t = extra[kb];
+#pragma unroll
+      for (int o = CPS; o < 16; o <<= 1)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] += __shfl_xor(t[i], o);
+      *(f32x4*)(base + (v++) * 256) = t;
+    }
+  }
+}
+
+template <typename G, bool EXTRA, int PART>
+__device__ __forceinline__ void reduce_part(const float* __restrict__ stage, float* __restrict__ out, int pW, int pB,
+                                            int tid) {
+  constexpr int NB = G::NB, CW = G::CW, CPS = G::CPS, NW = G::NW;
+  constexpr int NV = NB * NB + NB + ((EXTRA && PART == 0) ? NB : 0);
+  for (int o = tid; o < NV * 256; o += NW * 64) {
+    const int v = o >> 8, l4 = o & 255, ln = l4 >> 2, i = l4 & 3;
+    const int q = ln >> 4, r = ln & 15;
+    float s = 0.0f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += stage[(size_t)w * G::WSCR + o];
+    if (v < NB * NB) {
+      const int kb = v / NB, jb = v % NB;
+      out[pW + (16 * kb + 4 * q + i) * CW + 16 * jb + r] = s;
+    } else if (v < NB * NB + NB) {
+      const int kb = v - NB * NB;
+      if (r == 0) out[pB + 16 * kb + 4 * q + i] = s;
+    } else {
+      const int kb = v - (NB * NB + NB);
+      const int s_loc = r / CPS, col = r % CPS;
+      if (s_loc == 0) out[G::P_K0 + col * CW + 16 * kb + 4 * q + i] = s;
+    }
+  }
+}
+
 // all threads: sum the staged vectors over the wavefronts (fixed order) and scatter them to
 // the partial record.  pW1/pB1/pW2/pB2 = section offsets of this attention block.
 template <typename G, bool EXTRA>
@@ -758,7 +814,15 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           }
         }
         if (NBUF > 1) bwd_dw<NB, TSTR>(T + ((pmax2 - 1) & 1) * TB, q, r, acc.dW1, acc.dW2);
-        stage_accs<NB, CPS, true>(acc, dk0, T, lane);
+        if constexpr (G::SPLIT) {  // two halves through the (smaller) staging area
+          stage_part<NB, CPS, true, 0>(acc, dk0, T, lane);
+          __syncthreads();
+          reduce_part<G, true, 0>(sT, prec, G::P_F2W1, G::P_F2B1, tid);
+          __syncthreads();
+          stage_part<NB, CPS, true, 1>(acc, dk0, T, lane);
+        } else {
+          stage_accs<NB, CPS, true>(acc, dk0, T, lane);
+        }
       }
 #pragma unroll
       for (int t = 0; t < G::TPW; ++t) {  // B fragments of the dlong GEMM (K rows), before the barrier
@@ -770,7 +834,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       TLSAN_STAMP(6);
       __syncthreads();
       TLSAN_STAMP(7);
-      reduce_staged<G, true>(sT, prec, G::P_F2W1, G::P_F2B1, G::P_F2W2, G::P_F2B2, tid);
+      if constexpr (G::SPLIT) reduce_part<G, true, 1>(sT, prec, G::P_F2W2, G::P_F2B2, tid);
+      else reduce_staged<G, true>(sT, prec, G::P_F2W1, G::P_F2B1, G::P_F2W2, G::P_F2B2, tid);
       // ---------------------------------------------------------------- P4: dlong GEMM
       // dlong[s][k] = sum_j dbridge[s][j] K[k][j]
 #pragma unroll
@@ -859,7 +924,15 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           }
           if (lead && vs)  // padded long slots and the row's alignment padding
             for (int p = a.di + n_l; p < a.WU; ++p) a.Gu[(size_t)sP[srow * PSTR + P_USR] * a.WU + p] = 0.0f;
+          if constexpr (G::SPLIT) {
+          stage_part<NB, CPS, false, 0>(acc, dummy, T, lane);
+          __syncthreads();
+          reduce_part<G, false, 0>(sT, prec, G::P_F1W1, G::P_F1B1, tid);
+          __syncthreads();
+          stage_part<NB, CPS, false, 1>(acc, dummy, T, lane);
+        } else {
           stage_accs<NB, CPS, false>(acc, dummy, T, lane);
+        }
         } else {
         AccSet<NB> acc;
         acc.zero();
@@ -928,7 +1001,15 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         }
         if (lead && vs)
           for (int p = a.di + Ls; p < a.WU; ++p) a.Gu[(size_t)sP[srow * PSTR + P_USR] * a.WU + p] = 0.0f;
-        stage_accs<NB, CPS, false>(acc, dummy, T, lane);
+        if constexpr (G::SPLIT) {
+          stage_part<NB, CPS, false, 0>(acc, dummy, T, lane);
+          __syncthreads();
+          reduce_part<G, false, 0>(sT, prec, G::P_F1W1, G::P_F1B1, tid);
+          __syncthreads();
+          stage_part<NB, CPS, false, 1>(acc, dummy, T, lane);
+        } else {
+          stage_accs<NB, CPS, false>(acc, dummy, T, lane);
+        }
         }
       }
       // scalars of this pass: wave-reduce, stage, one thread sums the waves in fixed order
@@ -948,7 +1029,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       }
       TLSAN_STAMP(10);
       __syncthreads();
-      reduce_staged<G, false>(sT, prec, G::P_F1W1, G::P_F1B1, G::P_F1W2, G::P_F1B2, tid);
+      if constexpr (G::SPLIT) reduce_part<G, false, 1>(sT, prec, G::P_F1W2, G::P_F1B2, tid);
+      else reduce_staged<G, false>(sT, prec, G::P_F1W1, G::P_F1B1, G::P_F1W2, G::P_F1B2, tid);
       if (tid < 3) {
         float s = 0.0f;
 #pragma unroll

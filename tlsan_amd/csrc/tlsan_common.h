@@ -95,7 +95,10 @@ struct Geo {
   static constexpr bool KEEP_A = NB == 1;           // long block's softmax weights kept in LDS for the backward
   static constexpr bool USE_SW = NB == 1;           // attention weights in LDS when they fit
   static constexpr int WSCR_T = NBUF * TBUF;
-  static constexpr int WSCR_A = (2 * NB * NB + 3 * NB) * 256;
+  // staged gradient accumulators: all 2 NB^2 + 3 NB vectors at once, or (NB > 1, to fit the LDS) in two
+  // halves {dW1, db1, dk0} / {dW2, db2}
+  static constexpr bool SPLIT = NB > 1;
+  static constexpr int WSCR_A = (SPLIT ? (NB * NB + 2 * NB) : (2 * NB * NB + 3 * NB)) * 256;
   static constexpr int WSCR = WSCR_T > WSCR_A ? WSCR_T : WSCR_A;
   // per-workgroup partial record (effective CWxCW layout), see k_dense_finalize
   static constexpr int P_W = CW * CW;
