@@ -110,7 +110,30 @@ def record_batches(ref_input, data, cls_name, batch_size, k, which):
     return rec
 
 
+def export_reviews():
+    """The INPUT of build_dataset.py as plain arrays -> ``reviews_<name>.npz``: the remapped review
+    log (reviewerID, asin, unixReviewTime in days; DataFrame row order), the item -> category map
+    and the counts that ``Data/<name>.pkl`` holds.  Together with ``packed_<name>.npz`` (the tuples
+    the real script built from it) this pins tlsan_amd/build_dataset.py."""
+    for short, data_name in DATASETS.items():
+        with open(os.path.join(REF, "Data", data_name + ".pkl"), "rb") as f:
+            reviews_df, meta_df = pickle.load(f)
+            icl = pickle.load(f)
+            counts = pickle.load(f)
+        assert (meta_df["asin"].values == np.arange(len(meta_df))).all()
+        assert (meta_df["categories"].values == np.asarray(icl)).all()   # what the script's per-item lookup returns
+        np.savez_compressed(
+            os.path.join(OUT, "reviews_%s.npz" % short),
+            reviewerID=reviews_df["reviewerID"].values.astype(np.int32), asin=reviews_df["asin"].values.astype(np.int32),
+            unixReviewTime=reviews_df["unixReviewTime"].values.astype(np.int32),
+            item_cate_list=np.asarray(icl, np.int32), counts=np.array(counts, np.int64))
+        print("reviews_%s.npz: %d rows" % (short, len(reviews_df)))
+
+
 def main():
+    if "--reviews-only" in sys.argv:
+        return export_reviews()
+    export_reviews()
     ref_input = load_ref_input()
     for short, data_name in DATASETS.items():
         print("building", data_name, flush=True)
