@@ -480,6 +480,15 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         for (int p = base; p < pend; ++p) {
           f32x4 xv[NB], z[NB], m2[NB];
           float scx, sce;
+          if constexpr (G::AT_USE && !LSTREAM) {  // weight fragments from LDS at the use
+            const int zz = opaque_zero(p);
+            if constexpr (G::AT_USE_T) {
+              load_frag_T<DH, NB>(w1W1 + zz, q, r, FT1);
+              load_bias<DH, NB>(w1b1 + zz, q, b1);
+              load_frag_T<DH, NB>(w1W2 + zz, q, r, FT2);
+              load_bias<DH, NB>(w1b2 + zz, q, b2);
+            }
+          }
           fetch_lrow(p, xv, scx, sce);
           const bool vp = p < n_l;
 #pragma unroll
@@ -672,6 +681,14 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     for (int p = 1; p < pmax2; ++p) {  // wave-uniform trip count
       const bool vt = (p - 1) < n_s;
       f32x4 xv[NB], z[NB], m2[NB];
+      if constexpr (G::AT_USE && !LSTREAM && G::AT_USE_T) {  // weight fragments from LDS at the use
+        const int zz = opaque_zero(p);
+        load_frag_T<DH, NB>(w2W1 + zz, q, r, FT1);
+        load_bias<DH, NB>(w2b1 + zz, q, b1);
+        load_frag_T<DH, NB>(w2W2 + zz, q, r, FT2);
+        load_bias<DH, NB>(w2b2 + zz, q, b2);
+      }
+
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb) xv[kb] = xnext[kb];
       if (p + 1 < pmax2) {  // prefetch the next row while this one is processed
@@ -773,6 +790,18 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         for (int p = 0; p < pmax2; ++p) {  // wave-uniform trip count
           const bool vt = p < n_pos;
           f32x4 xv[NB], z1[NB], zr[NB], m2[NB], av[NB], dx[NB];
+          if constexpr (G::AT_USE && !LSTREAM) {  // weight fragments from LDS at the use
+            const int zz = opaque_zero(p);
+            if constexpr (G::AT_USE_T) {
+              load_frag_T<DH, NB>(w2W1 + zz, q, r, FT1);
+              load_bias<DH, NB>(w2b1 + zz, q, b1);
+              load_frag_T<DH, NB>(w2W2 + zz, q, r, FT2);
+              load_bias<DH, NB>(w2b2 + zz, q, b2);
+            }
+            load_frag_N<DH, NB>(w2W1 + zz, q, r, FN1);
+            load_frag_N<DH, NB>(w2W2 + zz, q, r, FN2);
+          }
+
 #pragma unroll
           for (int kb = 0; kb < NB; ++kb) xv[kb] = xn2[kb];
           if (p + 1 < pmax2) {  // session entry t = p for the next position
@@ -881,6 +910,18 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
               const bool vp = p < n_l;
               f32x4 ev[NB], xv[NB], z1[NB], zr[NB], m2[NB], av[NB], dx[NB];
               float scx, sce;
+          if constexpr (G::AT_USE && !LSTREAM) {  // weight fragments from LDS at the use
+            const int zz = opaque_zero(p);
+            if constexpr (G::AT_USE_T) {
+              load_frag_T<DH, NB>(w1W1 + zz, q, r, FT1);
+              load_bias<DH, NB>(w1b1 + zz, q, b1);
+              load_frag_T<DH, NB>(w1W2 + zz, q, r, FT2);
+              load_bias<DH, NB>(w1b2 + zz, q, b2);
+            }
+            load_frag_N<DH, NB>(w1W1 + zz, q, r, FN1);
+            load_frag_N<DH, NB>(w1W2 + zz, q, r, FN2);
+          }
+
               fetch_lrow(p, ev, scx, sce);
 #pragma unroll
               for (int kb = 0; kb < NB; ++kb) {
@@ -946,6 +987,17 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             const float scp = (gamma * P * P) * uth;  // x = e_stored * scp
             const float sce = (gamma * P) * uth;      // d x / d e_true
             f32x4 xv[NB], z1[NB], zr[NB], m2[NB], av[NB], dx[NB];
+          if constexpr (G::AT_USE && !LSTREAM) {  // weight fragments from LDS at the use
+            const int zz = opaque_zero(p);
+            if constexpr (G::AT_USE_T) {
+              load_frag_T<DH, NB>(w1W1 + zz, q, r, FT1);
+              load_bias<DH, NB>(w1b1 + zz, q, b1);
+              load_frag_T<DH, NB>(w1W2 + zz, q, r, FT2);
+              load_bias<DH, NB>(w1b2 + zz, q, b2);
+            }
+            load_frag_N<DH, NB>(w1W1 + zz, q, r, FN1);
+            load_frag_N<DH, NB>(w1W2 + zz, q, r, FN2);
+          }
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) xv[kb] = e1[p][kb] * scp;
             if (p == 1) TLSAN_STAMP(12);

@@ -76,15 +76,8 @@ __device__ __forceinline__ f32x4 gather2(const FwdArgs& a, int it, int ct, int c
   return ld4(a.p.cate_emb, (uint32_t)ct * (uint32_t)a.dc + (uint32_t)(c - a.di));
 }
 
-// A zero the optimiser cannot see through.  Weight fragments live in LDS; adding this to their
-// address at every use keeps the loads AT the use instead of hoisted out of the position loops,
-// where six fragments would pin 24 VGPRs for a whole phase (the kernel must fit 128).
-__device__ __forceinline__ int opaque_zero(int x) {
-  int z;
-  asm volatile("v_mov_b32 %0, 0" : "=v"(z) : "v"(x));
-  return z;
-}
-
+// (opaque_zero, tlsan_common.h: weight fragments live in LDS; adding it to their address at every use keeps
+// the loads AT the use instead of hoisted out of the position loops, where six fragments would pin 24 VGPRs)
 // the two per-head maps of feature_wise_attention (model.py:380-382) with fragments fetched from LDS
 template <int DH>
 __device__ __forceinline__ void fwd_maps(const float* W1, const float* b1, const float* W2, const float* b2, int q, int r,

@@ -74,6 +74,13 @@ __device__ __forceinline__ void tbl_st4(float* __restrict__ base, size_t idx, f3
   for (int i = 0; i < 4; ++i) w[i] = __uint_as_float(b[i]);
 }
 
+// a zero the optimiser cannot see through (keeps LDS weight loads at their use; see Geo::AT_USE)
+__device__ __forceinline__ int opaque_zero(int x) {
+  int z;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(z) : "v"(x));
+  return z;
+}
+
 template <int D_, int DH_>
 struct Geo {
   static constexpr int D = D_;
@@ -93,7 +100,13 @@ struct Geo {
   static constexpr int TBUF = 4 * NB * 16 * TSTR;   // one buffer: x, dz1, m1, dm2 tiles
   static constexpr int NBUF = 1;                    // (double-buffering the tiles bought nothing measurable)
   static constexpr bool KEEP_A = NB == 1;           // long block's softmax weights kept in LDS for the backward
-  static constexpr bool USE_SW = NB == 1;           // attention weights in LDS when they fit
+  static constexpr bool USE_SW = true;              // attention weights staged in LDS
+  // NB > 1 (d = 256): six 16-register weight fragments cannot stay in registers for a whole phase:
+  // the window-in-registers variants re-read them from LDS at every position (behind a value the
+  // optimiser cannot hoist): 274 -> 239 us/step at B=4096.  The streamed variants keep them in
+  // registers (spilled): re-reading per position measured slower there (707 vs 659 us at Ls=90).
+  static constexpr bool AT_USE = NB > 1;
+  static constexpr bool AT_USE_T = true;            // (forward fragments as well: d=256, Ls=10: 239 us/step vs 261 without)
   static constexpr int WSCR_T = NBUF * TBUF;
   // staged gradient accumulators: all 2 NB^2 + 3 NB vectors at once, or (NB > 1, to fit the LDS) in two
   // halves {dW1, db1, dk0} / {dW2, db2}
