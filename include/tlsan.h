@@ -239,6 +239,19 @@ int tlsan_eval_ranks(const tlsan_dims* dims, const tlsan_params* p, const float*
                      const int32_t* labels, int32_t B, int32_t* ranks,
                      void* ws, size_t ws_bytes, void* stream);
 
+/* Item-sharded all-items scoring (the evaluation half of the multi-GPU path):
+ *   tlsan_eval_label_scores: scores[b] = u_t[b] . all_emb[labels[b]] + item_b[labels[b]] on a table that
+ *     holds the label rows (the rank that owns the users: its compact per-step table);
+ *   tlsan_eval_counts_shard: for every row of u_t (the users of ALL ranks, all-gathered) the number
+ *     of items of THIS rank's shard ranked ahead of the label under tf.nn.top_k's order; local item n
+ *     is global item n * id_mul + id_add (ties -> lower GLOBAL id first).  Summing the counts over
+ *     the ranks gives tlsan_eval_ranks' result on the unsharded table. */
+int tlsan_eval_label_scores(const tlsan_dims* dims, const tlsan_params* p, const float* u_t, const int32_t* labels,
+                            int32_t B, float* scores, void* ws, size_t ws_bytes, void* stream);
+int tlsan_eval_counts_shard(const tlsan_dims* dims, const tlsan_params* p, const float* u_t, const float* label_scores,
+                            const int32_t* labels_global, int32_t B, int32_t id_mul, int32_t id_add, int32_t* counts,
+                            void* ws, size_t ws_bytes, void* stream);
+
 /* Deterministic scatter-apply on one row table (the owner-side half of the multi-GPU step, and
  * the stand-alone form of the embedding update of model.py:198-205):
  *   for every row r < nrows:  g = gscale * sum_{k: dest[k]==r} grows[k] (+ reg * W[r] on the

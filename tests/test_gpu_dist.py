@@ -87,6 +87,24 @@ def _worker(rank, world, port, ret, d, prefetch):
                 du, dr = g - p[k], q[k] - p[k]
                 assert np.abs(du - dr).max() < 5e-4 * (np.abs(dr).max() + 1e-9) + 5e-7, (k, float(np.abs(du - dr).max()), float(np.abs(dr).max()))
         assert 0.0 <= auc <= 1.0
+        # all-items ranking with the items sharded == the oracle's ranks on the gathered parameters
+        tb = steps[0][rank]
+        ranks = m.label_ranks(tuple(list(_tuple(tb))[:2] + [tb["i"][::-1].copy()] + list(_tuple(tb))[3:])).cpu().numpy()
+        full = {k: np.asarray(v, np.float64) for k, v in got.items()}
+        out = orc.forward(full, cat, tb, 8)
+        sc = orc.all_item_scores(full, cat, out["u_t"]) if hasattr(orc, "all_item_scores") else None
+        if sc is None:
+            all_emb = np.concatenate([full["item_emb"], full["cate_emb"][np.asarray(cat)]], 1)
+            sc = out["u_t"] @ all_emb.T + full["item_b"][None, :]
+        lab = np.asarray(tb["i"])
+        own = sc[np.arange(len(lab)), lab]
+        ids = np.arange(sc.shape[1])[None, :]
+        ref_rank = ((sc > own[:, None]) | ((sc == own[:, None]) & (ids < lab[:, None]))).sum(1)
+        margin = np.abs(sc - own[:, None]); margin[np.arange(len(lab)), lab] = 1.0
+        clear = margin.min(1) > 1e-4            # rows whose rank does not hinge on an fp32-level near tie
+        assert clear.sum() >= len(lab) // 2 and np.array_equal(ranks[clear], ref_rank[clear]), (ranks, ref_rank)
+        rec = m.eval_recall(None, tuple(list(_tuple(tb))[:2] + [tb["i"][::-1].copy()] + list(_tuple(tb))[3:]))
+        assert len(rec) == 6 and all(0.0 <= x <= 1.0 for x in rec) and rec == sorted(rec)   # R@1 <= ... <= R@50, global batch
         ret[rank] = "ok"
     except Exception:
         import traceback

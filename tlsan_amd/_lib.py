@@ -17,7 +17,7 @@ EXPORTS = [
     "tlsan_abi_version", "tlsan_last_error", "tlsan_dense_layout_of", "tlsan_workspace_bytes",
     "tlsan_state_bytes", "tlsan_state_init", "tlsan_state_reindex", "tlsan_state_recategorize", "tlsan_state_scale",
     "tlsan_state_renorm", "tlsan_sync_derived", "tlsan_forward",
-    "tlsan_train_step", "tlsan_batch_pack", "tlsan_batch_index", "tlsan_grads", "tlsan_eval_ranks", "tlsan_profile_enable", "tlsan_profile_stride",
+    "tlsan_train_step", "tlsan_batch_pack", "tlsan_batch_index", "tlsan_grads", "tlsan_eval_ranks", "tlsan_eval_label_scores", "tlsan_eval_counts_shard", "tlsan_profile_enable", "tlsan_profile_stride",
     "tlsan_profile_collect", "tlsan_debug_stamps", "tlsan_rows_apply_workspace", "tlsan_rows_apply", "tlsan_scan_compact",
     "tlsan_route_plan", "tlsan_shard_gather", "tlsan_shard_summary", "tlsan_shard_apply_workspace", "tlsan_shard_apply",
 ]
@@ -112,6 +112,12 @@ def load():
                                 C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.tlsan_eval_ranks.argtypes = [P(Dims), P(Params), C.c_void_p, C.c_void_p, C.c_int32,
                                      C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.tlsan_eval_label_scores.argtypes = [P(Dims), P(Params), C.c_void_p, C.c_void_p, C.c_int32,
+                                            C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.tlsan_eval_label_scores.restype = C.c_int
+    lib.tlsan_eval_counts_shard.argtypes = [P(Dims), P(Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                            C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.tlsan_eval_counts_shard.restype = C.c_int
     lib.tlsan_profile_enable.argtypes = [C.c_int]
     lib.tlsan_profile_enable.restype = C.c_int
     lib.tlsan_profile_stride.argtypes = [C.c_int]

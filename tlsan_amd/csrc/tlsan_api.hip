@@ -667,13 +667,37 @@ int tlsan_grads(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch* b
   return TLSAN_OK;
 }
 
+static int eval_ranks_impl(const tlsan_dims* d, const tlsan_params* p, const float* u_t, const int32_t* labels, int32_t B,
+                           int32_t* ranks, void* ws, size_t ws_bytes, void* stream, const float* s_label_in, int id_mul,
+                           int id_add, float* s_label_out);
+
 int tlsan_eval_ranks(const tlsan_dims* d, const tlsan_params* p, const float* u_t, const int32_t* labels, int32_t B,
                      int32_t* ranks, void* ws, size_t ws_bytes, void* stream) {
+  return eval_ranks_impl(d, p, u_t, labels, B, ranks, ws, ws_bytes, stream, nullptr, 1, 0, nullptr);
+}
+
+int tlsan_eval_label_scores(const tlsan_dims* d, const tlsan_params* p, const float* u_t, const int32_t* labels, int32_t B,
+                            float* scores, void* ws, size_t ws_bytes, void* stream) {
+  if (!scores) return fail(TLSAN_E_BADARG, "tlsan_eval_label_scores: scores is NULL");
+  return eval_ranks_impl(d, p, u_t, labels, B, nullptr, ws, ws_bytes, stream, nullptr, 1, 0, scores);
+}
+
+int tlsan_eval_counts_shard(const tlsan_dims* d, const tlsan_params* p, const float* u_t, const float* label_scores,
+                            const int32_t* labels_global, int32_t B, int32_t id_mul, int32_t id_add, int32_t* counts,
+                            void* ws, size_t ws_bytes, void* stream) {
+  if (!label_scores || !counts || id_mul < 1 || id_add < 0) return fail(TLSAN_E_BADARG, "tlsan_eval_counts_shard: bad arguments");
+  return eval_ranks_impl(d, p, u_t, labels_global, B, counts, ws, ws_bytes, stream, label_scores, id_mul, id_add, nullptr);
+}
+
+// s_label_in == NULL: the label's score is computed here (labels index THIS table); s_label_out != NULL: only that.
+static int eval_ranks_impl(const tlsan_dims* d, const tlsan_params* p, const float* u_t, const int32_t* labels, int32_t B,
+                           int32_t* ranks, void* ws, size_t ws_bytes, void* stream, const float* s_label_in, int id_mul,
+                           int id_add, float* s_label_out) {
   Shape s;
   int rc = shape_of(d, &s);
   if (rc) return rc;
   if ((rc = check_params(p))) return rc;
-  if (!u_t || !labels || !ranks || B < 1) return fail(TLSAN_E_BADARG, "bad eval arguments");
+  if (!u_t || !labels || (!ranks && !s_label_out) || B < 1) return fail(TLSAN_E_BADARG, "bad eval arguments");
   if (!ws) return fail(TLSAN_E_WORKSPACE, "ws is NULL");
   Ws w;
   carve(d, s, B, 0, (char*)ws, &w);
@@ -682,8 +706,9 @@ int tlsan_eval_ranks(const tlsan_dims* d, const tlsan_params* p, const float* u_
   EvalArgs e;
   memset(&e, 0, sizeof(e));
   e.p = norm_params(p, d); e.u_t = u_t; e.labels = labels; e.B = B; e.I = d->item_count; e.di = d->d_item; e.dc = d->d_cate;
-  e.s_label = w.s_label; e.ranks = ranks; e.all_emb = w.all_emb;
-  if (hipMemsetAsync(ranks, 0, sizeof(int32_t) * (size_t)B, hs) != hipSuccess) return fail(TLSAN_E_LAUNCH, "memset ranks");
+  e.s_label = s_label_out ? s_label_out : (s_label_in ? const_cast<float*>(s_label_in) : w.s_label);
+  e.ranks = ranks; e.all_emb = w.all_emb; e.id_mul = id_mul; e.id_add = id_add;
+  if (ranks && hipMemsetAsync(ranks, 0, sizeof(int32_t) * (size_t)B, hs) != hipSuccess) return fail(TLSAN_E_LAUNCH, "memset ranks");
   const int ut = (B + 15) / 16;
   const int ntiles = (d->item_count + 15) / 16;
   int chunks = (ntiles + 3) / 4;
@@ -695,7 +720,8 @@ int tlsan_eval_ranks(const tlsan_dims* d, const tlsan_params* p, const float* u_
   if (ngrp > want) ngrp = want;
 #define EVAL_LAUNCH(DD)                                                                                  \
   do {                                                                                                   \
-    hipLaunchKernelGGL(k_eval_label<DD>, dim3(ut), dim3(64), 0, hs, e);                                  \
+    if (!s_label_in) hipLaunchKernelGGL(k_eval_label<DD>, dim3(ut), dim3(64), 0, hs, e);                 \
+    if (!ranks) break;                                                                                   \
     if (e.all_emb) {                                                                                     \
       hipLaunchKernelGGL(k_all_emb<DD>, dim3(nae), dim3(256), 0, hs, e);                                 \
       hipLaunchKernelGGL(k_eval_rank_dense<DD>, dim3(ut, ngrp), dim3(256), 0, hs, e);                    \

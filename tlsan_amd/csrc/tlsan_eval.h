@@ -15,6 +15,8 @@ struct EvalArgs {
   float* s_label;          // [B]
   int32_t* ranks;          // [B], zeroed before k_eval_rank
   float* all_emb;          // [I, D] dense [item_emb || cate_emb[item_cate]] (model.py:89-90), or NULL
+  // item-sharded scoring: local item n has the global id n * id_mul + id_add (labels are global ids)
+  int32_t id_mul, id_add;
 };
 
 __device__ __forceinline__ f32x4 all_emb4(const EvalArgs& a, int it, int c) {
@@ -93,10 +95,11 @@ __global__ __launch_bounds__(256) void k_eval_rank(EvalArgs a) {
     const int item = vn ? n : a.I - 1;
     const f32x4 acc = score_tile<D>(a, af, item, q) * P;
     const float bias = a.p.item_b[(size_t)item * a.p.ld_itemb];
+    const int gn = n * a.id_mul + a.id_add;  // global item id
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float s = acc[i] + bias;
-      const bool ahead = vn && n != lab[i] && (s > sl[i] || (s == sl[i] && n < lab[i]));
+      const bool ahead = vn && gn != lab[i] && (s > sl[i] || (s == sl[i] && gn < lab[i]));
       cnt[i] += ahead ? 1 : 0;
     }
   }
@@ -165,12 +168,13 @@ __global__ __launch_bounds__(256) void k_eval_rank_dense(EvalArgs a) {
     for (int tt = 0; tt < 4; ++tt) {
       const int n = n0 + 16 * tt + r;
       const bool vn = n < a.I;
+      const int gn = n * a.id_mul + a.id_add;  // global item id
       const float bias = a.p.item_b[(size_t)item[tt] * a.p.ld_itemb];
       const f32x4 sc = acc[tt] * P;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float s = sc[i] + bias;
-        const bool ahead = vn && n != lab[i] && (s > sl[i] || (s == sl[i] && n < lab[i]));
+        const bool ahead = vn && gn != lab[i] && (s > sl[i] || (s == sl[i] && gn < lab[i]));
         cnt[i] += ahead ? 1 : 0;
       }
     }

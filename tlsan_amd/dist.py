@@ -93,6 +93,21 @@ def allreduce_sum(t, group=None):
     return t
 
 
+def allgather_rows(t, group=None):
+    """[n, ...] per rank -> [world * n, ...] in rank order (equal n on every rank)."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return t
+    if _staged(group) and t.is_cuda:
+        c = t.cpu().contiguous()
+        o = torch.empty((world * c.shape[0],) + tuple(c.shape[1:]), dtype=c.dtype)
+        dist.all_gather_into_tensor(o, c, group=group)
+        return o.to(t.device)
+    o = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(o, t.contiguous(), group=group)
+    return o
+
+
 class ExchangePlan:
     __slots__ = ("order", "send_counts", "recv_counts", "recv_rows", "n")
 
@@ -292,6 +307,12 @@ class ShardedModel:
         self._flags = torch.zeros(self.router.nkeys, dtype=torch.int32, device=dev)   # zero at rest
         self._rows_pad = 4096     # compact-table rows are padded (grow-only): the kernels' state layout is stable
         self._side = None
+        self._ews = None
+        self._hits_p = np.zeros(6, np.int64)
+        self._hits_r = np.zeros(6, np.int64)
+        self._n_p = self._n_r = 0
+        loc = np.arange(self.rank, I, self.world)
+        self._icl_local = torch.as_tensor(np.concatenate([icl[loc], np.zeros(1, np.int32)])).to(dev)   # category of local item n
         self._slots = [None, None]          # routing plans: current / prefetched
         self._next_slot = 0
         self._slots_buf = torch.zeros(self.router.R * self.world, dtype=torch.int32, device=dev)  # zero at rest
@@ -564,18 +585,81 @@ class ShardedModel:
         return float(self.last_loss.item())
 
     # ------------------------------------------------------------------ evaluation
-    def forward(self, batch, is_test=True):
+    def forward(self, batch, is_test=True, want_ranks=False):
         db = self.device_batch(batch, is_test)
         sl = self._plan(db)
         table = self._fetch(sl)
         dims, cp, cb = self._compact(db, sl, table)
         li = torch.empty(db.B, dtype=torch.float32, device=self.device)
         lj = torch.empty(db.B, dtype=torch.float32, device=self.device) if db.j is not None else None
+        ut = torch.empty(db.B, self.d, dtype=torch.float32, device=self.device) if want_ranks else None
         L.check(self.lib.tlsan_forward(C.byref(dims), C.byref(cp), C.byref(cb), li.data_ptr(),
-                                       None if lj is None else lj.data_ptr(), None, None, 0, self._stream()),
-                "tlsan_forward")
+                                       None if lj is None else lj.data_ptr(), None if ut is None else ut.data_ptr(),
+                                       None, 0, self._stream()), "tlsan_forward")
+        ranks = self._ranks(db, dims, cp, cb, ut) if want_ranks else None
         torch.cuda.current_stream(self.device).synchronize()   # `table` stays alive until done
-        return li, lj
+        return (li, lj, ranks) if want_ranks else (li, lj)
+
+    def _ranks(self, db, dims, cp, cb, ut):
+        """All-items ranking with the items sharded: the label's own score comes from the
+        compact table of the rank that holds the user; u_t, label scores and label ids are
+        all-gathered; every rank counts the items of ITS shard that rank ahead of each label
+        (ties -> lower global id, tf.nn.top_k's order); one all-reduce of the counts gives the
+        ranks.  Same kernels as the single-GPU tlsan_eval_ranks."""
+        B, st = db.B, self._stream()
+        nws = self.lib.tlsan_workspace_bytes(C.byref(dims), B, 0)
+        if self._ws is None or self._ws.numel() < nws:
+            self._ws = torch.empty(int(nws * 1.25), dtype=torch.uint8, device=self.device)
+        s_lab = torch.empty(B, dtype=torch.float32, device=self.device)
+        L.check(self.lib.tlsan_eval_label_scores(C.byref(dims), C.byref(cp), ut.data_ptr(), cb.i, B, s_lab.data_ptr(),
+                                                 self._ws.data_ptr(), self._ws.numel(), st), "tlsan_eval_label_scores")
+        ut_all, s_all, lab_all = allgather_rows(ut, self.group), allgather_rows(s_lab, self.group), allgather_rows(db.i, self.group)
+        Bt = int(ut_all.shape[0])
+        nloc = ModPartition(self.I, self.world).local_count(self.rank)
+        ldims = L.Dims(self.U, max(nloc, 1), self.C, self.d, self.di, self.dc, self.H, self.Ls)
+        base = self.shard.data_ptr()
+        lp = L.Params(base, base + 4 * self.di, base, base + 4 * self.di, self.cate_emb.data_ptr(), self.dense.data_ptr(),
+                      self.dense_KT.data_ptr(), self._icl_local.data_ptr(), self.W, self.W, self.W, self.W, None)
+        nws = self.lib.tlsan_workspace_bytes(C.byref(ldims), Bt, 0)
+        if self._ews is None or self._ews.numel() < nws:
+            self._ews = torch.empty(int(nws * 1.25), dtype=torch.uint8, device=self.device)
+        counts = torch.zeros(Bt, dtype=torch.int32, device=self.device)
+        if nloc > 0:
+            L.check(self.lib.tlsan_eval_counts_shard(C.byref(ldims), C.byref(lp), ut_all.data_ptr(), s_all.data_ptr(),
+                                                     lab_all.data_ptr(), Bt, self.world, self.rank, counts.data_ptr(),
+                                                     self._ews.data_ptr(), self._ews.numel(), st), "tlsan_eval_counts_shard")
+        if self.world > 1:
+            allreduce_sum(counts, self.group)
+        return counts[self.rank * B:(self.rank + 1) * B]
+
+    def _hits(self, batch):
+        from .model import KS
+        r = self.label_ranks(batch)
+        h = torch.stack([(r < k).sum() for k in KS] + [torch.tensor(r.numel(), device=r.device)]).to(torch.int64)
+        if self.world > 1:
+            allreduce_sum(h, self.group)        # hits and rows of the GLOBAL test batch
+        h = h.cpu().numpy()
+        return h[:-1], int(h[-1])
+
+    def eval_prec(self, sess, batch):
+        """Streaming precision_at_k over the global batch (model.py:265-281); cumulative like the reference's
+        never-reset local variables (train.py:75-76,82).  Identical on every rank."""
+        from .model import KS
+        h, n = self._hits(batch)
+        self._hits_p += h
+        self._n_p += n
+        return [self._hits_p[i] / (k * self._n_p) for i, k in enumerate(KS)]
+
+    def eval_recall(self, sess, batch):
+        from .model import KS
+        h, n = self._hits(batch)
+        self._hits_r += h
+        self._n_r += n
+        return [self._hits_r[i] / self._n_r for i in range(len(KS))]
+
+    def label_ranks(self, batch):
+        """rank of the positive item among ALL items for each test row of this rank's batch (model.py:140-156)"""
+        return self.forward(batch, is_test=True, want_ranks=True)[2]
 
     def eval_auc(self, sess, batch):
         li, lj = self.forward(batch, is_test=True)
