@@ -23,9 +23,9 @@ torch.cuda.synchronize()
 lib.tlsan_debug_stamps(None)
 s = st.cpu().numpy()[OFF:].reshape(NBLK, 8).astype(np.float64)
 used = s[:, 0] > 0
-n = int(used.sum())
+n = int(np.flatnonzero(used).max()) + 1   # (lazy row blocks past the used rows leave no stamps)
 s = s[:n]
-t0 = s[:, 0].min()
+t0 = s[used[:n], 0].min()
 C = cfg["cate_count"]
 Sn = db.Sn
 ni = min(cfg["item_count"], B * (cfg["Ls"] + Sn + 1))
@@ -34,6 +34,7 @@ nbU = (min(B, cfg["user_count"]) + 15) // 16
 print("blocks %d: cate %d, item %d, user %d, dense %d; span %.0f ticks (100 MHz -> %.1f us)" % (n, C, nbI, nbU, n - C - nbI - nbU, s[:, 6].max() - t0, (s[:, 6].max() - t0) / 100))
 def show(name, lo, hi):
     x = s[lo:hi]
+    x = x[x[:, 0] > 0]
     if len(x) == 0:
         return
     print("%-6s start p0/50/100 %5.0f %5.0f %5.0f | end p50/100 %5.0f %5.0f | dur p50 %5.0f max %5.0f" % (
@@ -48,15 +49,16 @@ def show(name, lo, hi):
 show("cate", 0, C)
 show("item", C, C + nbI)
 show("user", C + nbI, C + nbI + nbU)
-show("dense", C + nbI + nbU, n)
+show("dense/fin", C + nbI + nbU, n)
 
 # timeline on the device-wide 100 MHz clock (slots 4/5)
-r0 = s[:, 4].min()
+r0 = s[s[:, 4] > 0, 4].min()
 print("timeline (us after the first workgroup start; 100 MHz s_memrealtime): kernel span %.2f us" % ((s[:, 5].max() - r0) / 100))
-for nm, lo, hi in [("cate", 0, C), ("item", C, C + nbI), ("user", C + nbI, C + nbI + nbU), ("dense", C + nbI + nbU, n)]:
+for nm, lo, hi in [("cate", 0, C), ("item", C, C + nbI), ("user", C + nbI, C + nbI + nbU), ("dense/fin", C + nbI + nbU, n)]:
     x = s[lo:hi]
+    x = x[x[:, 4] > 0]
     if len(x):
         st, en = (x[:, 4] - r0) / 100, (x[:, 5] - r0) / 100
-        print("  %-5s start p0/10/50/90/100 %s | end p50/90/100 %s | dur p50 %.2f" % (
+        print("  %-9s start p0/10/50/90/100 %s | end p50/90/100 %s | dur p50 %.2f" % (
             nm, " ".join("%5.2f" % v for v in np.percentile(st, [0, 10, 50, 90, 100])),
             " ".join("%5.2f" % v for v in np.percentile(en, [50, 90, 100])), np.median(en - st)))

@@ -78,6 +78,7 @@ static int shape_of(const tlsan_dims* d, Shape* s) {
 
 #define EVAL_DENSE_MAX ((size_t)256 << 20)  // all-items scoring materialises all_emb (model.py:89-90) up to this size
 struct Ws {  // carve-up of the caller's scratch buffer
+  float *Rc, *Ri, *Rb, *Ru;  // summed rows of the split lazy update
   float *Gi, *Gb, *Gu, *Gc, *gLong, *gDB, *partials, *Kp, *gd, *sqd, *scal, *logits, *s_label;
   float* all_emb;  // evaluation: dense [I, D] item matrix (NULL when it would exceed EVAL_DENSE_MAX bytes)
   double* rownorm_part;
@@ -119,6 +120,14 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
     w->all_emb = ae <= EVAL_DENSE_MAX ? (float*)take(ae) : nullptr;
   }
   const size_t nrowblk = (size_t)(d->item_count + 15) / 16 + (d->user_count + 15) / 16 + d->cate_count;
+  {  // summed rows of the used rows (lazy update: k_finalize_presum -> k_update_lazy)
+    const size_t ri = (NI < (size_t)d->item_count ? NI : (size_t)d->item_count) + AP_ROWS_PB;
+    const size_t ru = ((size_t)B < (size_t)d->user_count ? (size_t)B : (size_t)d->user_count) + AP_ROWS_PB;
+    w->Ri = (float*)take(sizeof(float) * ri * d->d_item);
+    w->Rb = (float*)take(sizeof(float) * ri);
+    w->Ru = (float*)take(sizeof(float) * ru * w->WU);
+    w->Rc = (float*)take(sizeof(float) * (size_t)d->cate_count * d->d_cate);
+  }
   w->rownorm_part = (double*)take(8 * nrowblk);
   w->rownorm = (double*)take(8);
   w->bytes = o;
@@ -251,6 +260,7 @@ static void fill_apply(ApplyArgs& A, const tlsan_dims* d, const Shape& s, const 
   A.n_uniq_item = st.hdr ? &st.hdr->n_uniq[k][0] : nullptr; A.n_uniq_user = st.hdr ? &st.hdr->n_uniq[k][1] : nullptr;
   A.cate_off = st.cate_off; A.cate_cnt = st.cate_cnt; A.cate_items = st.cate_items;
   A.gd = w.gd;
+  A.Rc = w.Rc; A.Ri = w.Ri; A.Rb = w.Rb; A.Ru = w.Ru;
   A.part_out = st.S_part; A.hdr = st.hdr;
   A.urec_item = st.urec_item[k]; A.urec_user = st.urec_user[k];
   if (hp) { A.lr = hp->lr; A.reg = hp->reg; }
@@ -260,14 +270,35 @@ static void fill_apply(ApplyArgs& A, const tlsan_dims* d, const Shape& s, const 
 
 // one apply pass = one launch: category rows, item/user rows (+ dense parameters).
 // lazy (UPDATE only): the row blocks walk the compacted records of used rows.
-static int launch_apply(int mode, bool lazy, ApplyArgs A, bool with_dense, int B, int Sn, hipStream_t hs) {
-  if (lazy) {  // at most min(rows, uses) rows were used
-    const long ni = (long)B * (A.Ls + Sn + 1);
-    A.nbI = (int)(((ni < A.I ? ni : A.I) + AP_ROWS_PB - 1) / AP_ROWS_PB);
-    A.nbU = ((B < A.U ? B : A.U) + AP_ROWS_PB - 1) / AP_ROWS_PB;
+static void lazy_blocks(ApplyArgs& A, int B, int Sn) {  // at most min(rows, uses) rows were used
+  const long ni = (long)B * (A.Ls + Sn + 1);
+  A.nbI = (int)(((ni < A.I ? ni : A.I) + AP_ROWS_PB - 1) / AP_ROWS_PB);
+  A.nbU = ((B < A.U ? B : A.U) + AP_ROWS_PB - 1) / AP_ROWS_PB;
+}
+
+static bool apply_wide(const ApplyArgs& A) { return A.di > 64 || A.dc > 64 || A.WU > 128; }  // more float4 chunks per lane
+
+// second half of the split lazy update (the first half rides with the dense finalize, run_backward)
+static int launch_update_lazy(ApplyArgs A, int B, int Sn, hipStream_t hs) {
+  lazy_blocks(A, B, Sn);
+  const int nbC16 = (A.C + 15) / 16;
+  const dim3 g1(nbC16 + A.nbI + A.nbU + A.nbD), blk(256);
+  const bool wide = apply_wide(A);
+  if (A.p.table_dtype == TLSAN_TABLE_BF16) {
+    if (wide) hipLaunchKernelGGL((k_update_lazy<true, TLSAN_TABLE_BF16>), g1, blk, 0, hs, A, nbC16);
+    else hipLaunchKernelGGL((k_update_lazy<false, TLSAN_TABLE_BF16>), g1, blk, 0, hs, A, nbC16);
+  } else {
+    if (wide) hipLaunchKernelGGL((k_update_lazy<true, TLSAN_TABLE_F32>), g1, blk, 0, hs, A, nbC16);
+    else hipLaunchKernelGGL((k_update_lazy<false, TLSAN_TABLE_F32>), g1, blk, 0, hs, A, nbC16);
   }
+  CHECK_LAUNCH("k_update_lazy");
+  return TLSAN_OK;
+}
+
+static int launch_apply(int mode, bool lazy, ApplyArgs A, bool with_dense, int B, int Sn, hipStream_t hs) {
+  if (lazy) lazy_blocks(A, B, Sn);
   const dim3 g1(A.nbC + A.nbI + A.nbU + (with_dense ? A.nbD : 0)), blk(256);
-  const bool wide = A.di > 64 || A.dc > 64 || A.WU > 128;  // more float4 chunks per lane
+  const bool wide = apply_wide(A);
   const bool bf16 = A.p.table_dtype == TLSAN_TABLE_BF16;
 #define AP_LAUNCH(M, LZ)                                                                                     \
   do {                                                                                                       \
@@ -506,7 +537,7 @@ static int build_index(const tlsan_dims* d, const tlsan_batch* b, const St& st, 
 // shared front half of train_step / grads: index build, fused fwd+bwd, dense-grad reduction
 static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params* p, const tlsan_batch* b,
                         const tlsan_hparams* hp, bool update, const tlsan_step_out* out, const Ws& w, const St& st,
-                        const tlsan_dense_layout& L, hipStream_t hs) {
+                        const tlsan_dense_layout& L, hipStream_t hs, const ApplyArgs* presum = nullptr) {
   const bool commit = update && hp->l2_mode == TLSAN_L2_LAZY;
   const int k = hp->index_slot;
   int rc;
@@ -551,6 +582,25 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   f.out_loss = out ? out->loss : nullptr;
   f.out_gnorm = out ? out->gnorm : nullptr;
   f.out_sq = out ? out->sq_rows : nullptr;
+  if (presum) {
+    // lazy update: the exact row sums of the apply pass share the launch (they wait for nothing it produces)
+    ApplyArgs A = *presum;
+    lazy_blocks(A, b->B, b->Sn);
+    const dim3 grid(w.nfin + 1 + A.nbC + A.nbI + A.nbU);
+    const bool wide = apply_wide(A);
+#define FP_LAUNCH(DD, HH)                                                                                         \
+  do {                                                                                                            \
+    if (wide) hipLaunchKernelGGL((k_finalize_presum<DD, HH, true>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);   \
+    else hipLaunchKernelGGL((k_finalize_presum<DD, HH, false>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);       \
+  } while (0)
+    if (s.D == 64) FP_LAUNCH(64, 8);
+    else if (s.D == 128) FP_LAUNCH(128, 16);
+    else FP_LAUNCH(256, 32);
+#undef FP_LAUNCH
+    CHECK_LAUNCH("k_finalize_presum");
+    prof_mark(4, hs);
+    return TLSAN_OK;
+  }
   if (s.D == 64) hipLaunchKernelGGL((k_dense_finalize<64, 8>), dim3(w.nfin + 1), dim3(256), 0, hs, f, w.nbK, w.nbS);
   else if (s.D == 128) hipLaunchKernelGGL((k_dense_finalize<128, 16>), dim3(w.nfin + 1), dim3(256), 0, hs, f, w.nbK, w.nbS);
   else hipLaunchKernelGGL((k_dense_finalize<256, 32>), dim3(w.nfin + 1), dim3(256), 0, hs, f, w.nbK, w.nbS);
@@ -631,11 +681,17 @@ int tlsan_train_step(const tlsan_dims* d, const tlsan_params* p, const tlsan_bat
   hipStream_t hs = (hipStream_t)stream;
   tlsan_dense_layout L;
   tlsan_dense_layout_of(d, &L);
-  if ((rc = run_backward(d, s, p, b, hp, true, out, w, st, L, hs))) return rc;
   ApplyArgs A;
   fill_apply(A, d, s, p, b, hp, w, st, L);
-  if (hp->norm_mode == TLSAN_NORM_DEDUP && (rc = clip_dedup(A, hp, out, w, st, b, hs))) return rc;
-  if ((rc = launch_apply(AP_UPDATE, hp->l2_mode == TLSAN_L2_LAZY, A, true, b->B, b->Sn, hs))) return rc;
+  static const int split = [] { const char* v = getenv("TLSAN_APPLY_SPLIT"); return v ? atoi(v) : 1; }();
+  if (hp->l2_mode == TLSAN_L2_LAZY && split) {
+    if ((rc = run_backward(d, s, p, b, hp, true, out, w, st, L, hs, &A))) return rc;
+    if ((rc = launch_update_lazy(A, b->B, b->Sn, hs))) return rc;
+  } else {
+    if ((rc = run_backward(d, s, p, b, hp, true, out, w, st, L, hs))) return rc;
+    if (hp->norm_mode == TLSAN_NORM_DEDUP && (rc = clip_dedup(A, hp, out, w, st, b, hs))) return rc;
+    if ((rc = launch_apply(AP_UPDATE, hp->l2_mode == TLSAN_L2_LAZY, A, true, b->B, b->Sn, hs))) return rc;
+  }
   prof_mark(5, hs);
   prof_step_done();
   return TLSAN_OK;

@@ -349,11 +349,10 @@ __device__ __forceinline__ double block_sum_double(const double* __restrict__ v,
 // with 16 lanes per parameter (lane l sums records l, l+16, ...; fixed xor tree after);
 // the last block reduces S_part -> S_total.  Every sum has a fixed order -> deterministic.
 template <int D, int DH>
-__global__ __launch_bounds__(256) void k_dense_finalize(FinArgs a, int nbK, int nbS) {
+__device__ __forceinline__ void dense_finalize_block(const FinArgs& a, int nbK, int nbS, int blk, double* shd, int* sh_last) {
   using G = Geo<D, DH>;
   constexpr int CW = G::CW, NPB = G::NPB, HPC = CW / DH;  // heads per 16-wide column block
-  __shared__ double shd[256];
-  const int tid = threadIdx.x, blk = blockIdx.x;
+  const int tid = threadIdx.x;
   const tlsan_dense_layout& L = a.lay;
   if (blk == nbK + nbS) {
     // the apply kernels leave per-workgroup CHANGES of the tables' sum of squares: fold them in
@@ -457,11 +456,17 @@ __global__ __launch_bounds__(256) void k_dense_finalize(FinArgs a, int nbK, int 
     if (rl == 0) pub_f32(a.scal + which, t);
   }
   // ---- the last workgroup to arrive sees every other one's results and writes the step summary
+  __syncthreads();
+  if (tid == 0) *sh_last = atomicAdd(&a.hdr->ticket, 1) == nbK + nbS;  // nbK + nbS + 1 finalize workgroups
+  __syncthreads();
+  if (*sh_last) step_summary(a, nbK + nbS, shd);
+}
+
+template <int D, int DH>
+__global__ __launch_bounds__(256) void k_dense_finalize(FinArgs a, int nbK, int nbS) {
+  __shared__ double shd[256];
   __shared__ int sh_last;
-  __syncthreads();
-  if (tid == 0) sh_last = atomicAdd(&a.hdr->ticket, 1) == (int)gridDim.x - 1;
-  __syncthreads();
-  if (sh_last) step_summary(a, nbK + nbS, shd);
+  dense_finalize_block<D, DH>(a, nbK, nbS, blockIdx.x, shd, &sh_last);
 }
 
 // dedup-norm mode: norm^2 = sum over destination rows of |summed row gradient|^2 (ROWNORM pass)
@@ -498,7 +503,8 @@ __global__ void k_transpose_K(const float* __restrict__ K, float* __restrict__ K
 }
 
 // ------------------------------------------------------------------------------------------
-enum { AP_UPDATE = 0, AP_GRADS = 1, AP_SUMSQ = 2, AP_ROWNORM = 3 };
+enum { AP_UPDATE = 0, AP_GRADS = 1, AP_SUMSQ = 2, AP_ROWNORM = 3,
+       AP_PRESUM = 4 };  // PRESUM: only the exact per-row sums, left in Rc / Ri / Rb / Ru for k_update_lazy
 
 struct ApplyArgs {
   tlsan_params p;
@@ -511,6 +517,7 @@ struct ApplyArgs {
   const int4* urec_item; const int4* urec_user;   // lazy L2: (row, first position, uses) of the rows used this step
   const int32_t* cate_off; const int32_t* cate_cnt; const int32_t* cate_items;  // static CSR
   const float* gd;
+  float* Rc; float* Ri; float* Rb; float* Ru;   // PRESUM -> k_update_lazy: summed rows [C][dc], [slot][di], [slot], [slot][WU]
   double* part_out;        // UPDATE: change of the stored tables' sum of squares per workgroup;
                            // SUMSQ: sum of squares; ROWNORM: sum g^2
   const StateHdr* hdr;     // P, P_prev, coef
@@ -663,15 +670,17 @@ struct ApCtx {
 template <int MODE, bool LAZY, int NCH, int DT>
 __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx& x, double* shd, double* shp,
                                                  int* sh_pos, int* sh_lo, int* sh_n, int* sh_wtot) {
-  constexpr bool RESET = MODE == AP_UPDATE || MODE == AP_GRADS;  // counters are zero at rest
+  constexpr bool RESET = MODE == AP_UPDATE || MODE == AP_GRADS || MODE == AP_PRESUM;  // counters are zero at rest
   const int tid = x.tid, wave = x.wave, lane = x.lane, grp = x.grp, l16 = x.l16, gid = x.gid;
   const int c = x.blk;
   const int W4 = a.dc / 4;
   const size_t wrow = (size_t)c * a.dc;  // element index of the row in cate_emb
   f32x4 w[NCH];
+  if constexpr (MODE != AP_PRESUM) {
 #pragma unroll
-  for (int ch = 0; ch < NCH; ++ch)
-    if (l16 + 16 * ch < W4) w[ch] = tbl_ld4<DT>(a.p.cate_emb, wrow + 4 * (l16 + 16 * ch));
+    for (int ch = 0; ch < NCH; ++ch)
+      if (l16 + 16 * ch < W4) w[ch] = tbl_ld4<DT>(a.p.cate_emb, wrow + 4 * (l16 + 16 * ch));
+  }
   double acc[NCH][4];
   zero_acc(acc);
   double part = 0.0;
@@ -741,6 +750,22 @@ __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx
     }
   }
   AP_STAMP(3);
+  if constexpr (MODE == AP_PRESUM) {
+    if (wave == 0 && grp == 0) {
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        const int c4 = l16 + 16 * ch;
+        if (c4 < W4) {
+          f32x4 g;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) g[i] = (float)acc[ch][i];
+          *(f32x4*)(a.Rc + wrow + 4 * c4) = g;
+        }
+      }
+    }
+    if (tid == 0 && nu > 0) a.cnt_uc[c] = 0;
+    return;
+  }
   if (wave == 0 && grp == 0) {
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
@@ -777,7 +802,7 @@ __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx
 // in flight per group; longer segments are finished by the whole wavefront.
 template <int MODE, bool LAZY, bool IS_ITEM, int NCH, int OWN, int DT>
 __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx& x, int slot0, double* shp) {
-  constexpr bool RESET = MODE == AP_UPDATE || MODE == AP_GRADS;
+  constexpr bool RESET = MODE == AP_UPDATE || MODE == AP_GRADS || MODE == AP_PRESUM;
   const int lane = x.lane, grp = x.grp, l16 = x.l16;
   const int slot = slot0 + x.gid;
   int row = 0, off = 0, n = 0;
@@ -807,18 +832,20 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
   const size_t wrow = IS_ITEM ? (size_t)row * a.p.ld_item : (size_t)row * a.p.ld_user;  // element index of the row
   float* Trow = a.p.usert_emb + (size_t)row * a.p.ld_usert;
   f32x4 w[NCH];
-#pragma unroll
-  for (int ch = 0; ch < NCH; ++ch) {
-    const int cc = 4 * (l16 + 16 * ch);
-    if (cc < a.di) {
-      w[ch] = tbl_ld4<DT>(Wtab, wrow + cc);
-    } else if (!IS_ITEM) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) w[ch][i] = (cc + i - a.di < a.Ls) ? Trow[cc + i - a.di] : 0.0f;
-    }
-  }
   float wb = 0.0f;
-  if (IS_ITEM && l16 == 0) wb = a.p.item_b[(size_t)row * a.p.ld_itemb];
+  if constexpr (MODE != AP_PRESUM) {
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int cc = 4 * (l16 + 16 * ch);
+      if (cc < a.di) {
+        w[ch] = tbl_ld4<DT>(Wtab, wrow + cc);
+      } else if (!IS_ITEM) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[ch][i] = (cc + i - a.di < a.Ls) ? Trow[cc + i - a.di] : 0.0f;
+      }
+    }
+    if (IS_ITEM && l16 == 0) wb = a.p.item_b[(size_t)row * a.p.ld_itemb];
+  }
   // ---- exact sum of the row's segment
   double acc[NCH][4];
   zero_acc(acc);
@@ -880,6 +907,26 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
     }
   }
   AP_STAMP(3);
+  if constexpr (MODE == AP_PRESUM) {
+    if (vr) {
+      float* R = IS_ITEM ? a.Ri + (size_t)slot * a.di : a.Ru + (size_t)slot * a.WU;
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        const int c4 = l16 + 16 * ch;
+        if (c4 < W4) {
+          f32x4 g;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) g[i] = (float)acc[ch][i];
+          *(f32x4*)(R + 4 * c4) = g;
+        }
+      }
+      if (l16 == 0) {
+        if (IS_ITEM) a.Rb[slot] = (float)bacc;
+        if (n > 0) (IS_ITEM ? a.cnt_item : a.cnt_user)[row] = 0;
+      }
+    }
+    return;
+  }
   if (vr) {
     // column cc of the row: cc < di -> item_emb / user_emb;  user rows, di <= cc < di+Ls -> usert_emb
 #pragma unroll
@@ -993,6 +1040,162 @@ __global__ __launch_bounds__(256) void k_apply(ApplyArgs a) {
   if (a.stamps != nullptr && x.tid == 0) a.stamps[(size_t)x.blk * 8 + 5] = __builtin_amdgcn_s_memrealtime();
 }
 #undef AP_STAMP
+
+// ------------------------------------------------------------------------------------------
+// The lazy-L2 train step splits the apply pass so that the row sums (which need neither the clip
+// coefficient nor the dense gradients) overlap the dense finalize instead of waiting for it:
+//   k_finalize_presum : workgroups [0, nbK+nbS] are k_dense_finalize's, the rest are k_apply's in
+//                       PRESUM mode (exact per-row sums -> Rc / Ri / Rb / Ru, counters reset)
+//   k_update_lazy     : elementwise w -= scale * sum for the used rows + the dense parameters
+// Same arithmetic per element as k_apply<AP_UPDATE, lazy> (the sums are rounded to float there too).
+template <int D, int DH, bool WIDE>
+__global__ __launch_bounds__(256) void k_finalize_presum(FinArgs f, int nbK, int nbS, ApplyArgs a) {
+  constexpr int NC = WIDE ? 2 : 1, NI = WIDE ? 2 : 1, NU = WIDE ? 4 : 2;
+  __shared__ double shd[4 * 16 * NC * 4 > 256 ? 4 * 16 * NC * 4 : 256];
+  __shared__ double shp[4];
+  __shared__ int sh_pos[AP_CAP];
+  __shared__ int sh_lo[256], sh_n[256];
+  __shared__ int sh_wtot[4];
+  __shared__ int sh_last;
+  const int nfin = nbK + nbS + 1;
+  if ((int)blockIdx.x < nfin) {
+    // (debug stamps: the finalize workgroups are listed after the apply workgroups)
+    unsigned long long* stp = a.stamps ? a.stamps + (size_t)(gridDim.x - nfin + blockIdx.x) * 8 : nullptr;
+    if (stp && threadIdx.x == 0) { stp[0] = __builtin_amdgcn_s_memtime(); stp[4] = __builtin_amdgcn_s_memrealtime(); }
+    dense_finalize_block<D, DH>(f, nbK, nbS, blockIdx.x, shd, &sh_last);
+    if (stp && threadIdx.x == 0) { stp[6] = __builtin_amdgcn_s_memtime(); stp[5] = __builtin_amdgcn_s_memrealtime(); }
+    return;
+  }
+  ApCtx x;
+  x.tid = threadIdx.x; x.wave = x.tid >> 6; x.lane = x.tid & 63; x.grp = x.lane >> 4; x.l16 = x.lane & 15;
+  x.gid = x.wave * 4 + x.grp;
+  x.blk = blockIdx.x - nfin;
+  x.P = 1.0f; x.invP = 1.0f; x.step = 0.0f; x.lazy_scale = 0.0f; x.salt = 0u;
+  unsigned long long* stp = a.stamps ? a.stamps + (size_t)x.blk * 8 : nullptr;
+  if (stp && x.tid == 0) { stp[0] = __builtin_amdgcn_s_memtime(); stp[4] = __builtin_amdgcn_s_memrealtime(); }
+  const int blk = x.blk;
+  if (blk < a.nbC) apply_cate_block<AP_PRESUM, true, NC, TLSAN_TABLE_F32>(a, x, shd, shp, sh_pos, sh_lo, sh_n, sh_wtot);
+  else if (blk < a.nbC + a.nbI) apply_rows_block<AP_PRESUM, true, true, NI, AP_OWN, TLSAN_TABLE_F32>(a, x, (blk - a.nbC) * AP_ROWS_PB, shp);
+  else apply_rows_block<AP_PRESUM, true, false, NU, AP_OWN / 2, TLSAN_TABLE_F32>(a, x, (blk - a.nbC - a.nbI) * AP_ROWS_PB, shp);
+  if (stp && x.tid == 0) { stp[6] = __builtin_amdgcn_s_memtime(); stp[5] = __builtin_amdgcn_s_memrealtime(); }
+}
+
+// grid: nbC16 = ceil(C / 16) blocks of category rows, nbI / nbU blocks of used item / user rows
+// (one row per 16-lane group), nbD blocks of 256 dense parameters
+template <bool WIDE, int DT>
+__global__ __launch_bounds__(256) void k_update_lazy(ApplyArgs a, int nbC16) {
+  constexpr int NC = WIDE ? 2 : 1, NI = WIDE ? 2 : 1, NU = WIDE ? 4 : 2;
+  __shared__ double shp[4];
+  const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, gid = tid >> 4, blk = blockIdx.x;
+  const float P = a.hdr->P_prev;  // (the step summary already advanced hdr->P)
+  const float step = a.lr * a.hdr->coef;
+  const float lazy_scale = step / (P * (1.0f - step * a.reg));
+  const uint32_t salt = a.hdr->nstep;
+  double part = 0.0;
+  if (blk < nbC16) {
+    const int c = blk * 16 + gid;
+    if (c < a.C) {
+      const size_t wrow = (size_t)c * a.dc;
+      f32x4 w[NC], g[NC];
+#pragma unroll
+      for (int ch = 0; ch < NC; ++ch)
+        if (4 * (l16 + 16 * ch) < a.dc) {
+          w[ch] = tbl_ld4<DT>(a.p.cate_emb, wrow + 4 * (l16 + 16 * ch));
+          g[ch] = *(const f32x4*)(a.Rc + wrow + 4 * (l16 + 16 * ch));
+        }
+#pragma unroll
+      for (int ch = 0; ch < NC; ++ch)
+        if (4 * (l16 + 16 * ch) < a.dc) {
+          const f32x4 w0 = w[ch];
+          w[ch] = w0 - lazy_scale * g[ch];
+          tbl_st4<DT>(a.p.cate_emb, wrow + 4 * (l16 + 16 * ch), w[ch], salt ^ 0x3c6ef372u);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) part += (double)w[ch][i] * (double)w[ch][i] - (double)w0[i] * (double)w0[i];
+        }
+    }
+  } else if (blk < nbC16 + a.nbI) {
+    const int slot0 = (blk - nbC16) * AP_ROWS_PB, slot = slot0 + gid;
+    const int nuq = *a.n_uniq_item;
+    if (slot0 >= nuq) return;
+    if (slot < nuq) {
+      const int row = a.urec_item[slot].x;
+      const size_t wrow = (size_t)row * a.p.ld_item;
+      f32x4 w[NI], g[NI];
+      float wb = 0.0f, gb = 0.0f;
+#pragma unroll
+      for (int ch = 0; ch < NI; ++ch)
+        if (4 * (l16 + 16 * ch) < a.di) {
+          w[ch] = tbl_ld4<DT>(a.p.item_emb, wrow + 4 * (l16 + 16 * ch));
+          g[ch] = *(const f32x4*)(a.Ri + (size_t)slot * a.di + 4 * (l16 + 16 * ch));
+        }
+      if (l16 == 0) { wb = a.p.item_b[(size_t)row * a.p.ld_itemb]; gb = a.Rb[slot]; }
+#pragma unroll
+      for (int ch = 0; ch < NI; ++ch)
+        if (4 * (l16 + 16 * ch) < a.di) {
+          const f32x4 w0 = w[ch];
+          w[ch] = w0 - lazy_scale * g[ch];
+          tbl_st4<DT>(a.p.item_emb, wrow + 4 * (l16 + 16 * ch), w[ch], salt ^ 0x85ebca6bu);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) part += (double)w[ch][i] * (double)w[ch][i] - (double)w0[i] * (double)w0[i];
+        }
+      if (l16 == 0) a.p.item_b[(size_t)row * a.p.ld_itemb] = wb - step * gb;  // not regularised, never scaled
+    }
+  } else if (blk < nbC16 + a.nbI + a.nbU) {
+    const int slot0 = (blk - nbC16 - a.nbI) * AP_ROWS_PB, slot = slot0 + gid;
+    const int nuq = *a.n_uniq_user;
+    if (slot0 >= nuq) return;
+    if (slot < nuq) {
+      const int row = a.urec_user[slot].x;
+      const size_t wrow = (size_t)row * a.p.ld_user;
+      float* Trow = a.p.usert_emb + (size_t)row * a.p.ld_usert;
+      f32x4 w[NU], g[NU];
+#pragma unroll
+      for (int ch = 0; ch < NU; ++ch) {
+        const int cc = 4 * (l16 + 16 * ch);
+        if (cc < a.WU) g[ch] = *(const f32x4*)(a.Ru + (size_t)slot * a.WU + cc);
+        if (cc < a.di) {
+          w[ch] = tbl_ld4<DT>(a.p.user_emb, wrow + cc);
+        } else if (cc < a.WU) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) w[ch][i] = (cc + i - a.di < a.Ls) ? Trow[cc + i - a.di] : 0.0f;
+        }
+      }
+#pragma unroll
+      for (int ch = 0; ch < NU; ++ch) {
+        const int cc = 4 * (l16 + 16 * ch);
+        if (cc < a.di) {
+          const f32x4 w0 = w[ch];
+          w[ch] = w0 - lazy_scale * g[ch];
+          tbl_st4<DT>(a.p.user_emb, wrow + cc, w[ch], salt ^ 0xc2b2ae35u);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) part += (double)w[ch][i] * (double)w[ch][i] - (double)w0[i] * (double)w0[i];
+        } else if (cc < a.WU) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int p = cc + i - a.di;
+            if (p < a.Ls) {
+              const float w0 = w[ch][i], wn = w0 - lazy_scale * g[ch][i];
+              Trow[p] = wn;
+              part += (double)wn * (double)wn - (double)w0 * (double)w0;
+            }
+          }
+        }
+      }
+    }
+  } else {
+    const int nd = (blk - nbC16 - a.nbI - a.nbU) * 256 + tid;
+    if (nd < a.lay.n_dense) {
+      const float wn = a.p.dense[nd] - step * a.gd[nd];
+      a.p.dense[nd] = wn;
+      if (nd >= a.lay.K && nd < a.lay.k0) {
+        const int idx = nd - a.lay.K;
+        a.p.dense_KT[(size_t)(idx % a.D) * a.D + idx / a.D] = wn;
+      }
+    }
+    return;
+  }
+  block_part_store(part, shp, &a.part_out[blk]);
+}
 
 
 // stored *= P for one table (tlsan_state_renorm)
