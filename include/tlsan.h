@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TLSAN_ABI_VERSION 4
+#define TLSAN_ABI_VERSION 5
 
 enum {
   TLSAN_OK = 0,
@@ -183,6 +183,33 @@ int tlsan_forward(const tlsan_dims* dims, const tlsan_params* p, const tlsan_bat
 int tlsan_train_step(const tlsan_dims* dims, const tlsan_params* p, const tlsan_batch* b,
                      const tlsan_hparams* hp, const tlsan_step_out* out,
                      void* state, void* ws, size_t ws_bytes, void* stream);
+
+/* The reference's other optimizers (model.py:188-193: adadelta | adam | rmsprop, TF-1.8 defaults).
+ * Their per-parameter accumulators ("slots") are two more sets of tables with the shapes of
+ * `tlsan_params` (fp32, own row strides; item_cate / dense_KT / scale / table_dtype are ignored):
+ *   ADAM     (beta1 0.9, beta2 0.999, epsilon 1e-8):  slot1 = m, slot2 = v, zero-initialised;
+ *            `step` = number of this update counted from 1 (the beta powers);
+ *   RMSPROP  (beta1 = decay 0.9, beta2 = momentum 0.0, epsilon 1e-10): slot1 = rms (initialised
+ *            to ONE as TF does), slot2 = momentum (zero);
+ *   ADADELTA (beta1 = rho 0.95, epsilon 1e-8): slot1 = accum, slot2 = accum_update (zero).
+ * Arithmetic of TF 1.8's training ops (core/kernels/training_ops.cc ApplyAdam / ApplyRMSProp /
+ * ApplyAdadelta and their Sparse* forms).  The embedding gradients reach the optimizer as
+ * IndexedSlices covering every row (gathers + the dense L2 term), so every row of the four
+ * regularised tables is updated every step; item_b (not regularised) is updated where used
+ * (RMSProp, Adadelta) or everywhere (Adam, whose sparse form decays m and v of all rows).
+ * Needs hp->l2_mode == TLSAN_L2_DENSE and fp32 tables.  kind == TLSAN_OPT_SGD (or opt == NULL) is
+ * tlsan_train_step. */
+enum { TLSAN_OPT_SGD = 0, TLSAN_OPT_ADAM = 1, TLSAN_OPT_RMSPROP = 2, TLSAN_OPT_ADADELTA = 3 };
+typedef struct {
+  int32_t kind;
+  int32_t step;
+  float beta1, beta2, epsilon;
+  const tlsan_params* slot1;
+  const tlsan_params* slot2;
+} tlsan_optimizer;
+int tlsan_train_step_opt(const tlsan_dims* dims, const tlsan_params* p, const tlsan_batch* b,
+                         const tlsan_hparams* hp, const tlsan_optimizer* opt, const tlsan_step_out* out,
+                         void* state, void* ws, size_t ws_bytes, void* stream);
 
 /* Device-resident batcher.  A sample set packed as CSR, every pointer a DEVICE
  * pointer (counterpart of the python lists `dataset.pkl` holds, build_dataset.py:58-59,71):

@@ -282,13 +282,78 @@ def global_norm(p, g, sparse, reg, mode="tf18"):
     return float(np.sqrt(tot))
 
 
-def train_step(p, item_cate_list, b, H, reg, lr, clip=5.0, norm_mode="tf18"):
-    """One step of model.py:185-205 with the default 'sgd' optimizer (:195):
-    grads -> clip_by_global_norm(clip) -> W -= lr * g.  Returns (loss, new_params, info)."""
+# TF-1.8 constructor defaults of the optimizers model.py:188-193 builds with only learning_rate set
+OPT_DEFAULTS = {
+    "adam": dict(beta1=0.9, beta2=0.999, epsilon=1e-8),       # tf.train.AdamOptimizer
+    "rmsprop": dict(decay=0.9, momentum=0.0, epsilon=1e-10),  # tf.train.RMSPropOptimizer
+    "adadelta": dict(rho=0.95, epsilon=1e-8),                 # tf.train.AdadeltaOptimizer
+}
+
+
+def init_opt_state(p, optimizer):
+    """Slot variables as TF 1.8 creates them: Adam m, v = 0; RMSProp rms = 1, momentum = 0;
+    Adadelta accum, accum_update = 0.  t = number of updates applied so far."""
+    one = optimizer == "rmsprop"
+    return dict(t=0,
+                slot1={k: (np.ones_like(v) if one else np.zeros_like(v)) for k, v in p.items()},
+                slot2={k: np.zeros_like(v) for k, v in p.items()})
+
+
+def apply_optimizer(p, g, lr, optimizer, state, used_item_b=None):
+    """opt.apply_gradients (model.py:204) for adam | rmsprop | adadelta on CLIPPED gradients g
+    (TF 1.8 core/kernels/training_ops.cc: ApplyAdam, ApplyRMSProp, ApplyAdadelta; python adam.py
+    _apply_sparse_shared for IndexedSlices).  The four regularised tables receive IndexedSlices that
+    cover every row (gathers + dense L2 term), so they are updated everywhere; item_b only receives
+    the gathered rows: the sparse RMSProp / Adadelta kernels touch those rows only (`used_item_b`,
+    boolean mask), sparse Adam decays m and v of every row and updates every row."""
+    hp = OPT_DEFAULTS[optimizer]
+    state["t"] += 1
+    t = state["t"]
+    newp = {}
+    for k in p:
+        w, gk, s1, s2 = p[k].astype(np.float64), g[k].astype(np.float64), state["slot1"][k], state["slot2"][k]
+        mask = None
+        if k == "item_b" and optimizer != "adam" and used_item_b is not None:
+            mask = used_item_b
+        if optimizer == "adam":
+            b1, b2, eps = hp["beta1"], hp["beta2"], hp["epsilon"]
+            alpha = lr * np.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+            n1 = s1 * b1 + gk * (1.0 - b1)
+            n2 = s2 * b2 + gk * gk * (1.0 - b2)
+            nw = w - alpha * n1 / (np.sqrt(n2) + eps)
+        elif optimizer == "rmsprop":
+            rho, mom, eps = hp["decay"], hp["momentum"], hp["epsilon"]
+            n1 = s1 * rho + gk * gk * (1.0 - rho)
+            n2 = s2 * mom + lr * gk / np.sqrt(n1 + eps)
+            nw = w - n2
+        elif optimizer == "adadelta":
+            rho, eps = hp["rho"], hp["epsilon"]
+            n1 = s1 * rho + gk * gk * (1.0 - rho)
+            upd = np.sqrt(s2 + eps) / np.sqrt(n1 + eps) * gk
+            nw = w - upd * lr
+            n2 = s2 * rho + upd * upd * (1.0 - rho)
+        else:
+            raise ValueError(optimizer)
+        if mask is not None:
+            n1, n2, nw = np.where(mask, n1, s1), np.where(mask, n2, s2), np.where(mask, nw, w)
+        state["slot1"][k], state["slot2"][k] = n1.astype(s1.dtype), n2.astype(s2.dtype)
+        newp[k] = nw.astype(p[k].dtype)
+    return newp
+
+
+def train_step(p, item_cate_list, b, H, reg, lr, clip=5.0, norm_mode="tf18", optimizer="sgd", opt_state=None):
+    """One step of model.py:185-205: grads -> clip_by_global_norm(clip) -> optimizer.  The default
+    'sgd' (:195) is W -= lr * g; adam | rmsprop | adadelta (:188-193) keep their slots in
+    `opt_state` (init_opt_state).  Returns (loss, new_params, info)."""
     loss, logits, g, sparse = backward(p, item_cate_list, b, H, reg)
     norm = global_norm(p, g, sparse, reg, norm_mode)
     coef = clip / max(norm, clip)                             # clip_by_global_norm
-    newp = {k: (p[k] - lr * coef * g[k]).astype(p[k].dtype) for k in p}
+    if optimizer == "sgd":
+        newp = {k: (p[k] - lr * coef * g[k]).astype(p[k].dtype) for k in p}
+    else:
+        used = np.zeros(p["item_b"].shape, bool)
+        used[b["i"]] = True                                   # item_b is gathered by the candidates only (:87)
+        newp = apply_optimizer(p, {k: coef * g[k] for k in g}, lr, optimizer, opt_state, used)
     return loss, newp, dict(norm=norm, coef=coef, grads=g, logits=logits)
 
 

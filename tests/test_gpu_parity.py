@@ -607,3 +607,45 @@ def test_bf16_tables(l2_mode):
     for k in runs[0][0]:
         assert np.array_equal(runs[0][0][k], runs[1][0][k]), k
     assert runs[0][1] == runs[1][1]
+
+
+@pytest.mark.parametrize("optimizer,lr", [("adam", 0.05), ("rmsprop", 0.02), ("adadelta", 1.0)])
+def test_other_optimizers_track_oracle(optimizer, lr, tmp_path):
+    """model.py:188-193: adam | rmsprop | adadelta with TF 1.8's defaults, every row of the regularised
+    tables updated every step, clipped gradients; parameters AND both accumulators follow the oracle.
+    The step counter / accumulators survive save + restore."""
+    cfg = make_config(U=30, I=45, C=7, d=64, regulation_rate=1e-3, max_gradient_norm=0.05, optimizer=optimizer,
+                      model_dir=str(tmp_path))
+    p = _p32(random_params(cfg, seed=61))
+    _, cat = random_batch(cfg, B=8, Sn=3, seed=0)
+    batches = [random_batch(cfg, B=36, Sn=1 + s % 3, seed=600 + s)[0] for s in range(5)]
+    m = _model(cfg, cat, p)
+    q, st = dict(p), orc.init_opt_state(p, optimizer)
+    for n, b in enumerate(batches):
+        prev = q
+        loss, q, info = orc.train_step(q, cat, b, 8, cfg["regulation_rate"], lr=lr, clip=0.05, optimizer=optimizer,
+                                       opt_state=st)
+        assert info["coef"] < 1.0                 # the clip is active
+        l = m.train(None, _tuple(b), lr)
+        assert abs(l - loss) < 2e-4 * max(1.0, abs(loss))
+        got = m.get_params()
+        for k in q:
+            if k.endswith("_b2"):
+                # the softmax over positions is invariant to b2, so its gradient is rounding noise (1e-14 in
+                # fp64, 1e-9 in fp32) which Adam normalises to +-lr: not comparable, and without effect
+                continue
+            step = np.abs(q[k] - prev[k]).max()
+            assert np.abs(np.asarray(got[k], np.float64).reshape(q[k].shape) - q[k]).max() < 2e-3 * step * (n + 1) + 1e-7, (n, k)
+        if n == 2:                                # checkpoint round trip in the middle of the run
+            path = m.save()
+            m = _model(cfg, cat, None)
+            m.restore(None, path)
+    s1, s2 = m.get_slots()
+    for k in q:
+        if k.endswith("_b2"):
+            continue
+        for got, ref in ((s1[k], st["slot1"][k]), (s2[k], st["slot2"][k])):
+            assert np.abs(np.asarray(got, np.float64).reshape(ref.shape) - ref).max() < 2e-3 * np.abs(ref).max() + 1e-9, k
+    assert np.array_equal(m.dense_KT.cpu().numpy(), m.get_params()["dense_K"].T)
+    with pytest.raises(NotImplementedError):
+        _model(cfg, cat, p, l2_mode="lazy")

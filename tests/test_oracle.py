@@ -109,3 +109,59 @@ def test_eval_helpers():
     for row in range(5):
         assert top[row, r[row]] == lab[row]
     assert orc.hits_at_k(s, lab).shape == (6,)
+
+
+@pytest.mark.parametrize("optimizer", ["adam", "rmsprop", "adadelta"])
+def test_optimizer_formulas_against_torch(optimizer):
+    """apply_optimizer (TF 1.8 training_ops arithmetic) against torch.optim on a toy problem.  The two
+    families differ only in where epsilon sits (TF: sqrt(v) + eps before the bias correction for Adam,
+    sqrt(ms + eps) for RMSProp) and in RMSProp's initial accumulator (TF: ones), so with gradients far
+    above epsilon and the accumulator preset they agree to ~1e-7."""
+    import torch
+    rng = np.random.default_rng(5)
+    p = {"a": rng.normal(size=(7, 3)), "item_b": rng.normal(size=9)}
+    st = orc.init_opt_state(p, optimizer)
+    tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+    lr = {"adam": 0.05, "rmsprop": 0.02, "adadelta": 1.0}[optimizer]
+    hp = orc.OPT_DEFAULTS[optimizer]
+    if optimizer == "adam":
+        opt = torch.optim.Adam(tp.values(), lr=lr, betas=(hp["beta1"], hp["beta2"]), eps=hp["epsilon"])
+    elif optimizer == "rmsprop":
+        opt = torch.optim.RMSprop(tp.values(), lr=lr, alpha=hp["decay"], eps=hp["epsilon"], momentum=0.0)
+        for t in tp.values():           # create the state, then preset it to TF's initial value (ones)
+            t.grad = torch.zeros_like(t)
+        opt.step()
+        for t in tp.values():
+            opt.state[t]["square_avg"].fill_(1.0)
+    else:
+        opt = torch.optim.Adadelta(tp.values(), lr=lr, rho=hp["rho"], eps=hp["epsilon"])
+    q = dict(p)
+    for step in range(5):
+        g = {k: rng.normal(size=v.shape) * 0.3 + 0.5 for k, v in p.items()}
+        q = orc.apply_optimizer(q, g, lr, optimizer, st)
+        for k, t in tp.items():
+            t.grad = torch.tensor(g[k])
+        opt.step()
+        for k in p:
+            assert np.abs(q[k] - tp[k].detach().numpy()).max() < 1e-6, (optimizer, step, k)
+    assert st["t"] == 5
+
+
+def test_sparse_optimizers_touch_only_gathered_item_b_rows():
+    """item_b reaches the optimizer as IndexedSlices of the candidate rows only: the sparse RMSProp /
+    Adadelta kernels leave every other row and its accumulators alone, Adam's sparse form does not."""
+    rng = np.random.default_rng(6)
+    p = {"item_b": rng.normal(size=6)}
+    g = {"item_b": np.array([0.3, 0.0, 0.0, -0.2, 0.0, 0.0])}
+    used = g["item_b"] != 0
+    for optimizer in ("rmsprop", "adadelta"):
+        st = orc.init_opt_state(p, optimizer)
+        q = orc.apply_optimizer(p, g, 0.1, optimizer, st, used)
+        assert np.array_equal(q["item_b"][~used], p["item_b"][~used])
+        assert np.array_equal(st["slot1"]["item_b"][~used], orc.init_opt_state(p, optimizer)["slot1"]["item_b"][~used])
+        assert np.all(q["item_b"][used] != p["item_b"][used])
+    st = orc.init_opt_state(p, "adam")
+    q = orc.apply_optimizer(p, g, 0.1, "adam", st, used)
+    st["slot1"]["item_b"][:] = 0.5   # a row with momentum keeps moving without a gradient
+    q2 = orc.apply_optimizer(q, {"item_b": np.zeros(6)}, 0.1, "adam", st, np.zeros(6, bool))
+    assert np.all(q2["item_b"] != q["item_b"])

@@ -8,7 +8,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libtlsan_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 NORM_TF18, NORM_DEDUP = 0, 1
 TABLE_F32, TABLE_BF16 = 0, 1
 L2_DENSE, L2_LAZY = 0, 1
@@ -17,7 +17,7 @@ EXPORTS = [
     "tlsan_abi_version", "tlsan_last_error", "tlsan_dense_layout_of", "tlsan_workspace_bytes",
     "tlsan_state_bytes", "tlsan_state_init", "tlsan_state_reindex", "tlsan_state_recategorize", "tlsan_state_scale",
     "tlsan_state_renorm", "tlsan_sync_derived", "tlsan_forward",
-    "tlsan_train_step", "tlsan_batch_pack", "tlsan_batch_index", "tlsan_grads", "tlsan_eval_ranks", "tlsan_eval_label_scores", "tlsan_eval_counts_shard", "tlsan_profile_enable", "tlsan_profile_stride",
+    "tlsan_train_step", "tlsan_train_step_opt", "tlsan_batch_pack", "tlsan_batch_index", "tlsan_grads", "tlsan_eval_ranks", "tlsan_eval_label_scores", "tlsan_eval_counts_shard", "tlsan_profile_enable", "tlsan_profile_stride",
     "tlsan_profile_collect", "tlsan_debug_stamps", "tlsan_rows_apply_workspace", "tlsan_rows_apply", "tlsan_scan_compact",
     "tlsan_route_plan", "tlsan_shard_gather", "tlsan_shard_summary", "tlsan_shard_apply_workspace", "tlsan_shard_apply",
 ]
@@ -54,6 +54,14 @@ class Packed(C.Structure):
 class HParams(C.Structure):
     _fields_ = [("lr", C.c_float), ("reg", C.c_float), ("clip", C.c_float),
                 ("norm_mode", C.c_int32), ("l2_mode", C.c_int32), ("index_slot", C.c_int32), ("index_prebuilt", C.c_int32)]
+
+
+class Optimizer(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("step", C.c_int32), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("epsilon", C.c_float), ("slot1", C.c_void_p), ("slot2", C.c_void_p)]
+
+
+OPT_SGD, OPT_ADAM, OPT_RMSPROP, OPT_ADADELTA = 0, 1, 2, 3
 
 
 class StepOut(C.Structure):
@@ -104,6 +112,9 @@ def load():
                                   C.c_void_p, C.c_size_t, C.c_void_p]
     lib.tlsan_train_step.argtypes = [P(Dims), P(Params), P(Batch), P(HParams), P(StepOut),
                                      C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.tlsan_train_step_opt.argtypes = [P(Dims), P(Params), P(Batch), P(HParams), P(Optimizer), P(StepOut),
+                                         C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.tlsan_train_step_opt.restype = C.c_int
     lib.tlsan_batch_pack.argtypes = [P(Packed), C.c_void_p, C.c_int32, P(Batch), C.c_int32, C.c_int32, C.c_void_p]
     lib.tlsan_batch_pack.restype = C.c_int
     lib.tlsan_batch_index.argtypes = [P(Dims), P(Batch), C.c_void_p, C.c_int32, C.c_void_p]

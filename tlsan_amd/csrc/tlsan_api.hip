@@ -673,16 +673,45 @@ int tlsan_batch_index(const tlsan_dims* d, const tlsan_batch* b, void* state, in
   return build_index(d, b, st, slot, (hipStream_t)stream);
 }
 
+static int check_slot(const tlsan_params* q, const char* name) {
+  if (!q || !q->item_emb || !q->item_b || !q->user_emb || !q->usert_emb || !q->cate_emb || !q->dense)
+    return fail(TLSAN_E_BADARG, "tlsan_optimizer: NULL table in %s", name);
+  if (q->ld_item % 4 || q->ld_user % 4) return fail(TLSAN_E_UNSUPPORTED, "tlsan_optimizer: row strides of %s must be multiples of 4 floats", name);
+  return TLSAN_OK;
+}
+
 int tlsan_train_step(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch* b, const tlsan_hparams* hp,
                      const tlsan_step_out* out, void* state, void* ws, size_t ws_bytes, void* stream) {
+  return tlsan_train_step_opt(d, p, b, hp, nullptr, out, state, ws, ws_bytes, stream);
+}
+
+int tlsan_train_step_opt(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch* b, const tlsan_hparams* hp,
+                         const tlsan_optimizer* opt, const tlsan_step_out* out, void* state, void* ws, size_t ws_bytes,
+                         void* stream) {
   Shape s; Ws w; St st;
   int rc = prep_step(d, &s, p, b, hp, state, ws, ws_bytes, &w, &st);
   if (rc) return rc;
+  const bool other = opt && opt->kind != TLSAN_OPT_SGD;
+  if (other) {
+    if (opt->kind != TLSAN_OPT_ADAM && opt->kind != TLSAN_OPT_RMSPROP && opt->kind != TLSAN_OPT_ADADELTA)
+      return fail(TLSAN_E_BADARG, "tlsan_optimizer: kind %d", opt->kind);
+    if (hp->l2_mode != TLSAN_L2_DENSE) return fail(TLSAN_E_UNSUPPORTED, "optimizers other than sgd update every row: l2_mode must be TLSAN_L2_DENSE");
+    if (p->table_dtype != TLSAN_TABLE_F32) return fail(TLSAN_E_UNSUPPORTED, "optimizers other than sgd need fp32 tables");
+    if ((rc = check_slot(opt->slot1, "slot1")) || (rc = check_slot(opt->slot2, "slot2"))) return rc;
+    if (opt->kind == TLSAN_OPT_ADAM && opt->step < 1) return fail(TLSAN_E_BADARG, "tlsan_optimizer: Adam's step counts from 1");
+  }
   hipStream_t hs = (hipStream_t)stream;
   tlsan_dense_layout L;
   tlsan_dense_layout_of(d, &L);
   ApplyArgs A;
   fill_apply(A, d, s, p, b, hp, w, st, L);
+  if (other) {
+    A.opt = opt->kind;
+    A.s1 = norm_params(opt->slot1, d); A.s2 = norm_params(opt->slot2, d);
+    A.ob1 = opt->beta1; A.ob2 = opt->beta2; A.oeps = opt->epsilon;
+    if (opt->kind == TLSAN_OPT_ADAM)  // adam.py: lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)
+      A.oalpha = (float)((double)hp->lr * sqrt(1.0 - pow((double)opt->beta2, opt->step)) / (1.0 - pow((double)opt->beta1, opt->step)));
+  }
   static const int split = [] { const char* v = getenv("TLSAN_APPLY_SPLIT"); return v ? atoi(v) : 1; }();
   if (hp->l2_mode == TLSAN_L2_LAZY && split) {
     if ((rc = run_backward(d, s, p, b, hp, true, out, w, st, L, hs, &A))) return rc;

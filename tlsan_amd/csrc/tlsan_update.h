@@ -524,6 +524,10 @@ struct ApplyArgs {
   const int32_t* n_uniq_item; const int32_t* n_uniq_user;   // used-row counts of this step's index slot
   float lr, reg;
   int32_t nbI, nbU, nbC, nbD;
+  // optimizers other than SGD (dense UPDATE only): accumulator tables shaped like p, see tlsan_optimizer
+  tlsan_params s1, s2;
+  int32_t opt;
+  float ob1, ob2, oeps, oalpha;   // oalpha: Adam's lr * sqrt(1 - beta2^t) / (1 - beta1^t)
   unsigned long long* stamps;  // debug: 8 s_memtime stamps per workgroup (tlsan_debug_stamps)
 };
 
@@ -601,6 +605,29 @@ __device__ __forceinline__ float apply_elem(float& w, float gs, float P, float i
   return g;
 }
 
+// One element under TF 1.8's Adam / RMSProp / Adadelta (training_ops.cc; the Sparse* forms are the
+// same arithmetic per row).  g: clipped gradient of the parameter; s1, s2: its two accumulators.
+struct OptCtx {
+  int opt;
+  float lr, b1, b2, eps, alpha;
+};
+__device__ __forceinline__ void opt_elem(const OptCtx& o, float& w, float g, float& s1, float& s2) {
+  if (o.opt == TLSAN_OPT_ADAM) {
+    s1 = s1 * o.b1 + g * (1.0f - o.b1);
+    s2 = s2 * o.b2 + (g * g) * (1.0f - o.b2);
+    w -= o.alpha * s1 / (sqrtf(s2) + o.eps);
+  } else if (o.opt == TLSAN_OPT_RMSPROP) {  // b1 = decay, b2 = momentum
+    s1 = s1 * o.b1 + (g * g) * (1.0f - o.b1);
+    s2 = s2 * o.b2 + o.lr * g / sqrtf(s1 + o.eps);
+    w -= s2;
+  } else {  // Adadelta, b1 = rho
+    s1 = s1 * o.b1 + (g * g) * (1.0f - o.b1);
+    const float upd = sqrtf(s2 + o.eps) / sqrtf(s1 + o.eps) * g;
+    w -= upd * o.lr;
+    s2 = s2 * o.b1 + (upd * upd) * (1.0f - o.b1);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // k_apply: ONE launch applies the step to every embedding table and the dense parameters.
 // Block layout: [0,nbC) one category row per workgroup, then nbI blocks of item rows and nbU
@@ -659,6 +686,8 @@ struct ApCtx {
   int tid, wave, lane, grp, l16, gid, blk;
   float P, invP, step, lazy_scale;
   uint32_t salt;      // per-step salt of the stochastic rounding (bf16 tables)
+  float coef;         // clip coefficient (optimizers other than SGD)
+  OptCtx oc;
 };
 
 #define AP_STAMP(k)                                                                      \
@@ -781,6 +810,19 @@ __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx
           w[ch][i] = wi;
         }
         if constexpr (MODE == AP_GRADS) *(f32x4*)(a.go.cate_emb + (size_t)c * a.dc + 4 * c4) = g;
+        if constexpr (MODE == AP_UPDATE && !LAZY) {
+          if (a.opt != TLSAN_OPT_SGD) {
+            f32x4 m1 = *(const f32x4*)(a.s1.cate_emb + wrow + 4 * c4), m2 = *(const f32x4*)(a.s2.cate_emb + wrow + 4 * c4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float wi = w0[i], a1 = m1[i], a2 = m2[i];
+              opt_elem(x.oc, wi, x.coef * g[i], a1, a2);
+              w[ch][i] = wi; m1[i] = a1; m2[i] = a2;
+            }
+            *(f32x4*)(a.s1.cate_emb + wrow + 4 * c4) = m1;
+            *(f32x4*)(a.s2.cate_emb + wrow + 4 * c4) = m2;
+          }
+        }
         if constexpr (MODE == AP_UPDATE) {
           tbl_st4<DT>(a.p.cate_emb, wrow + 4 * c4, w[ch], x.salt ^ 0x3c6ef372u);
 #pragma unroll
@@ -943,6 +985,21 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
           g[i] = apply_elem<MODE, LAZY>(wi, (float)acc[ch][i], x.P, x.invP, a.reg, x.step, x.lazy_scale, pe);
           w[ch][i] = wi;
         }
+        if constexpr (MODE == AP_UPDATE && !LAZY) {
+          if (a.opt != TLSAN_OPT_SGD) {
+            float* S1 = IS_ITEM ? a.s1.item_emb + (size_t)row * a.s1.ld_item : a.s1.user_emb + (size_t)row * a.s1.ld_user;
+            float* S2 = IS_ITEM ? a.s2.item_emb + (size_t)row * a.s2.ld_item : a.s2.user_emb + (size_t)row * a.s2.ld_user;
+            f32x4 m1 = *(const f32x4*)(S1 + cc), m2 = *(const f32x4*)(S2 + cc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float wi = w0[i], a1 = m1[i], a2 = m2[i];
+              opt_elem(x.oc, wi, x.coef * g[i], a1, a2);
+              w[ch][i] = wi; m1[i] = a1; m2[i] = a2;
+            }
+            *(f32x4*)(S1 + cc) = m1;
+            *(f32x4*)(S2 + cc) = m2;
+          }
+        }
         if constexpr (MODE == AP_GRADS) {
           if (!a.go.sparse || n > 0)
             *(f32x4*)((IS_ITEM ? a.go.item_emb + (size_t)row * a.go.ld_item : a.go.user_emb + (size_t)row * a.go.ld_user) + cc) = g;
@@ -960,9 +1017,22 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
           const int p = cc + i - a.di;
           if (p < a.Ls) {
             float wi = w[ch][i];
+            const float w00 = wi;
             const float gg = apply_elem<MODE, LAZY>(wi, (float)acc[ch][i], x.P, x.invP, a.reg, x.step, x.lazy_scale, part);
             if constexpr (MODE == AP_GRADS) {
               if (!a.go.sparse || n > 0) a.go.usert_emb[(size_t)row * a.go.ld_usert + p] = gg;
+            }
+            if constexpr (MODE == AP_UPDATE && !LAZY) {
+              if (a.opt != TLSAN_OPT_SGD) {
+                float* q1 = a.s1.usert_emb + (size_t)row * a.s1.ld_usert + p;
+                float* q2 = a.s2.usert_emb + (size_t)row * a.s2.ld_usert + p;
+                float a1 = *q1, a2 = *q2;
+                part -= (double)wi * (double)wi;
+                wi = w00;
+                opt_elem(x.oc, wi, x.coef * gg, a1, a2);
+                part += (double)wi * (double)wi;
+                *q1 = a1; *q2 = a2;
+              }
             }
             if constexpr (MODE == AP_UPDATE) Trow[p] = wi;
           }
@@ -976,7 +1046,21 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
       }
       if constexpr (MODE == AP_ROWNORM) part += (double)g * (double)g;
       if constexpr (MODE == AP_UPDATE) {
-        if (n > 0) a.p.item_b[(size_t)row * a.p.ld_itemb] = wb - x.step * g;
+        bool sgd = true;
+        if constexpr (!LAZY) sgd = a.opt == TLSAN_OPT_SGD;
+        if (sgd) {
+          if (n > 0) a.p.item_b[(size_t)row * a.p.ld_itemb] = wb - x.step * g;
+        } else if (g != 0.0f || a.opt == TLSAN_OPT_ADAM) {
+          // sparse Adam decays m, v of every row; the sparse RMSProp / Adadelta kernels touch the rows the
+          // candidates gathered -- recognised by their non-zero gradient (a candidate whose sigmoid
+          // saturates to exactly y has gradient 0 and is skipped here, where TF would still decay its slots)
+          float* q1 = a.s1.item_b + (size_t)row * a.s1.ld_itemb;
+          float* q2 = a.s2.item_b + (size_t)row * a.s2.ld_itemb;
+          float a1 = *q1, a2 = *q2, wi = wb;
+          opt_elem(x.oc, wi, x.coef * g, a1, a2);
+          a.p.item_b[(size_t)row * a.p.ld_itemb] = wi;
+          *q1 = a1; *q2 = a2;
+        }
       }
     }
     if constexpr (RESET) {
@@ -1007,6 +1091,8 @@ __global__ __launch_bounds__(256) void k_apply(ApplyArgs a) {
   x.step = MODE == AP_UPDATE ? a.lr * a.hdr->coef : 0.0f;
   x.lazy_scale = x.step / (x.P * (1.0f - x.step * a.reg));
   x.salt = a.hdr->nstep;
+  x.coef = MODE == AP_UPDATE ? a.hdr->coef : 0.0f;
+  x.oc.opt = a.opt; x.oc.lr = a.lr; x.oc.b1 = a.ob1; x.oc.b2 = a.ob2; x.oc.eps = a.oeps; x.oc.alpha = a.oalpha;
   const int blk = x.blk;
   if (blk < a.nbC) {
     apply_cate_block<MODE, LAZY, NC, DT>(a, x, shd, shp, sh_pos, sh_lo, sh_n, sh_wtot);
@@ -1025,7 +1111,15 @@ __global__ __launch_bounds__(256) void k_apply(ApplyArgs a) {
         if constexpr (MODE == AP_GRADS) {
           a.go.dense[nd] = g;
         } else {
-          const float wn = w0 - x.step * g;
+          float wn = w0 - x.step * g;
+          if constexpr (!LAZY) {
+            if (a.opt != TLSAN_OPT_SGD) {
+              float a1 = a.s1.dense[nd], a2 = a.s2.dense[nd];
+              wn = w0;
+              opt_elem(x.oc, wn, x.coef * g, a1, a2);
+              a.s1.dense[nd] = a1; a.s2.dense[nd] = a2;
+            }
+          }
           a.p.dense[nd] = wn;
           if (nd >= a.lay.K && nd < a.lay.k0) {
             const int idx = nd - a.lay.K;

@@ -63,6 +63,10 @@ def glorot_uniform(rng, shape):
 DENSE_KEYS = ("fwa1_W1", "fwa1_b1", "fwa1_W2", "fwa1_b2", "dense_K", "dense_b",
               "fwa2_W1", "fwa2_b1", "fwa2_W2", "fwa2_b2", "gamma")
 TABLE_KEYS = ("item_emb", "item_b", "user_emb", "usert_emb", "cate_emb")
+# optimizer -> (TLSAN_OPT_*, beta1 | decay | rho, beta2 | momentum, epsilon): TF 1.8's constructor
+# defaults, which model.py:188-193 keeps (only learning_rate is passed)
+OPTIMIZERS = {"sgd": (L.OPT_SGD, 0.0, 0.0, 0.0), "adam": (L.OPT_ADAM, 0.9, 0.999, 1e-8),
+              "rmsprop": (L.OPT_RMSPROP, 0.9, 0.0, 1e-10), "adadelta": (L.OPT_ADADELTA, 0.95, 0.0, 1e-8)}
 
 
 class DeviceBatch:
@@ -144,8 +148,16 @@ class Model(object):
             raise ValueError("num_blocks != 1 is degenerate in the reference (model.py:330-364) and unsupported")
         if config.get("dropout", 0.0) != 0.0:
             raise NotImplementedError("dropout > 0 (model.py:428-431) is not implemented")
-        if config.get("optimizer", "sgd") != "sgd":
-            raise NotImplementedError("only optimizer='sgd' (model.py:195) is implemented")
+        self.optimizer = config.get("optimizer", "sgd")           # model.py:188-195
+        if self.optimizer not in OPTIMIZERS:
+            raise ValueError("optimizer must be one of %s" % (sorted(OPTIMIZERS),))
+        if self.optimizer != "sgd":
+            # adam / rmsprop / adadelta see every row of the regularised tables every step (the L2 term
+            # makes the reference's gradients dense), so the lazy-L2 form does not apply
+            if l2_mode != "dense":
+                raise NotImplementedError("optimizer=%r needs l2_mode='dense'" % self.optimizer)
+            if table_dtype != "f32":
+                raise NotImplementedError("optimizer=%r needs fp32 tables" % self.optimizer)
         self.train_writer = _Writer(os.path.join(config.get("model_dir", "."), "train"))
         self.eval_writer = _Writer(os.path.join(config.get("model_dir", "."), "eval"))
         d = config["hidden_units"]
@@ -172,6 +184,7 @@ class Model(object):
         self.item_cate = torch.as_tensor(icl).to(self.device)
         self._alloc_params()
         self.set_params(self.init_params(config, seed))
+        self._alloc_slots()
         self.state = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
         if self.l2_mode == L.L2_LAZY:
             self.cparams.scale = self.lib.tlsan_state_scale(self.state.data_ptr())
@@ -241,6 +254,53 @@ class Model(object):
                                 self.usert_emb.data_ptr(), self.cate_emb.data_ptr(), self.dense.data_ptr(),
                                 self.dense_KT.data_ptr(), self.item_cate.data_ptr(), 0, 0, 0, 0, None,
                                 L.TABLE_BF16 if self.table_dtype == "bf16" else L.TABLE_F32)
+
+    def _alloc_slots(self):
+        """Accumulators of adam / rmsprop / adadelta (tlsan_optimizer in include/tlsan.h): two sets of
+        tables shaped like the parameters; RMSProp's first slot starts at one as in TF 1.8."""
+        self.slots = None
+        self._copt = None
+        if self.optimizer == "sgd":
+            return
+        self.slots, self._cslots = [], []
+        for which in range(2):
+            fill = 1.0 if (self.optimizer == "rmsprop" and which == 0) else 0.0
+            t = {k: torch.full_like(getattr(self, k), fill, dtype=torch.float32) for k in TABLE_KEYS}
+            t["dense"] = torch.full_like(self.dense, fill)
+            self.slots.append(t)
+            self._cslots.append(L.Params(t["item_emb"].data_ptr(), t["item_b"].data_ptr(), t["user_emb"].data_ptr(),
+                                         t["usert_emb"].data_ptr(), t["cate_emb"].data_ptr(), t["dense"].data_ptr(),
+                                         None, None, 0, 0, 0, 0, None, L.TABLE_F32))
+        kind, b1, b2, eps = OPTIMIZERS[self.optimizer]
+        self._copt = L.Optimizer(kind, 0, b1, b2, eps, C.addressof(self._cslots[0]), C.addressof(self._cslots[1]))
+
+    def _train_call(self, db, hp, out, ws):
+        if self._copt is None:
+            L.check(self.lib.tlsan_train_step(C.byref(self.dims), C.byref(self.cparams), C.byref(db.c), C.byref(hp),
+                                              C.byref(out), self.state.data_ptr(), ws.data_ptr(), ws.numel(),
+                                              self._stream()), "tlsan_train_step")
+        else:
+            self._copt.step = self._step + 1      # Adam's beta powers: updates applied so far + 1
+            L.check(self.lib.tlsan_train_step_opt(C.byref(self.dims), C.byref(self.cparams), C.byref(db.c), C.byref(hp),
+                                                  C.byref(self._copt), C.byref(out), self.state.data_ptr(),
+                                                  ws.data_ptr(), ws.numel(), self._stream()), "tlsan_train_step_opt")
+
+    def get_slots(self):
+        """The optimizer's accumulators as two dicts of numpy arrays named like the parameters (None for sgd)."""
+        if self.slots is None:
+            return None
+        out = []
+        for t in self.slots:
+            d = {k: t[k].cpu().numpy().copy() for k in TABLE_KEYS}
+            d.update(self.unpack_dense(t["dense"].cpu().numpy()))
+            out.append(d)
+        return out
+
+    def set_slots(self, slots):
+        for t, src in zip(self.slots, slots):
+            for k in TABLE_KEYS:
+                t[k].copy_(torch.as_tensor(np.asarray(src[k], np.float32)))
+            t["dense"].copy_(torch.as_tensor(self.pack_dense(src)))
 
     def _dense_slices(self):
         lay, d = self.lay, self.config["hidden_units"]
@@ -339,10 +399,10 @@ class Model(object):
         ws = self._workspace(db.B, db.Sn)
         out = L.StepOut(self._out.data_ptr(), self._out.data_ptr() + 4, None if logits is None else logits.data_ptr(), None)
         if torch.cuda.is_current_stream_capturing():   # hipGraph capture: one self-contained step
+            if self.optimizer == "adam":
+                raise NotImplementedError("Adam's step count is a launch argument: capture is not supported")
             hp = self.hparams(lr)
-            L.check(self.lib.tlsan_train_step(C.byref(self.dims), C.byref(self.cparams), C.byref(db.c), C.byref(hp),
-                                              C.byref(out), self.state.data_ptr(), ws.data_ptr(), ws.numel(),
-                                              self._stream()), "tlsan_train_step")
+            self._train_call(db, hp, out, ws)
             self._step += 1
             return db
         if self.l2_mode == L.L2_LAZY and self.renorm_every and self._step and self._step % self.renorm_every == 0:
@@ -365,9 +425,7 @@ class Model(object):
             ndb = self.device_batch(next_batch)
             self._pre_event.record(main)
         hp = self.hparams(lr, k, 1 if pre else 0)
-        L.check(self.lib.tlsan_train_step(C.byref(self.dims), C.byref(self.cparams), C.byref(db.c), C.byref(hp),
-                                          C.byref(out), self.state.data_ptr(), ws.data_ptr(), ws.numel(),
-                                          self._stream()), "tlsan_train_step")
+        self._train_call(db, hp, out, ws)
         if ndb is not None:
             if self._side is None:
                 self._side = torch.cuda.Stream(self.device)
@@ -486,7 +544,11 @@ class Model(object):
         os.makedirs(self.config["model_dir"], exist_ok=True)
         base = os.path.join(self.config["model_dir"], "TLSAN")
         path = "%s-%d.npz" % (base, self._step)
-        np.savez(path, global_step=self._step, global_epoch_step=self._epoch, **self.get_params())
+        extra = {}
+        if self.slots is not None:        # tf.train.Saver keeps the optimizer's slot variables too
+            for n, sl in enumerate(self.get_slots()):
+                extra.update({"slot%d/%s" % (n + 1, k): v for k, v in sl.items()})
+        np.savez(path, global_step=self._step, global_epoch_step=self._epoch, **self.get_params(), **extra)
         json.dump(self.config, open("%s-%d.json" % (base, self._step), "w"), indent=2)
         print("model saved at %s" % path, flush=True)
         return path
@@ -497,4 +559,6 @@ class Model(object):
         self.set_params({k: z[k] for k in TABLE_KEYS + DENSE_KEYS})
         self._step = int(z["global_step"])
         self._epoch = int(z["global_epoch_step"])
+        if self.slots is not None and "slot1/item_emb" in z:
+            self.set_slots([{k: z["slot%d/%s" % (n, k)] for k in TABLE_KEYS + DENSE_KEYS} for n in (1, 2)])
         print("model restored from %s" % path, flush=True)
