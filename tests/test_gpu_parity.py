@@ -213,7 +213,10 @@ def test_errors():
     cfg = make_config(d=96)
     with pytest.raises(TlsanError):
         Model(cfg, np.zeros(cfg["item_count"], np.int32))
-    cfg = make_config(d=64, optimizer="adam")
+    cfg = make_config(d=64, optimizer="adagrad")          # not one of model.py:188-195
+    with pytest.raises(ValueError):
+        Model(cfg, np.zeros(cfg["item_count"], np.int32))
+    cfg = make_config(d=64, dropout=0.1)
     with pytest.raises(NotImplementedError):
         Model(cfg, np.zeros(cfg["item_count"], np.int32))
     cfg = make_config(d=64)
