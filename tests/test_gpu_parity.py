@@ -370,6 +370,14 @@ def test_train_driver_on_real_clothing(tmp_path):
     assert 0.80 < res["init_auc"] < 0.90          # the README leak quirk: ~0.86 at random init
     assert res["final_auc"] > res["init_auc"] + 0.003
     assert len(res["prec"]) == 6 and 0.0 <= res["recall"][-1] <= 1.0
+    # summaries (model.py:174-183, train.py:91-118) land next to the checkpoints as step,tag,value rows
+    rows = [l.strip().split(",") for l in open(tmp_path / "ckpt" / "train" / "scalars.csv")]
+    tags = {r[1] for r in rows}
+    assert {"Training Loss", "L2_norm_user_item", "gamma", "embedding/1_item_emb/std"} <= tags
+    assert sorted({int(r[0]) for r in rows}) == [100, 200, 300, 400, 500, 600]          # display_freq 100
+    ev = [l.strip().split(",") for l in open(tmp_path / "ckpt" / "eval" / "scalars.csv")]
+    assert [float(r[2]) for r in ev if r[1] == "AUC"][-1] == pytest.approx(res["final_auc"], abs=1e-6)
+    assert {"P@1", "P@50", "R@20"} <= {r[1] for r in ev}
 
 
 @pytest.mark.parametrize("d,Ls,Sn,B", [(128, 20, 3, 37), (128, 90, 5, 21), (64, 33, 2, 50), (256, 16, 2, 9), (256, 90, 4, 19)])

@@ -39,6 +39,7 @@ CPU/gloo in the tests); all arithmetic on rows is in libtlsan_hip.so.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -321,7 +322,8 @@ class ShardedModel:
         self._epoch = 0
         self.global_step = _Var(lambda: self._step)
         self.global_epoch_step = _Var(lambda: self._epoch)
-        self.train_writer, self.eval_writer = _Writer("train"), _Writer("eval")
+        self.train_writer = _Writer(os.path.join(config.get("model_dir", "."), "train"))
+        self.eval_writer = _Writer(os.path.join(config.get("model_dir", "."), "eval"))
         self.set_params(Model.init_params(config, seed))   # identical on every rank (numpy, seeded)
 
     # ------------------------------------------------------------------ helpers
@@ -699,6 +701,64 @@ class ShardedModel:
             out[k] = flat[off:off + n].reshape(shape).copy()
         return out
 
+    # ------------------------------------------------------------------ checkpoints (model.py:302-313)
+    def save(self, sess=None, sharded=True):
+        """Sharded checkpoint: every rank writes its own rows (TLSAN-<step>.shard<r>of<G>.npz: the fused
+        [item | user] shard as it sits in HBM), rank 0 adds the replicated parts (cate_emb, dense weights,
+        counters) and the config JSON -- nothing is gathered, so tables that exceed one host's memory
+        can be saved.  sharded=False gathers everything to rank 0 and writes the single-GPU format of
+        tlsan_amd.model.Model.save (restores into either model, any world size).  Returns the path prefix."""
+        import json
+        os.makedirs(self.config["model_dir"], exist_ok=True)
+        base = os.path.join(self.config["model_dir"], "TLSAN-%d" % self._step)
+        if not sharded:
+            full = self.gather_params()                      # (a collective: every rank takes part)
+            if self.rank == 0:
+                np.savez(base + ".npz", global_step=self._step, global_epoch_step=self._epoch, **full)
+        else:
+            np.savez("%s.shard%dof%d.npz" % (base, self.rank, self.world), shard=self.shard.cpu().numpy(),
+                     cI=self.cI, W=self.W, item_count=self.I, user_count=self.U)
+            if self.rank == 0:
+                np.savez(base + ".replicated.npz", cate_emb=self.cate_emb.cpu().numpy(), dense=self.dense.cpu().numpy(),
+                         global_step=self._step, global_epoch_step=self._epoch, world=self.world)
+        if self.rank == 0:
+            json.dump(self.config, open(base + ".json", "w"), indent=2)
+        if self.world > 1:
+            dist.barrier(group=self.group)                   # the files exist when any rank returns
+        return base
+
+    def restore(self, sess, path):
+        """`path`: the prefix save() returned (sharded checkpoint of the SAME world size), or a
+        single-file .npz checkpoint of Model.save / save(sharded=False) -- then every rank keeps its rows."""
+        if path.endswith(".npz"):
+            z = np.load(path)
+            self.set_params({k: z[k] for k in z.files if k not in ("global_step", "global_epoch_step")})
+        else:
+            rep_ = np.load(path + ".replicated.npz")
+            if int(rep_["world"]) != self.world:
+                raise ValueError("sharded checkpoint of %d ranks cannot be restored on %d (use sharded=False)"
+                                 % (int(rep_["world"]), self.world))
+            zs = np.load("%s.shard%dof%d.npz" % (path, self.rank, self.world))
+            if tuple(zs["shard"].shape) != tuple(self.shard.shape) or int(zs["cI"]) != self.cI:
+                raise ValueError("shard shape %s does not match this model" % (zs["shard"].shape,))
+            self.shard.copy_(torch.as_tensor(zs["shard"]))
+            self.cate_emb.copy_(torch.as_tensor(rep_["cate_emb"]))
+            self.dense.copy_(torch.as_tensor(rep_["dense"]))
+            K = self.dense[self.lay.K:self.lay.K + self.d * self.d].view(self.d, self.d)
+            self.dense_KT.copy_(K.t())
+            self._refresh_squares()
+            z = rep_
+        self._step = int(z["global_step"])
+        self._epoch = int(z["global_epoch_step"])
+
+    def _refresh_squares(self):
+        it, us = self._table_views()
+        di, Ls = self.di, self.Ls
+        # running sums of squares of the regularised tables (tf.nn.l2_loss terms, model.py:164-169)
+        self._sq[0] = it[:, :di].double().pow(2).sum() + us[:, :di + Ls].double().pow(2).sum()
+        self._sq[1] = self.cate_emb.double().pow(2).sum()
+        self._flat[self.lay.n_dense + self.C * self.dc + 2] = self._sq[0].float()   # rides in the all-reduce
+
     def set_params(self, p):
         """Load full parameters (dict of numpy arrays); every rank keeps its own rows."""
         G, r, di, Ls = self.world, self.rank, self.di, self.Ls
@@ -712,8 +772,4 @@ class ShardedModel:
         self.shard.copy_(torch.as_tensor(t))
         self.cate_emb.copy_(torch.as_tensor(np.asarray(p["cate_emb"], np.float32)))
         self._pack_dense(p)
-        it, us = self._table_views()
-        # running sums of squares of the regularised tables (tf.nn.l2_loss terms, model.py:164-169)
-        self._sq[0] = it[:, :di].double().pow(2).sum() + us[:, :di + Ls].double().pow(2).sum()
-        self._sq[1] = self.cate_emb.double().pow(2).sum()
-        self._flat[self.lay.n_dense + self.C * self.dc + 2] = self._sq[0].float()   # rides in the all-reduce
+        self._refresh_squares()

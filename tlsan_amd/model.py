@@ -41,17 +41,32 @@ class _Var:
 
 
 class _Writer:
-    """tf.summary.FileWriter stand-in (model.py:18-19): keeps (tag, value, step) rows."""
+    """tf.summary.FileWriter stand-in (model.py:18-19; train.py:91-118): scalar summaries as rows
+    `step,tag,value` appended to <logdir>/scalars.csv (histogram summaries of model.py:174-181 are kept
+    as their count / min / max / mean / std).  Also keeps the rows in memory (`.rows`)."""
 
     def __init__(self, path):
         self.path = path
         self.rows = []
+        self._pending = []
 
     def add_summary(self, summary=None, global_step=None):
         self.rows.append((global_step, summary))
+        items = summary if isinstance(summary, list) else [summary]
+        for it in items:
+            if isinstance(it, tuple) and len(it) == 2:
+                self._pending.append((global_step, it[0], it[1]))
+        if len(self._pending) >= 64:
+            self.flush()
 
     def flush(self):
-        pass
+        if not self._pending:
+            return
+        os.makedirs(self.path, exist_ok=True)
+        with open(os.path.join(self.path, "scalars.csv"), "a") as f:
+            for step, tag, val in self._pending:
+                f.write("%s,%s,%.9g\n" % ("" if step is None else int(step), tag, float(val)))
+        self._pending = []
 
 
 def glorot_uniform(rng, shape):
@@ -462,8 +477,27 @@ class Model(object):
         self.train_async(batch, lr)
         loss = float(self._out[0].item())
         if add_summary:
-            self.train_writer.add_summary(("Training Loss", loss), global_step=self._step)
+            self.train_writer.add_summary(self.train_summary(loss), global_step=self._step)
         return loss
+
+    def train_summary(self, loss=None):
+        """model.py:174-183's merged summary as (tag, value) pairs: the two scalars, and for every
+        histogram its count / min / max / mean / std (`attention_output`, the histogram of u_t, needs
+        a forward pass of the batch and is not kept)."""
+        P = float(self.state[:4].view(torch.float32).item()) if self.l2_mode == L.L2_LAZY else 1.0
+        out = []
+        l2 = 0.0
+        for tag, t in (("embedding/1_item_emb", self.item_emb), ("embedding/2_user_emb", self.user_emb),
+                       ("embedding/3_cate_emb", self.cate_emb), ("embedding/4_usert_emb", self.usert_emb)):
+            v = t.float() * P                              # true parameter = P * stored (lazy L2)
+            l2 += 0.5 * float(v.double().pow(2).sum().item())     # tf.nn.l2_loss (model.py:164-169)
+            for name, x in (("count", v.numel()), ("min", v.min().item()), ("max", v.max().item()),
+                            ("mean", v.mean().item()), ("std", v.std().item())):
+                out.append(("%s/%s" % (tag, name), float(x)))
+        out.append(("gamma", float(self.dense[self.lay.gamma].item())))
+        out.append(("L2_norm_user_item", l2))
+        out.append(("Training Loss", float(self._out[0].item()) if loss is None else float(loss)))
+        return out
 
     def last_gnorm(self):
         return float(self._out[1].item())

@@ -72,7 +72,9 @@ def eval_auc(model, test_set, config):
     s = 0.0
     for _, batch in _test_batches(test_set, config):
         s += model.eval_auc(None, batch) * len(batch[0] if isinstance(batch, tuple) else batch)
-    return s / len(test_set)
+    res = s / len(test_set)
+    model.eval_writer.add_summary(("AUC", res), global_step=model.global_step.eval())     # train.py:91-94
+    return res
 
 
 def eval_prec_recall(model, test_set, config):
@@ -80,7 +82,12 @@ def eval_prec_recall(model, test_set, config):
     for _, batch in _test_batches(test_set, config):
         model.eval_prec(None, batch)
         model.eval_recall(None, batch)
-    return ([getattr(model, "prec_%d" % k).eval() for k in KS], [getattr(model, "recall_%d" % k).eval() for k in KS])
+    prec = [getattr(model, "prec_%d" % k).eval() for k in KS]
+    recall = [getattr(model, "recall_%d" % k).eval() for k in KS]
+    step = model.global_step.eval()
+    model.eval_writer.add_summary([("P@%d" % k, v) for k, v in zip(KS, prec)] +                 # train.py:103-106
+                                  [("R@%d" % k, v) for k, v in zip(KS, recall)], global_step=step)   # :114-117
+    return prec, recall
 
 
 def _lookahead(it):
@@ -128,6 +135,8 @@ def train(args):
             model.train_async(batch, lr, next_batch=None if last else nxt)
             loss_sum += model._out[0]
             step = model.global_step.eval()
+            if args.display_freq and step % args.display_freq == 0:    # train.py:194-195 (add_summary)
+                model.train_writer.add_summary(model.train_summary(), global_step=step)
             if step % args.eval_freq == 0:
                 auc = eval_auc(model, test_set, config)
                 history.append((step, time.time() - t0, auc))
@@ -149,6 +158,8 @@ def train(args):
     prec, recall = eval_prec_recall(model, test_set, config)
     final_auc = eval_auc(model, test_set, config)
     best_auc = max(best_auc, final_auc)
+    model.train_writer.flush()
+    model.eval_writer.flush()
     say("Best test_auc:", best_auc)
     say("P@k:", " ".join("@%d=%.4f" % (k, p) for k, p in zip(KS, prec)))
     say("R@k:", " ".join("@%d=%.4f" % (k, r) for k, r in zip(KS, recall)))
