@@ -168,24 +168,26 @@ def test_rows_apply_matches_numpy_and_is_deterministic():
     assert abs(outs[0][1] - (ref[:, :reg_cols] ** 2).sum()) < 1e-3 * (ref[:, :reg_cols] ** 2).sum()
 
 
-def test_route_plan_matches_key_router():
+@pytest.mark.parametrize("n_items,n_users,n_uses", [(203, 117, 700), (260_000, 90_000, 5000)])
+def test_route_plan_matches_key_router(n_items, n_users, n_uses):
     """tlsan_route_plan (the GPU routing of the sharded step) against KeyRouter.plan with the torch
     scan (what tests/test_dist_cpu.py checks over gloo): same distinct rows, same per-owner counts,
-    same local row numbers in all-to-all order, same compact ids, same category map."""
+    same local row numbers in all-to-all order, same compact ids, same category map.  The large case
+    has a key space of 86 chunks of 4096 -> the scan runs in its two-launch form with chunk sums."""
     import ctypes as C
     from tlsan_amd import _lib as L
     from tlsan_amd.dist import KeyRouter
     lib = L.load()
-    G, n_items, n_users = 4, 203, 117
+    G = 4
     r = KeyRouter(n_items, n_users, G, 0)
     rng = np.random.RandomState(11)
-    items, users = rng.randint(0, n_items, 700), rng.randint(0, n_users, 64)
+    items, users = rng.randint(0, n_items, n_uses), rng.randint(0, n_users, 64)
     keys = torch.cat([r.item_keys(torch.as_tensor(items)), r.user_keys(torch.as_tensor(users))]).to(torch.int32).cuda()
     cbk = torch.full((r.nkeys,), -1, dtype=torch.int32)
     ids = np.arange(n_items)
     cbk[(ids % G) * r.R + ids // G] = torch.as_tensor(rng.randint(0, 9, n_items).astype(np.int32))
     cbk = cbk.cuda()
-    nk, cap, pad = int(keys.numel()), r.R, 1024
+    nk, cap, pad = int(keys.numel()), r.R, 8192
     z = lambda n: torch.zeros(n, dtype=torch.int32, device="cuda")
     flags, rank, uniq, n_uniq, sendbuf, cate_c, comp = z(r.nkeys), z(r.nkeys), z(r.nkeys), z(1), z(G * (1 + cap)), z(pad), z(nk)
     L.check(lib.tlsan_route_plan(keys.data_ptr(), nk, r.R, G, cbk.data_ptr(), flags.data_ptr(), rank.data_ptr(), uniq.data_ptr(),

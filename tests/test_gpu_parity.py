@@ -660,3 +660,27 @@ def test_other_optimizers_track_oracle(optimizer, lr, tmp_path):
     assert np.array_equal(m.dense_KT.cpu().numpy(), m.get_params()["dense_K"].T)
     with pytest.raises(NotImplementedError):
         _model(cfg, cat, p, l2_mode="lazy")
+
+
+@pytest.mark.parametrize("l2_mode", ["lazy", "dense"])
+def test_large_tables_take_the_two_level_scan(l2_mode):
+    """Tables of more than 16 chunks of 4096 rows build their destination index with per-chunk sums
+    (k_scan_block_sums + k_index_scan) instead of the single launch; the step must not notice.
+    Two steps on 300k users / 150k items against the oracle."""
+    cfg = make_config(U=300_000, I=150_000, C=40, d=64, regulation_rate=1e-3, max_gradient_norm=5.0)
+    p = _p32(random_params(cfg, seed=81))
+    _, cat = random_batch(cfg, B=4, Sn=2, seed=0)
+    batches = [random_batch(cfg, B=48, Sn=2 + s, seed=810 + s)[0] for s in range(2)]
+    m = _model(cfg, cat, p, l2_mode=l2_mode)
+    q = dict(p)
+    for b in batches:
+        loss, newq, info = orc.train_step(q, cat, b, 8, cfg["regulation_rate"], lr=0.9)
+        l = m.train(None, _tuple(b), 0.9)
+        assert abs(l - loss) < 1e-4 * max(1.0, abs(loss))
+        assert abs(m.last_gnorm() - info["norm"]) < 2e-4 * info["norm"]
+        q = newq
+    got = m.get_params()
+    for k in q:
+        du = np.asarray(got[k], np.float64).reshape(p[k].shape) - p[k]
+        dr = q[k] - p[k]
+        assert np.abs(du - dr).max() < 3e-4 * (np.abs(dr).max() + 1e-9) + 3e-7, k

@@ -143,6 +143,7 @@ struct St {  // persistent state
   int32_t *cate_off, *cate_cnt, *cate_cur, *cate_items;   // static CSR category -> items
   StateHdr* hdr;
   double *S_part, *S_total;
+  long long* scan_bsum;                                   // per-chunk sums of the index scan (large tables)
   size_t bytes;
   int nbI, nbU, nbC;
 };
@@ -172,6 +173,8 @@ static void carve_state(const tlsan_dims* d, char* base, St* s) {
   s->cate_cur = (int32_t*)take(4 * (size_t)d->cate_count);
   s->cate_items = (int32_t*)take(4 * (size_t)d->item_count);
   s->S_part = (double*)take(8 * (size_t)(s->nbI + s->nbU + s->nbC));
+  s->scan_bsum = (long long*)take(8 * ((size_t)(d->item_count + 4095) / 4096 + (d->cate_count + 4095) / 4096 +
+                                       (d->user_count + 4095) / 4096));
   s->S_total = base ? &s->hdr->St : nullptr;
   s->bytes = o;
 }
@@ -323,6 +326,28 @@ static int launch_apply(int mode, bool lazy, ApplyArgs A, bool with_dense, int B
   CHECK_LAUNCH("k_apply");
   return TLSAN_OK;
 }
+
+// exclusive scans of up to three count arrays in one launch (two for large tables, see k_index_scan);
+// bsum: scratch of >= nscan packed sums, or NULL (then always the single launch)
+static int launch_scan(ScanArgs& sa, int nscan, long long* bsum, hipStream_t hs) {
+  int big = 0;
+  for (int k = 0; k < 3; ++k) {
+    const int nb = (k < 2 ? sa.blk0[k + 1] : nscan) - sa.blk0[k];
+    if (nb > SCAN_TWO_LEVEL_BLOCKS) big = 1;
+  }
+  sa.bsum = nullptr;
+  if (big && bsum) {
+    sa.bsum = bsum;
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(nscan), dim3(1024), 0, hs, sa);
+    CHECK_LAUNCH("k_scan_block_sums");
+  }
+  hipLaunchKernelGGL(k_index_scan, dim3(nscan), dim3(1024), 0, hs, sa);
+  CHECK_LAUNCH("k_index_scan");
+  return TLSAN_OK;
+}
+
+static int scan_compact_impl(const int32_t* cnt, int32_t n, int32_t* prefix, int32_t* uniq, int32_t* n_uniq, long long* bsum,
+                             hipStream_t hs);
 
 // static CSR category -> items from p->item_cate (counting sort with the generic index kernels)
 static int build_cate_csr(const tlsan_dims* d, const tlsan_params* p, const St& st, hipStream_t hs) {
@@ -529,9 +554,7 @@ static int build_index(const tlsan_dims* d, const tlsan_batch* b, const St& st, 
   sa.urec[0] = st.urec_item[k]; sa.urec[2] = st.urec_user[k];
   sa.total[0] = sa.total[1] = sa.total[2] = 1;
   sa.n_uniq[0] = &st.hdr->n_uniq[k][0]; sa.n_uniq[1] = nullptr; sa.n_uniq[2] = &st.hdr->n_uniq[k][1];
-  hipLaunchKernelGGL(k_index_scan, dim3(nscan), dim3(1024), 0, hs, sa);
-  CHECK_LAUNCH("k_index_scan");
-  return TLSAN_OK;
+  return launch_scan(sa, nscan, st.scan_bsum, hs);
 }
 
 // shared front half of train_step / grads: index build, fused fwd+bwd, dense-grad reduction
@@ -822,7 +845,7 @@ static int eval_ranks_impl(const tlsan_dims* d, const tlsan_params* p, const flo
   return TLSAN_OK;
 }
 
-struct RowsWs { int32_t *cnt, *off, *cur, *list; double* part; size_t bytes; int nblk; };
+struct RowsWs { int32_t *cnt, *off, *cur, *list; double* part; long long* bsum; size_t bytes; int nblk; };
 static void carve_rows(int32_t nrows, int32_t n, char* base, RowsWs* w) {
   size_t o = 0;
   auto take = [&](size_t nb) { char* p = base ? base + o : nullptr; o += al(nb); return p; };
@@ -832,6 +855,7 @@ static void carve_rows(int32_t nrows, int32_t n, char* base, RowsWs* w) {
   w->cur = (int32_t*)take(4 * (size_t)nrows);
   w->list = (int32_t*)take(4 * (size_t)(n > 0 ? n : 1));
   w->part = (double*)take(8 * (size_t)w->nblk);
+  w->bsum = (long long*)take(8 * ((size_t)nrows + 4095) / 4096);
   w->bytes = o;
 }
 
@@ -864,8 +888,10 @@ int tlsan_rows_apply(float* W, int32_t ld, int32_t nrows, int32_t width, int32_t
   sa.cnt[0] = w.cnt; sa.off[0] = w.off; sa.cur[0] = w.cur; sa.n[0] = nrows;
   const int nscan = (nrows + 4095) / 4096;
   sa.blk0[0] = 0; sa.blk0[1] = nscan; sa.blk0[2] = nscan;
-  hipLaunchKernelGGL(k_index_scan, dim3(nscan), dim3(1024), 0, hs, sa);
-  CHECK_LAUNCH("k_index_scan");
+  {
+    const int rc = launch_scan(sa, nscan, w.bsum, hs);
+    if (rc) return rc;
+  }
   if (n > 0) { hipLaunchKernelGGL(k_gidx<true>, dim3((n + 255) / 256), dim3(256), 0, hs, gi); CHECK_LAUNCH("k_gidx<fill>"); }
   RowsArgs ra;
   ra.W = W; ra.ld = ld; ra.nrows = nrows; ra.width = width; ra.reg_cols = reg_cols; ra.G = grows; ra.ldg = ldg;
@@ -899,7 +925,13 @@ int tlsan_route_plan(const int32_t* keys, int32_t n_keys, int32_t R, int32_t G, 
   if (cate_pad > nt) nt = cate_pad;
   hipLaunchKernelGGL(k_route_mark, dim3((n_keys + 255) / 256), dim3(256), 0, hs, a);
   CHECK_LAUNCH("k_route_mark");
-  int rc = tlsan_scan_compact(flags, nkeys, rank, uniq, n_uniq, stream);
+  // chunk sums of the scan: `uniq` receives at most min(n_keys, nkeys) entries, so when the key space
+  // is larger than the batch its tail is free during the call (8-byte aligned slice)
+  const int nscan = (nkeys + 4095) / 4096;
+  const long long first = ((long long)(n_keys < nkeys ? n_keys : nkeys) + 1) / 2 * 2;
+  long long* bsum = ((reinterpret_cast<uintptr_t>(uniq) & 7) == 0 && first + 2LL * nscan <= nkeys)
+                        ? reinterpret_cast<long long*>(uniq + first) : nullptr;
+  int rc = scan_compact_impl(flags, nkeys, rank, uniq, n_uniq, bsum, hs);
   if (rc) return rc;
   hipLaunchKernelGGL(k_route_finish, dim3((nt + 255) / 256), dim3(256), 0, hs, a);
   CHECK_LAUNCH("k_route_finish");
@@ -979,7 +1011,8 @@ int tlsan_shard_apply(float* shard, int32_t ld, int32_t cI, int32_t R, int32_t W
   return TLSAN_OK;
 }
 
-int tlsan_scan_compact(const int32_t* cnt, int32_t n, int32_t* prefix, int32_t* uniq, int32_t* n_uniq, void* stream) {
+static int scan_compact_impl(const int32_t* cnt, int32_t n, int32_t* prefix, int32_t* uniq, int32_t* n_uniq, long long* bsum,
+                             hipStream_t hs) {
   if (!cnt || !prefix || n < 1) return fail(TLSAN_E_BADARG, "tlsan_scan_compact: bad arguments");
   ScanArgs sa;
   memset(&sa, 0, sizeof(sa));
@@ -987,9 +1020,13 @@ int tlsan_scan_compact(const int32_t* cnt, int32_t n, int32_t* prefix, int32_t* 
   sa.uniq[0] = uniq; sa.n_uniq[0] = n_uniq;
   const int nscan = (n + 4095) / 4096;
   sa.blk0[0] = 0; sa.blk0[1] = nscan; sa.blk0[2] = nscan;
-  hipLaunchKernelGGL(k_index_scan, dim3(nscan), dim3(1024), 0, (hipStream_t)stream, sa);
-  CHECK_LAUNCH("k_index_scan");
-  return TLSAN_OK;
+  return launch_scan(sa, nscan, bsum, hs);
+}
+
+// (no scratch: one launch whose prefix re-read grows with the square of n / 4096 -- meant for tables up
+//  to a few hundred thousand entries; tlsan_route_plan scans its key space with chunk sums)
+int tlsan_scan_compact(const int32_t* cnt, int32_t n, int32_t* prefix, int32_t* uniq, int32_t* n_uniq, void* stream) {
+  return scan_compact_impl(cnt, n, prefix, uniq, n_uniq, nullptr, (hipStream_t)stream);
 }
 
 int tlsan_debug_stamps(void* device_buf) {

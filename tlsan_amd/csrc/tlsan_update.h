@@ -20,7 +20,8 @@ struct StateHdr {
   double St;               // sum of squares of the four STORED tables (true value: P^2 * St)
   float coef;              // global-norm clip coefficient of the current step (model.py:201)
   uint32_t nstep;          // update steps taken (salt of the stochastic rounding of bf16 tables)
-  float pad0[22];
+  int32_t spart_n;         // leading entries of S_part the last update may have written (the rest is zero)
+  float pad0[21];
   // ---- its own 128-B line: hammered by atomics, must not share a line with anything that is read
   int32_t ticket;          // arrival counter of k_dense_finalize: the last workgroup writes the step summary
   int32_t pad1[31];
@@ -106,13 +107,45 @@ struct ScanArgs {
   int32_t* n_uniq[3];  // optional: how many
   int4* urec[3];       // optional: (id, first position, count) of the ids with cnt > 0 (lazy L2: rows to update)
   int32_t total[3];    // != 0: off has n+1 entries, off[n] = sum of all counts
+  long long* bsum;     // optional [gridDim.x]: per-chunk packed sums (k_scan_block_sums) -- large tables
 };
+#define SCAN_TWO_LEVEL_BLOCKS 16  // tables of more chunks than this take the two-launch form
 
 // Exclusive scan of the per-row counts, one launch: block j of a table owns ids
 // [4096 j, 4096 j + 4096); it first sums every count that precedes its chunk (coalesced
 // re-read of at most n ints from L2: cheaper than a second launch or a serial carry chain),
 // then scans its own chunk.  The number of non-zero counts is scanned alongside (high 32 bits
 // of a packed 64-bit sum) to compact the list of used rows.
+// The re-read is quadratic in the number of chunks, so for large tables (millions of rows) a
+// first launch leaves one packed sum per chunk (k_scan_block_sums) and the blocks add up the
+// preceding CHUNK sums instead (ScanArgs.bsum).
+__global__ __launch_bounds__(1024) void k_scan_block_sums(ScanArgs a) {
+  __shared__ long long wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int which = 0;
+  if ((int)blockIdx.x >= a.blk0[1]) which = 1;
+  if ((int)blockIdx.x >= a.blk0[2]) which = 2;
+  const int32_t* __restrict__ cnt = a.cnt[which];
+  const int n = a.n[which];
+  const int i0 = ((int)blockIdx.x - a.blk0[which]) * 4096 + tid * 4;
+  long long part = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = (i0 + k < n) ? cnt[i0 + k] : 0;
+    part += (long long)c + ((long long)(c > 0) << 32);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
+  if (lane == 0) wsum[wave] = part;
+  __syncthreads();
+  if (tid == 0) {
+    long long t = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += wsum[w];
+    a.bsum[blockIdx.x] = t;
+  }
+}
+
 __global__ __launch_bounds__(1024) void k_index_scan(ScanArgs a) {
   __shared__ long long wsum[16];
   __shared__ long long prefix;
@@ -126,9 +159,13 @@ __global__ __launch_bounds__(1024) void k_index_scan(ScanArgs a) {
   auto pack = [](int c) { return (long long)c + ((long long)(c > 0) << 32); };
   // ---- packed sum over cnt[0, base)
   long long part = 0;
-  for (int k = tid * 4; k < base; k += 4096) {
-    const int4 v = *(const int4*)(cnt + k);  // base is a multiple of 4096 -> always in range
-    part += pack(v.x) + pack(v.y) + pack(v.z) + pack(v.w);
+  if (a.bsum != nullptr) {
+    for (int k = a.blk0[which] + tid; k < (int)blockIdx.x; k += 1024) part += a.bsum[k];
+  } else {
+    for (int k = tid * 4; k < base; k += 4096) {
+      const int4 v = *(const int4*)(cnt + k);  // base is a multiple of 4096 -> always in range
+      part += pack(v.x) + pack(v.y) + pack(v.z) + pack(v.w);
+    }
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
@@ -357,8 +394,11 @@ __device__ __forceinline__ void dense_finalize_block(const FinArgs& a, int nbK, 
   if (blk == nbK + nbS) {
     // the apply kernels leave per-workgroup CHANGES of the tables' sum of squares: fold them in
     // and clear them (consumed exactly once)
-    const double s = block_sum_double(a.S_part, a.n_spart, shd);
-    for (int k = tid; k < a.n_spart; k += 256) a.S_part[k] = 0.0;
+    // (only the entries the last update can have written: a lazy update of a 10^7-row table leaves
+    //  a few thousand, not rows / 16)
+    const int np = min(a.n_spart, a.hdr->spart_n);
+    const double s = block_sum_double(a.S_part, np, shd);
+    for (int k = tid; k < np; k += 256) a.S_part[k] = 0.0;
     if (tid == 0) pub_f64(a.S_total, *a.S_total + s);
     __syncthreads();  // shd is reused below
   }
@@ -520,7 +560,7 @@ struct ApplyArgs {
   float* Rc; float* Ri; float* Rb; float* Ru;   // PRESUM -> k_update_lazy: summed rows [C][dc], [slot][di], [slot], [slot][WU]
   double* part_out;        // UPDATE: change of the stored tables' sum of squares per workgroup;
                            // SUMSQ: sum of squares; ROWNORM: sum g^2
-  const StateHdr* hdr;     // P, P_prev, coef
+  StateHdr* hdr;           // P, P_prev, coef (read); spart_n (written by an update)
   const int32_t* n_uniq_item; const int32_t* n_uniq_user;   // used-row counts of this step's index slot
   float lr, reg;
   int32_t nbI, nbU, nbC, nbD;
@@ -1092,6 +1132,7 @@ __global__ __launch_bounds__(256) void k_apply(ApplyArgs a) {
   x.lazy_scale = x.step / (x.P * (1.0f - x.step * a.reg));
   x.salt = a.hdr->nstep;
   x.coef = MODE == AP_UPDATE ? a.hdr->coef : 0.0f;
+  if (MODE == AP_UPDATE && x.blk == 0 && x.tid == 0) a.hdr->spart_n = a.nbC + a.nbI + a.nbU;
   x.oc.opt = a.opt; x.oc.lr = a.lr; x.oc.b1 = a.ob1; x.oc.b2 = a.ob2; x.oc.eps = a.oeps; x.oc.alpha = a.oalpha;
   const int blk = x.blk;
   if (blk < a.nbC) {
@@ -1185,6 +1226,7 @@ __global__ __launch_bounds__(256) void k_update_lazy(ApplyArgs a, int nbC16) {
   const float step = a.lr * a.hdr->coef;
   const float lazy_scale = step / (P * (1.0f - step * a.reg));
   const uint32_t salt = a.hdr->nstep;
+  if (blk == 0 && tid == 0) a.hdr->spart_n = nbC16 + a.nbI + a.nbU;
   double part = 0.0;
   if (blk < nbC16) {
     const int c = blk * 16 + gid;
