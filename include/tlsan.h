@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TLSAN_ABI_VERSION 5
+#define TLSAN_ABI_VERSION 6
 
 enum {
   TLSAN_OK = 0,
@@ -302,10 +302,12 @@ int tlsan_rows_apply(float* W, int32_t ld, int32_t nrows, int32_t width, int32_t
  *   sendbuf [G][1 + cap] = per owner {count, row numbers inside the owner's shard ...}: the payload of
  *   ONE equal-split all-to-all (cap >= min(R, n_keys)).  cate_c entries [n_uniq, cate_pad) are set
  *   to -1 (a compact table padded to a fixed row count).  flags[G*R] is scratch that must be zero
- *   on entry and is zero again on exit. */
+ *   on entry and is zero again on exit.  counts_out (optional, [G]): the per-owner counts once more,
+ *   written by the kernel -- pass device-visible pinned host memory to have the exchange sizes on
+ *   the host without a copy. */
 int tlsan_route_plan(const int32_t* keys, int32_t n_keys, int32_t R, int32_t G, const int32_t* cate_by_key,
                      int32_t* flags, int32_t* rank, int32_t* uniq, int32_t* n_uniq, int32_t* sendbuf, int32_t cap,
-                     int32_t* cate_c, int32_t cate_pad, int32_t* comp, void* stream);
+                     int32_t* cate_c, int32_t cate_pad, int32_t* comp, int32_t* counts_out, void* stream);
 
 /* tlsan_shard_gather: owner side of the row fetch.  recvbuf [G][1 + cap] as received from the G
  * ranks; n_recv = sum of the counts (host value).  rows_out [n_recv, W] = the requested rows of

@@ -190,9 +190,11 @@ def test_route_plan_matches_key_router(n_items, n_users, n_uses):
     nk, cap, pad = int(keys.numel()), r.R, 8192
     z = lambda n: torch.zeros(n, dtype=torch.int32, device="cuda")
     flags, rank, uniq, n_uniq, sendbuf, cate_c, comp = z(r.nkeys), z(r.nkeys), z(r.nkeys), z(1), z(G * (1 + cap)), z(pad), z(nk)
+    hostc = torch.zeros(G, dtype=torch.int32).pin_memory()      # the kernel writes the counts straight to the host
     L.check(lib.tlsan_route_plan(keys.data_ptr(), nk, r.R, G, cbk.data_ptr(), flags.data_ptr(), rank.data_ptr(), uniq.data_ptr(),
                                  n_uniq.data_ptr(), sendbuf.data_ptr(), cap, cate_c.data_ptr(), pad, comp.data_ptr(),
-                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)), "tlsan_route_plan")
+                                 hostc.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "tlsan_route_plan")
+    torch.cuda.synchronize()
     # reference: the same quantities KeyRouter.plan derives (checked over gloo in tests/test_dist_cpu.py)
     kn = keys.cpu().numpy().astype(np.int64)
     u_ref = np.unique(kn)                                   # distinct keys, ascending = grouped by owner
@@ -201,7 +203,7 @@ def test_route_plan_matches_key_router(n_items, n_users, n_uses):
     assert int(n_uniq.item()) == n
     assert np.array_equal(uniq[:n].cpu().numpy(), u_ref)
     sb = sendbuf.view(G, 1 + cap).cpu().numpy()
-    assert sb[:, 0].tolist() == counts
+    assert sb[:, 0].tolist() == counts == hostc.tolist()
     rows = np.concatenate([sb[g, 1:1 + counts[g]] for g in range(G)])
     assert np.array_equal(rows, u_ref % r.R)                # local row numbers in all-to-all send order
     assert np.array_equal(comp.cpu().numpy(), np.searchsorted(u_ref, kn))

@@ -8,7 +8,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libtlsan_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 NORM_TF18, NORM_DEDUP = 0, 1
 TABLE_F32, TABLE_BF16 = 0, 1
 L2_DENSE, L2_LAZY = 0, 1
@@ -144,7 +144,7 @@ def load():
     lib.tlsan_scan_compact.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.tlsan_scan_compact.restype = C.c_int
     lib.tlsan_route_plan.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 6 + \
-                                    [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+                                    [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.tlsan_shard_gather.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
                                        C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.tlsan_shard_gather.restype = C.c_int

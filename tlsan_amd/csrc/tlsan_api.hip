@@ -908,7 +908,7 @@ int tlsan_rows_apply(float* W, int32_t ld, int32_t nrows, int32_t width, int32_t
 
 int tlsan_route_plan(const int32_t* keys, int32_t n_keys, int32_t R, int32_t G, const int32_t* cate_by_key,
                      int32_t* flags, int32_t* rank, int32_t* uniq, int32_t* n_uniq, int32_t* sendbuf, int32_t cap,
-                     int32_t* cate_c, int32_t cate_pad, int32_t* comp, void* stream) {
+                     int32_t* cate_c, int32_t cate_pad, int32_t* comp, int32_t* counts_out, void* stream) {
   if (!keys || !cate_by_key || !flags || !rank || !uniq || !n_uniq || !sendbuf || !cate_c || !comp)
     return fail(TLSAN_E_BADARG, "tlsan_route_plan: NULL pointer");
   if (n_keys < 1 || R < 1 || G < 1 || (long long)R * G >= (1LL << 31)) return fail(TLSAN_E_BADARG, "tlsan_route_plan: bad sizes");
@@ -920,7 +920,7 @@ int tlsan_route_plan(const int32_t* keys, int32_t n_keys, int32_t R, int32_t G, 
   memset(&a, 0, sizeof(a));
   a.keys = keys; a.n_keys = n_keys; a.R = R; a.G = G; a.prefix = rank; a.uniq = uniq; a.n_uniq = n_uniq;
   a.cate_by_key = cate_by_key; a.flags = flags; a.sendbuf = sendbuf; a.cap = cap;
-  a.cate_c = cate_c; a.cate_pad = cate_pad; a.comp = comp;
+  a.cate_c = cate_c; a.cate_pad = cate_pad; a.comp = comp; a.counts_out = counts_out;
   int nt = n_keys > G ? n_keys : G;
   if (cate_pad > nt) nt = cate_pad;
   hipLaunchKernelGGL(k_route_mark, dim3((n_keys + 255) / 256), dim3(256), 0, hs, a);

@@ -19,6 +19,7 @@ struct RouteArgs {
   int32_t* cate_c;          // [cate_pad] item -> category map of the compact table (-1 past n_uniq)
   int32_t cate_pad;
   int32_t* comp;            // [n_keys] compact row of every id of the batch
+  int32_t* counts_out;      // optional [G]: the per-owner counts once more, e.g. straight into pinned host memory
 };
 
 __global__ void k_route_mark(RouteArgs a) {
@@ -38,8 +39,11 @@ __global__ void k_route_finish(RouteArgs a) {
   } else if (t < a.cate_pad) {
     a.cate_c[t] = -1;  // rows of the (padded) compact table that are not in use: in no category
   }
-  if (t < a.G)
-    a.sendbuf[(size_t)t * (1 + a.cap)] = (t + 1 < a.G ? a.prefix[(size_t)(t + 1) * a.R] : nu) - a.prefix[(size_t)t * a.R];
+  if (t < a.G) {
+    const int c = (t + 1 < a.G ? a.prefix[(size_t)(t + 1) * a.R] : nu) - a.prefix[(size_t)t * a.R];
+    a.sendbuf[(size_t)t * (1 + a.cap)] = c;
+    if (a.counts_out) a.counts_out[t] = c;
+  }
 }
 
 // Owner side of the row fetch: the rows the G ranks asked for (recvbuf [G][1 + cap] as received:

@@ -308,6 +308,7 @@ class ShardedModel:
         self._flags = torch.zeros(self.router.nkeys, dtype=torch.int32, device=dev)   # zero at rest
         self._rows_pad = 4096     # compact-table rows are padded (grow-only): the kernels' state layout is stable
         self._side = None
+        self._sizes = {}      # (compact rows, categories, B, Sn) -> (state bytes, workspace bytes)
         self._ews = None
         self._hits_p = np.zeros(6, np.int64)
         self._hits_r = np.zeros(6, np.int64)
@@ -371,7 +372,6 @@ class ShardedModel:
                       # per peer {count, local row numbers ...}: ONE equal-split all-to-all carries both
                       sendbuf=torch.zeros(G, 1 + pcap, dtype=torch.int32, device=dev),
                       recvbuf=torch.zeros(G, 1 + pcap, dtype=torch.int32, device=dev),
-                      cnts=torch.zeros(2, G, dtype=torch.int32, device=dev),       # [send | recv] per peer
                       cate_c=torch.empty(max(cap, self._rows_pad), dtype=torch.int32, device=dev),
                       comp=torch.empty(cap, dtype=torch.int32, device=dev),
                       host=torch.zeros(2, G, dtype=torch.int32).pin_memory(),
@@ -393,7 +393,7 @@ class ShardedModel:
                                           self._flags.data_ptr(), sl["rank"].data_ptr(), sl["uniq"].data_ptr(),
                                           sl["n_uniq"].data_ptr(), sl["sendbuf"].data_ptr(), sl["pcap"],
                                           sl["cate_c"].data_ptr(), sl["cate_pad"], sl["comp"].data_ptr(),
-                                          self._stream()),
+                                          sl["host"].data_ptr(), self._stream()),     # send counts -> host[0]
                 "tlsan_route_plan")
         if self.world > 1:
             a2a(sl["recvbuf"].view(-1), sl["sendbuf"].view(-1), None, None, self.group)
@@ -401,9 +401,8 @@ class ShardedModel:
         else:
             rb = sl["sendbuf"]
         sl["rb"] = rb
-        sl["cnts"][0].copy_(sl["sendbuf"][:, 0])
-        sl["cnts"][1].copy_(rb[:, 0])
-        sl["host"].copy_(sl["cnts"], non_blocking=True)
+        if self.world > 1:      # what the peers ask of this rank (at one rank: the same numbers, see stage 2)
+            sl["host"][1].copy_(rb[:, 0], non_blocking=True)
         sl["event"].record(torch.cuda.current_stream(self.device))
         sl["db"] = db
         sl["prepared"] = False
@@ -416,7 +415,8 @@ class ShardedModel:
             return sl
         sl["event"].synchronize()
         h = sl["host"]
-        send, recv = h[0].tolist(), h[1].tolist()
+        send = h[0].tolist()
+        recv = h[1].tolist() if self.world > 1 else send
         n, n_recv = int(sum(send)), int(sum(recv))
         recv_rows = torch.empty(max(n_recv, 1), dtype=torch.int32, device=self.device)
         off = [0]
@@ -455,6 +455,21 @@ class ShardedModel:
         return table
 
     def _compact(self, db, sl, table):
+        """ctypes views of the step on the compact table (cached per slot: building the three structs
+        costs the host more than a kernel launch, and their pointers only change when a buffer does)"""
+        key = (id(db), sl["comp"].data_ptr(), sl["cate_c"].data_ptr(), None if table is None else table.data_ptr(),
+               self._rows_pad)
+        cache = sl.setdefault("_compact", {})
+        hit = cache.get(key)
+        if hit is not None and hit[0] is db:
+            return hit[1]
+        if len(cache) >= 8:
+            cache.clear()
+        out = self._compact_build(db, sl, table)
+        cache[key] = (db, out)
+        return out
+
+    def _compact_build(self, db, sl, table):
         B, Ls, Sn = db.B, self.Ls, db.Sn
         comp = sl["comp"]
         esz = 4
@@ -499,10 +514,14 @@ class ShardedModel:
         nsl["prepared"] = True
 
     def _buffers(self, sl, dims, cp, B, Sn, prepared=False):
-        nst = self.lib.tlsan_state_bytes(C.byref(dims))
-        nws = self.lib.tlsan_workspace_bytes(C.byref(dims), B, Sn)
-        if nst == 0 or nws == 0:
-            raise L.TlsanError(self.lib.tlsan_last_error().decode())
+        skey = (dims.item_count, dims.cate_count, B, Sn)
+        if skey not in self._sizes:
+            nst = self.lib.tlsan_state_bytes(C.byref(dims))
+            nws = self.lib.tlsan_workspace_bytes(C.byref(dims), B, Sn)
+            if nst == 0 or nws == 0:
+                raise L.TlsanError(self.lib.tlsan_last_error().decode())
+            self._sizes[skey] = (nst, nws)
+        nst, nws = self._sizes[skey]
         fresh = sl["state"] is None or sl["state"].numel() < nst
         if fresh:
             sl["state"] = torch.zeros(int(nst * 1.5), dtype=torch.uint8, device=self.device)
