@@ -560,7 +560,8 @@ static int build_index(const tlsan_dims* d, const tlsan_batch* b, const St& st, 
 // shared front half of train_step / grads: index build, fused fwd+bwd, dense-grad reduction
 static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params* p, const tlsan_batch* b,
                         const tlsan_hparams* hp, bool update, const tlsan_step_out* out, const Ws& w, const St& st,
-                        const tlsan_dense_layout& L, hipStream_t hs, const ApplyArgs* presum = nullptr) {
+                        const tlsan_dense_layout& L, hipStream_t hs, const ApplyArgs* presum = nullptr,
+                        float* gd_out = nullptr) {
   const bool commit = update && hp->l2_mode == TLSAN_L2_LAZY;
   const int k = hp->index_slot;
   int rc;
@@ -598,7 +599,7 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   FinArgs f;
   memset(&f, 0, sizeof(f));
   f.lay = L; f.partials = w.partials; f.nrec = (b->B + grp - 1) / grp; f.Kp = w.Kp; f.nsplit = w.nsplit;
-  f.gd = w.gd; f.sqd = w.sqd; f.scal = w.scal;
+  f.gd = gd_out ? gd_out : w.gd; f.sqd = w.sqd; f.scal = w.scal;
   f.S_part = st.S_part; f.n_spart = st.nbI + st.nbU + st.nbC; f.S_total = st.S_total;
   f.hdr = st.hdr; f.lr = hp->lr; f.reg = hp->reg; f.clip = hp->clip; f.inv_B = 1.0f / (float)b->B;
   f.norm_mode = hp->norm_mode; f.commit = commit ? 1 : 0; f.count_step = update ? 1 : 0;
@@ -759,7 +760,6 @@ int tlsan_grads(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch* b
   hipStream_t hs = (hipStream_t)stream;
   tlsan_dense_layout L;
   tlsan_dense_layout_of(d, &L);
-  if ((rc = run_backward(d, s, p, b, hp, false, out, w, st, L, hs))) return rc;
   ApplyArgs A;
   fill_apply(A, d, s, p, b, hp, w, st, L);
   A.go = *g;
@@ -768,6 +768,17 @@ int tlsan_grads(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch* b
   if (A.go.ld_user == 0) A.go.ld_user = d->d_item;
   if (A.go.ld_usert == 0) A.go.ld_usert = d->Ls;
   if (A.go.ld_item % 4 || A.go.ld_user % 4) return fail(TLSAN_E_UNSUPPORTED, "gradient row strides must be multiples of 4 floats");
+  if (hp->reg == 0.0f && g->sparse && hp->norm_mode == TLSAN_NORM_TF18) {
+    // pure per-row sums of the used rows (what the sharded step asks for): they ride with the dense
+    // finalize as in the lazy train step, written straight to the output rows -- no apply launch
+    A.presum_rows = 1;
+    A.Rc = g->cate_emb;
+    if ((rc = run_backward(d, s, p, b, hp, false, out, w, st, L, hs, &A, g->dense))) return rc;
+    prof_mark(5, hs);
+    prof_step_done();
+    return TLSAN_OK;
+  }
+  if ((rc = run_backward(d, s, p, b, hp, false, out, w, st, L, hs))) return rc;
   if (hp->norm_mode == TLSAN_NORM_DEDUP && (rc = clip_dedup(A, hp, out, w, st, b, hs))) return rc;
   if ((rc = launch_apply(AP_GRADS, false, A, true, b->B, b->Sn, hs))) return rc;
   prof_mark(5, hs);

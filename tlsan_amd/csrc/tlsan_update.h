@@ -558,6 +558,7 @@ struct ApplyArgs {
   const int32_t* cate_off; const int32_t* cate_cnt; const int32_t* cate_items;  // static CSR
   const float* gd;
   float* Rc; float* Ri; float* Rb; float* Ru;   // PRESUM -> k_update_lazy: summed rows [C][dc], [slot][di], [slot], [slot][WU]
+  int32_t presum_rows;     // PRESUM: write the item / user sums to the rows of `go` instead (tlsan_grads with reg = 0)
   double* part_out;        // UPDATE: change of the stored tables' sum of squares per workgroup;
                            // SUMSQ: sum of squares; ROWNORM: sum g^2
   StateHdr* hdr;           // P, P_prev, coef (read); spart_n (written by an update)
@@ -991,7 +992,9 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
   AP_STAMP(3);
   if constexpr (MODE == AP_PRESUM) {
     if (vr) {
+      const bool by_row = a.presum_rows != 0;  // (workgroup-uniform)
       float* R = IS_ITEM ? a.Ri + (size_t)slot * a.di : a.Ru + (size_t)slot * a.WU;
+      if (by_row) R = IS_ITEM ? a.go.item_emb + (size_t)row * a.go.ld_item : a.go.user_emb + (size_t)row * a.go.ld_user;
 #pragma unroll
       for (int ch = 0; ch < NCH; ++ch) {
         const int c4 = l16 + 16 * ch;
@@ -999,11 +1002,19 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
           f32x4 g;
 #pragma unroll
           for (int i = 0; i < 4; ++i) g[i] = (float)acc[ch][i];
-          *(f32x4*)(R + 4 * c4) = g;
+          if (!by_row || 4 * c4 < a.di) {
+            *(f32x4*)(R + 4 * c4) = g;
+          } else {  // usert_emb columns of a user row
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int p = 4 * c4 + i - a.di;
+              if (p < a.Ls) a.go.usert_emb[(size_t)row * a.go.ld_usert + p] = g[i];
+            }
+          }
         }
       }
       if (l16 == 0) {
-        if (IS_ITEM) a.Rb[slot] = (float)bacc;
+        if (IS_ITEM) (by_row ? a.go.item_b[(size_t)row * a.go.ld_itemb] : a.Rb[slot]) = (float)bacc;
         if (n > 0) (IS_ITEM ? a.cnt_item : a.cnt_user)[row] = 0;
       }
     }
