@@ -11,17 +11,17 @@ cfg = synth.make_config("electronics")
 m = ShardedModel(cfg, synth.item_cate_list(cfg))
 dbs = [m.device_batch(b) for b in synth.make_batches(cfg, 4, 4096, seed=1)]
 for s in range(10):
-    m.train_async(dbs[s % 4], 1.0)
+    m.train_async(dbs[s % 4], 1.0, next_batch=dbs[(s + 1) % 4])
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for s in range(50):
-    m.train_async(dbs[s % 4], 1.0)
+    m.train_async(dbs[s % 4], 1.0, next_batch=dbs[(s + 1) % 4])
 torch.cuda.synchronize()
 print("step %.1f us" % ((time.perf_counter() - t0) / 50 * 1e6))
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     for s in range(10):
-        m.train_async(dbs[s % 4], 1.0)
+        m.train_async(dbs[s % 4], 1.0, next_batch=dbs[(s + 1) % 4])
     torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=25, max_name_column_width=60))
 print(prof.key_averages().table(sort_by="cpu_time_total", row_limit=22, max_name_column_width=60))

@@ -692,12 +692,14 @@ class ShardedModel:
 
     def gather_params(self):
         """Full (un-sharded) parameters on every rank, as numpy (tests / checkpoints)."""
-        host = self.shard.cpu()
         if self.world > 1:
-            outs = [torch.empty_like(host) for _ in range(self.world)]
-            dist.all_gather(outs, host, group=self.group)
+            # (RCCL gathers device buffers; gloo, used by the single-GPU multi-process tests, host ones)
+            src = self.shard.cpu() if _staged(self.group) else self.shard
+            outs = [torch.empty_like(src) for _ in range(self.world)]
+            dist.all_gather(outs, src, group=self.group)
+            outs = [o.cpu() for o in outs]
         else:
-            outs = [host]
+            outs = [self.shard.cpu()]
         I, U, G, di, Ls = self.I, self.U, self.world, self.di, self.Ls
         item = np.zeros((I, self.W), np.float32)
         user = np.zeros((U, self.W), np.float32)
