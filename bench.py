@@ -67,13 +67,14 @@ def cpu_baseline(cfg, icl, batch, seconds):
     b = tref.batch_to_torch(orc.as_batch(batch), dtype=torch.float32)
     B = len(batch[0])
     # eager torch on many small ops does not scale with threads: probe a few counts, keep the best
-    best, cores = None, 1
+    best, cores, probe = None, 1, {}
     for th in sorted({1, min(8, ncpu), min(32, ncpu)}):
         torch.set_num_threads(th)
         tref.train_step_(p, icl, b, cfg["num_heads"], cfg["regulation_rate"], 1.0)  # warm
         t1 = time.perf_counter()
         tref.train_step_(p, icl, b, cfg["num_heads"], cfg["regulation_rate"], 1.0)
         dt1 = time.perf_counter() - t1
+        probe[th] = round(B / dt1, 1)
         if best is None or dt1 < best:
             best, cores = dt1, th
     torch.set_num_threads(cores)
@@ -84,8 +85,35 @@ def cpu_baseline(cfg, icl, batch, seconds):
         dt = time.perf_counter() - t0
         if dt >= seconds or n >= 200:
             break
-    return dict(value=round(n * B / dt, 1), unit="user-sequences/s", cores=cores, kind="port",
-                sample="%d train steps of batch %d (same synthetic batch 0, fp32 eager torch, %.1f s)" % (n, B, dt))
+    res = dict(value=round(n * B / dt, 1), unit="user-sequences/s", cores=cores, kind="port",
+               sample="%d train steps of batch %d (same synthetic batch 0, fp32 eager torch, %.1f s)" % (n, B, dt))
+    # SURVEY 8d asks for these beside it (short samples, same port): one thread at the config's batch,
+    # the reference's default batch 32 (train.py:44), and eval_auc's two forward passes at its test batch 128
+    from tlsan_amd import synth
+
+    def rate(fn, nseq, budget):
+        fn()
+        k, t1 = 0, time.perf_counter()
+        while True:
+            fn()
+            k += 1
+            e = time.perf_counter() - t1
+            if e >= budget or k >= 400:
+                return round(k * nseq / e, 1)
+    also = {"train_1_thread_batch_%d" % B: probe.get(1)}
+    b32 = tref.batch_to_torch(orc.as_batch(synth.make_batches(cfg, 1, 32, seed=99)[0]), dtype=torch.float32)
+    also["train_batch_32"] = rate(lambda: tref.train_step_(p, icl, b32, cfg["num_heads"], cfg["regulation_rate"], 1.0), 32, 2.0)
+    tb = orc.as_batch(synth.make_batches(cfg, 1, 128, seed=98, test=True)[0], is_test=True)
+    tb_i = tref.batch_to_torch(dict(tb, y=np.zeros(128, np.float32)), dtype=torch.float32)
+    tb_j = tref.batch_to_torch(dict(tb, i=tb["j"], y=np.zeros(128, np.float32)), dtype=torch.float32)
+
+    def eval_auc():
+        with torch.no_grad():
+            tref.forward(p, icl, tb_i, cfg["num_heads"])
+            tref.forward(p, icl, tb_j, cfg["num_heads"])
+    also["eval_auc_batch_128"] = rate(eval_auc, 128, 2.0)
+    res["also"] = also
+    return res
 
 
 def main():
