@@ -43,6 +43,8 @@ def parse(argv=None):
     ap.add_argument("--table_dtype", default="f32", choices=["f32", "bf16"],
                     help="storage of item/user/category tables (bf16: fp32 arithmetic, stochastic rounding on update)")
     ap.add_argument("--l2_mode", default="dense", choices=["dense", "lazy"])
+    ap.add_argument("--eval_topk", type=int, default=1,
+                    help="P@k / R@k at every evaluation point like the reference (train.py:209-218); 0: once at the end")
     ap.add_argument("--device_input", type=int, default=1,
                     help="1: keep the sample sets in HBM and assemble batches on the device (tlsan_amd.device_input); "
                          "0: the host batcher (tlsan_amd.input), one upload per batch")
@@ -78,11 +80,12 @@ def eval_auc(model, test_set, config):
 
 
 def eval_prec_recall(model, test_set, config):
-    """train.py:98-118 (cumulative counters, as the reference)."""
+    """train.py:98-118: one pass for precision, one for recall (cumulative counters, as the reference)."""
     for _, batch in _test_batches(test_set, config):
         model.eval_prec(None, batch)
-        model.eval_recall(None, batch)
     prec = [getattr(model, "prec_%d" % k).eval() for k in KS]
+    for _, batch in _test_batches(test_set, config):
+        model.eval_recall(None, batch)
     recall = [getattr(model, "recall_%d" % k).eval() for k in KS]
     step = model.global_step.eval()
     model.eval_writer.add_summary([("P@%d" % k, v) for k, v in zip(KS, prec)] +                 # train.py:103-106
@@ -123,6 +126,8 @@ def train(args):
     lr = args.learning_rate
     rng = np.random.RandomState(1234)  # train.py:15-16 seeds; the shuffle stream itself differs from CPython's
     best_auc, history = 0.0, []
+    best_prec, best_recall = [0.0] * 6, [0.0] * 6              # train.py:187-188
+    prec, recall = [0.0] * 6, [0.0] * 6
     import torch
     loss_sum = torch.zeros((), dtype=torch.float32, device=args.device)
     done = False
@@ -143,6 +148,13 @@ def train(args):
                 say("Epoch %d Global_step %d\tTrain_loss: %.4f\tEval_auc: %.4f" %
                     (model.global_epoch_step.eval(), step, float(loss_sum.item()) / args.eval_freq, auc), flush=True)
                 loss_sum.zero_()
+                if args.eval_topk:                             # train.py:209-218: P@k / R@k at every evaluation
+                    prec, recall = eval_prec_recall(model, test_set, config)
+                    say("Precision:\n" + " ".join("@%d = %.4f" % (k, v) for k, v in zip(KS, prec)))
+                    say("Recall:\n" + " ".join("@%d = %.4f" % (k, v) for k, v in zip(KS, recall)))
+                    if step > 20000:                           # :222-227
+                        best_prec = [max(a_, b_) for a_, b_ in zip(best_prec, prec)]
+                        best_recall = [max(a_, b_) for a_, b_ in zip(best_recall, recall)]
                 if auc > 0.8 and auc > best_auc:  # train.py:228-230
                     best_auc = auc
                     model.save(None)
@@ -152,19 +164,24 @@ def train(args):
             if args.max_steps and step >= args.max_steps:
                 done = True
                 break
+        say("Epoch %d DONE\tCost time: %.2f" % (model.global_epoch_step.eval(), time.time() - t0), flush=True)  # :235-237
         model.global_epoch_step_op.eval()
         if done:
             break
-    prec, recall = eval_prec_recall(model, test_set, config)
+    if not args.eval_topk or not history:   # (the reference reports what its evaluations saw; make sure there is one)
+        prec, recall = eval_prec_recall(model, test_set, config)
     final_auc = eval_auc(model, test_set, config)
     best_auc = max(best_auc, final_auc)
+    model.save(None)                                           # train.py:239
     model.train_writer.flush()
     model.eval_writer.flush()
     say("Best test_auc:", best_auc)
-    say("P@k:", " ".join("@%d=%.4f" % (k, p) for k, p in zip(KS, prec)))
-    say("R@k:", " ".join("@%d=%.4f" % (k, r) for k, r in zip(KS, recall)))
+    say("Best precision:\n" + " ".join("@%d = %.4f" % (k, v) for k, v in zip(KS, best_prec)))   # :241-248
+    say("Best recall:\n" + " ".join("@%d = %.4f" % (k, v) for k, v in zip(KS, best_recall)))
+    say("Finished", flush=True)
     return dict(init_auc=init_auc, best_auc=best_auc, final_auc=final_auc, steps=model.global_step.eval(),
-                seconds=time.time() - t0, history=history, prec=prec, recall=recall)
+                seconds=time.time() - t0, history=history, prec=prec, recall=recall,
+                best_prec=best_prec, best_recall=best_recall)
 
 
 def main(argv=None):
