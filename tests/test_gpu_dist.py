@@ -28,17 +28,17 @@ def _tuple(b):
     return (b["u"], b["i"], b["y"], b["hist_i"], b["hist_i_new"], b["hist_t"], b["sl"], b["sl_new"], b["u_cate"])
 
 
-def _case(d=128):
-    cfg = make_config(U=61, I=83, C=9, d=d, regulation_rate=1e-3, max_gradient_norm=5.0)
+def _case(d=128, clip=5.0):
+    cfg = make_config(U=61, I=83, C=9, d=d, regulation_rate=1e-3, max_gradient_norm=clip)
     p = {k: np.asarray(v, np.float32).astype(np.float64) for k, v in random_params(cfg, seed=17).items()}
     _, cat = random_batch(cfg, B=4, Sn=2, seed=0)
     return cfg, p, cat
 
 
-def _split_batches(cfg, world, steps, B):
+def _split_batches(cfg, world, steps, B, uneven=False):
     out = []
     for s in range(steps):
-        per = [random_batch(cfg, B=B, Sn=3, seed=1000 + 10 * s + r)[0] for r in range(world)]
+        per = [random_batch(cfg, B=B - (7 * r if uneven else 0), Sn=3, seed=1000 + 10 * s + r)[0] for r in range(world)]
         out.append(per)
     return out
 
@@ -55,31 +55,35 @@ def _concat(per):
     return out
 
 
-def _worker(rank, world, port, ret, d, prefetch, ckpt):
+def _worker(rank, world, port, ret, d, prefetch, ckpt, uneven=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from tlsan_amd.dist import ShardedModel
-        cfg, p, cat = _case(d)
+        clip = 0.05 if uneven else 5.0          # (uneven shares: with the clip active, so that the weighted squares matter)
+        cfg, p, cat = _case(d, clip)
         m = ShardedModel(cfg, cat, device="cuda:0")
         m.set_params({k: np.asarray(v, np.float32) for k, v in p.items()})
-        steps = _split_batches(cfg, world, 4, B=24)
+        steps = _split_batches(cfg, world, 4, B=24, uneven=uneven)
+        wgt = lambda per: len(per[rank]["u"]) * world / sum(len(q_["u"]) for q_ in per)
         losses = []
         if prefetch:   # every step is told its successor: routing plan + indices are built a step ahead
             dbs = [m.device_batch(_tuple(per[rank])) for per in steps]
             for k, db in enumerate(dbs):
-                m.train_async(db, 0.8, next_batch=dbs[k + 1] if k + 1 < len(dbs) else None)
+                m.train_async(db, 0.8, next_batch=dbs[k + 1] if k + 1 < len(dbs) else None, weight=wgt(steps[k]))
                 losses.append(float(m.last_loss.item()))
         else:
             for per in steps:
-                losses.append(m.train(None, _tuple(per[rank]), 0.8))
+                m.train_async(_tuple(per[rank]), 0.8, weight=wgt(per))
+                losses.append(float(m.last_loss.item()))
         got = m.gather_params()
         auc = m.eval_auc(None, tuple(list(_tuple(steps[0][rank]))[:2] + [steps[0][rank]["i"][::-1].copy()] + list(_tuple(steps[0][rank]))[3:]))
         if rank == 0:
             q = dict(p)
             ref = []
             for per in steps:
-                l, q, info = orc.train_step(q, cat, _concat(per), 8, cfg["regulation_rate"], lr=0.8)
+                l, q, info = orc.train_step(q, cat, _concat(per), 8, cfg["regulation_rate"], lr=0.8, clip=clip)
+                assert (info["coef"] < 1.0) == uneven
                 ref.append(l)
             assert np.allclose(losses, ref, rtol=2e-4, atol=1e-5), (losses, ref)
             for k in q:
@@ -87,6 +91,9 @@ def _worker(rank, world, port, ret, d, prefetch, ckpt):
                 du, dr = g - p[k], q[k] - p[k]
                 assert np.abs(du - dr).max() < 5e-4 * (np.abs(dr).max() + 1e-9) + 5e-7, (k, float(np.abs(du - dr).max()), float(np.abs(dr).max()))
         assert 0.0 <= auc <= 1.0
+        if uneven:     # (the ranking's all-gather is equal-sized: tlsan_amd.train pads the shares, see _equal_share)
+            ret[rank] = "ok"
+            return
         # all-items ranking with the items sharded == the oracle's ranks on the gathered parameters
         tb = steps[0][rank]
         ranks = m.label_ranks(tuple(list(_tuple(tb))[:2] + [tb["i"][::-1].copy()] + list(_tuple(tb))[3:])).cpu().numpy()
@@ -126,11 +133,13 @@ def _worker(rank, world, port, ret, d, prefetch, ckpt):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,d,prefetch", [(1, 128, False), (2, 128, False), (2, 64, False), (1, 128, True), (2, 128, True)])
-def test_sharded_model_matches_oracle(world, d, prefetch, tmp_path):
+@pytest.mark.parametrize("world,d,prefetch,uneven", [(1, 128, False, False), (2, 128, False, False), (2, 64, False, False),
+                                                     (1, 128, True, False), (2, 128, True, False), (2, 128, True, True)])
+def test_sharded_model_matches_oracle(world, d, prefetch, uneven, tmp_path):
+    """(uneven: the ranks hold 24 and 17 samples of each global batch and enter with their shares)"""
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), ret, d, prefetch, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), ret, d, prefetch, str(tmp_path), uneven), nprocs=world, join=True)
     assert all(v == "ok" for v in dict(ret).values()) and len(ret) == world, dict(ret)
 
 
@@ -211,3 +220,40 @@ def test_route_plan_matches_key_router(n_items, n_users, n_uses):
     assert (cate_c[n:pad] == -1).all() and int(flags.abs().sum().item()) == 0     # pads marked, marks cleared
     # and the python router agrees on the key space
     assert np.array_equal(r.item_keys(torch.as_tensor(items)).numpy(), (items % G) * r.R + items // G)
+
+
+def _driver_worker(rank, world, port, ret, ckpt):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tlsan_amd import train as T
+        ds = os.path.join(os.path.dirname(__file__), "golden", "packed_clothing.npz")
+        # batch 33 over 2 ranks: uneven shares (16 / 17) -> the weighted means; test batches of 128 split 64 / 64,
+        # the last one (2010 % 128 = 90) 45 / 45
+        argv = ["--dataset", ds, "--max_steps", "40", "--eval_freq", "20", "--quiet", "--train_batch_size", "33",
+                "--model_dir", os.path.join(ckpt, "r%d" % rank), "--device_input", "0"]
+        res = T.train_sharded(T.parse(argv + ["--sharded", "1"]))
+        if rank == 0:
+            one = T.train(T.parse(argv))
+            assert res["steps"] == one["steps"] == 40 and res["world"] == world
+            assert abs(res["init_auc"] - one["init_auc"]) < 1e-9
+            assert abs(res["final_auc"] - one["final_auc"]) < 2e-3, (res["final_auc"], one["final_auc"])
+            for a, b in zip(res["history"], one["history"]):
+                assert a[0] == b[0] and abs(a[2] - b[2]) < 2e-3
+            assert np.allclose(res["recall"], one["recall"], atol=2e-3) and np.allclose(res["prec"], one["prec"], atol=2e-3)
+        ret[rank] = "ok"
+    except Exception:
+        import traceback
+        ret[rank] = "FAIL: " + traceback.format_exc()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_train_driver_matches_single_gpu(tmp_path):
+    """python -m tlsan_amd.train --sharded: the reference's train.py flow over 2 ranks (global batches
+    split over the ranks, unevenly here; evaluation over split test batches) against the single-GPU driver
+    on the same data and shuffle."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_driver_worker, args=(2, _free_port(), ret, str(tmp_path)), nprocs=2, join=True)
+    assert all(v == "ok" for v in dict(ret).values()) and len(ret) == 2, dict(ret)

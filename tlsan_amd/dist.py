@@ -542,8 +542,11 @@ class ShardedModel:
                     "tlsan_state_recategorize")
 
     # ------------------------------------------------------------------ training
-    def train_async(self, batch, lr, next_batch=None):
-        """One step.  `next_batch` (optional): its routing plan is queued before this step's heavy
+    def train_async(self, batch, lr, next_batch=None, weight=1.0):
+        """One step.  `weight`: this rank's share of the global mean when the ranks' batches differ in
+        size, B_rank * world / B_global (1 when they are equal; 0 for a rank that only holds a
+        placeholder row of a global batch smaller than the world).
+          `next_batch` (optional): its routing plan is queued before this step's heavy
         kernels, so that the next step's host wait for the exchange sizes costs nothing."""
         db = self.device_batch(batch)
         G = self.world
@@ -574,6 +577,11 @@ class ShardedModel:
         st = self._stream()
         L.check(self.lib.tlsan_grads(C.byref(dims), C.byref(cp), C.byref(cb), C.byref(hp), C.byref(go), C.byref(out),
                                      sl["state"].data_ptr(), self._ws.data_ptr(), self._ws.numel(), st), "tlsan_grads")
+        if weight != 1.0:      # uneven split of the global batch: the local means enter with their share
+            k = n_dense + n_cate
+            flat[:k + 1].mul_(float(weight))
+            flat[k + 1:k + 2].mul_(float(weight) ** 2)
+            gf.mul_(float(weight))
         # ---- one all-reduce: dense grads | cate grads | loss | per-use squares | local table squares
         if G > 1:
             allreduce_sum(flat, self.group)
@@ -653,27 +661,30 @@ class ShardedModel:
             allreduce_sum(counts, self.group)
         return counts[self.rank * B:(self.rank + 1) * B]
 
-    def _hits(self, batch):
+    def _hits(self, batch, n_valid=None):
         from .model import KS
         r = self.label_ranks(batch)
+        if n_valid is not None:        # rows past n_valid only pad this rank's share to the common size
+            r = r[:n_valid]
         h = torch.stack([(r < k).sum() for k in KS] + [torch.tensor(r.numel(), device=r.device)]).to(torch.int64)
         if self.world > 1:
             allreduce_sum(h, self.group)        # hits and rows of the GLOBAL test batch
         h = h.cpu().numpy()
         return h[:-1], int(h[-1])
 
-    def eval_prec(self, sess, batch):
+    def eval_prec(self, sess, batch, n_valid=None):
         """Streaming precision_at_k over the global batch (model.py:265-281); cumulative like the reference's
-        never-reset local variables (train.py:75-76,82).  Identical on every rank."""
+        never-reset local variables (train.py:75-76,82).  Identical on every rank.  Every rank must pass
+        the same number of rows (the all-gather is equal-sized); n_valid marks how many of them count."""
         from .model import KS
-        h, n = self._hits(batch)
+        h, n = self._hits(batch, n_valid)
         self._hits_p += h
         self._n_p += n
         return [self._hits_p[i] / (k * self._n_p) for i, k in enumerate(KS)]
 
-    def eval_recall(self, sess, batch):
+    def eval_recall(self, sess, batch, n_valid=None):
         from .model import KS
-        h, n = self._hits(batch)
+        h, n = self._hits(batch, n_valid)
         self._hits_r += h
         self._n_r += n
         return [self._hits_r[i] / self._n_r for i in range(len(KS))]

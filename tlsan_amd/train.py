@@ -45,6 +45,8 @@ def parse(argv=None):
     ap.add_argument("--l2_mode", default="dense", choices=["dense", "lazy"])
     ap.add_argument("--eval_topk", type=int, default=1,
                     help="P@k / R@k at every evaluation point like the reference (train.py:209-218); 0: once at the end")
+    ap.add_argument("--sharded", type=int, default=0,
+                    help="1: row-sharded tables over the ranks of torch.distributed (implied by WORLD_SIZE > 1)")
     ap.add_argument("--device_input", type=int, default=1,
                     help="1: keep the sample sets in HBM and assemble batches on the device (tlsan_amd.device_input); "
                          "0: the host batcher (tlsan_amd.input), one upload per batch")
@@ -184,9 +186,146 @@ def train(args):
                 best_prec=best_prec, best_recall=best_recall)
 
 
+def _share(batch, rank, world):
+    """This rank's rows of a global batch (contiguous, as even as possible) and how many of them are
+    real: a rank without rows gets row 0 as a placeholder (0 real rows), so that every rank takes
+    part in every collective."""
+    n = len(batch[0])
+    lo, hi = n * rank // world, n * (rank + 1) // world
+    if hi == lo:
+        return tuple(np.asarray(a)[:1] for a in batch), 0
+    return tuple(np.asarray(a)[lo:hi] for a in batch), hi - lo
+
+
+def _equal_share(batch, rank, world):
+    """Like _share, padded (by repeating the last row) to ceil(n / world) rows: the evaluation's
+    all-gather is equal-sized.  -> (rows, real rows)"""
+    part, real = _share(batch, rank, world)
+    want = -(-len(batch[0]) // world)
+    have = len(part[0])
+    if have < want:
+        part = tuple(np.concatenate([a, np.repeat(a[-1:], want - have, axis=0)], 0) for a in part)
+    return part, real
+
+
+def train_sharded(args):
+    """The same flow on N GPUs (`python -m torch.distributed.run --nproc-per-node N -m tlsan_amd.train
+    --sharded 1 ...`): tables row-sharded over the ranks (tlsan_amd.dist.ShardedModel), every global
+    batch of train_batch_size samples split over the ranks -- one SGD step per global batch, exactly
+    the single-GPU trajectory up to fp32 summation order -- evaluation over the split test batches."""
+    import torch
+    import torch.distributed as dist
+    from .dist import ShardedModel
+    if not dist.is_initialized():
+        import os
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        rank_, world_ = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        args.device = "cuda:%d" % local
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank_, world_size=world_, device_id=torch.device(args.device))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    say = print if (rank == 0 and not args.quiet) else (lambda *a, **k: None)
+    train_set, test_set, (U, I, Cc), icl = load_dataset(args.dataset)
+    config = {name: getattr(args, name) for name, _, _ in FLAGS}
+    config.update(user_count=U, item_count=I, cate_count=Cc, from_scratch=args.from_scratch)
+    model = ShardedModel(config, icl, device=args.device)
+    dev = model.device
+
+    def reduce_sum(vals):
+        t = torch.tensor(vals, dtype=torch.float64, device=dev)
+        if world > 1:
+            from .dist import allreduce_sum
+            allreduce_sum(t)
+        return t.tolist()
+
+    def eval_auc_():
+        # train.py:86-96: sum_b auc_b * len_b / N == (pairs ranked right) / N, summed over the ranks' shares
+        right = 0.0
+        for _, batch in DataInputTest(test_set, config["test_batch_size"], config["Ls"]):
+            part, real = _share(batch, rank, world)
+            a = model.eval_auc(None, part)            # (a collective inside: every rank calls it, placeholder or not)
+            right += a * real if real else 0.0
+        res = reduce_sum([right])[0] / len(test_set)
+        model.eval_writer.add_summary(("AUC", res), global_step=model.global_step.eval())
+        return res
+
+    def eval_pr_():
+        prec = recall = None
+        for _, batch in DataInputTest(test_set, config["test_batch_size"], config["Ls"]):
+            part, real = _equal_share(batch, rank, world)
+            prec = model.eval_prec(None, part, n_valid=real)
+        for _, batch in DataInputTest(test_set, config["test_batch_size"], config["Ls"]):
+            part, real = _equal_share(batch, rank, world)
+            recall = model.eval_recall(None, part, n_valid=real)
+        return [float(x) for x in prec], [float(x) for x in recall]
+
+    t0 = time.time()
+    init_auc = eval_auc_()
+    say("Init AUC: %.4f" % init_auc)
+    lr = args.learning_rate
+    rng = np.random.RandomState(1234)              # the same shuffle on every rank
+    best_auc, history = 0.0, []
+    best_prec, best_recall = [0.0] * 6, [0.0] * 6
+    prec, recall = [0.0] * 6, [0.0] * 6
+    loss_sum = torch.zeros((), dtype=torch.float32, device=dev)
+    done = False
+    for _ in range(args.max_epochs):
+        train_set.shuffle(rng)
+        shares = (_share(b, rank, world) + (len(b[0]),) for _, b in DataInput(train_set, args.train_batch_size, config["Ls"]))
+        for (part, real, n_glob), nxt in _lookahead((model.device_batch(p_), r_, n_) for p_, r_, n_ in shares):
+            last = nxt is None or (args.max_steps and model.global_step.eval() + 1 >= args.max_steps)
+            model.train_async(part, lr, next_batch=None if last else nxt[0], weight=real * world / n_glob)
+            loss_sum += model.last_loss[0]
+            step = model.global_step.eval()
+            if step % args.eval_freq == 0:
+                auc = eval_auc_()
+                history.append((step, time.time() - t0, auc))
+                say("Epoch %d Global_step %d\tTrain_loss: %.4f\tEval_auc: %.4f" %
+                    (model.global_epoch_step.eval(), step, float(loss_sum.item()) / args.eval_freq, auc), flush=True)
+                loss_sum.zero_()
+                if args.eval_topk:
+                    prec, recall = eval_pr_()
+                    say("Precision:\n" + " ".join("@%d = %.4f" % (k, v) for k, v in zip(KS, prec)))
+                    say("Recall:\n" + " ".join("@%d = %.4f" % (k, v) for k, v in zip(KS, recall)))
+                    if step > 20000:
+                        best_prec = [max(a_, b_) for a_, b_ in zip(best_prec, prec)]
+                        best_recall = [max(a_, b_) for a_, b_ in zip(best_recall, recall)]
+                if auc > 0.8 and auc > best_auc:
+                    best_auc = auc
+                    model.save(None)
+                best_auc = max(best_auc, auc)
+            if step == 150000:
+                lr = 0.1
+            if args.max_steps and step >= args.max_steps:
+                done = True
+                break
+        say("Epoch %d DONE\tCost time: %.2f" % (model.global_epoch_step.eval(), time.time() - t0), flush=True)
+        model._epoch += 1
+        if done:
+            break
+    if not args.eval_topk or not history:
+        prec, recall = eval_pr_()
+    final_auc = eval_auc_()
+    best_auc = max(best_auc, final_auc)
+    model.save(None)
+    model.train_writer.flush()
+    model.eval_writer.flush()
+    say("Best test_auc:", best_auc)
+    say("Finished", flush=True)
+    return dict(init_auc=init_auc, best_auc=best_auc, final_auc=final_auc, steps=model.global_step.eval(),
+                seconds=time.time() - t0, history=history, prec=prec, recall=recall,
+                best_prec=best_prec, best_recall=best_recall, world=world)
+
+
 def main(argv=None):
-    res = train(parse(argv))
-    print(json.dumps({k: v for k, v in res.items() if k != "history"}))
+    import os
+    args = parse(argv)
+    sharded = args.sharded or int(os.environ.get("WORLD_SIZE", "1")) > 1
+    res = train_sharded(args) if sharded else train(args)
+    if not sharded or int(os.environ.get("RANK", "0")) == 0:
+        print(json.dumps({k: v for k, v in res.items() if k != "history"}))
 
 
 if __name__ == "__main__":
