@@ -16,7 +16,7 @@ static hipError_t launch_variant_dt(const FwdArgs& a, int grid, hipStream_t st) 
   const size_t smem = fwd_smem_bytes<D, DH>(TRAIN, LSTREAM);
   auto k = k_fwd_bwd<D, DH, TRAIN, LSTREAM, DT>;
   if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, st, a);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(Geo<D, DH>::NW * 64), smem, st, a);
   return hipGetLastError();
 }
 

@@ -89,7 +89,7 @@ struct Geo {
   static constexpr int NB = CW / 16;            // 16-channel blocks per column
   static constexpr int CPS = D / CW;            // columns per sample
   static constexpr int SPW = 16 / CPS;          // samples per wavefront
-  static constexpr int NW = 8;                  // wavefronts per workgroup
+  static constexpr int NW = D_ == 64 ? 4 : 8;   // wavefronts per workgroup
   static constexpr int NSB = NW * SPW;          // samples per workgroup pass
   static constexpr int RT = NSB / 16;           // 16-row tiles of the bridge GEMM
   static constexpr int NT = D / 16;             // 16-col tiles of the bridge GEMM
