@@ -104,29 +104,57 @@ def as_batch(batch, is_test=False):
 
 
 # --------------------------------------------------------------------------- forward
-def _fwa_forward(x, length, W1, b1, W2, b2, H):
-    """feature_wise_attention, model.py:370-394 (bn off, keep_prob 1, relu then linear).
+def dropout_scale(rate, seed, B, L, d, net, which, sample0=0):
+    """The keep / drop pattern of tf.nn.dropout on the input of one linear map (model.py:428-431) as
+    the scale it multiplies with: 1 / keep_prob where the element is kept, 0 where it is dropped,
+    independently per (sample, position, channel).  TF's own random stream cannot be reproduced;
+    the pattern is a counter-based hash, the same one the HIP kernel evaluates (tlsan_common.h
+    drop_scale4): element e = ((((sample * 2 + net) * 128 + position) * 2 + which) * 256 + channel,
+    h = murmur3's 32-bit finaliser of (e xor seed), kept iff h < keep_prob * 2^32.
+    net: 0 long block / 1 short block; which: 0 input of map1 / 1 input of map2.  -> [B, L, d]"""
+    keep = 1.0 - rate
+    b = (np.arange(B, dtype=np.uint64)[:, None, None] + np.uint64(sample0))
+    l = np.arange(L, dtype=np.uint64)[None, :, None]
+    c = np.arange(d, dtype=np.uint64)[None, None, :]
+    e = ((((b * 2 + net) * 128 + l) * 2 + which) * 256 + c) & 0xFFFFFFFF
+    h = (e ^ np.uint64(seed & 0xFFFFFFFF)).astype(np.uint64)
+    h ^= h >> 16
+    h = (h * 0x85EBCA6B) & 0xFFFFFFFF
+    h ^= h >> 13
+    h = (h * 0xC2B2AE35) & 0xFFFFFFFF
+    h ^= h >> 16
+    thr = min(int(keep * 4294967296.0), 0xFFFFFFFF)
+    return np.where(h < thr, 1.0 / np.float32(keep), 0.0).astype(np.float64)
+
+
+def _fwa_forward(x, length, W1, b1, W2, b2, H, k1=None, k2=None):
+    """feature_wise_attention, model.py:370-394 (bn off, relu then linear; k1 / k2: dropout scales
+    of the two maps' inputs, None = keep_prob 1).
 
     x [B,L,d]; heads = contiguous channel blocks (tf.split axis 2, :374); softmax is over
     the sequence axis independently per (sample, head, channel) (:386)."""
     B, L, d = x.shape
     dh = d // H
     xh = x.reshape(B, L, H, dh)
-    z1 = xh @ W1 + b1                      # :380 (bn_dense_layer -> linear -> _linear :451)
+    k1 = None if k1 is None else k1.reshape(B, L, H, dh).astype(x.dtype)
+    k2 = None if k2 is None else k2.reshape(B, L, H, dh).astype(x.dtype)
+    z1 = (xh if k1 is None else xh * k1) @ W1 + b1   # :380 (bn_dense_layer -> linear -> _linear :451; dropout :428-431)
     m1 = np.maximum(z1, 0.0)               # relu :405
-    m2 = m1 @ W2 + b2                      # :382
+    m2 = (m1 if k2 is None else m1 * k2) @ W2 + b2   # :382
     mask = (np.arange(L)[None, :] < length[:, None])            # sequence_mask :376
     m2m = m2 + (1.0 - mask[:, :, None, None]) * VERY_NEGATIVE_NUMBER  # :384, 480-483
     mx = m2m.max(axis=1, keepdims=True)
     e = np.exp(m2m - mx)
     soft = e / e.sum(axis=1, keepdims=True)  # :386
     out = (soft * xh).sum(axis=1)            # :387
-    cache = dict(xh=xh, z1=z1, m1=m1, soft=soft, out=out)
+    cache = dict(xh=xh, z1=z1, m1=m1, soft=soft, out=out, k1=k1, k2=k2)
     return out.reshape(B, d), soft, cache
 
 
-def forward(p, item_cate_list, b, H, want_cache=False):
-    """model.py:84-137 (+ attention_net :316-366).  Returns logits [B] and intermediates."""
+def forward(p, item_cate_list, b, H, want_cache=False, dropout=None):
+    """model.py:84-137 (+ attention_net :316-366).  Returns logits [B] and intermediates.
+    dropout: None (inference / dropout_rate 0) or (rate, seed) -- training with
+    config['dropout'] > 0 (model.py:116-118, 428-431), pattern of dropout_scale."""
     cat = np.asarray(item_cate_list, np.int64)
     dt = p["item_emb"].dtype
     i_emb = np.concatenate([p["item_emb"][b["i"]], p["cate_emb"][cat[b["i"]]]], -1)      # :84-86
@@ -140,12 +168,18 @@ def forward(p, item_cate_list, b, H, want_cache=False):
     h = e_long * s[:, :, None]                                                          # :107-109
     h_new = np.concatenate([p["item_emb"][b["hist_i_new"]],
                             p["cate_emb"][cat[b["hist_i_new"]]]], -1)                   # :111-113
+    B_, d_ = h.shape[0], h.shape[2]
+    ks = [None] * 4
+    if dropout is not None and dropout[0] > 0.0:
+        rate, seed = dropout
+        ks = [dropout_scale(rate, seed, B_, h.shape[1], d_, 0, 0), dropout_scale(rate, seed, B_, h.shape[1], d_, 0, 1),
+              dropout_scale(rate, seed, B_, h_new.shape[1] + 1, d_, 1, 0), dropout_scale(rate, seed, B_, h_new.shape[1] + 1, d_, 1, 1)]
     long_, att0, c1 = _fwa_forward(h, b["sl"], p["fwa1_W1"], p["fwa1_b1"],
-                                   p["fwa1_W2"], p["fwa1_b2"], H)                       # :334-345
+                                   p["fwa1_W2"], p["fwa1_b2"], H, ks[0], ks[1])         # :334-345
     bridge = long_ @ p["dense_K"] + p["dense_b"]                                        # :347
     enc = np.concatenate([bridge[:, None, :], h_new], 1)                                # :350
     short, att1, c2 = _fwa_forward(enc, b["sl_new"] + 1, p["fwa2_W1"], p["fwa2_b1"],
-                                   p["fwa2_W2"], p["fwa2_b2"], H)                       # :353-364
+                                   p["fwa2_W2"], p["fwa2_b2"], H, ks[2], ks[3])         # :353-364
     u_t = short + u_emb                                                                 # :135
     logits = (u_t * i_emb).sum(-1) + i_b                                                # :137
     res = dict(logits=logits, u_t=u_t, att0=att0, att1=att1)
@@ -174,9 +208,9 @@ def l2_term(p):
     return sum(0.5 * float((p[k].astype(np.float64) ** 2).sum()) for k in REG_TABLES)
 
 
-def loss_fn(p, item_cate_list, b, H, reg):
+def loss_fn(p, item_cate_list, b, H, reg, dropout=None):
     """model.py:171-172."""
-    out = forward(p, item_cate_list, b, H)
+    out = forward(p, item_cate_list, b, H, dropout=dropout)
     y = b["y"].astype(out["logits"].dtype)
     return bce_with_logits(out["logits"], y).mean() + reg * l2_term(p)
 
@@ -184,23 +218,26 @@ def loss_fn(p, item_cate_list, b, H, reg):
 # --------------------------------------------------------------------------- backward
 def _fwa_backward(dout, c, W1, W2, H):
     """Manual gradient of _fwa_forward (what tf.gradients, model.py:198, differentiates)."""
-    xh, z1, m1, soft = c["xh"], c["z1"], c["m1"], c["soft"]
+    xh, z1, m1, soft, k1, k2 = c["xh"], c["z1"], c["m1"], c["soft"], c.get("k1"), c.get("k2")
     B, L, Hh, dh = xh.shape
     doh = dout.reshape(B, 1, Hh, dh)
     dsoft = doh * xh
     dx = soft * doh
     dm2 = soft * (dsoft - (soft * dsoft).sum(axis=1, keepdims=True))
-    dW2 = np.einsum("blhk,blhj->kj", m1, dm2)
+    dW2 = np.einsum("blhk,blhj->kj", m1 if k2 is None else m1 * k2, dm2)
     db2 = dm2.sum(axis=(0, 1, 2))
     dm1 = dm2 @ W2.T
+    if k2 is not None:
+        dm1 = dm1 * k2
     dz1 = dm1 * (z1 > 0)
-    dW1 = np.einsum("blhk,blhj->kj", xh, dz1)
+    dW1 = np.einsum("blhk,blhj->kj", xh if k1 is None else xh * k1, dz1)
     db1 = dz1.sum(axis=(0, 1, 2))
-    dx = dx + dz1 @ W1.T
+    dxm = dz1 @ W1.T
+    dx = dx + (dxm if k1 is None else dxm * k1)
     return dx.reshape(B, L, Hh * dh), dict(W1=dW1, b1=db1, W2=dW2, b2=db2)
 
 
-def backward(p, item_cate_list, b, H, reg, dlogits=None):
+def backward(p, item_cate_list, b, H, reg, dlogits=None, dropout=None):
     """Gradients of model.py:171-172's loss w.r.t. every trainable (model.py:198).
 
     Returns ``(loss, logits, grads, sparse)`` where ``grads[k]`` is the mathematically
@@ -209,7 +246,7 @@ def backward(p, item_cate_list, b, H, reg, dlogits=None):
     ``sparse['sq_per_use']`` = sum of squares of every per-use gather-gradient row with
     NO de-duplication (how TF-1.8 forms global_norm for IndexedSlices)."""
     cat = np.asarray(item_cate_list, np.int64)
-    out = forward(p, item_cate_list, b, H, want_cache=True)
+    out = forward(p, item_cate_list, b, H, want_cache=True, dropout=dropout)
     c = out["cache"]
     logits, u_t = out["logits"], out["u_t"]
     dt = logits.dtype
@@ -341,11 +378,12 @@ def apply_optimizer(p, g, lr, optimizer, state, used_item_b=None):
     return newp
 
 
-def train_step(p, item_cate_list, b, H, reg, lr, clip=5.0, norm_mode="tf18", optimizer="sgd", opt_state=None):
+def train_step(p, item_cate_list, b, H, reg, lr, clip=5.0, norm_mode="tf18", optimizer="sgd", opt_state=None,
+               dropout=None):
     """One step of model.py:185-205: grads -> clip_by_global_norm(clip) -> optimizer.  The default
     'sgd' (:195) is W -= lr * g; adam | rmsprop | adadelta (:188-193) keep their slots in
     `opt_state` (init_opt_state).  Returns (loss, new_params, info)."""
-    loss, logits, g, sparse = backward(p, item_cate_list, b, H, reg)
+    loss, logits, g, sparse = backward(p, item_cate_list, b, H, reg, dropout=dropout)
     norm = global_norm(p, g, sparse, reg, norm_mode)
     coef = clip / max(norm, clip)                             # clip_by_global_norm
     if optimizer == "sgd":

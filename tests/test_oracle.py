@@ -165,3 +165,28 @@ def test_sparse_optimizers_touch_only_gathered_item_b_rows():
     st["slot1"]["item_b"][:] = 0.5   # a row with momentum keeps moving without a gradient
     q2 = orc.apply_optimizer(q, {"item_b": np.zeros(6)}, 0.1, "adam", st, np.zeros(6, bool))
     assert np.all(q2["item_b"] != q["item_b"])
+
+
+@pytest.mark.parametrize("d,H,Ls,Sn", [(64, 8, 10, 3), (128, 8, 6, 0)])
+def test_dropout_backward_against_autograd(d, H, Ls, Sn):
+    """dropout > 0 (model.py:428-431): with the same keep / drop pattern, the oracle's manual gradients
+    equal autograd's of the torch restatement; the pattern keeps about keep_prob of the elements,
+    scales the kept ones by 1 / keep_prob and is a pure function of (seed, sample, position, channel)."""
+    cfg = make_config(d=d, H=H, Ls=Ls)
+    p = random_params(cfg, seed=5)
+    b, cat = random_batch(cfg, B=7, Sn=Sn, seed=6)
+    rate, seed, reg = 0.3, 0xC0FFEE, 5e-3
+    loss, logits, g, _ = orc.backward(p, cat, b, H, reg, dropout=(rate, seed))
+    ks = [orc.dropout_scale(rate, seed, 7, Ls, d, 0, 0), orc.dropout_scale(rate, seed, 7, Ls, d, 0, 1),
+          orc.dropout_scale(rate, seed, 7, Sn + 1, d, 1, 0), orc.dropout_scale(rate, seed, 7, Sn + 1, d, 1, 1)]
+    tl, tlog, tg = tref.grads(tref.params_to_torch(p), cat, tref.batch_to_torch(b), H, reg, [torch.tensor(k) for k in ks])
+    assert abs(loss - float(tl)) < TOL and np.abs(logits - tlog.numpy()).max() < TOL
+    for k in p:
+        assert np.abs(g[k] - tg[k].numpy()).max() < TOL, k
+    l0 = orc.backward(p, cat, b, H, reg)[0]
+    assert abs(l0 - loss) > 1e-6                                   # it does something
+    big = orc.dropout_scale(rate, seed, 64, 16, 128, 0, 0)
+    assert set(np.unique(big)) == {0.0, float(1.0 / np.float32(0.7))}
+    assert abs((big > 0).mean() - 0.7) < 0.01
+    assert np.array_equal(big[5:9], orc.dropout_scale(rate, seed, 4, 16, 128, 0, 0, sample0=5))
+    assert not np.array_equal(big, orc.dropout_scale(rate, seed + 1, 64, 16, 128, 0, 0))
