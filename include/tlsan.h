@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TLSAN_ABI_VERSION 6
+#define TLSAN_ABI_VERSION 7
 
 enum {
   TLSAN_OK = 0,
@@ -123,6 +123,13 @@ typedef struct {
    * while the previous step ran), otherwise the step builds it itself.  Defaults 0, 0. */
   int32_t index_slot;
   int32_t index_prebuilt;
+  /* config['dropout'] (model.py:116-118, 428-431): tf.nn.dropout with keep_prob = 1 - dropout on
+   * the inputs of the two linear maps of both attention blocks, train steps only (forward / evaluation
+   * never drop).  TF's random stream is not reproducible; the keep / drop pattern is a hash of
+   * (dropout_seed, sample, block, position, map, channel) -- pass a different seed every step.
+   * 0 = off (the reference's default).  Supported for Ls <= 10 and fp32 tables. */
+  float dropout;
+  uint32_t dropout_seed;
 } tlsan_hparams;
 
 /* Device-side results of a train step (all optional except loss). */

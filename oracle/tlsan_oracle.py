@@ -112,7 +112,7 @@ def dropout_scale(rate, seed, B, L, d, net, which, sample0=0):
     drop_scale4): element e = ((((sample * 2 + net) * 128 + position) * 2 + which) * 256 + channel,
     h = murmur3's 32-bit finaliser of (e xor seed), kept iff h < keep_prob * 2^32.
     net: 0 long block / 1 short block; which: 0 input of map1 / 1 input of map2.  -> [B, L, d]"""
-    keep = 1.0 - rate
+    keep = np.float32(1.0 - float(np.float32(rate)))        # the kernel's fp32 keep_prob
     b = (np.arange(B, dtype=np.uint64)[:, None, None] + np.uint64(sample0))
     l = np.arange(L, dtype=np.uint64)[None, :, None]
     c = np.arange(d, dtype=np.uint64)[None, None, :]
@@ -123,8 +123,8 @@ def dropout_scale(rate, seed, B, L, d, net, which, sample0=0):
     h ^= h >> 13
     h = (h * 0xC2B2AE35) & 0xFFFFFFFF
     h ^= h >> 16
-    thr = min(int(keep * 4294967296.0), 0xFFFFFFFF)
-    return np.where(h < thr, 1.0 / np.float32(keep), 0.0).astype(np.float64)
+    thr = min(int(float(keep) * 4294967296.0), 0xFFFFFFFF)
+    return np.where(h < thr, np.float32(1.0) / keep, np.float32(0.0)).astype(np.float64)
 
 
 def _fwa_forward(x, length, W1, b1, W2, b2, H, k1=None, k2=None):

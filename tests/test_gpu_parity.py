@@ -216,7 +216,7 @@ def test_errors():
     cfg = make_config(d=64, optimizer="adagrad")          # not one of model.py:188-195
     with pytest.raises(ValueError):
         Model(cfg, np.zeros(cfg["item_count"], np.int32))
-    cfg = make_config(d=64, dropout=0.1)
+    cfg = make_config(d=64, dropout=0.1, Ls=20)            # dropout is built for the in-register window only
     with pytest.raises(NotImplementedError):
         Model(cfg, np.zeros(cfg["item_count"], np.int32))
     cfg = make_config(d=64)
@@ -684,3 +684,34 @@ def test_large_tables_take_the_two_level_scan(l2_mode):
         du = np.asarray(got[k], np.float64).reshape(p[k].shape) - p[k]
         dr = q[k] - p[k]
         assert np.abs(du - dr).max() < 3e-4 * (np.abs(dr).max() + 1e-9) + 3e-7, k
+
+
+@pytest.mark.parametrize("d,rate", [(64, 0.2), (128, 0.35), (256, 0.5)])
+def test_dropout_training_matches_oracle(d, rate):
+    """config['dropout'] > 0 (model.py:116-118, 428-431): tf.nn.dropout on the inputs of the two maps of
+    both attention blocks, train steps only.  With the same keep / drop pattern (a hash of seed, sample,
+    block, position, map, channel) three train steps follow the oracle; evaluation does not drop."""
+    cfg = make_config(U=40, I=60, C=9, d=d, regulation_rate=1e-3, dropout=rate)
+    p = _p32(random_params(cfg, seed=91))
+    _, cat = random_batch(cfg, B=8, Sn=3, seed=0)
+    batches = [random_batch(cfg, B=37, Sn=2 + s, seed=910 + s)[0] for s in range(3)]
+    m = _model(cfg, cat, p)
+    q = dict(p)
+    for n, b in enumerate(batches):
+        seed = m.dropout_seed()
+        loss, newq, info = orc.train_step(q, cat, b, 8, cfg["regulation_rate"], lr=0.6, dropout=(rate, seed))
+        plain = orc.loss_fn(q, cat, b, 8, cfg["regulation_rate"])
+        assert abs(plain - loss) > 1e-5                        # the pattern matters
+        l = m.train(None, _tuple(b), 0.6)
+        assert abs(l - loss) < 1e-4 * max(1.0, abs(loss)), (n, l, loss, plain)
+        assert abs(m.last_gnorm() - info["norm"]) < 2e-4 * info["norm"]
+        got = m.get_params()
+        for k in newq:
+            du = np.asarray(got[k], np.float64).reshape(q[k].shape) - q[k]
+            dr = newq[k] - q[k]
+            assert np.abs(du - dr).max() < 3e-4 * (np.abs(dr).max() + 1e-9) + 3e-7, (n, k)
+        q = {k: np.asarray(got[k], np.float64).reshape(newq[k].shape) for k in newq}   # follow the device
+    # forward / evaluation: no dropout
+    li, _, _, _ = m.forward(_tuple(batches[0]), is_test=False)
+    ref = orc.forward(q, cat, batches[0], 8)["logits"]
+    assert np.abs(li.cpu().numpy() - ref).max() < LOGIT_TOL

@@ -8,7 +8,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libtlsan_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 NORM_TF18, NORM_DEDUP = 0, 1
 TABLE_F32, TABLE_BF16 = 0, 1
 L2_DENSE, L2_LAZY = 0, 1
@@ -53,7 +53,8 @@ class Packed(C.Structure):
 
 class HParams(C.Structure):
     _fields_ = [("lr", C.c_float), ("reg", C.c_float), ("clip", C.c_float),
-                ("norm_mode", C.c_int32), ("l2_mode", C.c_int32), ("index_slot", C.c_int32), ("index_prebuilt", C.c_int32)]
+                ("norm_mode", C.c_int32), ("l2_mode", C.c_int32), ("index_slot", C.c_int32), ("index_prebuilt", C.c_int32),
+                ("dropout", C.c_float), ("dropout_seed", C.c_uint32)]
 
 
 class Optimizer(C.Structure):

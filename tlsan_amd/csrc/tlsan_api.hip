@@ -574,7 +574,17 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   a.Gi = w.Gi; a.Gb = w.Gb; a.Gu = w.Gu; a.Gc = w.Gc; a.WU = w.WU;
   a.cur_item = st.cur_item[k]; a.cur_user = st.cur_user[k]; a.cur_uc = st.cur_uc[k];
   a.gLong = w.gLong; a.gDB = w.gDB; a.partials = w.partials;
-  const bool v2 = fwd_v2(s, true, d, a.p, b);
+  if (hp->dropout != 0.0f) {
+    if (!(hp->dropout > 0.0f && hp->dropout < 1.0f)) return fail(TLSAN_E_BADARG, "dropout must be in [0, 1)");
+    if (d->Ls > TLSAN_LS_MAX || a.p.table_dtype != TLSAN_TABLE_F32)
+      return fail(TLSAN_E_UNSUPPORTED, "dropout > 0 is built for Ls <= %d and fp32 tables", TLSAN_LS_MAX);
+    const float keep = (float)(1.0 - (double)hp->dropout);
+    const double t = (double)keep * 4294967296.0;
+    a.drop_thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+    a.drop_inv = 1.0f / keep;
+    a.drop_seed = hp->dropout_seed;
+  }
+  const bool v2 = fwd_v2(s, true, d, a.p, b) && hp->dropout == 0.0f;
   const int grp = v2 ? 16 : s.NSB;  // samples per workgroup pass of the kernel that runs (= per partial record)
   a.ngroups = (b->B + grp - 1) / grp;
   prof_mark(1, hs);

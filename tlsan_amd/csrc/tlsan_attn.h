@@ -27,12 +27,14 @@
 // plus the per-channel softmax statistics (mx = max score, Z = 1/sum exp) from which the
 // backward recomputes a[p] = exp(m2[p] - mx) * Z (exactly 0 on masked positions).
 // Positions are processed two per (wave-uniform) branch so their MFMA chains interleave.
-template <int NB, int NPOS>
+// DROP: dropout on the inputs of both maps (model.py:428-431), pattern drop_scale4(dc, net, p, ., chb).
+template <int NB, int NPOS, bool DROP = false>
 __device__ __forceinline__ void fwa_forward(const float (&FT1)[NB][NB][4], const f32x4 (&b1)[NB],
                                             const float (&FT2)[NB][NB][4], const f32x4 (&b2)[NB],
                                             const f32x4 (&e)[NPOS][NB], const float (&sc)[NPOS],
                                             int n_valid, int pmax, f32x4 (&mx)[NB],
-                                            f32x4 (&Z)[NB], f32x4 (&out)[NB], float* __restrict__ sAw) {
+                                            f32x4 (&Z)[NB], f32x4 (&out)[NB], float* __restrict__ sAw,
+                                            const DropCtx& dc = DropCtx{}, int net = 0, const int* chb = nullptr) {
   f32x4 a[NPOS][NB];
 #pragma unroll
   for (int kb = 0; kb < NB; ++kb) mx[kb] = (f32x4)(TLSAN_NEG);
@@ -44,11 +46,19 @@ __device__ __forceinline__ void fwa_forward(const float (&FT1)[NB][NB][4], const
         f32x4 xv[NB], z[NB], m2[NB];
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) xv[kb] = e[p][kb] * sc[p];
+        if constexpr (DROP) {
+#pragma unroll
+          for (int kb = 0; kb < NB; ++kb) xv[kb] *= drop_scale4(dc, net, p, 0, chb[kb]);
+        }
         map_apply<NB>(FT1, b1, xv, z);  // model.py:380 (relu below)
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
           for (int i = 0; i < 4; ++i) z[kb][i] = fmaxf(z[kb][i], 0.0f);
+        if constexpr (DROP) {
+#pragma unroll
+          for (int kb = 0; kb < NB; ++kb) z[kb] *= drop_scale4(dc, net, p, 1, chb[kb]);
+        }
         map_apply<NB>(FT2, b2, z, m2);  // model.py:382
         const bool valid = p < n_valid;
 #pragma unroll
@@ -100,13 +110,17 @@ __device__ __forceinline__ void fwa_forward(const float (&FT1)[NB][NB][4], const
 // a (softmax weight), outv (block output), dout (gradient of block output).
 // Produces dx, accumulates db1 / db2, and writes the four 16x16 tiles (x, dz1, m1, dm2) of
 // this position transposed-ready into the LDS scratch `T` for bwd_dw.
-template <int NB, int TSTR>
+// DROP: k1 / k2 are the dropout scales of this position's map inputs (x (.) k1 entered map 1,
+// relu(z1) (.) k2 entered map 2): the staged operands of the dW products and the two
+// back-propagated vectors carry them.
+template <int NB, int TSTR, bool DROP = false>
 __device__ __forceinline__ void bwd_compute(const float (&FN2)[NB][NB][4],
                                             const float (&FN1)[NB][NB][4], const f32x4 (&xv)[NB],
                                             const f32x4 (&z1)[NB], const f32x4 (&av)[NB],
                                             const f32x4 (&outv)[NB], const f32x4 (&dout)[NB],
                                             float* __restrict__ T, int q, int r,
-                                            f32x4 (&db1)[NB], f32x4 (&db2)[NB], f32x4 (&dx)[NB]) {
+                                            f32x4 (&db1)[NB], f32x4 (&db2)[NB], f32x4 (&dx)[NB],
+                                            const f32x4* k1 = nullptr, const f32x4* k2 = nullptr) {
   f32x4 m1[NB], dm2[NB], dm1[NB], dz1[NB], dxm[NB], zero[NB];
 #pragma unroll
   for (int kb = 0; kb < NB; ++kb) {
@@ -116,11 +130,22 @@ __device__ __forceinline__ void bwd_compute(const float (&FN2)[NB][NB][4],
     for (int i = 0; i < 4; ++i) m1[kb][i] = fmaxf(z1[kb][i], 0.0f);
   }
   map_apply<NB>(FN2, zero, dm2, dm1);  // dm1 = dm2 . W2^T
+  if constexpr (DROP) {
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+      dm1[kb] *= k2[kb];
+      m1[kb] *= k2[kb];   // what map 2 saw: the dW2 operand
+    }
+  }
 #pragma unroll
   for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
     for (int i = 0; i < 4; ++i) dz1[kb][i] = z1[kb][i] > 0.0f ? dm1[kb][i] : 0.0f;
   map_apply<NB>(FN1, zero, dz1, dxm);  // dz1 . W1^T
+  if constexpr (DROP) {
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) dxm[kb] *= k1[kb];
+  }
 #pragma unroll
   for (int kb = 0; kb < NB; ++kb) {
     dx[kb] = av[kb] * dout[kb] + dxm[kb];
@@ -131,7 +156,7 @@ __device__ __forceinline__ void bwd_compute(const float (&FN2)[NB][NB][4],
   const int wofs = r * TSTR + 4 * q;
 #pragma unroll
   for (int kb = 0; kb < NB; ++kb) {
-    *(f32x4*)(T + (0 * NB + kb) * 16 * TSTR + wofs) = xv[kb];
+    *(f32x4*)(T + (0 * NB + kb) * 16 * TSTR + wofs) = DROP ? xv[kb] * k1[kb] : xv[kb];   // what map 1 saw: the dW1 operand
     *(f32x4*)(T + (1 * NB + kb) * 16 * TSTR + wofs) = dz1[kb];
     *(f32x4*)(T + (2 * NB + kb) * 16 * TSTR + wofs) = m1[kb];
     *(f32x4*)(T + (3 * NB + kb) * 16 * TSTR + wofs) = dm2[kb];
@@ -350,8 +375,9 @@ __device__ __forceinline__ void online_step(f32x4 (&mx)[NB], f32x4 (&Z)[NB], f32
 
 // LSTREAM: the long block is streamed like the short one (any Ls <= TLSAN_LS_CAP); otherwise its
 // Ls <= TLSAN_LS_MAX positions stay in registers between forward and backward.
-template <int D, int DH, bool TRAIN, bool LSTREAM, int DT = TLSAN_TABLE_F32>
+template <int D, int DH, bool TRAIN, bool LSTREAM, int DT = TLSAN_TABLE_F32, bool DROP = false>
 __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
+  static_assert(!DROP || (TRAIN && !LSTREAM), "dropout: training with the long window in registers");
   using G = Geo<D, DH>;
   constexpr int NB = G::NB, CPS = G::CPS, SPW = G::SPW, NW = G::NW, NSB = G::NSB;
   constexpr int LS = LSTREAM ? 1 : TLSAN_LS_MAX;             // positions held in registers
@@ -409,6 +435,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     TLSAN_STAMP(0);
     const int bidx = g * NSB + srow;
     const bool vs = bidx < B;
+    DropCtx dc;
+    dc.seed = a.drop_seed; dc.thr = a.drop_thr; dc.inv = a.drop_inv; dc.sbase = 2u * (uint32_t)bidx;
     const int bb = vs ? bidx : 0;
     const int uid = a.b.u[bb];
     const int it_i = a.b.i[bb];
@@ -558,7 +586,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       load_frag_T<DH, NB>(w1W2, q, r, FT2);
       load_bias<DH, NB>(w1b1, q, b1);
       load_bias<DH, NB>(w1b2, q, b2);
-      fwa_forward<NB, LS>(FT1, b1, FT2, b2, e1, sc1, n_l, pmax1, mx1, iz1, long4, KEEP_A ? sAw : nullptr);
+      fwa_forward<NB, LS, DROP>(FT1, b1, FT2, b2, e1, sc1, n_l, pmax1, mx1, iz1, long4, KEEP_A ? sAw : nullptr, dc, 0, chb);
     }
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
@@ -666,11 +694,22 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       f32x4 xv[NB], z[NB];
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb) xv[kb] = *(const f32x4*)(sB + srow * LSTR + chb[kb]);
-      map_apply<NB>(FT1, b1, xv, z);
+      if constexpr (DROP) {
+        f32x4 xd[NB];
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) xd[kb] = xv[kb] * drop_scale4(dc, 1, 0, 0, chb[kb]);
+        map_apply<NB>(FT1, b1, xd, z);
+      } else {
+        map_apply<NB>(FT1, b1, xv, z);
+      }
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
         for (int i = 0; i < 4; ++i) z[kb][i] = fmaxf(z[kb][i], 0.0f);
+      if constexpr (DROP) {
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) z[kb] *= drop_scale4(dc, 1, 0, 1, chb[kb]);
+      }
       map_apply<NB>(FT2, b2, z, mx);  // position 0 is always valid: running max = its score
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb) {
@@ -695,11 +734,22 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         if ((p % NL) == 0) load_chunk(p);
         fetch_row(p, xnext);
       }
-      map_apply<NB>(FT1, b1, xv, z);
+      if constexpr (DROP) {
+        f32x4 xd[NB];
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) xd[kb] = xv[kb] * drop_scale4(dc, 1, p, 0, chb[kb]);
+        map_apply<NB>(FT1, b1, xd, z);
+      } else {
+        map_apply<NB>(FT1, b1, xv, z);
+      }
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
         for (int i = 0; i < 4; ++i) z[kb][i] = fmaxf(z[kb][i], 0.0f);
+      if constexpr (DROP) {
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) z[kb] *= drop_scale4(dc, 1, p, 1, chb[kb]);
+      }
       map_apply<NB>(FT2, b2, z, m2);
       if (vt) {
 #pragma unroll
@@ -808,11 +858,27 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             if (p > 0 && (p % NL) == 0) load_chunk(p);
             fetch_row(p, xn2);
           }
-          map_apply<NB>(FT1, b1, xv, z1);
+          f32x4 k1[NB], k2[NB];
+          if constexpr (DROP) {
+            f32x4 xd[NB];
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+              k1[kb] = drop_scale4(dc, 1, p, 0, chb[kb]);
+              k2[kb] = drop_scale4(dc, 1, p, 1, chb[kb]);
+              xd[kb] = xv[kb] * k1[kb];
+            }
+            map_apply<NB>(FT1, b1, xd, z1);
+          } else {
+            map_apply<NB>(FT1, b1, xv, z1);
+          }
 #pragma unroll
           for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
             for (int i = 0; i < 4; ++i) zr[kb][i] = fmaxf(z1[kb][i], 0.0f);
+          if constexpr (DROP) {
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) zr[kb] *= k2[kb];
+          }
           map_apply<NB>(FT2, b2, zr, m2);
 #pragma unroll
           for (int kb = 0; kb < NB; ++kb)
@@ -820,7 +886,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             for (int i = 0; i < 4; ++i)
               av[kb][i] = vt ? __expf(m2[kb][i] - mx[kb][i]) * Zs[kb][i] : 0.0f;
           float* Tp = T + (NBUF > 1 ? (p & 1) * TB : 0);
-          bwd_compute<NB, TSTR>(FN2, FN1, xv, z1, av, short4, dout, Tp, q, r, acc.db1, acc.db2, dx);
+          bwd_compute<NB, TSTR, DROP>(FN2, FN1, xv, z1, av, short4, dout, Tp, q, r, acc.db1, acc.db2, dx, k1, k2);
           if (NBUF == 1) bwd_dw<NB, TSTR>(Tp, q, r, acc.dW1, acc.dW2);
           else if (p > 0) bwd_dw<NB, TSTR>(T + ((p - 1) & 1) * TB, q, r, acc.dW1, acc.dW2);
           if (p == 0) {
@@ -1001,7 +1067,19 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) xv[kb] = e1[p][kb] * scp;
             if (p == 1) TLSAN_STAMP(12);
-            map_apply<NB>(FT1, b1, xv, z1);
+            f32x4 k1[NB], k2[NB];
+            if constexpr (DROP) {
+              f32x4 xd[NB];
+#pragma unroll
+              for (int kb = 0; kb < NB; ++kb) {
+                k1[kb] = drop_scale4(dc, 0, p, 0, chb[kb]);
+                k2[kb] = drop_scale4(dc, 0, p, 1, chb[kb]);
+                xd[kb] = xv[kb] * k1[kb];
+              }
+              map_apply<NB>(FT1, b1, xd, z1);
+            } else {
+              map_apply<NB>(FT1, b1, xv, z1);
+            }
             if constexpr (KEEP_A) {
 #pragma unroll
               for (int kb = 0; kb < NB; ++kb) av[kb] = *(const f32x4*)(sAw + (p * NB + kb) * 256);
@@ -1010,6 +1088,10 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
               for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) zr[kb][i] = fmaxf(z1[kb][i], 0.0f);
+              if constexpr (DROP) {
+#pragma unroll
+                for (int kb = 0; kb < NB; ++kb) zr[kb] *= k2[kb];
+              }
               map_apply<NB>(FT2, b2, zr, m2);
 #pragma unroll
               for (int kb = 0; kb < NB; ++kb)
@@ -1019,7 +1101,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             }
             if (p == 1) TLSAN_STAMP(13);
             float* Tp = T + (NBUF > 1 ? (p & 1) * TB : 0);
-            bwd_compute<NB, TSTR>(FN2, FN1, xv, z1, av, long4, dlong, Tp, q, r, acc.db1, acc.db2, dx);
+            bwd_compute<NB, TSTR, DROP>(FN2, FN1, xv, z1, av, long4, dlong, Tp, q, r, acc.db1, acc.db2, dx, k1, k2);
             if (p == 1) TLSAN_STAMP(14);
             if (NBUF == 1) bwd_dw<NB, TSTR>(Tp, q, r, acc.dW1, acc.dW2);
             else if (p > 0) bwd_dw<NB, TSTR>(T + ((p - 1) & 1) * TB, q, r, acc.dW1, acc.dW2);

@@ -11,10 +11,10 @@ static size_t fwd_smem_bytes(bool train, bool lstream) {
                           ((G::KEEP_A && train && !lstream) ? G::NW * TLSAN_LS_MAX * G::NB * 256 : 0));
 }
 
-template <int D, int DH, bool TRAIN, bool LSTREAM, int DT>
+template <int D, int DH, bool TRAIN, bool LSTREAM, int DT, bool DROP = false>
 static hipError_t launch_variant_dt(const FwdArgs& a, int grid, hipStream_t st) {
   const size_t smem = fwd_smem_bytes<D, DH>(TRAIN, LSTREAM);
-  auto k = k_fwd_bwd<D, DH, TRAIN, LSTREAM, DT>;
+  auto k = k_fwd_bwd<D, DH, TRAIN, LSTREAM, DT, DROP>;
   if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(k, dim3(grid), dim3(Geo<D, DH>::NW * 64), smem, st, a);
   return hipGetLastError();
@@ -24,7 +24,12 @@ static hipError_t launch_variant_dt(const FwdArgs& a, int grid, hipStream_t st) 
 template <int D, int DH, bool TRAIN, bool LSTREAM>
 static hipError_t launch_variant(const FwdArgs& a, int grid, hipStream_t st) {
   if (a.p.table_dtype == TLSAN_TABLE_BF16) {
+    if (a.drop_thr != 0) return hipErrorNotSupported;
     if constexpr (!LSTREAM) return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_BF16>(a, grid, st);
+    else return hipErrorNotSupported;
+  }
+  if (a.drop_thr != 0) {  // dropout: training, long window in registers, fp32 tables
+    if constexpr (TRAIN && !LSTREAM) return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_F32, true>(a, grid, st);
     else return hipErrorNotSupported;
   }
   return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_F32>(a, grid, st);

@@ -263,4 +263,27 @@ struct FwdArgs {
   float* gDB;       // [B, D]   d loss / d bridge     (B operand of dK)
   float* partials;  // [ngroups, NPB]
   unsigned long long* stamps;  // diagnostic only (NULL in production): [gridDim.x*8 waves][16]
+  // dropout on the inputs of the attention maps (model.py:428-431), training with config['dropout'] > 0
+  uint32_t drop_seed, drop_thr;   // kept iff hash < drop_thr (keep_prob * 2^32); drop_thr == 0: no dropout
+  float drop_inv;                 // 1 / keep_prob
 };
+
+// Keep / drop pattern of tf.nn.dropout as the scale the element is multiplied with (0 or 1/keep_prob):
+// a counter-based hash of (seed, sample, block, position, map, channel) -- the forward and the two
+// recomputations of the backward see the same pattern without storing it (oracle: dropout_scale).
+struct DropCtx {
+  uint32_t seed, thr;
+  float inv;
+  uint32_t sbase;  // 2 * global sample index
+};
+__device__ __forceinline__ f32x4 drop_scale4(const DropCtx& dc, int net, int pos, int which, int chan) {
+  const uint32_t e0 = ((((dc.sbase + (uint32_t)net) * 128u + (uint32_t)pos) * 2u + (uint32_t)which) * 256u) + (uint32_t)chan;
+  f32x4 k;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint32_t h = (e0 + (uint32_t)i) ^ dc.seed;
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    k[i] = h < dc.thr ? dc.inv : 0.0f;
+  }
+  return k;
+}

@@ -161,8 +161,12 @@ class Model(object):
         torch.cuda.set_device(self.device)
         if config.get("num_blocks", 1) != 1:
             raise ValueError("num_blocks != 1 is degenerate in the reference (model.py:330-364) and unsupported")
-        if config.get("dropout", 0.0) != 0.0:
-            raise NotImplementedError("dropout > 0 (model.py:428-431) is not implemented")
+        self.dropout = float(config.get("dropout", 0.0))           # model.py:116-118, 428-431
+        if not 0.0 <= self.dropout < 1.0:
+            raise ValueError("dropout must be in [0, 1)")
+        if self.dropout > 0.0 and (config["Ls"] > 10 or table_dtype != "f32"):
+            raise NotImplementedError("dropout > 0 is built for Ls <= 10 and fp32 tables")
+        self._seed = int(seed)
         self.optimizer = config.get("optimizer", "sgd")           # model.py:188-195
         if self.optimizer not in OPTIMIZERS:
             raise ValueError("optimizer must be one of %s" % (sorted(OPTIMIZERS),))
@@ -394,9 +398,16 @@ class Model(object):
         self._epoch += 1
         return self._epoch
 
+    def dropout_seed(self, step=None):
+        """Seed of the keep / drop pattern of update number `step` (default: the next one): a fixed
+        function of the model's seed and the step, so that runs are reproducible."""
+        step = self._step if step is None else step
+        return ((self._seed * 0x9E3779B1) ^ ((step + 1) * 0x85EBCA77)) & 0xFFFFFFFF
+
     def hparams(self, lr, index_slot=0, index_prebuilt=0):
         return L.HParams(float(lr), float(self.config["regulation_rate"]), float(self.config["max_gradient_norm"]),
-                         self.norm_mode, self.l2_mode, index_slot, index_prebuilt)
+                         self.norm_mode, self.l2_mode, index_slot, index_prebuilt,
+                         self.dropout, self.dropout_seed() if self.dropout > 0.0 else 0)
 
     # ------------------------------------------------------------------ training
     def device_batch(self, batch, is_test=False):
@@ -414,6 +425,8 @@ class Model(object):
         ws = self._workspace(db.B, db.Sn)
         out = L.StepOut(self._out.data_ptr(), self._out.data_ptr() + 4, None if logits is None else logits.data_ptr(), None)
         if torch.cuda.is_current_stream_capturing():   # hipGraph capture: one self-contained step
+            if self.dropout > 0.0:
+                raise NotImplementedError("the dropout seed is a launch argument: capture is not supported")
             if self.optimizer == "adam":
                 raise NotImplementedError("Adam's step count is a launch argument: capture is not supported")
             hp = self.hparams(lr)
