@@ -715,3 +715,30 @@ def test_dropout_training_matches_oracle(d, rate):
     li, _, _, _ = m.forward(_tuple(batches[0]), is_test=False)
     ref = orc.forward(q, cat, batches[0], 8)["logits"]
     assert np.abs(li.cpu().numpy() - ref).max() < LOGIT_TOL
+
+
+@pytest.mark.parametrize("d", [64, 128])
+def test_empty_histories(d):
+    """sl = 0 (no long-term history; the reference's placeholders allow it although build_dataset.py never
+    emits it): every position is masked, exp_mask leaves -1e30 everywhere (model.py:384, 480-483), the
+    softmax is uniform over rows that are all zero -> the long summary is exactly 0 and nothing flows back
+    into the window.  Mixed with ordinary samples, forward and one train step against the oracle."""
+    cfg = make_config(U=30, I=50, C=7, d=d, regulation_rate=1e-3)
+    p = _p32(random_params(cfg, seed=95))
+    b, cat = random_batch(cfg, B=41, Sn=3, seed=96)
+    b["sl"][::3] = 0
+    ar = np.arange(cfg["Ls"])[None, :]
+    b["hist_i"] = np.where(ar < b["sl"][:, None], b["hist_i"], 0)
+    b["hist_t"] = np.where(ar < b["sl"][:, None], b["hist_t"], 0).astype(np.float32)
+    ref = orc.forward(p, cat, b, 8)
+    m = _model(cfg, cat, p)
+    li, _, _, _ = m.forward(_tuple(b), is_test=False)
+    assert np.abs(li.cpu().numpy() - ref["logits"]).max() < LOGIT_TOL
+    loss, newp, info = orc.train_step(p, cat, b, 8, cfg["regulation_rate"], lr=0.5)
+    l = m.train(None, _tuple(b), 0.5)
+    assert abs(l - loss) < 1e-4 * max(1.0, abs(loss))
+    got = m.get_params()
+    for k in newp:
+        du = np.asarray(got[k], np.float64).reshape(p[k].shape) - p[k]
+        dr = newp[k] - p[k]
+        assert np.abs(du - dr).max() < 3e-4 * (np.abs(dr).max() + 1e-9) + 3e-7, k
