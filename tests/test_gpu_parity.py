@@ -742,3 +742,32 @@ def test_empty_histories(d):
         du = np.asarray(got[k], np.float64).reshape(p[k].shape) - p[k]
         dr = newp[k] - p[k]
         assert np.abs(du - dr).max() < 3e-4 * (np.abs(dr).max() + 1e-9) + 3e-7, k
+
+
+@pytest.mark.parametrize("l2_mode", ["lazy", "dense"])
+def test_one_hot_row_takes_every_use(l2_mode):
+    """Collisions at their worst: every sample is the same user, every window and session the same item,
+    the candidate the last item of the table -- one destination row receives all 3000+ per-use gradient
+    rows (long segments finished by the whole wavefront, one category with every use), one user row
+    all 256; one train step against the oracle, bitwise reproducible."""
+    cfg = make_config(U=9, I=31, C=4, d=128, regulation_rate=1e-3)
+    p = _p32(random_params(cfg, seed=97))
+    b, cat = random_batch(cfg, B=256, Sn=2, seed=98, full=True)
+    b["u"][:] = cfg["user_count"] - 1
+    b["hist_i"][:] = 7
+    b["hist_i_new"][:] = 7
+    b["i"][:] = cfg["item_count"] - 1
+    b["u_cate"][:] = int(cat[7])
+    loss, newp, info = orc.train_step(p, cat, b, 8, cfg["regulation_rate"], lr=0.5)
+    outs = []
+    for rep in range(2):
+        m = _model(cfg, cat, p, l2_mode=l2_mode)
+        l = m.train(None, _tuple(b), 0.5)
+        assert abs(l - loss) < 1e-4 * max(1.0, abs(loss))
+        assert abs(m.last_gnorm() - info["norm"]) < 2e-4 * info["norm"]
+        outs.append(m.get_params())
+    for k in newp:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+        du = np.asarray(outs[0][k], np.float64).reshape(p[k].shape) - p[k]
+        dr = newp[k] - p[k]
+        assert np.abs(du - dr).max() < 3e-4 * (np.abs(dr).max() + 1e-9) + 3e-7, k
