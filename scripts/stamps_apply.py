@@ -6,8 +6,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tlsan_amd import _lib as L, synth
 from tlsan_amd.model import Model
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-cfg = synth.make_config("electronics")
+B = int(sys.argv[1]) if len(sys.argv) > 1 and "=" not in sys.argv[1] else 4096
+kw = dict(x.split("=") for x in sys.argv[1:] if "=" in x)     # e.g. U=35896 I=28589 C=15 (Movies-TV shape)
+cfg = synth.make_config("electronics", user_count=int(kw.get("U", 39991)), item_count=int(kw.get("I", 22048)),
+                        cate_count=int(kw.get("C", 673)))
 m = Model(cfg, synth.item_cate_list(cfg), l2_mode="lazy")
 lib = L.load()
 hb = synth.make_batches(cfg, 1, B, seed=7)[0]
@@ -28,6 +30,8 @@ s = s[:n]
 t0 = s[used[:n], 0].min()
 C = cfg["cate_count"]
 Sn = db.Sn
+uses = -(-(B * (cfg["Ls"] + db.Sn + 2)) // C)
+C = C * (min(64, uses // 128) if uses > 512 else 1)     # workgroups of the category part (split categories, tlsan_train_step)
 ni = min(cfg["item_count"], B * (cfg["Ls"] + Sn + 1))
 nbI = (ni + 15) // 16
 nbU = (min(B, cfg["user_count"]) + 15) // 16

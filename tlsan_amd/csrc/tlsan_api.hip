@@ -133,6 +133,7 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
   w->bytes = o;
 }
 
+#define UC_LIST_CAP (1 << 18)  // batches up to this many samples keep a per-category sample list in the state
 struct St {  // persistent state
   // two index slots (a batch's destination index depends only on its ids, so it lives with the
   // state, not in the per-call workspace whose layout follows the batch shape):
@@ -144,6 +145,8 @@ struct St {  // persistent state
   StateHdr* hdr;
   double *S_part, *S_total;
   long long* scan_bsum;                                   // per-chunk sums of the index scan (large tables)
+  int32_t* uc_list[2];                                    // samples of every category (u_cate uses), UC_LIST_CAP each
+  double* Rc64;                                           // category sums of a split PRESUM pass, zero at rest
   size_t bytes;
   int nbI, nbU, nbC;
 };
@@ -173,6 +176,8 @@ static void carve_state(const tlsan_dims* d, char* base, St* s) {
   s->cate_cur = (int32_t*)take(4 * (size_t)d->cate_count);
   s->cate_items = (int32_t*)take(4 * (size_t)d->item_count);
   s->S_part = (double*)take(8 * (size_t)(s->nbI + s->nbU + s->nbC));
+  for (int k = 0; k < 2; ++k) s->uc_list[k] = (int32_t*)take(4 * (size_t)UC_LIST_CAP);
+  s->Rc64 = (double*)take(8 * (size_t)d->cate_count * d->d_cate);
   s->scan_bsum = (long long*)take(8 * ((size_t)(d->item_count + 4095) / 4096 + (d->cate_count + 4095) / 4096 +
                                        (d->user_count + 4095) / 4096));
   s->S_total = base ? &s->hdr->St : nullptr;
@@ -262,6 +267,9 @@ static void fill_apply(ApplyArgs& A, const tlsan_dims* d, const Shape& s, const 
   A.off_item = st.off_item[k]; A.off_uc = st.off_uc[k]; A.off_user = st.off_user[k];
   A.n_uniq_item = st.hdr ? &st.hdr->n_uniq[k][0] : nullptr; A.n_uniq_user = st.hdr ? &st.hdr->n_uniq[k][1] : nullptr;
   A.cate_off = st.cate_off; A.cate_cnt = st.cate_cnt; A.cate_items = st.cate_items;
+  A.uc_list = (b && b->B <= UC_LIST_CAP) ? st.uc_list[k] : nullptr;
+  A.Rc64 = st.Rc64;
+  A.csplit = 1; A.cpass = 256;
   A.gd = w.gd;
   A.Rc = w.Rc; A.Ri = w.Ri; A.Rb = w.Rb; A.Ru = w.Ru;
   A.part_out = st.S_part; A.hdr = st.hdr;
@@ -534,6 +542,7 @@ int tlsan_forward(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch*
 // destination index of a batch into slot k: use counts per destination row -> first sorted position
 // of every row (+ records of the used rows)
 static int build_index(const tlsan_dims* d, const tlsan_batch* b, const St& st, int k, hipStream_t hs) {
+  int rc;
   CountArgs ca;
   memset(&ca, 0, sizeof(ca));
   ca.b = *b; ca.Ls = d->Ls;
@@ -554,7 +563,12 @@ static int build_index(const tlsan_dims* d, const tlsan_batch* b, const St& st, 
   sa.urec[0] = st.urec_item[k]; sa.urec[2] = st.urec_user[k];
   sa.total[0] = sa.total[1] = sa.total[2] = 1;
   sa.n_uniq[0] = &st.hdr->n_uniq[k][0]; sa.n_uniq[1] = nullptr; sa.n_uniq[2] = &st.hdr->n_uniq[k][1];
-  return launch_scan(sa, nscan, st.scan_bsum, hs);
+  if ((rc = launch_scan(sa, nscan, st.scan_bsum, hs))) return rc;
+  if (b->B <= UC_LIST_CAP) {
+    hipLaunchKernelGGL(k_uc_fill, dim3((b->B + 255) / 256), dim3(256), 0, hs, b->u_cate, b->B, st.cur_uc[k], st.uc_list[k]);
+    CHECK_LAUNCH("k_uc_fill");
+  }
+  return TLSAN_OK;
 }
 
 // shared front half of train_step / grads: index build, fused fwd+bwd, dense-grad reduction
@@ -573,6 +587,7 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   a.logits_i = (out && out->logits) ? out->logits : w.logits;
   a.Gi = w.Gi; a.Gb = w.Gb; a.Gu = w.Gu; a.Gc = w.Gc; a.WU = w.WU;
   a.cur_item = st.cur_item[k]; a.cur_user = st.cur_user[k]; a.cur_uc = st.cur_uc[k];
+  a.uc_by_sample = b->B <= UC_LIST_CAP ? 1 : 0;
   a.gLong = w.gLong; a.gDB = w.gDB; a.partials = w.partials;
   if (hp->dropout != 0.0f) {
     if (!(hp->dropout > 0.0f && hp->dropout < 1.0f)) return fail(TLSAN_E_BADARG, "dropout must be in [0, 1)");
@@ -620,6 +635,7 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
     // lazy update: the exact row sums of the apply pass share the launch (they wait for nothing it produces)
     ApplyArgs A = *presum;
     lazy_blocks(A, b->B, b->Sn);
+    A.nbC = A.C * A.csplit;
     const dim3 grid(w.nfin + 1 + A.nbC + A.nbI + A.nbU);
     const bool wide = apply_wide(A);
 #define FP_LAUNCH(DD, HH)                                                                                         \
@@ -748,6 +764,15 @@ int tlsan_train_step_opt(const tlsan_dims* d, const tlsan_params* p, const tlsan
   }
   static const int split = [] { const char* v = getenv("TLSAN_APPLY_SPLIT"); return v ? atoi(v) : 1; }();
   if (hp->l2_mode == TLSAN_L2_LAZY && split) {
+    // few, large categories: several workgroups per category in the row-sum pass, about 128 uses each
+    // (estimated from the batch shape; up to 64 per category), every one with its share of the items
+    const long uses = ((long)b->B * (d->Ls + b->Sn + 2) + d->cate_count - 1) / d->cate_count;
+    const int per = (d->item_count + d->cate_count - 1) / d->cate_count;
+    if (uses > 512) {
+      A.csplit = (int)(uses / 128 < 64 ? uses / 128 : 64);
+      int ps = (per + A.csplit - 1) / A.csplit;
+      A.cpass = ps < 1 ? 1 : (ps > 256 ? 256 : ps);
+    }
     if ((rc = run_backward(d, s, p, b, hp, true, out, w, st, L, hs, &A))) return rc;
     if ((rc = launch_update_lazy(A, b->B, b->Sn, hs))) return rc;
   } else {

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(1024) void k_fwd_bwd2(FwdArgs a) {
       if (lead && vs) {
         pos_t = draw(a.cur_item, (uint32_t)it_i);
         pos_u = draw(a.cur_user, (uint32_t)uid);
-        pos_c = draw(a.cur_uc, (uint32_t)ucat);
+        pos_c = a.uc_by_sample ? bidx : draw(a.cur_uc, (uint32_t)ucat);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -259,6 +259,8 @@ struct FwdArgs {
   float* Gu;        // [B, WU]           [user_emb | usert_emb | pad] rows, grouped by user id
   float* Gc;        // [B, dc]           u_cate rows, grouped by category
   int32_t* cur_item; int32_t* cur_user; int32_t* cur_uc;
+  int32_t uc_by_sample;   // != 0: Gc rows are written in SAMPLE order (row b = sample b) and the index holds the
+                          // samples of every category (uc_list, k_uc_fill): no cursor is drawn for the u_cate use
   float* gLong;     // [B, D]   long-term summaries (A operand of dK)
   float* gDB;       // [B, D]   d loss / d bridge     (B operand of dK)
   float* partials;  // [ngroups, NPB]

@@ -62,6 +62,14 @@ __global__ void k_count(CountArgs a) {
 // One thread per (sample, slot): slots [0,Ls) the long window -- sl = min(len, Ls), the LAST Ls
 // items when the history is longer (input.py:41-45), left-aligned otherwise (:47-49), zeros past
 // sl -- slots [Ls, Ls+Sn) the current session padded with zeros, slot Ls+Sn the scalars.
+// Samples of every category for the u_cate uses (counting sort by category, after the scan): the
+// fused kernel then writes those gradient rows in sample order and draws no cursor for them -- with
+// few categories (15 in Movies-TV) 4096 returning atomics on 15 addresses cost it 20 us.
+__global__ void k_uc_fill(const int32_t* __restrict__ u_cate, int B, int32_t* cur_uc, int32_t* uc_list) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) uc_list[atomicAdd(&cur_uc[u_cate[b]], 1)] = b;
+}
+
 struct PackArgs {
   tlsan_packed set;
   const int32_t* order;  // sample permutation of the epoch (train.py:191 shuffles the list)
@@ -556,9 +564,17 @@ struct ApplyArgs {
   const int32_t* off_item; const int32_t* off_user; const int32_t* off_uc;   // n+1 entries each
   const int4* urec_item; const int4* urec_user;   // lazy L2: (row, first position, uses) of the rows used this step
   const int32_t* cate_off; const int32_t* cate_cnt; const int32_t* cate_items;  // static CSR
+  const int32_t* uc_list;  // optional: samples of every category (segments off_uc); then Gc is in sample order
   const float* gd;
   float* Rc; float* Ri; float* Rb; float* Ru;   // PRESUM -> k_update_lazy: summed rows [C][dc], [slot][di], [slot], [slot][WU]
   int32_t presum_rows;     // PRESUM: write the item / user sums to the rows of `go` instead (tlsan_grads with reg = 0)
+  // PRESUM with few, large categories (Movies-TV: 15): csplit > 1 workgroups share a category (each takes
+  // every csplit-th pass of cpass items and its share of the u_cate uses) and add their exact partial
+  // sums into Rc64 with double atomics --
+  // sums of 2^-40-grid values are exact in any order, so the result stays bitwise reproducible;
+  // k_update_lazy rounds them to float (as a single workgroup would have) and clears them
+  int32_t csplit, cpass;
+  double* Rc64;            // [C][dc], zero at rest (state)
   double* part_out;        // UPDATE: change of the stored tables' sum of squares per workgroup;
                            // SUMSQ: sum of squares; ROWNORM: sum g^2
   StateHdr* hdr;           // P, P_prev, coef (read); spart_n (written by an update)
@@ -742,7 +758,10 @@ __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx
                                                  int* sh_pos, int* sh_lo, int* sh_n, int* sh_wtot) {
   constexpr bool RESET = MODE == AP_UPDATE || MODE == AP_GRADS || MODE == AP_PRESUM;  // counters are zero at rest
   const int tid = x.tid, wave = x.wave, lane = x.lane, grp = x.grp, l16 = x.l16, gid = x.gid;
-  const int c = x.blk;
+  int c = x.blk, split = 0, nsplit = 1;
+  if constexpr (MODE == AP_PRESUM) {
+    if (a.csplit > 1) { nsplit = a.csplit; c = x.blk % a.C; split = x.blk / a.C; }
+  }
   const int W4 = a.dc / 4;
   const size_t wrow = (size_t)c * a.dc;  // element index of the row in cate_emb
   f32x4 w[NCH];
@@ -757,11 +776,20 @@ __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx
   int nu = 0;
   if constexpr (MODE != AP_SUMSQ) {
     const int i0 = a.cate_off[c], ni = a.cate_cnt[c];
-    const int ou = a.off_uc[c];
-    nu = a.off_uc[c + 1] - ou;
-    for (int p0 = 0; p0 == 0 || p0 < ni; p0 += 256) {
+    int ou = a.off_uc[c];
+    const int nu_all = a.off_uc[c + 1] - ou;
+    nu = nu_all;
+    int PS = 256;  // items per pass
+    if (nsplit > 1) {  // this workgroup's share of the u_cate uses and its pass size
+      PS = a.cpass;
+      const int chunk = (nu_all + nsplit - 1) / nsplit;
+      ou += split * chunk;
+      nu = max(0, min(chunk, nu_all - split * chunk));
+    }
+    bool first = true;
+    for (int p0 = split * PS; first || p0 < ni; p0 += nsplit * PS, first = false) {
       int lo = 0, n = 0;
-      if (p0 + tid < ni) {
+      if (tid < PS && p0 + tid < ni) {
         const int item = a.cate_items[i0 + p0 + tid];
         lo = a.off_item[item];
         n = a.off_item[item + 1] - lo;
@@ -778,11 +806,11 @@ __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx
 #pragma unroll
       for (int w_ = 0; w_ < 4; ++w_) pre += (w_ < wave) ? sh_wtot[w_] : 0;
       const int T = (sh_wtot[0] + sh_wtot[1]) + (sh_wtot[2] + sh_wtot[3]);
-      const bool last = p0 + 256 >= ni;
+      const bool last = p0 + nsplit * PS >= ni;  // this workgroup's last pass
       const int extra = last ? nu : 0;  // the u_cate uses ride along with the last pass
       if (T + extra <= AP_CAP) {
         for (int j = 0; j < n; ++j) sh_pos[pre + j] = lo + j;
-        for (int j = tid; j < extra; j += 256) sh_pos[T + j] = ~(ou + j);
+        for (int j = tid; j < extra; j += 256) sh_pos[T + j] = ~(a.uc_list ? a.uc_list[ou + j] : ou + j);
         __syncthreads();
         AP_STAMP(1);
         list_accum<NCH>(a, sh_pos, T + extra, gid, l16, W4, acc);
@@ -791,12 +819,27 @@ __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx
         sh_lo[tid] = lo;
         sh_n[tid] = n;
         __syncthreads();
-        const int cnt = min(256, ni - p0);
+        const int cnt = max(0, min(PS, ni - p0));
         for (int t = 0; t < cnt; ++t) {
           const int nt = sh_n[t], lt = sh_lo[t];
           if (nt > 0) seg_accum<NCH>(a.Gi + a.di, a.D, lt + gid, lt + nt, 16, W4, l16, acc);
         }
-        if (last) seg_accum<NCH>(a.Gc, a.dc, ou + gid, ou + nu, 16, W4, l16, acc);
+        if (last) {
+          if (a.uc_list == nullptr) {
+            seg_accum<NCH>(a.Gc, a.dc, ou + gid, ou + nu, 16, W4, l16, acc);
+          } else {  // (rows in sample order: through the category's sample list)
+            for (int k = ou + gid; k < ou + nu; k += 16) {
+              const float* src = a.Gc + (size_t)a.uc_list[k] * a.dc;
+#pragma unroll
+              for (int ch = 0; ch < NCH; ++ch)
+                if (l16 + 16 * ch < W4) {
+                  const f32x4 v = *(const f32x4*)(src + 4 * (l16 + 16 * ch));
+#pragma unroll
+                  for (int i = 0; i < 4; ++i) acc[ch][i] += exact_term(v[i]);
+                }
+            }
+          }
+        }
       }
       __syncthreads();  // sh_pos / sh_wtot are rewritten by the next pass
     }
@@ -826,14 +869,20 @@ __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx
       for (int ch = 0; ch < NCH; ++ch) {
         const int c4 = l16 + 16 * ch;
         if (c4 < W4) {
-          f32x4 g;
+          if (nsplit > 1) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) g[i] = (float)acc[ch][i];
-          *(f32x4*)(a.Rc + wrow + 4 * c4) = g;
+            for (int i = 0; i < 4; ++i)
+              if (acc[ch][i] != 0.0) unsafeAtomicAdd(a.Rc64 + wrow + 4 * c4 + i, acc[ch][i]);  // (hardware f64 add, no CAS loop)
+          } else {
+            f32x4 g;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g[i] = (float)acc[ch][i];
+            *(f32x4*)(a.Rc + wrow + 4 * c4) = g;
+          }
         }
       }
     }
-    if (tid == 0 && nu > 0) a.cnt_uc[c] = 0;
+    if (tid == 0 && split == 0 && nu > 0) a.cnt_uc[c] = 0;
     return;
   }
   if (wave == 0 && grp == 0) {
@@ -1248,7 +1297,13 @@ __global__ __launch_bounds__(256) void k_update_lazy(ApplyArgs a, int nbC16) {
       for (int ch = 0; ch < NC; ++ch)
         if (4 * (l16 + 16 * ch) < a.dc) {
           w[ch] = tbl_ld4<DT>(a.p.cate_emb, wrow + 4 * (l16 + 16 * ch));
-          g[ch] = *(const f32x4*)(a.Rc + wrow + 4 * (l16 + 16 * ch));
+          if (a.csplit > 1) {
+            double* r64 = a.Rc64 + wrow + 4 * (l16 + 16 * ch);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { g[ch][i] = (float)r64[i]; r64[i] = 0.0; }
+          } else {
+            g[ch] = *(const f32x4*)(a.Rc + wrow + 4 * (l16 + 16 * ch));
+          }
         }
 #pragma unroll
       for (int ch = 0; ch < NC; ++ch)
