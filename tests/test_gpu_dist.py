@@ -28,8 +28,8 @@ def _tuple(b):
     return (b["u"], b["i"], b["y"], b["hist_i"], b["hist_i_new"], b["hist_t"], b["sl"], b["sl_new"], b["u_cate"])
 
 
-def _case(d=128, clip=5.0):
-    cfg = make_config(U=61, I=83, C=9, d=d, regulation_rate=1e-3, max_gradient_norm=clip)
+def _case(d=128, clip=5.0, C=9):
+    cfg = make_config(U=61, I=83, C=C, d=d, regulation_rate=1e-3, max_gradient_norm=clip)
     p = {k: np.asarray(v, np.float32).astype(np.float64) for k, v in random_params(cfg, seed=17).items()}
     _, cat = random_batch(cfg, B=4, Sn=2, seed=0)
     return cfg, p, cat
@@ -55,16 +55,18 @@ def _concat(per):
     return out
 
 
-def _worker(rank, world, port, ret, d, prefetch, ckpt, uneven=False):
+def _worker(rank, world, port, ret, d, prefetch, ckpt, uneven=False, hotcat=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from tlsan_amd.dist import ShardedModel
         clip = 0.05 if uneven else 5.0          # (uneven shares: with the clip active, so that the weighted squares matter)
-        cfg, p, cat = _case(d, clip)
+        # (hotcat: 2 categories and 150 samples per rank -> >1000 uses per category: the row-sum pass of
+        #  tlsan_grads splits every category over several workgroups)
+        cfg, p, cat = _case(d, clip, C=2 if hotcat else 9)
         m = ShardedModel(cfg, cat, device="cuda:0")
         m.set_params({k: np.asarray(v, np.float32) for k, v in p.items()})
-        steps = _split_batches(cfg, world, 4, B=24, uneven=uneven)
+        steps = _split_batches(cfg, world, 4, B=150 if hotcat else 24, uneven=uneven)
         wgt = lambda per: len(per[rank]["u"]) * world / sum(len(q_["u"]) for q_ in per)
         losses = []
         if prefetch:   # every step is told its successor: routing plan + indices are built a step ahead
@@ -133,13 +135,16 @@ def _worker(rank, world, port, ret, d, prefetch, ckpt, uneven=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,d,prefetch,uneven", [(1, 128, False, False), (2, 128, False, False), (2, 64, False, False),
-                                                     (1, 128, True, False), (2, 128, True, False), (2, 128, True, True)])
-def test_sharded_model_matches_oracle(world, d, prefetch, uneven, tmp_path):
-    """(uneven: the ranks hold 24 and 17 samples of each global batch and enter with their shares)"""
+@pytest.mark.parametrize("world,d,prefetch,uneven,hotcat", [(1, 128, False, False, False), (2, 128, False, False, False),
+                                                            (2, 64, False, False, False), (1, 128, True, False, False),
+                                                            (2, 128, True, False, False), (2, 128, True, True, False),
+                                                            (2, 128, True, False, True)])
+def test_sharded_model_matches_oracle(world, d, prefetch, uneven, hotcat, tmp_path):
+    """(uneven: the ranks hold 24 and 17 samples of each global batch and enter with their shares;
+    hotcat: two categories with > 1000 uses each)"""
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), ret, d, prefetch, str(tmp_path), uneven), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), ret, d, prefetch, str(tmp_path), uneven, hotcat), nprocs=world, join=True)
     assert all(v == "ok" for v in dict(ret).values()) and len(ret) == world, dict(ret)
 
 

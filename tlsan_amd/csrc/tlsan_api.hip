@@ -289,6 +289,18 @@ static void lazy_blocks(ApplyArgs& A, int B, int Sn) {  // at most min(rows, use
 
 static bool apply_wide(const ApplyArgs& A) { return A.di > 64 || A.dc > 64 || A.WU > 128; }  // more float4 chunks per lane
 
+// few, large categories: several workgroups per category in the row-sum pass, about 128 uses each
+// (estimated from the batch shape; up to 64 per category), every one with its share of the items
+static void category_split(ApplyArgs& A, const tlsan_dims* d, const tlsan_batch* b) {
+  const long uses = ((long)b->B * (d->Ls + b->Sn + 2) + d->cate_count - 1) / d->cate_count;
+  const int per = (d->item_count + d->cate_count - 1) / d->cate_count;
+  if (uses > 512) {
+    A.csplit = (int)(uses / 128 < 64 ? uses / 128 : 64);
+    const int ps = (per + A.csplit - 1) / A.csplit;
+    A.cpass = ps < 1 ? 1 : (ps > 256 ? 256 : ps);
+  }
+}
+
 // second half of the split lazy update (the first half rides with the dense finalize, run_backward)
 static int launch_update_lazy(ApplyArgs A, int B, int Sn, hipStream_t hs) {
   lazy_blocks(A, B, Sn);
@@ -764,15 +776,7 @@ int tlsan_train_step_opt(const tlsan_dims* d, const tlsan_params* p, const tlsan
   }
   static const int split = [] { const char* v = getenv("TLSAN_APPLY_SPLIT"); return v ? atoi(v) : 1; }();
   if (hp->l2_mode == TLSAN_L2_LAZY && split) {
-    // few, large categories: several workgroups per category in the row-sum pass, about 128 uses each
-    // (estimated from the batch shape; up to 64 per category), every one with its share of the items
-    const long uses = ((long)b->B * (d->Ls + b->Sn + 2) + d->cate_count - 1) / d->cate_count;
-    const int per = (d->item_count + d->cate_count - 1) / d->cate_count;
-    if (uses > 512) {
-      A.csplit = (int)(uses / 128 < 64 ? uses / 128 : 64);
-      int ps = (per + A.csplit - 1) / A.csplit;
-      A.cpass = ps < 1 ? 1 : (ps > 256 ? 256 : ps);
-    }
+    category_split(A, d, b);
     if ((rc = run_backward(d, s, p, b, hp, true, out, w, st, L, hs, &A))) return rc;
     if ((rc = launch_update_lazy(A, b->B, b->Sn, hs))) return rc;
   } else {
@@ -808,7 +812,13 @@ int tlsan_grads(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch* b
     // finalize as in the lazy train step, written straight to the output rows -- no apply launch
     A.presum_rows = 1;
     A.Rc = g->cate_emb;
+    category_split(A, d, b);
     if ((rc = run_backward(d, s, p, b, hp, false, out, w, st, L, hs, &A, g->dense))) return rc;
+    if (A.csplit > 1) {  // the split workgroups left exact double sums: round them into the output
+      const int n = d->cate_count * d->d_cate;
+      hipLaunchKernelGGL(k_rc64_to_float, dim3((n + 255) / 256), dim3(256), 0, hs, st.Rc64, g->cate_emb, n);
+      CHECK_LAUNCH("k_rc64_to_float");
+    }
     prof_mark(5, hs);
     prof_step_done();
     return TLSAN_OK;

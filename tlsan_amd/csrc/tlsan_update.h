@@ -1275,6 +1275,15 @@ __global__ __launch_bounds__(256) void k_finalize_presum(FinArgs f, int nbK, int
   if (stp && x.tid == 0) { stp[6] = __builtin_amdgcn_s_memtime(); stp[5] = __builtin_amdgcn_s_memrealtime(); }
 }
 
+// split category sums (Rc64, exact doubles) -> float output, and back to zero at rest (tlsan_grads)
+__global__ void k_rc64_to_float(double* __restrict__ r64, float* __restrict__ out, int n) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) {
+    out[t] = (float)r64[t];
+    r64[t] = 0.0;
+  }
+}
+
 // grid: nbC16 = ceil(C / 16) blocks of category rows, nbI / nbU blocks of used item / user rows
 // (one row per 16-lane group), nbD blocks of 256 dense parameters
 template <bool WIDE, int DT>
