@@ -133,7 +133,12 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
   w->bytes = o;
 }
 
-#define UC_LIST_CAP (1 << 18)  // batches up to this many samples keep a per-category sample list in the state
+#define UC_LIST_CAP (1 << 18)  // batches up to this many samples may keep a per-category sample list in the state
+// ... and do when a category sees many of the batch's samples (cursor atomics on few addresses inside the
+// fused kernel cost more than the extra launch on the index stream): more than 32 samples per category
+static inline bool uc_by_list(const tlsan_dims* d, const tlsan_batch* b) {
+  return b && b->B <= UC_LIST_CAP && (long)b->B > 32L * d->cate_count;
+}
 struct St {  // persistent state
   // two index slots (a batch's destination index depends only on its ids, so it lives with the
   // state, not in the per-call workspace whose layout follows the batch shape):
@@ -267,7 +272,7 @@ static void fill_apply(ApplyArgs& A, const tlsan_dims* d, const Shape& s, const 
   A.off_item = st.off_item[k]; A.off_uc = st.off_uc[k]; A.off_user = st.off_user[k];
   A.n_uniq_item = st.hdr ? &st.hdr->n_uniq[k][0] : nullptr; A.n_uniq_user = st.hdr ? &st.hdr->n_uniq[k][1] : nullptr;
   A.cate_off = st.cate_off; A.cate_cnt = st.cate_cnt; A.cate_items = st.cate_items;
-  A.uc_list = (b && b->B <= UC_LIST_CAP) ? st.uc_list[k] : nullptr;
+  A.uc_list = uc_by_list(d, b) ? st.uc_list[k] : nullptr;
   A.Rc64 = st.Rc64;
   A.csplit = 1; A.cpass = 256;
   A.gd = w.gd;
@@ -576,7 +581,7 @@ static int build_index(const tlsan_dims* d, const tlsan_batch* b, const St& st, 
   sa.total[0] = sa.total[1] = sa.total[2] = 1;
   sa.n_uniq[0] = &st.hdr->n_uniq[k][0]; sa.n_uniq[1] = nullptr; sa.n_uniq[2] = &st.hdr->n_uniq[k][1];
   if ((rc = launch_scan(sa, nscan, st.scan_bsum, hs))) return rc;
-  if (b->B <= UC_LIST_CAP) {
+  if (uc_by_list(d, b)) {
     hipLaunchKernelGGL(k_uc_fill, dim3((b->B + 255) / 256), dim3(256), 0, hs, b->u_cate, b->B, st.cur_uc[k], st.uc_list[k]);
     CHECK_LAUNCH("k_uc_fill");
   }
@@ -599,7 +604,7 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   a.logits_i = (out && out->logits) ? out->logits : w.logits;
   a.Gi = w.Gi; a.Gb = w.Gb; a.Gu = w.Gu; a.Gc = w.Gc; a.WU = w.WU;
   a.cur_item = st.cur_item[k]; a.cur_user = st.cur_user[k]; a.cur_uc = st.cur_uc[k];
-  a.uc_by_sample = b->B <= UC_LIST_CAP ? 1 : 0;
+  a.uc_by_sample = uc_by_list(d, b) ? 1 : 0;
   a.gLong = w.gLong; a.gDB = w.gDB; a.partials = w.partials;
   if (hp->dropout != 0.0f) {
     if (!(hp->dropout > 0.0f && hp->dropout < 1.0f)) return fail(TLSAN_E_BADARG, "dropout must be in [0, 1)");
@@ -652,7 +657,10 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
     const bool wide = apply_wide(A);
 #define FP_LAUNCH(DD, HH)                                                                                         \
   do {                                                                                                            \
-    if (wide) hipLaunchKernelGGL((k_finalize_presum<DD, HH, true>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);   \
+    if (A.csplit > 1) {                                                                                           \
+      if (wide) hipLaunchKernelGGL((k_finalize_presum<DD, HH, true, true>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);  \
+      else hipLaunchKernelGGL((k_finalize_presum<DD, HH, false, true>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);      \
+    } else if (wide) hipLaunchKernelGGL((k_finalize_presum<DD, HH, true>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);   \
     else hipLaunchKernelGGL((k_finalize_presum<DD, HH, false>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);       \
   } while (0)
     if (s.D == 64) FP_LAUNCH(64, 8);

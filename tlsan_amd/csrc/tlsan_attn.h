@@ -485,7 +485,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       if constexpr (TRAIN) {
         posv[LS] = (lead && vs) ? atomicAdd(&a.cur_item[it_i], 1) : 0;
         posv[LS + 1] = (lead && vs) ? atomicAdd(&a.cur_user[uid], 1) : 0;
-        posv[LS + 2] = (lead && vs) ? (a.uc_by_sample ? bidx : atomicAdd(&a.cur_uc[a.b.u_cate[bb]], 1)) : 0;
+        // (a per-lane copy of the flag: a scalar branch here would split the batch of returning atomics)
+        posv[LS + 2] = (lead && vs && (a.uc_by_sample + opaque_zero(lane)) == 0) ? atomicAdd(&a.cur_uc[a.b.u_cate[bb]], 1) : bidx;
       }
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb) {
@@ -561,7 +562,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         for (int p = 0; p < LS; ++p) posv[p] = (lead && p < n_l) ? atomicAdd(&a.cur_item[its[p]], 1) : 0;
         posv[LS] = (lead && vs) ? atomicAdd(&a.cur_item[it_i], 1) : 0;
         posv[LS + 1] = (lead && vs) ? atomicAdd(&a.cur_user[uid], 1) : 0;
-        posv[LS + 2] = (lead && vs) ? (a.uc_by_sample ? bidx : atomicAdd(&a.cur_uc[a.b.u_cate[bb]], 1)) : 0;
+        // (a per-lane copy of the flag: a scalar branch here would split the batch of returning atomics)
+        posv[LS + 2] = (lead && vs && (a.uc_by_sample + opaque_zero(lane)) == 0) ? atomicAdd(&a.cur_uc[a.b.u_cate[bb]], 1) : bidx;
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

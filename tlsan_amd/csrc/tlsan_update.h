@@ -753,14 +753,14 @@ struct ApCtx {
   } while (0)
 
 // ================= one category row per workgroup =================
-template <int MODE, bool LAZY, int NCH, int DT>
+template <int MODE, bool LAZY, int NCH, int DT, bool CSPLIT = false>
 __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx& x, double* shd, double* shp,
                                                  int* sh_pos, int* sh_lo, int* sh_n, int* sh_wtot) {
   constexpr bool RESET = MODE == AP_UPDATE || MODE == AP_GRADS || MODE == AP_PRESUM;  // counters are zero at rest
   const int tid = x.tid, wave = x.wave, lane = x.lane, grp = x.grp, l16 = x.l16, gid = x.gid;
   int c = x.blk, split = 0, nsplit = 1;
-  if constexpr (MODE == AP_PRESUM) {
-    if (a.csplit > 1) { nsplit = a.csplit; c = x.blk % a.C; split = x.blk / a.C; }
+  if constexpr (MODE == AP_PRESUM && CSPLIT) {  // (a compile-time variant: the common single-workgroup case pays nothing)
+    nsplit = a.csplit; c = x.blk % a.C; split = x.blk / a.C;
   }
   const int W4 = a.dc / 4;
   const size_t wrow = (size_t)c * a.dc;  // element index of the row in cate_emb
@@ -780,7 +780,7 @@ __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx
     const int nu_all = a.off_uc[c + 1] - ou;
     nu = nu_all;
     int PS = 256;  // items per pass
-    if (nsplit > 1) {  // this workgroup's share of the u_cate uses and its pass size
+    if constexpr (CSPLIT) {  // this workgroup's share of the u_cate uses and its pass size
       PS = a.cpass;
       const int chunk = (nu_all + nsplit - 1) / nsplit;
       ou += split * chunk;
@@ -869,7 +869,7 @@ __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx
       for (int ch = 0; ch < NCH; ++ch) {
         const int c4 = l16 + 16 * ch;
         if (c4 < W4) {
-          if (nsplit > 1) {
+          if constexpr (CSPLIT) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
               if (acc[ch][i] != 0.0) unsafeAtomicAdd(a.Rc64 + wrow + 4 * c4 + i, acc[ch][i]);  // (hardware f64 add, no CAS loop)
@@ -1243,7 +1243,7 @@ __global__ __launch_bounds__(256) void k_apply(ApplyArgs a) {
 //                       PRESUM mode (exact per-row sums -> Rc / Ri / Rb / Ru, counters reset)
 //   k_update_lazy     : elementwise w -= scale * sum for the used rows + the dense parameters
 // Same arithmetic per element as k_apply<AP_UPDATE, lazy> (the sums are rounded to float there too).
-template <int D, int DH, bool WIDE>
+template <int D, int DH, bool WIDE, bool CSPLIT = false>
 __global__ __launch_bounds__(256) void k_finalize_presum(FinArgs f, int nbK, int nbS, ApplyArgs a) {
   constexpr int NC = WIDE ? 2 : 1, NI = WIDE ? 2 : 1, NU = WIDE ? 4 : 2;
   __shared__ double shd[4 * 16 * NC * 4 > 256 ? 4 * 16 * NC * 4 : 256];
@@ -1269,7 +1269,7 @@ __global__ __launch_bounds__(256) void k_finalize_presum(FinArgs f, int nbK, int
   unsigned long long* stp = a.stamps ? a.stamps + (size_t)x.blk * 8 : nullptr;
   if (stp && x.tid == 0) { stp[0] = __builtin_amdgcn_s_memtime(); stp[4] = __builtin_amdgcn_s_memrealtime(); }
   const int blk = x.blk;
-  if (blk < a.nbC) apply_cate_block<AP_PRESUM, true, NC, TLSAN_TABLE_F32>(a, x, shd, shp, sh_pos, sh_lo, sh_n, sh_wtot);
+  if (blk < a.nbC) apply_cate_block<AP_PRESUM, true, NC, TLSAN_TABLE_F32, CSPLIT>(a, x, shd, shp, sh_pos, sh_lo, sh_n, sh_wtot);
   else if (blk < a.nbC + a.nbI) apply_rows_block<AP_PRESUM, true, true, NI, AP_OWN, TLSAN_TABLE_F32>(a, x, (blk - a.nbC) * AP_ROWS_PB, shp);
   else apply_rows_block<AP_PRESUM, true, false, NU, AP_OWN / 2, TLSAN_TABLE_F32>(a, x, (blk - a.nbC - a.nbI) * AP_ROWS_PB, shp);
   if (stp && x.tid == 0) { stp[6] = __builtin_amdgcn_s_memtime(); stp[5] = __builtin_amdgcn_s_memrealtime(); }
