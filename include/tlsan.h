@@ -307,7 +307,10 @@ int tlsan_rows_apply(float* W, int32_t ld, int32_t nrows, int32_t width, int32_t
  *   keys [n_keys] (duplicates fine) -> rank[G*R] compact index of every key, uniq[<=n_keys]
  *   distinct keys ascending, n_uniq[1], cate_c[n_uniq] = cate_by_key[uniq], comp[n_keys] = rank[keys],
  *   sendbuf [G][1 + cap] = per owner {count, row numbers inside the owner's shard ...}: the payload of
- *   ONE equal-split all-to-all (cap >= min(R, n_keys)).  cate_c entries [n_uniq, cate_pad) are set
+ *   ONE equal-split all-to-all.  cap must be the same on every rank (the exchange is equal-split);
+ *   when it is smaller than min(R, n_keys), what this batch may need, no rows are written and every
+ *   count is -min(R, n_keys): all ranks then see the same negative counts after the exchange, agree on a
+ *   larger cap and repeat the plan.  cate_c entries [n_uniq, cate_pad) are set
  *   to -1 (a compact table padded to a fixed row count).  flags[G*R] is scratch that must be zero
  *   on entry and is zero again on exit.  counts_out (optional, [G]): the per-owner counts once more,
  *   written by the kernel -- pass device-visible pinned host memory to have the exchange sizes on

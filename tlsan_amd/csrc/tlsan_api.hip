@@ -976,7 +976,8 @@ int tlsan_route_plan(const int32_t* keys, int32_t n_keys, int32_t R, int32_t G, 
   if (!keys || !cate_by_key || !flags || !rank || !uniq || !n_uniq || !sendbuf || !cate_c || !comp)
     return fail(TLSAN_E_BADARG, "tlsan_route_plan: NULL pointer");
   if (n_keys < 1 || R < 1 || G < 1 || (long long)R * G >= (1LL << 31)) return fail(TLSAN_E_BADARG, "tlsan_route_plan: bad sizes");
-  if (cap < (R < n_keys ? R : n_keys)) return fail(TLSAN_E_BADARG, "tlsan_route_plan: cap must be >= min(R, n_keys)");
+  if (cap < 0) return fail(TLSAN_E_BADARG, "tlsan_route_plan: cap < 0");
+  const int need = R < n_keys ? R : n_keys;   // rows one owner can be asked for
   hipStream_t hs = (hipStream_t)stream;
   const int nkeys = R * G;
   if (cate_pad < 0) return fail(TLSAN_E_BADARG, "tlsan_route_plan: cate_pad < 0");
@@ -985,6 +986,7 @@ int tlsan_route_plan(const int32_t* keys, int32_t n_keys, int32_t R, int32_t G, 
   a.keys = keys; a.n_keys = n_keys; a.R = R; a.G = G; a.prefix = rank; a.uniq = uniq; a.n_uniq = n_uniq;
   a.cate_by_key = cate_by_key; a.flags = flags; a.sendbuf = sendbuf; a.cap = cap;
   a.cate_c = cate_c; a.cate_pad = cate_pad; a.comp = comp; a.counts_out = counts_out;
+  a.overflow_need = cap < need ? need : 0;
   int nt = n_keys > G ? n_keys : G;
   if (cate_pad > nt) nt = cate_pad;
   hipLaunchKernelGGL(k_route_mark, dim3((n_keys + 255) / 256), dim3(256), 0, hs, a);

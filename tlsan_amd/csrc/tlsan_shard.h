@@ -20,6 +20,7 @@ struct RouteArgs {
   int32_t cate_pad;
   int32_t* comp;            // [n_keys] compact row of every id of the batch
   int32_t* counts_out;      // optional [G]: the per-owner counts once more, e.g. straight into pinned host memory
+  int32_t overflow_need;    // > 0: cap is too small for this batch -- every header becomes -overflow_need, no rows
 };
 
 __global__ void k_route_mark(RouteArgs a) {
@@ -33,14 +34,15 @@ __global__ void k_route_finish(RouteArgs a) {
   if (t < a.n_keys) a.comp[t] = a.prefix[a.keys[t]];
   if (t < nu) {
     const int k = a.uniq[t], g = k / a.R;
-    a.sendbuf[(size_t)g * (1 + a.cap) + 1 + (t - a.prefix[(size_t)g * a.R])] = k - g * a.R;
+    if (a.overflow_need == 0) a.sendbuf[(size_t)g * (1 + a.cap) + 1 + (t - a.prefix[(size_t)g * a.R])] = k - g * a.R;
     a.cate_c[t] = a.cate_by_key[k];
     a.flags[k] = 0;  // the marks are zero at rest: no memset per step
   } else if (t < a.cate_pad) {
     a.cate_c[t] = -1;  // rows of the (padded) compact table that are not in use: in no category
   }
   if (t < a.G) {
-    const int c = (t + 1 < a.G ? a.prefix[(size_t)(t + 1) * a.R] : nu) - a.prefix[(size_t)t * a.R];
+    int c = (t + 1 < a.G ? a.prefix[(size_t)(t + 1) * a.R] : nu) - a.prefix[(size_t)t * a.R];
+    if (a.overflow_need > 0) c = -a.overflow_need;
     a.sendbuf[(size_t)t * (1 + a.cap)] = c;
     if (a.counts_out) a.counts_out[t] = c;
   }

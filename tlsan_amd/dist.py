@@ -307,6 +307,7 @@ class ShardedModel:
         self._ws = None
         self._flags = torch.zeros(self.router.nkeys, dtype=torch.int32, device=dev)   # zero at rest
         self._rows_pad = 4096     # compact-table rows are padded (grow-only): the kernels' state layout is stable
+        self._pcap = 65536        # shared per-owner capacity of the id exchange (see _slot)
         self._side = None
         self._sizes = {}      # (compact rows, categories, B, Sn) -> (state bytes, workspace bytes)
         self._ews = None
@@ -315,7 +316,7 @@ class ShardedModel:
         self._n_p = self._n_r = 0
         loc = np.arange(self.rank, I, self.world)
         self._icl_local = torch.as_tensor(np.concatenate([icl[loc], np.zeros(1, np.int32)])).to(dev)   # category of local item n
-        self._slots = [None, None]          # routing plans: current / prefetched
+        self._slots = [None, None, None]    # routing plans: current / prefetched / forward-only (evaluation)
         self._next_slot = 0
         self._slots_buf = torch.zeros(self.router.R * self.world, dtype=torch.int32, device=dev)  # zero at rest
         self._aws = torch.empty(int(self.lib.tlsan_shard_apply_workspace(self.router.R, Cc)), dtype=torch.uint8, device=dev)
@@ -362,11 +363,14 @@ class ShardedModel:
         """Per-slot routing buffers (two slots: the plan of the next batch is built while the
         current one is in use)."""
         sl = self._slots[k]
-        if sl is None or sl["cap"] < n_keys:
+        # rows one owner can be asked for by one rank: the id exchange is equal-split, so this capacity
+        # must be the SAME on every rank -- it is a value all ranks share (self._pcap: a constant at first,
+        # raised in lockstep by the overflow protocol of _plan_stage2), never this rank's batch size
+        pcap = min(self.router.R, self._pcap)
+        if sl is None or sl["cap"] < n_keys or sl["pcap"] != pcap:
             dev, G, nk = self.device, self.world, self.router.nkeys
-            cap = int(n_keys * 1.25) + 16
-            pcap = min(self.router.R, cap)   # distinct rows one owner can be asked for
-            sl = dict(cap=cap, pcap=pcap, rank=torch.empty(nk, dtype=torch.int32, device=dev),
+            cap = max(int(n_keys * 1.25) + 16, sl["cap"] if sl is not None else 0)
+            sl = dict(k=k, cap=cap, pcap=pcap, rank=torch.empty(nk, dtype=torch.int32, device=dev),
                       uniq=torch.empty(nk, dtype=torch.int32, device=dev),
                       n_uniq=torch.zeros(1, dtype=torch.int32, device=dev),
                       # per peer {count, local row numbers ...}: ONE equal-split all-to-all carries both
@@ -417,6 +421,14 @@ class ShardedModel:
         h = sl["host"]
         send = h[0].tolist()
         recv = h[1].tolist() if self.world > 1 else send
+        over = [-x for x in send + recv if x < 0]
+        if over:
+            # some rank's batch may ask one owner for more rows than the shared capacity holds: it sent
+            # -need in every header and no rows.  Every rank sees the same negative headers, so all of
+            # them raise the capacity to the same value and repeat the plan (rare: the capacity only grows)
+            self._pcap = int(max(over) * 1.25) + 16
+            sl["stage2"] = None
+            return self._plan_stage2(self._plan_stage1(sl["db"], sl["k"]))
         n, n_recv = int(sum(send)), int(sum(recv))
         recv_rows = torch.empty(max(n_recv, 1), dtype=torch.int32, device=self.device)
         off = [0]
@@ -427,13 +439,21 @@ class ShardedModel:
         return sl
 
     def _plan(self, db):
-        """The plan of `db`: prefetched (train_async(..., next_batch=)) or built now."""
+        """The plan of a TRAINING batch: prefetched (train_async(..., next_batch=)) or built now."""
         k = self._next_slot
         sl = self._slots[k]
         if sl is None or sl.get("db") is not db:
+            if sl is not None and sl.get("prepared"):
+                raise RuntimeError("train_async: the batch announced as next_batch must be the next one trained "
+                                   "(its destination index is already counted into the slot's state)")
             sl = self._plan_stage1(db, k)
         self._next_slot = 1 - k
         return self._plan_stage2(sl)
+
+    def _plan_eval(self, db):
+        """The plan of a forward-only batch, in a slot of its own: evaluation may run between a training
+        step and the successor it has announced (whose plan and indices are waiting in the other slots)."""
+        return self._plan_stage2(self._plan_stage1(db, 2))
 
     def _fetch(self, sl):
         """compact per-step table: row k = the owner's shard row of the k-th distinct key"""
@@ -616,7 +636,7 @@ class ShardedModel:
     # ------------------------------------------------------------------ evaluation
     def forward(self, batch, is_test=True, want_ranks=False):
         db = self.device_batch(batch, is_test)
-        sl = self._plan(db)
+        sl = self._plan_eval(db)
         table = self._fetch(sl)
         dims, cp, cb = self._compact(db, sl, table)
         li = torch.empty(db.B, dtype=torch.float32, device=self.device)
