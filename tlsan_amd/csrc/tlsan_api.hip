@@ -149,7 +149,7 @@ struct St {  // persistent state
   int32_t *cate_off, *cate_cnt, *cate_cur, *cate_items;   // static CSR category -> items
   StateHdr* hdr;
   double *S_part, *S_total;
-  long long* scan_bsum;                                   // per-chunk sums of the index scan (large tables)
+  long long* scan_bsum[2];                                // per-chunk sums of the index scan (large tables), per slot
   int32_t* uc_list[2];                                    // samples of every category (u_cate uses), UC_LIST_CAP each
   double* Rc64;                                           // category sums of a split PRESUM pass, zero at rest
   size_t bytes;
@@ -183,8 +183,9 @@ static void carve_state(const tlsan_dims* d, char* base, St* s) {
   s->S_part = (double*)take(8 * (size_t)(s->nbI + s->nbU + s->nbC));
   for (int k = 0; k < 2; ++k) s->uc_list[k] = (int32_t*)take(4 * (size_t)UC_LIST_CAP);
   s->Rc64 = (double*)take(8 * (size_t)d->cate_count * d->d_cate);
-  s->scan_bsum = (long long*)take(8 * ((size_t)(d->item_count + 4095) / 4096 + (d->cate_count + 4095) / 4096 +
-                                       (d->user_count + 4095) / 4096));
+  for (int k = 0; k < 2; ++k)
+    s->scan_bsum[k] = (long long*)take(8 * ((size_t)(d->item_count + 4095) / 4096 + (d->cate_count + 4095) / 4096 +
+                                            (d->user_count + 4095) / 4096));
   s->S_total = base ? &s->hdr->St : nullptr;
   s->bytes = o;
 }
@@ -580,7 +581,7 @@ static int build_index(const tlsan_dims* d, const tlsan_batch* b, const St& st, 
   sa.urec[0] = st.urec_item[k]; sa.urec[2] = st.urec_user[k];
   sa.total[0] = sa.total[1] = sa.total[2] = 1;
   sa.n_uniq[0] = &st.hdr->n_uniq[k][0]; sa.n_uniq[1] = nullptr; sa.n_uniq[2] = &st.hdr->n_uniq[k][1];
-  if ((rc = launch_scan(sa, nscan, st.scan_bsum, hs))) return rc;
+  if ((rc = launch_scan(sa, nscan, st.scan_bsum[k], hs))) return rc;
   if (uc_by_list(d, b)) {
     hipLaunchKernelGGL(k_uc_fill, dim3((b->B + 255) / 256), dim3(256), 0, hs, b->u_cate, b->B, st.cur_uc[k], st.uc_list[k]);
     CHECK_LAUNCH("k_uc_fill");

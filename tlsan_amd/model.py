@@ -525,7 +525,11 @@ class Model(object):
         go = L.GradsOut(g["item_emb"].data_ptr(), g["item_b"].data_ptr(), g["user_emb"].data_ptr(),
                         g["usert_emb"].data_ptr(), g["cate_emb"].data_ptr(), gd.data_ptr())
         out = L.StepOut(self._out.data_ptr(), self._out.data_ptr() + 4, logits.data_ptr(), self._out.data_ptr() + 8)
-        hp = self.hparams(lr)
+        # (an index slot at rest: the other one may hold the index prefetched for an announced next batch)
+        slot = self._idx_slot if self._idx_ready[self._idx_slot] is None else 1 - self._idx_slot
+        if self._idx_ready[slot] is not None:
+            raise RuntimeError("grads: both index slots are in use")
+        hp = self.hparams(lr, slot, 0)
         L.check(self.lib.tlsan_grads(C.byref(self.dims), C.byref(self.cparams), C.byref(db.c), C.byref(hp),
                                      C.byref(go), C.byref(out), self.state.data_ptr(), ws.data_ptr(), ws.numel(),
                                      self._stream()), "tlsan_grads")
