@@ -771,3 +771,25 @@ def test_one_hot_row_takes_every_use(l2_mode):
         du = np.asarray(outs[0][k], np.float64).reshape(p[k].shape) - p[k]
         dr = newp[k] - p[k]
         assert np.abs(du - dr).max() < 3e-4 * (np.abs(dr).max() + 1e-9) + 3e-7, k
+
+
+@pytest.mark.parametrize("extra", [["--optimizer", "adam", "--learning_rate", "0.01"],
+                                   ["--dropout", "0.2"],
+                                   ["--l2_mode", "lazy", "--table_dtype", "bf16"]])
+def test_train_driver_variants(extra, tmp_path):
+    """The driver's other switches on the real Clothing tuples: 200 steps with adam, with dropout, and
+    with lazy L2 + bf16 tables run through, learn (loss falls) and leave a restorable checkpoint."""
+    import os
+    from tlsan_amd import train as T
+    from tlsan_amd.model import Model
+    ds = os.path.join(os.path.dirname(__file__), "golden", "packed_clothing.npz")
+    args = T.parse(["--dataset", ds, "--max_steps", "200", "--eval_freq", "100", "--quiet", "--eval_topk", "0",
+                    "--model_dir", str(tmp_path / "ck")] + extra)
+    res = T.train(args)
+    assert res["steps"] == 200 and np.isfinite(res["final_auc"]) and 0.8 < res["final_auc"] < 1.0
+    files = sorted(os.listdir(tmp_path / "ck"))
+    assert "TLSAN-200.npz" in files and "TLSAN-200.json" in files
+    z = np.load(tmp_path / "ck" / "TLSAN-200.npz")
+    assert int(z["global_step"]) == 200 and all(np.isfinite(z[k]).all() for k in ("item_emb", "user_emb", "dense_K"))
+    if "adam" in extra:
+        assert "slot1/item_emb" in z.files and "slot2/dense_K" in z.files
