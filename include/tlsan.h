@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TLSAN_ABI_VERSION 7
+#define TLSAN_ABI_VERSION 8
 
 enum {
   TLSAN_OK = 0,
@@ -130,6 +130,7 @@ typedef struct {
    * 0 = off (the reference's default).  Supported for Ls <= 10 and fp32 tables. */
   float dropout;
   uint32_t dropout_seed;
+  uint32_t dropout_sample0;   /* position of this batch's first sample in the pattern: a rank's offset into the global batch */
 } tlsan_hparams;
 
 /* Device-side results of a train step (all optional except loss). */
@@ -329,10 +330,28 @@ int tlsan_shard_gather(const float* shard, int32_t ld, int32_t R, int32_t W, con
 /* tlsan_shard_summary: after the all-reduce (sum over G ranks) of
  *   flat = [dense grads n_dense | cate grads n_cate | mean BCE | per-use row squares | table squares | pad]:
  * global norm (tf18 rule), clip coefficient (model.py:201), loss (model.py:164-172), the device
- * step size lr*coef, and the SGD update of the replicated dense parameters (+ K^T copy). */
+ * step size lr*coef (step_dev[0]; step_dev[1] = coef), and the SGD update of the replicated dense
+ * parameters (+ K^T copy). */
 int tlsan_shard_summary(const float* flat, int32_t n_dense, int32_t n_cate, int32_t G, float lr, float reg, float clip,
                         const double* S_cate, float* dense, float* dense_KT, const tlsan_dims* dims,
                         float* step_dev, float* loss_out, float* gnorm_out, void* stream);
+
+/* The other optimizers (tlsan_optimizer above: same kinds, defaults and arithmetic) on the sharded step:
+ * accumulators laid out like what they belong to -- the shard rows [R, ld], cate_emb [C, dc] and the
+ * dense parameters (the last two replicated: every rank applies the same update).  kind SGD / NULL =
+ * the plain functions.  item_b (column reg_item of an item row) is touched where a gradient arrived
+ * (sparse RMSProp / Adadelta) or everywhere (Adam), as on one GPU. */
+typedef struct {
+  int32_t kind, step;
+  float beta1, beta2, epsilon;
+  float* shard_s1; float* shard_s2;
+  float* cate_s1; float* cate_s2;
+  float* dense_s1; float* dense_s2;
+} tlsan_shard_optimizer;
+int tlsan_shard_summary_opt(const float* flat, int32_t n_dense, int32_t n_cate, int32_t G, float lr, float reg, float clip,
+                            const double* S_cate, float* dense, float* dense_KT, const tlsan_dims* dims,
+                            float* step_dev, float* loss_out, float* gnorm_out, const tlsan_shard_optimizer* opt,
+                            void* stream);
 
 /* tlsan_shard_apply: owner-side update of the fused shard table [R, W] (rows [0,cI) items with
  * reg_item regularised columns, rows [cI,R) users with reg_user) from the row gradients received
@@ -349,6 +368,12 @@ int tlsan_shard_apply(float* shard, int32_t ld, int32_t cI, int32_t R, int32_t W
                       int32_t G, int32_t* slots, float gscale, const float* step_dev, float reg,
                       float* cate_emb, int32_t C, int32_t dc, const float* g_cate,
                       double* sumsq_out, float* sumsq_f32, void* ws, size_t ws_bytes, void* stream);
+int tlsan_shard_apply_opt(float* shard, int32_t ld, int32_t cI, int32_t R, int32_t W, int32_t reg_item, int32_t reg_user,
+                          const float* vals, int32_t ldv, const int32_t* rows, int32_t n_recv, const int32_t* src_off,
+                          int32_t G, int32_t* slots, float gscale, const float* step_dev, float reg,
+                          float* cate_emb, int32_t C, int32_t dc, const float* g_cate,
+                          double* sumsq_out, float* sumsq_f32, const tlsan_shard_optimizer* opt, float lr,
+                          void* ws, size_t ws_bytes, void* stream);
 
 /* Exclusive prefix sum + compaction of a device int32 array (the id-routing step of the sharded
  * path): prefix[k] = sum(cnt[0..k)), uniq = ascending list of k with cnt[k] > 0 and

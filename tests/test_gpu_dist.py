@@ -28,8 +28,8 @@ def _tuple(b):
     return (b["u"], b["i"], b["y"], b["hist_i"], b["hist_i_new"], b["hist_t"], b["sl"], b["sl_new"], b["u_cate"])
 
 
-def _case(d=128, clip=5.0, C=9):
-    cfg = make_config(U=61, I=83, C=C, d=d, regulation_rate=1e-3, max_gradient_norm=clip)
+def _case(d=128, clip=5.0, C=9, **extra):
+    cfg = make_config(U=61, I=83, C=C, d=d, regulation_rate=1e-3, max_gradient_norm=clip, **extra)
     p = {k: np.asarray(v, np.float32).astype(np.float64) for k, v in random_params(cfg, seed=17).items()}
     _, cat = random_batch(cfg, B=4, Sn=2, seed=0)
     return cfg, p, cat
@@ -267,3 +267,52 @@ def test_sharded_train_driver_matches_single_gpu(tmp_path):
     ret = mgr.dict()
     mp.spawn(_driver_worker, args=(2, _free_port(), ret, str(tmp_path)), nprocs=2, join=True)
     assert all(v == "ok" for v in dict(ret).values()) and len(ret) == 2, dict(ret)
+
+
+def _opt_worker(rank, world, port, ret, optimizer, dropout):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tlsan_amd.dist import ShardedModel
+        clip, lr = 0.05, {"sgd": 0.8, "adam": 0.05, "rmsprop": 0.02, "adadelta": 1.0}[optimizer]
+        cfg, p, cat = _case(128, clip, optimizer=optimizer, dropout=dropout)
+        m = ShardedModel(cfg, cat, device="cuda:0")
+        m.set_params({k: np.asarray(v, np.float32) for k, v in p.items()})
+        steps = _split_batches(cfg, world, 4, B=24)
+        q = dict(p)
+        st = orc.init_opt_state(p, optimizer) if optimizer != "sgd" else None
+        for per in steps:
+            seed = m.dropout_seed()
+            m.train_async(_tuple(per[rank]), lr, sample0=24 * rank)
+            loss = float(m.last_loss.item())
+            ref, q, info = orc.train_step(q, cat, _concat(per), 8, cfg["regulation_rate"], lr=lr, clip=clip,
+                                          optimizer=optimizer, opt_state=st,
+                                          dropout=(dropout, seed) if dropout > 0 else None)
+            assert info["coef"] < 1.0
+            assert abs(loss - ref) < 2e-4 * max(1.0, abs(ref)), (loss, ref)
+        got = m.gather_params()
+        if rank == 0:
+            for k in q:
+                if k.endswith("_b2") and optimizer == "adam":
+                    continue        # zero-gradient parameter: Adam turns rounding noise into +-lr (see the single-GPU test)
+                g = np.asarray(got[k], np.float64).reshape(q[k].shape)
+                du, dr = g - p[k], q[k] - p[k]
+                assert np.abs(du - dr).max() < 3e-3 * (np.abs(dr).max() + 1e-9) + 1e-6, (k, float(np.abs(du - dr).max()), float(np.abs(dr).max()))
+        ret[rank] = "ok"
+    except Exception:
+        import traceback
+        ret[rank] = "FAIL: " + traceback.format_exc()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,optimizer,dropout", [(2, "adam", 0.0), (2, "rmsprop", 0.0), (1, "adadelta", 0.0),
+                                                     (2, "sgd", 0.3), (2, "adam", 0.2)])
+def test_sharded_optimizers_and_dropout(world, optimizer, dropout):
+    """The other optimizers (accumulators sharded like the rows they belong to) and dropout (the pattern
+    indexed by the sample's position in the GLOBAL batch) on the sharded step, against the oracle on the
+    concatenated batch, clip active."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_opt_worker, args=(world, _free_port(), ret, optimizer, dropout), nprocs=world, join=True)
+    assert all(v == "ok" for v in dict(ret).values()) and len(ret) == world, dict(ret)

@@ -616,6 +616,7 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
     a.drop_thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
     a.drop_inv = 1.0f / keep;
     a.drop_seed = hp->dropout_seed;
+    a.drop_sample0 = hp->dropout_sample0;
   }
   const bool v2 = fwd_v2(s, true, d, a.p, b) && hp->dropout == 0.0f;
   const int grp = v2 ? 16 : s.NSB;  // samples per workgroup pass of the kernel that runs (= per partial record)
@@ -1019,9 +1020,31 @@ int tlsan_shard_gather(const float* shard, int32_t ld, int32_t R, int32_t W, con
   return TLSAN_OK;
 }
 
+static int shard_opt_ctx(const tlsan_shard_optimizer* o, float lr, OptCtx* oc) {
+  memset(oc, 0, sizeof(*oc));
+  if (!o || o->kind == TLSAN_OPT_SGD) return TLSAN_OK;
+  if (o->kind != TLSAN_OPT_ADAM && o->kind != TLSAN_OPT_RMSPROP && o->kind != TLSAN_OPT_ADADELTA)
+    return fail(TLSAN_E_BADARG, "tlsan_shard_optimizer: kind %d", o->kind);
+  if (!o->shard_s1 || !o->shard_s2 || !o->cate_s1 || !o->cate_s2 || !o->dense_s1 || !o->dense_s2)
+    return fail(TLSAN_E_BADARG, "tlsan_shard_optimizer: NULL accumulator");
+  if (o->kind == TLSAN_OPT_ADAM && o->step < 1) return fail(TLSAN_E_BADARG, "tlsan_shard_optimizer: Adam's step counts from 1");
+  oc->opt = o->kind; oc->lr = lr; oc->b1 = o->beta1; oc->b2 = o->beta2; oc->eps = o->epsilon;
+  if (o->kind == TLSAN_OPT_ADAM)
+    oc->alpha = (float)((double)lr * sqrt(1.0 - pow((double)o->beta2, o->step)) / (1.0 - pow((double)o->beta1, o->step)));
+  return TLSAN_OK;
+}
+
 int tlsan_shard_summary(const float* flat, int32_t n_dense, int32_t n_cate, int32_t G, float lr, float reg, float clip,
                         const double* S_cate, float* dense, float* dense_KT, const tlsan_dims* d,
                         float* step_dev, float* loss_out, float* gnorm_out, void* stream) {
+  return tlsan_shard_summary_opt(flat, n_dense, n_cate, G, lr, reg, clip, S_cate, dense, dense_KT, d, step_dev, loss_out,
+                                 gnorm_out, nullptr, stream);
+}
+
+int tlsan_shard_summary_opt(const float* flat, int32_t n_dense, int32_t n_cate, int32_t G, float lr, float reg, float clip,
+                            const double* S_cate, float* dense, float* dense_KT, const tlsan_dims* d,
+                            float* step_dev, float* loss_out, float* gnorm_out, const tlsan_shard_optimizer* opt,
+                            void* stream) {
   if (!flat || !S_cate || !dense || !dense_KT || !d || !step_dev || !loss_out || !gnorm_out || G < 1)
     return fail(TLSAN_E_BADARG, "tlsan_shard_summary: bad arguments");
   tlsan_dense_layout L;
@@ -1032,6 +1055,8 @@ int tlsan_shard_summary(const float* flat, int32_t n_dense, int32_t n_cate, int3
   a.flat = flat; a.n_dense = n_dense; a.n_cate = n_cate; a.G = G; a.lr = lr; a.reg = reg; a.clip = clip;
   a.S_cate = S_cate; a.dense = dense; a.dense_KT = dense_KT; a.D = d->d; a.K_off = L.K; a.k0_off = L.k0;
   a.step_dev = step_dev; a.loss_out = loss_out; a.gnorm_out = gnorm_out;
+  if ((rc = shard_opt_ctx(opt, lr, &a.oc))) return rc;
+  a.dense_s1 = opt ? opt->dense_s1 : nullptr; a.dense_s2 = opt ? opt->dense_s2 : nullptr;
   hipLaunchKernelGGL(k_shard_summary, dim3((n_dense + 1023) / 1024), dim3(1024), 0, (hipStream_t)stream, a);
   CHECK_LAUNCH("k_shard_summary");
   return TLSAN_OK;
@@ -1047,6 +1072,16 @@ int tlsan_shard_apply(float* shard, int32_t ld, int32_t cI, int32_t R, int32_t W
                       int32_t G, int32_t* slots, float gscale, const float* step_dev, float reg,
                       float* cate_emb, int32_t C, int32_t dc, const float* g_cate,
                       double* sumsq_out, float* sumsq_f32, void* ws, size_t ws_bytes, void* stream) {
+  return tlsan_shard_apply_opt(shard, ld, cI, R, W, reg_item, reg_user, vals, ldv, rows, n_recv, src_off, G, slots, gscale,
+                               step_dev, reg, cate_emb, C, dc, g_cate, sumsq_out, sumsq_f32, nullptr, 0.0f, ws, ws_bytes, stream);
+}
+
+int tlsan_shard_apply_opt(float* shard, int32_t ld, int32_t cI, int32_t R, int32_t W, int32_t reg_item, int32_t reg_user,
+                          const float* vals, int32_t ldv, const int32_t* rows, int32_t n_recv, const int32_t* src_off,
+                          int32_t G, int32_t* slots, float gscale, const float* step_dev, float reg,
+                          float* cate_emb, int32_t C, int32_t dc, const float* g_cate,
+                          double* sumsq_out, float* sumsq_f32, const tlsan_shard_optimizer* opt, float lr,
+                          void* ws, size_t ws_bytes, void* stream) {
   if (!shard || !slots || !step_dev || !cate_emb || !g_cate || !sumsq_out || !src_off || n_recv < 0 ||
       (n_recv > 0 && (!vals || !rows)))
     return fail(TLSAN_E_BADARG, "tlsan_shard_apply: bad pointer / size");
@@ -1063,6 +1098,14 @@ int tlsan_shard_apply(float* shard, int32_t ld, int32_t cI, int32_t R, int32_t W
   if (a.src_off[0] != 0 || a.src_off[G] != n_recv) return fail(TLSAN_E_BADARG, "tlsan_shard_apply: src_off must run from 0 to n_recv");
   a.slots = slots; a.gscale = gscale; a.step_dev = step_dev; a.reg = reg;
   a.cate_emb = cate_emb; a.C = C; a.dc = dc; a.g_cate = g_cate;
+  {
+    const int rc_ = shard_opt_ctx(opt, lr, &a.oc);
+    if (rc_) return rc_;
+  }
+  if (a.oc.opt != TLSAN_OPT_SGD) {
+    a.shard_s1 = opt->shard_s1; a.shard_s2 = opt->shard_s2; a.cate_s1 = opt->cate_s1; a.cate_s2 = opt->cate_s2;
+    a.bias_col = reg_item;   // fused item rows: [item_emb (reg_item columns) | item_b | pad]
+  }
   a.part_out = (double*)ws;
   a.nb_rows = (R + AP_ROWS_PB - 1) / AP_ROWS_PB;
   a.nb_cate = (C + AP_ROWS_PB - 1) / AP_ROWS_PB;

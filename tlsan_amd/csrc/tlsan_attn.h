@@ -436,7 +436,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     const int bidx = g * NSB + srow;
     const bool vs = bidx < B;
     DropCtx dc;
-    dc.seed = a.drop_seed; dc.thr = a.drop_thr; dc.inv = a.drop_inv; dc.sbase = 2u * (uint32_t)bidx;
+    dc.seed = a.drop_seed; dc.thr = a.drop_thr; dc.inv = a.drop_inv; dc.sbase = 2u * ((uint32_t)bidx + a.drop_sample0);
     const int bb = vs ? bidx : 0;
     const int uid = a.b.u[bb];
     const int it_i = a.b.i[bb];

@@ -268,6 +268,7 @@ struct FwdArgs {
   // dropout on the inputs of the attention maps (model.py:428-431), training with config['dropout'] > 0
   uint32_t drop_seed, drop_thr;   // kept iff hash < drop_thr (keep_prob * 2^32); drop_thr == 0: no dropout
   float drop_inv;                 // 1 / keep_prob
+  uint32_t drop_sample0;          // index of this batch's first sample in the pattern (a rank's share of a global batch)
 };
 
 // Keep / drop pattern of tf.nn.dropout as the scale the element is multiplied with (0 or 1/keep_prob):

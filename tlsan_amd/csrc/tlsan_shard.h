@@ -84,14 +84,16 @@ struct SummaryArgs {
   float lr, reg, clip;
   const double* S_cate;   // sum of squares of the (replicated) category table
   float* dense; float* dense_KT; int32_t D, K_off, k0_off;
-  float* step_dev; float* loss_out; float* gnorm_out;
+  float* step_dev; float* loss_out; float* gnorm_out;   // step_dev[0] = lr * coef, step_dev[1] = coef
+  OptCtx oc;                       // optimizers other than SGD (oc.opt != 0): accumulators of the dense parameters
+  float* dense_s1; float* dense_s2;
 };
 
 // Every workgroup recomputes the norm (n_dense L2-resident floats, same fixed tree -> same bits)
 // and then updates its own 1024-element slice: no second launch, no cross-workgroup hand-over.
 __global__ __launch_bounds__(1024) void k_shard_summary(SummaryArgs a) {
   __shared__ double sh[1024];
-  __shared__ float sh_step;
+  __shared__ float sh_step, sh_coef;
   const int tid = threadIdx.x;
   const float inv_g = 1.0f / (float)a.G;
   double s = 0.0;
@@ -119,8 +121,10 @@ __global__ __launch_bounds__(1024) void k_shard_summary(SummaryArgs a) {
     const float norm = (float)sqrt(sq);
     const float coef = a.clip / fmaxf(norm, a.clip);  // clip_by_global_norm (model.py:201)
     sh_step = coef * a.lr;
+    sh_coef = coef;
     if (blockIdx.x == 0) {
-      *a.step_dev = sh_step;
+      a.step_dev[0] = sh_step;
+      a.step_dev[1] = coef;
       *a.gnorm_out = norm;
       *a.loss_out = tail[0] * inv_g + a.reg * 0.5f * (float)S_tot;
     }
@@ -129,7 +133,14 @@ __global__ __launch_bounds__(1024) void k_shard_summary(SummaryArgs a) {
   const float step = sh_step;
   const int k = blockIdx.x * 1024 + tid;
   if (k < a.n_dense) {
-    const float w = a.dense[k] - step * (a.flat[k] * inv_g);
+    float w = a.dense[k];
+    if (a.oc.opt == TLSAN_OPT_SGD) {
+      w -= step * (a.flat[k] * inv_g);
+    } else {  // adam | rmsprop | adadelta on the clipped gradient (tlsan_optimizer)
+      float s1 = a.dense_s1[k], s2 = a.dense_s2[k];
+      opt_elem(a.oc, w, sh_coef * (a.flat[k] * inv_g), s1, s2);
+      a.dense_s1[k] = s1; a.dense_s2[k] = s2;
+    }
     a.dense[k] = w;
     if (k >= a.K_off && k < a.k0_off) {
       const int idx = k - a.K_off;
@@ -155,6 +166,10 @@ struct ShardApplyArgs {
   float gscale; const float* step_dev; float reg;
   float* cate_emb; int32_t C, dc; const float* g_cate;
   double* part_out; int32_t nb_rows, nb_cate;
+  // optimizers other than SGD: accumulators laid out like the shard rows / like cate_emb; step_dev[1] = coef
+  OptCtx oc;
+  float* shard_s1; float* shard_s2; float* cate_s1; float* cate_s2;
+  int32_t bias_col;   // column of item_b inside an item row: touched where gathered (sparse RMSProp / Adadelta)
 };
 
 __global__ void k_slot_mark(ShardApplyArgs a) {
@@ -229,12 +244,35 @@ __global__ __launch_bounds__(256) void k_shard_apply(ShardApplyArgs a) {
     for (int ch = 0; ch < SHARD_NCH; ++ch) {
       const int c4 = l16 + 16 * ch;
       if (c4 < W4) {
+        if (a.oc.opt == TLSAN_OPT_SGD) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const bool rg = 4 * c4 + i < reg_cols;
-          const float g = a.gscale * (float)acc[ch][i] + (rg ? a.reg * w[ch][i] : 0.0f);
-          w[ch][i] -= step * g;
-          if (rg) part += (double)w[ch][i] * (double)w[ch][i];
+          for (int i = 0; i < 4; ++i) {
+            const bool rg = 4 * c4 + i < reg_cols;
+            const float g = a.gscale * (float)acc[ch][i] + (rg ? a.reg * w[ch][i] : 0.0f);
+            w[ch][i] -= step * g;
+            if (rg) part += (double)w[ch][i] * (double)w[ch][i];
+          }
+        } else {
+          float* S1 = (is_cate ? a.cate_s1 + (size_t)rc * a.dc : a.shard_s1 + (size_t)rc * a.ld) + 4 * c4;
+          float* S2 = (is_cate ? a.cate_s2 + (size_t)rc * a.dc : a.shard_s2 + (size_t)rc * a.ld) + 4 * c4;
+          f32x4 m1 = *(const f32x4*)S1, m2 = *(const f32x4*)S2;
+          const float coef = a.step_dev[1];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int col = 4 * c4 + i;
+            const bool rg = col < reg_cols;
+            const float g = a.gscale * (float)acc[ch][i] + (rg ? a.reg * w[ch][i] : 0.0f);
+            // item_b reaches the optimizer as the gathered rows only: sparse RMSProp / Adadelta leave the rest alone
+            const bool skip = !is_cate && rc < a.cI && col == a.bias_col && g == 0.0f && a.oc.opt != TLSAN_OPT_ADAM;
+            if (!skip) {
+              float wi = w[ch][i], a1 = m1[i], a2 = m2[i];
+              opt_elem(a.oc, wi, coef * g, a1, a2);
+              w[ch][i] = wi; m1[i] = a1; m2[i] = a2;
+            }
+            if (rg) part += (double)w[ch][i] * (double)w[ch][i];
+          }
+          *(f32x4*)S1 = m1;
+          *(f32x4*)S2 = m2;
         }
         *(f32x4*)(Wr + 4 * c4) = w[ch];
       }

@@ -260,8 +260,18 @@ class ShardedModel:
     def __init__(self, config, item_cate_list, device="cuda:0", seed=1234, group=None):
         if not dist.is_initialized():
             raise RuntimeError("ShardedModel needs torch.distributed to be initialised (one process per GPU)")
-        if config.get("optimizer", "sgd") != "sgd" or config.get("dropout", 0.0) != 0.0 or config.get("num_blocks", 1) != 1:
-            raise NotImplementedError("only optimizer='sgd', dropout=0, num_blocks=1 (see tlsan_amd.model.Model)")
+        from .model import OPTIMIZERS
+        if config.get("num_blocks", 1) != 1:
+            raise NotImplementedError("num_blocks != 1 (see tlsan_amd.model.Model)")
+        self.optimizer = config.get("optimizer", "sgd")
+        if self.optimizer not in OPTIMIZERS:
+            raise ValueError("optimizer must be one of %s" % (sorted(OPTIMIZERS),))
+        self.dropout = float(config.get("dropout", 0.0))
+        if not 0.0 <= self.dropout < 1.0:
+            raise ValueError("dropout must be in [0, 1)")
+        if self.dropout > 0.0 and config["Ls"] > 10:
+            raise NotImplementedError("dropout > 0 is built for Ls <= 10")
+        self._seed = int(seed)
         self.config = config
         self.lib = L.load()
         self.group = group
@@ -301,7 +311,17 @@ class ShardedModel:
         # all-reduced vector: dense grads | cate grads | mean BCE | per-use squares | local table squares | pad
         self._flat = torch.zeros(self.lay.n_dense + Cc * self.dc + 4, dtype=torch.float32, device=dev)
         self._gn_local = torch.zeros(1, dtype=torch.float32, device=dev)
-        self._step_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._step_dev = torch.zeros(2, dtype=torch.float32, device=dev)     # lr * coef, coef
+        # adam / rmsprop / adadelta: accumulators laid out like what they belong to (RMSProp's first starts at one)
+        self._sopt = None
+        if self.optimizer != "sgd":
+            kind, b1, b2, eps = OPTIMIZERS[self.optimizer]
+            one = 1.0 if self.optimizer == "rmsprop" else 0.0
+            self.slots = dict(shard_s1=torch.full_like(self.shard, one), shard_s2=torch.zeros_like(self.shard),
+                              cate_s1=torch.full_like(self.cate_emb, one), cate_s2=torch.zeros_like(self.cate_emb),
+                              dense_s1=torch.full_like(self.dense, one), dense_s2=torch.zeros_like(self.dense))
+            self._sopt = L.ShardOptimizer(kind, 0, b1, b2, eps, *[self.slots[k].data_ptr() for k in
+                                          ("shard_s1", "shard_s2", "cate_s1", "cate_s2", "dense_s1", "dense_s2")])
         self.last_loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self.last_gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
         self._ws = None
@@ -562,8 +582,14 @@ class ShardedModel:
                     "tlsan_state_recategorize")
 
     # ------------------------------------------------------------------ training
-    def train_async(self, batch, lr, next_batch=None, weight=1.0):
-        """One step.  `weight`: this rank's share of the global mean when the ranks' batches differ in
+    def dropout_seed(self, step=None):
+        """As tlsan_amd.model.Model.dropout_seed: the same pattern on every rank (ranks differ by sample offset)."""
+        step = self._step if step is None else step
+        return ((self._seed * 0x9E3779B1) ^ ((step + 1) * 0x85EBCA77)) & 0xFFFFFFFF
+
+    def train_async(self, batch, lr, next_batch=None, weight=1.0, sample0=0):
+        """One step.  sample0: position of this rank's first sample in the global batch (dropout pattern).
+          `weight`: this rank's share of the global mean when the ranks' batches differ in
         size, B_rank * world / B_global (1 when they are equal; 0 for a rank that only holds a
         placeholder row of a global batch smaller than the world).
           `next_batch` (optional): its routing plan is queued before this step's heavy
@@ -593,7 +619,8 @@ class ShardedModel:
         go = L.GradsOut(g0, g0 + 4 * di, g0, g0 + 4 * di, fp + 4 * n_dense, fp, W, W, W, W, 1)
         tail = fp + 4 * (n_dense + n_cate)
         out = L.StepOut(tail, self._gn_local.data_ptr(), None, tail + 4)
-        hp = L.HParams(float(lr), 0.0, self.clip, L.NORM_TF18, L.L2_DENSE, 0, 1 if prepared else 0)   # reg: applied by the owners
+        hp = L.HParams(float(lr), 0.0, self.clip, L.NORM_TF18, L.L2_DENSE, 0, 1 if prepared else 0,   # reg: applied by the owners
+                       self.dropout, self.dropout_seed() if self.dropout > 0.0 else 0, int(sample0))
         st = self._stream()
         L.check(self.lib.tlsan_grads(C.byref(dims), C.byref(cp), C.byref(cb), C.byref(hp), C.byref(go), C.byref(out),
                                      sl["state"].data_ptr(), self._ws.data_ptr(), self._ws.numel(), st), "tlsan_grads")
@@ -605,10 +632,13 @@ class ShardedModel:
         # ---- one all-reduce: dense grads | cate grads | loss | per-use squares | local table squares
         if G > 1:
             allreduce_sum(flat, self.group)
-        L.check(self.lib.tlsan_shard_summary(fp, n_dense, n_cate, G, float(lr), self.reg, self.clip,
-                                             self._sq.data_ptr() + 8, self.dense.data_ptr(), self.dense_KT.data_ptr(),
-                                             C.byref(self.dims_full), self._step_dev.data_ptr(),
-                                             self.last_loss.data_ptr(), self.last_gnorm.data_ptr(), st),
+        if self._sopt is not None:
+            self._sopt.step = self._step + 1
+        sopt = None if self._sopt is None else C.byref(self._sopt)
+        L.check(self.lib.tlsan_shard_summary_opt(fp, n_dense, n_cate, G, float(lr), self.reg, self.clip,
+                                                 self._sq.data_ptr() + 8, self.dense.data_ptr(), self.dense_KT.data_ptr(),
+                                                 C.byref(self.dims_full), self._step_dev.data_ptr(),
+                                                 self.last_loss.data_ptr(), self.last_gnorm.data_ptr(), sopt, st),
                 "tlsan_shard_summary")
         # ---- row gradients back to the owners, deterministic apply with dense L2 decay of every row
         if G > 1:
@@ -616,11 +646,12 @@ class ShardedModel:
             a2a(vals[:sl["n_recv"]], gf[:sl["n"]], sl["recv"], sl["send"], self.group)
         else:
             vals = gf
-        L.check(self.lib.tlsan_shard_apply(self.shard.data_ptr(), W, self.cI, self.router.R, W, di, di + Ls,
-                                           vals.data_ptr(), W, sl["recv_rows"].data_ptr(), sl["n_recv"], sl["src_off"],
-                                           G, self._slots_buf.data_ptr(), 1.0 / G, self._step_dev.data_ptr(), self.reg,
-                                           self.cate_emb.data_ptr(), Cc, self.dc, fp + 4 * n_dense,
-                                           self._sq.data_ptr(), tail + 8, self._aws.data_ptr(), self._aws.numel(), st),
+        L.check(self.lib.tlsan_shard_apply_opt(self.shard.data_ptr(), W, self.cI, self.router.R, W, di, di + Ls,
+                                               vals.data_ptr(), W, sl["recv_rows"].data_ptr(), sl["n_recv"], sl["src_off"],
+                                               G, self._slots_buf.data_ptr(), 1.0 / G, self._step_dev.data_ptr(), self.reg,
+                                               self.cate_emb.data_ptr(), Cc, self.dc, fp + 4 * n_dense,
+                                               self._sq.data_ptr(), tail + 8, sopt, float(lr),
+                                               self._aws.data_ptr(), self._aws.numel(), st),
                 "tlsan_shard_apply")
         self._step += 1
         self._keep = (table, gf, vals, sl["recv_rows"])
@@ -768,11 +799,14 @@ class ShardedModel:
             if self.rank == 0:
                 np.savez(base + ".npz", global_step=self._step, global_epoch_step=self._epoch, **full)
         else:
+            sl = {} if self._sopt is None else {k: v.cpu().numpy() for k, v in self.slots.items()}
             np.savez("%s.shard%dof%d.npz" % (base, self.rank, self.world), shard=self.shard.cpu().numpy(),
-                     cI=self.cI, W=self.W, item_count=self.I, user_count=self.U)
+                     cI=self.cI, W=self.W, item_count=self.I, user_count=self.U,
+                     **{k: v for k, v in sl.items() if k.startswith("shard_")})
             if self.rank == 0:
                 np.savez(base + ".replicated.npz", cate_emb=self.cate_emb.cpu().numpy(), dense=self.dense.cpu().numpy(),
-                         global_step=self._step, global_epoch_step=self._epoch, world=self.world)
+                         global_step=self._step, global_epoch_step=self._epoch, world=self.world,
+                         **{k: v for k, v in sl.items() if not k.startswith("shard_")})
         if self.rank == 0:
             json.dump(self.config, open(base + ".json", "w"), indent=2)
         if self.world > 1:
@@ -799,6 +833,9 @@ class ShardedModel:
             K = self.dense[self.lay.K:self.lay.K + self.d * self.d].view(self.d, self.d)
             self.dense_KT.copy_(K.t())
             self._refresh_squares()
+            if self._sopt is not None and "shard_s1" in zs.files:      # the optimizer's accumulators
+                for k in self.slots:
+                    self.slots[k].copy_(torch.as_tensor((zs if k.startswith("shard_") else rep_)[k]))
             z = rep_
         self._step = int(z["global_step"])
         self._epoch = int(z["global_epoch_step"])

@@ -276,7 +276,8 @@ def train_sharded(args):
         shares = (_share(b, rank, world) + (len(b[0]),) for _, b in DataInput(train_set, args.train_batch_size, config["Ls"]))
         for (part, real, n_glob), nxt in _lookahead((model.device_batch(p_), r_, n_) for p_, r_, n_ in shares):
             last = nxt is None or (args.max_steps and model.global_step.eval() + 1 >= args.max_steps)
-            model.train_async(part, lr, next_batch=None if last else nxt[0], weight=real * world / n_glob)
+            model.train_async(part, lr, next_batch=None if last else nxt[0], weight=real * world / n_glob,
+                              sample0=n_glob * rank // world)
             loss_sum += model.last_loss[0]
             step = model.global_step.eval()
             if step % args.eval_freq == 0:
