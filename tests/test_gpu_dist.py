@@ -231,7 +231,7 @@ def test_route_plan_matches_key_router(n_items, n_users, n_uses):
     assert np.array_equal(r.item_keys(torch.as_tensor(items)).numpy(), (items % G) * r.R + items // G)
 
 
-def _driver_worker(rank, world, port, ret, ckpt):
+def _driver_worker(rank, world, port, ret, ckpt, extra):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -240,7 +240,7 @@ def _driver_worker(rank, world, port, ret, ckpt):
         # batch 33 over 2 ranks: uneven shares (16 / 17) -> the weighted means; test batches of 128 split 64 / 64,
         # the last one (2010 % 128 = 90) 45 / 45
         argv = ["--dataset", ds, "--max_steps", "40", "--eval_freq", "20", "--quiet", "--train_batch_size", "33",
-                "--model_dir", os.path.join(ckpt, "r%d" % rank), "--device_input", "0"]
+                "--model_dir", os.path.join(ckpt, "r%d" % rank), "--device_input", "0"] + list(extra)
         res = T.train_sharded(T.parse(argv + ["--sharded", "1"]))
         if rank == 0:
             one = T.train(T.parse(argv))
@@ -259,13 +259,14 @@ def _driver_worker(rank, world, port, ret, ckpt):
         dist.destroy_process_group()
 
 
-def test_sharded_train_driver_matches_single_gpu(tmp_path):
+@pytest.mark.parametrize("extra", [(), ("--optimizer", "adam", "--learning_rate", "0.01", "--dropout", "0.1")])
+def test_sharded_train_driver_matches_single_gpu(extra, tmp_path):
     """python -m tlsan_amd.train --sharded: the reference's train.py flow over 2 ranks (global batches
     split over the ranks, unevenly here; evaluation over split test batches) against the single-GPU driver
-    on the same data and shuffle."""
+    on the same data and shuffle -- with the defaults, and with adam + dropout."""
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_driver_worker, args=(2, _free_port(), ret, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_driver_worker, args=(2, _free_port(), ret, str(tmp_path), extra), nprocs=2, join=True)
     assert all(v == "ok" for v in dict(ret).values()) and len(ret) == 2, dict(ret)
 
 
