@@ -216,9 +216,9 @@ def test_errors():
     cfg = make_config(d=64, optimizer="adagrad")          # not one of model.py:188-195
     with pytest.raises(ValueError):
         Model(cfg, np.zeros(cfg["item_count"], np.int32))
-    cfg = make_config(d=64, dropout=0.1, Ls=20)            # dropout is built for the in-register window only
+    cfg = make_config(d=64, dropout=0.1)                   # dropout is built for fp32 tables
     with pytest.raises(NotImplementedError):
-        Model(cfg, np.zeros(cfg["item_count"], np.int32))
+        Model(cfg, np.zeros(cfg["item_count"], np.int32), table_dtype="bf16")
     cfg = make_config(d=64)
     m = Model(cfg, np.zeros(cfg["item_count"], np.int32))
     b, _ = random_batch(cfg, B=4, Sn=2, seed=1)
@@ -686,12 +686,12 @@ def test_large_tables_take_the_two_level_scan(l2_mode):
         assert np.abs(du - dr).max() < 3e-4 * (np.abs(dr).max() + 1e-9) + 3e-7, k
 
 
-@pytest.mark.parametrize("d,rate", [(64, 0.2), (128, 0.35), (256, 0.5)])
-def test_dropout_training_matches_oracle(d, rate):
+@pytest.mark.parametrize("d,rate,Ls", [(64, 0.2, 10), (128, 0.35, 10), (256, 0.5, 10), (128, 0.3, 33), (64, 0.25, 90)])
+def test_dropout_training_matches_oracle(d, rate, Ls):
     """config['dropout'] > 0 (model.py:116-118, 428-431): tf.nn.dropout on the inputs of the two maps of
     both attention blocks, train steps only.  With the same keep / drop pattern (a hash of seed, sample,
     block, position, map, channel) three train steps follow the oracle; evaluation does not drop."""
-    cfg = make_config(U=40, I=60, C=9, d=d, regulation_rate=1e-3, dropout=rate)
+    cfg = make_config(U=40, I=60, C=9, d=d, regulation_rate=1e-3, dropout=rate, Ls=Ls)   # (Ls > 10: streamed window)
     p = _p32(random_params(cfg, seed=91))
     _, cat = random_batch(cfg, B=8, Sn=3, seed=0)
     batches = [random_batch(cfg, B=37, Sn=2 + s, seed=910 + s)[0] for s in range(3)]

@@ -609,8 +609,7 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   a.gLong = w.gLong; a.gDB = w.gDB; a.partials = w.partials;
   if (hp->dropout != 0.0f) {
     if (!(hp->dropout > 0.0f && hp->dropout < 1.0f)) return fail(TLSAN_E_BADARG, "dropout must be in [0, 1)");
-    if (d->Ls > TLSAN_LS_MAX || a.p.table_dtype != TLSAN_TABLE_F32)
-      return fail(TLSAN_E_UNSUPPORTED, "dropout > 0 is built for Ls <= %d and fp32 tables", TLSAN_LS_MAX);
+    if (a.p.table_dtype != TLSAN_TABLE_F32) return fail(TLSAN_E_UNSUPPORTED, "dropout > 0 is built for fp32 tables");
     const float keep = (float)(1.0 - (double)hp->dropout);
     const double t = (double)keep * 4294967296.0;
     a.drop_thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;

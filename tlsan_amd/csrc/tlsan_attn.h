@@ -377,7 +377,7 @@ __device__ __forceinline__ void online_step(f32x4 (&mx)[NB], f32x4 (&Z)[NB], f32
 // Ls <= TLSAN_LS_MAX positions stay in registers between forward and backward.
 template <int D, int DH, bool TRAIN, bool LSTREAM, int DT = TLSAN_TABLE_F32, bool DROP = false>
 __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
-  static_assert(!DROP || (TRAIN && !LSTREAM), "dropout: training with the long window in registers");
+  static_assert(!DROP || TRAIN, "dropout: train steps only");
   using G = Geo<D, DH>;
   constexpr int NB = G::NB, CPS = G::CPS, SPW = G::SPW, NW = G::NW, NSB = G::NSB;
   constexpr int LS = LSTREAM ? 1 : TLSAN_LS_MAX;             // positions held in registers
@@ -522,11 +522,22 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           const bool vp = p < n_l;
 #pragma unroll
           for (int kb = 0; kb < NB; ++kb) xv[kb] = vp ? xv[kb] * scx : (f32x4)(0.0f);
-          map_apply<NB>(FT1, b1, xv, z);
+          if constexpr (DROP) {
+            f32x4 xd[NB];
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) xd[kb] = xv[kb] * drop_scale4(dc, 0, p, 0, chb[kb]);
+            map_apply<NB>(FT1, b1, xd, z);
+          } else {
+            map_apply<NB>(FT1, b1, xv, z);
+          }
 #pragma unroll
           for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
             for (int i = 0; i < 4; ++i) z[kb][i] = fmaxf(z[kb][i], 0.0f);
+          if constexpr (DROP) {
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) z[kb] *= drop_scale4(dc, 0, p, 1, chb[kb]);
+          }
           map_apply<NB>(FT2, b2, z, m2);
           if (vp) online_step<NB>(mx1, Zl, long4, m2, xv);
         }
@@ -996,18 +1007,34 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
                 ev[kb] = vp ? ev[kb] : (f32x4)(0.0f);
                 xv[kb] = ev[kb] * scx;
               }
-              map_apply<NB>(FT1, b1, xv, z1);
+              f32x4 k1[NB], k2[NB];
+              if constexpr (DROP) {
+                f32x4 xd[NB];
+#pragma unroll
+                for (int kb = 0; kb < NB; ++kb) {
+                  k1[kb] = drop_scale4(dc, 0, p, 0, chb[kb]);
+                  k2[kb] = drop_scale4(dc, 0, p, 1, chb[kb]);
+                  xd[kb] = xv[kb] * k1[kb];
+                }
+                map_apply<NB>(FT1, b1, xd, z1);
+              } else {
+                map_apply<NB>(FT1, b1, xv, z1);
+              }
 #pragma unroll
               for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) zr[kb][i] = fmaxf(z1[kb][i], 0.0f);
+              if constexpr (DROP) {
+#pragma unroll
+                for (int kb = 0; kb < NB; ++kb) zr[kb] *= k2[kb];
+              }
               map_apply<NB>(FT2, b2, zr, m2);
 #pragma unroll
               for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                   av[kb][i] = vp ? __expf(m2[kb][i] - mx1[kb][i]) * iz1[kb][i] : 0.0f;
-              bwd_compute<NB, TSTR>(FN2, FN1, xv, z1, av, long4, dlong, T, q, r, acc.db1, acc.db2, dx);
+              bwd_compute<NB, TSTR, DROP>(FN2, FN1, xv, z1, av, long4, dlong, T, q, r, acc.db1, acc.db2, dx, k1, k2);
               bwd_dw<NB, TSTR>(T, q, r, acc.dW1, acc.dW2);
               float dsp = 0.0f;
 #pragma unroll

@@ -28,8 +28,8 @@ static hipError_t launch_variant(const FwdArgs& a, int grid, hipStream_t st) {
     if constexpr (!LSTREAM) return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_BF16>(a, grid, st);
     else return hipErrorNotSupported;
   }
-  if (a.drop_thr != 0) {  // dropout: training, long window in registers, fp32 tables
-    if constexpr (TRAIN && !LSTREAM) return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_F32, true>(a, grid, st);
+  if (a.drop_thr != 0) {  // dropout: training, fp32 tables
+    if constexpr (TRAIN) return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_F32, true>(a, grid, st);
     else return hipErrorNotSupported;
   }
   return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_F32>(a, grid, st);

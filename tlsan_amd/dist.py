@@ -269,8 +269,6 @@ class ShardedModel:
         self.dropout = float(config.get("dropout", 0.0))
         if not 0.0 <= self.dropout < 1.0:
             raise ValueError("dropout must be in [0, 1)")
-        if self.dropout > 0.0 and config["Ls"] > 10:
-            raise NotImplementedError("dropout > 0 is built for Ls <= 10")
         self._seed = int(seed)
         self.config = config
         self.lib = L.load()

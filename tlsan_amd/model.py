@@ -164,8 +164,8 @@ class Model(object):
         self.dropout = float(config.get("dropout", 0.0))           # model.py:116-118, 428-431
         if not 0.0 <= self.dropout < 1.0:
             raise ValueError("dropout must be in [0, 1)")
-        if self.dropout > 0.0 and (config["Ls"] > 10 or table_dtype != "f32"):
-            raise NotImplementedError("dropout > 0 is built for Ls <= 10 and fp32 tables")
+        if self.dropout > 0.0 and table_dtype != "f32":
+            raise NotImplementedError("dropout > 0 is built for fp32 tables")
         self._seed = int(seed)
         self.optimizer = config.get("optimizer", "sgd")           # model.py:188-195
         if self.optimizer not in OPTIMIZERS:
