@@ -148,7 +148,7 @@ def main():
         stepper = model
     else:
         from tlsan_amd.dist import ShardedModel
-        model = ShardedModel(cfg, icl, device=dev)
+        model = ShardedModel(cfg, icl, device=dev, l2_mode=args.l2_mode)
         stepper = model
     dbs = [stepper.device_batch(b) for b in host_batches]
     lr = 1.0
@@ -224,7 +224,7 @@ def main():
         eb = 2 if (args.table_dtype == "bf16" and not sharded) else 4   # e = bytes per table element
         ab = [synth.algorithmic_bytes(cfg, host_batches[(args.warmup + s) % len(host_batches)], eb) for s in range(args.steps)]
         k_bytes = float(np.mean([a["fwd_bwd_kernel"] for a in ab]))
-        l2 = "dense" if sharded else args.l2_mode
+        l2 = args.l2_mode
         step_bytes = float(np.mean([a["train_step"] for a in ab])) + (synth.dense_sweep_bytes(cfg) if l2 == "dense" else 0)
         k_flops = float(np.mean([synth.algorithmic_flops(cfg, host_batches[(args.warmup + s) % len(host_batches)]) for s in range(args.steps)]))
         k_ms = float(seg[:, 1].mean()) if nrec else float("nan")

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TLSAN_ABI_VERSION 8
+#define TLSAN_ABI_VERSION 9
 
 enum {
   TLSAN_OK = 0,
@@ -347,6 +347,10 @@ typedef struct {
   float* shard_s1; float* shard_s2;
   float* cate_s1; float* cate_s2;
   float* dense_s1; float* dense_s2;
+  /* lazy L2 on the sharded step (kind SGD only; the accumulators may then be NULL): the tables are
+   * scale[0] * stored, one scale that every rank advances alike (tlsan_shard_apply_lazy commits it);
+   * step_dev then has 4 floats: {lr coef, coef, lr coef / P_new, P_new}. */
+  float* scale;
 } tlsan_shard_optimizer;
 int tlsan_shard_summary_opt(const float* flat, int32_t n_dense, int32_t n_cate, int32_t G, float lr, float reg, float clip,
                             const double* S_cate, float* dense, float* dense_KT, const tlsan_dims* dims,
@@ -374,6 +378,21 @@ int tlsan_shard_apply_opt(float* shard, int32_t ld, int32_t cI, int32_t R, int32
                           float* cate_emb, int32_t C, int32_t dc, const float* g_cate,
                           double* sumsq_out, float* sumsq_f32, const tlsan_shard_optimizer* opt, float lr,
                           void* ws, size_t ws_bytes, void* stream);
+
+/* tlsan_shard_apply_lazy: the owner-side update in its lazy-L2 form,
+ *   W_stored -= (lr coef / P_new) * gscale * sum   for the rows whose gradients arrived (and every row of the
+ * replicated category table), item_b (column reg_item of item rows, not regularised, not scaled) -= lr coef * ...
+ * -- the same update as tlsan_shard_apply's dense sweep up to fp32 rounding, touching n_recv rows instead
+ * of R.  slots64: uint64 [R*G] scratch, any content (entries carry `stamp`, which must differ from step
+ * to step and never be 0 for a zero-initialised buffer).  sumsq_out[0] += the change of the stored shard
+ * rows' sum of squares (regularised columns), sumsq_out[1] = that of cate_emb (stored values).
+ * ws: tlsan_shard_apply_lazy_workspace(n_recv, C) bytes. */
+size_t tlsan_shard_apply_lazy_workspace(int32_t n_recv, int32_t C);
+int tlsan_shard_apply_lazy(float* shard, int32_t ld, int32_t cI, int32_t R, int32_t W, int32_t reg_item, int32_t reg_user,
+                           const float* vals, int32_t ldv, const int32_t* rows, int32_t n_recv, const int32_t* src_off,
+                           int32_t G, uint64_t* slots64, uint32_t stamp, float gscale, const float* step_dev,
+                           float* cate_emb, int32_t C, int32_t dc, const float* g_cate,
+                           double* sumsq_out, float* sumsq_f32, float* scale, void* ws, size_t ws_bytes, void* stream);
 
 /* Exclusive prefix sum + compaction of a device int32 array (the id-routing step of the sharded
  * path): prefix[k] = sum(cnt[0..k)), uniq = ascending list of k with cnt[k] > 0 and

@@ -8,7 +8,7 @@ dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cu
 from tlsan_amd import synth
 from tlsan_amd.dist import ShardedModel
 cfg = synth.make_config("electronics")
-m = ShardedModel(cfg, synth.item_cate_list(cfg))
+m = ShardedModel(cfg, synth.item_cate_list(cfg), l2_mode=os.environ.get("SHARD_L2", "dense"))
 dbs = [m.device_batch(b) for b in synth.make_batches(cfg, 4, 4096, seed=1)]
 for pf in (0, 1):
     for s in range(12):

@@ -55,7 +55,7 @@ def _concat(per):
     return out
 
 
-def _worker(rank, world, port, ret, d, prefetch, ckpt, uneven=False, hotcat=False):
+def _worker(rank, world, port, ret, d, prefetch, ckpt, uneven=False, hotcat=False, lazy=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -64,7 +64,7 @@ def _worker(rank, world, port, ret, d, prefetch, ckpt, uneven=False, hotcat=Fals
         # (hotcat: 2 categories and 150 samples per rank -> >1000 uses per category: the row-sum pass of
         #  tlsan_grads splits every category over several workgroups)
         cfg, p, cat = _case(d, clip, C=2 if hotcat else 9)
-        m = ShardedModel(cfg, cat, device="cuda:0")
+        m = ShardedModel(cfg, cat, device="cuda:0", l2_mode="lazy" if lazy else "dense")
         m.set_params({k: np.asarray(v, np.float32) for k, v in p.items()})
         if uneven:
             m._pcap = 5     # a shared exchange capacity far too small: the overflow protocol must raise it in lockstep
@@ -123,7 +123,7 @@ def _worker(rank, world, port, ret, d, prefetch, ckpt, uneven=False, hotcat=Fals
         prefix = m.save()
         one = m.save(sharded=False)
         for path in (prefix, one + ".npz"):
-            m2 = ShardedModel(cfg, cat, device="cuda:0", seed=99)       # different initial values
+            m2 = ShardedModel(cfg, cat, device="cuda:0", seed=99, l2_mode="lazy" if lazy else "dense")   # different initial values
             m2.restore(None, path)
             assert m2.global_step.eval() == m.global_step.eval() == 4
             back = m2.gather_params()
@@ -139,16 +139,17 @@ def _worker(rank, world, port, ret, d, prefetch, ckpt, uneven=False, hotcat=Fals
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,d,prefetch,uneven,hotcat", [(1, 128, False, False, False), (2, 128, False, False, False),
-                                                            (2, 64, False, False, False), (1, 128, True, False, False),
-                                                            (2, 128, True, False, False), (2, 128, True, True, False),
-                                                            (2, 128, True, False, True)])
-def test_sharded_model_matches_oracle(world, d, prefetch, uneven, hotcat, tmp_path):
+@pytest.mark.parametrize("world,d,prefetch,uneven,hotcat,lazy", [
+    (1, 128, False, False, False, False), (2, 128, False, False, False, False), (2, 64, False, False, False, False),
+    (1, 128, True, False, False, False), (2, 128, True, False, False, False), (2, 128, True, True, False, False),
+    (2, 128, True, False, True, False),
+    (1, 128, False, False, False, True), (2, 128, True, False, False, True), (2, 64, True, True, False, True)])
+def test_sharded_model_matches_oracle(world, d, prefetch, uneven, hotcat, lazy, tmp_path):
     """(uneven: the ranks hold 24 and 17 samples of each global batch and enter with their shares;
-    hotcat: two categories with > 1000 uses each)"""
+    hotcat: two categories with > 1000 uses each; lazy: the owners' update in its lazy-L2 form)"""
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), ret, d, prefetch, str(tmp_path), uneven, hotcat), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), ret, d, prefetch, str(tmp_path), uneven, hotcat, lazy), nprocs=world, join=True)
     assert all(v == "ok" for v in dict(ret).values()) and len(ret) == world, dict(ret)
 
 

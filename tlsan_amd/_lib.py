@@ -8,7 +8,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libtlsan_hip.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 NORM_TF18, NORM_DEDUP = 0, 1
 TABLE_F32, TABLE_BF16 = 0, 1
 L2_DENSE, L2_LAZY = 0, 1
@@ -20,7 +20,7 @@ EXPORTS = [
     "tlsan_train_step", "tlsan_train_step_opt", "tlsan_batch_pack", "tlsan_batch_index", "tlsan_grads", "tlsan_eval_ranks", "tlsan_eval_label_scores", "tlsan_eval_counts_shard", "tlsan_profile_enable", "tlsan_profile_stride",
     "tlsan_profile_collect", "tlsan_debug_stamps", "tlsan_rows_apply_workspace", "tlsan_rows_apply", "tlsan_scan_compact",
     "tlsan_route_plan", "tlsan_shard_gather", "tlsan_shard_summary", "tlsan_shard_apply_workspace", "tlsan_shard_apply",
-    "tlsan_shard_summary_opt", "tlsan_shard_apply_opt",
+    "tlsan_shard_summary_opt", "tlsan_shard_apply_opt", "tlsan_shard_apply_lazy_workspace", "tlsan_shard_apply_lazy",
 ]
 PROF_SEGMENTS = ("index_build", "fwd_bwd", "dk_partial", "dense_finalize", "apply_rows")
 
@@ -69,7 +69,7 @@ OPT_SGD, OPT_ADAM, OPT_RMSPROP, OPT_ADADELTA = 0, 1, 2, 3
 class ShardOptimizer(C.Structure):
     _fields_ = [("kind", C.c_int32), ("step", C.c_int32), ("beta1", C.c_float), ("beta2", C.c_float),
                 ("epsilon", C.c_float)] + [(n, C.c_void_p) for n in ("shard_s1", "shard_s2", "cate_s1", "cate_s2",
-                                                                      "dense_s1", "dense_s2")]
+                                                                      "dense_s1", "dense_s2", "scale")]
 
 
 class StepOut(C.Structure):
@@ -170,6 +170,13 @@ def load():
                                           C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                           P(ShardOptimizer), C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.tlsan_shard_apply_opt.restype = C.c_int
+    lib.tlsan_shard_apply_lazy_workspace.argtypes = [C.c_int32, C.c_int32]
+    lib.tlsan_shard_apply_lazy_workspace.restype = C.c_size_t
+    lib.tlsan_shard_apply_lazy.argtypes = [C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                           P(C.c_int32), C.c_int32, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p,
+                                           C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.tlsan_shard_apply_lazy.restype = C.c_int
     lib.tlsan_shard_apply_workspace.argtypes = [C.c_int32, C.c_int32]
     lib.tlsan_shard_apply_workspace.restype = C.c_size_t
     lib.tlsan_shard_apply.argtypes = [C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,

@@ -1022,6 +1022,7 @@ int tlsan_shard_gather(const float* shard, int32_t ld, int32_t R, int32_t W, con
 static int shard_opt_ctx(const tlsan_shard_optimizer* o, float lr, OptCtx* oc) {
   memset(oc, 0, sizeof(*oc));
   if (!o || o->kind == TLSAN_OPT_SGD) return TLSAN_OK;
+  if (o->scale) return fail(TLSAN_E_UNSUPPORTED, "tlsan_shard_optimizer: lazy L2 (scale) is for SGD only");
   if (o->kind != TLSAN_OPT_ADAM && o->kind != TLSAN_OPT_RMSPROP && o->kind != TLSAN_OPT_ADADELTA)
     return fail(TLSAN_E_BADARG, "tlsan_shard_optimizer: kind %d", o->kind);
   if (!o->shard_s1 || !o->shard_s2 || !o->cate_s1 || !o->cate_s2 || !o->dense_s1 || !o->dense_s2)
@@ -1056,6 +1057,7 @@ int tlsan_shard_summary_opt(const float* flat, int32_t n_dense, int32_t n_cate, 
   a.step_dev = step_dev; a.loss_out = loss_out; a.gnorm_out = gnorm_out;
   if ((rc = shard_opt_ctx(opt, lr, &a.oc))) return rc;
   a.dense_s1 = opt ? opt->dense_s1 : nullptr; a.dense_s2 = opt ? opt->dense_s2 : nullptr;
+  a.P_dev = opt ? opt->scale : nullptr;
   hipLaunchKernelGGL(k_shard_summary, dim3((n_dense + 1023) / 1024), dim3(1024), 0, (hipStream_t)stream, a);
   CHECK_LAUNCH("k_shard_summary");
   return TLSAN_OK;
@@ -1134,6 +1136,48 @@ static int scan_compact_impl(const int32_t* cnt, int32_t n, int32_t* prefix, int
 
 // (no scratch: one launch whose prefix re-read grows with the square of n / 4096 -- meant for tables up
 //  to a few hundred thousand entries; tlsan_route_plan scans its key space with chunk sums)
+size_t tlsan_shard_apply_lazy_workspace(int32_t n_recv, int32_t C) {
+  if (n_recv < 0 || C < 1) return 0;
+  return al(8 * (size_t)((n_recv + AP_ROWS_PB - 1) / AP_ROWS_PB + (C + AP_ROWS_PB - 1) / AP_ROWS_PB + 1));
+}
+
+int tlsan_shard_apply_lazy(float* shard, int32_t ld, int32_t cI, int32_t R, int32_t W, int32_t reg_item, int32_t reg_user,
+                           const float* vals, int32_t ldv, const int32_t* rows, int32_t n_recv, const int32_t* src_off,
+                           int32_t G, uint64_t* slots64, uint32_t stamp, float gscale, const float* step_dev,
+                           float* cate_emb, int32_t C, int32_t dc, const float* g_cate,
+                           double* sumsq_out, float* sumsq_f32, float* scale, void* ws, size_t ws_bytes, void* stream) {
+  if (!shard || !slots64 || !step_dev || !cate_emb || !g_cate || !sumsq_out || !src_off || !scale || n_recv < 0 ||
+      (n_recv > 0 && (!vals || !rows)))
+    return fail(TLSAN_E_BADARG, "tlsan_shard_apply_lazy: bad pointer / size");
+  if (G < 1 || G > SHARD_GMAX) return fail(TLSAN_E_UNSUPPORTED, "tlsan_shard_apply_lazy: 1..%d ranks", SHARD_GMAX);
+  if (W < 4 || W % 4 || dc % 4 || ld < W || ld % 4 || (n_recv > 0 && (ldv < W || ldv % 4)) || cI < 0 || cI > R ||
+      reg_item > W || reg_user > W || stamp == 0)
+    return fail(TLSAN_E_UNSUPPORTED, "tlsan_shard_apply_lazy: widths must be multiples of 4, stamp != 0");
+  if (!ws || ws_bytes < tlsan_shard_apply_lazy_workspace(n_recv, C)) return fail(TLSAN_E_WORKSPACE, "tlsan_shard_apply_lazy: workspace too small");
+  ShardLazyArgs a;
+  memset(&a, 0, sizeof(a));
+  a.shard = shard; a.ld = ld; a.cI = cI; a.R = R; a.W = W; a.reg_item = reg_item; a.reg_user = reg_user;
+  a.vals = vals ? vals : shard; a.ldv = vals ? ldv : ld; a.rows = rows; a.n_recv = n_recv; a.G = G;
+  for (int s = 0; s <= G; ++s) a.src_off[s] = src_off[s];
+  if (a.src_off[0] != 0 || a.src_off[G] != n_recv) return fail(TLSAN_E_BADARG, "tlsan_shard_apply_lazy: src_off must run from 0 to n_recv");
+  a.slots64 = (unsigned long long*)slots64; a.stamp = stamp; a.gscale = gscale; a.step_dev = step_dev;
+  a.cate_emb = cate_emb; a.C = C; a.dc = dc; a.g_cate = g_cate; a.P_dev = scale;
+  a.part_out = (double*)ws;
+  a.nb_rows = (n_recv + AP_ROWS_PB - 1) / AP_ROWS_PB;
+  if (a.nb_rows < 1) a.nb_rows = 1;   // (workgroup 0 commits the scale)
+  a.nb_cate = (C + AP_ROWS_PB - 1) / AP_ROWS_PB;
+  hipStream_t hs = (hipStream_t)stream;
+  if (n_recv > 0) {
+    hipLaunchKernelGGL(k_slot_mark64, dim3((n_recv + 255) / 256), dim3(256), 0, hs, a);
+    CHECK_LAUNCH("k_slot_mark64");
+  }
+  hipLaunchKernelGGL(k_shard_apply_lazy, dim3(a.nb_rows + a.nb_cate), dim3(256), 0, hs, a);
+  CHECK_LAUNCH("k_shard_apply_lazy");
+  hipLaunchKernelGGL(k_reduce_lazy2, dim3(2), dim3(256), 0, hs, a.part_out, a.nb_rows, a.nb_cate, sumsq_out, sumsq_f32);
+  CHECK_LAUNCH("k_reduce_lazy2");
+  return TLSAN_OK;
+}
+
 int tlsan_scan_compact(const int32_t* cnt, int32_t n, int32_t* prefix, int32_t* uniq, int32_t* n_uniq, void* stream) {
   return scan_compact_impl(cnt, n, prefix, uniq, n_uniq, nullptr, (hipStream_t)stream);
 }

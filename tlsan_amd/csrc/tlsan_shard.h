@@ -87,7 +87,8 @@ struct SummaryArgs {
   float* step_dev; float* loss_out; float* gnorm_out;   // step_dev[0] = lr * coef, step_dev[1] = coef
   OptCtx oc;                       // optimizers other than SGD (oc.opt != 0): accumulators of the dense parameters
   float* dense_s1; float* dense_s2;
-};
+  const float* P_dev;              // lazy L2 (SGD): table scale, tables = P * stored; step_dev[2] = lr coef / P_new,
+};                                 //   step_dev[3] = P_new = P (1 - lr coef reg), committed by k_shard_apply_lazy
 
 // Every workgroup recomputes the norm (n_dense L2-resident floats, same fixed tree -> same bits)
 // and then updates its own 1024-element slice: no second launch, no cross-workgroup hand-over.
@@ -116,7 +117,8 @@ __global__ __launch_bounds__(1024) void k_shard_summary(SummaryArgs a) {
   }
   if (tid == 0) {
     const float* tail = a.flat + a.n_dense + a.n_cate;
-    const double S_tot = (double)tail[2] + *a.S_cate;
+    const float P = a.P_dev ? *a.P_dev : 1.0f;
+    const double S_tot = ((double)tail[2] + *a.S_cate) * (double)P * (double)P;   // stored sums -> true tables
     const double sq = (double)tail[1] * (double)(inv_g * inv_g) + (double)a.reg * (double)a.reg * S_tot + sh[0];
     const float norm = (float)sqrt(sq);
     const float coef = a.clip / fmaxf(norm, a.clip);  // clip_by_global_norm (model.py:201)
@@ -125,6 +127,11 @@ __global__ __launch_bounds__(1024) void k_shard_summary(SummaryArgs a) {
     if (blockIdx.x == 0) {
       a.step_dev[0] = sh_step;
       a.step_dev[1] = coef;
+      if (a.P_dev) {
+        const float Pn = P * (1.0f - sh_step * a.reg);
+        a.step_dev[2] = sh_step / Pn;
+        a.step_dev[3] = Pn;
+      }
       *a.gnorm_out = norm;
       *a.loss_out = tail[0] * inv_g + a.reg * 0.5f * (float)S_tot;
     }
@@ -283,6 +290,111 @@ __global__ __launch_bounds__(256) void k_shard_apply(ShardApplyArgs a) {
   if (lane == 0) shd[wave] = part;
   __syncthreads();
   if (tid == 0) a.part_out[blk] = shd[0] + shd[1] + shd[2] + shd[3];
+}
+
+// ---- lazy-L2 owner update (SGD): W = P * W_stored with one scale P that every rank advances alike, so an
+// owner touches only the rows whose gradients arrived (tlsan_shard_apply_lazy).  Received entries are
+// filed under slots64[row][source] = (stamp << 32 | entry + 1): a per-step stamp instead of clearing, so
+// nothing has to be zero at rest; the entry of the lowest source owns its row and adds the contributions
+// of all sources in source order (fixed order -> bitwise reproducible).
+struct ShardLazyArgs {
+  float* shard; int32_t ld, cI, R, W, reg_item, reg_user;
+  const float* vals; int32_t ldv; const int32_t* rows; int32_t n_recv;
+  int32_t src_off[SHARD_GMAX + 1]; int32_t G;
+  unsigned long long* slots64; uint32_t stamp;
+  float gscale; const float* step_dev;
+  float* cate_emb; int32_t C, dc; const float* g_cate;
+  double* part_out; int32_t nb_rows, nb_cate;
+  float* P_dev;
+};
+
+__global__ void k_slot_mark64(ShardLazyArgs a) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= a.n_recv) return;
+  int s = 0;
+  while (s + 1 < a.G && e >= a.src_off[s + 1]) ++s;
+  const int r = a.rows[e];
+  if (r >= 0 && r < a.R) a.slots64[(size_t)r * a.G + s] = ((unsigned long long)a.stamp << 32) | (unsigned)(e + 1);
+}
+
+__global__ __launch_bounds__(256) void k_shard_apply_lazy(ShardLazyArgs a) {
+  __shared__ double shd[4];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, grp = lane >> 4, l16 = lane & 15;
+  const int blk = blockIdx.x;
+  const bool is_cate = blk >= a.nb_rows;
+  const float step = a.step_dev[0], lazy = a.step_dev[2];
+  if (blk == 0 && tid == 0) *a.P_dev = a.step_dev[3];   // (nothing in this launch reads P)
+  double part = 0.0;
+  if (is_cate) {  // replicated category table: every row, W_stored -= (step / P_new) * g
+    const int row = (blk - a.nb_rows) * AP_ROWS_PB + wave * 4 + grp;
+    if (row < a.C) {
+      float* Wr = a.cate_emb + (size_t)row * a.dc;
+      for (int c4 = l16; c4 < a.dc / 4; c4 += 16) {
+        f32x4 w = *(const f32x4*)(Wr + 4 * c4);
+        const f32x4 g = *(const f32x4*)(a.g_cate + (size_t)row * a.dc + 4 * c4);
+        w -= (lazy * a.gscale) * g;
+        *(f32x4*)(Wr + 4 * c4) = w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part += (double)w[i] * (double)w[i];
+      }
+    }
+  } else {
+    const int e = blk * AP_ROWS_PB + wave * 4 + grp;
+    if (e < a.n_recv) {
+      int s = 0;
+      while (s + 1 < a.G && e >= a.src_off[s + 1]) ++s;
+      const int r = min(max(a.rows[e], 0), a.R - 1);
+      const unsigned long long* sl = a.slots64 + (size_t)r * a.G;
+      bool owner = true;
+      for (int s1 = 0; s1 < s; ++s1) owner = owner && (uint32_t)(sl[s1] >> 32) != a.stamp;
+      if (owner) {
+        const int W4 = a.W / 4;
+        const int reg_cols = r < a.cI ? a.reg_item : a.reg_user;
+        float* Wr = a.shard + (size_t)r * a.ld;
+        for (int c4 = l16; c4 < W4; c4 += 16) {
+          double acc[4] = {0.0, 0.0, 0.0, 0.0};
+          for (int s2 = s; s2 < a.G; ++s2) {  // contributions in source order
+            const unsigned long long v = sl[s2];
+            if ((uint32_t)(v >> 32) == a.stamp) {
+              const f32x4 g = *(const f32x4*)(a.vals + (size_t)((uint32_t)v - 1u) * a.ldv + 4 * c4);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc[i] += (double)g[i];
+            }
+          }
+          f32x4 w = *(const f32x4*)(Wr + 4 * c4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const bool rg = 4 * c4 + i < reg_cols;
+            const float w0 = w[i];
+            // regularised columns are stored / P; item_b (and the padding) are not scaled
+            w[i] = w0 - (rg ? lazy : step) * (a.gscale * (float)acc[i]);
+            if (rg) part += (double)w[i] * (double)w[i] - (double)w0 * (double)w0;
+          }
+          *(f32x4*)(Wr + 4 * c4) = w;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) part += __shfl_xor(part, o);
+  if (lane == 0) shd[wave] = part;
+  __syncthreads();
+  if (tid == 0) a.part_out[blk] = shd[0] + shd[1] + shd[2] + shd[3];
+}
+
+// out[0] += sum(part[0, n0)) (changes of the stored shard rows' sum of squares), out[1] = sum(part[n0, n0+n1))
+__global__ __launch_bounds__(256) void k_reduce_lazy2(const double* part, int n0, int n1, double* out, float* sq_f32) {
+  __shared__ double shd[256];
+  const int b = blockIdx.x;
+  const double s = block_sum_double(part + (b ? n0 : 0), b ? n1 : n0, shd);
+  if (threadIdx.x == 0) {
+    if (b == 0) {
+      out[0] += s;
+      if (sq_f32) *sq_f32 = (float)out[0];
+    } else {
+      out[1] = s;
+    }
+  }
 }
 
 // out[0] = sum(part[0, n0)), out[1] = sum(part[n0, n0+n1)); sq_f32 (nullable) = (float)out[0]

@@ -257,7 +257,13 @@ def torch_scan(flags):
 class ShardedModel:
     """Model surface (train / eval_auc / ...) over row-sharded tables; see module docstring."""
 
-    def __init__(self, config, item_cate_list, device="cuda:0", seed=1234, group=None):
+    def __init__(self, config, item_cate_list, device="cuda:0", seed=1234, group=None, l2_mode="dense"):
+        """l2_mode: "dense" -- every owner decays every one of its rows every step, as the reference's dense L2
+        gradient does; "lazy" (sgd) -- the same update kept as W = P * W_stored with one scale P that all ranks
+        advance alike, so an owner touches only the rows whose gradients arrived (tlsan_shard_apply_lazy)."""
+        if l2_mode not in ("dense", "lazy"):
+            raise ValueError("l2_mode must be 'dense' or 'lazy'")
+        self.lazy = l2_mode == "lazy"
         if not dist.is_initialized():
             raise RuntimeError("ShardedModel needs torch.distributed to be initialised (one process per GPU)")
         from .model import OPTIMIZERS
@@ -270,6 +276,8 @@ class ShardedModel:
         if not 0.0 <= self.dropout < 1.0:
             raise ValueError("dropout must be in [0, 1)")
         self._seed = int(seed)
+        if self.lazy and self.optimizer != "sgd":
+            raise NotImplementedError("l2_mode='lazy' is the SGD update's form; optimizer=%r sweeps every row" % self.optimizer)
         self.config = config
         self.lib = L.load()
         self.group = group
@@ -309,7 +317,14 @@ class ShardedModel:
         # all-reduced vector: dense grads | cate grads | mean BCE | per-use squares | local table squares | pad
         self._flat = torch.zeros(self.lay.n_dense + Cc * self.dc + 4, dtype=torch.float32, device=dev)
         self._gn_local = torch.zeros(1, dtype=torch.float32, device=dev)
-        self._step_dev = torch.zeros(2, dtype=torch.float32, device=dev)     # lr * coef, coef
+        self._step_dev = torch.zeros(4, dtype=torch.float32, device=dev)     # lr * coef, coef, (lazy:) lr * coef / P_new, P_new
+        self.renorm_every = 4096
+        self._P = torch.ones(1, dtype=torch.float32, device=dev)            # lazy L2: tables = P * stored
+        if self.lazy:
+            self._slots64 = torch.zeros(self.router.R * self.world, dtype=torch.int64, device=dev)
+            self._lws = None
+            self._sopt_lazy = L.ShardOptimizer(L.OPT_SGD, 0, 0.0, 0.0, 0.0, None, None, None, None, None, None,
+                                               self._P.data_ptr())
         # adam / rmsprop / adadelta: accumulators laid out like what they belong to (RMSProp's first starts at one)
         self._sopt = None
         if self.optimizer != "sgd":
@@ -526,7 +541,7 @@ class ShardedModel:
         base = (self.shard if table is None else table).data_ptr()   # (None: only item_cate is looked at)
         cp = L.Params(base, base + 4 * self.di, base, base + 4 * self.di, self.cate_emb.data_ptr(),
                       self.dense.data_ptr(), self.dense_KT.data_ptr(), sl["cate_c"].data_ptr(),
-                      self.W, self.W, self.W, self.W, None)
+                      self.W, self.W, self.W, self.W, self._P.data_ptr() if self.lazy else None)
         # rows [n, pad) of the padded table are never referenced (no use, category -1)
         n = self._rows_pad
         dims = L.Dims(n, n, self.C, self.d, self.di, self.dc, self.H, self.Ls)
@@ -633,6 +648,8 @@ class ShardedModel:
         if self._sopt is not None:
             self._sopt.step = self._step + 1
         sopt = None if self._sopt is None else C.byref(self._sopt)
+        if self.lazy:
+            sopt = C.byref(self._sopt_lazy)
         L.check(self.lib.tlsan_shard_summary_opt(fp, n_dense, n_cate, G, float(lr), self.reg, self.clip,
                                                  self._sq.data_ptr() + 8, self.dense.data_ptr(), self.dense_KT.data_ptr(),
                                                  C.byref(self.dims_full), self._step_dev.data_ptr(),
@@ -644,6 +661,24 @@ class ShardedModel:
             a2a(vals[:sl["n_recv"]], gf[:sl["n"]], sl["recv"], sl["send"], self.group)
         else:
             vals = gf
+        if self.lazy:
+            nws = int(self.lib.tlsan_shard_apply_lazy_workspace(sl["n_recv"], Cc))
+            if self._lws is None or self._lws.numel() < nws:
+                self._lws = torch.empty(int(nws * 1.5) + 256, dtype=torch.uint8, device=dev)
+            L.check(self.lib.tlsan_shard_apply_lazy(self.shard.data_ptr(), W, self.cI, self.router.R, W, di, di + Ls,
+                                                    vals.data_ptr(), W, sl["recv_rows"].data_ptr(), sl["n_recv"],
+                                                    sl["src_off"], G, self._slots64.data_ptr(), (self._step + 1) & 0xFFFFFFFF,
+                                                    1.0 / G, self._step_dev.data_ptr(), self.cate_emb.data_ptr(), Cc, self.dc,
+                                                    fp + 4 * n_dense, self._sq.data_ptr(), tail + 8, self._P.data_ptr(),
+                                                    self._lws.data_ptr(), self._lws.numel(), st), "tlsan_shard_apply_lazy")
+            self._step += 1
+            self._keep = (table, gf, vals, sl["recv_rows"])
+            if self.renorm_every and self._step % self.renorm_every == 0:
+                self.fold_scale()
+            if ndb is not None:
+                nsl = self._plan_stage2(self._slots[self._next_slot])
+                self._prepare_side(ndb, nsl)
+            return db
         L.check(self.lib.tlsan_shard_apply_opt(self.shard.data_ptr(), W, self.cI, self.router.R, W, di, di + Ls,
                                                vals.data_ptr(), W, sl["recv_rows"].data_ptr(), sl["n_recv"], sl["src_off"],
                                                G, self._slots_buf.data_ptr(), 1.0 / G, self._step_dev.data_ptr(), self.reg,
@@ -697,7 +732,8 @@ class ShardedModel:
         ldims = L.Dims(self.U, max(nloc, 1), self.C, self.d, self.di, self.dc, self.H, self.Ls)
         base = self.shard.data_ptr()
         lp = L.Params(base, base + 4 * self.di, base, base + 4 * self.di, self.cate_emb.data_ptr(), self.dense.data_ptr(),
-                      self.dense_KT.data_ptr(), self._icl_local.data_ptr(), self.W, self.W, self.W, self.W, None)
+                      self.dense_KT.data_ptr(), self._icl_local.data_ptr(), self.W, self.W, self.W, self.W,
+                      self._P.data_ptr() if self.lazy else None)
         nws = self.lib.tlsan_workspace_bytes(C.byref(ldims), Bt, 0)
         if self._ews is None or self._ews.numel() < nws:
             self._ews = torch.empty(int(nws * 1.25), dtype=torch.uint8, device=self.device)
@@ -750,8 +786,23 @@ class ShardedModel:
     def _table_views(self):
         return self.shard[:self.cI], self.shard[self.cI:]
 
+    def fold_scale(self):
+        """lazy L2: multiply the scale into the stored tables (P -> 1); what is trained does not change.
+        Done on a fixed schedule (renorm_every) so that P stays away from fp32 underflow, and before the
+        parameters are read."""
+        if not self.lazy:
+            return
+        P = self._P
+        di, Ls = self.di, self.Ls
+        self.shard[:self.cI, :di].mul_(P)
+        self.shard[self.cI:, :di + Ls].mul_(P)
+        self.cate_emb.mul_(P)
+        self._P.fill_(1.0)
+        self._refresh_squares()
+
     def gather_params(self):
         """Full (un-sharded) parameters on every rank, as numpy (tests / checkpoints)."""
+        self.fold_scale()
         if self.world > 1:
             # (RCCL gathers device buffers; gloo, used by the single-GPU multi-process tests, host ones)
             src = self.shard.cpu() if _staged(self.group) else self.shard
@@ -790,6 +841,7 @@ class ShardedModel:
         can be saved.  sharded=False gathers everything to rank 0 and writes the single-GPU format of
         tlsan_amd.model.Model.save (restores into either model, any world size).  Returns the path prefix."""
         import json
+        self.fold_scale()
         os.makedirs(self.config["model_dir"], exist_ok=True)
         base = os.path.join(self.config["model_dir"], "TLSAN-%d" % self._step)
         if not sharded:
@@ -826,6 +878,7 @@ class ShardedModel:
             if tuple(zs["shard"].shape) != tuple(self.shard.shape) or int(zs["cI"]) != self.cI:
                 raise ValueError("shard shape %s does not match this model" % (zs["shard"].shape,))
             self.shard.copy_(torch.as_tensor(zs["shard"]))
+            self._P.fill_(1.0)
             self.cate_emb.copy_(torch.as_tensor(rep_["cate_emb"]))
             self.dense.copy_(torch.as_tensor(rep_["dense"]))
             K = self.dense[self.lay.K:self.lay.K + self.d * self.d].view(self.d, self.d)
@@ -858,5 +911,6 @@ class ShardedModel:
         t[self.cI:self.cI + len(gu), di:di + Ls] = np.asarray(p["usert_emb"], np.float32)[gu]
         self.shard.copy_(torch.as_tensor(t))
         self.cate_emb.copy_(torch.as_tensor(np.asarray(p["cate_emb"], np.float32)))
+        self._P.fill_(1.0)
         self._pack_dense(p)
         self._refresh_squares()

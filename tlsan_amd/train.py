@@ -230,7 +230,7 @@ def train_sharded(args):
     train_set, test_set, (U, I, Cc), icl = load_dataset(args.dataset)
     config = {name: getattr(args, name) for name, _, _ in FLAGS}
     config.update(user_count=U, item_count=I, cate_count=Cc, from_scratch=args.from_scratch)
-    model = ShardedModel(config, icl, device=args.device)
+    model = ShardedModel(config, icl, device=args.device, l2_mode=args.l2_mode if args.optimizer == "sgd" else "dense")
     dev = model.device
 
     def reduce_sum(vals):
