@@ -258,7 +258,11 @@ typedef struct {
   int32_t ld_item, ld_itemb, ld_user, ld_usert;
   /* != 0: rows that received no gradient are not written (the caller zeroed the buffers).  With
    * strides this lets item and user gradients land in ONE fused [rows, W] buffer when a row is
-   * only ever used as one kind (the compact per-step table of the sharded path). */
+   * only ever used as one kind (the compact per-step table of the sharded path).
+   * 2 (with hp->reg == 0 and the tf18 norm, the pure row-sum path): the four row outputs ARE one fused
+   * table of rows [item_emb | item_b | pad] / [user_emb | usert_emb | pad] of width ld_item == ld_user;
+   * a written row is written in full (its unowned tail cleared), so only rows that received no
+   * gradient keep the caller's content -- the buffer need not be zeroed when every row sent on is used. */
   int32_t sparse;
 } tlsan_grads_out;
 int tlsan_grads(const tlsan_dims* dims, const tlsan_params* p, const tlsan_batch* b,

@@ -819,7 +819,8 @@ int tlsan_grads(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch* b
   if (hp->reg == 0.0f && g->sparse && hp->norm_mode == TLSAN_NORM_TF18) {
     // pure per-row sums of the used rows (what the sharded step asks for): they ride with the dense
     // finalize as in the lazy train step, written straight to the output rows -- no apply launch
-    A.presum_rows = 1;
+    // (sparse == 2: the four outputs are views of ONE fused row table, see tlsan_grads_out)
+    A.presum_rows = g->sparse == 2 ? 2 : 1;
     A.Rc = g->cate_emb;
     category_split(A, d, b);
     if ((rc = run_backward(d, s, p, b, hp, false, out, w, st, L, hs, &A, g->dense))) return rc;

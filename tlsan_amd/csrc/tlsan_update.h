@@ -1066,6 +1066,13 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
         if (IS_ITEM) (by_row ? a.go.item_b[(size_t)row * a.go.ld_itemb] : a.Rb[slot]) = (float)bacc;
         if (n > 0) (IS_ITEM ? a.cnt_item : a.cnt_user)[row] = 0;
       }
+      if (a.presum_rows == 2) {
+        // fused rows [item_emb | item_b | pad] / [user_emb | usert_emb | pad] of one width (the sharded step):
+        // a row is written by exactly one of the two views -- clear the rest of it, so that the caller's
+        // buffer need not be zeroed
+        const int first = IS_ITEM ? a.di + 1 : a.di + a.Ls, width = IS_ITEM ? a.go.ld_item : a.go.ld_user;
+        for (int c = first + l16; c < width; c += 16) R[c] = 0.0f;
+      }
     }
     return;
   }

@@ -627,9 +627,11 @@ class ShardedModel:
         flat = self._flat
         fp = flat.data_ptr()
         # per-row gradients land directly in the fused layout (a compact row is an item or a user)
-        gf = torch.zeros(n, W, dtype=torch.float32, device=dev)
+        # (every compact row below sl["n"] is used by this batch and written in full: no zero fill; the rows
+        #  past it are padding that is never sent on)
+        gf = torch.empty(n, W, dtype=torch.float32, device=dev)
         g0 = gf.data_ptr()
-        go = L.GradsOut(g0, g0 + 4 * di, g0, g0 + 4 * di, fp + 4 * n_dense, fp, W, W, W, W, 1)
+        go = L.GradsOut(g0, g0 + 4 * di, g0, g0 + 4 * di, fp + 4 * n_dense, fp, W, W, W, W, 2)
         tail = fp + 4 * (n_dense + n_cate)
         out = L.StepOut(tail, self._gn_local.data_ptr(), None, tail + 4)
         hp = L.HParams(float(lr), 0.0, self.clip, L.NORM_TF18, L.L2_DENSE, 0, 1 if prepared else 0,   # reg: applied by the owners
