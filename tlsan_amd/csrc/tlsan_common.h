@@ -98,8 +98,14 @@ struct Geo {
   static constexpr int TSTR = 20;               // LDS row stride of the 16x16 transpose tiles
   // per-wave LDS scratch (floats): 4*NB transpose tiles, or the staged gradient accumulators
   static constexpr int TBUF = 4 * NB * 16 * TSTR;   // one buffer: x, dz1, m1, dm2 tiles
-  static constexpr int NBUF = 1;                    // (double-buffering the tiles bought nothing measurable)
-  static constexpr bool KEEP_A = NB == 1;           // long block's softmax weights kept in LDS for the backward
+#ifndef TLSAN_EXP_NBUF
+#define TLSAN_EXP_NBUF 1
+#endif
+  static constexpr int NBUF = TLSAN_EXP_NBUF;       // (double-buffering the tiles bought nothing measurable)
+#ifndef TLSAN_EXP_KEEP_A
+#define TLSAN_EXP_KEEP_A 1
+#endif
+  static constexpr bool KEEP_A = NB == 1 && TLSAN_EXP_KEEP_A;   // long block's softmax weights kept in LDS for the backward
   static constexpr bool USE_SW = true;              // attention weights staged in LDS
   // NB > 1 (d = 256): six 16-register weight fragments cannot stay in registers for a whole phase:
   // the window-in-registers variants re-read them from LDS at every position (behind a value the
