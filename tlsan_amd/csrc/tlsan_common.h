@@ -95,7 +95,10 @@ struct Geo {
   static constexpr int NT = D / 16;             // 16-col tiles of the bridge GEMM
   static constexpr int TPW = RT * NT / NW;      // bridge tiles per wavefront
   static constexpr int LSTR = D + 4;            // LDS row stride of [sample][channel] buffers
-  static constexpr int TSTR = 20;               // LDS row stride of the 16x16 transpose tiles
+#ifndef TLSAN_EXP_TSTR
+#define TLSAN_EXP_TSTR 20
+#endif
+  static constexpr int TSTR = TLSAN_EXP_TSTR;   // LDS row stride of the 16x16 transpose tiles
   // per-wave LDS scratch (floats): 4*NB transpose tiles, or the staged gradient accumulators
   static constexpr int TBUF = 4 * NB * 16 * TSTR;   // one buffer: x, dz1, m1, dm2 tiles
 #ifndef TLSAN_EXP_NBUF
