@@ -152,6 +152,7 @@ struct St {  // persistent state
   long long* scan_bsum[2];                                // per-chunk sums of the index scan (large tables), per slot
   int32_t* uc_list[2];                                    // samples of every category (u_cate uses), UC_LIST_CAP each
   double* Rc64;                                           // category sums of a split PRESUM pass, zero at rest
+  int32_t* hot_list[2];                                   // slots (urec_item) of the hot item rows, AP_HOT_CAP each
   size_t bytes;
   int nbI, nbU, nbC;
 };
@@ -183,6 +184,7 @@ static void carve_state(const tlsan_dims* d, char* base, St* s) {
   s->S_part = (double*)take(8 * (size_t)(s->nbI + s->nbU + s->nbC));
   for (int k = 0; k < 2; ++k) s->uc_list[k] = (int32_t*)take(4 * (size_t)UC_LIST_CAP);
   s->Rc64 = (double*)take(8 * (size_t)d->cate_count * d->d_cate);
+  for (int k = 0; k < 2; ++k) s->hot_list[k] = (int32_t*)take(4 * (size_t)AP_HOT_CAP);
   for (int k = 0; k < 2; ++k)
     s->scan_bsum[k] = (long long*)take(8 * ((size_t)(d->item_count + 4095) / 4096 + (d->cate_count + 4095) / 4096 +
                                             (d->user_count + 4095) / 4096));
@@ -276,6 +278,7 @@ static void fill_apply(ApplyArgs& A, const tlsan_dims* d, const Shape& s, const 
   A.uc_list = uc_by_list(d, b) ? st.uc_list[k] : nullptr;
   A.Rc64 = st.Rc64;
   A.csplit = 1; A.cpass = 256;
+  A.hot_n = st.hdr ? &st.hdr->n_hot[k] : nullptr; A.hot_list = st.hot_list[k]; A.nbH = 0;
   A.gd = w.gd;
   A.Rc = w.Rc; A.Ri = w.Ri; A.Rb = w.Rb; A.Ru = w.Ru;
   A.part_out = st.S_part; A.hdr = st.hdr;
@@ -564,6 +567,7 @@ static int build_index(const tlsan_dims* d, const tlsan_batch* b, const St& st, 
   CountArgs ca;
   memset(&ca, 0, sizeof(ca));
   ca.b = *b; ca.Ls = d->Ls;
+  ca.n_hot = &st.hdr->n_hot[k];
   ca.cnt_item = st.cnt_item[k]; ca.cnt_user = st.cnt_user[k]; ca.cnt_uc = st.cnt_uc[k];
   const int nthr = b->B * (d->Ls + b->Sn + 2);
   hipLaunchKernelGGL(k_count, dim3((nthr + 255) / 256), dim3(256), 0, hs, ca);
@@ -579,6 +583,7 @@ static int build_index(const tlsan_dims* d, const tlsan_batch* b, const St& st, 
   sa.blk0[2] = sa.blk0[1] + (sa.n[1] + 4095) / 4096;
   const int nscan = sa.blk0[2] + (sa.n[2] + 4095) / 4096;
   sa.urec[0] = st.urec_item[k]; sa.urec[2] = st.urec_user[k];
+  sa.hot_n[0] = &st.hdr->n_hot[k]; sa.hot_list[0] = st.hot_list[k];
   sa.total[0] = sa.total[1] = sa.total[2] = 1;
   sa.n_uniq[0] = &st.hdr->n_uniq[k][0]; sa.n_uniq[1] = nullptr; sa.n_uniq[2] = &st.hdr->n_uniq[k][1];
   if ((rc = launch_scan(sa, nscan, st.scan_bsum[k], hs))) return rc;
@@ -654,7 +659,8 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
     ApplyArgs A = *presum;
     lazy_blocks(A, b->B, b->Sn);
     A.nbC = A.C * A.csplit;
-    const dim3 grid(w.nfin + 1 + A.nbC + A.nbI + A.nbU);
+    A.nbH = AP_HOT_CAP;   // hot item rows: a workgroup each, leading the grid
+    const dim3 grid(w.nfin + 1 + A.nbH + A.nbC + A.nbI + A.nbU);
     const bool wide = apply_wide(A);
 #define FP_LAUNCH(DD, HH)                                                                                         \
   do {                                                                                                            \

@@ -21,14 +21,18 @@ struct StateHdr {
   float coef;              // global-norm clip coefficient of the current step (model.py:201)
   uint32_t nstep;          // update steps taken (salt of the stochastic rounding of bf16 tables)
   int32_t spart_n;         // leading entries of S_part the last update may have written (the rest is zero)
-  float pad0[21];
+  int32_t n_hot[2];        // [index slot] item rows with more than AP_HOT uses (k_index_scan; listed in the state)
+  float pad0[19];
   // ---- its own 128-B line: hammered by atomics, must not share a line with anything that is read
   int32_t ticket;          // arrival counter of k_dense_finalize: the last workgroup writes the step summary
   int32_t pad1[31];
 };
 static_assert(sizeof(StateHdr) == 256, "StateHdr layout");
 
+#define AP_HOT 48        // item rows with more uses than this are summed by a workgroup of their own ...
+#define AP_HOT_CAP 64    // ... when there are at most this many (the head of a Zipf distribution: a handful)
 struct CountArgs {
+  int32_t* n_hot;       // reset here for the scan that follows
   tlsan_batch b;
   int32_t Ls;
   int32_t* cnt_item; int32_t* cnt_user; int32_t* cnt_uc;  // persistent, zero at rest
@@ -41,6 +45,7 @@ struct CountArgs {
 __global__ void k_count(CountArgs a) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int B = a.b.B, Ls = a.Ls, Sn = a.b.Sn, S = Ls + Sn + 2;
+  if (t == 0 && a.n_hot) *a.n_hot = 0;
   if (t >= B * S) return;
   const int b = t / S, slot = t - b * S;
   if (slot < Ls) {
@@ -116,6 +121,7 @@ struct ScanArgs {
   int4* urec[3];       // optional: (id, first position, count) of the ids with cnt > 0 (lazy L2: rows to update)
   int32_t total[3];    // != 0: off has n+1 entries, off[n] = sum of all counts
   long long* bsum;     // optional [gridDim.x]: per-chunk packed sums (k_scan_block_sums) -- large tables
+  int32_t* hot_n[3]; int32_t* hot_list[3];   // optional (with urec): slots of the rows with more than AP_HOT uses
 };
 #define SCAN_TWO_LEVEL_BLOCKS 16  // tables of more chunks than this take the two-launch form
 
@@ -217,6 +223,10 @@ __global__ __launch_bounds__(1024) void k_index_scan(ScanArgs a) {
       if (cur) cur[i0 + k] = o;
       if (uniq && v[k] > 0) uniq[(int)(run >> 32)] = i0 + k;
       if (urec && v[k] > 0) urec[(int)(run >> 32)] = make_int4(i0 + k, o, v[k], 0);
+      if (urec && a.hot_n[which] && v[k] > AP_HOT) {
+        const int h = atomicAdd(a.hot_n[which], 1);
+        if (h < AP_HOT_CAP) a.hot_list[which][h] = (int)(run >> 32);
+      }
       run += pack(v[k]);
       if (i0 + k == n - 1) {
         if (a.n_uniq[which]) *a.n_uniq[which] = (int)(run >> 32);
@@ -574,6 +584,9 @@ struct ApplyArgs {
   // sums of 2^-40-grid values are exact in any order, so the result stays bitwise reproducible;
   // k_update_lazy rounds them to float (as a single workgroup would have) and clears them
   int32_t csplit, cpass;
+  // hot item rows (more than AP_HOT uses) get a workgroup each in the row-sum pass: nbH = AP_HOT_CAP such
+  // workgroups lead the grid, the item-row workgroups leave those rows to them (when the list did not overflow)
+  const int32_t* hot_n; const int32_t* hot_list; int32_t nbH;
   double* Rc64;            // [C][dc], zero at rest (state)
   double* part_out;        // UPDATE: change of the stored tables' sum of squares per workgroup;
                            // SUMSQ: sum of squares; ROWNORM: sum g^2
@@ -946,6 +959,9 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
     const int4 r = (IS_ITEM ? a.urec_item : a.urec_user)[slot];  // (row, first position, uses)
     vr = slot < nuq;
     if (vr) { row = r.x; off = r.y; n = r.z; }
+    if constexpr (MODE == AP_PRESUM && IS_ITEM) {
+      if (a.nbH > 0 && n > AP_HOT && *a.hot_n <= AP_HOT_CAP) { vr = false; n = 0; }   // a hot-row workgroup sums it
+    }
   } else {
     vr = slot < (IS_ITEM ? a.I : a.U);
     if (vr) row = slot;
@@ -1177,6 +1193,78 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
   if constexpr (MODE != AP_GRADS) block_part_store(part, shp, &a.part_out[x.blk]);
 }
 
+// ================= one hot item row per workgroup (PRESUM) =================
+template <int NCH>
+__device__ __forceinline__ void presum_hot_block(const ApplyArgs& a, int h, double* shd, double* shp) {
+  const int nh = *a.hot_n;
+  if (nh > AP_HOT_CAP || h >= nh) return;  // (workgroup-uniform) list overflowed: the item-row workgroups kept the rows
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, grp = lane >> 4, l16 = lane & 15, gid = wave * 4 + grp;
+  const int slot = a.hot_list[h];
+  const int4 r = a.urec_item[slot];
+  const int row = r.x, off = r.y, n = r.z;
+  const int W4 = a.di / 4;
+  double acc[NCH][4];
+  zero_acc(acc);
+  for (int k = off + gid; k < off + n; k += 16 * AP_OWN) {
+    f32x4 v[AP_OWN][NCH];
+#pragma unroll
+    for (int u = 0; u < AP_OWN; ++u) {
+      const int kk = k + 16 * u < off + n ? k + 16 * u : k;
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch)
+        if (l16 + 16 * ch < W4) v[u][ch] = *(const f32x4*)(a.Gi + (size_t)kk * a.D + 4 * (l16 + 16 * ch));
+    }
+#pragma unroll
+    for (int u = 0; u < AP_OWN; ++u)
+      if (k + 16 * u < off + n) {
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+          if (l16 + 16 * ch < W4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[ch][i] += exact_term(v[u][ch][i]);
+          }
+      }
+  }
+  double tb = 0.0;
+  for (int k = off + tid; k < off + n; k += 256) tb += exact_term(a.Gb[k]);
+  combine_groups(acc);
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) tb += __shfl_xor(tb, o);
+  if (grp == 0) {
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) shd[((wave * 16 + l16) * NCH + ch) * 4 + i] = acc[ch][i];
+  }
+  if (lane == 0) shp[wave] = tb;
+  __syncthreads();
+  if (wave == 0 && grp == 0) {
+    const bool by_row = a.presum_rows != 0;
+    float* R = by_row ? a.go.item_emb + (size_t)row * a.go.ld_item : a.Ri + (size_t)slot * a.di;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int c4 = l16 + 16 * ch;
+      if (c4 < W4) {
+        f32x4 g;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          double s = 0.0;
+          for (int w_ = 0; w_ < 4; ++w_) s += shd[((w_ * 16 + l16) * NCH + ch) * 4 + i];
+          g[i] = (float)s;
+        }
+        *(f32x4*)(R + 4 * c4) = g;
+      }
+    }
+    if (l16 == 0) {
+      const float gb = (float)((shp[0] + shp[1]) + (shp[2] + shp[3]));
+      (by_row ? a.go.item_b[(size_t)row * a.go.ld_itemb] : a.Rb[slot]) = gb;
+      a.cnt_item[row] = 0;
+    }
+    if (a.presum_rows == 2)
+      for (int c = a.di + 1 + l16; c < a.go.ld_item; c += 16) R[c] = 0.0f;
+  }
+}
+
 // WIDE: d_item / d_cate above 64 or d_item + Ls above 128 columns (more float4 chunks per lane)
 template <int MODE, bool LAZY, bool WIDE, int DT = TLSAN_TABLE_F32>
 __global__ __launch_bounds__(256) void k_apply(ApplyArgs a) {
@@ -1273,6 +1361,11 @@ __global__ __launch_bounds__(256) void k_finalize_presum(FinArgs f, int nbK, int
   x.gid = x.wave * 4 + x.grp;
   x.blk = blockIdx.x - nfin;
   x.P = 1.0f; x.invP = 1.0f; x.step = 0.0f; x.lazy_scale = 0.0f; x.salt = 0u;
+  if (x.blk < a.nbH) {   // hot item rows lead the grid (no debug stamps)
+    presum_hot_block<NI>(a, x.blk, shd, shp);
+    return;
+  }
+  x.blk -= a.nbH;
   unsigned long long* stp = a.stamps ? a.stamps + (size_t)x.blk * 8 : nullptr;
   if (stp && x.tid == 0) { stp[0] = __builtin_amdgcn_s_memtime(); stp[4] = __builtin_amdgcn_s_memrealtime(); }
   const int blk = x.blk;
