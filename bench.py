@@ -2,7 +2,10 @@
 """bench.py -- user-sequences/s of the TLSAN train step (forward + backward + update) on the
 Electronics-scale synthetic workload (BASELINE.json configs[2] shapes; SURVEY.md 8d inputs).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]           (N>1: launched by torch.distributed.run)
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  (N > 1: one process per GPU.  Under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`
+   the ranks come from the launcher's environment; started plainly, bench.py launches its N rank processes
+   itself -- before this process touches the GPU -- and relays rank 0's JSON line.)
 
 One "step" = one pass of the hot path over one batch of 4096 synthetic user-sequences that is
 already resident in HBM.  Rank 0 prints ONE JSON line with the whole-job throughput, the
@@ -52,7 +55,85 @@ def parse():
     ap.add_argument("--event-every", type=int, default=8,
                     help="every Nth timed step carries the HIP events that bracket k_fwd_bwd (graph mode: runs eagerly)")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded (multi-GPU) code path even at N=1")
+    ap.add_argument("--accuracy-steps", type=int, default=2000,
+                    help="accuracy leg (rank 0, N=1): train steps of the reference protocol on the real Digital-Music samples, "
+                         "HIP path and fp64 oracle side by side, then AUC / P@20 / R@20 of both (0: skip)")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """--gpus N > 1 without a launcher's environment: start the N ranks as child processes (this process has not
+    imported torch or touched a GPU yet; it never replaces itself), relay rank 0's JSON line, fail if any rank fails."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    text = out.decode(errors="replace")
+    lines = [l for l in text.splitlines() if l.startswith("{") and '"metric"' in l]
+    if any(codes) or not lines:
+        sys.stderr.write(text[-4000:])
+        raise SystemExit("bench.py: rank exit codes %s" % codes)
+    print(lines[-1], flush=True)
+
+
+def accuracy_leg(nsteps, dev):
+    """BASELINE.json's metric names accuracy beside throughput ("AUC@20": AUC, and P@20 / R@20): the
+    reference's protocol (train.py:26-49: d=64, batch 32, lr 1.0, L2 5e-5, clip 5; its shuffle stream) on the real
+    Digital-Music samples for `nsteps` steps, HIP path and fp64 oracle from the same initial values on the same
+    batches, then test AUC (model.py:263) and P@20 / R@20 (model.py:146,153) of both.  The oracle is the checker."""
+    from oracle import tlsan_oracle as orc
+    from tlsan_amd import synth
+    from tlsan_amd.input import DataInput, DataInputTest, load_packed
+    from tlsan_amd.model import Model
+    from tlsan_amd.train import epoch_rng
+    path = os.path.join(ROOT, "tests", "golden", "packed_digital_music.npz")
+    train_set, test_set, (U, I, C), icl = load_packed(path)
+    cfg = synth.make_config("clothing", hidden_units=64, itemid_embedding_size=32, userid_embedding_size=32,
+                            cateid_embedding_size=32, user_count=U, item_count=I, cate_count=C)
+    m = Model(cfg, icl, device=dev)
+    p = {k: v.astype(np.float64) for k, v in m.get_params().items()}
+    rng, step, t_gpu, t_orc = epoch_rng(), 0, 0.0, 0.0
+    while step < nsteps:
+        train_set.shuffle(rng)
+        for _, batch in DataInput(train_set, 32, 10):
+            t0 = time.perf_counter()
+            m.train_async(batch, 1.0)
+            t1 = time.perf_counter()
+            _, p, _ = orc.train_step(p, icl, orc.as_batch(batch), 8, cfg["regulation_rate"], 1.0)
+            t_gpu, t_orc = t_gpu + t1 - t0, t_orc + time.perf_counter() - t1
+            step += 1
+            if step >= nsteps:
+                break
+    ks, n = (1, 10, 20, 30, 40, 50), len(test_set)
+    g_auc = o_auc = 0.0
+    o_hits = np.zeros(len(ks))
+    for _, tb in DataInputTest(test_set, 128, 10):
+        g_auc += m.eval_auc(None, tb) * len(tb[0])
+        m.eval_prec(None, tb)
+        m.eval_recall(None, tb)
+        ob = orc.as_batch(tb, True)
+        a, _, _ = orc.eval_auc_batch(p, icl, ob, 8)
+        o_auc += a * len(tb[0])
+        ut = orc.forward(p, icl, dict(ob, y=np.zeros(len(tb[0]))), 8)["u_t"]
+        o_hits += np.asarray(orc.hits_at_k(orc.all_item_scores(p, icl, ut), np.asarray(tb[1]), ks), np.float64)
+    gp, gr = m.prec_20.eval(), m.recall_20.eval()
+    return {"dataset": "Digital-Music (real samples, tests/golden/packed_digital_music.npz)", "steps": step,
+            "protocol": "reference defaults (d=64, batch 32, lr 1.0, L2 5e-5, clip 5, train.py's shuffle stream); README.md:35 "
+                        "reports 0.9753 after 20 epochs (23.7 k steps)",
+            "hip": {"auc": round(g_auc / n, 6), "p_at_20": round(float(gp), 6), "r_at_20": round(float(gr), 6)},
+            "oracle_fp64": {"auc": round(o_auc / n, 6), "p_at_20": round(float(o_hits[2] / (20 * n)), 6),
+                            "r_at_20": round(float(o_hits[2] / n), 6)},
+            "auc_abs_diff": round(abs(g_auc - o_auc) / n, 9), "test_users": n}
 
 
 def cpu_baseline(cfg, icl, batch, seconds):
@@ -118,6 +199,8 @@ def cpu_baseline(cfg, icl, batch, seconds):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -229,13 +312,20 @@ def main():
         k_flops = float(np.mean([synth.algorithmic_flops(cfg, host_batches[(args.warmup + s) % len(host_batches)]) for s in range(args.steps)]))
         k_ms = float(seg[:, 1].mean()) if nrec else float("nan")
         achieved = k_bytes / (k_ms * 1e-3) / 1e9 if nrec else None
-        traffic = None
+        # HBM-side bytes per launch of the dominant kernel come from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in
+        # separate runs, FETCH doubled per MI355X_MICROARCH.md); counters cannot be read from inside this process, so
+        # the line carries the committed measurement WITH its provenance (profiles/traffic.json, scripts/refresh_profiles.sh)
+        traffic = traffic_src = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.workload == "electronics" and B == cfg["train_batch_size"] and eb == 4 and not sharded:
             try:
-                traffic = json.load(open(tpath)).get("k_fwd_bwd_hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("k_fwd_bwd_hbm_bytes_per_launch")
+                traffic_src = {"bytes": traffic, "source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                               "passes, FETCH doubled; not measured by this run)", "round": tj.get("round"),
+                               "FETCH_SIZE_KB": tj.get("FETCH_SIZE_KB"), "WRITE_SIZE_KB": tj.get("WRITE_SIZE_KB")}
             except Exception:
-                traffic = None
+                traffic = traffic_src = None
         out = {
             "metric": "user-sequences/sec (train step: fwd+bwd+update), Electronics-scale",
             "value": round(seqs / dt, 1),
@@ -261,7 +351,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_fwd_bwd", "achieved": None if achieved is None else round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": round(k_bytes), "kernel_ms": round(k_ms, 5),
                          "step_algorithmic_bytes": round(step_bytes),
                          "step_frac": round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
@@ -283,6 +373,8 @@ def main():
             out["segments_ms"] = {n: round(float(seg[:, i].mean()), 5) for i, n in enumerate(L.PROF_SEGMENTS)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, icl, host_batches[0], args.cpu_seconds)
+        if args.accuracy_steps > 0 and world == 1 and not sharded:
+            out["accuracy"] = accuracy_leg(args.accuracy_steps, dev)
         result = json.dumps(out)
     else:
         result = None

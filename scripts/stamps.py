@@ -14,7 +14,7 @@ db = m.device_batch(synth.make_batches(cfg, 1, B, seed=7)[0])
 for _ in range(5):
     m.train_async(db, 1.0)
 nblk = (B + 15) // 16
-NWV = 8 if os.environ.get('TLSAN_FWD_V2') == '0' else 16   # wavefronts per workgroup of the kernel that runs
+NWV = 16 if os.environ.get('TLSAN_FWD_V2') == '1' else 8   # wavefronts per workgroup of the kernel that runs
 st = torch.zeros((1 << 20) + 8 * 8192, dtype=torch.int64, device="cuda")   # k_apply stamps live from entry 2^20 on
 lib.tlsan_debug_stamps(st.data_ptr())
 m.train_async(db, 1.0)

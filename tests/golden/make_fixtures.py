@@ -27,6 +27,16 @@ DATASETS = {
     "digital_music": "Digital_Music",
     "clothing": "Clothing_Shoes_and_Jewelry",
 }
+# the other five datasets the reference ships (README.md:36,38-41): their review logs are exported like the
+# two above; of what the real build_dataset.py builds from them only a digest is kept (sha256 per array of
+# the CSR export + sizes + the first samples): tests/golden/digest_<name>.json
+MORE = {
+    "beauty": "Beauty",
+    "home_kitchen": "Home_and_Kitchen",
+    "office": "Office_Products",
+    "toys": "Toys_and_Games",
+    "video_games": "Video_Games",
+}
 
 
 def build_dataset(data_name):
@@ -115,7 +125,7 @@ def export_reviews():
     log (reviewerID, asin, unixReviewTime in days; DataFrame row order), the item -> category map
     and the counts that ``Data/<name>.pkl`` holds.  Together with ``packed_<name>.npz`` (the tuples
     the real script built from it) this pins tlsan_amd/build_dataset.py."""
-    for short, data_name in DATASETS.items():
+    for short, data_name in {**DATASETS, **MORE}.items():
         with open(os.path.join(REF, "Data", data_name + ".pkl"), "rb") as f:
             reviews_df, meta_df = pickle.load(f)
             icl = pickle.load(f)
@@ -130,9 +140,62 @@ def export_reviews():
         print("reviews_%s.npz: %d rows" % (short, len(reviews_df)))
 
 
+def digest(tr, te, counts, icl):
+    """sha256 of every array of the CSR export (dtypes normalised as tlsan_amd.input.PackedSet holds them)."""
+    import hashlib
+    norm = dict(u=np.int64, hist_off=np.int64, hist=np.int64, hist_t=np.float32, sess_off=np.int64, sess=np.int64,
+                cate=np.int64, target=np.int64, label=np.int64, pos=np.int64, neg=np.int64)
+    out = {"counts": [int(x) for x in counts], "item_cate_list": hashlib.sha256(np.asarray(icl, np.int32).tobytes()).hexdigest()}
+    for prefix, d in (("train_", tr), ("test_", te)):
+        out[prefix + "n"] = int(len(d["u"]))
+        for k, v in d.items():
+            out[prefix + k] = hashlib.sha256(np.ascontiguousarray(np.asarray(v).astype(norm[k])).tobytes()).hexdigest()
+    out["train_head"] = {k: np.asarray(tr[k][:8]).tolist() for k in ("u", "target", "label", "cate")}
+    out["test_head"] = {k: np.asarray(te[k][:8]).tolist() for k in ("u", "pos", "neg", "cate")}
+    return out
+
+
+def export_digests():
+    import json
+    for short, data_name in MORE.items():
+        print("building", data_name, flush=True)
+        train_set, test_set, counts, icl = build_dataset(data_name)
+        print("  train %d test %d counts %s" % (len(train_set), len(test_set), counts), flush=True)
+        json.dump(digest(pack(train_set, False), pack(test_set, True), counts, icl),
+                  open(os.path.join(OUT, "digest_%s.json" % short), "w"), indent=1)
+
+
+def export_epoch_order():
+    """What the reference's training loop feeds the model: ``random.seed(1234)`` at import (train.py:15), then
+    per epoch ``random.shuffle(train_set)`` and ``DataInput(train_set, 32, Ls)`` (train.py:190-192).  train.py
+    itself cannot be imported (TensorFlow), so those two lines are executed here on the sample list the real
+    build_dataset.py built (packed_<name>.npz) with the real input.py; recorded: the first two and the last
+    batch of epochs 1 and 2 -> ``epoch_order_<name>.npz``."""
+    import random
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from tlsan_amd.build_dataset import to_samples
+    from tlsan_amd.input import load_packed
+    ref_input = load_ref_input()
+    for short in DATASETS:
+        train_set = to_samples(load_packed(os.path.join(OUT, "packed_%s.npz" % short))[0])
+        random.seed(1234)                                    # train.py:15
+        rec = {}
+        for epoch in (1, 2):
+            random.shuffle(train_set)                        # train.py:191
+            r = record_batches(ref_input, train_set, "DataInput", 32, 10, [0, 1, -1])
+            rec.update({"e%d_%s" % (epoch, k): v for k, v in r.items()})
+        np.savez_compressed(os.path.join(OUT, "epoch_order_%s.npz" % short), **rec)
+        print("epoch_order_%s.npz" % short)
+
+
 def main():
     if "--reviews-only" in sys.argv:
         return export_reviews()
+    if "--epoch-order" in sys.argv:
+        return export_epoch_order()
+    if "--digests-only" in sys.argv:
+        export_reviews()
+        return export_digests()
     export_reviews()
     ref_input = load_ref_input()
     for short, data_name in DATASETS.items():
@@ -153,6 +216,8 @@ def main():
         rec.update(record_batches(ref_input, test_set, "DataInputTest", 50, 3, [0, -1]))
         rec.update(record_batches(ref_input, train_set, "DataInput", 1024, 10, [0, -1]))
         np.savez_compressed(os.path.join(OUT, "batches_%s.npz" % short), **rec)
+    export_digests()
+    export_epoch_order()
     print("done")
 
 

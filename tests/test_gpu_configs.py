@@ -1,0 +1,308 @@
+"""GPU tests at the shapes BASELINE.json's `configs` name, all through the C ABI:
+
+  C2  Digital-Music (1659 / 1583 / 53), d = 128 (64/64/64), fp32, batch 1024 -- the real fixture batch
+      `DataInput_bs1024_k10_b0` (captured from the reference's input.py) through one train step and an
+      evaluation, against the fp64 oracle;
+  C4  Movies-TV sizes (35896 / 28589 / 15), window of 90 positions, tables row-sharded over 2 ranks
+      (two processes on cuda:0, gloo): where the oracle is too slow, properties -- bitwise determinism and
+      sharded == single-GPU `Model` on the concatenated batch;
+  C5  10 M users / 5 M items / 10 k categories, d = 256 (128/128/128), window 90, batch 4096 on one GPU:
+      bitwise determinism, lazy L2 == dense L2 (the reference's update) on every row, untouched rows not
+      written, the item_b checksum.
+Plus the driver's resume flow (train.py:71-76,124-127) and the captured-graph workspace.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tlsan_oracle as orc
+from tests.helpers import fixture_batch, make_config
+
+pytestmark = pytest.mark.gpu
+LOGIT_TOL = 1e-4
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+# ------------------------------------------------------------------------------------------- C2
+def test_c2_digital_music_batch_1024_d128():
+    from tlsan_amd.model import Model
+    batch, (U, I, C), cat = fixture_batch("digital_music", "DataInput", 1024, 10, 0)
+    assert len(batch[0]) == 1024
+    cfg = make_config(U=U, I=I, C=C, d=128)                    # 64 / 64 / 64, the reference's other defaults
+    p = {k: np.asarray(v, np.float32).astype(np.float64) for k, v in orc.init_params(cfg, seed=1234, dtype=np.float32).items()}
+    b = orc.as_batch(batch)
+    ref = orc.forward(p, cat, b, 8)
+    loss, newp, info = orc.train_step(p, cat, b, 8, cfg["regulation_rate"], lr=1.0)
+    for l2 in ("dense", "lazy"):
+        m = Model(cfg, cat, l2_mode=l2)
+        m.set_params({k: np.asarray(v, np.float32) for k, v in p.items()})
+        li, _, ut, _ = m.forward(batch, is_test=False, want_u_t=True)
+        assert np.abs(li.cpu().numpy() - ref["logits"]).max() < LOGIT_TOL
+        assert np.abs(ut.cpu().numpy() - ref["u_t"]).max() < LOGIT_TOL
+        got_loss = m.train(None, batch, 1.0)
+        assert abs(got_loss - loss) < 1e-4 * max(1.0, abs(loss)), l2
+        assert abs(m.last_gnorm() - info["norm"]) < 3e-4 * info["norm"], l2
+        got = m.get_params()
+        for k in newp:
+            du = np.asarray(got[k], np.float64).reshape(p[k].shape) - p[k]
+            dr = newp[k] - p[k]
+            assert np.abs(du - dr).max() < 3e-4 * (np.abs(dr).max() + 1e-9) + 2e-7, (l2, k)
+    # evaluation on the test fixture batch of the same dataset (test batch 128, train.py:45) with the trained weights
+    tb, _, _ = fixture_batch("digital_music", "DataInputTest", 128, 10, 0)
+    tbo = orc.as_batch(tb, is_test=True)
+    q = {k: np.asarray(v, np.float64) for k, v in got.items()}
+    ri = orc.forward(q, cat, dict(tbo, y=np.zeros(128)), 8)["logits"]
+    rj = orc.forward(q, cat, dict(tbo, i=tbo["j"], y=np.zeros(128)), 8)["logits"]
+    li, lj, _, _ = m.forward(tb, is_test=True)
+    assert np.abs(li.cpu().numpy() - ri).max() < LOGIT_TOL and np.abs(lj.cpu().numpy() - rj).max() < LOGIT_TOL
+    clear = np.abs(ri - rj) > 2e-4
+    auc = m.eval_auc(None, tb)
+    assert abs(auc - float(((ri - rj) > 0).mean())) <= (~clear).sum() / 128.0 + 1e-9
+
+
+# ------------------------------------------------------------------------------------------- C5
+def test_c5_ten_million_users_d256_window_90():
+    from tlsan_amd import synth
+    from tlsan_amd.model import Model
+    cfg = synth.make_config("electronics", Ls=90, hidden_units=256, itemid_embedding_size=128, userid_embedding_size=128,
+                            cateid_embedding_size=128, user_count=10_000_000, item_count=5_000_000, cate_count=10_000)
+    icl = synth.item_cate_list(cfg)
+    batches = synth.make_batches(cfg, 2, 4096, seed=55)
+    touched_u = np.unique(np.concatenate([np.asarray(b[0]) for b in batches]))
+    runs = {}
+    for key, mode in (("lazy", "lazy"), ("lazy2", "lazy"), ("dense", "dense")):
+        m = Model(cfg, icl, l2_mode=mode, init="device", seed=7)
+        if key == "lazy":
+            before = m.user_emb[torch.as_tensor(touched_u, device=m.device)].clone()
+            probe = torch.arange(0, cfg["user_count"], 9973, device=m.device)
+            probe = probe[~torch.isin(probe, torch.as_tensor(touched_u, device=m.device))]
+            before_probe = m.user_emb[probe].clone()
+        losses = [m.train(None, b, 1.0) for b in batches]
+        norm = m.last_gnorm()
+        if key == "lazy":    # (before the fold: in lazy mode only rows that received a gradient are written)
+            assert torch.equal(m.user_emb[probe], before_probe)
+            assert not torch.equal(m.user_emb[torch.as_tensor(touched_u, device=m.device)], before)
+        m.fold_scale()
+        torch.cuda.synchronize()
+        runs[key] = dict(m=m, losses=losses, norm=norm)
+    a, b2, dn = runs["lazy"], runs["lazy2"], runs["dense"]
+    assert a["losses"] == b2["losses"] and a["norm"] == b2["norm"]
+    for k in ("item_emb", "item_b", "user_emb", "usert_emb", "cate_emb", "dense"):
+        ta, tb, td = getattr(a["m"], k), getattr(b2["m"], k), getattr(dn["m"], k)
+        assert torch.equal(ta, tb), k                                              # bitwise reproducible
+        scale = float(td.abs().max().item())
+        assert float((ta - td).abs().max().item()) <= 3e-6 * scale + 1e-9, k       # lazy == the reference's dense update
+    assert np.allclose(a["losses"], dn["losses"], rtol=3e-6, atol=0)
+    assert abs(a["norm"] - dn["norm"]) <= 2e-5 * dn["norm"]
+    assert np.isfinite(a["losses"]).all() and a["losses"][0] > 100.0               # the L2 term of 10^7 usert rows at -1
+    # checksum: item_b moves by -lr * coef * sum_b d loss / d logit_b
+    del runs, b2, dn
+    m = a["m"]
+    bt = batches[0]
+    li, _, _, _ = m.forward(bt, is_test=False)
+    logit = li.cpu().numpy().astype(np.float64)
+    dl_sum = ((1.0 / (1.0 + np.exp(-logit))) - np.asarray(bt[2], np.float64)).sum() / len(logit)
+    ib0 = m.item_b.double().sum().item()
+    m.train(None, bt, 1.0)
+    coef = min(1.0, cfg["max_gradient_norm"] / m.last_gnorm())
+    ib1 = m.item_b.double().sum().item()
+    assert abs((ib0 - ib1) - coef * dl_sum) < 1e-5 * max(1.0, abs(dl_sum)) + 1e-6
+
+
+# ------------------------------------------------------------------------------------------- C4
+def _c4_cfg():
+    from tlsan_amd import synth
+    return synth.make_config("movies_tv", Ls=90)
+
+
+def _c4_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tlsan_amd import synth
+        from tlsan_amd.dist import ShardedModel
+        from tlsan_amd.model import Model
+        cfg = _c4_cfg()
+        icl = synth.item_cate_list(cfg)
+        B = 1024
+        per_step = [[synth.make_batches(cfg, 1, B, seed=300 + 10 * s + r)[0] for r in range(world)] for s in range(2)]
+
+        def run():
+            m = ShardedModel(cfg, icl, device="cuda:0", l2_mode="lazy")
+            losses = []
+            for per in per_step:
+                m.train_async(per[rank], 1.0)
+                losses.append(float(m.last_loss.item()))
+            return m, losses, m.gather_params()
+        m1, l1, p1 = run()
+        m2, l2, p2 = run()
+        assert l1 == l2
+        for k in p1:
+            assert np.array_equal(p1[k], p2[k]), k                  # bitwise reproducible across runs
+        if rank == 0:
+            # the same two global batches (2048 sequences) through the single-GPU model
+            def cat2(per):
+                Sn = max(np.asarray(b[4]).shape[1] for b in per)
+                cols = []
+                for c in range(9):
+                    parts = [np.asarray(b[c]) for b in per]
+                    if c == 4:
+                        parts = [np.pad(x, ((0, 0), (0, Sn - x.shape[1]))) for x in parts]
+                    cols.append(np.concatenate(parts, 0))
+                return tuple(cols)
+            ms = Model(cfg, icl, l2_mode="lazy")
+            ls = [ms.train(None, cat2(per), 1.0) for per in per_step]
+            ps = ms.get_params()
+            assert np.allclose(l1, ls, rtol=3e-6, atol=0), (l1, ls)
+            p0 = Model.init_params(cfg, 1234)
+            for k in ps:
+                du = np.asarray(p1[k], np.float64).reshape(np.shape(ps[k])) - np.asarray(p0[k], np.float64)
+                dr = np.asarray(ps[k], np.float64) - np.asarray(p0[k], np.float64)
+                assert np.abs(du - dr).max() < 5e-4 * (np.abs(dr).max() + 1e-12) + 5e-7, (k, float(np.abs(du - dr).max()), float(np.abs(dr).max()))
+        ret[rank] = "ok"
+    except Exception:
+        import traceback
+        ret[rank] = "FAIL: " + traceback.format_exc()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_c4_movies_tv_window_90_sharded_over_two_ranks():
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_c4_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    assert all(ret.get(r) == "ok" for r in range(world)), dict(ret)
+
+
+# ------------------------------------------------------------------------------------------- multi-GPU over RCCL
+def _nccl_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:%d" % rank))
+    try:
+        from tests.helpers import random_batch, random_params
+        from tlsan_amd.dist import ShardedModel
+        cfg = make_config(U=61, I=83, C=9, d=128, regulation_rate=1e-3)
+        p = {k: np.asarray(v, np.float32).astype(np.float64) for k, v in random_params(cfg, seed=17).items()}
+        _, cat = random_batch(cfg, B=4, Sn=2, seed=0)
+        tup = lambda b: (b["u"], b["i"], b["y"], b["hist_i"], b["hist_i_new"], b["hist_t"], b["sl"], b["sl_new"], b["u_cate"])
+        steps = [[random_batch(cfg, B=24, Sn=3, seed=1000 + 10 * s + r)[0] for r in range(world)] for s in range(3)]
+        for lazy in (False, True):
+            m = ShardedModel(cfg, cat, device="cuda:%d" % rank, l2_mode="lazy" if lazy else "dense")
+            m.set_params({k: np.asarray(v, np.float32) for k, v in p.items()})
+            dbs = [m.device_batch(tup(per[rank])) for per in steps]
+            losses = []
+            for k, db in enumerate(dbs):
+                m.train_async(db, 0.8, next_batch=dbs[k + 1] if k + 1 < len(dbs) else None)
+                losses.append(float(m.last_loss.item()))
+            got = m.gather_params()
+            if rank == 0:
+                q, ref = dict(p), []
+                for per in steps:
+                    Sn = max(b["hist_i_new"].shape[1] for b in per)
+                    g = {k: np.concatenate([np.pad(b[k], ((0, 0), (0, Sn - b[k].shape[1]))) if k == "hist_i_new" else b[k]
+                                            for b in per], 0) for k in per[0]}
+                    l, q, _ = orc.train_step(q, cat, g, 8, cfg["regulation_rate"], lr=0.8)
+                    ref.append(l)
+                assert np.allclose(losses, ref, rtol=2e-4, atol=1e-5), (losses, ref)
+                for k in q:
+                    du = np.asarray(got[k], np.float64).reshape(q[k].shape) - p[k]
+                    dr = q[k] - p[k]
+                    assert np.abs(du - dr).max() < 5e-4 * (np.abs(dr).max() + 1e-9) + 5e-7, (lazy, k)
+        ret[rank] = "ok"
+    except Exception:
+        import traceback
+        ret[rank] = "FAIL: " + traceback.format_exc()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_step_over_rccl(world):
+    """The production transport: one process per GPU, all-to-all / all-reduce on device buffers over RCCL.
+    Needs `world` GPUs in the box (the 1-GPU boxes of the test pool skip it; the 8-GPU node runs it)."""
+    if torch.cuda.device_count() < world:
+        pytest.skip("needs %d GPUs, found %d" % (world, torch.cuda.device_count()))
+    import torch.multiprocessing as mp
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(900)
+    assert all(ret.get(r) == "ok" for r in range(world)), dict(ret)
+
+
+# ------------------------------------------------------------------------------------------- driver + graph
+def test_driver_resume_and_from_scratch(tmp_path):
+    """train.py:124-127 (`from_scratch` wipes model_dir) and :71-76 (otherwise the latest checkpoint is
+    reloaded: parameters, global_step, epoch counter) through tlsan_amd.train."""
+    from tlsan_amd import train as T
+    ds = os.path.join(GOLDEN, "packed_clothing.npz")
+    d = str(tmp_path / "ckpt")
+    base = ["--dataset", ds, "--eval_freq", "100", "--quiet", "--model_dir", d, "--eval_topk", "0"]
+    a = T.train(T.parse(base + ["--max_steps", "200"]))
+    assert a["steps"] == 200 and os.path.exists(os.path.join(d, "TLSAN-200.npz"))
+    open(os.path.join(d, "stale.txt"), "w").write("x")
+    b = T.train(T.parse(base + ["--max_steps", "300", "--from_scratch", "false"]))
+    # resumed: starts from the saved parameters (its initial AUC is the first run's final one), counts on from 200
+    assert b["init_auc"] == pytest.approx(a["final_auc"], abs=1e-9) and b["steps"] == 300
+    assert os.path.exists(os.path.join(d, "stale.txt")) and os.path.exists(os.path.join(d, "TLSAN-300.npz"))
+    rows = [l.split(",") for l in open(os.path.join(d, "eval", "scalars.csv"))]
+    assert [int(r[0]) for r in rows if r[1] == "AUC"][:2] == [0, 100]              # both runs' rows: appended
+    c = T.train(T.parse(base + ["--max_steps", "100"]))                              # from_scratch (default): wiped
+    assert not os.path.exists(os.path.join(d, "stale.txt")) and not os.path.exists(os.path.join(d, "TLSAN-300.npz"))
+    assert c["init_auc"] == pytest.approx(a["init_auc"], abs=1e-9) and c["steps"] == 100
+    # the same data order in both fresh runs (the reference's shuffle stream): identical trajectories
+    assert c["history"][0][2] == pytest.approx(a["history"][0][2], abs=1e-12)
+
+
+def test_captured_graphs_survive_longer_sessions():
+    """a graph bakes the workspace pointer in; capturing batches of growing session length must not
+    leave earlier graphs writing into a freed block."""
+    from tests.helpers import random_batch, random_params
+    from tlsan_amd.model import Model
+    cfg = make_config(U=80, I=120, C=9, d=128)
+    p = {k: np.asarray(v, np.float32) for k, v in random_params(cfg, seed=3).items()}
+    tup = lambda b: (b["u"], b["i"], b["y"], b["hist_i"], b["hist_i_new"], b["hist_t"], b["sl"], b["sl_new"], b["u_cate"])
+    bs = [random_batch(cfg, B=64, Sn=sn, seed=40 + sn)[0] for sn in (1, 4, 9, 17)]
+    cat = random_batch(cfg, B=4, Sn=1, seed=0)[1]
+    eager = Model(cfg, cat, l2_mode="lazy"); eager.set_params(p)
+    for b in bs + bs:
+        eager.train_async(tup(b), 0.7)
+    m = Model(cfg, cat, l2_mode="lazy"); m.set_params(p)
+    graphs = [m.capture_step(tup(b), 0.7) for b in bs]      # Sn grows from capture to capture
+    assert all(g._tlsan_ws is m._ws for g in graphs)
+    m.set_params(p)                                         # (capture_step ran one warm step per batch)
+    for g in graphs + graphs:
+        m.replay(g)
+    torch.cuda.synchronize()
+    a, b_ = eager.get_params(), m.get_params()
+    for k in a:
+        assert np.array_equal(a[k], b_[k]), k
+    # a batch larger than anything sized for makes the workspace grow: stale graphs refuse to replay
+    big = random_batch(cfg, B=4096, Sn=2, seed=99)[0]
+    m.train_async(tup(big), 0.7)
+    with pytest.raises(RuntimeError):
+        m.replay(graphs[0])

@@ -12,6 +12,7 @@ ABI_VERSION = 9
 NORM_TF18, NORM_DEDUP = 0, 1
 TABLE_F32, TABLE_BF16 = 0, 1
 L2_DENSE, L2_LAZY = 0, 1
+SN_CAP = 96     # TLSAN_SN_CAP (csrc/tlsan_common.h): longest session of a training batch
 
 EXPORTS = [
     "tlsan_abi_version", "tlsan_last_error", "tlsan_dense_layout_of", "tlsan_workspace_bytes",

@@ -355,7 +355,9 @@ __global__ __launch_bounds__(256) void k_shard_apply_lazy(ShardLazyArgs a) {
           double acc[4] = {0.0, 0.0, 0.0, 0.0};
           for (int s2 = s; s2 < a.G; ++s2) {  // contributions in source order
             const unsigned long long v = sl[s2];
-            if ((uint32_t)(v >> 32) == a.stamp) {
+            // (the entry is bounds-checked as well: a stamp alone cannot vouch for a slot written by an
+            //  earlier life of the model, e.g. after a restore to an earlier step)
+            if ((uint32_t)(v >> 32) == a.stamp && (uint32_t)v - 1u < (uint32_t)a.n_recv) {
               const f32x4 g = *(const f32x4*)(a.vals + (size_t)((uint32_t)v - 1u) * a.ldv + 4 * c4);
 #pragma unroll
               for (int i = 0; i < 4; ++i) acc[i] += (double)g[i];

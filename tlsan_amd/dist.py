@@ -363,15 +363,8 @@ class ShardedModel:
 
     # ------------------------------------------------------------------ helpers
     def _pack_dense(self, p):
-        d = self.d
-        lay = self.lay
-        flat = np.zeros(lay.n_dense, np.float32)
-        for k, off in (("fwa1_W1", lay.f1_W1), ("fwa1_b1", lay.f1_b1), ("fwa1_W2", lay.f1_W2), ("fwa1_b2", lay.f1_b2),
-                       ("dense_K", lay.K), ("dense_b", lay.k0), ("fwa2_W1", lay.f2_W1), ("fwa2_b1", lay.f2_b1),
-                       ("fwa2_W2", lay.f2_W2), ("fwa2_b2", lay.f2_b2), ("gamma", lay.gamma)):
-            a = np.asarray(p[k], np.float32).reshape(-1)
-            flat[off:off + a.size] = a
-        self.dense.copy_(torch.as_tensor(flat))
+        d, lay = self.d, self.lay
+        self.dense.copy_(torch.as_tensor(self._dense_flat(p)))
         self.dense_KT.copy_(self.dense[lay.K:lay.K + d * d].view(d, d).t())
 
     def _stream(self):
@@ -669,7 +662,7 @@ class ShardedModel:
                 self._lws = torch.empty(int(nws * 1.5) + 256, dtype=torch.uint8, device=dev)
             L.check(self.lib.tlsan_shard_apply_lazy(self.shard.data_ptr(), W, self.cI, self.router.R, W, di, di + Ls,
                                                     vals.data_ptr(), W, sl["recv_rows"].data_ptr(), sl["n_recv"],
-                                                    sl["src_off"], G, self._slots64.data_ptr(), (self._step + 1) & 0xFFFFFFFF,
+                                                    sl["src_off"], G, self._slots64.data_ptr(), self._lazy_stamp(),
                                                     1.0 / G, self._step_dev.data_ptr(), self.cate_emb.data_ptr(), Cc, self.dc,
                                                     fp + 4 * n_dense, self._sq.data_ptr(), tail + 8, self._P.data_ptr(),
                                                     self._lws.data_ptr(), self._lws.numel(), st), "tlsan_shard_apply_lazy")
@@ -694,6 +687,14 @@ class ShardedModel:
             nsl = self._plan_stage2(self._slots[self._next_slot])   # its counts arrived long ago
             self._prepare_side(ndb, nsl)
         return db
+
+    def _lazy_stamp(self):
+        """Stamp of this step's entries in _slots64 (tlsan_shard_apply_lazy): 1 .. 2^32-2, never 0 (the value
+        of a cleared slot); the slots are cleared whenever the sequence restarts."""
+        s = self._step % 0xFFFFFFFE
+        if s == 0 and self._step > 0:
+            self._slots64.zero_()
+        return s + 1
 
     def train(self, sess, batch, lr, add_summary=False):
         self.train_async(batch, lr)
@@ -802,17 +803,16 @@ class ShardedModel:
         self._P.fill_(1.0)
         self._refresh_squares()
 
-    def gather_params(self):
-        """Full (un-sharded) parameters on every rank, as numpy (tests / checkpoints)."""
-        self.fold_scale()
+    def _gather_tables(self, shard):
+        """A fused [item | user] shard tensor of every rank -> full tables (numpy), on every rank."""
         if self.world > 1:
             # (RCCL gathers device buffers; gloo, used by the single-GPU multi-process tests, host ones)
-            src = self.shard.cpu() if _staged(self.group) else self.shard
+            src = shard.cpu() if _staged(self.group) else shard
             outs = [torch.empty_like(src) for _ in range(self.world)]
             dist.all_gather(outs, src, group=self.group)
             outs = [o.cpu() for o in outs]
         else:
-            outs = [self.shard.cpu()]
+            outs = [shard.cpu()]
         I, U, G, di, Ls = self.I, self.U, self.world, self.di, self.Ls
         item = np.zeros((I, self.W), np.float32)
         user = np.zeros((U, self.W), np.float32)
@@ -821,11 +821,12 @@ class ShardedModel:
             ni, nu = len(range(r, I, G)), len(range(r, U, G))
             item[r::G] = t[:ni]
             user[r::G] = t[self.cI:self.cI + nu]
-        out = dict(item_emb=item[:, :di].copy(), item_b=item[:, di].copy(),
-                   user_emb=user[:, :di].copy(), usert_emb=user[:, di:di + Ls].copy(),
-                   cate_emb=self.cate_emb.cpu().numpy())
-        flat = self.dense.cpu().numpy()
+        return dict(item_emb=item[:, :di].copy(), item_b=item[:, di].copy(),
+                    user_emb=user[:, :di].copy(), usert_emb=user[:, di:di + Ls].copy())
+
+    def _unpack_dense(self, flat):
         d, dh, lay = self.d, self.d // self.H, self.lay
+        out = {}
         for k, off, shape in (("fwa1_W1", lay.f1_W1, (dh, dh)), ("fwa1_b1", lay.f1_b1, (dh,)),
                               ("fwa1_W2", lay.f1_W2, (dh, dh)), ("fwa1_b2", lay.f1_b2, (dh,)),
                               ("dense_K", lay.K, (d, d)), ("dense_b", lay.k0, (d,)),
@@ -833,6 +834,14 @@ class ShardedModel:
                               ("fwa2_W2", lay.f2_W2, (dh, dh)), ("fwa2_b2", lay.f2_b2, (dh,)), ("gamma", lay.gamma, ())):
             n = int(np.prod(shape)) if shape else 1
             out[k] = flat[off:off + n].reshape(shape).copy()
+        return out
+
+    def gather_params(self):
+        """Full (un-sharded) parameters on every rank, as numpy (tests / checkpoints)."""
+        self.fold_scale()
+        out = self._gather_tables(self.shard)
+        out["cate_emb"] = self.cate_emb.cpu().numpy()
+        out.update(self._unpack_dense(self.dense.cpu().numpy()))
         return out
 
     # ------------------------------------------------------------------ checkpoints (model.py:302-313)
@@ -848,8 +857,10 @@ class ShardedModel:
         base = os.path.join(self.config["model_dir"], "TLSAN-%d" % self._step)
         if not sharded:
             full = self.gather_params()                      # (a collective: every rank takes part)
+            slots = self.gather_slots()                      # tf.train.Saver keeps the optimizer's slot variables too
+            extra = {} if slots is None else {"slot%d/%s" % (n, k): v for n, sl_ in enumerate(slots, 1) for k, v in sl_.items()}
             if self.rank == 0:
-                np.savez(base + ".npz", global_step=self._step, global_epoch_step=self._epoch, **full)
+                np.savez(base + ".npz", global_step=self._step, global_epoch_step=self._epoch, **full, **extra)
         else:
             sl = {} if self._sopt is None else {k: v.cpu().numpy() for k, v in self.slots.items()}
             np.savez("%s.shard%dof%d.npz" % (base, self.rank, self.world), shard=self.shard.cpu().numpy(),
@@ -870,7 +881,9 @@ class ShardedModel:
         single-file .npz checkpoint of Model.save / save(sharded=False) -- then every rank keeps its rows."""
         if path.endswith(".npz"):
             z = np.load(path)
-            self.set_params({k: z[k] for k in z.files if k not in ("global_step", "global_epoch_step")})
+            self.set_params({k: z[k] for k in TABLE_KEYS + DENSE_KEYS})
+            if self._sopt is not None and "slot1/item_emb" in z.files:   # the optimizer's accumulators (Model.save)
+                self._set_slots([{k: z["slot%d/%s" % (n, k)] for k in TABLE_KEYS + DENSE_KEYS} for n in (1, 2)])
         else:
             rep_ = np.load(path + ".replicated.npz")
             if int(rep_["world"]) != self.world:
@@ -892,6 +905,56 @@ class ShardedModel:
             z = rep_
         self._step = int(z["global_step"])
         self._epoch = int(z["global_epoch_step"])
+        self._reset_step_state()
+
+    def _reset_step_state(self):
+        """After the parameters or the step counter were replaced: forget everything that was keyed by the old
+        step sequence (the stamped slots of the lazy owner update) or built for an announced successor."""
+        if self.lazy:
+            self._slots64.zero_()
+        self._slots = [None, None, None]
+        self._next_slot = 0
+
+    def _shard_layout(self, p):
+        """Full tables (dict of numpy arrays named like the parameters) -> this rank's fused [item | user] rows."""
+        G, r, di, Ls = self.world, self.rank, self.di, self.Ls
+        gi = np.arange(r, self.I, G)
+        gu = np.arange(r, self.U, G)
+        t = np.zeros(tuple(self.shard.shape), np.float32)
+        t[:len(gi), :di] = np.asarray(p["item_emb"], np.float32)[gi]
+        t[:len(gi), di] = np.asarray(p["item_b"], np.float32)[gi]
+        t[self.cI:self.cI + len(gu), :di] = np.asarray(p["user_emb"], np.float32)[gu]
+        t[self.cI:self.cI + len(gu), di:di + Ls] = np.asarray(p["usert_emb"], np.float32)[gu]
+        return t
+
+    def _dense_flat(self, p):
+        lay = self.lay
+        flat = np.zeros(lay.n_dense, np.float32)
+        for k, off in (("fwa1_W1", lay.f1_W1), ("fwa1_b1", lay.f1_b1), ("fwa1_W2", lay.f1_W2), ("fwa1_b2", lay.f1_b2),
+                       ("dense_K", lay.K), ("dense_b", lay.k0), ("fwa2_W1", lay.f2_W1), ("fwa2_b1", lay.f2_b1),
+                       ("fwa2_W2", lay.f2_W2), ("fwa2_b2", lay.f2_b2), ("gamma", lay.gamma)):
+            a = np.asarray(p[k], np.float32).reshape(-1)
+            flat[off:off + a.size] = a
+        return flat
+
+    def _set_slots(self, slots):
+        """The two accumulator sets of adam / rmsprop / adadelta from full tables (Model.get_slots' format)."""
+        for n, src in enumerate(slots, 1):
+            self.slots["shard_s%d" % n].copy_(torch.as_tensor(self._shard_layout(src)))
+            self.slots["cate_s%d" % n].copy_(torch.as_tensor(np.asarray(src["cate_emb"], np.float32)))
+            self.slots["dense_s%d" % n].copy_(torch.as_tensor(self._dense_flat(src)))
+
+    def gather_slots(self):
+        """Full (un-sharded) optimizer accumulators on every rank, in Model.get_slots' format (None for sgd)."""
+        if self._sopt is None:
+            return None
+        out = []
+        for n in (1, 2):
+            full = self._gather_tables(self.slots["shard_s%d" % n])
+            full["cate_emb"] = self.slots["cate_s%d" % n].cpu().numpy()
+            full.update(self._unpack_dense(self.slots["dense_s%d" % n].cpu().numpy()))
+            out.append(full)
+        return out
 
     def _refresh_squares(self):
         it, us = self._table_views()
@@ -903,16 +966,9 @@ class ShardedModel:
 
     def set_params(self, p):
         """Load full parameters (dict of numpy arrays); every rank keeps its own rows."""
-        G, r, di, Ls = self.world, self.rank, self.di, self.Ls
-        gi = np.arange(r, self.I, G)
-        gu = np.arange(r, self.U, G)
-        t = np.zeros(tuple(self.shard.shape), np.float32)
-        t[:len(gi), :di] = np.asarray(p["item_emb"], np.float32)[gi]
-        t[:len(gi), di] = np.asarray(p["item_b"], np.float32)[gi]
-        t[self.cI:self.cI + len(gu), :di] = np.asarray(p["user_emb"], np.float32)[gu]
-        t[self.cI:self.cI + len(gu), di:di + Ls] = np.asarray(p["usert_emb"], np.float32)[gu]
-        self.shard.copy_(torch.as_tensor(t))
+        self.shard.copy_(torch.as_tensor(self._shard_layout(p)))
         self.cate_emb.copy_(torch.as_tensor(np.asarray(p["cate_emb"], np.float32)))
         self._P.fill_(1.0)
         self._pack_dense(p)
         self._refresh_squares()
+        self._reset_step_state()

@@ -78,8 +78,16 @@ class PackedSet:
                    g("cate"), target=g("target"), label=g("label"))
 
     def shuffle(self, rng):
-        """Epoch shuffle (train.py:191 shuffles the python list; here the index order)."""
-        rng.shuffle(self.order)
+        """Epoch shuffle (train.py:191 shuffles the python list in place; here the index order, in place,
+        so that consecutive epochs compose as the reference's do).  `rng`: a `random.Random` (the
+        reference's stream, CPython's Fisher-Yates over a list) or a numpy RandomState / Generator."""
+        import random as _random
+        if isinstance(rng, _random.Random):
+            o = self.order.tolist()
+            rng.shuffle(o)
+            self.order = np.asarray(o, np.int64)
+        else:
+            rng.shuffle(self.order)
 
     # -- the batch ----------------------------------------------------------------------
     def make_batch(self, lo, hi, k):

@@ -146,10 +146,15 @@ class DeviceBatch:
 
 class Model(object):
     def __init__(self, config, item_cate_list, device="cuda:0", seed=1234, norm_mode="tf18", l2_mode="dense",
-                 table_dtype="f32"):
+                 table_dtype="f32", init="numpy"):
         """table_dtype: "f32" (the reference's precision) or "bf16" -- item_emb / user_emb / cate_emb stored
         as bfloat16 (BASELINE.json configs[2]), arithmetic in fp32, updates written back with
-        deterministic stochastic rounding; usert_emb, item_b and the dense weights stay fp32."""
+        deterministic stochastic rounding; usert_emb, item_b and the dense weights stay fp32.
+        init: "numpy" -- the variables' initial values drawn on the host (init_params; reproducible across
+        devices); "device" -- the same distributions drawn in HBM (tables of 10^7 rows: BASELINE.json
+        configs[4]; no host copy of the tables is ever made)."""
+        if init not in ("numpy", "device"):
+            raise ValueError("init must be 'numpy' or 'device'")
         if table_dtype not in ("f32", "bf16"):
             raise ValueError("table_dtype must be 'f32' or 'bf16'")
         self.table_dtype = table_dtype
@@ -202,7 +207,10 @@ class Model(object):
             raise ValueError("item_cate_list must be [item_count]")
         self.item_cate = torch.as_tensor(icl).to(self.device)
         self._alloc_params()
-        self.set_params(self.init_params(config, seed))
+        if init == "numpy":
+            self.set_params(self.init_params(config, seed))
+        else:
+            self._init_on_device(config, seed)
         self._alloc_slots()
         self.state = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
         if self.l2_mode == L.L2_LAZY:
@@ -256,6 +264,22 @@ class Model(object):
             p[blk + "_W2"] = glorot_uniform(rng, (dh, dh))
             p[blk + "_b2"] = np.zeros(dh, np.float32)
         return p
+
+    def _init_on_device(self, config, seed):
+        """init_params' distributions (glorot-uniform tables, usert_emb = -1, item_b = 0) drawn on the device;
+        the small dense weights still come from the host stream."""
+        g = torch.Generator(device=self.device)
+        g.manual_seed(int(seed))
+        for t in (self.item_emb, self.user_emb, self.cate_emb):
+            limit = float(np.sqrt(6.0 / (t.shape[0] + t.shape[1])))
+            if t.dtype == torch.float32:
+                t.uniform_(-limit, limit, generator=g)
+            else:
+                t.copy_(torch.empty(t.shape, dtype=torch.float32, device=self.device).uniform_(-limit, limit, generator=g))
+        self.item_b.zero_()
+        self.usert_emb.fill_(-1.0)
+        small = dict(config, item_count=1, user_count=1, cate_count=1)
+        self.dense.copy_(torch.as_tensor(self.pack_dense(self.init_params(small, seed))))
 
     def _alloc_params(self):
         cfg, dev = self.config, self.device
@@ -379,12 +403,21 @@ class Model(object):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _sync_state(self):
+        # tlsan_state_init clears the whole state, both destination-index slots included: an index that was
+        # prefetched for an announced successor (train_async(next_batch=)) is gone with it -- wait for the side
+        # stream to be done with the slot, then forget the announcement (the next step builds its index inline)
+        for k in (0, 1):
+            if self._idx_ready[k] is not None:
+                self._idx_event[k].synchronize()
+        self._idx_ready = [None, None]
         L.check(self.lib.tlsan_state_init(C.byref(self.dims), C.byref(self.cparams), self.state.data_ptr(),
                                           self._stream()), "tlsan_state_init")
 
     def _workspace(self, B, Sn):
         kB, kS = self._ws_key
         if self._ws is None or B > kB or Sn > kS:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("the workspace cannot grow during capture (capture_step sizes it first)")
             kB, kS = max(B, kB), max(Sn, kS)
             n = self.lib.tlsan_workspace_bytes(C.byref(self.dims), kB, kS)
             if n == 0:
@@ -471,7 +504,10 @@ class Model(object):
         side stream included) and return the graph: `g.replay()` re-runs the step on the same
         device buffers.  lr is baked in (re-capture when it changes, train.py:232-233)."""
         db = self.device_batch(batch)
-        self._workspace(db.B, db.Sn)
+        # the graph bakes the workspace pointer in: size it for the worst case of this batch size once (the
+        # longest session the kernels take, TLSAN_SN_CAP), so that a later, longer batch cannot make
+        # _workspace() reallocate it under graphs captured earlier
+        self._workspace(db.B, max(db.Sn, L.SN_CAP))
         self.train_async(db, lr)          # warm: lazy one-time initialisation happens outside capture
         self._step -= 1
         torch.cuda.synchronize(self.device)
@@ -480,9 +516,14 @@ class Model(object):
             self.train_async(db, lr)
         self._step -= 1
         g._tlsan_batch = db               # keep the captured buffers alive
+        g._tlsan_ws = self._ws            # ... and the workspace the graph writes to
         return g
 
     def replay(self, g):
+        if g._tlsan_ws is not self._ws:
+            # a larger batch made the workspace grow after the capture: the graph's block stays alive (pinned
+            # above), but it is no longer the model's -- recapture rather than run on a stale pointer
+            raise RuntimeError("replay: the workspace was reallocated after this graph was captured; recapture the step")
         g.replay()
         self._step += 1
 

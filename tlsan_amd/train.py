@@ -11,8 +11,13 @@ initial AUC / P@k / R@k, ``max_epochs`` epochs of shuffled batches, evaluation e
 from __future__ import annotations
 
 import argparse
+import glob
 import json
+import os
 import pickle
+import random
+import re
+import shutil
 import time
 
 import numpy as np
@@ -35,7 +40,7 @@ def parse(argv=None):
     for name, typ, default in FLAGS:
         ap.add_argument("--" + name, type=typ, default=default)
     ap.add_argument("--from_scratch", type=lambda s: s.lower() != "false", default=True)
-    ap.add_argument("--dataset", required=True)
+    ap.add_argument("--dataset", default=None, help="dataset.pkl of the reference's build_dataset.py, or a packed_<name>.npz export")
     ap.add_argument("--device", default="cuda:0")
     ap.add_argument("--max_steps", type=int, default=0, help="stop early (0 = run max_epochs)")
     ap.add_argument("--norm_mode", default="tf18", choices=["tf18", "dedup"])
@@ -47,6 +52,10 @@ def parse(argv=None):
                     help="P@k / R@k at every evaluation point like the reference (train.py:209-218); 0: once at the end")
     ap.add_argument("--sharded", type=int, default=0,
                     help="1: row-sharded tables over the ranks of torch.distributed (implied by WORLD_SIZE > 1)")
+    ap.add_argument("--seed", type=int, default=1234,
+                    help="seed of the variables' initial values (the reference seeds everything with 1234, train.py:15-17; "
+                         "TensorFlow's own stream cannot be reproduced, so this picks ONE draw of the same distributions)")
+    ap.add_argument("--shuffle_seed", type=int, default=1234, help="seed of the epoch shuffle stream (train.py:15,191: 1234)")
     ap.add_argument("--device_input", type=int, default=1,
                     help="1: keep the sample sets in HBM and assemble batches on the device (tlsan_amd.device_input); "
                          "0: the host batcher (tlsan_amd.input), one upload per batch")
@@ -62,6 +71,40 @@ def load_dataset(path):
         counts = pickle.load(f)
         icl = pickle.load(f)
     return PackedSet.from_samples(train_set), PackedSet.from_samples(test_set), tuple(counts), np.asarray(icl, np.int32)
+
+
+def prepare_model_dir(model_dir, from_scratch, rank=0, barrier=None):
+    """train.py:124-127: `from_scratch` wipes and recreates model_dir (rank 0 does it; the others wait at
+    `barrier`).  Returns the checkpoint to resume from, or None -- train.py:71-76 reloads
+    tf.train.get_checkpoint_state(model_dir).model_checkpoint_path, i.e. the LATEST save, when
+    from_scratch is false; here that is the TLSAN-<step> with the largest step (single-file `.npz` of
+    Model.save, or the `.replicated.npz` prefix of ShardedModel.save)."""
+    if from_scratch:
+        if rank == 0:
+            if os.path.isdir(model_dir):
+                shutil.rmtree(model_dir)
+            os.makedirs(model_dir, exist_ok=True)
+        if barrier is not None:
+            barrier()
+        return None
+    best = None
+    for f in glob.glob(os.path.join(model_dir, "TLSAN-*.npz")):
+        m = re.match(r"TLSAN-(\d+)(\.replicated)?\.npz$", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f[:-len(".replicated.npz")] if m.group(2) else f)
+    if rank == 0:
+        os.makedirs(model_dir, exist_ok=True)
+    if barrier is not None:
+        barrier()
+    return None if best is None else best[1]
+
+
+def epoch_rng(seed=1234):
+    """The reference's shuffle stream: `random.seed(1234)` at import (train.py:15) and
+    `random.shuffle(train_set)` once per epoch (:191) -- nothing else draws from `random` in between
+    (model.py and input.py never touch it), so a private `random.Random(1234)` shuffling the sample
+    ORDER in place epoch after epoch visits the samples exactly as the reference's list shuffle does."""
+    return random.Random(seed)
 
 
 def _test_batches(test_set, config):
@@ -109,13 +152,22 @@ def _lookahead(it):
     yield cur, None
 
 
-def train(args):
+def train(args, data=None):
+    """data (optional): (train PackedSet, test PackedSet, (U, I, C), item_cate_list) already in memory
+    (tlsan_amd.build_dataset.build_packed) instead of --dataset."""
     say = (lambda *a, **k: None) if args.quiet else print
-    train_set, test_set, (U, I, Cc), icl = load_dataset(args.dataset)
+    train_set, test_set, (U, I, Cc), icl = load_dataset(args.dataset) if data is None else data
     config = {name: getattr(args, name) for name, _, _ in FLAGS}
     config.update(user_count=U, item_count=I, cate_count=Cc, from_scratch=args.from_scratch)
     say(json.dumps(config, indent=4), flush=True)
-    model = Model(config, icl, device=args.device, norm_mode=args.norm_mode, l2_mode=args.l2_mode, table_dtype=args.table_dtype)
+    resume = prepare_model_dir(args.model_dir, args.from_scratch)      # train.py:124-127
+    model = Model(config, icl, device=args.device, seed=args.seed, norm_mode=args.norm_mode, l2_mode=args.l2_mode,
+                  table_dtype=args.table_dtype)
+    if resume is not None:                                             # train.py:71-76 (create_model)
+        say("Reloading model parameters..", flush=True)
+        model.restore(None, resume)
+    else:
+        say("Created new model parameters..", flush=True)
     if args.device_input:
         from .device_input import DeviceDataInput, DevicePackedSet
         train_set, test_set = DevicePackedSet(train_set, args.device), DevicePackedSet(test_set, args.device)
@@ -126,7 +178,7 @@ def train(args):
     init_auc = eval_auc(model, test_set, config)
     say("Init AUC: %.4f" % init_auc)
     lr = args.learning_rate
-    rng = np.random.RandomState(1234)  # train.py:15-16 seeds; the shuffle stream itself differs from CPython's
+    rng = epoch_rng(args.shuffle_seed)  # train.py:15,191
     best_auc, history = 0.0, []
     best_prec, best_recall = [0.0] * 6, [0.0] * 6              # train.py:187-188
     prec, recall = [0.0] * 6, [0.0] * 6
@@ -230,7 +282,18 @@ def train_sharded(args):
     train_set, test_set, (U, I, Cc), icl = load_dataset(args.dataset)
     config = {name: getattr(args, name) for name, _, _ in FLAGS}
     config.update(user_count=U, item_count=I, cate_count=Cc, from_scratch=args.from_scratch)
-    model = ShardedModel(config, icl, device=args.device, l2_mode=args.l2_mode if args.optimizer == "sgd" else "dense")
+    # flags this path does not implement are refused, not ignored
+    if args.table_dtype != "f32":
+        raise NotImplementedError("--table_dtype %s: the sharded step keeps fp32 rows" % args.table_dtype)
+    if args.norm_mode != "tf18":
+        raise NotImplementedError("--norm_mode %s: the sharded step forms the clip norm as TF 1.8 does (tf18)" % args.norm_mode)
+    resume = prepare_model_dir(args.model_dir, args.from_scratch, rank,
+                               (lambda: dist.barrier()) if world > 1 else None)     # train.py:124-127
+    model = ShardedModel(config, icl, device=args.device, seed=args.seed,
+                         l2_mode=args.l2_mode if args.optimizer == "sgd" else "dense")
+    if resume is not None:                                                          # train.py:71-76
+        say("Reloading model parameters..", flush=True)
+        model.restore(None, resume)
     dev = model.device
 
     def reduce_sum(vals):
@@ -265,7 +328,7 @@ def train_sharded(args):
     init_auc = eval_auc_()
     say("Init AUC: %.4f" % init_auc)
     lr = args.learning_rate
-    rng = np.random.RandomState(1234)              # the same shuffle on every rank
+    rng = epoch_rng(args.shuffle_seed)             # train.py:15,191; the same shuffle on every rank
     best_auc, history = 0.0, []
     best_prec, best_recall = [0.0] * 6, [0.0] * 6
     prec, recall = [0.0] * 6, [0.0] * 6
@@ -323,6 +386,8 @@ def train_sharded(args):
 def main(argv=None):
     import os
     args = parse(argv)
+    if args.dataset is None:
+        raise SystemExit("--dataset is required")
     sharded = args.sharded or int(os.environ.get("WORLD_SIZE", "1")) > 1
     res = train_sharded(args) if sharded else train(args)
     if not sharded or int(os.environ.get("RANK", "0")) == 0:
