@@ -375,9 +375,18 @@ class ShardedModel:
         db = batch if isinstance(batch, DeviceBatch) else DeviceBatch(batch, self.device, is_test, self.Ls)
         if not hasattr(db, "keys"):
             r = self.router
-            parts = [r.item_keys(db.i.long()), r.item_keys(db.hist_i.reshape(-1).long())]
+            # Padded slots of the windows (zeros past sl / sl_new, input.py:41-51) must not put item 0 into the plan:
+            # a row that only padding refers to receives no gradient, and the per-row gradient buffer of the step is
+            # not zero-filled (every compact row is expected to be written by a use).  They take the key of the
+            # sample's own candidate instead -- always a real use; the kernels weigh padded slots with exactly 0.
+            cand = db.i.long()
+            ar = torch.arange(self.Ls, device=db.i.device)[None, :]
+            hist = torch.where(ar < db.sl.long()[:, None], db.hist_i.long(), cand[:, None])
+            parts = [r.item_keys(cand), r.item_keys(hist.reshape(-1))]
             if db.Sn > 0:
-                parts.append(r.item_keys(db.hist_i_new.reshape(-1).long()))
+                ar = torch.arange(db.Sn, device=db.i.device)[None, :]
+                new = torch.where(ar < db.sl_new.long()[:, None], db.hist_i_new.reshape(db.B, db.Sn).long(), cand[:, None])
+                parts.append(r.item_keys(new.reshape(-1)))
             if db.j is not None:
                 parts.append(r.item_keys(db.j.long()))
             parts.append(r.user_keys(db.u.long()))

@@ -642,7 +642,8 @@ class Model(object):
                 extra.update({"slot%d/%s" % (n + 1, k): v for k, v in sl.items()})
         np.savez(path, global_step=self._step, global_epoch_step=self._epoch, **self.get_params(), **extra)
         json.dump(self.config, open("%s-%d.json" % (base, self._step), "w"), indent=2)
-        print("model saved at %s" % path, flush=True)
+        if not self.config.get("quiet"):
+            print("model saved at %s" % path, flush=True)
         return path
 
     def restore(self, sess, path):
@@ -653,4 +654,5 @@ class Model(object):
         self._epoch = int(z["global_epoch_step"])
         if self.slots is not None and "slot1/item_emb" in z:
             self.set_slots([{k: z["slot%d/%s" % (n, k)] for k in TABLE_KEYS + DENSE_KEYS} for n in (1, 2)])
-        print("model restored from %s" % path, flush=True)
+        if not self.config.get("quiet"):
+            print("model restored from %s" % path, flush=True)

@@ -158,7 +158,7 @@ def train(args, data=None):
     say = (lambda *a, **k: None) if args.quiet else print
     train_set, test_set, (U, I, Cc), icl = load_dataset(args.dataset) if data is None else data
     config = {name: getattr(args, name) for name, _, _ in FLAGS}
-    config.update(user_count=U, item_count=I, cate_count=Cc, from_scratch=args.from_scratch)
+    config.update(user_count=U, item_count=I, cate_count=Cc, from_scratch=args.from_scratch, quiet=bool(args.quiet))
     say(json.dumps(config, indent=4), flush=True)
     resume = prepare_model_dir(args.model_dir, args.from_scratch)      # train.py:124-127
     model = Model(config, icl, device=args.device, seed=args.seed, norm_mode=args.norm_mode, l2_mode=args.l2_mode,
@@ -281,7 +281,7 @@ def train_sharded(args):
     say = print if (rank == 0 and not args.quiet) else (lambda *a, **k: None)
     train_set, test_set, (U, I, Cc), icl = load_dataset(args.dataset)
     config = {name: getattr(args, name) for name, _, _ in FLAGS}
-    config.update(user_count=U, item_count=I, cate_count=Cc, from_scratch=args.from_scratch)
+    config.update(user_count=U, item_count=I, cate_count=Cc, from_scratch=args.from_scratch, quiet=bool(args.quiet))
     # flags this path does not implement are refused, not ignored
     if args.table_dtype != "f32":
         raise NotImplementedError("--table_dtype %s: the sharded step keeps fp32 rows" % args.table_dtype)
