@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TLSAN_ABI_VERSION 9
+#define TLSAN_ABI_VERSION 10
 
 enum {
   TLSAN_OK = 0,
@@ -74,9 +74,19 @@ typedef struct {
    * hash of step, table and element).  usert_emb, item_b and dense are always fp32.  A build
    * extension: the reference is fp32 throughout. */
   int32_t table_dtype;
+  /* Arithmetic of the matrix products of the fused kernel (the two maps of both attention blocks, forward and
+   * backward, their weight gradients, the bridge GEMM and its transpose): TLSAN_MATRIX_F32 (0) --
+   * v_mfma_f32_16x16x4_f32, exact fp32, the reference's precision; TLSAN_MATRIX_BF16 (1) -- both operands of
+   * every product rounded to bfloat16 (nearest even), products and sums in fp32
+   * (v_mfma_f32_16x16x16_bf16).  Everything else (softmax, loss, gradients' sums, updates) is fp32 either
+   * way.  A build extension for BASELINE.json configs[2] ("bf16"); logits then agree with the fp32 oracle
+   * to about 1e-2, not 1e-4. */
+  int32_t matrix_dtype;
 } tlsan_params;
 #define TLSAN_TABLE_F32 0
 #define TLSAN_TABLE_BF16 1
+#define TLSAN_MATRIX_F32 0
+#define TLSAN_MATRIX_BF16 1
 
 typedef struct {
   int32_t n_dense;

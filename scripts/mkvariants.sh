@@ -1,0 +1,17 @@
+#!/bin/bash
+# Build variants of libtlsan_hip.so that differ in compile-time toggles of the fused kernel (HERE; hipcc cross-compiles):
+#   scripts/mkvariants.sh name1:"-DTLSAN_EXP_X=1" name2:"-DTLSAN_EXP_Y=2 ..." ...
+# -> ab_libs/<name>.so (git-ignored, shipped by gpurun).  `base` (no flags) is always built.  Run them on ONE box with
+#   scripts/abrun.sh (interleaved rounds in one gpurun call).
+set -e
+R=$(cd "$(dirname "$0")/.." && pwd)
+cd "$R"
+mkdir -p ab_libs
+build() {  # name flags
+  rm -f tlsan_amd/csrc/build/tlsan_attn_d128.o tlsan_amd/csrc/build/tlsan_attn_d64.o
+  TLSAN_HIPCC_EXTRA="$2" python -c "from tlsan_amd import build; build.build()" > /dev/null
+  cp tlsan_amd/libtlsan_hip.so ab_libs/$1.so
+  echo "built ab_libs/$1.so  [$2]"
+}
+for spec in "$@"; do build "${spec%%:*}" "${spec#*:}"; done
+build base ""

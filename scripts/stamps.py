@@ -8,36 +8,43 @@ from tlsan_amd import _lib as L, synth
 from tlsan_amd.model import Model
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 cfg = synth.make_config("electronics")
-m = Model(cfg, synth.item_cate_list(cfg))
+m = Model(cfg, synth.item_cate_list(cfg), l2_mode="lazy", matrix_dtype=os.environ.get("MM", "f32"), table_dtype=os.environ.get("TD", "f32"))
 lib = L.load()
 db = m.device_batch(synth.make_batches(cfg, 1, B, seed=7)[0])
 for _ in range(5):
     m.train_async(db, 1.0)
 nblk = (B + 15) // 16
-NWV = 16 if os.environ.get('TLSAN_FWD_V2') == '1' else 8   # wavefronts per workgroup of the kernel that runs
+NWV = 8   # wavefronts per workgroup
 st = torch.zeros((1 << 20) + 8 * 8192, dtype=torch.int64, device="cuda")   # k_apply stamps live from entry 2^20 on
 lib.tlsan_debug_stamps(st.data_ptr())
 m.train_async(db, 1.0)
 torch.cuda.synchronize()
 lib.tlsan_debug_stamps(None)
-s = st.cpu().numpy()[:nblk * NWV * 16].reshape(nblk, NWV, 16)[:, :, :12].astype(np.float64)
+raw = st.cpu().numpy()[:nblk * NWV * 32].reshape(nblk, NWV, 32).astype(np.float64)
+s = raw[:, :, :12]
 d = np.diff(s, axis=2)
 names = ["P1 gather+fwa1", "bar1", "P2 bridge", "bar2", "P3 fwd+logit", "P3 bwd", "bar3", "P4+reduce", "bar4", "P5 bwd long", "bar5+reduce"]
 tot = s[:, :, 11] - s[:, :, 0]
 print("ticks/wave (s_memtime, 100 MHz on gfx950?): mean %.0f max %.0f" % (tot.mean(), tot.max()))
 for i, n in enumerate(names):
     print("%-16s mean %8.0f  p50 %8.0f  max %8.0f  (%.1f%%)" % (n, d[:, :, i].mean(), np.median(d[:, :, i]), d[:, :, i].max(), 100 * d[:, :, i].mean() / tot.mean()))
-f = st.cpu().numpy()[:nblk * NWV * 16].reshape(nblk, NWV, 16)[:, :, 12:16].astype(np.float64)
+f = raw[:, :, 12:16]
 fd = np.diff(f, axis=2)
 ok = (f[:, :, 0] > 0)
-if NWV == 16:   # k_fwd_bwd2: slots 12..14 split P1 (after the gathers, after the maps, after the softmax combine)
-    g = st.cpu().numpy()[:nblk * NWV * 16].reshape(nblk, NWV, 16).astype(np.float64)
-    for nm, lo, hi in (("P1: loads -> rows in registers", 0, 12), ("P1: maps of the lane's positions", 12, 13), ("P1: softmax combine + sum", 13, 14), ("P1: publish, LDS writes", 14, 1)):
-        dd = g[:, :, hi] - g[:, :, lo]
-        print("%-34s mean %8.0f p50 %8.0f max %8.0f" % (nm, dd.mean(), np.median(dd), dd.max()))
-    sys.exit(0)
 for i, n in enumerate(["P5 pos1: maps+exp", "P5 pos1: bwd_compute", "P5 pos1: bwd_dw"]):
     print("%-24s mean %8.0f p50 %8.0f max %8.0f" % (n, fd[:, :, i][ok].mean(), np.median(fd[:, :, i][ok]), fd[:, :, i][ok].max()))
+full = (raw[:, :, 9] > 0) & (raw[:, :, 18] > 0)     # waves whose window is full (position 9 ran)
+def seg(nm, lo, hi, sel=None):
+    dd = (raw[:, :, hi] - raw[:, :, lo])[ok if sel is None else sel]
+    print("%-44s mean %8.0f p50 %8.0f max %8.0f" % (nm, dd.mean(), np.median(dd), dd.max()))
+seg("P5: entry -> start of position 1 (frags, pos 0)", 9, 16)
+seg("P5 pos1: start -> row scaled (LDS read of uth)", 16, 12)
+seg("P5 pos1: after dW -> start of position 2 (stores)", 15, 17)
+seg("P5: position 1 in all", 16, 17)
+seg("P5: positions 2..8 (7 positions)", 17, 18, full)
+seg("P5: position 9 + last dW", 18, 19, full)
+seg("P5: dsp reductions + Gu stores", 19, 20)
+seg("P5: stage accumulators (to stamp 10)", 20, 10)
 span = s[:, :, 11].max() - s[:, :, 0].min()
 print("kernel span (first start -> last end): %.0f ticks" % span)
 p1 = d[:, :, 0]

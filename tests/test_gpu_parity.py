@@ -436,37 +436,6 @@ def test_prefetched_index_equals_inline():
         m.train_async(dbs[2], 0.6)
 
 
-@pytest.mark.parametrize("d", [64, 128])
-def test_experimental_one_sample_per_wave_kernel(d):
-    """TLSAN_FWD_V2=1 selects k_fwd_bwd2 (one sample per wavefront).  It is read once per process,
-    so run one training step in a child process and compare it with the default kernel here."""
-    import pickle
-    import subprocess
-    import sys
-    cfg = make_config(U=50, I=70, C=8, d=d, regulation_rate=1e-3)
-    p = _p32(random_params(cfg, seed=41))
-    b, cat = random_batch(cfg, B=45, Sn=5, seed=42)
-    m = _model(cfg, cat, p, l2_mode="lazy")
-    m.train(None, _tuple(b), 0.7)
-    ref = m.get_params()
-    code = (
-        "import pickle, sys, numpy as np\n"
-        "sys.path.insert(0, %r)\n"
-        "from tlsan_amd.model import Model\n"
-        "cfg, cat, p, batch = pickle.load(sys.stdin.buffer)\n"
-        "m = Model(cfg, cat, l2_mode='lazy'); m.set_params(p)\n"
-        "m.train(None, batch, 0.7)\n"
-        "pickle.dump(m.get_params(), sys.stdout.buffer)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    env = dict(os.environ, TLSAN_FWD_V2="1")
-    out = subprocess.run([sys.executable, "-c", code], input=pickle.dumps((cfg, cat, p, _tuple(b))), env=env,
-                         capture_output=True, timeout=300)
-    assert out.returncode == 0, out.stderr.decode()[-2000:]
-    got = pickle.loads(out.stdout)
-    for k in ref:
-        du, dr = np.asarray(got[k], np.float64) - p[k].reshape(np.shape(got[k])), np.asarray(ref[k], np.float64) - p[k].reshape(np.shape(ref[k]))
-        assert np.abs(du - dr).max() < 2e-4 * (np.abs(dr).max() + 1e-9) + 2e-7, k
-
-
 def test_full_scale_properties():
     """BASELINE.json configs[2] at full size (U=39991, I=22048, C=673, d=128, batch 4096), where the
     oracle is too slow: size-independent properties of the train step.

@@ -8,9 +8,10 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libtlsan_hip.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 NORM_TF18, NORM_DEDUP = 0, 1
 TABLE_F32, TABLE_BF16 = 0, 1
+MATRIX_F32, MATRIX_BF16 = 0, 1
 L2_DENSE, L2_LAZY = 0, 1
 SN_CAP = 96     # TLSAN_SN_CAP (csrc/tlsan_common.h): longest session of a training batch
 
@@ -34,7 +35,7 @@ class Dims(C.Structure):
 class Params(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
                 ("item_emb", "item_b", "user_emb", "usert_emb", "cate_emb", "dense", "dense_KT", "item_cate")] + \
-               [(n, C.c_int32) for n in ("ld_item", "ld_itemb", "ld_user", "ld_usert")] + [("scale", C.c_void_p), ("table_dtype", C.c_int32)]
+               [(n, C.c_int32) for n in ("ld_item", "ld_itemb", "ld_user", "ld_usert")] + [("scale", C.c_void_p), ("table_dtype", C.c_int32), ("matrix_dtype", C.c_int32)]
 
 
 class DenseLayout(C.Structure):

@@ -14,7 +14,6 @@
 hipError_t tlsan_launch_fwd_bwd_d64(bool train, bool lstream, const FwdArgs& a, int grid, hipStream_t st);
 hipError_t tlsan_launch_fwd_bwd_d128(bool train, bool lstream, const FwdArgs& a, int grid, hipStream_t st);
 hipError_t tlsan_launch_fwd_bwd_d256(bool train, bool lstream, const FwdArgs& a, int grid, hipStream_t st);
-hipError_t tlsan_launch_fwd_bwd2(int D, const FwdArgs& a, int grid, hipStream_t st);  // one sample per wavefront (training, d <= 128, Ls <= 10)
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, ...) {
@@ -237,6 +236,7 @@ static int check_params(const tlsan_params* p) {
       !p->dense_KT || !p->item_cate)
     return fail(TLSAN_E_BADARG, "NULL parameter pointer");
   if (p->table_dtype != TLSAN_TABLE_F32 && p->table_dtype != TLSAN_TABLE_BF16) return fail(TLSAN_E_BADARG, "table_dtype");
+  if (p->matrix_dtype != TLSAN_MATRIX_F32 && p->matrix_dtype != TLSAN_MATRIX_BF16) return fail(TLSAN_E_BADARG, "matrix_dtype");
   if (p->table_dtype == TLSAN_TABLE_BF16 && ((p->ld_item | p->ld_user) % 4))
     return fail(TLSAN_E_UNSUPPORTED, "bf16 tables need row strides that are multiples of 4 elements");
   return TLSAN_OK;
@@ -489,21 +489,6 @@ int tlsan_state_reindex(const tlsan_dims* d, const tlsan_params* p, void* state,
   return build_cate_csr(d, p, st, hs);
 }
 
-// which fused kernel runs: k_fwd_bwd (default), or with TLSAN_FWD_V2=1 the experimental k_fwd_bwd2
-// (one sample per wavefront, 16 wavefronts per workgroup; training at d <= 128 with the long window
-// in registers and every table / gradient buffer below 4 GiB).  Measured slower at the bench shape
-// (57 vs 46 us), kept selectable and tested because it documents that the kernel is
-// bound by the fp32 matrix pipe and the per-sample length imbalance, not by occupancy.
-static bool fwd_v2(const Shape& s, bool train, const tlsan_dims* d, const tlsan_params& q, const tlsan_batch* b) {
-  static const int on = [] { const char* v = getenv("TLSAN_FWD_V2"); return v ? atoi(v) : 0; }();
-  if (!on || !train || d->Ls > TLSAN_LS_MAX || s.D > 128 || q.table_dtype != TLSAN_TABLE_F32) return false;
-  const size_t lim = (size_t)1 << 32;  // it addresses with 32-bit byte offsets from the table bases
-  const size_t uses = (size_t)b->B * (d->Ls + b->Sn + 1);
-  return (size_t)d->item_count * q.ld_item * 4 < lim && (size_t)d->user_count * q.ld_user * 4 < lim &&
-         (size_t)d->user_count * q.ld_usert * 4 < lim && (size_t)d->item_count * q.ld_itemb * 4 < lim &&
-         (uses + 1) * s.D * 4 < lim && (size_t)b->B * (s.D + 4 * ((d->d_item + d->Ls + 3) / 4)) * 4 < lim;
-}
-
 int tlsan_state_recategorize(const tlsan_dims* d, const tlsan_params* p, void* state, void* stream) {
   Shape s;
   int rc = shape_of(d, &s);
@@ -515,15 +500,15 @@ int tlsan_state_recategorize(const tlsan_dims* d, const tlsan_params* p, void* s
   return build_cate_csr(d, p, st, (hipStream_t)stream);
 }
 
-static int launch_fwd(const Shape& s, bool train, bool v2, const FwdArgs& a, hipStream_t hs) {
+static int launch_fwd(const Shape& s, bool train, const FwdArgs& a, hipStream_t hs) {
   int grid = a.ngroups < 4096 ? a.ngroups : 4096;
   hipError_t e;
   const bool lstream = a.Ls > TLSAN_LS_MAX;  // long windows are streamed, short ones stay in registers
-  if (v2) e = tlsan_launch_fwd_bwd2(s.D, a, grid, hs);
-  else if (s.D == 64) e = tlsan_launch_fwd_bwd_d64(train, lstream, a, grid, hs);
+  if (s.D == 64) e = tlsan_launch_fwd_bwd_d64(train, lstream, a, grid, hs);
   else if (s.D == 128) e = tlsan_launch_fwd_bwd_d128(train, lstream, a, grid, hs);
   else e = tlsan_launch_fwd_bwd_d256(train, lstream, a, grid, hs);
-  if (e == hipErrorNotSupported) return fail(TLSAN_E_UNSUPPORTED, "bf16 tables with a streamed window (Ls > %d) are not built", TLSAN_LS_MAX);
+  if (e == hipErrorNotSupported)
+    return fail(TLSAN_E_UNSUPPORTED, "bf16 tables / bf16 matrix products are built for windows up to %d positions and without dropout", TLSAN_LS_MAX);
   if (e != hipSuccess) return fail(TLSAN_E_LAUNCH, "k_fwd_bwd: %s", hipGetErrorString(e));
   return TLSAN_OK;
 }
@@ -557,7 +542,7 @@ int tlsan_forward(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch*
   a.logits_i = logits_i;
   a.logits_j = logits_j;
   a.u_t = u_t;
-  return launch_fwd(s, false, false, a, (hipStream_t)stream);
+  return launch_fwd(s, false, a, (hipStream_t)stream);
 }
 
 // destination index of a batch into slot k: use counts per destination row -> first sorted position
@@ -622,11 +607,10 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
     a.drop_seed = hp->dropout_seed;
     a.drop_sample0 = hp->dropout_sample0;
   }
-  const bool v2 = fwd_v2(s, true, d, a.p, b) && hp->dropout == 0.0f;
-  const int grp = v2 ? 16 : s.NSB;  // samples per workgroup pass of the kernel that runs (= per partial record)
+  const int grp = s.NSB;  // samples per workgroup pass of the fused kernel (= per partial record)
   a.ngroups = (b->B + grp - 1) / grp;
   prof_mark(1, hs);
-  if ((rc = launch_fwd(s, true, v2, a, hs))) return rc;
+  if ((rc = launch_fwd(s, true, a, hs))) return rc;
   prof_mark(2, hs);
   // --- dense-parameter gradients
   {

@@ -28,9 +28,9 @@
 // backward recomputes a[p] = exp(m2[p] - mx) * Z (exactly 0 on masked positions).
 // Positions are processed two per (wave-uniform) branch so their MFMA chains interleave.
 // DROP: dropout on the inputs of both maps (model.py:428-431), pattern drop_scale4(dc, net, p, ., chb).
-template <int NB, int NPOS, bool DROP = false>
-__device__ __forceinline__ void fwa_forward(const float (&FT1)[NB][NB][4], const f32x4 (&b1)[NB],
-                                            const float (&FT2)[NB][NB][4], const f32x4 (&b2)[NB],
+template <int NB, int NPOS, bool DROP = false, int MM = TLSAN_MATRIX_F32>
+__device__ __forceinline__ void fwa_forward(const typename MMT<MM>::opd (&FT1)[NB][NB], const f32x4 (&b1)[NB],
+                                            const typename MMT<MM>::opd (&FT2)[NB][NB], const f32x4 (&b2)[NB],
                                             const f32x4 (&e)[NPOS][NB], const float (&sc)[NPOS],
                                             int n_valid, int pmax, f32x4 (&mx)[NB],
                                             f32x4 (&Z)[NB], f32x4 (&out)[NB], float* __restrict__ sAw,
@@ -50,7 +50,7 @@ __device__ __forceinline__ void fwa_forward(const float (&FT1)[NB][NB][4], const
 #pragma unroll
           for (int kb = 0; kb < NB; ++kb) xv[kb] *= drop_scale4(dc, net, p, 0, chb[kb]);
         }
-        map_apply<NB>(FT1, b1, xv, z);  // model.py:380 (relu below)
+        map_apply<NB, MM>(FT1, b1, xv, z);  // model.py:380 (relu below)
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
@@ -59,7 +59,7 @@ __device__ __forceinline__ void fwa_forward(const float (&FT1)[NB][NB][4], const
 #pragma unroll
           for (int kb = 0; kb < NB; ++kb) z[kb] *= drop_scale4(dc, net, p, 1, chb[kb]);
         }
-        map_apply<NB>(FT2, b2, z, m2);  // model.py:382
+        map_apply<NB, MM>(FT2, b2, z, m2);  // model.py:382
         const bool valid = p < n_valid;
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) {
@@ -113,9 +113,9 @@ __device__ __forceinline__ void fwa_forward(const float (&FT1)[NB][NB][4], const
 // DROP: k1 / k2 are the dropout scales of this position's map inputs (x (.) k1 entered map 1,
 // relu(z1) (.) k2 entered map 2): the staged operands of the dW products and the two
 // back-propagated vectors carry them.
-template <int NB, int TSTR, bool DROP = false>
-__device__ __forceinline__ void bwd_compute(const float (&FN2)[NB][NB][4],
-                                            const float (&FN1)[NB][NB][4], const f32x4 (&xv)[NB],
+template <int NB, int TSTR, bool DROP = false, int MM = TLSAN_MATRIX_F32>
+__device__ __forceinline__ void bwd_compute(const typename MMT<MM>::opd (&FN2)[NB][NB],
+                                            const typename MMT<MM>::opd (&FN1)[NB][NB], const f32x4 (&xv)[NB],
                                             const f32x4 (&z1)[NB], const f32x4 (&av)[NB],
                                             const f32x4 (&outv)[NB], const f32x4 (&dout)[NB],
                                             float* __restrict__ T, int q, int r,
@@ -129,7 +129,7 @@ __device__ __forceinline__ void bwd_compute(const float (&FN2)[NB][NB][4],
 #pragma unroll
     for (int i = 0; i < 4; ++i) m1[kb][i] = fmaxf(z1[kb][i], 0.0f);
   }
-  map_apply<NB>(FN2, zero, dm2, dm1);  // dm1 = dm2 . W2^T
+  map_apply<NB, MM>(FN2, zero, dm2, dm1);  // dm1 = dm2 . W2^T
   if constexpr (DROP) {
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
@@ -141,7 +141,7 @@ __device__ __forceinline__ void bwd_compute(const float (&FN2)[NB][NB][4],
   for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
     for (int i = 0; i < 4; ++i) dz1[kb][i] = z1[kb][i] > 0.0f ? dm1[kb][i] : 0.0f;
-  map_apply<NB>(FN1, zero, dz1, dxm);  // dz1 . W1^T
+  map_apply<NB, MM>(FN1, zero, dz1, dxm);  // dz1 . W1^T
   if constexpr (DROP) {
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) dxm[kb] *= k1[kb];
@@ -168,10 +168,10 @@ __device__ __forceinline__ void bwd_compute(const float (&FN2)[NB][NB][4],
 // staged in `T` (MFMA with the column index as the K dimension).  DS operations of a
 // wavefront execute in order, so reading what other lanes of the same wave wrote needs no
 // barrier, only program order.
-template <int NB, int TSTR>
+template <int NB, int TSTR, int MM = TLSAN_MATRIX_F32>
 __device__ __forceinline__ void bwd_dw(const float* __restrict__ T, int q, int r,
                                        f32x4 (&dW1)[NB][NB], f32x4 (&dW2)[NB][NB]) {
-  float ax[NB][4], bz[NB][4], am[NB][4], bd[NB][4];
+  f32x4 ax[NB], bz[NB], am[NB], bd[NB];
 #pragma unroll
   for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
@@ -182,15 +182,33 @@ __device__ __forceinline__ void bwd_dw(const float* __restrict__ T, int q, int r
       am[kb][s] = T[(2 * NB + kb) * 16 * TSTR + rofs];
       bd[kb][s] = T[(3 * NB + kb) * 16 * TSTR + rofs];
     }
+  if constexpr (MM == TLSAN_MATRIX_F32) {
 #pragma unroll
-  for (int kb = 0; kb < NB; ++kb)
+    for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
-    for (int jb = 0; jb < NB; ++jb)
+      for (int jb = 0; jb < NB; ++jb)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        dW1[kb][jb] = TLSAN_MFMA(ax[kb][s], bz[jb][s], dW1[kb][jb]);
-        dW2[kb][jb] = TLSAN_MFMA(am[kb][s], bd[jb][s], dW2[kb][jb]);
+        for (int s = 0; s < 4; ++s) {
+          dW1[kb][jb] = TLSAN_MFMA(ax[kb][s], bz[jb][s], dW1[kb][jb]);
+          dW2[kb][jb] = TLSAN_MFMA(am[kb][s], bd[jb][s], dW2[kb][jb]);
+        }
+  } else {
+    typename MMT<MM>::opd pax[NB], pbz[NB], pam[NB], pbd[NB];
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+      pax[kb] = mm_pack<MM>(ax[kb]);
+      pbz[kb] = mm_pack<MM>(bz[kb]);
+      pam[kb] = mm_pack<MM>(am[kb]);
+      pbd[kb] = mm_pack<MM>(bd[kb]);
+    }
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+      for (int jb = 0; jb < NB; ++jb) {
+        dW1[kb][jb] = mm_mma<MM>(pax[kb], pbz[jb], dW1[kb][jb]);
+        dW2[kb][jb] = mm_mma<MM>(pam[kb], pbd[jb], dW2[kb][jb]);
       }
+  }
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -245,18 +263,14 @@ __device__ __forceinline__ void stage_accs(AccSet<NB>& A, f32x4 (&extra)[NB], fl
   for (int kb = 0; kb < NB; ++kb) {
     f32x4 t = A.db1[kb];
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) t[i] += __shfl_xor(t[i], o);
+    for (int i = 0; i < 4; ++i) t[i] = lanes_sum<16>(t[i]);
     *(f32x4*)(base + (v++) * 256) = t;
   }
 #pragma unroll
   for (int kb = 0; kb < NB; ++kb) {
     f32x4 t = A.db2[kb];
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) t[i] += __shfl_xor(t[i], o);
+    for (int i = 0; i < 4; ++i) t[i] = lanes_sum<16>(t[i]);
     *(f32x4*)(base + (v++) * 256) = t;
   }
   if constexpr (EXTRA) {
@@ -265,9 +279,7 @@ __device__ __forceinline__ void stage_accs(AccSet<NB>& A, f32x4 (&extra)[NB], fl
     for (int kb = 0; kb < NB; ++kb) {
       f32x4 t = extra[kb];
 #pragma unroll
-      for (int o = CPS; o < 16; o <<= 1)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) t[i] += __shfl_xor(t[i], o);
+      for (int i = 0; i < 4; ++i) t[i] = stride_sum<CPS>(t[i]);
       *(f32x4*)(base + (v++) * 256) = t;
     }
   }
@@ -286,9 +298,7 @@ __device__ __forceinline__ void stage_part(AccSet<NB>& A, f32x4 (&extra)[NB], fl
   for (int kb = 0; kb < NB; ++kb) {
     f32x4 t = PART == 0 ? A.db1[kb] : A.db2[kb];
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) t[i] += __shfl_xor(t[i], o);
+    for (int i = 0; i < 4; ++i) t[i] = lanes_sum<16>(t[i]);
     *(f32x4*)(base + (v++) * 256) = t;
   }
   if constexpr (EXTRA && PART == 0) {
@@ -296,9 +306,7 @@ __device__ __forceinline__ void stage_part(AccSet<NB>& A, f32x4 (&extra)[NB], fl
     for (int kb = 0; kb < NB; ++kb) {
       f32x4 t = extra[kb];
 #pragma unroll
-      for (int o = CPS; o < 16; o <<= 1)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) t[i] += __shfl_xor(t[i], o);
+      for (int i = 0; i < 4; ++i) t[i] = stride_sum<CPS>(t[i]);
       *(f32x4*)(base + (v++) * 256) = t;
     }
   }
@@ -375,10 +383,11 @@ __device__ __forceinline__ void online_step(f32x4 (&mx)[NB], f32x4 (&Z)[NB], f32
 
 // LSTREAM: the long block is streamed like the short one (any Ls <= TLSAN_LS_CAP); otherwise its
 // Ls <= TLSAN_LS_MAX positions stay in registers between forward and backward.
-template <int D, int DH, bool TRAIN, bool LSTREAM, int DT = TLSAN_TABLE_F32, bool DROP = false>
+template <int D, int DH, bool TRAIN, bool LSTREAM, int DT = TLSAN_TABLE_F32, bool DROP = false, int MM = TLSAN_MATRIX_F32>
 __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   static_assert(!DROP || TRAIN, "dropout: train steps only");
   using G = Geo<D, DH>;
+  using opd = typename MMT<MM>::opd;   // an operand of one 16-deep contraction (tlsan_common.h)
   constexpr int NB = G::NB, CPS = G::CPS, SPW = G::SPW, NW = G::NW, NSB = G::NSB;
   constexpr int LS = LSTREAM ? 1 : TLSAN_LS_MAX;             // positions held in registers
   constexpr int LSC = LSTREAM ? TLSAN_LS_CAP : TLSAN_LS_MAX;  // position slots in the LDS tables
@@ -425,10 +434,30 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   const float *w1W1 = wb1, *w1b1 = wb1 + DH * DH, *w1W2 = w1b1 + DH, *w1b2 = w1W2 + DH * DH;
   const float *w2W1 = wb2, *w2b1 = w2W1 + DH * DH, *w2W2 = w2b1 + DH, *w2b2 = w2W2 + DH * DH;
 
+#ifndef TLSAN_EXP_PRIO
+#define TLSAN_EXP_PRIO 0
+#endif
+#ifndef TLSAN_EXP_STAGGER
+#define TLSAN_EXP_STAGGER 0
+#endif
+#ifndef TLSAN_EXP_FAKECAT
+#define TLSAN_EXP_FAKECAT 0
+#endif
+#ifndef TLSAN_EXP_SESS_EARLY
+#define TLSAN_EXP_SESS_EARLY 0
+#endif
+#ifndef TLSAN_EXP_ABL
+#define TLSAN_EXP_ABL 0   // timing-only ablations (wrong results): 1 no row stores in P5, 2 no position read, 4 no dW products in P5
+#endif
+  if constexpr (TLSAN_EXP_PRIO != 0 && NW == 8) {
+    // the second-dispatched half of an 8-wave workgroup loses the VALU arbitration to its SIMD partner on every
+    // segment (MI355X_MICROARCH.md, two waves per SIMD, item 4): one static priority raise, no flips
+    if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(TLSAN_EXP_PRIO);
+  }
 #define TLSAN_STAMP(k)                                                                       \
   do {                                                                                       \
     if (a.stamps != nullptr && lane == 0)                                                    \
-      a.stamps[((size_t)blockIdx.x * NW + wave) * 16 + (k)] = __builtin_amdgcn_s_memtime();  \
+      a.stamps[((size_t)blockIdx.x * NW + wave) * 32 + (k)] = __builtin_amdgcn_s_memtime();  \
   } while (0)
 
   for (int g = blockIdx.x; g < a.ngroups; g += gridDim.x) {
@@ -451,7 +480,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     // together; padding is applied afterwards by selects (padded slots contribute exactly 0).
     f32x4 e1[LS][NB], long4[NB], mx1[NB], iz1[NB];
     int posv[TRAIN ? LS + 3 : 1];
-    const int pmax1 = wave_max_i32(n_l);
+    const int pmax1 = wave_max_samples<CPS>(n_l);
     // ---- streamed long block (LSTREAM): ids, scales and positions live one per lane of the sample
     // (lane kk = entry base + kk of the current chunk) and are broadcast with cross-lane reads
     constexpr int NLc = 4 * CPS;
@@ -467,19 +496,43 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     };
     auto fetch_lrow = [&](int p, f32x4 (&xr)[NB], float& scx, float& sce) {  // position p of the loaded chunk
       const int k = p % NLc;
-      const int src = (k / CPS) * 16 + s_loc * CPS + (k % CPS);
-      const int it = __shfl(lid, src), ct = __shfl(lct, src);
-      const float uth = __shfl(lut, src) * __shfl(lht, src);
+      const int it = sample_pick<CPS>(lid, k / CPS, k % CPS, s_loc), ct = sample_pick<CPS>(lct, k / CPS, k % CPS, s_loc);
+      const float uth = sample_pick<CPS>(lut, k / CPS, k % CPS, s_loc) * sample_pick<CPS>(lht, k / CPS, k % CPS, s_loc);
       scx = (gamma * P * P) * uth;  // x = e_stored * scx
       sce = (gamma * P) * uth;      // d x / d e_true
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb) xr[kb] = gather_item4c<DT>(a, it, ct, chb[kb]);
     };
+    // session ids (and their categories) are fetched once, one per lane of the sample
+    // (lane k = q*CPS + col holds entry k of the current chunk of NL entries), then broadcast
+    // with a cross-lane read: no dependent index loads inside the position loops.
+    constexpr int NL = 4 * CPS;
+    constexpr bool SESS_EARLY = TLSAN_EXP_SESS_EARLY != 0 && !LSTREAM;
+    const int kk = q * CPS + col;
+    int sid = 0, scat = 0;
+    auto load_chunk = [&](int base) {
+      const int t = min(base + kk, max(Sn - 1, 0));
+      sid = (Sn > 0) ? a.b.hist_i_new[(size_t)bb * Sn + t] : 0;
+      scat = a.p.item_cate[sid];
+    };
+    auto fetch_row = [&](int t, f32x4 (&xr)[NB]) {  // row of session entry t (chunk must be loaded)
+      const int k = t % NL;
+      const int it = sample_pick<CPS>(sid, k / CPS, k % CPS, s_loc), ct = sample_pick<CPS>(scat, k / CPS, k % CPS, s_loc);
+      const bool vt = t < n_s;
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) {
+        const f32x4 v = gather_item4c<DT>(a, it, ct, chb[kb]) * P;
+        xr[kb] = vt ? v : (f32x4)(0.0f);
+      }
+    };
+    int spos0 = 0;  // position of session use kk (first chunk): one returning atomic per use
+    f32x4 xnext[NB];
+    const int pmax2e = wave_max_samples<CPS>(n_s + 1);
     if constexpr (LSTREAM) {
-      float FT1[NB][NB][4], FT2[NB][NB][4];
+      opd FT1[NB][NB], FT2[NB][NB];
       f32x4 b1[NB], b2[NB], Zl[NB];
-      load_frag_T<DH, NB>(w1W1, q, r, FT1);
-      load_frag_T<DH, NB>(w1W2, q, r, FT2);
+      load_frag_T<DH, NB, MM>(w1W1, q, r, FT1);
+      load_frag_T<DH, NB, MM>(w1W2, q, r, FT2);
       load_bias<DH, NB>(w1b1, q, b1);
       load_bias<DH, NB>(w1b2, q, b2);
       if constexpr (TRAIN) {
@@ -512,9 +565,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           if constexpr (G::AT_USE && !LSTREAM) {  // weight fragments from LDS at the use
             const int zz = opaque_zero(p);
             if constexpr (G::AT_USE_T) {
-              load_frag_T<DH, NB>(w1W1 + zz, q, r, FT1);
+              load_frag_T<DH, NB, MM>(w1W1 + zz, q, r, FT1);
               load_bias<DH, NB>(w1b1 + zz, q, b1);
-              load_frag_T<DH, NB>(w1W2 + zz, q, r, FT2);
+              load_frag_T<DH, NB, MM>(w1W2 + zz, q, r, FT2);
               load_bias<DH, NB>(w1b2 + zz, q, b2);
             }
           }
@@ -526,9 +579,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             f32x4 xd[NB];
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) xd[kb] = xv[kb] * drop_scale4(dc, 0, p, 0, chb[kb]);
-            map_apply<NB>(FT1, b1, xd, z);
+            map_apply<NB, MM>(FT1, b1, xd, z);
           } else {
-            map_apply<NB>(FT1, b1, xv, z);
+            map_apply<NB, MM>(FT1, b1, xv, z);
           }
 #pragma unroll
           for (int kb = 0; kb < NB; ++kb)
@@ -538,7 +591,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) z[kb] *= drop_scale4(dc, 0, p, 1, chb[kb]);
           }
-          map_apply<NB>(FT2, b2, z, m2);
+          map_apply<NB, MM>(FT2, b2, z, m2);
           if (vp) online_step<NB>(mx1, Zl, long4, m2, xv);
         }
       }
@@ -563,9 +616,14 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         hts[p] = a.b.hist_t[(size_t)bb * Ls + pc];
         uts[p] = a.p.usert_emb[(size_t)uid * a.p.ld_usert + pc];
       }
+      // (SESS_EARLY) the short block's first chunk of ids, their categories, the cursor draws and the first session
+      // row depend on the ids only: each of their three dependent loads rides with the long block's stage of the
+      // same depth, instead of three round trips of their own at the start of P3
+      if constexpr (SESS_EARLY) sid = (Sn > 0) ? a.b.hist_i_new[(size_t)bb * Sn + min(kk, max(Sn - 1, 0))] : 0;
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (SESS_EARLY) scat = a.p.item_cate[sid];
 #pragma unroll
-      for (int p = 0; p < LS; ++p) cts[p] = a.p.item_cate[its[p]];
+      for (int p = 0; p < LS; ++p) cts[p] = TLSAN_EXP_FAKECAT ? (its[p] & 511) : a.p.item_cate[its[p]];
       if constexpr (TRAIN) {
         // destination-sorted row of every long use: issue all the returning atomics now; their
         // results are only published to LDS after the bridge GEMM (nothing waits on them here)
@@ -575,12 +633,16 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         posv[LS + 1] = (lead && vs) ? atomicAdd(&a.cur_user[uid], 1) : 0;
         // (a per-lane copy of the flag: a scalar branch here would split the batch of returning atomics)
         posv[LS + 2] = (lead && vs && (a.uc_by_sample + opaque_zero(lane)) == 0) ? atomicAdd(&a.cur_uc[a.b.u_cate[bb]], 1) : bidx;
+        if constexpr (SESS_EARLY) spos0 = (vs && kk < n_s) ? atomicAdd(&a.cur_item[sid], 1) : 0;
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int p = 0; p < LS; ++p)
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) e1[p][kb] = gather_item4c<DT>(a, its[p], cts[p], chb[kb]);
+      if constexpr (SESS_EARLY) {
+        if (pmax2e > 1) fetch_row(0, xnext);
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int p = 0; p < LS; ++p) {
@@ -593,13 +655,13 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) e1[p][kb] = vp ? e1[p][kb] : (f32x4)(0.0f);
       }
-      float FT1[NB][NB][4], FT2[NB][NB][4];
+      opd FT1[NB][NB], FT2[NB][NB];
       f32x4 b1[NB], b2[NB];
-      load_frag_T<DH, NB>(w1W1, q, r, FT1);
-      load_frag_T<DH, NB>(w1W2, q, r, FT2);
+      load_frag_T<DH, NB, MM>(w1W1, q, r, FT1);
+      load_frag_T<DH, NB, MM>(w1W2, q, r, FT2);
       load_bias<DH, NB>(w1b1, q, b1);
       load_bias<DH, NB>(w1b2, q, b2);
-      fwa_forward<NB, LS, DROP>(FT1, b1, FT2, b2, e1, sc1, n_l, pmax1, mx1, iz1, long4, KEEP_A ? sAw : nullptr, dc, 0, chb);
+      fwa_forward<NB, LS, DROP, MM>(FT1, b1, FT2, b2, e1, sc1, n_l, pmax1, mx1, iz1, long4, KEEP_A ? sAw : nullptr, dc, 0, chb);
     }
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
@@ -619,13 +681,13 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 
     // B fragments of the bridge GEMM (K^T rows, L2-resident) do not depend on the barrier:
     // fetch them first so their latency overlaps the wait for the slowest wavefront
-    f32x4 bfr[G::TPW][D / 16];
+    opd bfr[G::TPW][D / 16];
 #pragma unroll
     for (int t = 0; t < G::TPW; ++t) {
       const int ct = (wave * G::TPW + t) % G::NT;
       const float* Brow = a.p.dense_KT + (size_t)(16 * ct + r) * D + 4 * q;
 #pragma unroll
-      for (int kc = 0; kc < D / 16; ++kc) bfr[t][kc] = *(const f32x4*)(Brow + 16 * kc);
+      for (int kc = 0; kc < D / 16; ++kc) bfr[t][kc] = mm_pack<MM>(*(const f32x4*)(Brow + 16 * kc));
     }
     TLSAN_STAMP(1);
     __syncthreads();
@@ -639,11 +701,16 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       const float* Arow = sA + (16 * rt + r) * LSTR + 4 * q;
 #pragma unroll
       for (int kc = 0; kc < D / 16; kc += 2) {
-        const f32x4 av0 = *(const f32x4*)(Arow + 16 * kc), av1 = *(const f32x4*)(Arow + 16 * kc + 16);
+        const opd av0 = mm_pack<MM>(*(const f32x4*)(Arow + 16 * kc)), av1 = mm_pack<MM>(*(const f32x4*)(Arow + 16 * kc + 16));
+        if constexpr (MM == TLSAN_MATRIX_F32) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          acc0 = TLSAN_MFMA(av0[s], bfr[t][kc][s], acc0);
-          acc1 = TLSAN_MFMA(av1[s], bfr[t][kc + 1][s], acc1);
+          for (int s = 0; s < 4; ++s) {
+            acc0 = TLSAN_MFMA(av0[s], bfr[t][kc][s], acc0);
+            acc1 = TLSAN_MFMA(av1[s], bfr[t][kc + 1][s], acc1);
+          }
+        } else {
+          acc0 = mm_mma<MM>(av0, bfr[t][kc], acc0);
+          acc1 = mm_mma<MM>(av1, bfr[t][kc + 1], acc1);
         }
       }
       acc0 += acc1;
@@ -657,7 +724,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     // positions: 0 = bridge, 1..n_s = session rows (model.py:350); streamed with an online
     // softmax so registers do not grow with the session length.
     const int n_pos = n_s + 1;  // model.py:355: rep_length = sl_new + 1
-    const int pmax2 = wave_max_i32(n_pos);
+    const int pmax2 = wave_max_samples<CPS>(n_pos);
     if constexpr (TRAIN) {
       if (lead) {
         if constexpr (!LSTREAM) {
@@ -669,39 +736,17 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         sP[srow * PSTR + P_UC] = posv[LS + 2];
       }
     }
-    float FT1[NB][NB][4], FT2[NB][NB][4];
+    opd FT1[NB][NB], FT2[NB][NB];
     f32x4 b1[NB], b2[NB];
-    load_frag_T<DH, NB>(w2W1, q, r, FT1);
-    load_frag_T<DH, NB>(w2W2, q, r, FT2);
+    load_frag_T<DH, NB, MM>(w2W1, q, r, FT1);
+    load_frag_T<DH, NB, MM>(w2W2, q, r, FT2);
     load_bias<DH, NB>(w2b1, q, b1);
     load_bias<DH, NB>(w2b2, q, b2);
-    // session ids (and their categories) are fetched once, one per lane of the sample
-    // (lane k = q*CPS + col holds entry k of the current chunk of NL entries), then broadcast
-    // with a cross-lane read: no dependent index loads inside the position loops.
-    constexpr int NL = 4 * CPS;
-    const int kk = q * CPS + col;
-    int sid = 0, scat = 0;
-    auto load_chunk = [&](int base) {
-      const int t = min(base + kk, max(Sn - 1, 0));
-      sid = (Sn > 0) ? a.b.hist_i_new[(size_t)bb * Sn + t] : 0;
-      scat = a.p.item_cate[sid];
-    };
-    auto fetch_row = [&](int t, f32x4 (&xr)[NB]) {  // row of session entry t (chunk must be loaded)
-      const int k = t % NL;
-      const int src = (k / CPS) * 16 + s_loc * CPS + (k % CPS);
-      const int it = __shfl(sid, src), ct = __shfl(scat, src);
-      const bool vt = t < n_s;
-#pragma unroll
-      for (int kb = 0; kb < NB; ++kb) {
-        const f32x4 v = gather_item4c<DT>(a, it, ct, chb[kb]) * P;
-        xr[kb] = vt ? v : (f32x4)(0.0f);
-      }
-    };
-    load_chunk(0);
-    int spos0 = 0;  // position of session use kk (first chunk): one returning atomic per use
-    if constexpr (TRAIN) spos0 = (vs && kk < n_s) ? atomicAdd(&a.cur_item[sid], 1) : 0;
-    f32x4 xnext[NB];
-    if (pmax2 > 1) fetch_row(0, xnext);
+    if constexpr (!SESS_EARLY) {
+      load_chunk(0);
+      if constexpr (TRAIN) spos0 = (vs && kk < n_s) ? atomicAdd(&a.cur_item[sid], 1) : 0;
+      if (pmax2 > 1) fetch_row(0, xnext);
+    }
     f32x4 mx[NB], Zs[NB], short4[NB];
     {
       f32x4 xv[NB], z[NB];
@@ -711,9 +756,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         f32x4 xd[NB];
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) xd[kb] = xv[kb] * drop_scale4(dc, 1, 0, 0, chb[kb]);
-        map_apply<NB>(FT1, b1, xd, z);
+        map_apply<NB, MM>(FT1, b1, xd, z);
       } else {
-        map_apply<NB>(FT1, b1, xv, z);
+        map_apply<NB, MM>(FT1, b1, xv, z);
       }
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb)
@@ -723,7 +768,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) z[kb] *= drop_scale4(dc, 1, 0, 1, chb[kb]);
       }
-      map_apply<NB>(FT2, b2, z, mx);  // position 0 is always valid: running max = its score
+      map_apply<NB, MM>(FT2, b2, z, mx);  // position 0 is always valid: running max = its score
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb) {
         Zs[kb] = (f32x4)(1.0f);
@@ -735,9 +780,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       f32x4 xv[NB], z[NB], m2[NB];
       if constexpr (G::AT_USE && !LSTREAM && G::AT_USE_T) {  // weight fragments from LDS at the use
         const int zz = opaque_zero(p);
-        load_frag_T<DH, NB>(w2W1 + zz, q, r, FT1);
+        load_frag_T<DH, NB, MM>(w2W1 + zz, q, r, FT1);
         load_bias<DH, NB>(w2b1 + zz, q, b1);
-        load_frag_T<DH, NB>(w2W2 + zz, q, r, FT2);
+        load_frag_T<DH, NB, MM>(w2W2 + zz, q, r, FT2);
         load_bias<DH, NB>(w2b2 + zz, q, b2);
       }
 
@@ -751,9 +796,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         f32x4 xd[NB];
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) xd[kb] = xv[kb] * drop_scale4(dc, 1, p, 0, chb[kb]);
-        map_apply<NB>(FT1, b1, xd, z);
+        map_apply<NB, MM>(FT1, b1, xd, z);
       } else {
-        map_apply<NB>(FT1, b1, xv, z);
+        map_apply<NB, MM>(FT1, b1, xv, z);
       }
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb)
@@ -763,7 +808,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) z[kb] *= drop_scale4(dc, 1, p, 1, chb[kb]);
       }
-      map_apply<NB>(FT2, b2, z, m2);
+      map_apply<NB, MM>(FT2, b2, z, m2);
       if (vt) {
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb)
@@ -841,9 +886,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         }
       }
       {
-        float FN1[NB][NB][4], FN2[NB][NB][4];
-        load_frag_N<DH, NB>(w2W1, q, r, FN1);
-        load_frag_N<DH, NB>(w2W2, q, r, FN2);
+        opd FN1[NB][NB], FN2[NB][NB];
+        load_frag_N<DH, NB, MM>(w2W1, q, r, FN1);
+        load_frag_N<DH, NB, MM>(w2W2, q, r, FN2);
         AccSet<NB> acc;
         acc.zero();
         if (pmax2 - 1 > NL) load_chunk(0);  // (wave-uniform) the forward loop moved past chunk 0
@@ -856,13 +901,13 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           if constexpr (G::AT_USE && !LSTREAM) {  // weight fragments from LDS at the use
             const int zz = opaque_zero(p);
             if constexpr (G::AT_USE_T) {
-              load_frag_T<DH, NB>(w2W1 + zz, q, r, FT1);
+              load_frag_T<DH, NB, MM>(w2W1 + zz, q, r, FT1);
               load_bias<DH, NB>(w2b1 + zz, q, b1);
-              load_frag_T<DH, NB>(w2W2 + zz, q, r, FT2);
+              load_frag_T<DH, NB, MM>(w2W2 + zz, q, r, FT2);
               load_bias<DH, NB>(w2b2 + zz, q, b2);
             }
-            load_frag_N<DH, NB>(w2W1 + zz, q, r, FN1);
-            load_frag_N<DH, NB>(w2W2 + zz, q, r, FN2);
+            load_frag_N<DH, NB, MM>(w2W1 + zz, q, r, FN1);
+            load_frag_N<DH, NB, MM>(w2W2 + zz, q, r, FN2);
           }
 
 #pragma unroll
@@ -880,9 +925,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
               k2[kb] = drop_scale4(dc, 1, p, 1, chb[kb]);
               xd[kb] = xv[kb] * k1[kb];
             }
-            map_apply<NB>(FT1, b1, xd, z1);
+            map_apply<NB, MM>(FT1, b1, xd, z1);
           } else {
-            map_apply<NB>(FT1, b1, xv, z1);
+            map_apply<NB, MM>(FT1, b1, xv, z1);
           }
 #pragma unroll
           for (int kb = 0; kb < NB; ++kb)
@@ -892,16 +937,16 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) zr[kb] *= k2[kb];
           }
-          map_apply<NB>(FT2, b2, zr, m2);
+          map_apply<NB, MM>(FT2, b2, zr, m2);
 #pragma unroll
           for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
               av[kb][i] = vt ? __expf(m2[kb][i] - mx[kb][i]) * Zs[kb][i] : 0.0f;
           float* Tp = T + (NBUF > 1 ? (p & 1) * TB : 0);
-          bwd_compute<NB, TSTR, DROP>(FN2, FN1, xv, z1, av, short4, dout, Tp, q, r, acc.db1, acc.db2, dx, k1, k2);
-          if (NBUF == 1) bwd_dw<NB, TSTR>(Tp, q, r, acc.dW1, acc.dW2);
-          else if (p > 0) bwd_dw<NB, TSTR>(T + ((p - 1) & 1) * TB, q, r, acc.dW1, acc.dW2);
+          bwd_compute<NB, TSTR, DROP, MM>(FN2, FN1, xv, z1, av, short4, dout, Tp, q, r, acc.db1, acc.db2, dx, k1, k2);
+          if (NBUF == 1) bwd_dw<NB, TSTR, MM>(Tp, q, r, acc.dW1, acc.dW2);
+          else if (p > 0) bwd_dw<NB, TSTR, MM>(T + ((p - 1) & 1) * TB, q, r, acc.dW1, acc.dW2);
           if (p == 0) {
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) {
@@ -921,7 +966,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             }
           }
         }
-        if (NBUF > 1) bwd_dw<NB, TSTR>(T + ((pmax2 - 1) & 1) * TB, q, r, acc.dW1, acc.dW2);
+        if (NBUF > 1) bwd_dw<NB, TSTR, MM>(T + ((pmax2 - 1) & 1) * TB, q, r, acc.dW1, acc.dW2);
         if constexpr (G::SPLIT) {  // two halves through the (smaller) staging area
           stage_part<NB, CPS, true, 0>(acc, dk0, T, lane);
           __syncthreads();
@@ -937,7 +982,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         const int kt = (wave * G::TPW + t) % G::NT;
         const float* Brow = dn + a.lay.K + (size_t)(16 * kt + r) * D + 4 * q;
 #pragma unroll
-        for (int jc = 0; jc < D / 16; ++jc) bfr[t][jc] = *(const f32x4*)(Brow + 16 * jc);
+        for (int jc = 0; jc < D / 16; ++jc) bfr[t][jc] = mm_pack<MM>(*(const f32x4*)(Brow + 16 * jc));
       }
       TLSAN_STAMP(6);
       __syncthreads();
@@ -953,11 +998,16 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         const float* Arow = sA + (16 * rt + r) * LSTR + 4 * q;
 #pragma unroll
         for (int jc = 0; jc < D / 16; jc += 2) {
-          const f32x4 av0 = *(const f32x4*)(Arow + 16 * jc), av1 = *(const f32x4*)(Arow + 16 * jc + 16);
+          const opd av0 = mm_pack<MM>(*(const f32x4*)(Arow + 16 * jc)), av1 = mm_pack<MM>(*(const f32x4*)(Arow + 16 * jc + 16));
+          if constexpr (MM == TLSAN_MATRIX_F32) {
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            acc0 = TLSAN_MFMA(av0[s], bfr[t][jc][s], acc0);
-            acc1 = TLSAN_MFMA(av1[s], bfr[t][jc + 1][s], acc1);
+            for (int s = 0; s < 4; ++s) {
+              acc0 = TLSAN_MFMA(av0[s], bfr[t][jc][s], acc0);
+              acc1 = TLSAN_MFMA(av1[s], bfr[t][jc + 1][s], acc1);
+            }
+          } else {
+            acc0 = mm_mma<MM>(av0, bfr[t][jc], acc0);
+            acc1 = mm_mma<MM>(av1, bfr[t][jc + 1], acc1);
           }
         }
         acc0 += acc1;
@@ -968,17 +1018,22 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       __syncthreads();
       TLSAN_STAMP(9);
       // ---------------------------------------------------------------- P5: long backward
+      if constexpr (TLSAN_EXP_STAGGER != 0 && NW == 8) {
+        // SIMD partners (waves w and w + 4) leave the barrier in lockstep and would want the matrix pipe, the LDS and
+        // the VALU at the same moments of every position: start the younger half a fraction of a position later
+        if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_sleep(TLSAN_EXP_STAGGER);
+      }
       {
         f32x4 dlong[NB], dummy[NB];
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) dlong[kb] = *(const f32x4*)(sB + srow * LSTR + chb[kb]);
-        float FN1[NB][NB][4], FN2[NB][NB][4];
-        load_frag_T<DH, NB>(w1W1, q, r, FT1);
+        opd FN1[NB][NB], FN2[NB][NB];
+        load_frag_T<DH, NB, MM>(w1W1, q, r, FT1);
         load_bias<DH, NB>(w1b1, q, b1);
-        load_frag_T<DH, NB>(w1W2, q, r, FT2);
+        load_frag_T<DH, NB, MM>(w1W2, q, r, FT2);
         load_bias<DH, NB>(w1b2, q, b2);
-        load_frag_N<DH, NB>(w1W1, q, r, FN1);
-        load_frag_N<DH, NB>(w1W2, q, r, FN2);
+        load_frag_N<DH, NB, MM>(w1W1, q, r, FN1);
+        load_frag_N<DH, NB, MM>(w1W2, q, r, FN2);
         if constexpr (LSTREAM) {
           AccSet<NB> acc;
           acc.zero();
@@ -992,13 +1047,13 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           if constexpr (G::AT_USE && !LSTREAM) {  // weight fragments from LDS at the use
             const int zz = opaque_zero(p);
             if constexpr (G::AT_USE_T) {
-              load_frag_T<DH, NB>(w1W1 + zz, q, r, FT1);
+              load_frag_T<DH, NB, MM>(w1W1 + zz, q, r, FT1);
               load_bias<DH, NB>(w1b1 + zz, q, b1);
-              load_frag_T<DH, NB>(w1W2 + zz, q, r, FT2);
+              load_frag_T<DH, NB, MM>(w1W2 + zz, q, r, FT2);
               load_bias<DH, NB>(w1b2 + zz, q, b2);
             }
-            load_frag_N<DH, NB>(w1W1 + zz, q, r, FN1);
-            load_frag_N<DH, NB>(w1W2 + zz, q, r, FN2);
+            load_frag_N<DH, NB, MM>(w1W1 + zz, q, r, FN1);
+            load_frag_N<DH, NB, MM>(w1W2 + zz, q, r, FN2);
           }
 
               fetch_lrow(p, ev, scx, sce);
@@ -1016,9 +1071,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
                   k2[kb] = drop_scale4(dc, 0, p, 1, chb[kb]);
                   xd[kb] = xv[kb] * k1[kb];
                 }
-                map_apply<NB>(FT1, b1, xd, z1);
+                map_apply<NB, MM>(FT1, b1, xd, z1);
               } else {
-                map_apply<NB>(FT1, b1, xv, z1);
+                map_apply<NB, MM>(FT1, b1, xv, z1);
               }
 #pragma unroll
               for (int kb = 0; kb < NB; ++kb)
@@ -1028,14 +1083,14 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
                 for (int kb = 0; kb < NB; ++kb) zr[kb] *= k2[kb];
               }
-              map_apply<NB>(FT2, b2, zr, m2);
+              map_apply<NB, MM>(FT2, b2, zr, m2);
 #pragma unroll
               for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                   av[kb][i] = vp ? __expf(m2[kb][i] - mx1[kb][i]) * iz1[kb][i] : 0.0f;
-              bwd_compute<NB, TSTR, DROP>(FN2, FN1, xv, z1, av, long4, dlong, T, q, r, acc.db1, acc.db2, dx, k1, k2);
-              bwd_dw<NB, TSTR>(T, q, r, acc.dW1, acc.dW2);
+              bwd_compute<NB, TSTR, DROP, MM>(FN2, FN1, xv, z1, av, long4, dlong, T, q, r, acc.db1, acc.db2, dx, k1, k2);
+              bwd_dw<NB, TSTR, MM>(T, q, r, acc.dW1, acc.dW2);
               float dsp = 0.0f;
 #pragma unroll
               for (int kb = 0; kb < NB; ++kb) dsp += dot4(dx[kb], ev[kb]);
@@ -1078,6 +1133,10 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           dsp[p] = 0.0f;
           if (p < pmax1) {
             const bool vp = p < n_l;
+            if (p == 1) TLSAN_STAMP(16);
+            if (p == 2) TLSAN_STAMP(17);
+            if (p == 9) TLSAN_STAMP(18);
+            const int posp = sP[srow * PSTR + p];   // (read with the position's other LDS operands; used by its stores)
             const float uth = sH[srow * 2 * LSC + LSC + p];
             const float scp = (gamma * P * P) * uth;  // x = e_stored * scp
             const float sce = (gamma * P) * uth;      // d x / d e_true
@@ -1085,13 +1144,13 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           if constexpr (G::AT_USE && !LSTREAM) {  // weight fragments from LDS at the use
             const int zz = opaque_zero(p);
             if constexpr (G::AT_USE_T) {
-              load_frag_T<DH, NB>(w1W1 + zz, q, r, FT1);
+              load_frag_T<DH, NB, MM>(w1W1 + zz, q, r, FT1);
               load_bias<DH, NB>(w1b1 + zz, q, b1);
-              load_frag_T<DH, NB>(w1W2 + zz, q, r, FT2);
+              load_frag_T<DH, NB, MM>(w1W2 + zz, q, r, FT2);
               load_bias<DH, NB>(w1b2 + zz, q, b2);
             }
-            load_frag_N<DH, NB>(w1W1 + zz, q, r, FN1);
-            load_frag_N<DH, NB>(w1W2 + zz, q, r, FN2);
+            load_frag_N<DH, NB, MM>(w1W1 + zz, q, r, FN1);
+            load_frag_N<DH, NB, MM>(w1W2 + zz, q, r, FN2);
           }
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) xv[kb] = e1[p][kb] * scp;
@@ -1105,9 +1164,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
                 k2[kb] = drop_scale4(dc, 0, p, 1, chb[kb]);
                 xd[kb] = xv[kb] * k1[kb];
               }
-              map_apply<NB>(FT1, b1, xd, z1);
+              map_apply<NB, MM>(FT1, b1, xd, z1);
             } else {
-              map_apply<NB>(FT1, b1, xv, z1);
+              map_apply<NB, MM>(FT1, b1, xv, z1);
             }
             if constexpr (KEEP_A) {
 #pragma unroll
@@ -1121,7 +1180,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
                 for (int kb = 0; kb < NB; ++kb) zr[kb] *= k2[kb];
               }
-              map_apply<NB>(FT2, b2, zr, m2);
+              map_apply<NB, MM>(FT2, b2, zr, m2);
 #pragma unroll
               for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
@@ -1130,40 +1189,74 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             }
             if (p == 1) TLSAN_STAMP(13);
             float* Tp = T + (NBUF > 1 ? (p & 1) * TB : 0);
-            bwd_compute<NB, TSTR, DROP>(FN2, FN1, xv, z1, av, long4, dlong, Tp, q, r, acc.db1, acc.db2, dx, k1, k2);
+            bwd_compute<NB, TSTR, DROP, MM>(FN2, FN1, xv, z1, av, long4, dlong, Tp, q, r, acc.db1, acc.db2, dx, k1, k2);
             if (p == 1) TLSAN_STAMP(14);
-            if (NBUF == 1) bwd_dw<NB, TSTR>(Tp, q, r, acc.dW1, acc.dW2);
-            else if (p > 0) bwd_dw<NB, TSTR>(T + ((p - 1) & 1) * TB, q, r, acc.dW1, acc.dW2);
+#if !(TLSAN_EXP_ABL & 4)
+            if (NBUF == 1) bwd_dw<NB, TSTR, MM>(Tp, q, r, acc.dW1, acc.dW2);
+            else if (p > 0) bwd_dw<NB, TSTR, MM>(T + ((p - 1) & 1) * TB, q, r, acc.dW1, acc.dW2);
+#endif
             if (p == 1) TLSAN_STAMP(15);
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) dsp[p] += dot4(dx[kb], e1[p][kb]);
             if (vs && vp) {
-              const int pos = sP[srow * PSTR + p];
+#if TLSAN_EXP_ABL & 2
+              const int pos = bidx * 10 + p;   // (timing experiment: no position read)
+#else
+              const int pos = posp;
+#endif
+#if !(TLSAN_EXP_ABL & 1)
               if (lead) a.Gb[pos] = 0.0f;
+#endif
 #pragma unroll
               for (int kb = 0; kb < NB; ++kb) {
                 const f32x4 de = dx[kb] * sce;
+#if TLSAN_EXP_ABL & 1
+                asm volatile("" :: "v"(de), "v"(pos));   // (timing experiment: no gradient-row stores in the long backward)
+#else
                 *(f32x4*)(a.Gi + (size_t)pos * D + chb[kb]) = de;
+#endif
                 sq_acc += dot4(de, de);
               }
             }
           }
         }
-        if (NBUF > 1 && pmax1 > 0) bwd_dw<NB, TSTR>(T + ((pmax1 - 1) & 1) * TB, q, r, acc.dW1, acc.dW2);
-        // usert_emb / gamma gradients: batched cross-lane reductions (independent chains)
+        if (NBUF > 1 && pmax1 > 0) bwd_dw<NB, TSTR, MM>(T + ((pmax1 - 1) & 1) * TB, q, r, acc.dW1, acc.dW2);
+        TLSAN_STAMP(19);
+        // usert_emb / gamma gradients.  Branch-free: every lane of a sample forms the same ten sums (vector-ALU
+        // cross-lane steps only, independent chains), the sample's hist_t / usert*hist_t rows come from the LDS
+        // as five 16-B reads, and the lead lane stores its [Ls | pad] piece of the user's gradient row as 16-B
+        // pieces.  (As ten lead-lane blocks, each with its own LDS reads and scalar store, this took 7.5 k cycles.)
+        {
+          static_assert(LSC % 2 == 0 && (2 * LSC) % 4 == 0, "sH rows are read as float4");
+          constexpr int NH4 = 2 * LSC / 4;
+          f32x4 sh4[NH4];
 #pragma unroll
-        for (int p = 0; p < LS; ++p) {
-          const float ds = sample_sum<CPS>(dsp[p]) * P;  // d loss / d scale[p] (e_true = P * e_stored)
-          if (lead && vs && p < Ls) {
-            const bool vp = p < n_l;
-            const float gt = vp ? ds * (gamma * sH[srow * 2 * LSC + p]) : 0.0f;  // d / d usert_emb[u][p]
-            a.Gu[(size_t)sP[srow * PSTR + P_USR] * a.WU + a.di + p] = gt;  // padded slots: 0
-            sq_acc += gt * gt;
-            dgam += vp ? ds * (P * sH[srow * 2 * LSC + LSC + p]) : 0.0f;
+          for (int k = 0; k < NH4; ++k) sh4[k] = *(const f32x4*)(sH + srow * 2 * LSC + 4 * k);
+          const int pos_u = sP[srow * PSTR + P_USR];
+          const float own = (lead && vs) ? 1.0f : 0.0f;   // one lane per sample counts
+          constexpr int NG = (LS + 3) / 4 + 1;            // float4 pieces that can hold [0, WU - di): Ls <= LS entries + padding
+          f32x4 gt4[NG];
+#pragma unroll
+          for (int k = 0; k < NG; ++k) gt4[k] = (f32x4)(0.0f);
+#pragma unroll
+          for (int p = 0; p < LS; ++p) {
+            const float ds = sample_sum<CPS>(dsp[p]) * P;  // d loss / d scale[p] (e_true = P * e_stored)
+            const bool vp = p < n_l;                        // (n_l <= Ls: padded slots and the row's padding stay 0)
+            const float ht = sh4[p / 4][p % 4], uth = sh4[(LSC + p) / 4][(LSC + p) % 4];
+            const float gt = vp ? ds * (gamma * ht) : 0.0f;  // d / d usert_emb[u][p]
+            gt4[p / 4][p % 4] = gt;
+            sq_acc += own * (gt * gt);
+            dgam += (vp ? ds * (P * uth) : 0.0f) * own;
+          }
+          if (lead && vs) {
+            float* gu = a.Gu + (size_t)pos_u * a.WU + a.di;
+            const int n4 = (a.WU - a.di) >> 2;
+#pragma unroll
+            for (int k = 0; k < NG; ++k)
+              if (k < n4) *(f32x4*)(gu + 4 * k) = gt4[k];
           }
         }
-        if (lead && vs)
-          for (int p = a.di + Ls; p < a.WU; ++p) a.Gu[(size_t)sP[srow * PSTR + P_USR] * a.WU + p] = 0.0f;
+        TLSAN_STAMP(20);
         if constexpr (G::SPLIT) {
           stage_part<NB, CPS, false, 0>(acc, dummy, T, lane);
           __syncthreads();
@@ -1177,13 +1270,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       }
       // scalars of this pass: wave-reduce, stage, one thread sums the waves in fixed order
       {
-        float s0 = dgam, s1 = loss_acc, s2 = sq_acc;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          s0 += __shfl_xor(s0, o);
-          s1 += __shfl_xor(s1, o);
-          s2 += __shfl_xor(s2, o);
-        }
+        const float s0 = wave_sum(dgam), s1 = wave_sum(loss_acc), s2 = wave_sum(sq_acc);
         if (lane == 0) {
           sS[wave * 4 + 0] = s0;
           sS[wave * 4 + 1] = s1;

@@ -11,10 +11,10 @@ static size_t fwd_smem_bytes(bool train, bool lstream) {
                           ((G::KEEP_A && train && !lstream) ? G::NW * TLSAN_LS_MAX * G::NB * 256 : 0));
 }
 
-template <int D, int DH, bool TRAIN, bool LSTREAM, int DT, bool DROP = false>
+template <int D, int DH, bool TRAIN, bool LSTREAM, int DT, bool DROP = false, int MM = TLSAN_MATRIX_F32>
 static hipError_t launch_variant_dt(const FwdArgs& a, int grid, hipStream_t st) {
   const size_t smem = fwd_smem_bytes<D, DH>(TRAIN, LSTREAM);
-  auto k = k_fwd_bwd<D, DH, TRAIN, LSTREAM, DT, DROP>;
+  auto k = k_fwd_bwd<D, DH, TRAIN, LSTREAM, DT, DROP, MM>;
   if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(k, dim3(grid), dim3(Geo<D, DH>::NW * 64), smem, st, a);
   return hipGetLastError();
@@ -23,6 +23,15 @@ static hipError_t launch_variant_dt(const FwdArgs& a, int grid, hipStream_t st) 
 // bf16 table storage: the common variants only (window in registers); streamed windows stay fp32
 template <int D, int DH, bool TRAIN, bool LSTREAM>
 static hipError_t launch_variant(const FwdArgs& a, int grid, hipStream_t st) {
+  if (a.p.matrix_dtype == TLSAN_MATRIX_BF16) {  // bf16 matrix products: window in registers, either table storage, no dropout
+    if (a.drop_thr != 0) return hipErrorNotSupported;
+    if constexpr (!LSTREAM) {
+      if (a.p.table_dtype == TLSAN_TABLE_BF16) return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_BF16, false, TLSAN_MATRIX_BF16>(a, grid, st);
+      return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_F32, false, TLSAN_MATRIX_BF16>(a, grid, st);
+    } else {
+      return hipErrorNotSupported;
+    }
+  }
   if (a.p.table_dtype == TLSAN_TABLE_BF16) {
     if (a.drop_thr != 0) return hipErrorNotSupported;
     if constexpr (!LSTREAM) return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_BF16>(a, grid, st);

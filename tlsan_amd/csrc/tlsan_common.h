@@ -22,7 +22,46 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
 #define TLSAN_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// ---- arithmetic of the matrix products (tlsan_params.matrix_dtype) ---------------------------------------
+// MM = TLSAN_MATRIX_F32: v_mfma_f32_16x16x4_f32, exact fp32 (the reference's precision); an operand of one
+// 16-deep contraction is the lane's f32x4 (k-step s = element s), i.e. four chained MFMAs.
+// MM = TLSAN_MATRIX_BF16: the same contraction as ONE v_mfma_f32_16x16x16_bf16 (lane (q, .) supplies
+// k = 4q .. 4q+3 -- exactly the four channels it owns): both operands rounded to bfloat16 (nearest even),
+// products and sums in fp32.  1/8 of the matrix-pipe time and a quarter of the dependent chain; the price
+// is 8 significant bits per operand (BASELINE.json configs[2] names bf16; a labelled build extension).
+template <int MM> struct MMT { typedef f32x4 opd; };
+template <> struct MMT<TLSAN_MATRIX_BF16> { typedef s16x4 opd; };
+
+template <int MM>
+__device__ __forceinline__ typename MMT<MM>::opd mm_pack(f32x4 v) {
+  if constexpr (MM == TLSAN_MATRIX_F32) {
+    return v;
+  } else {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};       // (one v_cvt_pk_bf16_f32 per pair)
+    uint2 u;
+    u.x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
+    u.y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
+    return __builtin_bit_cast(s16x4, u);
+  }
+}
+
+// acc += A (16 x 16-deep) . B  for one 16-channel contraction whose operands are held as above
+template <int MM>
+__device__ __forceinline__ f32x4 mm_mma(typename MMT<MM>::opd a, typename MMT<MM>::opd b, f32x4 acc) {
+  if constexpr (MM == TLSAN_MATRIX_F32) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = TLSAN_MFMA(a[s], b[s], acc);
+    return acc;
+  } else {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc, 0, 0, 0);
+  }
+}
 #define TLSAN_NEG (-1e30f)  // VERY_NEGATIVE_NUMBER, reference TLSAN/model.py:10-11
 
 #define TLSAN_LS_MAX 10  // long-term windows up to this size stay in registers (reference default Ls = 10)
@@ -154,28 +193,34 @@ __device__ __forceinline__ float weff(const float* __restrict__ W, int k, int j)
 
 // "T" fragment: A operand of  out[j] = sum_k W[k][j] v[k]   (forward maps):
 //   F[jb][kb][s] on lane (q, m=r)  = W_eff[16kb + 4q + s][16jb + r]
-template <int DH, int NB>
+template <int DH, int NB, int MM = TLSAN_MATRIX_F32>
 __device__ __forceinline__ void load_frag_T(const float* __restrict__ W, int q, int r,
-                                            float (&F)[NB][NB][4]) {
+                                            typename MMT<MM>::opd (&F)[NB][NB]) {
 #pragma unroll
   for (int jb = 0; jb < NB; ++jb)
 #pragma unroll
-    for (int kb = 0; kb < NB; ++kb)
+    for (int kb = 0; kb < NB; ++kb) {
+      f32x4 t;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) F[jb][kb][s] = weff<DH>(W, 16 * kb + 4 * q + s, 16 * jb + r);
+      for (int s = 0; s < 4; ++s) t[s] = weff<DH>(W, 16 * kb + 4 * q + s, 16 * jb + r);
+      F[jb][kb] = mm_pack<MM>(t);
+    }
 }
 
 // "N" fragment: A operand of  out[k] = sum_j W[k][j] v[j]   (backward maps):
 //   F[kb][jb][s] on lane (q, m=r)  = W_eff[16kb + r][16jb + 4q + s]
-template <int DH, int NB>
+template <int DH, int NB, int MM = TLSAN_MATRIX_F32>
 __device__ __forceinline__ void load_frag_N(const float* __restrict__ W, int q, int r,
-                                            float (&F)[NB][NB][4]) {
+                                            typename MMT<MM>::opd (&F)[NB][NB]) {
 #pragma unroll
   for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
-    for (int jb = 0; jb < NB; ++jb)
+    for (int jb = 0; jb < NB; ++jb) {
+      f32x4 t;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) F[kb][jb][s] = weff<DH>(W, 16 * kb + r, 16 * jb + 4 * q + s);
+      for (int s = 0; s < 4; ++s) t[s] = weff<DH>(W, 16 * kb + r, 16 * jb + 4 * q + s);
+      F[kb][jb] = mm_pack<MM>(t);
+    }
 }
 
 // bias in C-layout: lane (q, .) reg i of block jb  <->  channel-in-column 16jb + 4q + i
@@ -190,37 +235,117 @@ __device__ __forceinline__ void load_bias(const float* __restrict__ b, int q, f3
 // out = bias + F (x) v  in C-layout (see header comment).  Two accumulators per output block
 // (k-steps {0,1} and {2,3}) halve the dependent-MFMA chain: a lone wavefront stalls ~40 cycles
 // on every back-to-back dependent v_mfma_f32_16x16x4_f32.
-template <int NB>
-__device__ __forceinline__ void map_apply(const float (&F)[NB][NB][4], const f32x4 (&bias)[NB],
+template <int NB, int MM = TLSAN_MATRIX_F32>
+__device__ __forceinline__ void map_apply(const typename MMT<MM>::opd (&F)[NB][NB], const f32x4 (&bias)[NB],
                                           const f32x4 (&v)[NB], f32x4 (&out)[NB]) {
+  if constexpr (MM == TLSAN_MATRIX_F32) {
 #pragma unroll
-  for (int ob = 0; ob < NB; ++ob) {
-    f32x4 acc0 = bias[ob], acc1 = (f32x4)(0.0f);
+    for (int ob = 0; ob < NB; ++ob) {
+      f32x4 acc0 = bias[ob], acc1 = (f32x4)(0.0f);
 #pragma unroll
-    for (int ib = 0; ib < NB; ++ib) {
-      acc0 = TLSAN_MFMA(F[ob][ib][0], v[ib][0], acc0);
-      acc1 = TLSAN_MFMA(F[ob][ib][2], v[ib][2], acc1);
-      acc0 = TLSAN_MFMA(F[ob][ib][1], v[ib][1], acc0);
-      acc1 = TLSAN_MFMA(F[ob][ib][3], v[ib][3], acc1);
+      for (int ib = 0; ib < NB; ++ib) {
+        acc0 = TLSAN_MFMA(F[ob][ib][0], v[ib][0], acc0);
+        acc1 = TLSAN_MFMA(F[ob][ib][2], v[ib][2], acc1);
+        acc0 = TLSAN_MFMA(F[ob][ib][1], v[ib][1], acc0);
+        acc1 = TLSAN_MFMA(F[ob][ib][3], v[ib][3], acc1);
+      }
+      out[ob] = acc0 + acc1;
     }
-    out[ob] = acc0 + acc1;
+  } else {
+    typename MMT<MM>::opd pv[NB];
+#pragma unroll
+    for (int ib = 0; ib < NB; ++ib) pv[ib] = mm_pack<MM>(v[ib]);
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob) {
+      f32x4 acc = bias[ob];
+#pragma unroll
+      for (int ib = 0; ib < NB; ++ib) acc = mm_mma<MM>(F[ob][ib], pv[ib], acc);
+      out[ob] = acc;
+    }
   }
 }
 
-__device__ __forceinline__ int wave_max_i32(int v) {
+// ---- cross-lane helpers without the LDS ------------------------------------------------------------------
+// __shfl / __shfl_xor compile to ds_bpermute_b32: an LDS round trip each, and hipcc waits lgkmcnt(0) after
+// every one that sits in its own basic block -- the ten dependent 5-step sums at the end of the long backward
+// alone cost 7.5 k cycles per wavefront (scripts/stamps.py).  Everything below stays in the vector ALU:
+// DPP row operations inside a 16-lane row, v_permlane16/32_swap across the four rows, v_readlane for
+// wave-uniform picks.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+#define TLSAN_DPP_XOR1 0xB1   // quad_perm:[1,0,3,2]
+#define TLSAN_DPP_XOR2 0x4E   // quad_perm:[2,3,0,1]
+#define TLSAN_DPP_HMIRROR 0x141  // row_half_mirror: i <-> 7 - i   (after the quad steps: the other quad's sum)
+#define TLSAN_DPP_MIRROR 0x140   // row_mirror:      i <-> 15 - i  (after the half step: the other half's sum)
+#define TLSAN_DPP_ROR(n) (0x120 + (n))  // row_ror:n: lane i reads lane (i + n) % 16 of its row
+
+// sum over N consecutive lanes (aligned group of N = 2, 4, 8 or 16 inside a row); every lane gets the sum
+template <int N>
+__device__ __forceinline__ float lanes_sum(float v) {
+  if constexpr (N >= 2) v += dpp_f32<TLSAN_DPP_XOR1>(v);
+  if constexpr (N >= 4) v += dpp_f32<TLSAN_DPP_XOR2>(v);
+  if constexpr (N >= 8) v += dpp_f32<TLSAN_DPP_HMIRROR>(v);
+  if constexpr (N >= 16) v += dpp_f32<TLSAN_DPP_MIRROR>(v);
+  return v;
+}
+// sum over the lanes {i, i + S, i + 2S, ...} of a row (S = 1 .. 16 a power of two); every lane gets the sum
+template <int S>
+__device__ __forceinline__ float stride_sum(float v) {
+  if constexpr (S <= 8) v += dpp_f32<TLSAN_DPP_ROR(8)>(v);
+  if constexpr (S <= 4) v += dpp_f32<TLSAN_DPP_ROR(4)>(v);
+  if constexpr (S <= 2) v += dpp_f32<TLSAN_DPP_ROR(2)>(v);
+  if constexpr (S <= 1) v += dpp_f32<TLSAN_DPP_ROR(1)>(v);
+  return v;
+}
+// sum over the four rows of the wavefront (lane bits 4 and 5); every lane gets the sum.
+// v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second,
+// v_permlane32_swap the upper half of the first with the lower half of the second: fed two copies of v they
+// leave (r0, r0, r2, r2) / (r1, r1, r3, r3), then (lo, lo) / (hi, hi).  (Inline asm: the builtin folds the
+// two results of identical operands into one on ROCm 7.2; the s_nop covers the VALU-write -> permlane hazard.)
+__device__ __forceinline__ float rows_sum(float v) {
+  float a = v, b = v;
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  a += b;
+  b = a;
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+__device__ __forceinline__ float wave_sum(float v) { return rows_sum(lanes_sum<16>(v)); }
+
+// max over the wavefront of a value that is uniform over the lanes of each sample (lane s * CPS of row 0
+// speaks for sample s): SPW readlanes instead of six dependent cross-lane steps
+template <int CPS>
+__device__ __forceinline__ int wave_max_samples(int v) {
+  int m = __builtin_amdgcn_readlane(v, 0);
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v = max(v, __shfl_xor(v, o));
-  return __builtin_amdgcn_readfirstlane(v);
+  for (int s = 1; s < 16 / CPS; ++s) m = max(m, __builtin_amdgcn_readlane(v, s * CPS));
+  return m;
 }
 
 // sum over the lanes that own one sample: quarters (lane bits 4,5) and the CPS columns
 template <int CPS>
 __device__ __forceinline__ float sample_sum(float v) {
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 32);
+  return rows_sum(lanes_sum<CPS>(v));
+}
+
+// the value lane (row, s * CPS + c) holds, for the sample s of the calling lane: `row` and `c` wave-uniform
+// (one v_readlane per sample of the wavefront and a select, instead of a ds_bpermute)
+template <int CPS>
+__device__ __forceinline__ int sample_pick(int v, int row, int c, int s_loc) {
+  const int base = __builtin_amdgcn_readfirstlane(row * 16 + c);
+  int out = __builtin_amdgcn_readlane(v, base);
 #pragma unroll
-  for (int o = 1; o < CPS; o <<= 1) v += __shfl_xor(v, o);
-  return v;
+  for (int s = 1; s < 16 / CPS; ++s) {
+    const int x = __builtin_amdgcn_readlane(v, base + s * CPS);
+    out = (s_loc == s) ? x : out;
+  }
+  return out;
+}
+template <int CPS>
+__device__ __forceinline__ float sample_pick(float v, int row, int c, int s_loc) {
+  return __builtin_bit_cast(float, sample_pick<CPS>(__builtin_bit_cast(int, v), row, c, s_loc));
 }
 
 __device__ __forceinline__ float dot4(f32x4 a, f32x4 b) {

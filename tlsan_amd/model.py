@@ -146,7 +146,7 @@ class DeviceBatch:
 
 class Model(object):
     def __init__(self, config, item_cate_list, device="cuda:0", seed=1234, norm_mode="tf18", l2_mode="dense",
-                 table_dtype="f32", init="numpy"):
+                 table_dtype="f32", init="numpy", matrix_dtype="f32"):
         """table_dtype: "f32" (the reference's precision) or "bf16" -- item_emb / user_emb / cate_emb stored
         as bfloat16 (BASELINE.json configs[2]), arithmetic in fp32, updates written back with
         deterministic stochastic rounding; usert_emb, item_b and the dense weights stay fp32.
@@ -155,6 +155,12 @@ class Model(object):
         configs[4]; no host copy of the tables is ever made)."""
         if init not in ("numpy", "device"):
             raise ValueError("init must be 'numpy' or 'device'")
+        # matrix_dtype: arithmetic of the fused kernel's matrix products -- "f32": exact fp32 MFMA (the reference's
+        # precision); "bf16": operands rounded to bfloat16, fp32 products and sums (include/tlsan.h,
+        # tlsan_params.matrix_dtype).  An extension for BASELINE.json configs[2]; windows up to 10, no dropout.
+        if matrix_dtype not in ("f32", "bf16"):
+            raise ValueError("matrix_dtype must be 'f32' or 'bf16'")
+        self.matrix_dtype = matrix_dtype
         if table_dtype not in ("f32", "bf16"):
             raise ValueError("table_dtype must be 'f32' or 'bf16'")
         self.table_dtype = table_dtype
@@ -169,8 +175,8 @@ class Model(object):
         self.dropout = float(config.get("dropout", 0.0))           # model.py:116-118, 428-431
         if not 0.0 <= self.dropout < 1.0:
             raise ValueError("dropout must be in [0, 1)")
-        if self.dropout > 0.0 and table_dtype != "f32":
-            raise NotImplementedError("dropout > 0 is built for fp32 tables")
+        if self.dropout > 0.0 and (table_dtype != "f32" or matrix_dtype != "f32"):
+            raise NotImplementedError("dropout > 0 is built for fp32 tables and fp32 matrix products")
         self._seed = int(seed)
         self.optimizer = config.get("optimizer", "sgd")           # model.py:188-195
         if self.optimizer not in OPTIMIZERS:
@@ -296,7 +302,8 @@ class Model(object):
         self.cparams = L.Params(self.item_emb.data_ptr(), self.item_b.data_ptr(), self.user_emb.data_ptr(),
                                 self.usert_emb.data_ptr(), self.cate_emb.data_ptr(), self.dense.data_ptr(),
                                 self.dense_KT.data_ptr(), self.item_cate.data_ptr(), 0, 0, 0, 0, None,
-                                L.TABLE_BF16 if self.table_dtype == "bf16" else L.TABLE_F32)
+                                L.TABLE_BF16 if self.table_dtype == "bf16" else L.TABLE_F32,
+                                L.MATRIX_BF16 if self.matrix_dtype == "bf16" else L.MATRIX_F32)
 
     def _alloc_slots(self):
         """Accumulators of adam / rmsprop / adadelta (tlsan_optimizer in include/tlsan.h): two sets of
