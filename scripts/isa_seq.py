@@ -9,7 +9,7 @@ subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + ro
                 "-fPIC", "-c", root + "/tlsan_amd/csrc/tlsan_attn_d128.hip", "-save-temps", "-o", "x.o"], cwd=tmp,
                stderr=subprocess.DEVNULL)
 src = open(glob.glob(tmp + "/*gfx950*.s")[0]).read().split("\n")
-a = next(i for i, l in enumerate(src) if l.startswith("_Z9k_fwd_bwdILi128ELi16ELb1ELb0ELi0ELb0EEv7FwdArgs:"))
+a = next(i for i, l in enumerate(src) if l.startswith("_Z9k_fwd_bwdILi128ELi16ELb1ELb0ELi0ELb0ELi0EEv7FwdArgs:"))
 b = next(i for i in range(a, len(src)) if "s_endpgm" in src[i])
 lines = src[a:b]
 marks = [i for i, l in enumerate(lines) if "s_memtime" in l]

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Diagnostic: per-phase cycle shares of k_fwd_bwd from in-kernel s_memtime stamps."""
 import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the production kernel carries no stamp code: build the variant first (scripts/mkvariants.sh stamps:"-DTLSAN_STAMPS=1")
+os.environ.setdefault("TLSAN_LIB_PATH", os.path.join(ROOT, "ab_libs", "stamps.so"))
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -37,6 +40,15 @@ full = (raw[:, :, 9] > 0) & (raw[:, :, 18] > 0)     # waves whose window is full
 def seg(nm, lo, hi, sel=None):
     dd = (raw[:, :, hi] - raw[:, :, lo])[ok if sel is None else sel]
     print("%-44s mean %8.0f p50 %8.0f max %8.0f" % (nm, dd.mean(), np.median(dd), dd.max()))
+seg("P1: loads issued -> rows in registers", 0, 21)
+seg("P1: weight fragments from the LDS", 21, 22)
+seg("P1: long forward (maps, softmax)", 22, 23)
+seg("P1: store long, issue P3's row loads + bridge B", 23, 1)
+seg("P3: frags + first session loads", 4, 24)
+seg("P3: forward positions + normalise", 24, 25)
+seg("P3: logit, BCE, candidate / user stores", 25, 26)
+seg("P3: backward positions", 26, 27)
+seg("P3: stage accumulators + dlong B loads", 27, 6)
 seg("P5: entry -> start of position 1 (frags, pos 0)", 9, 16)
 seg("P5 pos1: start -> row scaled (LDS read of uth)", 16, 12)
 seg("P5 pos1: after dW -> start of position 2 (stores)", 15, 17)

@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libtlsan_hip.so")
+# (TLSAN_LIB_PATH: a diagnostic build of the same library, e.g. the -DTLSAN_STAMPS=1 variant of scripts/stamps.py)
+LIB_PATH = os.environ.get("TLSAN_LIB_PATH") or os.path.join(HERE, "libtlsan_hip.so")
 
 ABI_VERSION = 10
 NORM_TF18, NORM_DEDUP = 0, 1

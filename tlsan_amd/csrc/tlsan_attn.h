@@ -92,7 +92,7 @@ __device__ __forceinline__ void fwa_forward(const typename MMT<MM>::opd (&FT1)[N
   for (int kb = 0; kb < NB; ++kb) {
     out[kb] = (f32x4)(0.0f);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) Z[kb][i] = 1.0f / Z[kb][i];
+    for (int i = 0; i < 4; ++i) Z[kb][i] = fast_rcp(Z[kb][i]);
   }
 #pragma unroll
   for (int p = 0; p < NPOS; ++p)
@@ -214,16 +214,18 @@ __device__ __forceinline__ void bwd_dw(const float* __restrict__ T, int q, int r
 
 // 16-B gather of channels [c, c+4) of the concatenated row [item_emb[it] || cate_emb[cat[it]]]
 // (model.py:84-86,105-107,111-113)
+// (the ADDRESS is selected, then one load is issued: a load in each arm of a ?: makes hipcc branch around both)
 template <int DT = TLSAN_TABLE_F32>
-__device__ __forceinline__ f32x4 gather_item4(const FwdArgs& a, int it, int c) {
-  return (c < a.di) ? tbl_ld4<DT>(a.p.item_emb, (size_t)it * a.p.ld_item + c)
-                    : tbl_ld4<DT>(a.p.cate_emb, (size_t)a.p.item_cate[it] * a.dc + (c - a.di));
+__device__ __forceinline__ f32x4 gather_item4c(const FwdArgs& a, int it, int ct, int c) {
+  const bool item = c < a.di;
+  const float* base = item ? a.p.item_emb : a.p.cate_emb;
+  const size_t idx = item ? (size_t)it * a.p.ld_item + c : (size_t)ct * a.dc + (c - a.di);
+  return tbl_ld4<DT>(base, idx);
 }
 
 template <int DT = TLSAN_TABLE_F32>
-__device__ __forceinline__ f32x4 gather_item4c(const FwdArgs& a, int it, int ct, int c) {
-  return (c < a.di) ? tbl_ld4<DT>(a.p.item_emb, (size_t)it * a.p.ld_item + c)
-                    : tbl_ld4<DT>(a.p.cate_emb, (size_t)ct * a.dc + (c - a.di));
+__device__ __forceinline__ f32x4 gather_item4(const FwdArgs& a, int it, int c) {
+  return gather_item4c<DT>(a, it, a.p.item_cate[it], c);
 }
 
 // Per-pass, per-wave gradient accumulators of one attention block, and their deterministic
@@ -446,6 +448,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #ifndef TLSAN_EXP_SESS_EARLY
 #define TLSAN_EXP_SESS_EARLY 0
 #endif
+#ifndef TLSAN_EXP_FLIP
+#define TLSAN_EXP_FLIP 0
+#endif
 #ifndef TLSAN_EXP_ABL
 #define TLSAN_EXP_ABL 0   // timing-only ablations (wrong results): 1 no row stores in P5, 2 no position read, 4 no dW products in P5
 #endif
@@ -454,11 +459,21 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     // segment (MI355X_MICROARCH.md, two waves per SIMD, item 4): one static priority raise, no flips
     if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(TLSAN_EXP_PRIO);
   }
+  // diagnostic cycle stamps: only in a -DTLSAN_STAMPS=1 build (scripts/stamps.py loads it through TLSAN_LIB_PATH;
+  // the production kernel carries no stamp code).  Kept in the LDS while the pass runs -- a global store per stamp
+  // would sit in front of every later vmcnt(0) wait and distort what it measures -- and copied out at the end.
+#ifndef TLSAN_STAMPS
+#define TLSAN_STAMPS 0
+#endif
+#if TLSAN_STAMPS
+  unsigned long long* sStamp = (unsigned long long*)(sT + NW * G::WSCR + ((G::KEEP_A && TRAIN && !LSTREAM) ? NW * LS * NB * 256 : 0)) + wave * 32;
 #define TLSAN_STAMP(k)                                                                       \
   do {                                                                                       \
-    if (a.stamps != nullptr && lane == 0)                                                    \
-      a.stamps[((size_t)blockIdx.x * NW + wave) * 32 + (k)] = __builtin_amdgcn_s_memtime();  \
+    if (a.stamps != nullptr && lane == 0) sStamp[k] = __builtin_amdgcn_s_memtime();          \
   } while (0)
+#else
+#define TLSAN_STAMP(k) do { } while (0)
+#endif
 
   for (int g = blockIdx.x; g < a.ngroups; g += gridDim.x) {
     TLSAN_STAMP(0);
@@ -479,7 +494,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     // back to back: three dependent round trips (ids -> categories -> rows) for all LS positions
     // together; padding is applied afterwards by selects (padded slots contribute exactly 0).
     f32x4 e1[LS][NB], long4[NB], mx1[NB], iz1[NB];
-    int posv[TRAIN ? LS + 3 : 1];
+    int posv[(TRAIN && LSTREAM) ? LS + 3 : 1];   // (streamed window: the three single uses, drawn by the lead lane)
+    int upos = 0;                                // (window in registers: the cursor draw of this lane's use slot)
     const int pmax1 = wave_max_samples<CPS>(n_l);
     // ---- streamed long block (LSTREAM): ids, scales and positions live one per lane of the sample
     // (lane kk = entry base + kk of the current chunk) and are broadcast with cross-lane reads
@@ -528,7 +544,10 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     int spos0 = 0;  // position of session use kk (first chunk): one returning atomic per use
     f32x4 xnext[NB];
     const int pmax2e = wave_max_samples<CPS>(n_s + 1);
+    int ucat = 0, ct_i = 0;   // category of the user's row / of the candidate: fetched with the window's ids
     if constexpr (LSTREAM) {
+      ucat = a.b.u_cate[bb];
+      ct_i = a.p.item_cate[it_i];
       opd FT1[NB][NB], FT2[NB][NB];
       f32x4 b1[NB], b2[NB], Zl[NB];
       load_frag_T<DH, NB, MM>(w1W1, q, r, FT1);
@@ -599,70 +618,80 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          iz1[kb][i] = Zl[kb][i] > 0.0f ? 1.0f / Zl[kb][i] : 0.0f;  // samples past the batch: no position
+          iz1[kb][i] = Zl[kb][i] > 0.0f ? fast_rcp(Zl[kb][i]) : 0.0f;  // samples past the batch: no position
           long4[kb][i] *= iz1[kb][i];
         }
     } else
     {
-      // Three explicit load stages (ids/scales -> categories -> rows); sched_barrier keeps the
-      // compiler from interleaving a stage's loads with their first uses, which otherwise
-      // serialises them into one round trip per position.
-      float sc1[LS], hts[LS], uts[LS];
-      int its[LS], cts[LS];
-#pragma unroll
-      for (int p = 0; p < LS; ++p) {
-        const int pc = min(p, Ls - 1);
-        its[p] = a.b.hist_i[(size_t)bb * Ls + pc];
-        hts[p] = a.b.hist_t[(size_t)bb * Ls + pc];
-        uts[p] = a.p.usert_emb[(size_t)uid * a.p.ld_usert + pc];
-      }
+      // Four explicit issue stages, each one dependent round trip deep: ids / scales -> categories -> rows ->
+      // cursor draws.  sched_barrier keeps the compiler from interleaving a stage's loads with their first uses
+      // (left alone it serialises them into one round trip per position).  The returning atomics come LAST:
+      // vmcnt retires in issue order, so rows issued behind them would not count as arrived before every atomic
+      // of the wavefront has returned (about 3 k cycles with all CUs drawing at once) -- as it was when each
+      // use drew its cursor from the lead lane in a block of its own, with a vmcnt(0) in the middle.
+      // Now lane k of a sample's 4*CPS lanes owns use slot k (long positions, candidate, user, u_cate): ONE
+      // atomic instruction per wavefront draws them all and lane k files its result in the LDS itself.
+      // The window's ids, time weights, usert entries and categories are loaded ONE ENTRY PER LANE (lane k of the
+      // sample's lanes: entry k) -- four coalesced wave instructions instead of forty that each fetch the same two
+      // dwords for all lanes of a sample (the vector-memory front end, not latency, paces the head of the kernel) --
+      // and handed to the sample's lanes with v_readlane (sample_pick).
+      float sc1[LS];
+      constexpr int NU = LS + 3;
+      static_assert(4 * CPS >= NU, "a sample's lanes must cover its use slots");
+      const int kku = q * CPS + col;
+      const int kc = min(kku, Ls - 1);
+      const int id_k = a.b.hist_i[(size_t)bb * Ls + kc];
+      const float ht_k = a.b.hist_t[(size_t)bb * Ls + kc];
+      const float ut_k = a.p.usert_emb[(size_t)uid * a.p.ld_usert + kc];
+      ucat = a.b.u_cate[bb];
+      ct_i = a.p.item_cate[it_i];   // (with the stage that already waits for the sample's scalars: no trip of its own later)
       // (SESS_EARLY) the short block's first chunk of ids, their categories, the cursor draws and the first session
       // row depend on the ids only: each of their three dependent loads rides with the long block's stage of the
       // same depth, instead of three round trips of their own at the start of P3
       if constexpr (SESS_EARLY) sid = (Sn > 0) ? a.b.hist_i_new[(size_t)bb * Sn + min(kk, max(Sn - 1, 0))] : 0;
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (SESS_EARLY) scat = a.p.item_cate[sid];
-#pragma unroll
-      for (int p = 0; p < LS; ++p) cts[p] = TLSAN_EXP_FAKECAT ? (its[p] & 511) : a.p.item_cate[its[p]];
-      if constexpr (TRAIN) {
-        // destination-sorted row of every long use: issue all the returning atomics now; their
-        // results are only published to LDS after the bridge GEMM (nothing waits on them here)
-#pragma unroll
-        for (int p = 0; p < LS; ++p) posv[p] = (lead && p < n_l) ? atomicAdd(&a.cur_item[its[p]], 1) : 0;
-        posv[LS] = (lead && vs) ? atomicAdd(&a.cur_item[it_i], 1) : 0;
-        posv[LS + 1] = (lead && vs) ? atomicAdd(&a.cur_user[uid], 1) : 0;
-        // (a per-lane copy of the flag: a scalar branch here would split the batch of returning atomics)
-        posv[LS + 2] = (lead && vs && (a.uc_by_sample + opaque_zero(lane)) == 0) ? atomicAdd(&a.cur_uc[a.b.u_cate[bb]], 1) : bidx;
-        if constexpr (SESS_EARLY) spos0 = (vs && kk < n_s) ? atomicAdd(&a.cur_item[sid], 1) : 0;
-      }
+      const int ct_k = TLSAN_EXP_FAKECAT ? (id_k & 511) : a.p.item_cate[id_k];
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int p = 0; p < LS; ++p)
+      for (int p = 0; p < LS; ++p) {
+        const int it = sample_pick<CPS>(id_k, p / CPS, p % CPS, s_loc), ct = sample_pick<CPS>(ct_k, p / CPS, p % CPS, s_loc);
 #pragma unroll
-        for (int kb = 0; kb < NB; ++kb) e1[p][kb] = gather_item4c<DT>(a, its[p], cts[p], chb[kb]);
+        for (int kb = 0; kb < NB; ++kb) e1[p][kb] = gather_item4c<DT>(a, it, ct, chb[kb]);
+      }
       if constexpr (SESS_EARLY) {
         if (pmax2e > 1) fetch_row(0, xnext);
       }
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int p = 0; p < LS; ++p) {
-        const bool vp = p < n_l;
-        sc1[p] = vp ? (gamma * P * P) * (uts[p] * hts[p]) : 0.0f;  // model.py:100-102,109 (e1, ut stored / P)
-        if (TRAIN && lead) {
-          sH[srow * 2 * LSC + p] = vp ? hts[p] : 0.0f;
-          sH[srow * 2 * LSC + LSC + p] = vp ? uts[p] * hts[p] : 0.0f;
-        }
-#pragma unroll
-        for (int kb = 0; kb < NB; ++kb) e1[p][kb] = vp ? e1[p][kb] : (f32x4)(0.0f);
+      if constexpr (TRAIN) {
+        const bool is_long = kku < LS;
+        const int id = is_long ? id_k : (kku == LS ? it_i : (kku == LS + 1 ? uid : ucat));
+        int32_t* cur = kku <= LS ? a.cur_item : (kku == LS + 1 ? a.cur_user : a.cur_uc);
+        const bool act = vs && (is_long ? kku < n_l : (kku < LS + 2 || (kku == LS + 2 && a.uc_by_sample == 0)));
+        upos = act ? atomicAdd(cur + id, 1) : (kku == LS + 2 ? bidx : 0);   // (u_cate rows in sample order: position = sample)
+        if constexpr (SESS_EARLY) spos0 = (vs && kk < n_s) ? atomicAdd(&a.cur_item[sid], 1) : 0;
       }
+      __builtin_amdgcn_sched_barrier(0);
+      // padded slots: scale 0 (model.py:384 gives them weight exactly 0; their clamped rows are finite table rows),
+      // so no select on the rows themselves -- the forward can start on position 0 while later rows are in flight
+      const float uth_k = (kku < n_l) ? ut_k * ht_k : 0.0f;
+      if (TRAIN && kku < LS) {   // lane k files its own entry: hist_t and usert * hist_t of the pass (0 on padded slots)
+        sH[srow * 2 * LSC + kku] = (kku < n_l) ? ht_k : 0.0f;
+        sH[srow * 2 * LSC + LSC + kku] = uth_k;
+      }
+#pragma unroll
+      for (int p = 0; p < LS; ++p) sc1[p] = (gamma * P * P) * sample_pick<CPS>(uth_k, p / CPS, p % CPS, s_loc);  // model.py:100-102,109
+      TLSAN_STAMP(21);
       opd FT1[NB][NB], FT2[NB][NB];
       f32x4 b1[NB], b2[NB];
       load_frag_T<DH, NB, MM>(w1W1, q, r, FT1);
       load_frag_T<DH, NB, MM>(w1W2, q, r, FT2);
       load_bias<DH, NB>(w1b1, q, b1);
       load_bias<DH, NB>(w1b2, q, b2);
+      TLSAN_STAMP(22);
       fwa_forward<NB, LS, DROP, MM>(FT1, b1, FT2, b2, e1, sc1, n_l, pmax1, mx1, iz1, long4, KEEP_A ? sAw : nullptr, dc, 0, chb);
     }
+    TLSAN_STAMP(23);
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
       *(f32x4*)(sA + srow * LSTR + chb[kb]) = long4[kb];
@@ -673,9 +702,13 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
       const int c = chb[kb];
-      uemb[kb] = ((c < a.di) ? tbl_ld4<DT>(a.p.user_emb, (size_t)uid * a.p.ld_user + c)
-                             : tbl_ld4<DT>(a.p.cate_emb, (size_t)a.b.u_cate[bb] * a.dc + (c - a.di))) * P;
-      iemb[kb] = gather_item4<DT>(a, it_i, c) * P;
+      {
+        const bool usr = c < a.di;
+        const float* ub = usr ? a.p.user_emb : a.p.cate_emb;
+        const size_t ui = usr ? (size_t)uid * a.p.ld_user + c : (size_t)ucat * a.dc + (c - a.di);
+        uemb[kb] = tbl_ld4<DT>(ub, ui) * P;
+      }
+      iemb[kb] = gather_item4c<DT>(a, it_i, ct_i, c) * P;
     }
     const float ib_i = a.p.item_b[(size_t)it_i * a.p.ld_itemb];
 
@@ -726,14 +759,15 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     const int n_pos = n_s + 1;  // model.py:355: rep_length = sl_new + 1
     const int pmax2 = wave_max_samples<CPS>(n_pos);
     if constexpr (TRAIN) {
-      if (lead) {
-        if constexpr (!LSTREAM) {
-#pragma unroll
-          for (int p = 0; p < LS; ++p) sP[srow * PSTR + p] = posv[p];
+      if constexpr (LSTREAM) {
+        if (lead) {
+          sP[srow * PSTR + P_TGT] = posv[LS];
+          sP[srow * PSTR + P_USR] = posv[LS + 1];
+          sP[srow * PSTR + P_UC] = posv[LS + 2];
         }
-        sP[srow * PSTR + P_TGT] = posv[LS];
-        sP[srow * PSTR + P_USR] = posv[LS + 1];
-        sP[srow * PSTR + P_UC] = posv[LS + 2];
+      } else {
+        const int kku = q * CPS + col;   // use slot of this lane (P_TGT, P_USR, P_UC are consecutive)
+        if (kku < LS + 3) sP[srow * PSTR + (kku < LS ? kku : P_TGT + (kku - LS))] = upos;
       }
     }
     opd FT1[NB][NB], FT2[NB][NB];
@@ -747,6 +781,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       if constexpr (TRAIN) spos0 = (vs && kk < n_s) ? atomicAdd(&a.cur_item[sid], 1) : 0;
       if (pmax2 > 1) fetch_row(0, xnext);
     }
+    TLSAN_STAMP(24);
     f32x4 mx[NB], Zs[NB], short4[NB];
     {
       f32x4 xv[NB], z[NB];
@@ -826,7 +861,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        Zs[kb][i] = 1.0f / Zs[kb][i];
+        Zs[kb][i] = fast_rcp(Zs[kb][i]);
         short4[kb][i] *= Zs[kb][i];
       }
     if constexpr (TRAIN) {  // publish the session positions (the atomics are long back by now)
@@ -836,6 +871,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         if (vs && t < n_s) sP[srow * PSTR + LSC + t] = atomicAdd(&a.cur_item[a.b.hist_i_new[(size_t)bb * Sn + t]], 1);
       }
     }
+    TLSAN_STAMP(25);
     // u_t = short + [user_emb[u] || cate_emb[u_cate]]   (model.py:93-95,135)
     f32x4 ut4[NB];
     float part = 0.0f;
@@ -862,7 +898,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       const float yv = a.b.y[bb];
       const float en = __expf(-fabsf(logit));
       const float lb = fmaxf(logit, 0.0f) - logit * yv + __logf(1.0f + en);
-      const float sg = logit >= 0.0f ? 1.0f / (1.0f + en) : en / (1.0f + en);
+      const float rden = fast_rcp(1.0f + en);
+      const float sg = logit >= 0.0f ? rden : en * rden;
       const float dl = vs ? (sg - yv) * a.inv_B : 0.0f;
       const int pos_t = sP[srow * PSTR + P_TGT], pos_u = sP[srow * PSTR + P_USR], pos_c = sP[srow * PSTR + P_UC];
       if (lead && vs) {
@@ -885,6 +922,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           sq_acc += dot4(dout[kb], dout[kb]) + dot4(gi, gi);
         }
       }
+      TLSAN_STAMP(26);
       {
         opd FN1[NB][NB], FN2[NB][NB];
         load_frag_N<DH, NB, MM>(w2W1, q, r, FN1);
@@ -967,6 +1005,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           }
         }
         if (NBUF > 1) bwd_dw<NB, TSTR, MM>(T + ((pmax2 - 1) & 1) * TB, q, r, acc.dW1, acc.dW2);
+        TLSAN_STAMP(27);
         if constexpr (G::SPLIT) {  // two halves through the (smaller) staging area
           stage_part<NB, CPS, true, 0>(acc, dk0, T, lane);
           __syncthreads();
@@ -1136,6 +1175,13 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             if (p == 1) TLSAN_STAMP(16);
             if (p == 2) TLSAN_STAMP(17);
             if (p == 9) TLSAN_STAMP(18);
+#if TLSAN_EXP_FLIP
+            // SIMD partners (waves w, w + 4) take turns at the higher issue priority, position by position
+            if (NW == 8) {
+              if ((__builtin_amdgcn_readfirstlane(wave) >> 2) == (p & 1)) __builtin_amdgcn_s_setprio(1);
+              else __builtin_amdgcn_s_setprio(0);
+            }
+#endif
             const int posp = sP[srow * PSTR + p];   // (read with the position's other LDS operands; used by its stores)
             const float uth = sH[srow * 2 * LSC + LSC + p];
             const float scp = (gamma * P * P) * uth;  // x = e_stored * scp
@@ -1288,6 +1334,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         prec[G::P_GAMMA + tid] = s;
       }
       TLSAN_STAMP(11);
+#if TLSAN_STAMPS
+      if (a.stamps != nullptr && lane < 32) a.stamps[((size_t)blockIdx.x * NW + wave) * 32 + lane] = sStamp[lane];
+#endif
     }
     // Next pass: sA is rewritten in P1 (last read in P4), sB in P2 (last read at the top of
     // P5), sH rows are wave-private, sT/sS are rewritten in P3/P5 (last read right above; the
