@@ -23,14 +23,17 @@ for d in (64, 128, 256):
             out = m.grads(tup(b))
             el = np.abs(out["logits"] - r["logits"]).max()
             gq = orc.backward(q, cat, b, 8, cfg["regulation_rate"])
+            gq_loss = gq[0]
             gq = gq[2]
-            errs = {}
+            errs, l2 = {}, {}
             for k, v in out["grads"].items():
                 if k in gq and not k.endswith("_b2"):      # (b2 of both blocks: mathematically zero gradient)
                     ref_g = np.asarray(gq[k], np.float64).reshape(np.shape(v))
                     errs[k] = float(np.abs(v - ref_g).max() / (np.abs(ref_g).max() + 1e-12))
-            print("d=%d tables=%s matrix=%s: max|dlogit| %.2e (logit scale %.2f)  worst rel grad err %.2e (%s)" %
-                  (d, tdt, mdt, el, np.abs(r["logits"]).max(), max(errs.values()) if errs else -1, max(errs, key=errs.get) if errs else ""), flush=True)
+                    l2[k] = float(np.linalg.norm(v - ref_g) / (np.linalg.norm(ref_g) + 1e-30))
+            print("d=%d tables=%s matrix=%s: max|dlogit| %.2e (logit scale %.2f)  worst rel grad err %.2e (%s)  worst L2-rel %.2e (%s) loss err %.2e" %
+                  (d, tdt, mdt, el, np.abs(r["logits"]).max(), max(errs.values()) if errs else -1, max(errs, key=errs.get) if errs else "",
+                   max(l2.values()), max(l2, key=l2.get), abs(out["loss"] - gq_loss)), flush=True)
 cfg = synth.make_config("electronics")
 icl = synth.item_cate_list(cfg)
 hb = synth.make_batches(cfg, 8, 4096, seed=1234)

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--epochs", type=int, default=20)
     ap.add_argument("--l2_mode", default="dense")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--extra", default="", help="further tlsan_amd.train flags, e.g. '--matrix_dtype bf16 --hidden_units 128'")
     a = ap.parse_args()
     from tlsan_amd import train as T
     from tlsan_amd.build_dataset import build_packed
@@ -50,7 +51,7 @@ def main():
         res = []
         for seed in seeds:
             args = T.parse(["--quiet", "--eval_topk", "0", "--max_epochs", str(a.epochs), "--seed", str(seed),
-                            "--l2_mode", a.l2_mode, "--model_dir", "/tmp/tlsan_band/%s_%d" % (name, seed)])
+                            "--l2_mode", a.l2_mode, "--model_dir", "/tmp/tlsan_band/%s_%d" % (name, seed)] + a.extra.split())
             train_set.order = np.arange(len(train_set.u), dtype=np.int64)      # every run starts from the built order
             r = T.train(args, data=(train_set, test_set, (U, I, C), z["item_cate_list"].astype(np.int32)))
             res.append(dict(seed=seed, init_auc=r["init_auc"], best_auc=r["best_auc"], final_auc=r["final_auc"],
@@ -72,7 +73,8 @@ def main():
         print("| %s | %d / %d / %d | %d | %.4f | %.4f ± %.4f (%s) | %+.4f | %+.1f | %.4f |"
               % (r["readme_name"], r["users"], r["items"], r["cates"], r["train_samples"], r["readme_auc"], r["mean"], sg,
                  ", ".join("%.4f" % x["best_auc"] for x in r["runs"]), d, d / sg if sg else float("nan"), r["sampling_sigma"]))
-    print("\n(%d runs, %.0f s wall; protocol: tlsan_amd.train defaults = TLSAN/train.py:26-49; l2_mode=%s)" % (len(rows) * len(seeds), time.time() - t_all, a.l2_mode))
+    print("\n(%d runs, %.0f s wall; protocol: tlsan_amd.train defaults = TLSAN/train.py:26-49; l2_mode=%s%s)"
+          % (len(rows) * len(seeds), time.time() - t_all, a.l2_mode, "; extra flags: " + a.extra if a.extra else ""))
     if a.json:
         json.dump(rows, open(a.json, "w"), indent=1)
 

@@ -47,6 +47,8 @@ def parse(argv=None):
     ap.add_argument("--quiet", action="store_true")
     ap.add_argument("--table_dtype", default="f32", choices=["f32", "bf16"],
                     help="storage of item/user/category tables (bf16: fp32 arithmetic, stochastic rounding on update)")
+    ap.add_argument("--matrix_dtype", default="f32", choices=["f32", "bf16"],
+                    help="arithmetic of the fused kernel's matrix products (bf16: operands rounded to bfloat16, fp32 accumulate)")
     ap.add_argument("--l2_mode", default="dense", choices=["dense", "lazy"])
     ap.add_argument("--eval_topk", type=int, default=1,
                     help="P@k / R@k at every evaluation point like the reference (train.py:209-218); 0: once at the end")
@@ -162,7 +164,7 @@ def train(args, data=None):
     say(json.dumps(config, indent=4), flush=True)
     resume = prepare_model_dir(args.model_dir, args.from_scratch)      # train.py:124-127
     model = Model(config, icl, device=args.device, seed=args.seed, norm_mode=args.norm_mode, l2_mode=args.l2_mode,
-                  table_dtype=args.table_dtype)
+                  table_dtype=args.table_dtype, matrix_dtype=args.matrix_dtype)
     if resume is not None:                                             # train.py:71-76 (create_model)
         say("Reloading model parameters..", flush=True)
         model.restore(None, resume)
@@ -287,6 +289,8 @@ def train_sharded(args):
         raise NotImplementedError("--table_dtype %s: the sharded step keeps fp32 rows" % args.table_dtype)
     if args.norm_mode != "tf18":
         raise NotImplementedError("--norm_mode %s: the sharded step forms the clip norm as TF 1.8 does (tf18)" % args.norm_mode)
+    if args.matrix_dtype != "f32":
+        raise NotImplementedError("--matrix_dtype %s: the sharded step computes in fp32" % args.matrix_dtype)
     resume = prepare_model_dir(args.model_dir, args.from_scratch, rank,
                                (lambda: dist.barrier()) if world > 1 else None)     # train.py:124-127
     model = ShardedModel(config, icl, device=args.device, seed=args.seed,
