@@ -8,7 +8,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 cd "$R"
 mkdir -p ab_libs
 build() {  # name flags
-  rm -f tlsan_amd/csrc/build/tlsan_attn_d128.o tlsan_amd/csrc/build/tlsan_attn_d64.o
+  rm -f tlsan_amd/csrc/build/*.o
   TLSAN_HIPCC_EXTRA="$2" python -c "from tlsan_amd import build; build.build()" > /dev/null
   cp tlsan_amd/libtlsan_hip.so ab_libs/$1.so
   echo "built ab_libs/$1.so  [$2]"

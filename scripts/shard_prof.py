@@ -10,17 +10,17 @@ from tlsan_amd.dist import ShardedModel
 cfg = synth.make_config("electronics")
 m = ShardedModel(cfg, synth.item_cate_list(cfg), l2_mode=os.environ.get("SHARD_L2", "dense"))
 dbs = [m.device_batch(b) for b in synth.make_batches(cfg, 4, 4096, seed=1)]
-for s in range(10):
+for s in range(12):
     m.train_async(dbs[s % 4], 1.0, next_batch=dbs[(s + 1) % 4])
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-for s in range(50):
+for s in range(52):
     m.train_async(dbs[s % 4], 1.0, next_batch=dbs[(s + 1) % 4])
 torch.cuda.synchronize()
-print("step %.1f us" % ((time.perf_counter() - t0) / 50 * 1e6))
+print("step %.1f us" % ((time.perf_counter() - t0) / 52 * 1e6))
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
-    for s in range(10):
+    for s in range(12):
         m.train_async(dbs[s % 4], 1.0, next_batch=dbs[(s + 1) % 4])
     torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=25, max_name_column_width=60))

@@ -57,6 +57,20 @@ seg("P5: positions 2..8 (7 positions)", 17, 18, full)
 seg("P5: position 9 + last dW", 18, 19, full)
 seg("P5: dsp reductions + Gu stores", 19, 20)
 seg("P5: stage accumulators (to stamp 10)", 20, 10)
+# the workgroup's critical path: a barrier releases when its slowest wavefront arrives
+arr = [1, 3, 6, 8, 10]   # stamps taken on arrival at the five barriers
+rel0 = s[:, :, 0].min(1)
+prev = rel0
+names_cp = ["P1 (to barrier 1)", "P2 bridge (to barrier 2)", "P3 (to barrier 3)", "P4 dlong (to barrier 4)", "P5 (to barrier 5)"]
+tot_cp = 0
+for nm, k in zip(names_cp, arr):
+    rel = s[:, :, k].max(1)
+    print("critical path  %-26s mean %8.0f  p50 %8.0f  max %8.0f" % (nm, (rel - prev).mean(), np.median(rel - prev), (rel - prev).max()))
+    tot_cp += (rel - prev).mean()
+    prev = rel
+endw = s[:, :, 11].max(1)
+print("critical path  %-26s mean %8.0f" % ("final reduce", (endw - prev).mean()))
+print("critical path  total per workgroup: mean %.0f  max %.0f ticks" % ((endw - rel0).mean(), (endw - rel0).max()))
 span = s[:, :, 11].max() - s[:, :, 0].min()
 print("kernel span (first start -> last end): %.0f ticks" % span)
 p1 = d[:, :, 0]

@@ -87,6 +87,11 @@ struct Ws {  // carve-up of the caller's scratch buffer
 };
 
 static int ru4(int x) { return (x + 3) / 4 * 4; }
+// the dK product rides in k_fwd_bwd for D <= 128 (Geo::FUSE_DK); its launch then has at most this many workgroups
+// (each loops over its passes), so that the per-workgroup partials stay a few tens of MB at any batch size
+static bool fused_dk(int D) { return TLSAN_EXP_FUSE_DK != 0 && D <= 128; }
+#define FWD_TRAIN_GRID_MAX 1024
+static int fwd_train_grid(int ngroups) { return ngroups < FWD_TRAIN_GRID_MAX ? ngroups : FWD_TRAIN_GRID_MAX; }
 
 static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base, Ws* w) {
   size_t o = 0;
@@ -96,7 +101,9 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
   tlsan_dense_layout_of(d, &L);
   w->WU = ru4(d->d_item + d->Ls);
   w->ngroups = (B + 15) / 16;  // partial records: one per workgroup pass (16 samples with k_fwd_bwd2, NSB otherwise)
-  w->nsplit = dk_nsplit(B);
+  // dK partials: one per batch split of k_dk_partial, or (fused into the forward/backward kernel, D <= 128) one per
+  // workgroup of that launch
+  w->nsplit = fused_dk(s.D) ? fwd_train_grid((B + s.NSB - 1) / s.NSB) : dk_nsplit(B);
   w->nbK = (s.D * s.D + 255) / 256;
   w->nbS = (L.n_dense - s.D * s.D + 15) / 16;
   w->nfin = w->nbK + w->nbS;
@@ -502,6 +509,7 @@ int tlsan_state_recategorize(const tlsan_dims* d, const tlsan_params* p, void* s
 
 static int launch_fwd(const Shape& s, bool train, const FwdArgs& a, hipStream_t hs) {
   int grid = a.ngroups < 4096 ? a.ngroups : 4096;
+  if (train && fused_dk(s.D)) grid = fwd_train_grid(a.ngroups);
   hipError_t e;
   const bool lstream = a.Ls > TLSAN_LS_MAX;  // long windows are streamed, short ones stay in registers
   if (s.D == 64) e = tlsan_launch_fwd_bwd_d64(train, lstream, a, grid, hs);
@@ -596,7 +604,7 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   a.Gi = w.Gi; a.Gb = w.Gb; a.Gu = w.Gu; a.Gc = w.Gc; a.WU = w.WU;
   a.cur_item = st.cur_item[k]; a.cur_user = st.cur_user[k]; a.cur_uc = st.cur_uc[k];
   a.uc_by_sample = uc_by_list(d, b) ? 1 : 0;
-  a.gLong = w.gLong; a.gDB = w.gDB; a.partials = w.partials;
+  a.gLong = w.gLong; a.gDB = w.gDB; a.partials = w.partials; a.Kp = w.Kp;
   if (hp->dropout != 0.0f) {
     if (!(hp->dropout > 0.0f && hp->dropout < 1.0f)) return fail(TLSAN_E_BADARG, "dropout must be in [0, 1)");
     if (a.p.table_dtype != TLSAN_TABLE_F32) return fail(TLSAN_E_UNSUPPORTED, "dropout > 0 is built for fp32 tables");
@@ -612,10 +620,10 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   prof_mark(1, hs);
   if ((rc = launch_fwd(s, true, a, hs))) return rc;
   prof_mark(2, hs);
-  // --- dense-parameter gradients
-  {
+  // --- dense-parameter gradients (D <= 128: the dK partials were left by k_fwd_bwd, one per workgroup)
+  if (!fused_dk(s.D)) {
     const int spw = dk_spw(b->B), nq = (s.D / 64) * (s.D / 64);
-    const dim3 grid(nq * w.nsplit), blk(512);
+    const dim3 grid(nq * w.nsplit), blk(DK_WAVES * 64);
 #define DK_LAUNCH(DD)                                                                                           \
   do {                                                                                                          \
     (void)hipFuncSetAttribute((const void*)k_dk_partial<DD>, hipFuncAttributeMaxDynamicSharedMemorySize, DK_SMEM_BYTES); \

@@ -2,14 +2,17 @@
 // so the big kernels compile in parallel).
 #pragma once
 #include "tlsan_attn.h"
+#ifndef TLSAN_STAMPS
+#define TLSAN_STAMPS 0
+#endif
 
 template <int D, int DH>
 static size_t fwd_smem_bytes(bool train, bool lstream) {
   using G = Geo<D, DH>;
   const int lsc = lstream ? TLSAN_LS_CAP : TLSAN_LS_MAX;
-  return sizeof(float) * ((train ? G::NSB * (lsc + TLSAN_SN_CAP + 4) : 0) + 2 * G::NSB * G::LSTR + G::NW * 4 + G::NSB * 2 * lsc + (G::USE_SW ? 2 * (2 * DH * DH + 2 * DH) : 0) + G::NW * G::WSCR +
+  return sizeof(float) * ((train ? G::NSB * (lsc + TLSAN_SN_CAP + 4) : 0) + 2 * G::NSB * G::LSTR + ((train && G::FUSE_DK) ? G::NSB * G::LSTR : 0) + G::NW * 4 + G::NSB * 2 * lsc + (G::USE_SW ? 2 * (2 * DH * DH + 2 * DH) : 0) + G::NW * G::WSCR +
                           ((G::KEEP_A && train && !lstream) ? G::NW * TLSAN_LS_MAX * G::NB * 256 : 0) +
-                          G::NW * 32 * 2 /* diagnostic stamps */);
+                          (TLSAN_STAMPS ? G::NW * 32 * 2 : 0) /* diagnostic stamps */);
 }
 
 template <int D, int DH, bool TRAIN, bool LSTREAM, int DT, bool DROP = false, int MM = TLSAN_MATRIX_F32>

@@ -134,6 +134,18 @@ struct Geo {
   static constexpr int NT = D / 16;             // 16-col tiles of the bridge GEMM
   static constexpr int TPW = RT * NT / NW;      // bridge tiles per wavefront
   static constexpr int LSTR = D + 4;            // LDS row stride of [sample][channel] buffers
+  // dK = long^T . dbridge (gradient of the bridge's kernel, model.py:347): for D <= 128 every workgroup forms the
+  // product over its own 16 samples right after the dlong GEMM, while both operands sit in the LDS, and leaves one
+  // D x D partial per workgroup for k_dense_finalize -- no k_dk_partial launch, no [B, D] round trip through HBM.
+  // (D = 256: the partials would be 256 KB per workgroup; the separate kernel stays.)
+  // MEASURED AND LEFT OFF (round 2, gpurun_out/r02_ab8.txt): the k_dk_partial launch (8.3 us) goes away, but k_fwd_bwd
+  // grows by 2.4 us (six spilled registers at D = 128), k_dense_finalize reads 256 partials instead of 64 (+2.5 us on the
+  // launch it shares with the row sums), and the step does not get shorter (72.1-73.6 vs 71.0-71.8 us): the tail of
+  // the step overlaps the next batch's index build on the second stream either way.
+#ifndef TLSAN_EXP_FUSE_DK
+#define TLSAN_EXP_FUSE_DK 0
+#endif
+  static constexpr bool FUSE_DK = TLSAN_EXP_FUSE_DK != 0 && D_ <= 128;
 #ifndef TLSAN_EXP_TSTR
 #define TLSAN_EXP_TSTR 20
 #endif
@@ -399,8 +411,9 @@ struct FwdArgs {
   int32_t* cur_item; int32_t* cur_user; int32_t* cur_uc;
   int32_t uc_by_sample;   // != 0: Gc rows are written in SAMPLE order (row b = sample b) and the index holds the
                           // samples of every category (uc_list, k_uc_fill): no cursor is drawn for the u_cate use
-  float* gLong;     // [B, D]   long-term summaries (A operand of dK)
+  float* gLong;     // [B, D]   long-term summaries (A operand of dK)   -- written only when the dK product is NOT fused
   float* gDB;       // [B, D]   d loss / d bridge     (B operand of dK)
+  float* Kp;        // fused dK (Geo::FUSE_DK): [gridDim.x][D*D] partial products long^T . dbridge, one per workgroup
   float* partials;  // [ngroups, NPB]
   unsigned long long* stamps;  // diagnostic only (NULL in production): [gridDim.x*8 waves][16]
   // dropout on the inputs of the attention maps (model.py:428-431), training with config['dropout'] > 0

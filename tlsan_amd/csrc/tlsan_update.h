@@ -246,20 +246,25 @@ __global__ __launch_bounds__(1024) void k_index_scan(ScanArgs a) {
 // i.e. tile ta x tb covers rows 4m+ta, columns 4n+tb -- 16 independent accumulators per k-step
 // and the float4 write-out is contiguous again.  The 8 wavefronts are summed through LDS in a
 // fixed order, so a launch leaves nsplit (<= DK_SPLITS_MAX) partial matrices for k_dense_finalize.
-#define DK_SPLITS_MAX 32
-static inline int dk_nsplit(int B) { const int n = (B + 127) / 128; return n < DK_SPLITS_MAX ? n : DK_SPLITS_MAX; }
-static inline int dk_spw(int B) { const int per = (B + dk_nsplit(B) * 8 - 1) / (dk_nsplit(B) * 8); return (per + 3) / 4 * 4; }
-#define DK_SMEM_BYTES (8 * 64 * 64 * 4)
+#ifndef TLSAN_EXP_DKW
+#define TLSAN_EXP_DKW 4
+#endif
+#define DK_WAVES TLSAN_EXP_DKW   // wavefronts per workgroup: 4 -> 64 splits x (D/64)^2 quadrants = 256 workgroups at B = 4096, one
+                                 // wavefront per SIMD on every CU (8 left half the chip idle with two wavefronts per SIMD)
+#define DK_SPLITS_MAX (256 / DK_WAVES)
+static inline int dk_nsplit(int B) { const int n = (B + DK_WAVES * 16 - 1) / (DK_WAVES * 16); return n < DK_SPLITS_MAX ? n : DK_SPLITS_MAX; }
+static inline int dk_spw(int B) { const int per = (B + dk_nsplit(B) * DK_WAVES - 1) / (dk_nsplit(B) * DK_WAVES); return (per + 3) / 4 * 4; }
+#define DK_SMEM_BYTES (DK_WAVES * 64 * 64 * 4)
 template <int D>
-__global__ __launch_bounds__(512) void k_dk_partial(const float* __restrict__ gLong,
-                                                    const float* __restrict__ gDB, int B, int spw,
-                                                    float* __restrict__ Kp) {
+__global__ __launch_bounds__(DK_WAVES * 64) void k_dk_partial(const float* __restrict__ gLong,
+                                                              const float* __restrict__ gDB, int B, int spw,
+                                                              float* __restrict__ Kp) {
   constexpr int NQ = D / 64;
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // [8 wavefronts][64][64]
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [DK_WAVES wavefronts][64][64]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, r = lane & 15;
   const int quad = blockIdx.x % (NQ * NQ), split = blockIdx.x / (NQ * NQ);
   const int M0 = (quad / NQ) * 64, N0 = (quad % NQ) * 64;
-  const int s_begin = (split * 8 + wave) * spw, s_end = min(s_begin + spw, B);
+  const int s_begin = (split * DK_WAVES + wave) * spw, s_end = min(s_begin + spw, B);
   f32x4 acc[4][4];
 #pragma unroll
   for (int ta = 0; ta < 4; ++ta)
@@ -296,11 +301,11 @@ __global__ __launch_bounds__(512) void k_dk_partial(const float* __restrict__ gL
   __syncthreads();
   float* out = Kp + (size_t)split * D * D;
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int f = tid + 512 * k;  // float4 index inside the 64x64 quadrant
+  for (int k = 0; k < 1024 / (DK_WAVES * 64); ++k) {
+    const int f = tid + DK_WAVES * 64 * k;  // float4 index inside the 64x64 quadrant
     f32x4 v = *(const f32x4*)(smem + 4 * f);
 #pragma unroll
-    for (int w_ = 1; w_ < 8; ++w_) v += *(const f32x4*)(smem + w_ * 4096 + 4 * f);
+    for (int w_ = 1; w_ < DK_WAVES; ++w_) v += *(const f32x4*)(smem + w_ * 4096 + 4 * f);
     *(f32x4*)(out + (size_t)(M0 + f / 16) * D + N0 + 4 * (f % 16)) = v;
   }
 }
@@ -426,18 +431,20 @@ __device__ __forceinline__ void dense_finalize_block(const FinArgs& a, int nbK, 
   } else if (blk < nbK) {
     const int idx = blk * 256 + tid;
     if (idx < D * D) {
-      // all split partials in flight at once (clamped addresses, masked sum), fixed order
-      float v[DK_SPLITS_MAX];
-#pragma unroll
-      for (int sidx = 0; sidx < DK_SPLITS_MAX; ++sidx)
-        v[sidx] = a.Kp[(size_t)min(sidx, a.nsplit - 1) * D * D + idx];
+      // the partials in chunks of 32, all loads of a chunk in flight at once (clamped addresses, masked sum), fixed order
       float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f;
+      for (int s0 = 0; s0 < a.nsplit; s0 += 32) {
+        float v[32];
 #pragma unroll
-      for (int sidx = 0; sidx < DK_SPLITS_MAX; sidx += 4) {
-        g0 += sidx + 0 < a.nsplit ? v[sidx + 0] : 0.0f;
-        g1 += sidx + 1 < a.nsplit ? v[sidx + 1] : 0.0f;
-        g2 += sidx + 2 < a.nsplit ? v[sidx + 2] : 0.0f;
-        g3 += sidx + 3 < a.nsplit ? v[sidx + 3] : 0.0f;
+        for (int u = 0; u < 32; ++u)
+          v[u] = a.Kp[(size_t)min(s0 + u, a.nsplit - 1) * D * D + idx];
+#pragma unroll
+        for (int u = 0; u < 32; u += 4) {
+          g0 += s0 + u + 0 < a.nsplit ? v[u + 0] : 0.0f;
+          g1 += s0 + u + 1 < a.nsplit ? v[u + 1] : 0.0f;
+          g2 += s0 + u + 2 < a.nsplit ? v[u + 2] : 0.0f;
+          g3 += s0 + u + 3 < a.nsplit ? v[u + 3] : 0.0f;
+        }
       }
       g = (g0 + g1) + (g2 + g3);
       a.gd[L.K + idx] = g;

@@ -482,8 +482,12 @@ class Model(object):
             raise RuntimeError("train_async: the batch announced as next_batch must be the next one trained "
                                "(its destination index is already counted into the state)")
         pre = self._idx_ready[k] is db
+        dev_wait = os.environ.get("TLSAN_DEVICE_WAIT", "0") == "1"
         if pre:
-            self._idx_event[k].synchronize()       # the side stream finished this batch's index
+            if dev_wait:
+                torch.cuda.current_stream(self.device).wait_event(self._idx_event[k])
+            else:
+                self._idx_event[k].synchronize()       # the side stream finished this batch's index
         self._idx_ready[k] = None
         main = torch.cuda.current_stream(self.device)
         ndb = None
@@ -496,8 +500,14 @@ class Model(object):
         self._train_call(db, hp, out, ws)
         if ndb is not None:
             if self._side is None:
-                self._side = torch.cuda.Stream(self.device)
-            self._pre_event.synchronize()
+                # (high priority: the index kernels are short and the NEXT step cannot start without them; left at
+                #  the default they trail behind the 2400 workgroups of the row-sum / update launches they share
+                #  the chip with -- k_fwd_bwd itself leaves them no registers to run beside it)
+                self._side = torch.cuda.Stream(self.device, priority=int(os.environ.get("TLSAN_SIDE_PRIORITY", "-1")))
+            if dev_wait:
+                self._side.wait_event(self._pre_event)
+            else:
+                self._pre_event.synchronize()
             L.check(self.lib.tlsan_batch_index(C.byref(self.dims), C.byref(ndb.c), self.state.data_ptr(), 1 - k,
                                                C.c_void_p(self._side.cuda_stream)), "tlsan_batch_index")
             self._idx_event[1 - k].record(self._side)
