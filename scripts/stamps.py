@@ -13,7 +13,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 cfg = synth.make_config("electronics")
 m = Model(cfg, synth.item_cate_list(cfg), l2_mode="lazy", matrix_dtype=os.environ.get("MM", "f32"), table_dtype=os.environ.get("TD", "f32"))
 lib = L.load()
-db = m.device_batch(synth.make_batches(cfg, 1, B, seed=7)[0])
+db_host = synth.make_batches(cfg, 1, B, seed=7)[0]
+db = m.device_batch(db_host)
 for _ in range(5):
     m.train_async(db, 1.0)
 nblk = (B + 15) // 16
@@ -71,8 +72,29 @@ for nm, k in zip(names_cp, arr):
 endw = s[:, :, 11].max(1)
 print("critical path  %-26s mean %8.0f" % ("final reduce", (endw - prev).mean()))
 print("critical path  total per workgroup: mean %.0f  max %.0f ticks" % ((endw - rel0).mean(), (endw - rel0).max()))
-span = s[:, :, 11].max() - s[:, :, 0].min()
-print("kernel span (first start -> last end): %.0f ticks" % span)
+# s_memtime counters differ between CUs; stamps 28 / 29 are s_memrealtime (100 MHz, device-wide) at the start / end
+rt0 = raw[:, :, 28].min(1)
+rt1 = raw[:, :, 29].max(1)
+t00 = rt0.min()
+print("device clock: workgroup starts after the first (us): p50 %.2f p90 %.2f max %.2f;  ends: p10 %.2f p50 %.2f p90 %.2f max %.2f"
+      % (tuple(np.percentile(rt0 - t00, [50, 90, 100]) / 100) + tuple(np.percentile(rt1 - t00, [10, 50, 90, 100]) / 100)))
+dur = (rt1 - rt0) / 100
+print("workgroup durations (us): p10 %.2f p50 %.2f p90 %.2f max %.2f;  cycles per 10 ns tick: %.1f" % (tuple(np.percentile(dur, [10, 50, 90, 100])) + (np.median((s[:, :, 11].max(1) - s[:, :, 0].min(1)) / (rt1 - rt0)),)))
+order = np.argsort(rt1)[::-1][:8]
+print("last workgroups to end: " + ", ".join("#%d start %.2f dur %.2f" % (b, (rt0[b] - t00) / 100, dur[b]) for b in order))
+cp = []
+prev = s[:, :, 0].min(1)
+for k in arr + [11]:
+    rel = s[:, :, k].max(1)
+    cp.append(rel - prev)
+    prev = rel
+cp = np.stack(cp, 1)
+print("critical path of the median workgroup (P1 P2 P3 P4 P5 end):", np.median(cp, 0).astype(int))
+sl_new = np.asarray(db_host[7])
+for b in order[:6]:
+    extra = ""
+    extra = "  sessions " + str(sorted(sl_new[16 * b:16 * b + 16].tolist(), reverse=True)[:6])
+    print("  workgroup #%d:" % b, cp[b].astype(int), extra)
 p1 = d[:, :, 0]
 print("P1 percentiles:", np.percentile(p1, [1, 10, 25, 50, 75, 90, 99, 100]).astype(int))
 print("P1 mean by XCD (block%8):", [int(p1[x::8].mean()) for x in range(8)])

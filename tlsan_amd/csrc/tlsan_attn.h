@@ -449,6 +449,12 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #ifndef TLSAN_EXP_SESS_EARLY
 #define TLSAN_EXP_SESS_EARLY 0
 #endif
+#ifndef TLSAN_EXP_FOLD
+#define TLSAN_EXP_FOLD 1
+#endif
+#ifndef TLSAN_EXP_HELP
+#define TLSAN_EXP_HELP 1
+#endif
 #ifndef TLSAN_EXP_BALANCE
 #define TLSAN_EXP_BALANCE 1
 #endif
@@ -481,6 +487,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 
   for (int g = blockIdx.x; g < a.ngroups; g += gridDim.x) {
     TLSAN_STAMP(0);
+#if TLSAN_STAMPS
+    if (a.stamps != nullptr && lane == 0) sStamp[28] = __builtin_amdgcn_s_memrealtime();   // (100 MHz, one clock for the whole device)
+#endif
 #if TLSAN_EXP_BALANCE
     // Which sample a slot of the pass takes.  The 16 samples are ranked by cost (session length first, then window
     // length) and dealt out in that order: the two waves of a SIMD do not run alike -- the first-dispatched half of
@@ -499,7 +508,10 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) rank += (__builtin_amdgcn_readlane(key, j) > key) ? 1 : 0;
       int* sPerm = (int*)T;                       // (the wave's own scratch: free until P3)
-      if (q == 0) sPerm[rank] = r;
+      // (windows held in registers, two samples per wavefront: the wavefront with the k-th longest session also takes
+      // the k-th shortest -- its lanes then share the long one, see HELP in P3)
+      const int slot = (TLSAN_EXP_FOLD != 0 && SPW == 2 && !LSTREAM && !DROP) ? (rank < 8 ? 2 * rank : 2 * (15 - rank) + 1) : rank;
+      if (q == 0) sPerm[slot] = r;
       wave_lds_fence();
       bidx = g * NSB + sPerm[srow];
       wave_lds_fence();
@@ -560,16 +572,26 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       sid = (Sn > 0) ? a.b.hist_i_new[(size_t)bb * Sn + t] : 0;
       scat = a.p.item_cate[sid];
     };
-    auto fetch_row = [&](int t, f32x4 (&xr)[NB]) {  // row of session entry t (chunk must be loaded)
-      const int k = t % NL;
-      const int it = sample_pick<CPS>(sid, k / CPS, k % CPS, s_loc), ct = sample_pick<CPS>(scat, k / CPS, k % CPS, s_loc);
-      const bool vt = t < n_s;
+    // row of session entry t0 + dt of the wavefront's sample s_sel (n_sel entries; its chunk must be loaded): normally
+    // the lane's own sample and dt = 0; while one half of the lanes helps with a long session (HELP, see P3) both halves
+    // fetch for that sample, the helping half the odd entry (t0, s_sel, n_sel and `two` are wave-uniform, dt per lane)
+    auto fetch_row_of = [&](int t0, int dt, bool two, f32x4 (&xr)[NB], int s_sel, int n_sel) {
+      const int k = t0 % NL;
+      int it = sample_pick<CPS>(sid, k / CPS, k % CPS, s_sel), ct = sample_pick<CPS>(scat, k / CPS, k % CPS, s_sel);
+      if (two) {
+        const int k1 = min(k + 1, NL - 1);
+        const int it1 = sample_pick<CPS>(sid, k1 / CPS, k1 % CPS, s_sel), ct1 = sample_pick<CPS>(scat, k1 / CPS, k1 % CPS, s_sel);
+        it = dt ? it1 : it;
+        ct = dt ? ct1 : ct;
+      }
+      const bool vt = t0 + dt < n_sel;
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb) {
         const f32x4 v = gather_item4c<DT>(a, it, ct, chb[kb]) * P;
         xr[kb] = vt ? v : (f32x4)(0.0f);
       }
     };
+    auto fetch_row = [&](int t, f32x4 (&xr)[NB]) { fetch_row_of(t, 0, false, xr, s_loc, n_s); };
     int spos0 = 0;  // position of session use kk (first chunk): one returning atomic per use
     f32x4 xnext[NB];
     const int pmax2e = wave_max_samples<CPS>(n_s + 1);
@@ -840,8 +862,54 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         short4[kb] = xv[kb];
       }
     }
-    for (int p = 1; p < pmax2; ++p) {  // wave-uniform trip count
-      const bool vt = (p - 1) < n_s;
+    // ---- HELP: a long session is shared by the wavefront's two halves.  The kernel ends with its slowest workgroup,
+    // and that is the one holding the batch's longest session (P3 costs ~3.8 k cycles per session position; one
+    // sample in a few thousand has six or more).  Once the shorter of the wavefront's two sessions is exhausted, its
+    // half of the lanes takes every second remaining entry of the longer one: the MFMA columns are then (entry 2j,
+    // 8 heads | entry 2j+1, 8 heads) of ONE sample, the helping half keeps a partial online-softmax state of its own,
+    // and the two are merged with one cross-lane step (lane r <-> r ^ 8: row_ror:8) -- forward here, and in the
+    // backward the helper reads the sample's statistics / output gradient the same way.  Session steps of the
+    // wavefront: lo + ceil((hi - lo) / 2) instead of hi.
+    constexpr bool HELP = TLSAN_EXP_HELP != 0 && SPW == 2 && !DROP;
+    int h_lo = 0, h_hi = 0, h_L = 0;
+    bool h_on = false;
+    if constexpr (HELP) {
+      const int ns0 = __builtin_amdgcn_readlane(n_s, 0), ns1 = __builtin_amdgcn_readlane(n_s, CPS);
+      h_lo = min(ns0, ns1);
+      h_hi = max(ns0, ns1);
+      h_L = ns0 >= ns1 ? 0 : 1;
+      h_on = (h_hi - h_lo >= 2) && h_hi <= NL;   // (sessions beyond one chunk of ids: rare, left to the plain loop)
+    }
+    const int nsess = h_on ? h_lo + (h_hi - h_lo + 1) / 2 : pmax2 - 1;   // session steps of this wavefront
+    const bool helper = HELP && h_on && s_loc != h_L;
+    struct Sel { int s, t0, dt, n; bool two; };   // (sample, even entry, +1 for the helping half, its length, shared step)
+    auto sel_of = [&](int u) -> Sel {             // session step u of this wavefront -> what this lane works on
+      if (HELP && h_on && u >= h_lo) return Sel{h_L, h_lo + 2 * (u - h_lo), helper ? 1 : 0, h_hi, true};
+      return Sel{s_loc, u, 0, n_s, false};
+    };
+    if constexpr (HELP) {
+      if (h_on && pmax2 > 1 && h_lo == 0) {   // (the row prefetched above was the lane's own entry 0: the helper needs entry 1)
+        const Sel e = sel_of(0);
+        fetch_row_of(e.t0, e.dt, e.two, xnext, e.s, e.n);
+      }
+    }
+    for (int u = 0; u < nsess; ++u) {  // wave-uniform trip count
+      const int p = u + 1;             // (position of the step in the block: 0 is the bridge)
+      const Sel e = sel_of(u);
+      const bool vt = e.t0 + e.dt < e.n;
+      if constexpr (HELP) {
+        if (h_on && u == h_lo && helper) {   // the helping half parks its own (finished) state and starts a partial one
+#pragma unroll
+          for (int kb = 0; kb < NB; ++kb) {
+            *(f32x4*)(T + ((0 * NB + kb) * 64 + lane) * 4) = mx[kb];
+            *(f32x4*)(T + ((1 * NB + kb) * 64 + lane) * 4) = Zs[kb];
+            *(f32x4*)(T + ((2 * NB + kb) * 64 + lane) * 4) = short4[kb];
+            mx[kb] = (f32x4)(TLSAN_NEG);
+            Zs[kb] = (f32x4)(0.0f);
+            short4[kb] = (f32x4)(0.0f);
+          }
+        }
+      }
       f32x4 xv[NB], z[NB], m2[NB];
       if constexpr (G::AT_USE && !LSTREAM && G::AT_USE_T) {  // weight fragments from LDS at the use
         const int zz = opaque_zero(p);
@@ -853,9 +921,10 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb) xv[kb] = xnext[kb];
-      if (p + 1 < pmax2) {  // prefetch the next row while this one is processed
-        if ((p % NL) == 0) load_chunk(p);
-        fetch_row(p, xnext);
+      if (u + 1 < nsess) {  // prefetch the next row while this one is processed
+        if (!h_on && (p % NL) == 0) load_chunk(p);
+        const Sel e2 = sel_of(u + 1);
+        fetch_row_of(e2.t0, e2.dt, e2.two, xnext, e2.s, e2.n);
       }
       if constexpr (DROP) {
         f32x4 xd[NB];
@@ -885,6 +954,28 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             short4[kb][i] = short4[kb][i] * so + ev * xv[kb][i];
             mx[kb][i] = mn;
           }
+      }
+    }
+    if constexpr (HELP) {
+      if (h_on) {   // merge the helper's partial state into the sample's, give the helper its own state back
+        wave_lds_fence();
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+          const f32x4 own_mx = *(const f32x4*)(T + ((0 * NB + kb) * 64 + lane) * 4);
+          const f32x4 own_Z = *(const f32x4*)(T + ((1 * NB + kb) * 64 + lane) * 4);
+          const f32x4 own_N = *(const f32x4*)(T + ((2 * NB + kb) * 64 + lane) * 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float o_mx = dpp_f32<TLSAN_DPP_ROR(8)>(mx[kb][i]), o_Z = dpp_f32<TLSAN_DPP_ROR(8)>(Zs[kb][i]);
+            const float o_N = dpp_f32<TLSAN_DPP_ROR(8)>(short4[kb][i]);
+            const float mn = fmaxf(mx[kb][i], o_mx);
+            const float sa = __expf(mx[kb][i] - mn), sb = __expf(o_mx - mn);
+            mx[kb][i] = helper ? own_mx[i] : mn;
+            Zs[kb][i] = helper ? own_Z[i] : Zs[kb][i] * sa + o_Z * sb;
+            short4[kb][i] = helper ? own_N[i] : short4[kb][i] * sa + o_N * sb;
+          }
+        }
+        wave_lds_fence();
       }
     }
 #pragma unroll
@@ -963,8 +1054,12 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         f32x4 xn2[NB];
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) xn2[kb] = *(const f32x4*)(sB + srow * LSTR + chb[kb]);
-        for (int p = 0; p < pmax2; ++p) {  // wave-uniform trip count
-          const bool vt = p < n_pos;
+        for (int p = 0; p <= nsess; ++p) {  // wave-uniform trip count: the bridge, then the session steps
+          const Sel e = sel_of(p > 0 ? p - 1 : 0);
+          const int s_sel = e.s, t = e.t0 + e.dt;
+          const bool vt = p == 0 || t < e.n;
+          const bool shared = p > 0 && e.two;                          // (wave-uniform) both halves work on one sample
+          const bool oth = shared && helper;                           // this lane works for the other half's sample
           f32x4 xv[NB], z1[NB], zr[NB], m2[NB], av[NB], dx[NB];
           if constexpr (G::AT_USE && !LSTREAM) {  // weight fragments from LDS at the use
             const int zz = opaque_zero(p);
@@ -980,9 +1075,10 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 
 #pragma unroll
           for (int kb = 0; kb < NB; ++kb) xv[kb] = xn2[kb];
-          if (p + 1 < pmax2) {  // session entry t = p for the next position
-            if (p > 0 && (p % NL) == 0) load_chunk(p);
-            fetch_row(p, xn2);
+          if (p < nsess) {  // the row of the next session step
+            if (!h_on && p > 0 && (p % NL) == 0) load_chunk(p);
+            const Sel e2 = sel_of(p);
+            fetch_row_of(e2.t0, e2.dt, e2.two, xn2, e2.s, e2.n);
           }
           f32x4 k1[NB], k2[NB];
           if constexpr (DROP) {
@@ -1006,13 +1102,32 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             for (int kb = 0; kb < NB; ++kb) zr[kb] *= k2[kb];
           }
           map_apply<NB, MM>(FT2, b2, zr, m2);
+          // statistics, output and output gradient of the sample this lane works for (the other half's, read
+          // across the row, while helping)
+          f32x4 outs[NB], douts[NB];
+          if (shared) {
 #pragma unroll
-          for (int kb = 0; kb < NB; ++kb)
+            for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-              av[kb][i] = vt ? __expf(m2[kb][i] - mx[kb][i]) * Zs[kb][i] : 0.0f;
+              for (int i = 0; i < 4; ++i) {
+                const float o_mx = dpp_f32<TLSAN_DPP_ROR(8)>(mx[kb][i]), o_Z = dpp_f32<TLSAN_DPP_ROR(8)>(Zs[kb][i]);
+                const float o_out = dpp_f32<TLSAN_DPP_ROR(8)>(short4[kb][i]), o_do = dpp_f32<TLSAN_DPP_ROR(8)>(dout[kb][i]);
+                const float mxs = oth ? o_mx : mx[kb][i], zss = oth ? o_Z : Zs[kb][i];
+                outs[kb][i] = oth ? o_out : short4[kb][i];
+                douts[kb][i] = oth ? o_do : dout[kb][i];
+                av[kb][i] = vt ? __expf(m2[kb][i] - mxs) * zss : 0.0f;
+              }
+          } else {
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+              outs[kb] = short4[kb];
+              douts[kb] = dout[kb];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) av[kb][i] = vt ? __expf(m2[kb][i] - mx[kb][i]) * Zs[kb][i] : 0.0f;
+            }
+          }
           float* Tp = T + (NBUF > 1 ? (p & 1) * TB : 0);
-          bwd_compute<NB, TSTR, DROP, MM>(FN2, FN1, xv, z1, av, short4, dout, Tp, q, r, acc.db1, acc.db2, dx, k1, k2);
+          bwd_compute<NB, TSTR, DROP, MM>(FN2, FN1, xv, z1, av, outs, douts, Tp, q, r, acc.db1, acc.db2, dx, k1, k2);
           if (NBUF == 1) bwd_dw<NB, TSTR, MM>(Tp, q, r, acc.dW1, acc.dW2);
           else if (p > 0) bwd_dw<NB, TSTR, MM>(T + ((p - 1) & 1) * TB, q, r, acc.dW1, acc.dW2);
           if (p == 0) {
@@ -1024,8 +1139,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
                 dk0[kb] += dx[kb];
               }
             }
-          } else if (vs && vt) {
-            const int pos = sP[srow * PSTR + LSC + (p - 1)];
+          } else if ((vs || oth) && vt) {
+            const int pos = sP[(wave * SPW + s_sel) * PSTR + LSC + t];
             if (lead) a.Gb[pos] = 0.0f;
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) {
@@ -1034,7 +1149,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             }
           }
         }
-        if (NBUF > 1) bwd_dw<NB, TSTR, MM>(T + ((pmax2 - 1) & 1) * TB, q, r, acc.dW1, acc.dW2);
+        if (NBUF > 1) bwd_dw<NB, TSTR, MM>(T + (nsess & 1) * TB, q, r, acc.dW1, acc.dW2);
         TLSAN_STAMP(27);
         if constexpr (G::SPLIT) {  // two halves through the (smaller) staging area
           stage_part<NB, CPS, true, 0>(acc, dk0, T, lane);
@@ -1406,6 +1521,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         prec[G::P_GAMMA + tid] = s;
       }
       TLSAN_STAMP(11);
+#if TLSAN_STAMPS
+      if (a.stamps != nullptr && lane == 0) sStamp[29] = __builtin_amdgcn_s_memrealtime();
+#endif
 #if TLSAN_STAMPS
       if (a.stamps != nullptr && lane < 32) a.stamps[((size_t)blockIdx.x * NW + wave) * 32 + lane] = sStamp[lane];
 #endif

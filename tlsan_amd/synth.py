@@ -48,8 +48,14 @@ def item_cate_list(cfg, seed=1234):
     return rng.integers(0, cfg["cate_count"], cfg["item_count"]).astype(np.int32)
 
 
-def make_batches(cfg, n_batches, batch_size=None, seed=1234, test=False):
-    """List of 9-tuples in the layout of TLSAN/input.py:54 (train) / :107 (test)."""
+# session lengths of the Digital-Music training set (tests/golden/packed_digital_music.npz, 37 970 samples):
+# counts of lengths 1 .. 12 (12 = "12 or more")
+_AMAZON_SESSION_HIST = np.array([33124, 3366, 848, 324, 150, 50, 44, 26, 16, 8, 0, 14], np.float64)
+
+
+def make_batches(cfg, n_batches, batch_size=None, seed=1234, test=False, sessions="geometric"):
+    """List of 9-tuples in the layout of TLSAN/input.py:54 (train) / :107 (test).
+    sessions: "geometric" (the bench's distribution since round 1) or "amazon" (the empirical, longer-tailed one)."""
     rng = np.random.default_rng(seed + (1 if test else 0))
     U, I, C, Ls = cfg["user_count"], cfg["item_count"], cfg["cate_count"], cfg["Ls"]
     B = batch_size or cfg["train_batch_size"]
@@ -59,7 +65,10 @@ def make_batches(cfg, n_batches, batch_size=None, seed=1234, test=False):
         u = rng.integers(0, U, B)
         n_pre = np.minimum(90, np.ceil(rng.lognormal(2.2, 1.0, B))).astype(np.int64)
         sl = np.minimum(n_pre, Ls)
-        sl_new = np.minimum(18, rng.geometric(0.82, B))
+        if sessions == "amazon":
+            sl_new = 1 + rng.choice(12, B, p=_AMAZON_SESSION_HIST / _AMAZON_SESSION_HIST.sum())
+        else:
+            sl_new = np.minimum(18, rng.geometric(0.82, B))
         ar = np.arange(Ls)[None, :]
         valid = ar < sl[:, None]
         hist_i = np.where(valid, sampler.draw(rng, (B, Ls)), 0).astype(np.int64)
