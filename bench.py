@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--event-every", type=int, default=8,
                     help="every Nth timed step carries the HIP events that bracket k_fwd_bwd (graph mode: runs eagerly)")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded (multi-GPU) code path even at N=1")
+    ap.add_argument("--static-rows", type=int, default=1,
+                    help="sharded path, lazy L2: fixed-size row exchanges (no exchange size passes through the host)")
     ap.add_argument("--accuracy-steps", type=int, default=2000,
                     help="accuracy leg (rank 0, N=1): train steps of the reference protocol on the real Digital-Music samples, "
                          "HIP path and fp64 oracle side by side, then AUC / P@20 / R@20 of both (0: skip)")
@@ -231,7 +233,8 @@ def main():
         stepper = model
     else:
         from tlsan_amd.dist import ShardedModel
-        model = ShardedModel(cfg, icl, device=dev, l2_mode=args.l2_mode)
+        # lazy L2: the static-shape step (fixed-size exchanges, nothing passes through the host)
+        model = ShardedModel(cfg, icl, device=dev, l2_mode=args.l2_mode, static_rows=bool(args.static_rows) and args.l2_mode == "lazy")
         stepper = model
     dbs = [stepper.device_batch(b) for b in host_batches]
     lr = 1.0
@@ -248,9 +251,12 @@ def main():
                     stepper.train_async(dbs[k], lr)
                 else:
                     model.replay(graphs[k])
+            elif sharded and model.static_rows:
+                # the next two batches are known (as in any input pipeline): their routing plans are built beside this step
+                stepper.train_async(dbs[k], lr, next_batch=dbs[(k + 1) % len(dbs)], after_next=dbs[(k + 2) % len(dbs)])
             elif sharded or args.prefetch:
-                # the next batch is known (as in any input pipeline): its routing plan (sharded) /
-                # destination index (single GPU) is queued while this step computes
+                # the next batch is known: its routing plan (sharded) / destination index (single GPU) is queued
+                # while this step computes
                 stepper.train_async(dbs[k], lr, next_batch=dbs[(k + 1) % len(dbs)])
             else:
                 stepper.train_async(dbs[k], lr)
@@ -279,6 +285,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss = float(model.last_loss.item()) if sharded else float(model._out[0].item())
+    if sharded and model.static_rows:
+        model.check_static_overflow()     # a batch that did not fit the fixed exchange voids the run: raise, print nothing
     also = also_mm = None
     if args.also_bf16 and not sharded and args.table_dtype == "f32" and not use_graph:
         # same batches, same step count with (a) the tables stored as bf16 -- the storage BASELINE.json configs[2] names --
@@ -363,7 +371,8 @@ def main():
                                       "dense (every row decayed every step, as the reference)" if l2 == "dense" else
                                       "lazy (reference's dense-L2 update as W = P*W_stored; only used rows touched)"),
                        "global_batch": B * world, "parallelism": "1 process/GPU, tables %s"
-                       % ("on one GPU" if not sharded else "row-sharded (id %% N), RCCL all-to-all + one all-reduce")},
+                       % ("on one GPU" if not sharded else "row-sharded (id %% N), RCCL all-to-all + one all-reduce" +
+                          (", static-shape exchanges, plans two batches ahead" if model.static_rows else ""))},
             "roofline": {"bound": "hbm", "kernel": "k_fwd_bwd", "achieved": None if achieved is None else round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
@@ -381,6 +390,7 @@ def main():
             "launch": ("hipGraph replay (1 graph/step; every %dth step eager for the HIP-event kernel timing)" % args.event_every)
                       if use_graph else ("eager, 4 launches/step on the main stream + the next batch's index (2 launches) "
                                          "on a second stream" if (args.prefetch and not sharded) else "eager"),
+            "static_overflow_checked": True if (sharded and model.static_rows) else None,
             "final_loss": round(loss, 6),
         }
         if also is not None:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TLSAN_ABI_VERSION 10
+#define TLSAN_ABI_VERSION 11
 
 enum {
   TLSAN_OK = 0,
@@ -407,6 +407,35 @@ int tlsan_shard_apply_lazy(float* shard, int32_t ld, int32_t cI, int32_t R, int3
                            int32_t G, uint64_t* slots64, uint32_t stamp, float gscale, const float* step_dev,
                            float* cate_emb, int32_t C, int32_t dc, const float* g_cate,
                            double* sumsq_out, float* sumsq_f32, float* scale, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- static-shape forms of the sharded step (tlsan_amd/dist.py, ShardedModel(static_rows=True)).
+ * Every (source, owner) pair exchanges exactly `cap` row slots in both directions, so no size ever has to reach
+ * the host: the ids, the rows and the gradients travel in equal-split all-to-alls of fixed size, every kernel
+ * argument is a constant of the shape, and a step can be recorded in a HIP graph.  The step's compact table is
+ * numbered by slot: the j-th distinct row of owner g is compact row g * cap + j (at one rank: the plain compact
+ * numbering); unused slots are in no category and never referenced.
+ *
+ * tlsan_route_plan_static: as tlsan_route_plan with that numbering; cate_c has G * cap entries.
+ *   counts_out (optional [G]): the TRUE per-owner counts; the headers of sendbuf are clamped to cap.
+ *   status [1] (device int32, zero-initialised by the caller): atomicMax of every count that exceeded cap.  A
+ *   batch that needs more than cap rows of one owner is truncated -- that step is wrong; the host checks status
+ *   when it next synchronises and must report it (cap >= min(R, n_keys) can never overflow).
+ * tlsan_shard_gather_static: rows_out [G * cap, W], recv_rows [G * cap] (-1 = empty slot); when slots64 is
+ *   given, the lazy apply's slot marks are written here (saves a launch): stamp is a DEVICE uint32 (never 0).
+ * tlsan_shard_apply_lazy_static: tlsan_shard_apply_lazy over the G * cap slots (rows[e] < 0: skipped); the
+ *   device-side stamp is advanced for the next step.  marked != 0: the slot marks were written by the gather. */
+int tlsan_route_plan_static(const int32_t* keys, int32_t n_keys, int32_t R, int32_t G, const int32_t* cate_by_key,
+                            int32_t* flags, int32_t* rank, int32_t* uniq, int32_t* n_uniq, int32_t* sendbuf, int32_t cap,
+                            int32_t* cate_c, int32_t* comp, int32_t* counts_out, int32_t* status, void* stream);
+int tlsan_shard_gather_static(const float* shard, int32_t ld, int32_t R, int32_t W, const int32_t* recvbuf, int32_t cap,
+                              int32_t G, float* rows_out, int32_t* recv_rows, uint64_t* slots64, const uint32_t* stamp,
+                              void* stream);
+int tlsan_shard_apply_lazy_static(float* shard, int32_t ld, int32_t cI, int32_t R, int32_t W, int32_t reg_item, int32_t reg_user,
+                                  const float* vals, int32_t ldv, const int32_t* rows, int32_t cap, int32_t G,
+                                  uint64_t* slots64, uint32_t* stamp, int32_t marked, float gscale, const float* step_dev,
+                                  float* cate_emb, int32_t C, int32_t dc, const float* g_cate,
+                                  double* sumsq_out, float* sumsq_f32, float* scale,
+                                  void* ws, size_t ws_bytes, void* stream);
 
 /* Exclusive prefix sum + compaction of a device int32 array (the id-routing step of the sharded
  * path): prefix[k] = sum(cnt[0..k)), uniq = ascending list of k with cnt[k] > 0 and

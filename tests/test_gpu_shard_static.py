@@ -1,0 +1,147 @@
+"""Static-shape sharded step (ShardedModel(static_rows=...), include/tlsan.h tlsan_*_static): the same numbers, bit for
+bit, as the step whose exchange sizes pass through the host -- eagerly with one or two batches announced ahead, replayed
+from HIP graphs, over two ranks -- and a loud failure when a batch does not fit the fixed exchange."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _one_rank_worker(port, ret):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from tlsan_amd import synth
+        from tlsan_amd.dist import ShardedModel
+        cfg = synth.make_config("electronics", user_count=3001, item_count=2203, cate_count=67)
+        icl = synth.item_cate_list(cfg)
+        batches = synth.make_batches(cfg, 4, 512, seed=5, sessions="amazon")
+        N = 12
+
+        def run(static, ahead, graphs=False):
+            m = ShardedModel(cfg, icl, device="cuda:0", l2_mode="lazy", static_rows=static)
+            dbs = [m.device_batch(b) for b in batches]
+            losses = []
+            nb = lambda s, j: dbs[(s + j) % 4] if ahead >= j else None
+            n_eager = 4 if graphs else N
+            for s in range(n_eager):
+                kw = dict(after_next=nb(s, 2)) if static else {}
+                m.train_async(dbs[s % 4], 0.7, next_batch=nb(s, 1), **kw)
+                losses.append(float(m.last_loss.item()))
+            if graphs:
+                gs = []
+                for i in range(4):            # capture and replay alternately along the cycle
+                    g = m.capture_step(dbs[i], dbs[(i + 1) % 4], 0.7)
+                    m.replay(g)
+                    losses.append(float(m.last_loss.item()))
+                    gs.append(g)
+                for s in range(8, N):
+                    m.replay(gs[s % 4])
+                    losses.append(float(m.last_loss.item()))
+            if static:
+                m.check_static_overflow()
+            return losses, m.gather_params()
+
+        l0, p0 = run(False, 1)
+        for name, args in (("static, one ahead", (True, 1)), ("static, two ahead", (True, 2)), ("static, none ahead", (True, 0)),
+                           ("static, fixed capacity", (2560, 2)), ("static, graphs", (True, 1, True))):
+            l1, p1 = run(*args)
+            assert l1 == l0, (name, l0, l1)
+            for k in p0:
+                assert np.array_equal(p0[k], p1[k]), (name, k)
+
+        # a batch that needs more rows of an owner than the exchange holds is reported, not silently truncated
+        m = ShardedModel(cfg, icl, device="cuda:0", l2_mode="lazy", static_rows=64)
+        m.train_async(m.device_batch(batches[0]), 0.7)
+        try:
+            m.check_static_overflow()
+            raise AssertionError("overflow not reported")
+        except RuntimeError as e:
+            assert "static_rows" in str(e)
+        try:
+            ShardedModel(cfg, icl, device="cuda:0", l2_mode="dense", static_rows=True)
+            raise AssertionError("dense + static accepted")
+        except NotImplementedError:
+            pass
+        ret[0] = "ok"
+    except Exception:
+        import traceback
+        ret[0] = "FAIL: " + traceback.format_exc()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_static_step_equals_dynamic_step_at_one_rank():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    p = ctx.Process(target=_one_rank_worker, args=(_free_port(), ret))
+    p.start()
+    p.join(600)
+    assert ret.get(0) == "ok", dict(ret)
+
+
+def _two_rank_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tlsan_amd import synth
+        from tlsan_amd.dist import ShardedModel
+        cfg = synth.make_config("electronics", user_count=3001, item_count=2203, cate_count=67)
+        icl = synth.item_cate_list(cfg)
+        per_step = [[synth.make_batches(cfg, 1, 256, seed=700 + 10 * s + r, sessions="amazon")[0] for r in range(world)] for s in range(4)]
+
+        def run(static, ahead):
+            m = ShardedModel(cfg, icl, device="cuda:0", l2_mode="lazy", static_rows=static)
+            dbs = [m.device_batch(per[rank]) for per in per_step]
+            losses = []
+            for s in range(6):
+                nb = lambda j: dbs[(s + j) % 4] if ahead >= j else None
+                kw = dict(after_next=nb(2)) if static else {}
+                m.train_async(dbs[s % 4], 0.7, next_batch=nb(1), **kw)
+                losses.append(float(m.last_loss.item()))
+            if static:
+                m.check_static_overflow()
+            return losses, m.gather_params()
+
+        l0, p0 = run(False, 1)
+        for args in ((True, 1), (True, 2)):
+            l1, p1 = run(*args)
+            assert l1 == l0, (args, l0, l1)
+            for k in p0:
+                assert np.array_equal(p0[k], p1[k]), (args, k)
+        ret[rank] = "ok"
+    except Exception:
+        import traceback
+        ret[rank] = "FAIL: " + traceback.format_exc()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_static_step_equals_dynamic_step_over_two_ranks():
+    """Two processes on one GPU (gloo stages the collectives through the host): the equal-split exchange of the static
+    step against the sized one, rows owned by the other rank included."""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    assert all(ret.get(r) == "ok" for r in range(world)), dict(ret)

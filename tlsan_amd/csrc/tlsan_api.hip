@@ -388,9 +388,14 @@ static int scan_compact_impl(const int32_t* cnt, int32_t n, int32_t* prefix, int
 // static CSR category -> items from p->item_cate (counting sort with the generic index kernels)
 static int build_cate_csr(const tlsan_dims* d, const tlsan_params* p, const St& st, hipStream_t hs) {
   const int I = d->item_count, C = d->cate_count;
-  if (hipMemsetAsync(st.cate_cnt, 0, 4 * (size_t)C, hs) != hipSuccess) return fail(TLSAN_E_LAUNCH, "memset cate_cnt");
   GIdxArgs gi;
   gi.dest = p->item_cate; gi.n = I; gi.nrows = C; gi.cnt = st.cate_cnt; gi.cur = st.cate_cur; gi.list = st.cate_items;
+  if (I <= CSR_SMALL_MAXN && C <= CSR_SMALL_MAXROWS) {   // one launch (the sharded step rebuilds this every step)
+    hipLaunchKernelGGL(k_csr_small, dim3(CSR_SMALL_WG), dim3(1024), 0, hs, gi, st.cate_off);
+    CHECK_LAUNCH("k_csr_small");
+    return TLSAN_OK;
+  }
+  if (hipMemsetAsync(st.cate_cnt, 0, 4 * (size_t)C, hs) != hipSuccess) return fail(TLSAN_E_LAUNCH, "memset cate_cnt");
   hipLaunchKernelGGL(k_gidx<false>, dim3((I + 255) / 256), dim3(256), 0, hs, gi);
   CHECK_LAUNCH("k_gidx<count>");
   ScanArgs sa;
@@ -1172,7 +1177,88 @@ int tlsan_shard_apply_lazy(float* shard, int32_t ld, int32_t cI, int32_t R, int3
   }
   hipLaunchKernelGGL(k_shard_apply_lazy, dim3(a.nb_rows + a.nb_cate), dim3(256), 0, hs, a);
   CHECK_LAUNCH("k_shard_apply_lazy");
-  hipLaunchKernelGGL(k_reduce_lazy2, dim3(2), dim3(256), 0, hs, a.part_out, a.nb_rows, a.nb_cate, sumsq_out, sumsq_f32);
+  hipLaunchKernelGGL(k_reduce_lazy2, dim3(2), dim3(256), 0, hs, a.part_out, a.nb_rows, a.nb_cate, sumsq_out, sumsq_f32, (uint32_t*)nullptr);
+  CHECK_LAUNCH("k_reduce_lazy2");
+  return TLSAN_OK;
+}
+
+// ---- static-shape forms of the three calls above (include/tlsan.h): fixed `cap` row slots per (source, owner) pair
+int tlsan_route_plan_static(const int32_t* keys, int32_t n_keys, int32_t R, int32_t G, const int32_t* cate_by_key,
+                            int32_t* flags, int32_t* rank, int32_t* uniq, int32_t* n_uniq, int32_t* sendbuf, int32_t cap,
+                            int32_t* cate_c, int32_t* comp, int32_t* counts_out, int32_t* status, void* stream) {
+  if (!keys || !cate_by_key || !flags || !rank || !uniq || !n_uniq || !sendbuf || !cate_c || !comp || !status)
+    return fail(TLSAN_E_BADARG, "tlsan_route_plan_static: NULL pointer");
+  if (n_keys < 1 || R < 1 || G < 1 || (long long)R * G >= (1LL << 31)) return fail(TLSAN_E_BADARG, "tlsan_route_plan_static: bad sizes");
+  if (cap < 1 || (long long)cap * G >= (1LL << 31)) return fail(TLSAN_E_BADARG, "tlsan_route_plan_static: bad cap");
+  hipStream_t hs = (hipStream_t)stream;
+  const int nkeys = R * G;
+  RouteArgs a;
+  memset(&a, 0, sizeof(a));
+  a.keys = keys; a.n_keys = n_keys; a.R = R; a.G = G; a.prefix = rank; a.uniq = uniq; a.n_uniq = n_uniq;
+  a.cate_by_key = cate_by_key; a.flags = flags; a.sendbuf = sendbuf; a.cap = cap;
+  a.cate_c = cate_c; a.cate_pad = G * cap; a.comp = comp; a.counts_out = counts_out;
+  hipLaunchKernelGGL(k_route_mark, dim3((n_keys + 255) / 256), dim3(256), 0, hs, a);
+  CHECK_LAUNCH("k_route_mark");
+  const int nscan = (nkeys + 4095) / 4096;
+  const long long first = ((long long)(n_keys < nkeys ? n_keys : nkeys) + 1) / 2 * 2;
+  long long* bsum = ((reinterpret_cast<uintptr_t>(uniq) & 7) == 0 && first + 2LL * nscan <= nkeys)
+                        ? reinterpret_cast<long long*>(uniq + first) : nullptr;
+  int rc = scan_compact_impl(flags, nkeys, rank, uniq, n_uniq, bsum, hs);
+  if (rc) return rc;
+  int nt = n_keys > G * cap ? n_keys : G * cap;
+  hipLaunchKernelGGL(k_route_finish_static, dim3((nt + 255) / 256), dim3(256), 0, hs, a, status);
+  CHECK_LAUNCH("k_route_finish_static");
+  return TLSAN_OK;
+}
+
+int tlsan_shard_gather_static(const float* shard, int32_t ld, int32_t R, int32_t W, const int32_t* recvbuf, int32_t cap,
+                              int32_t G, float* rows_out, int32_t* recv_rows, uint64_t* slots64, const uint32_t* stamp,
+                              void* stream) {
+  if (!shard || !recvbuf || !rows_out || !recv_rows || G < 1 || R < 1 || cap < 1 || (slots64 && !stamp))
+    return fail(TLSAN_E_BADARG, "tlsan_shard_gather_static: bad arguments");
+  if (W < 4 || W % 4 || ld < W || ld % 4) return fail(TLSAN_E_UNSUPPORTED, "tlsan_shard_gather_static: W, ld must be multiples of 4");
+  GatherStaticArgs a;
+  a.shard = shard; a.ld = ld; a.W = W; a.recvbuf = recvbuf; a.cap = cap; a.G = G; a.R = R;
+  a.rows_out = rows_out; a.recv_rows = recv_rows; a.slots64 = (unsigned long long*)slots64; a.stamp_dev = stamp;
+  hipLaunchKernelGGL(k_shard_gather_static, dim3((G * cap + 15) / 16), dim3(256), 0, (hipStream_t)stream, a);
+  CHECK_LAUNCH("k_shard_gather_static");
+  return TLSAN_OK;
+}
+
+int tlsan_shard_apply_lazy_static(float* shard, int32_t ld, int32_t cI, int32_t R, int32_t W, int32_t reg_item, int32_t reg_user,
+                                  const float* vals, int32_t ldv, const int32_t* rows, int32_t cap, int32_t G,
+                                  uint64_t* slots64, uint32_t* stamp, int32_t marked, float gscale, const float* step_dev,
+                                  float* cate_emb, int32_t C, int32_t dc, const float* g_cate,
+                                  double* sumsq_out, float* sumsq_f32, float* scale,
+                                  void* ws, size_t ws_bytes, void* stream) {
+  if (!shard || !slots64 || !stamp || !step_dev || !cate_emb || !g_cate || !sumsq_out || !scale || !vals || !rows)
+    return fail(TLSAN_E_BADARG, "tlsan_shard_apply_lazy_static: NULL pointer");
+  if (G < 1 || G > SHARD_GMAX) return fail(TLSAN_E_UNSUPPORTED, "tlsan_shard_apply_lazy_static: 1..%d ranks", SHARD_GMAX);
+  if (cap < 1 || (long long)cap * G >= (1LL << 31)) return fail(TLSAN_E_BADARG, "tlsan_shard_apply_lazy_static: bad cap");
+  if (W < 4 || W % 4 || dc % 4 || ld < W || ld % 4 || ldv < W || ldv % 4 || cI < 0 || cI > R || reg_item > W || reg_user > W)
+    return fail(TLSAN_E_UNSUPPORTED, "tlsan_shard_apply_lazy_static: widths must be multiples of 4");
+  const int n_recv = G * cap;
+  if (!ws || ws_bytes < tlsan_shard_apply_lazy_workspace(n_recv, C)) return fail(TLSAN_E_WORKSPACE, "tlsan_shard_apply_lazy_static: workspace too small");
+  ShardLazyArgs a;
+  memset(&a, 0, sizeof(a));
+  a.shard = shard; a.ld = ld; a.cI = cI; a.R = R; a.W = W; a.reg_item = reg_item; a.reg_user = reg_user;
+  a.vals = vals; a.ldv = ldv; a.rows = rows; a.n_recv = n_recv; a.G = G;
+  for (int s = 0; s <= G; ++s) a.src_off[s] = s * cap;
+  a.slots64 = (unsigned long long*)slots64; a.stamp_dev = stamp; a.gscale = gscale; a.step_dev = step_dev;
+  a.cate_emb = cate_emb; a.C = C; a.dc = dc; a.g_cate = g_cate; a.P_dev = scale;
+  a.part_out = (double*)ws;
+  a.nb_rows = (n_recv + AP_ROWS_PB - 1) / AP_ROWS_PB;
+  a.nb_cate = (C + AP_ROWS_PB - 1) / AP_ROWS_PB;
+  hipStream_t hs = (hipStream_t)stream;
+  if (!marked) {
+    hipLaunchKernelGGL(k_slot_mark64, dim3((n_recv + 255) / 256), dim3(256), 0, hs, a);
+    CHECK_LAUNCH("k_slot_mark64");
+  }
+  hipLaunchKernelGGL(k_shard_apply_lazy, dim3(a.nb_rows + a.nb_cate), dim3(256), 0, hs, a);
+  CHECK_LAUNCH("k_shard_apply_lazy");
+  // (the closing sums stay a launch of their own: taken by the last workgroup to finish they cost ~2000 same-address
+  //  ticket atomics, 29 us against 7 + 4)
+  hipLaunchKernelGGL(k_reduce_lazy2, dim3(2), dim3(256), 0, hs, a.part_out, a.nb_rows, a.nb_cate, sumsq_out, sumsq_f32, stamp);
   CHECK_LAUNCH("k_reduce_lazy2");
   return TLSAN_OK;
 }

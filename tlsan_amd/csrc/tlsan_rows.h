@@ -23,6 +23,72 @@ __global__ void k_gidx(GIdxArgs a) {
   else a.list[atomicAdd(&a.cur[d], 1)] = t;
 }
 
+// The same counting sort (cnt, off, list of a destination array) in ONE launch, counters in the LDS: for the
+// per-step category index of the sharded step's compact table (a few 10^4 rows, <= 8192 categories), where the
+// four-launch form above (memset + count + scan + fill) costs more in launch latency than in work.  CSR_SMALL_WG
+// workgroups, each owning a contiguous range of destination rows: every workgroup reads all of dest (L2-resident),
+// counts its own rows in the LDS and, in one register counter, everything that sorts before its range -- that is
+// its base offset, so the workgroups need nothing from each other.
+#define CSR_SMALL_MAXROWS 8192
+#define CSR_SMALL_MAXN (1 << 18)
+#define CSR_SMALL_WG 8
+__global__ __launch_bounds__(1024) void k_csr_small(GIdxArgs a, int32_t* __restrict__ off) {
+  __shared__ int s_cnt[CSR_SMALL_MAXROWS / CSR_SMALL_WG + 1];
+  __shared__ int s_part[1024];
+  __shared__ int s_below[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int span = (a.nrows + CSR_SMALL_WG - 1) / CSR_SMALL_WG;
+  const int r0 = (int)blockIdx.x * span, r1 = min(r0 + span, a.nrows), nr = max(r1 - r0, 0);
+  for (int c = tid; c < nr; c += 1024) s_cnt[c] = 0;
+  __syncthreads();
+  int below = 0;
+  for (int t0 = tid; t0 < a.n; t0 += 1024 * 8) {   // 8 loads in flight per thread
+    int d[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) d[u] = t0 + 1024 * u < a.n ? a.dest[t0 + 1024 * u] : -1;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (d[u] >= r0 && d[u] < r1) atomicAdd(&s_cnt[d[u] - r0], 1);
+      below += (d[u] >= 0 && d[u] < r0) ? 1 : 0;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) below += __shfl_xor(below, o);
+  if (lane == 0) s_below[wave] = below;
+  __syncthreads();
+  int base = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) base += s_below[w];
+  const int per = (nr + 1023) / 1024, lo = tid * per;
+  int sum = 0;
+  for (int c = lo; c < min(lo + per, nr); ++c) sum += s_cnt[c];
+  s_part[tid] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {   // inclusive scan of the chunk sums
+    const int v = tid >= o ? s_part[tid - o] : 0;
+    __syncthreads();
+    s_part[tid] += v;
+    __syncthreads();
+  }
+  int run = base + s_part[tid] - sum;
+  for (int c = lo; c < min(lo + per, nr); ++c) {
+    const int n = s_cnt[c];
+    a.cnt[r0 + c] = n;
+    off[r0 + c] = run;
+    s_cnt[c] = run;   // cursor of the fill pass
+    run += n;
+  }
+  __syncthreads();
+  for (int t0 = tid; t0 < a.n; t0 += 1024 * 8) {
+    int d[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) d[u] = t0 + 1024 * u < a.n ? a.dest[t0 + 1024 * u] : -1;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (d[u] >= r0 && d[u] < r1) a.list[atomicAdd(&s_cnt[d[u] - r0], 1)] = t0 + 1024 * u;
+  }
+}
+
 struct RowsArgs {
   float* W;
   int32_t ld, nrows, width, reg_cols;

@@ -48,6 +48,40 @@ __global__ void k_route_finish(RouteArgs a) {
   }
 }
 
+// Static-shape plan (tlsan_route_plan_static): every (source, owner) pair exchanges exactly `cap` row slots in both
+// directions, so no size ever has to reach the host and the whole step can be recorded in a HIP graph.  The compact
+// table of the step is numbered by slot: row of the j-th distinct key of owner g = g * cap + j  (at one rank: the
+// plain compact numbering).  Unused slots: category -1, never referenced by the batch.
+//   status[0] = largest per-owner count seen so far (atomicMax): the host compares it with cap when it next looks
+//   (a batch that needs more than cap rows of one owner is truncated -- the step is then wrong and must be reported).
+__global__ void k_route_finish_static(RouteArgs a, int32_t* status) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nu = *a.n_uniq;
+  if (t < a.n_keys) {
+    const int key = a.keys[t], g = key / a.R;
+    const int j = a.prefix[key] - a.prefix[(size_t)g * a.R];
+    a.comp[t] = g * a.cap + min(j, a.cap - 1);
+  }
+  if (t < a.G * a.cap) {
+    const int g = t / a.cap, j = t - g * a.cap;
+    const int base = a.prefix[(size_t)g * a.R];
+    const int cnt = (g + 1 < a.G ? a.prefix[(size_t)(g + 1) * a.R] : nu) - base;
+    int cat = -1;
+    if (j < cnt) {
+      const int k = a.uniq[base + j];
+      a.sendbuf[(size_t)g * (1 + a.cap) + 1 + j] = k - g * a.R;
+      cat = a.cate_by_key[k];
+    }
+    a.cate_c[t] = cat;
+    if (j == 0) {
+      a.sendbuf[(size_t)g * (1 + a.cap)] = min(cnt, a.cap);
+      if (a.counts_out) a.counts_out[g] = cnt;
+      if (cnt > a.cap) atomicMax(status, cnt);
+    }
+  }
+  if (t < nu) a.flags[a.uniq[t]] = 0;  // the marks are zero at rest: no memset per step
+}
+
 // Owner side of the row fetch: the rows the G ranks asked for (recvbuf [G][1 + cap] as received:
 // {count, local row numbers}) copied contiguously in source-rank order (= all-to-all send order),
 // plus the flat list of those row numbers for the gradient apply.  One 16-lane group per row.
@@ -69,6 +103,32 @@ __global__ __launch_bounds__(256) void k_shard_gather(GatherArgs a) {
   int r = a.recvbuf[(size_t)s * (1 + a.cap) + 1 + j];
   r = min(max(r, 0), a.R - 1);
   if (l16 == 0) a.recv_rows[e] = r;
+  const float* src = a.shard + (size_t)r * a.ld;
+  float* dst = a.rows_out + (size_t)e * a.W;
+  for (int c4 = l16; c4 < a.W / 4; c4 += 16) *(f32x4*)(dst + 4 * c4) = *(const f32x4*)(src + 4 * c4);
+}
+
+// Static-shape form: slot e = s * cap + j holds the j-th row rank s asked for (or nothing: recv_rows[e] = -1), which is
+// also the equal-split all-to-all layout of the reply.  The lazy apply's slot marks (k_slot_mark64) are written here,
+// one launch earlier: they depend on the row numbers only.
+struct GatherStaticArgs {
+  const float* shard; int32_t ld, W;
+  const int32_t* recvbuf; int32_t cap, G, R;
+  float* rows_out; int32_t* recv_rows;
+  unsigned long long* slots64; const uint32_t* stamp_dev;   // nullable; the step's stamp lives on the device (graph replay)
+};
+__global__ __launch_bounds__(256) void k_shard_gather_static(GatherStaticArgs a) {
+  const int e = blockIdx.x * 16 + (threadIdx.x >> 4), l16 = threadIdx.x & 15;
+  if (e >= a.G * a.cap) return;
+  const int s = e / a.cap, j = e - s * a.cap;
+  const int c = a.recvbuf[(size_t)s * (1 + a.cap)];
+  int r = j < c ? a.recvbuf[(size_t)s * (1 + a.cap) + 1 + j] : -1;
+  if (r < 0 || r >= a.R) r = -1;
+  if (l16 == 0) {
+    a.recv_rows[e] = r;
+    if (r >= 0 && a.slots64) a.slots64[(size_t)r * a.G + s] = ((unsigned long long)*a.stamp_dev << 32) | (unsigned)(e + 1);
+  }
+  if (r < 0) return;
   const float* src = a.shard + (size_t)r * a.ld;
   float* dst = a.rows_out + (size_t)e * a.W;
   for (int c4 = l16; c4 < a.W / 4; c4 += 16) *(f32x4*)(dst + 4 * c4) = *(const f32x4*)(src + 4 * c4);
@@ -306,23 +366,26 @@ struct ShardLazyArgs {
   float* cate_emb; int32_t C, dc; const float* g_cate;
   double* part_out; int32_t nb_rows, nb_cate;
   float* P_dev;
+  uint32_t* stamp_dev;   // static-shape step: the stamp is read from (and advanced on) the device, `stamp` is unused
 };
 
 __global__ void k_slot_mark64(ShardLazyArgs a) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= a.n_recv) return;
+  const uint32_t stamp = a.stamp_dev ? *a.stamp_dev : a.stamp;
   int s = 0;
   while (s + 1 < a.G && e >= a.src_off[s + 1]) ++s;
   const int r = a.rows[e];
-  if (r >= 0 && r < a.R) a.slots64[(size_t)r * a.G + s] = ((unsigned long long)a.stamp << 32) | (unsigned)(e + 1);
+  if (r >= 0 && r < a.R) a.slots64[(size_t)r * a.G + s] = ((unsigned long long)stamp << 32) | (unsigned)(e + 1);
 }
 
-__global__ __launch_bounds__(256) void k_shard_apply_lazy(ShardLazyArgs a) {
-  __shared__ double shd[4];
+// one workgroup's share of the lazy apply; returns this thread's part of the change of the sums of squares
+__device__ __forceinline__ double shard_apply_lazy_part(const ShardLazyArgs& a) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, grp = lane >> 4, l16 = lane & 15;
   const int blk = blockIdx.x;
   const bool is_cate = blk >= a.nb_rows;
   const float step = a.step_dev[0], lazy = a.step_dev[2];
+  const uint32_t stamp = a.stamp_dev ? *a.stamp_dev : a.stamp;
   if (blk == 0 && tid == 0) *a.P_dev = a.step_dev[3];   // (nothing in this launch reads P)
   double part = 0.0;
   if (is_cate) {  // replicated category table: every row, W_stored -= (step / P_new) * g
@@ -340,13 +403,13 @@ __global__ __launch_bounds__(256) void k_shard_apply_lazy(ShardLazyArgs a) {
     }
   } else {
     const int e = blk * AP_ROWS_PB + wave * 4 + grp;
-    if (e < a.n_recv) {
+    const int r = e < a.n_recv ? a.rows[e] : -1;   // (static-shape exchange: slots nobody filled hold -1)
+    if (r >= 0 && r < a.R) {
       int s = 0;
       while (s + 1 < a.G && e >= a.src_off[s + 1]) ++s;
-      const int r = min(max(a.rows[e], 0), a.R - 1);
       const unsigned long long* sl = a.slots64 + (size_t)r * a.G;
       bool owner = true;
-      for (int s1 = 0; s1 < s; ++s1) owner = owner && (uint32_t)(sl[s1] >> 32) != a.stamp;
+      for (int s1 = 0; s1 < s; ++s1) owner = owner && (uint32_t)(sl[s1] >> 32) != stamp;
       if (owner) {
         const int W4 = a.W / 4;
         const int reg_cols = r < a.cI ? a.reg_item : a.reg_user;
@@ -357,7 +420,7 @@ __global__ __launch_bounds__(256) void k_shard_apply_lazy(ShardLazyArgs a) {
             const unsigned long long v = sl[s2];
             // (the entry is bounds-checked as well: a stamp alone cannot vouch for a slot written by an
             //  earlier life of the model, e.g. after a restore to an earlier step)
-            if ((uint32_t)(v >> 32) == a.stamp && (uint32_t)v - 1u < (uint32_t)a.n_recv) {
+            if ((uint32_t)(v >> 32) == stamp && (uint32_t)v - 1u < (uint32_t)a.n_recv) {
               const f32x4 g = *(const f32x4*)(a.vals + (size_t)((uint32_t)v - 1u) * a.ldv + 4 * c4);
 #pragma unroll
               for (int i = 0; i < 4; ++i) acc[i] += (double)g[i];
@@ -377,15 +440,24 @@ __global__ __launch_bounds__(256) void k_shard_apply_lazy(ShardLazyArgs a) {
       }
     }
   }
+  return part;
+}
+
+__global__ __launch_bounds__(256) void k_shard_apply_lazy(ShardLazyArgs a) {
+  __shared__ double shd[4];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  double part = shard_apply_lazy_part(a);
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) part += __shfl_xor(part, o);
   if (lane == 0) shd[wave] = part;
   __syncthreads();
-  if (tid == 0) a.part_out[blk] = shd[0] + shd[1] + shd[2] + shd[3];
+  if (tid == 0) a.part_out[blockIdx.x] = shd[0] + shd[1] + shd[2] + shd[3];
 }
 
 // out[0] += sum(part[0, n0)) (changes of the stored shard rows' sum of squares), out[1] = sum(part[n0, n0+n1))
-__global__ __launch_bounds__(256) void k_reduce_lazy2(const double* part, int n0, int n1, double* out, float* sq_f32) {
+// stamp_dev (nullable): the static-shape step keeps its stamp on the device; every workgroup of the apply has read this
+// step's value by now, the next step files under the next one (never 0, the value of a cleared slot)
+__global__ __launch_bounds__(256) void k_reduce_lazy2(const double* part, int n0, int n1, double* out, float* sq_f32, uint32_t* stamp_dev) {
   __shared__ double shd[256];
   const int b = blockIdx.x;
   const double s = block_sum_double(part + (b ? n0 : 0), b ? n1 : n0, shd);
@@ -393,6 +465,10 @@ __global__ __launch_bounds__(256) void k_reduce_lazy2(const double* part, int n0
     if (b == 0) {
       out[0] += s;
       if (sq_f32) *sq_f32 = (float)out[0];
+      if (stamp_dev) {
+        const uint32_t n = *stamp_dev + 1u;
+        *stamp_dev = n == 0xFFFFFFFFu ? 1u : n;
+      }
     } else {
       out[1] = s;
     }

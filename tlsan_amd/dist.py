@@ -46,7 +46,10 @@ import torch
 import torch.distributed as dist
 
 from . import _lib as L
-from .model import DENSE_KEYS, TABLE_KEYS, DeviceBatch, Model, _Var, _Writer
+from .model import DENSE_KEYS, TABLE_KEYS, DeviceBatch, Model, _Var, _Writer, concurrent_streams
+
+
+_STATIC_SLOTS = 4     # routing plans of the static-shape step: the current batch and up to two announced successors
 
 
 class ModPartition:
@@ -257,13 +260,21 @@ def torch_scan(flags):
 class ShardedModel:
     """Model surface (train / eval_auc / ...) over row-sharded tables; see module docstring."""
 
-    def __init__(self, config, item_cate_list, device="cuda:0", seed=1234, group=None, l2_mode="dense"):
+    def __init__(self, config, item_cate_list, device="cuda:0", seed=1234, group=None, l2_mode="dense", static_rows=False):
         """l2_mode: "dense" -- every owner decays every one of its rows every step, as the reference's dense L2
         gradient does; "lazy" (sgd) -- the same update kept as W = P * W_stored with one scale P that all ranks
-        advance alike, so an owner touches only the rows whose gradients arrived (tlsan_shard_apply_lazy)."""
+        advance alike, so an owner touches only the rows whose gradients arrived (tlsan_shard_apply_lazy).
+          static_rows (lazy only): False -- exchange sizes follow the batch (the host reads them once per step);
+        True or an int -- every (source, owner) pair exchanges a FIXED number of row slots (the int, or 1.5 x what
+        the first batch needs, agreed over the ranks), no size reaches the host, and a step can be recorded in a HIP
+        graph (capture_step / replay).  A batch that needs more slots than that raises at the next host check."""
         if l2_mode not in ("dense", "lazy"):
             raise ValueError("l2_mode must be 'dense' or 'lazy'")
         self.lazy = l2_mode == "lazy"
+        if static_rows and not self.lazy:
+            raise NotImplementedError("static_rows is the lazy-L2 step's form (l2_mode='lazy')")
+        self.static_rows = static_rows
+        self._st = None            # static-shape buffers (made at the first training batch)
         if not dist.is_initialized():
             raise RuntimeError("ShardedModel needs torch.distributed to be initialised (one process per GPU)")
         from .model import OPTIMIZERS
@@ -558,7 +569,7 @@ class ShardedModel:
             return   # first use of the slot or the padded shape grows: the step does it inline
         dims, cp, cb = self._compact(ndb, nsl, None)
         if self._side is None:
-            self._side = torch.cuda.Stream(self.device)
+            self._side = concurrent_streams(self.device, 1)[0]
             self._side_event = [torch.cuda.Event(), torch.cuda.Event()]
         sst = C.c_void_p(self._side.cuda_stream)
         L.check(self.lib.tlsan_state_recategorize(C.byref(dims), C.byref(cp), st8.data_ptr(), sst), "tlsan_state_recategorize")
@@ -602,15 +613,19 @@ class ShardedModel:
         step = self._step if step is None else step
         return ((self._seed * 0x9E3779B1) ^ ((step + 1) * 0x85EBCA77)) & 0xFFFFFFFF
 
-    def train_async(self, batch, lr, next_batch=None, weight=1.0, sample0=0):
+    def train_async(self, batch, lr, next_batch=None, weight=1.0, sample0=0, after_next=None):
         """One step.  sample0: position of this rank's first sample in the global batch (dropout pattern).
           `weight`: this rank's share of the global mean when the ranks' batches differ in
         size, B_rank * world / B_global (1 when they are equal; 0 for a rank that only holds a
         placeholder row of a global batch smaller than the world).
           `next_batch` (optional): its routing plan is queued before this step's heavy
-        kernels, so that the next step's host wait for the exchange sizes costs nothing."""
+        kernels, so that the next step's host wait for the exchange sizes costs nothing.
+          `after_next` (optional, static_rows): the batch after that; its plan is built two steps ahead, beside the
+        second half of this step and all of the next, and is off the critical path altogether."""
         db = self.device_batch(batch)
         G = self.world
+        if self.static_rows:
+            return self._train_static(db, lr, next_batch, weight, sample0, after_next)
         sl = self._plan(db)
         ndb = None
         if next_batch is not None:
@@ -696,6 +711,290 @@ class ShardedModel:
             nsl = self._plan_stage2(self._slots[self._next_slot])   # its counts arrived long ago
             self._prepare_side(ndb, nsl)
         return db
+
+    # ------------------------------------------------------------------ static-shape step (static_rows)
+    def _static_setup(self, db):
+        """Buffers of the static-shape step, sized once: `cap` row slots per (source, owner) pair."""
+        r, G, dev, W = self.router, self.world, self.device, self.W
+        if self.static_rows is True:
+            # what this batch needs of its busiest owner (one host read, at set-up only), with headroom; the
+            # all-to-alls are equal-split, so every rank must use the same number
+            flags = torch.zeros(r.nkeys, dtype=torch.int32, device=dev)
+            flags[db.keys.long()] = 1
+            need = int(flags.view(G, r.R).sum(1).max().item())
+            t = torch.tensor([need], dtype=torch.int64, device=dev)
+            if G > 1:
+                if _staged(self.group):
+                    c = t.cpu(); dist.all_reduce(c, op=dist.ReduceOp.MAX, group=self.group); t = c
+                else:
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            cap = (int(t.item()) * 3 // 2 + 64 + 255) // 256 * 256
+        else:
+            cap = int(self.static_rows)
+        cap = max(1, min(cap, r.R))
+        n = G * cap
+        kcap = db.B * (self.Ls + L.SN_CAP + 3)      # ids of the largest batch the kernels take
+        side, side2 = concurrent_streams(self.device, 2)     # on hardware queues of their own (see there)
+        st = dict(cap=cap, n=n, kcap=kcap, B=db.B,
+                  status=torch.zeros(1, dtype=torch.int32, device=dev),
+                  stamp=torch.ones(1, dtype=torch.int32, device=dev),           # uint32 on the device side; never 0
+                  gf=torch.zeros(n, W, dtype=torch.float32, device=dev),
+                  vals=torch.zeros(n, W, dtype=torch.float32, device=dev) if G > 1 else None,
+                  lws=torch.empty(int(self.lib.tlsan_shard_apply_lazy_workspace(n, self.C)) + 256, dtype=torch.uint8, device=dev),
+                  slots=[None] * _STATIC_SLOTS, next=0, side=side, side2=side2,
+                  fork=torch.cuda.Event(),
+                  side_group=None, checked=0, graphs=0, warm=False)
+        if G > 1:
+            # the next batch's id exchange runs on the side stream while the main stream's collectives are in
+            # flight: a communicator of its own keeps the two sequences independent
+            ranks = list(range(G)) if self.group is None else dist.get_process_group_ranks(self.group)
+            st["side_group"] = dist.new_group(ranks, backend=dist.get_backend(self.group))
+        dims = L.Dims(n, n, self.C, self.d, self.di, self.dc, self.H, self.Ls)
+        nst = self.lib.tlsan_state_bytes(C.byref(dims))
+        nws = self.lib.tlsan_workspace_bytes(C.byref(dims), db.B, L.SN_CAP)
+        if nst == 0 or nws == 0:
+            raise L.TlsanError(self.lib.tlsan_last_error().decode())
+        st["dims"] = dims
+        if self._ws is None or self._ws.numel() < nws:
+            self._ws = torch.empty(int(nws), dtype=torch.uint8, device=dev)
+        for k in range(_STATIC_SLOTS):
+            sl = dict(k=k, rank=torch.empty(r.nkeys, dtype=torch.int32, device=dev),
+                      uniq=torch.empty(r.nkeys, dtype=torch.int32, device=dev),
+                      n_uniq=torch.zeros(1, dtype=torch.int32, device=dev),
+                      sendbuf=torch.zeros(G, 1 + cap, dtype=torch.int32, device=dev),
+                      recvbuf=torch.zeros(G, 1 + cap, dtype=torch.int32, device=dev) if G > 1 else None,
+                      cate_c=torch.full((n,), -1, dtype=torch.int32, device=dev),
+                      comp=torch.zeros(kcap, dtype=torch.int32, device=dev),
+                      rows=torch.zeros(n, W, dtype=torch.float32, device=dev),
+                      table=torch.zeros(n, W, dtype=torch.float32, device=dev) if G > 1 else None,
+                      recv_rows=torch.full((n,), -1, dtype=torch.int32, device=dev),
+                      state=torch.zeros(int(nst), dtype=torch.uint8, device=dev), db=None, views={},
+                      done=(torch.cuda.Event(), torch.cuda.Event()), pending=False, fresh=False)
+            sl["state"][:4].view(torch.float32).fill_(1.0)     # table scale P = 1 (the owners apply the decay)
+            st["slots"][k] = sl
+        self._st = st
+        return st
+
+    def _static_views(self, sl, db):
+        """ctypes views of a batch on a slot's compact table (cached: the pointers are constants of the pair)"""
+        hit = sl["views"].get(id(db))
+        if hit is not None and hit[0] is db:
+            return hit[1]
+        if len(sl["views"]) >= 16:
+            sl["views"].clear()
+        st = self._st
+        if int(db.keys.numel()) > st["kcap"]:
+            raise ValueError("static_rows: this batch holds more ids than the buffers were sized for (batch size grew?)")
+        B, Ls, Sn = db.B, self.Ls, db.Sn
+        base_c, o = sl["comp"].data_ptr(), 0
+        p_i = base_c + 4 * o; o += B
+        p_hist = base_c + 4 * o; o += B * Ls
+        p_new = base_c + 4 * o if Sn > 0 else db.hist_i_new.data_ptr(); o += B * Sn
+        p_j = None
+        if db.j is not None:
+            p_j = base_c + 4 * o; o += B
+        p_u = base_c + 4 * o
+        ptr = lambda t: None if t is None else t.data_ptr()
+        cb = L.Batch(B, Sn, p_u, p_i, p_j, ptr(db.y), p_hist, p_new, ptr(db.hist_t), ptr(db.sl), ptr(db.sl_new), ptr(db.u_cate))
+        table = sl["rows"] if self.world == 1 else sl["table"]
+        base = table.data_ptr()
+        cp = L.Params(base, base + 4 * self.di, base, base + 4 * self.di, self.cate_emb.data_ptr(),
+                      self.dense.data_ptr(), self.dense_KT.data_ptr(), sl["cate_c"].data_ptr(),
+                      self.W, self.W, self.W, self.W, self._P.data_ptr())
+        out = (cp, cb)
+        sl["views"][id(db)] = (db, out)
+        return out
+
+    def _static_plan(self, db, k, stream, group, stream2=None):
+        """Routing plan of `db` into slot k, destination index included: device work only, queued on `stream`
+        (the destination index on `stream2` when given: it needs the plan's compact ids, the category index needs its
+        category map -- two independent tails; the slot's `done` events then mark their ends)."""
+        st, r = self._st, self.router
+        sl = st["slots"][k]
+        sp = C.c_void_p(stream.cuda_stream)
+        nk = int(db.keys.numel())
+        cp, cb = self._static_views(sl, db)
+        L.check(self.lib.tlsan_route_plan_static(db.keys.data_ptr(), nk, r.R, r.G, self.cate_by_key.data_ptr(),
+                                                 self._flags.data_ptr(), sl["rank"].data_ptr(), sl["uniq"].data_ptr(),
+                                                 sl["n_uniq"].data_ptr(), sl["sendbuf"].data_ptr(), st["cap"],
+                                                 sl["cate_c"].data_ptr(), sl["comp"].data_ptr(), None,
+                                                 st["status"].data_ptr(), sp), "tlsan_route_plan_static")
+        dims = st["dims"]
+        if stream2 is not None:
+            stream2.wait_stream(stream)
+            L.check(self.lib.tlsan_batch_index(C.byref(dims), C.byref(cb), sl["state"].data_ptr(), 0,
+                                               C.c_void_p(stream2.cuda_stream)), "tlsan_batch_index")
+            sl["done"][1].record(stream2)
+        if self.world > 1:
+            with torch.cuda.stream(stream):
+                a2a(sl["recvbuf"].view(-1), sl["sendbuf"].view(-1), None, None, group)
+        L.check(self.lib.tlsan_state_recategorize(C.byref(dims), C.byref(cp), sl["state"].data_ptr(), sp), "tlsan_state_recategorize")
+        if stream2 is None:
+            L.check(self.lib.tlsan_batch_index(C.byref(dims), C.byref(cb), sl["state"].data_ptr(), 0, sp), "tlsan_batch_index")
+        else:
+            sl["done"][0].record(stream)
+        sl["pending"] = stream2 is not None
+        sl["db"] = db
+        sl["fresh"] = True      # (a step consumes its plan: the destination index counts down to zero)
+
+    def check_static_overflow(self):
+        """Host check of the static exchange (synchronises): raises when a batch needed more row slots of one owner
+        than the exchange holds -- the steps since then are wrong."""
+        st = self._st
+        if st is None:
+            return
+        need = int(st["status"].item())
+        if need > st["cap"]:
+            raise RuntimeError("static_rows: a batch needed %d rows of one owner, the exchange holds %d per pair; "
+                               "rebuild the model with static_rows >= %d" % (need, st["cap"], need))
+
+    def _train_static(self, db, lr, next_batch, weight, sample0, after_next=None):
+        st = self._st if self._st is not None else self._static_setup(db)
+        G, W, di, Ls, Cc = self.world, self.W, self.di, self.Ls, self.C
+        NS = _STATIC_SLOTS
+        main = torch.cuda.current_stream(self.device)
+        capturing = torch.cuda.is_current_stream_capturing()
+        k = st["next"]
+        sl = st["slots"][k]
+        if sl["db"] is not db or not sl["fresh"]:      # not announced by an earlier step: plan it now, in line
+            if not capturing:
+                main.wait_stream(st["side"])     # (whatever an abandoned announcement left running in the slots)
+                main.wait_stream(st["side2"])
+            self._static_plan(db, k, main, self.group)
+        elif sl["pending"]:
+            if not capturing:                    # (recorded steps join their side work at their own end)
+                main.wait_event(sl["done"][0])
+                main.wait_event(sl["done"][1])
+            sl["pending"] = False
+        sl["fresh"] = False
+        st["next"] = (k + 1) % NS
+        ahead = [(self.device_batch(b), (k + 1 + j) % NS) for j, b in enumerate((next_batch, after_next)) if b is not None]
+        ahead = [(b, kk) for b, kk in ahead if not (st["slots"][kk]["db"] is b and st["slots"][kk]["fresh"])]
+        if ahead:
+            st["fork"].record(main)      # everything before this step: the slots the new plans go to are free from here
+
+        def plan_ahead():
+            # plans and indices of the announced batches on two more streams, beside this step from its start
+            st["side"].wait_event(st["fork"])
+            for b, kk in ahead:
+                self._static_plan(b, kk, st["side"], st["side_group"], st["side2"])
+
+        # Where in the host's launch order the plans go (the device-side dependencies are the same): after the
+        # forward/backward.  That kernel fills the GPU, so a plan can only run beside the small kernels around it;
+        # queued ahead of it, the plan delays it.  One rank, same box: eager 110 us either way, graph replay 113 us with
+        # the plan queued after the kernel, 153 us before.
+        cp, cb = self._static_views(sl, db)
+        dims, n = st["dims"], st["n"]
+        sp = C.c_void_p(main.cuda_stream)
+        L.check(self.lib.tlsan_shard_gather_static(self.shard.data_ptr(), W, self.router.R, W,
+                                                   (sl["recvbuf"] if G > 1 else sl["sendbuf"]).data_ptr(), st["cap"], G,
+                                                   sl["rows"].data_ptr(), sl["recv_rows"].data_ptr(),
+                                                   self._slots64.data_ptr(), st["stamp"].data_ptr(), sp),
+                "tlsan_shard_gather_static")
+        if G > 1:
+            a2a(sl["table"].view(-1), sl["rows"].view(-1), None, None, self.group)
+        n_dense, n_cate = self.lay.n_dense, Cc * self.dc
+        flat, gf = self._flat, st["gf"]
+        fp, g0 = flat.data_ptr(), gf.data_ptr()
+        go = L.GradsOut(g0, g0 + 4 * di, g0, g0 + 4 * di, fp + 4 * n_dense, fp, W, W, W, W, 2)
+        tail = fp + 4 * (n_dense + n_cate)
+        out = L.StepOut(tail, self._gn_local.data_ptr(), None, tail + 4)
+        hp = L.HParams(float(lr), 0.0, self.clip, L.NORM_TF18, L.L2_DENSE, 0, 1, self.dropout,
+                       self.dropout_seed() if self.dropout > 0.0 else 0, int(sample0))
+        L.check(self.lib.tlsan_grads(C.byref(dims), C.byref(cp), C.byref(cb), C.byref(hp), C.byref(go), C.byref(out),
+                                     sl["state"].data_ptr(), self._ws.data_ptr(), self._ws.numel(), sp), "tlsan_grads")
+        if ahead:
+            plan_ahead()
+        if weight != 1.0:
+            kk = n_dense + n_cate
+            flat[:kk + 1].mul_(float(weight))
+            flat[kk + 1:kk + 2].mul_(float(weight) ** 2)
+            gf.mul_(float(weight))
+        if G > 1:
+            allreduce_sum(flat, self.group)
+        L.check(self.lib.tlsan_shard_summary_opt(fp, n_dense, n_cate, G, float(lr), self.reg, self.clip,
+                                                 self._sq.data_ptr() + 8, self.dense.data_ptr(), self.dense_KT.data_ptr(),
+                                                 C.byref(self.dims_full), self._step_dev.data_ptr(),
+                                                 self.last_loss.data_ptr(), self.last_gnorm.data_ptr(),
+                                                 C.byref(self._sopt_lazy), sp), "tlsan_shard_summary")
+        vals = gf
+        if G > 1:
+            vals = st["vals"]
+            a2a(vals.view(-1), gf.view(-1), None, None, self.group)
+        L.check(self.lib.tlsan_shard_apply_lazy_static(self.shard.data_ptr(), W, self.cI, self.router.R, W, di, di + Ls,
+                                                       vals.data_ptr(), W, sl["recv_rows"].data_ptr(), st["cap"], G,
+                                                       self._slots64.data_ptr(), st["stamp"].data_ptr(), 1, 1.0 / G,
+                                                       self._step_dev.data_ptr(), self.cate_emb.data_ptr(), Cc, self.dc,
+                                                       fp + 4 * n_dense, self._sq.data_ptr(), tail + 8, self._P.data_ptr(),
+                                                       st["lws"].data_ptr(), st["lws"].numel(), sp),
+                "tlsan_shard_apply_lazy_static")
+        if ahead and capturing:              # a recording must join its forks; eager steps wait where a plan is used
+            main.wait_stream(st["side"])
+            main.wait_stream(st["side2"])
+            for b, kk in ahead:
+                st["slots"][kk]["pending"] = False
+        self._step += 1
+        if not capturing:
+            st["warm"] = True
+            if self.renorm_every and self._step % self.renorm_every == 0:
+                self.fold_scale()
+            if self._step - st["checked"] >= 1024:
+                st["checked"] = self._step
+                self.check_static_overflow()
+        return db
+
+    def capture_step(self, batch, next_batch, lr):
+        """Record one static-shape step (this batch in the slot it is planned in, the next batch's plan on the side
+        streams) in a HIP graph.  Replays must follow the order of capture: the step of `batch` expects its plan
+        where the previous step left it.  Capture and replay alternately along a cycle whose length is a multiple of
+        the number of plan slots (4):  g0 = capture(b0, b1); replay(g0); g1 = capture(b1, b2); replay(g1); ...;
+        g3 = capture(b3, b0); replay(g3) -- then replay the graphs in that order.  lr is baked in."""
+        if not self.static_rows:
+            raise RuntimeError("capture_step needs static_rows (the exchange sizes of the dynamic step pass through the host)")
+        db, ndb = self.device_batch(batch), self.device_batch(next_batch)
+        st = self._st
+        if st is None or not st["warm"]:
+            raise RuntimeError("capture_step: run one eager step first (one-time initialisation cannot be recorded)")
+        main = torch.cuda.current_stream(self.device)
+        main.wait_stream(st["side"])                          # nothing of the eager steps is left in flight
+        main.wait_stream(st["side2"])
+        k0, step0 = st["next"], self._step
+        k1 = (k0 + 1) % _STATIC_SLOTS
+        for sl in st["slots"]:
+            sl["pending"] = False
+        if st["slots"][k0]["db"] is not db or not st["slots"][k0]["fresh"]:   # the recorded step expects its plan in place
+            self._static_plan(db, k0, main, self.group)
+        st["slots"][k1]["fresh"] = False                      # ... and builds the next one itself, every time
+        self._static_views(st["slots"][k0], db)               # ctypes structs are built outside the capture
+        self._static_views(st["slots"][k1], ndb)
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._train_static(db, lr, ndb, 1.0, 0)
+        # recording queues nothing: take the host-side bookkeeping of the step back
+        st["next"], self._step = k0, step0
+        st["slots"][k0]["fresh"] = True
+        st["slots"][k1]["fresh"] = False
+        g._tlsan = (db, ndb, k0, self._ws)
+        st["graphs"] += 1
+        return g
+
+    def replay(self, g):
+        db, ndb, k0, ws = g._tlsan
+        st = self._st
+        if ws is not self._ws:
+            raise RuntimeError("replay: the workspace was reallocated after this graph was captured; recapture the step")
+        if st["next"] != k0 or st["slots"][k0]["db"] is not db or not st["slots"][k0]["fresh"] or st["slots"][k0]["pending"]:
+            raise RuntimeError("replay: this step expects its batch planned in slot %d by the step before it "
+                               "(replay the graphs in the order they were captured)" % k0)
+        g.replay()
+        k1 = (k0 + 1) % _STATIC_SLOTS
+        st["slots"][k0]["fresh"] = False
+        st["slots"][k1]["db"] = ndb
+        st["slots"][k1]["fresh"] = True
+        st["slots"][k1]["pending"] = False
+        st["next"] = k1
+        self._step += 1
 
     def _lazy_stamp(self):
         """Stamp of this step's entries in _slots64 (tlsan_shard_apply_lazy): 1 .. 2^32-2, never 0 (the value
@@ -923,6 +1222,12 @@ class ShardedModel:
             self._slots64.zero_()
         self._slots = [None, None, None]
         self._next_slot = 0
+        if self._st is not None:       # static-shape step: no plan is pending, the stamps restart
+            self._st["stamp"].fill_(1)
+            self._st["next"] = 0
+            for sl in self._st["slots"]:
+                sl["db"] = None
+                sl["fresh"] = sl["pending"] = False
 
     def _shard_layout(self, p):
         """Full tables (dict of numpy arrays named like the parameters) -> this rank's fused [item | user] rows."""
