@@ -261,7 +261,7 @@ def _driver_worker(rank, world, port, ret, ckpt, extra):
 
 
 @pytest.mark.parametrize("extra", [(), ("--optimizer", "adam", "--learning_rate", "0.01", "--dropout", "0.1"),
-                                   ("--l2_mode", "lazy")])
+                                   ("--l2_mode", "lazy"), ("--l2_mode", "lazy", "--static_rows", "1")])
 def test_sharded_train_driver_matches_single_gpu(extra, tmp_path):
     """python -m tlsan_amd.train --sharded: the reference's train.py flow over 2 ranks (global batches
     split over the ranks, unevenly here; evaluation over split test batches) against the single-GPU driver

@@ -499,6 +499,10 @@ class ShardedModel:
     def _plan_eval(self, db):
         """The plan of a forward-only batch, in a slot of its own: evaluation may run between a training
         step and the successor it has announced (whose plan and indices are waiting in the other slots)."""
+        if self._st is not None:   # static-shape training: plans announced ahead may be running on the side streams
+            main = torch.cuda.current_stream(self.device)     # (they use the same mark scratch as this plan)
+            main.wait_stream(self._st["side"])
+            main.wait_stream(self._st["side2"])
         return self._plan_stage2(self._plan_stage1(db, 2))
 
     def _fetch(self, sl):
@@ -1160,6 +1164,7 @@ class ShardedModel:
         can be saved.  sharded=False gathers everything to rank 0 and writes the single-GPU format of
         tlsan_amd.model.Model.save (restores into either model, any world size).  Returns the path prefix."""
         import json
+        self.check_static_overflow()       # never write down the result of a truncated exchange
         self.fold_scale()
         os.makedirs(self.config["model_dir"], exist_ok=True)
         base = os.path.join(self.config["model_dir"], "TLSAN-%d" % self._step)

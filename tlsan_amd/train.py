@@ -47,6 +47,10 @@ def parse(argv=None):
     ap.add_argument("--quiet", action="store_true")
     ap.add_argument("--table_dtype", default="f32", choices=["f32", "bf16"],
                     help="storage of item/user/category tables (bf16: fp32 arithmetic, stochastic rounding on update)")
+    ap.add_argument("--static_rows", type=int, default=0,
+                    help="sharded driver, lazy L2: 0 = exchange sizes follow the batch (read by the host once a step); "
+                         "1 = fixed-size exchanges sized from the first batch (x1.5); N > 1 = N row slots per rank pair. "
+                         "A batch that does not fit raises at the next check (every 1024 steps, at evaluation, at the end)")
     ap.add_argument("--matrix_dtype", default="f32", choices=["f32", "bf16"],
                     help="arithmetic of the fused kernel's matrix products (bf16: operands rounded to bfloat16, fp32 accumulate)")
     ap.add_argument("--l2_mode", default="dense", choices=["dense", "lazy"])
@@ -240,6 +244,19 @@ def train(args, data=None):
                 best_prec=best_prec, best_recall=best_recall)
 
 
+def _lookahead2(it):
+    """(item, next_or_None, one_after_or_None) triples (ShardedModel.train_async(next_batch=, after_next=))."""
+    buf = []
+    for x in it:
+        buf.append(x)
+        if len(buf) == 3:
+            yield buf[0], buf[1], buf[2]
+            buf.pop(0)
+    while buf:
+        yield buf[0], (buf[1] if len(buf) > 1 else None), None
+        buf.pop(0)
+
+
 def _share(batch, rank, world):
     """This rank's rows of a global batch (contiguous, as even as possible) and how many of them are
     real: a rank without rows gets row 0 as a placeholder (0 real rows), so that every rank takes
@@ -293,8 +310,11 @@ def train_sharded(args):
         raise NotImplementedError("--matrix_dtype %s: the sharded step computes in fp32" % args.matrix_dtype)
     resume = prepare_model_dir(args.model_dir, args.from_scratch, rank,
                                (lambda: dist.barrier()) if world > 1 else None)     # train.py:124-127
-    model = ShardedModel(config, icl, device=args.device, seed=args.seed,
-                         l2_mode=args.l2_mode if args.optimizer == "sgd" else "dense")
+    l2_mode = args.l2_mode if args.optimizer == "sgd" else "dense"
+    if args.static_rows and l2_mode != "lazy":
+        raise NotImplementedError("--static_rows is the lazy-L2 SGD step's form (--l2_mode lazy --optimizer sgd)")
+    model = ShardedModel(config, icl, device=args.device, seed=args.seed, l2_mode=l2_mode,
+                         static_rows=(True if args.static_rows == 1 else args.static_rows))
     if resume is not None:                                                          # train.py:71-76
         say("Reloading model parameters..", flush=True)
         model.restore(None, resume)
@@ -309,6 +329,7 @@ def train_sharded(args):
 
     def eval_auc_():
         # train.py:86-96: sum_b auc_b * len_b / N == (pairs ranked right) / N, summed over the ranks' shares
+        model.check_static_overflow()      # (static_rows: a step that did not fit its exchange is reported here at the latest)
         right = 0.0
         for _, batch in DataInputTest(test_set, config["test_batch_size"], config["Ls"]):
             part, real = _share(batch, rank, world)
@@ -341,10 +362,11 @@ def train_sharded(args):
     for _ in range(args.max_epochs):
         train_set.shuffle(rng)
         shares = (_share(b, rank, world) + (len(b[0]),) for _, b in DataInput(train_set, args.train_batch_size, config["Ls"]))
-        for (part, real, n_glob), nxt in _lookahead((model.device_batch(p_), r_, n_) for p_, r_, n_ in shares):
-            last = nxt is None or (args.max_steps and model.global_step.eval() + 1 >= args.max_steps)
-            model.train_async(part, lr, next_batch=None if last else nxt[0], weight=real * world / n_glob,
-                              sample0=n_glob * rank // world)
+        for (part, real, n_glob), nxt, nxt2 in _lookahead2((model.device_batch(p_), r_, n_) for p_, r_, n_ in shares):
+            left = (args.max_steps - model.global_step.eval() - 1) if args.max_steps else 2     # steps after this one
+            model.train_async(part, lr, next_batch=nxt[0] if (nxt is not None and left >= 1) else None,
+                              after_next=nxt2[0] if (nxt2 is not None and left >= 2 and args.static_rows) else None,
+                              weight=real * world / n_glob, sample0=n_glob * rank // world)
             loss_sum += model.last_loss[0]
             step = model.global_step.eval()
             if step % args.eval_freq == 0:
