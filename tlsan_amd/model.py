@@ -21,6 +21,7 @@ from __future__ import annotations
 import ctypes as C
 import json
 import os
+import sys
 
 import numpy as np
 import torch
@@ -115,9 +116,17 @@ def concurrent_streams(device, want=1, pool=6, **stream_kw):
         with torch.cuda.stream(c):
             x.add_(1.0)
     chosen = []
-    for c in cands:
-        if len(chosen) < want and overlaps(main, c) and all(overlaps(o, c) for o in chosen):
-            chosen.append(c)
+    dbg = os.environ.get("TLSAN_DEBUG_STREAMS") == "1"
+    for k, c in enumerate(cands):
+        if len(chosen) < want:
+            ok_main = overlaps(main, c)
+            t_main = (ev[0].elapsed_time(ev[2]), ev[0].elapsed_time(ev[1]))
+            ok = ok_main and all(overlaps(o, c) for o in chosen)
+            if dbg:
+                print("concurrent_streams: candidate %d vs main: tiny kernel done after %.3f ms, spin %.3f ms -> %s"
+                      % (k, t_main[0], t_main[1], "taken" if ok else "shares a queue"), file=sys.stderr)
+            if ok:
+                chosen.append(c)
     for c in cands:                     # fewer independent queues than asked for: take what there is
         if len(chosen) < want and c not in chosen:
             chosen.append(c)
