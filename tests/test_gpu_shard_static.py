@@ -145,3 +145,26 @@ def test_static_step_equals_dynamic_step_over_two_ranks():
     for p in procs:
         p.join(600)
     assert all(ret.get(r) == "ok" for r in range(world)), dict(ret)
+
+
+def test_side_streams_run_beside_the_main_stream():
+    """model.concurrent_streams: the streams it returns overlap work on the current stream and on each other (HIP
+    multiplexes streams onto a few hardware queues; two streams on one queue execute like one)."""
+    from tlsan_amd.model import concurrent_streams
+    dev = torch.device("cuda:0")
+    streams = concurrent_streams(dev, 2)
+    assert len(streams) == 2 and streams[0] is not streams[1]
+    main = torch.cuda.current_stream(dev)
+    x = torch.zeros(64, device=dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    for a, b in ((main, streams[0]), (main, streams[1]), (streams[0], streams[1])):
+        torch.cuda.synchronize(dev)
+        with torch.cuda.stream(a):
+            ev[0].record(a)
+            torch.cuda._sleep(2000000)           # ~1 ms of spinning on a
+            ev[1].record(a)
+        with torch.cuda.stream(b):
+            x.add_(1.0)                          # launched after it, on b
+            ev[2].record(b)
+        torch.cuda.synchronize(dev)
+        assert ev[0].elapsed_time(ev[2]) < 0.5 * ev[0].elapsed_time(ev[1]), "the tiny kernel waited for the spin: one queue"
