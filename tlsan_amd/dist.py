@@ -753,6 +753,11 @@ class ShardedModel:
             # flight: a communicator of its own keeps the two sequences independent
             ranks = list(range(G)) if self.group is None else dist.get_process_group_ranks(self.group)
             st["side_group"] = dist.new_group(ranks, backend=dist.get_backend(self.group))
+            # communicators are set up at their first collective: do that here, on every rank at the same point, not in
+            # the middle of the first step with the main communicator's collectives in flight
+            warm = torch.zeros(G, dtype=torch.int32, device=dev)
+            a2a(torch.empty_like(warm), warm, None, None, st["side_group"])
+            torch.cuda.synchronize(dev)
         dims = L.Dims(n, n, self.C, self.d, self.di, self.dc, self.H, self.Ls)
         nst = self.lib.tlsan_state_bytes(C.byref(dims))
         nws = self.lib.tlsan_workspace_bytes(C.byref(dims), db.B, L.SN_CAP)
