@@ -232,6 +232,76 @@ def test_route_plan_matches_key_router(n_items, n_users, n_uses):
     assert np.array_equal(r.item_keys(torch.as_tensor(items)).numpy(), (items % G) * r.R + items // G)
 
 
+@pytest.mark.parametrize("n_items,n_users,n_uses,cap", [(203, 117, 700, 96), (260_000, 90_000, 5000, 1536), (203, 117, 700, 40)])
+def test_static_route_plan_and_gather(n_items, n_users, n_uses, cap):
+    """tlsan_route_plan_static / tlsan_shard_gather_static against numpy: slot numbering (the j-th distinct row of
+    owner g is compact row g * cap + j), per-owner request lists, category map with -1 in the empty slots, and on the
+    owner's side the gathered rows, `recv_rows` (-1 = empty) and the slot marks.  cap = 40 is too small for this
+    batch: counts are clamped and the true maximum lands in `status`."""
+    import ctypes as C
+    from tlsan_amd import _lib as L
+    from tlsan_amd.dist import KeyRouter
+    lib = L.load()
+    G = 4
+    r = KeyRouter(n_items, n_users, G, 0)
+    rng = np.random.RandomState(12)
+    items, users = rng.randint(0, n_items, n_uses), rng.randint(0, n_users, 64)
+    keys = torch.cat([r.item_keys(torch.as_tensor(items)), r.user_keys(torch.as_tensor(users))]).to(torch.int32).cuda()
+    cbk = torch.full((r.nkeys,), -1, dtype=torch.int32)
+    ids = np.arange(n_items)
+    cbk[(ids % G) * r.R + ids // G] = torch.as_tensor(rng.randint(0, 9, n_items).astype(np.int32))
+    cbk = cbk.cuda()
+    nk = int(keys.numel())
+    z = lambda n: torch.zeros(n, dtype=torch.int32, device="cuda")
+    flags, rank, uniq, n_uniq, sendbuf, comp, status = z(r.nkeys), z(r.nkeys), z(r.nkeys), z(1), z(G * (1 + cap)), z(nk), z(1)
+    cate_c = torch.full((G * cap,), 7777, dtype=torch.int32, device="cuda")
+    counts_out = z(G)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(lib.tlsan_route_plan_static(keys.data_ptr(), nk, r.R, G, cbk.data_ptr(), flags.data_ptr(), rank.data_ptr(),
+                                        uniq.data_ptr(), n_uniq.data_ptr(), sendbuf.data_ptr(), cap, cate_c.data_ptr(),
+                                        comp.data_ptr(), counts_out.data_ptr(), status.data_ptr(), st), "tlsan_route_plan_static")
+    torch.cuda.synchronize()
+    kn = keys.cpu().numpy().astype(np.int64)
+    u_ref = np.unique(kn)
+    per = [u_ref[(u_ref >= g * r.R) & (u_ref < (g + 1) * r.R)] for g in range(G)]
+    true_counts = [len(x) for x in per]
+    assert counts_out.cpu().tolist() == true_counts
+    assert int(flags.abs().sum().item()) == 0                                      # marks cleared
+    sb = sendbuf.view(G, 1 + cap).cpu().numpy()
+    cc = cate_c.cpu().numpy().reshape(G, cap)
+    cbk_h = cbk.cpu().numpy()
+    fits = max(true_counts) <= cap
+    assert int(status.item()) == (0 if fits else max(true_counts))
+    for g in range(G):
+        c = min(true_counts[g], cap)
+        assert sb[g, 0] == c
+        assert np.array_equal(sb[g, 1:1 + c], per[g][:c] - g * r.R)                # row numbers inside the owner's shard
+        assert np.array_equal(cc[g, :c], cbk_h[per[g][:c]]) and (cc[g, c:] == -1).all()
+    if fits:
+        where = {int(k): g * cap + j for g in range(G) for j, k in enumerate(per[g])}
+        assert np.array_equal(comp.cpu().numpy(), np.array([where[int(k)] for k in kn]))
+    # owner side (as if this rank were asked by all G ranks for what it asked of owner g: reuse sendbuf as recvbuf)
+    W = 12
+    shard = torch.arange(r.R * W, dtype=torch.float32, device="cuda").view(r.R, W)
+    rows = torch.full((G * cap, W), -5.0, device="cuda")
+    recv_rows = z(G * cap)
+    slots = torch.zeros(r.R * G, dtype=torch.int64, device="cuda")
+    stamp = torch.full((1,), 9, dtype=torch.int32, device="cuda")
+    L.check(lib.tlsan_shard_gather_static(shard.data_ptr(), W, r.R, W, sendbuf.data_ptr(), cap, G, rows.data_ptr(),
+                                          recv_rows.data_ptr(), slots.data_ptr(), stamp.data_ptr(), st), "tlsan_shard_gather_static")
+    torch.cuda.synchronize()
+    rr = recv_rows.cpu().numpy().reshape(G, cap)
+    rows_h, sl = rows.cpu().numpy().reshape(G, cap, W), slots.cpu().numpy().reshape(r.R, G)
+    for g in range(G):
+        c = sb[g, 0]
+        assert np.array_equal(rr[g, :c], sb[g, 1:1 + c]) and (rr[g, c:] == -1).all()
+        assert np.array_equal(rows_h[g, :c], shard.cpu().numpy()[sb[g, 1:1 + c]])
+        assert (rows_h[g, c:] == -5.0).all()                                        # empty slots are not touched
+        for j in range(c):
+            assert sl[sb[g, 1 + j], g] == (9 << 32) | (g * cap + j + 1)
+    assert np.count_nonzero(sl) == int(sb[:, 0].sum())
+
+
 def _driver_worker(rank, world, port, ret, ckpt, extra):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
