@@ -410,6 +410,39 @@ def test_long_windows_streamed(d, Ls, Sn, B):
             assert np.abs(du - dr).max() < 3e-4 * (np.abs(dr).max() + 1e-9) + 5e-7, (k, l2)
 
 
+@pytest.mark.parametrize("d,Ls,Sn,B", [(128, 20, 3, 37), (128, 90, 5, 21), (64, 33, 2, 50)])
+def test_bf16_tables_with_streamed_windows(d, Ls, Sn, B):
+    """bf16 table storage with Ls > 10 (the Movies-TV configuration asks for both): forward and gradients equal the
+    fp64 oracle evaluated on the stored (bf16-rounded) tables, and a training step runs and is reproducible."""
+    cfg = make_config(U=50, I=150, C=8, d=d, Ls=Ls, regulation_rate=1e-3)
+    p = _p32(random_params(cfg, seed=Ls + d))
+    for k in BF16_TABLES:
+        p[k] = _bf16_round(p[k]).astype(np.float64)
+    b, cat = random_batch(cfg, B=B, Sn=Sn, seed=Ls)
+    b["sl"][:4] = [Ls, 1, Ls - 1, min(Ls, 11)]
+    ar = np.arange(Ls)[None, :]
+    b["hist_i"] = np.where(ar < b["sl"][:, None], np.random.RandomState(2).randint(0, 150, (B, Ls)), 0)
+    b["hist_t"] = np.where(ar < b["sl"][:, None], (1.0 / np.random.RandomState(3).randint(1, 13, (B, Ls))), 0).astype(np.float32)
+    m = _model(cfg, cat, p, l2_mode="lazy", table_dtype="bf16")
+    ref = orc.forward(p, cat, b, 8)
+    li, _, _, _ = m.forward(_tuple(b), is_test=False)
+    assert np.abs(li.cpu().numpy() - ref["logits"]).max() < LOGIT_TOL
+    g = m.grads(_tuple(b))
+    _, _, ref_g, _ = orc.backward(p, cat, b, 8, cfg["regulation_rate"])
+    for k in ref_g:
+        a, r = np.asarray(g["grads"][k], np.float64).reshape(ref_g[k].shape), ref_g[k]
+        assert np.abs(a - r).max() < 3e-4 * np.abs(r).max() + 1e-6, k
+    loss = orc.train_step(p, cat, b, 8, cfg["regulation_rate"], lr=0.6)[0]
+    outs = []
+    for rep in range(2):
+        mm = _model(cfg, cat, p, l2_mode="lazy", table_dtype="bf16")
+        l = mm.train(None, _tuple(b), 0.6)
+        assert abs(l - loss) < 2e-4 * max(1.0, abs(loss))
+        outs.append(mm.get_params())
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
 def test_prefetched_index_equals_inline():
     """train_async(next_batch=...) builds the next batch's destination index on a second stream
     (tlsan_batch_index) while the step runs; the result must be bitwise the same as building it

@@ -24,7 +24,7 @@ static hipError_t launch_variant_dt(const FwdArgs& a, int grid, hipStream_t st) 
   return hipGetLastError();
 }
 
-// bf16 table storage: the common variants only (window in registers); streamed windows stay fp32
+// bf16 table storage: window in registers or streamed; bf16 matrix products: window in registers only
 template <int D, int DH, bool TRAIN, bool LSTREAM>
 static hipError_t launch_variant(const FwdArgs& a, int grid, hipStream_t st) {
   if (a.p.matrix_dtype == TLSAN_MATRIX_BF16) {  // bf16 matrix products: window in registers, either table storage, no dropout
@@ -38,8 +38,7 @@ static hipError_t launch_variant(const FwdArgs& a, int grid, hipStream_t st) {
   }
   if (a.p.table_dtype == TLSAN_TABLE_BF16) {
     if (a.drop_thr != 0) return hipErrorNotSupported;
-    if constexpr (!LSTREAM) return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_BF16>(a, grid, st);
-    else return hipErrorNotSupported;
+    return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_BF16>(a, grid, st);
   }
   if (a.drop_thr != 0) {  // dropout: training, fp32 tables
     if constexpr (TRAIN) return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_F32, true>(a, grid, st);
