@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--event-every", type=int, default=8,
                     help="every Nth timed step carries the HIP events that bracket k_fwd_bwd (graph mode: runs eagerly)")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded (multi-GPU) code path even at N=1")
+    ap.add_argument("--wire-dtype", default="f32", choices=["f32", "bf16"],
+                    help="sharded path: rows cross the wire with fp32 or bf16 embedding values (the owners' weights stay fp32)")
     ap.add_argument("--static-rows", type=int, default=1,
                     help="sharded path, lazy L2: fixed-size row exchanges (no exchange size passes through the host)")
     ap.add_argument("--accuracy-steps", type=int, default=2000,
@@ -234,7 +236,8 @@ def main():
     else:
         from tlsan_amd.dist import ShardedModel
         # lazy L2: the static-shape step (fixed-size exchanges, nothing passes through the host)
-        model = ShardedModel(cfg, icl, device=dev, l2_mode=args.l2_mode, static_rows=bool(args.static_rows) and args.l2_mode == "lazy")
+        model = ShardedModel(cfg, icl, device=dev, l2_mode=args.l2_mode, static_rows=bool(args.static_rows) and args.l2_mode == "lazy",
+                             wire_dtype=args.wire_dtype)
         stepper = model
     dbs = [stepper.device_batch(b) for b in host_batches]
     lr = 1.0
@@ -372,7 +375,8 @@ def main():
                                       "lazy (reference's dense-L2 update as W = P*W_stored; only used rows touched)"),
                        "global_batch": B * world, "parallelism": "1 process/GPU, tables %s"
                        % ("on one GPU" if not sharded else "row-sharded (id %% N), RCCL all-to-all + one all-reduce" +
-                          (", static-shape exchanges, plans two batches ahead" if model.static_rows else ""))},
+                          (", static-shape exchanges, plans two batches ahead" if model.static_rows else "") +
+                          (", bf16 rows on the wire (fp32 weights at the owners)" if args.wire_dtype == "bf16" else ""))},
             "roofline": {"bound": "hbm", "kernel": "k_fwd_bwd", "achieved": None if achieved is None else round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),

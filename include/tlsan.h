@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TLSAN_ABI_VERSION 11
+#define TLSAN_ABI_VERSION 12
 
 enum {
   TLSAN_OK = 0,
@@ -430,6 +430,15 @@ int tlsan_route_plan_static(const int32_t* keys, int32_t n_keys, int32_t R, int3
 int tlsan_shard_gather_static(const float* shard, int32_t ld, int32_t R, int32_t W, const int32_t* recvbuf, int32_t cap,
                               int32_t G, float* rows_out, int32_t* recv_rows, uint64_t* slots64, const uint32_t* stamp,
                               void* stream);
+/* tlsan_shard_gather_wire_bf16: tlsan_shard_gather_static with bf16 rows on the wire.  Owners keep fp32 rows; slot e
+ * of rows_out (pitch bytes per slot, a multiple of 16) receives
+ *   [ the first d_emb floats of the row as bf16, round to nearest even | the next `tail` floats as fp32 | pad ]
+ * -- for the fused [item_emb | item_b] / [user_emb | usert_emb] rows of tlsan_amd/dist.py: tail = max(1, Ls).  The
+ * consumer points its tlsan_params, table_dtype = TLSAN_TABLE_BF16, into the slots: item_emb / user_emb at the slot base
+ * with ld = pitch / 2, item_b / usert_emb at base + 2 * d_emb bytes with ld = pitch / 4. */
+int tlsan_shard_gather_wire_bf16(const float* shard, int32_t ld, int32_t R, int32_t d_emb, int32_t tail,
+                                 const int32_t* recvbuf, int32_t cap, int32_t G, void* rows_out, int32_t pitch,
+                                 int32_t* recv_rows, uint64_t* slots64, const uint32_t* stamp, void* stream);
 int tlsan_shard_apply_lazy_static(float* shard, int32_t ld, int32_t cI, int32_t R, int32_t W, int32_t reg_item, int32_t reg_user,
                                   const float* vals, int32_t ldv, const int32_t* rows, int32_t cap, int32_t G,
                                   uint64_t* slots64, uint32_t* stamp, int32_t marked, float gscale, const float* step_dev,

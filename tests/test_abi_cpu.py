@@ -21,11 +21,11 @@ def _lib():
 def test_header_symbols_exported():
     L, lib = _lib()
     hdr = open(os.path.join(ROOT, "include", "tlsan.h")).read()
-    declared = set(re.findall(r"\b(tlsan_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(tlsan_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(L.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.tlsan_abi_version() == L.ABI_VERSION == 11
+    assert lib.tlsan_abi_version() == L.ABI_VERSION == 12
 
 
 def test_dense_layout_and_sizes():

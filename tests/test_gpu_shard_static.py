@@ -168,3 +168,81 @@ def test_side_streams_run_beside_the_main_stream():
             ev[2].record(b)
         torch.cuda.synchronize(dev)
         assert ev[0].elapsed_time(ev[2]) < 0.5 * ev[0].elapsed_time(ev[1]), "the tiny kernel waited for the spin: one queue"
+
+
+def _bf16_round(a):
+    t = torch.as_tensor(np.asarray(a, np.float32))
+    return t.to(torch.bfloat16).to(torch.float32).numpy()
+
+
+def _wire_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import tlsan_oracle as orc
+        from tests.helpers import make_config, random_batch, random_params
+        from tlsan_amd.dist import ShardedModel
+        reg = 1e-3
+        cfg = make_config(U=61, I=83, C=9, d=128, regulation_rate=reg)
+        p = {k: np.asarray(v, np.float32).astype(np.float64) for k, v in random_params(cfg, seed=17).items()}
+        _, cat = random_batch(cfg, B=4, Sn=2, seed=0)
+        tup = lambda b: (b["u"], b["i"], b["y"], b["hist_i"], b["hist_i_new"], b["hist_t"], b["sl"], b["sl_new"], b["u_cate"])
+        steps = [[random_batch(cfg, B=24, Sn=3, seed=2000 + 10 * s + r)[0] for r in range(world)] for s in range(3)]
+        m = ShardedModel(cfg, cat, device="cuda:0", l2_mode="lazy", static_rows=True, wire_dtype="bf16")
+        m.set_params({k: np.asarray(v, np.float32) for k, v in p.items()})
+        dbs = [m.device_batch(tup(per[rank])) for per in steps]
+        losses = []
+        for k, db in enumerate(dbs):
+            m.train_async(db, 0.8, next_batch=dbs[k + 1] if k + 1 < len(dbs) else None)
+            losses.append(float(m.last_loss.item()))
+        m.check_static_overflow()
+        got = m.gather_params()
+        if rank == 0:
+            # the same steps on the CPU: forward / backward at the bf16-rounded embedding tables, L2 term, clip norm and
+            # update on the fp32 weights the owners keep
+            q, ref, P = dict(p), [], 1.0        # P: the lazy-L2 table scale (tables = P * stored; what is rounded is `stored`)
+            for per in steps:
+                Sn = max(b["hist_i_new"].shape[1] for b in per)
+                g_b = {k: np.concatenate([np.pad(b[k], ((0, 0), (0, Sn - b[k].shape[1]))) if k == "hist_i_new" else b[k]
+                                          for b in per], 0) for k in per[0]}
+                qr = dict(q)
+                for k in ("item_emb", "user_emb", "cate_emb"):
+                    qr[k] = _bf16_round(q[k] / P).astype(np.float64) * P
+                bce, _, g, sparse = orc.backward(qr, cat, g_b, 8, 0.0)
+                for k in orc.REG_TABLES:
+                    g[k] = sparse["g_sparse"][k] + reg * q[k]
+                norm = orc.global_norm(q, g, sparse, reg, "tf18")
+                coef = 5.0 / max(norm, 5.0)
+                ref.append(bce + reg * orc.l2_term(q))
+                q = {k: q[k] - 0.8 * coef * g[k] for k in q}
+                P *= 1.0 - 0.8 * coef * reg
+            assert np.allclose(losses, ref, rtol=3e-4, atol=1e-5), (losses, ref)
+            for k in q:
+                du = np.asarray(got[k], np.float64).reshape(q[k].shape) - p[k]
+                dr = q[k] - p[k]
+                # (a value within fp32 rounding of a bf16 tie may round the other way here than on the GPU: one such
+                #  element moves a few gradient rows by 2^-8 of themselves)
+                assert np.abs(du - dr).max() < 5e-3 * (np.abs(dr).max() + 1e-9) + 1e-6, (k, float(np.abs(du - dr).max()), float(np.abs(dr).max()))
+        ret[rank] = "ok"
+    except Exception:
+        import traceback
+        ret[rank] = "FAIL: " + traceback.format_exc()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_bf16_rows_on_the_wire(world):
+    """ShardedModel(wire_dtype="bf16"): owners keep fp32 rows, the copies the kernels gather from carry bf16 embedding
+    values.  Against the oracle run the same way: gradients at the rounded tables, L2 / clip / update on the fp32 ones."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_wire_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    assert all(ret.get(r) == "ok" for r in range(world)), dict(ret)

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # (TLSAN_LIB_PATH: a diagnostic build of the same library, e.g. the -DTLSAN_STAMPS=1 variant of scripts/stamps.py)
 LIB_PATH = os.environ.get("TLSAN_LIB_PATH") or os.path.join(HERE, "libtlsan_hip.so")
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 NORM_TF18, NORM_DEDUP = 0, 1
 TABLE_F32, TABLE_BF16 = 0, 1
 MATRIX_F32, MATRIX_BF16 = 0, 1
@@ -24,7 +24,7 @@ EXPORTS = [
     "tlsan_profile_collect", "tlsan_debug_stamps", "tlsan_rows_apply_workspace", "tlsan_rows_apply", "tlsan_scan_compact",
     "tlsan_route_plan", "tlsan_shard_gather", "tlsan_shard_summary", "tlsan_shard_apply_workspace", "tlsan_shard_apply",
     "tlsan_shard_summary_opt", "tlsan_shard_apply_opt", "tlsan_shard_apply_lazy_workspace", "tlsan_shard_apply_lazy",
-    "tlsan_route_plan_static", "tlsan_shard_gather_static", "tlsan_shard_apply_lazy_static",
+    "tlsan_route_plan_static", "tlsan_shard_gather_static", "tlsan_shard_apply_lazy_static", "tlsan_shard_gather_wire_bf16",
 ]
 PROF_SEGMENTS = ("index_build", "fwd_bwd", "dk_partial", "dense_finalize", "apply_rows")
 
@@ -187,6 +187,9 @@ def load():
     lib.tlsan_shard_gather_static.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.tlsan_shard_gather_static.restype = C.c_int
+    lib.tlsan_shard_gather_wire_bf16.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                                 C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.tlsan_shard_gather_wire_bf16.restype = C.c_int
     lib.tlsan_shard_apply_lazy_static.argtypes = [C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                                   C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p,
                                                   C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -1225,6 +1225,22 @@ int tlsan_shard_gather_static(const float* shard, int32_t ld, int32_t R, int32_t
   return TLSAN_OK;
 }
 
+int tlsan_shard_gather_wire_bf16(const float* shard, int32_t ld, int32_t R, int32_t d_emb, int32_t tail,
+                                 const int32_t* recvbuf, int32_t cap, int32_t G, void* rows_out, int32_t pitch,
+                                 int32_t* recv_rows, uint64_t* slots64, const uint32_t* stamp, void* stream) {
+  if (!shard || !recvbuf || !rows_out || !recv_rows || G < 1 || R < 1 || cap < 1 || (slots64 && !stamp))
+    return fail(TLSAN_E_BADARG, "tlsan_shard_gather_wire_bf16: bad arguments");
+  if (d_emb < 4 || d_emb % 4 || tail < 0 || ld < d_emb + tail || ld % 4 || pitch % 16 || pitch < 2 * d_emb + 4 * tail)
+    return fail(TLSAN_E_UNSUPPORTED, "tlsan_shard_gather_wire_bf16: d_emb %% 4 == 0, pitch %% 16 == 0, pitch >= 2 d_emb + 4 tail");
+  GatherWireArgs w;
+  w.g.shard = shard; w.g.ld = ld; w.g.W = 0; w.g.recvbuf = recvbuf; w.g.cap = cap; w.g.G = G; w.g.R = R;
+  w.g.rows_out = (float*)rows_out; w.g.recv_rows = recv_rows; w.g.slots64 = (unsigned long long*)slots64; w.g.stamp_dev = stamp;
+  w.d_emb = d_emb; w.tail = tail; w.pitch = pitch;
+  hipLaunchKernelGGL(k_shard_gather_wire_bf16, dim3((G * cap + 15) / 16), dim3(256), 0, (hipStream_t)stream, w);
+  CHECK_LAUNCH("k_shard_gather_wire_bf16");
+  return TLSAN_OK;
+}
+
 int tlsan_shard_apply_lazy_static(float* shard, int32_t ld, int32_t cI, int32_t R, int32_t W, int32_t reg_item, int32_t reg_user,
                                   const float* vals, int32_t ldv, const int32_t* rows, int32_t cap, int32_t G,
                                   uint64_t* slots64, uint32_t* stamp, int32_t marked, float gscale, const float* step_dev,

@@ -134,6 +134,39 @@ __global__ __launch_bounds__(256) void k_shard_gather_static(GatherStaticArgs a)
   for (int c4 = l16; c4 < a.W / 4; c4 += 16) *(f32x4*)(dst + 4 * c4) = *(const f32x4*)(src + 4 * c4);
 }
 
+// bf16 rows on the wire (ShardedModel(wire_dtype="bf16")): the owners keep fp32 rows (the weights that are updated);
+// what travels to the ranks that use a row, and what their kernels gather from, is
+//   [ d_emb embedding values as bf16, round to nearest even | the row's fp32 tail | pad ]   (pitch bytes per slot)
+// where the tail is item_b for item rows (column d_emb of the fused row) and the Ls position weights for user rows
+// (columns d_emb .. d_emb + Ls): tlsan_params then points its bf16 tables and its fp32 item_b / usert_emb into the
+// same slots with byte-derived strides.  The gradients travel back in fp32 as before.
+struct GatherWireArgs {
+  GatherStaticArgs g;
+  int32_t d_emb, tail;      // embedding width (floats of the fused row that become bf16), fp32 tail floats copied after them
+  int32_t pitch;            // bytes per slot of rows_out (multiple of 16)
+};
+__global__ __launch_bounds__(256) void k_shard_gather_wire_bf16(GatherWireArgs w) {
+  const GatherStaticArgs& a = w.g;
+  const int e = blockIdx.x * 16 + (threadIdx.x >> 4), l16 = threadIdx.x & 15;
+  if (e >= a.G * a.cap) return;
+  const int s = e / a.cap, j = e - s * a.cap;
+  const int c = a.recvbuf[(size_t)s * (1 + a.cap)];
+  int r = j < c ? a.recvbuf[(size_t)s * (1 + a.cap) + 1 + j] : -1;
+  if (r < 0 || r >= a.R) r = -1;
+  if (l16 == 0) {
+    a.recv_rows[e] = r;
+    if (r >= 0 && a.slots64) a.slots64[(size_t)r * a.G + s] = ((unsigned long long)*a.stamp_dev << 32) | (unsigned)(e + 1);
+  }
+  if (r < 0) return;
+  const float* src = a.shard + (size_t)r * a.ld;
+  char* dst = (char*)a.rows_out + (size_t)e * w.pitch;
+  for (int c4 = l16; c4 < w.d_emb / 4; c4 += 16) {
+    const s16x4 pk = mm_pack<TLSAN_MATRIX_BF16>(*(const f32x4*)(src + 4 * c4));   // v_cvt_pk_bf16_f32: round to nearest even
+    *(s16x4*)(dst + 8 * c4) = pk;
+  }
+  for (int t = l16; t < w.tail; t += 16) *(float*)(dst + 2 * w.d_emb + 4 * t) = src[w.d_emb + t];
+}
+
 // ------------------------------------------------------------------------------------------
 // After the all-reduce of flat = [dense grads | cate grads | loss | per-use squares | table squares]
 // (sums over the G ranks of per-rank MEANS over their own batches): global norm, clip coefficient,

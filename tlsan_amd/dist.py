@@ -260,10 +260,13 @@ def torch_scan(flags):
 class ShardedModel:
     """Model surface (train / eval_auc / ...) over row-sharded tables; see module docstring."""
 
-    def __init__(self, config, item_cate_list, device="cuda:0", seed=1234, group=None, l2_mode="dense", static_rows=False):
+    def __init__(self, config, item_cate_list, device="cuda:0", seed=1234, group=None, l2_mode="dense", static_rows=False,
+                 wire_dtype="f32"):
         """l2_mode: "dense" -- every owner decays every one of its rows every step, as the reference's dense L2
         gradient does; "lazy" (sgd) -- the same update kept as W = P * W_stored with one scale P that all ranks
         advance alike, so an owner touches only the rows whose gradients arrived (tlsan_shard_apply_lazy).
+          wire_dtype (static_rows only): "f32", or "bf16" -- rows cross the wire with bf16 embedding values (fp32 weights
+        stay with their owners; see below).
           static_rows (lazy only): False -- exchange sizes follow the batch (the host reads them once per step);
         True or an int -- every (source, owner) pair exchanges a FIXED number of row slots (the int, or 1.5 x what
         the first batch needs, agreed over the ranks), no size reaches the host, and a step can be recorded in a HIP
@@ -273,6 +276,15 @@ class ShardedModel:
         self.lazy = l2_mode == "lazy"
         if static_rows and not self.lazy:
             raise NotImplementedError("static_rows is the lazy-L2 step's form (l2_mode='lazy')")
+        if wire_dtype not in ("f32", "bf16"):
+            raise ValueError("wire_dtype must be 'f32' or 'bf16'")
+        if wire_dtype == "bf16" and not static_rows:
+            raise NotImplementedError("wire_dtype='bf16' is built for the static-shape step (static_rows)")
+        # wire_dtype="bf16": the owners keep (and update) fp32 rows; the copies that travel to the ranks using them, and
+        # that the kernels gather from, carry the embedding values as bf16 (round to nearest even) -- 176 instead of 304
+        # bytes per row at d = 128, Ls = 10.  The category table (replicated) is read through a bf16 shadow refreshed
+        # every step.  Gradients travel back in fp32.
+        self.wire_dtype = wire_dtype
         self.static_rows = static_rows
         self._st = None            # static-shape buffers (made at the first training batch)
         if not dist.is_initialized():
@@ -766,6 +778,15 @@ class ShardedModel:
         st["dims"] = dims
         if self._ws is None or self._ws.numel() < nws:
             self._ws = torch.empty(int(nws), dtype=torch.uint8, device=dev)
+        wire = self.wire_dtype == "bf16"
+        di = self.di
+        tail = max(1, self.Ls)                              # fp32 floats after the embedding: item_b / the position weights
+        pitch = (2 * di + 4 * tail + 15) // 16 * 16 if wire else 4 * W      # bytes per slot of the compact table
+        st.update(wire=wire, pitch=pitch, tail=tail)
+        if wire:
+            if di % 4:
+                raise NotImplementedError("wire_dtype='bf16': embedding widths must be multiples of 4")
+            st["cate_bf16"] = torch.zeros(self.C, self.dc, dtype=torch.bfloat16, device=dev)
         for k in range(_STATIC_SLOTS):
             sl = dict(k=k, rank=torch.empty(r.nkeys, dtype=torch.int32, device=dev),
                       uniq=torch.empty(r.nkeys, dtype=torch.int32, device=dev),
@@ -774,8 +795,8 @@ class ShardedModel:
                       recvbuf=torch.zeros(G, 1 + cap, dtype=torch.int32, device=dev) if G > 1 else None,
                       cate_c=torch.full((n,), -1, dtype=torch.int32, device=dev),
                       comp=torch.zeros(kcap, dtype=torch.int32, device=dev),
-                      rows=torch.zeros(n, W, dtype=torch.float32, device=dev),
-                      table=torch.zeros(n, W, dtype=torch.float32, device=dev) if G > 1 else None,
+                      rows=torch.zeros(n, pitch, dtype=torch.uint8, device=dev),
+                      table=torch.zeros(n, pitch, dtype=torch.uint8, device=dev) if G > 1 else None,
                       recv_rows=torch.full((n,), -1, dtype=torch.int32, device=dev),
                       state=torch.zeros(int(nst), dtype=torch.uint8, device=dev), db=None, views={},
                       done=(torch.cuda.Event(), torch.cuda.Event()), pending=False, fresh=False)
@@ -807,9 +828,15 @@ class ShardedModel:
         cb = L.Batch(B, Sn, p_u, p_i, p_j, ptr(db.y), p_hist, p_new, ptr(db.hist_t), ptr(db.sl), ptr(db.sl_new), ptr(db.u_cate))
         table = sl["rows"] if self.world == 1 else sl["table"]
         base = table.data_ptr()
-        cp = L.Params(base, base + 4 * self.di, base, base + 4 * self.di, self.cate_emb.data_ptr(),
-                      self.dense.data_ptr(), self.dense_KT.data_ptr(), sl["cate_c"].data_ptr(),
-                      self.W, self.W, self.W, self.W, self._P.data_ptr())
+        if st["wire"]:      # bf16 embedding values + fp32 tail in one slot: strides in elements of each pointer's type
+            pitch = st["pitch"]
+            cp = L.Params(base, base + 2 * self.di, base, base + 2 * self.di, st["cate_bf16"].data_ptr(),
+                          self.dense.data_ptr(), self.dense_KT.data_ptr(), sl["cate_c"].data_ptr(),
+                          pitch // 2, pitch // 4, pitch // 2, pitch // 4, self._P.data_ptr(), L.TABLE_BF16)
+        else:
+            cp = L.Params(base, base + 4 * self.di, base, base + 4 * self.di, self.cate_emb.data_ptr(),
+                          self.dense.data_ptr(), self.dense_KT.data_ptr(), sl["cate_c"].data_ptr(),
+                          self.W, self.W, self.W, self.W, self._P.data_ptr())
         out = (cp, cb)
         sl["views"][id(db)] = (db, out)
         return out
@@ -895,11 +922,18 @@ class ShardedModel:
         cp, cb = self._static_views(sl, db)
         dims, n = st["dims"], st["n"]
         sp = C.c_void_p(main.cuda_stream)
-        L.check(self.lib.tlsan_shard_gather_static(self.shard.data_ptr(), W, self.router.R, W,
-                                                   (sl["recvbuf"] if G > 1 else sl["sendbuf"]).data_ptr(), st["cap"], G,
-                                                   sl["rows"].data_ptr(), sl["recv_rows"].data_ptr(),
-                                                   self._slots64.data_ptr(), st["stamp"].data_ptr(), sp),
-                "tlsan_shard_gather_static")
+        rb = (sl["recvbuf"] if G > 1 else sl["sendbuf"]).data_ptr()
+        if st["wire"]:
+            st["cate_bf16"].copy_(self.cate_emb)      # (round to nearest even; the table is small and replicated)
+            L.check(self.lib.tlsan_shard_gather_wire_bf16(self.shard.data_ptr(), W, self.router.R, di, st["tail"], rb, st["cap"], G,
+                                                          sl["rows"].data_ptr(), st["pitch"], sl["recv_rows"].data_ptr(),
+                                                          self._slots64.data_ptr(), st["stamp"].data_ptr(), sp),
+                    "tlsan_shard_gather_wire_bf16")
+        else:
+            L.check(self.lib.tlsan_shard_gather_static(self.shard.data_ptr(), W, self.router.R, W, rb, st["cap"], G,
+                                                       sl["rows"].data_ptr(), sl["recv_rows"].data_ptr(),
+                                                       self._slots64.data_ptr(), st["stamp"].data_ptr(), sp),
+                    "tlsan_shard_gather_static")
         if G > 1:
             a2a(sl["table"].view(-1), sl["rows"].view(-1), None, None, self.group)
         n_dense, n_cate = self.lay.n_dense, Cc * self.dc

@@ -47,6 +47,8 @@ def parse(argv=None):
     ap.add_argument("--quiet", action="store_true")
     ap.add_argument("--table_dtype", default="f32", choices=["f32", "bf16"],
                     help="storage of item/user/category tables (bf16: fp32 arithmetic, stochastic rounding on update)")
+    ap.add_argument("--wire_dtype", default="f32", choices=["f32", "bf16"],
+                    help="sharded driver with --static_rows: embedding values of the rows that cross the wire (owners keep fp32)")
     ap.add_argument("--static_rows", type=int, default=0,
                     help="sharded driver, lazy L2: 0 = exchange sizes follow the batch (read by the host once a step); "
                          "1 = fixed-size exchanges sized from the first batch (x1.5); N > 1 = N row slots per rank pair. "
@@ -314,7 +316,7 @@ def train_sharded(args):
     if args.static_rows and l2_mode != "lazy":
         raise NotImplementedError("--static_rows is the lazy-L2 SGD step's form (--l2_mode lazy --optimizer sgd)")
     model = ShardedModel(config, icl, device=args.device, seed=args.seed, l2_mode=l2_mode,
-                         static_rows=(True if args.static_rows == 1 else args.static_rows))
+                         static_rows=(True if args.static_rows == 1 else args.static_rows), wire_dtype=args.wire_dtype)
     if resume is not None:                                                          # train.py:71-76
         say("Reloading model parameters..", flush=True)
         model.restore(None, resume)
