@@ -151,6 +151,29 @@ def _c4_worker(rank, world, port, ret):
         assert l1 == l2
         for k in p1:
             assert np.array_equal(p1[k], p2[k]), k                  # bitwise reproducible across runs
+
+        # the configuration as BASELINE.json names it: static-shape exchanges with bf16 rows on the wire (fp32 weights at
+        # the owners) -- reproducible bit for bit, and close to the fp32 exchange (the forward sees bf16-rounded tables)
+        def run_wire():
+            m = ShardedModel(cfg, icl, device="cuda:0", l2_mode="lazy", static_rows=True, wire_dtype="bf16")
+            dbs = [m.device_batch(per[rank]) for per in per_step]
+            losses = []
+            for s, db in enumerate(dbs):
+                m.train_async(db, 1.0, next_batch=dbs[s + 1] if s + 1 < len(dbs) else None)
+                losses.append(float(m.last_loss.item()))
+            m.check_static_overflow()
+            return losses, m.gather_params()
+        lw1, pw1 = run_wire()
+        lw2, pw2 = run_wire()
+        assert lw1 == lw2
+        for k in pw1:
+            assert np.array_equal(pw1[k], pw2[k]), k
+        assert np.allclose(lw1, l1, rtol=2e-3), (lw1, l1)
+        p00 = Model.init_params(cfg, 1234)
+        for k in pw1:
+            du = np.asarray(pw1[k], np.float64) - np.asarray(p00[k], np.float64).reshape(np.shape(pw1[k]))
+            dr = np.asarray(p1[k], np.float64) - np.asarray(p00[k], np.float64).reshape(np.shape(p1[k]))
+            assert np.abs(du - dr).max() < 0.15 * (np.abs(dr).max() + 1e-12) + 1e-6, (k, float(np.abs(du - dr).max()), float(np.abs(dr).max()))   # (sanity; the semantics are pinned by test_bf16_rows_on_the_wire)
         if rank == 0:
             # the same two global batches (2048 sequences) through the single-GPU model
             def cat2(per):
