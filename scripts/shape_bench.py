@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Train-step time at other shapes of BASELINE.json's configs (single GPU, resident batches):
-python scripts/shape_bench.py d=256 Ls=10 B=4096 [U=.. I=.. C=..] [sess=amazon]"""
+python scripts/shape_bench.py d=256 Ls=10 B=4096 [U=.. I=.. C=..] [sess=amazon] [td=bf16] [mm=bf16]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,7 +11,7 @@ d, Ls, B = int(kw.get("d", 256)), int(kw.get("Ls", 10)), int(kw.get("B", 4096))
 cfg = synth.make_config("electronics", Ls=Ls, hidden_units=d, itemid_embedding_size=d // 2, userid_embedding_size=d // 2,
                         cateid_embedding_size=d // 2, user_count=int(kw.get("U", 39991)), item_count=int(kw.get("I", 22048)),
                         cate_count=int(kw.get("C", 673)))
-m = Model(cfg, synth.item_cate_list(cfg), l2_mode="lazy")
+m = Model(cfg, synth.item_cate_list(cfg), l2_mode="lazy", table_dtype=kw.get("td", "f32"), matrix_dtype=kw.get("mm", "f32"))
 dbs = [m.device_batch(b) for b in synth.make_batches(cfg, 4, B, seed=1234, sessions=kw.get("sess", "geometric"))]
 for s in range(10):
     m.train_async(dbs[s % 4], 1.0, next_batch=dbs[(s + 1) % 4])
@@ -22,4 +22,4 @@ for s in range(10, 10 + N):
     m.train_async(dbs[s % 4], 1.0, next_batch=dbs[(s + 1) % 4])
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / N
-print("d=%d Ls=%d B=%d%s: %.1f us/step, %.2f M seq/s, loss %.4f" % (d, Ls, B, " sess=" + kw["sess"] if "sess" in kw else "", dt * 1e6, B / dt / 1e6, float(m._out[0].item())))
+print("d=%d Ls=%d B=%d%s: %.1f us/step, %.2f M seq/s, loss %.4f" % (d, Ls, B, "".join(" %s=%s" % (k, kw[k]) for k in ("sess", "td", "mm") if k in kw), dt * 1e6, B / dt / 1e6, float(m._out[0].item())))

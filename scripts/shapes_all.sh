@@ -21,4 +21,9 @@ d=256 Ls=10 B=4096 sess=amazon
 d=256 Ls=90 B=4096
 d=128 Ls=10 B=4096 U=10000000 I=5000000 C=10000
 d=256 Ls=90 B=4096 U=10000000 I=5000000 C=10000
+d=128 Ls=10 B=4096 td=bf16 mm=bf16
+d=128 Ls=90 B=4096 U=35896 I=28589 C=15 td=bf16 mm=bf16
+d=256 Ls=10 B=4096 td=bf16 mm=bf16
+d=256 Ls=90 B=4096 td=bf16 mm=bf16
+d=256 Ls=90 B=4096 U=10000000 I=5000000 C=10000 td=bf16 mm=bf16
 SHAPES

@@ -27,14 +27,10 @@ static hipError_t launch_variant_dt(const FwdArgs& a, int grid, hipStream_t st) 
 // bf16 table storage: window in registers or streamed; bf16 matrix products: window in registers only
 template <int D, int DH, bool TRAIN, bool LSTREAM>
 static hipError_t launch_variant(const FwdArgs& a, int grid, hipStream_t st) {
-  if (a.p.matrix_dtype == TLSAN_MATRIX_BF16) {  // bf16 matrix products: window in registers, either table storage, no dropout
+  if (a.p.matrix_dtype == TLSAN_MATRIX_BF16) {  // bf16 matrix products: either window form, either table storage, no dropout
     if (a.drop_thr != 0) return hipErrorNotSupported;
-    if constexpr (!LSTREAM) {
-      if (a.p.table_dtype == TLSAN_TABLE_BF16) return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_BF16, false, TLSAN_MATRIX_BF16>(a, grid, st);
-      return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_F32, false, TLSAN_MATRIX_BF16>(a, grid, st);
-    } else {
-      return hipErrorNotSupported;
-    }
+    if (a.p.table_dtype == TLSAN_TABLE_BF16) return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_BF16, false, TLSAN_MATRIX_BF16>(a, grid, st);
+    return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_F32, false, TLSAN_MATRIX_BF16>(a, grid, st);
   }
   if (a.p.table_dtype == TLSAN_TABLE_BF16) {
     if (a.drop_thr != 0) return hipErrorNotSupported;
