@@ -50,8 +50,8 @@ def parse():
                     help="single GPU, fp32 run: also time the same steps with bf16 tables (BASELINE.json configs[2] names "
                          "bf16 storage) and report them under 'bf16_tables'")
     ap.add_argument("--graph", type=int, default=0, help="replay hipGraph-captured steps instead of eager launches (single-GPU path)")
-    ap.add_argument("--prefetch", type=int, default=1,
-                    help="eager mode: build the next batch's destination index on a second stream during the step")
+    ap.add_argument("--prefetch", type=int, default=2,
+                    help="eager mode: build the destination index of the next batch(es) on a second stream: 1 = one step ahead, 2 = two")
     ap.add_argument("--event-every", type=int, default=8,
                     help="every Nth timed step carries the HIP events that bracket k_fwd_bwd (graph mode: runs eagerly)")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded (multi-GPU) code path even at N=1")
@@ -244,6 +244,7 @@ def main():
     lib = L.load()
 
     use_graph = bool(args.graph) and not sharded
+    lib_fused = cfg["hidden_units"] <= 128      # (Geo::FUSE_DK: the dK product rides in k_fwd_bwd, no k_dk_partial launch)
     graphs = [model.capture_step(db, lr) for db in dbs] if use_graph else None
 
     def run(n, first, timed=False):
@@ -257,10 +258,13 @@ def main():
             elif sharded and model.static_rows:
                 # the next two batches are known (as in any input pipeline): their routing plans are built beside this step
                 stepper.train_async(dbs[k], lr, next_batch=dbs[(k + 1) % len(dbs)], after_next=dbs[(k + 2) % len(dbs)])
-            elif sharded or args.prefetch:
-                # the next batch is known: its routing plan (sharded) / destination index (single GPU) is queued
-                # while this step computes
+            elif sharded:
                 stepper.train_async(dbs[k], lr, next_batch=dbs[(k + 1) % len(dbs)])
+            elif args.prefetch:
+                # the next two batches are known (as in any input pipeline): their destination indices are built on a
+                # second stream, two steps ahead (--prefetch 1: one step ahead)
+                stepper.train_async(dbs[k], lr, next_batch=dbs[(k + 1) % len(dbs)],
+                                    after_next=dbs[(k + 2) % len(dbs)] if args.prefetch >= 2 else None)
             else:
                 stepper.train_async(dbs[k], lr)
 
@@ -299,14 +303,14 @@ def main():
         def variant(table_dtype, matrix_dtype, what):
             mv = Model(cfg, icl, device=dev, l2_mode=args.l2_mode, table_dtype=table_dtype, matrix_dtype=matrix_dtype)
             for s in range(args.warmup):
-                mv.train_async(dbs[s % len(dbs)], lr, next_batch=dbs[(s + 1) % len(dbs)])
+                mv.train_async(dbs[s % len(dbs)], lr, next_batch=dbs[(s + 1) % len(dbs)], after_next=dbs[(s + 2) % len(dbs)])
             torch.cuda.synchronize()
             lib.tlsan_profile_stride(args.event_every)
             lib.tlsan_profile_enable(args.profile_level)
             t1 = time.perf_counter()
             for s in range(args.steps):
                 k = (args.warmup + s) % len(dbs)
-                mv.train_async(dbs[k], lr, next_batch=dbs[(k + 1) % len(dbs)])
+                mv.train_async(dbs[k], lr, next_batch=dbs[(k + 1) % len(dbs)], after_next=dbs[(k + 2) % len(dbs)])
             torch.cuda.synchronize()
             dtv = time.perf_counter() - t1
             pb = (ctypes.c_float * (nprof * 5))()
@@ -392,8 +396,9 @@ def main():
                               "frac": None if not nrec else round(k_flops / (k_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
                               "algorithmic_flops_per_launch": round(k_flops)},
             "launch": ("hipGraph replay (1 graph/step; every %dth step eager for the HIP-event kernel timing)" % args.event_every)
-                      if use_graph else ("eager, 4 launches/step on the main stream + the next batch's index (2 launches) "
-                                         "on a second stream" if (args.prefetch and not sharded) else "eager"),
+                      if use_graph else ("eager, %d launches/step on the main stream + the destination index (2 launches) of the "
+                                         "batch %s on a second stream" % (3 if lib_fused else 4, "after next" if args.prefetch >= 2 else "next")
+                                         if (args.prefetch and not sharded) else "eager"),
             "static_overflow_checked": True if (sharded and model.static_rows) else None,
             "final_loss": round(loss, 6),
         }

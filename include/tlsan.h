@@ -128,7 +128,7 @@ typedef struct {
   int32_t norm_mode;  /* TLSAN_NORM_*: how clip_by_global_norm's norm treats repeated ids */
   int32_t l2_mode;    /* TLSAN_L2_*                                                       */
   /* The destination index of a batch (use counts, segment offsets, used-row records) depends only on
-   * the batch's ids.  The state holds two index slots: index_slot picks the one this
+   * the batch's ids.  The state holds three index slots (0..2): index_slot picks the one this
    * step uses; index_prebuilt != 0 says tlsan_batch_index already built it (e.g. on a second stream
    * while the previous step ran), otherwise the step builds it itself.  Defaults 0, 0. */
   int32_t index_slot;

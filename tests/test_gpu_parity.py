@@ -444,23 +444,25 @@ def test_bf16_tables_with_streamed_windows(d, Ls, Sn, B):
 
 
 def test_prefetched_index_equals_inline():
-    """train_async(next_batch=...) builds the next batch's destination index on a second stream
-    (tlsan_batch_index) while the step runs; the result must be bitwise the same as building it
-    inside the step, for batches of different shapes."""
+    """train_async(next_batch=..., after_next=...) builds the destination index of the next batch(es) on a second
+    stream (tlsan_batch_index) one or two steps ahead; the result must be bitwise the same as building it inside the
+    step, for batches of different shapes."""
     cfg = make_config(U=60, I=80, C=9, d=128, regulation_rate=1e-3)
     p = _p32(random_params(cfg, seed=31))
     _, cat = random_batch(cfg, B=8, Sn=2, seed=0)
     batches = [_tuple(random_batch(cfg, B=40 + 7 * (s % 3), Sn=1 + s % 4, seed=300 + s)[0]) for s in range(7)]
     runs = []
-    for prefetch in (False, True):
+    for prefetch in (0, 1, 2, 3):     # none / one step ahead / two steps ahead / two ahead, announced irregularly
         m = _model(cfg, cat, p, l2_mode="lazy")
         dbs = [m.device_batch(b) for b in batches]
         for s, db in enumerate(dbs):
             nxt = dbs[s + 1] if (prefetch and s + 1 < len(dbs)) else None
-            m.train_async(db, 0.6, next_batch=nxt)
+            nn = dbs[s + 2] if (prefetch >= 2 and s + 2 < len(dbs) and (prefetch == 2 or s % 2 == 0)) else None
+            m.train_async(db, 0.6, next_batch=nxt, after_next=nn)
         runs.append(m.get_params())
-    for k in runs[0]:
-        assert np.array_equal(runs[0][k], runs[1][k]), k
+    for r in runs[1:]:
+        for k in runs[0]:
+            assert np.array_equal(runs[0][k], r[k]), k
     # announcing a batch and then training another one is an error (its uses are already counted)
     m = _model(cfg, cat, p, l2_mode="lazy")
     dbs = [m.device_batch(b) for b in batches[:3]]

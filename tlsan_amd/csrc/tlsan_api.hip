@@ -148,17 +148,17 @@ static inline bool uc_by_list(const tlsan_dims* d, const tlsan_batch* b) {
 struct St {  // persistent state
   // two index slots (a batch's destination index depends only on its ids, so it lives with the
   // state, not in the per-call workspace whose layout follows the batch shape):
-  int32_t *cnt_item[2], *cnt_uc[2], *cnt_user[2];         // use counters, zero at rest
-  int32_t *off_item[2], *off_uc[2], *off_user[2];         // segment offsets (n+1 entries)
-  int32_t *cur_item[2], *cur_uc[2], *cur_user[2];         // fill cursors
-  int4 *urec_item[2], *urec_user[2];                      // (row, first position, uses) of the used rows
+  int32_t *cnt_item[TLSAN_INDEX_SLOTS], *cnt_uc[TLSAN_INDEX_SLOTS], *cnt_user[TLSAN_INDEX_SLOTS];   // use counters, zero at rest
+  int32_t *off_item[TLSAN_INDEX_SLOTS], *off_uc[TLSAN_INDEX_SLOTS], *off_user[TLSAN_INDEX_SLOTS];   // segment offsets (n+1 entries)
+  int32_t *cur_item[TLSAN_INDEX_SLOTS], *cur_uc[TLSAN_INDEX_SLOTS], *cur_user[TLSAN_INDEX_SLOTS];   // fill cursors
+  int4 *urec_item[TLSAN_INDEX_SLOTS], *urec_user[TLSAN_INDEX_SLOTS];   // (row, first position, uses) of the used rows
   int32_t *cate_off, *cate_cnt, *cate_cur, *cate_items;   // static CSR category -> items
   StateHdr* hdr;
   double *S_part, *S_total;
-  long long* scan_bsum[2];                                // per-chunk sums of the index scan (large tables), per slot
-  int32_t* uc_list[2];                                    // samples of every category (u_cate uses), UC_LIST_CAP each
+  long long* scan_bsum[TLSAN_INDEX_SLOTS];                                // per-chunk sums of the index scan (large tables), per slot
+  int32_t* uc_list[TLSAN_INDEX_SLOTS];                                    // samples of every category (u_cate uses), UC_LIST_CAP each
   double* Rc64;                                           // category sums of a split PRESUM pass, zero at rest
-  int32_t* hot_list[2];                                   // slots (urec_item) of the hot item rows, AP_HOT_CAP each
+  int32_t* hot_list[TLSAN_INDEX_SLOTS];                                   // slots (urec_item) of the hot item rows, AP_HOT_CAP each
   size_t bytes;
   int nbI, nbU, nbC;
 };
@@ -170,7 +170,7 @@ static void carve_state(const tlsan_dims* d, char* base, St* s) {
   s->nbU = (d->user_count + AP_ROWS_PB - 1) / AP_ROWS_PB;
   s->nbC = d->cate_count;
   s->hdr = (StateHdr*)take(sizeof(StateHdr));  // must stay first: tlsan_state_scale(state) == state
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < TLSAN_INDEX_SLOTS; ++k) {
     s->cnt_item[k] = (int32_t*)take(4 * (size_t)d->item_count);
     s->cnt_uc[k] = (int32_t*)take(4 * (size_t)d->cate_count);
     s->cnt_user[k] = (int32_t*)take(4 * (size_t)d->user_count);
@@ -188,10 +188,10 @@ static void carve_state(const tlsan_dims* d, char* base, St* s) {
   s->cate_cur = (int32_t*)take(4 * (size_t)d->cate_count);
   s->cate_items = (int32_t*)take(4 * (size_t)d->item_count);
   s->S_part = (double*)take(8 * (size_t)(s->nbI + s->nbU + s->nbC));
-  for (int k = 0; k < 2; ++k) s->uc_list[k] = (int32_t*)take(4 * (size_t)UC_LIST_CAP);
+  for (int k = 0; k < TLSAN_INDEX_SLOTS; ++k) s->uc_list[k] = (int32_t*)take(4 * (size_t)UC_LIST_CAP);
   s->Rc64 = (double*)take(8 * (size_t)d->cate_count * d->d_cate);
-  for (int k = 0; k < 2; ++k) s->hot_list[k] = (int32_t*)take(4 * (size_t)AP_HOT_CAP);
-  for (int k = 0; k < 2; ++k)
+  for (int k = 0; k < TLSAN_INDEX_SLOTS; ++k) s->hot_list[k] = (int32_t*)take(4 * (size_t)AP_HOT_CAP);
+  for (int k = 0; k < TLSAN_INDEX_SLOTS; ++k)
     s->scan_bsum[k] = (long long*)take(8 * ((size_t)(d->item_count + 4095) / 4096 + (d->cate_count + 4095) / 4096 +
                                             (d->user_count + 4095) / 4096));
   s->S_total = base ? &s->hdr->St : nullptr;
@@ -691,7 +691,7 @@ static int prep_step(const tlsan_dims* d, Shape* s, const tlsan_params* p, const
   if ((rc = check_batch(d, b, true))) return rc;
   if (!hp) return fail(TLSAN_E_BADARG, "hparams is NULL");
   if (hp->l2_mode != TLSAN_L2_DENSE && hp->l2_mode != TLSAN_L2_LAZY) return fail(TLSAN_E_BADARG, "l2_mode");
-  if (hp->index_slot < 0 || hp->index_slot > 1) return fail(TLSAN_E_BADARG, "index_slot must be 0 or 1");
+  if (hp->index_slot < 0 || hp->index_slot >= TLSAN_INDEX_SLOTS) return fail(TLSAN_E_BADARG, "index_slot must be 0 .. %d", TLSAN_INDEX_SLOTS - 1);
   if (hp->l2_mode == TLSAN_L2_LAZY) {
     if (hp->norm_mode != TLSAN_NORM_TF18) return fail(TLSAN_E_UNSUPPORTED, "TLSAN_L2_LAZY supports norm_mode TF18 only");
     if (p->scale != tlsan_state_scale(state)) return fail(TLSAN_E_BADARG, "TLSAN_L2_LAZY needs params->scale == tlsan_state_scale(state)");
@@ -741,7 +741,7 @@ int tlsan_batch_index(const tlsan_dims* d, const tlsan_batch* b, void* state, in
   int rc = shape_of(d, &s);
   if (rc) return rc;
   if ((rc = check_batch(d, b, true))) return rc;
-  if (slot < 0 || slot > 1) return fail(TLSAN_E_BADARG, "index slot must be 0 or 1");
+  if (slot < 0 || slot >= TLSAN_INDEX_SLOTS) return fail(TLSAN_E_BADARG, "index slot must be 0 .. %d", TLSAN_INDEX_SLOTS - 1);
   if (!state) return fail(TLSAN_E_WORKSPACE, "state is NULL");
   carve_state(d, (char*)state, &st);
   return build_index(d, b, st, slot, (hipStream_t)stream);

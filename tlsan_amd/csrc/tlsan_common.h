@@ -138,12 +138,15 @@ struct Geo {
   // product over its own 16 samples right after the dlong GEMM, while both operands sit in the LDS, and leaves one
   // D x D partial per workgroup for k_dense_finalize -- no k_dk_partial launch, no [B, D] round trip through HBM.
   // (D = 256: the partials would be 256 KB per workgroup; the separate kernel stays.)
-  // MEASURED AND LEFT OFF (round 2, gpurun_out/r02_ab8.txt): the k_dk_partial launch (8.3 us) goes away, but k_fwd_bwd
-  // grows by 2.4 us (six spilled registers at D = 128), k_dense_finalize reads 256 partials instead of 64 (+2.5 us on the
-  // launch it shares with the row sums), and the step does not get shorter (72.1-73.6 vs 71.0-71.8 us): the tail of
-  // the step overlaps the next batch's index build on the second stream either way.
+  // Costs and gains (round 2): the k_dk_partial launch (7.2 us + a gap) goes away, k_fwd_bwd grows by ~1.3 us (six
+  // spilled registers at D = 128), k_dense_finalize reads 256 partials instead of 64.  With the next batch's index
+  // built ONE step ahead this bought nothing (72.1-73.6 vs 71.0-71.8 us): the step was then bounded by a second path
+  // of the same length -- k_fwd_bwd -> index build on the side stream (it cannot run beside that kernel) -> host
+  // wake-up -> launch of the next step -- so a shorter tail only made the GPU wait for the host.  With the index built
+  // TWO steps ahead (Model.train_async(after_next=)) that path is gone and the main stream's chain is the step:
+  // 70.0 us without the fusion, 66.7 us with it (profiles/r02_ab/r02_ab_fuse2.txt).
 #ifndef TLSAN_EXP_FUSE_DK
-#define TLSAN_EXP_FUSE_DK 0
+#define TLSAN_EXP_FUSE_DK 1
 #endif
   static constexpr bool FUSE_DK = TLSAN_EXP_FUSE_DK != 0 && D_ <= 128;
 #ifndef TLSAN_EXP_TSTR

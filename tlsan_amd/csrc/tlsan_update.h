@@ -11,18 +11,20 @@
 #pragma once
 #include "tlsan_common.h"
 
+// index slots of the state: the batch being trained and up to two announced successors (tlsan_batch_index)
+#define TLSAN_INDEX_SLOTS 3
 // first bytes of the persistent state buffer
 struct StateHdr {
   // ---- read-mostly line
   float P;                 // scale of the four regularised tables: W_true = P * W_stored (1 unless lazy L2)
   float P_prev;            // P before the current step's commit: what k_apply scales with
-  int32_t n_uniq[2][2];    // [index slot][item, user]: rows that received a gradient (k_index_scan)
+  int32_t n_uniq[TLSAN_INDEX_SLOTS][2];    // [index slot][item, user]: rows that received a gradient (k_index_scan)
   double St;               // sum of squares of the four STORED tables (true value: P^2 * St)
   float coef;              // global-norm clip coefficient of the current step (model.py:201)
   uint32_t nstep;          // update steps taken (salt of the stochastic rounding of bf16 tables)
   int32_t spart_n;         // leading entries of S_part the last update may have written (the rest is zero)
-  int32_t n_hot[2];        // [index slot] item rows with more than AP_HOT uses (k_index_scan; listed in the state)
-  float pad0[19];
+  int32_t n_hot[TLSAN_INDEX_SLOTS];        // [index slot] item rows with more than AP_HOT uses (k_index_scan; listed in the state)
+  float pad0[16];
   // ---- its own 128-B line: hammered by atomics, must not share a line with anything that is read
   int32_t ticket;          // arrival counter of k_dense_finalize: the last workgroup writes the step summary
   int32_t pad1[31];

@@ -85,6 +85,9 @@ OPTIMIZERS = {"sgd": (L.OPT_SGD, 0.0, 0.0, 0.0), "adam": (L.OPT_ADAM, 0.9, 0.999
               "rmsprop": (L.OPT_RMSPROP, 0.9, 0.0, 1e-10), "adadelta": (L.OPT_ADADELTA, 0.95, 0.0, 1e-8)}
 
 
+_STREAM_CACHE = {}
+
+
 def concurrent_streams(device, want=1, pool=6, **stream_kw):
     """`want` new streams whose work can run WHILE the current stream is busy, and while each other is.
 
@@ -96,6 +99,12 @@ def concurrent_streams(device, want=1, pool=6, **stream_kw):
     launched after it on stream b -- b finishes early exactly when the two are on different queues."""
     dev = torch.device(device)
     main = torch.cuda.current_stream(dev)
+    # one set per (device, current stream) and process: every new stream is one more tenant of the four queues, and a
+    # process that builds several models (bench.py's variants) would end up with side streams sharing queues again
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), main.cuda_stream, tuple(sorted(stream_kw.items())))
+    have = _STREAM_CACHE.setdefault(key, [])
+    if len(have) >= want:       # (bench.py's third model, with streams of its own: 98-113 us/step instead of 57)
+        return have[:want]
     cands = [torch.cuda.Stream(dev, **stream_kw) for _ in range(max(pool, want))]
     x = torch.zeros(64, device=dev)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
@@ -131,6 +140,7 @@ def concurrent_streams(device, want=1, pool=6, **stream_kw):
         if len(chosen) < want and c not in chosen:
             chosen.append(c)
     torch.cuda.synchronize(dev)
+    have[:] = chosen
     return chosen
 
 
@@ -276,8 +286,8 @@ class Model(object):
         self.renorm_every = 4096   # lazy L2: fold the table scale into the tables every so many steps (0 = never)
         # two destination-index slots: the current step's and the one being built for the next batch
         self._idx_slot = 0
-        self._idx_ready = [None, None]
-        self._idx_event = [torch.cuda.Event(), torch.cuda.Event()]
+        self._idx_ready = [None] * L.INDEX_SLOTS     # batch whose destination index sits (or is being built) in the slot
+        self._idx_event = [torch.cuda.Event() for _ in range(L.INDEX_SLOTS)]
         self._pre_event = torch.cuda.Event()
         self._side = None
         self._step = 0
@@ -463,10 +473,10 @@ class Model(object):
         # tlsan_state_init clears the whole state, both destination-index slots included: an index that was
         # prefetched for an announced successor (train_async(next_batch=)) is gone with it -- wait for the side
         # stream to be done with the slot, then forget the announcement (the next step builds its index inline)
-        for k in (0, 1):
+        for k in range(L.INDEX_SLOTS):
             if self._idx_ready[k] is not None:
                 self._idx_event[k].synchronize()
-        self._idx_ready = [None, None]
+        self._idx_ready = [None] * L.INDEX_SLOTS
         L.check(self.lib.tlsan_state_init(C.byref(self.dims), C.byref(self.cparams), self.state.data_ptr(),
                                           self._stream()), "tlsan_state_init")
 
@@ -503,14 +513,20 @@ class Model(object):
     def device_batch(self, batch, is_test=False):
         return batch if isinstance(batch, DeviceBatch) else DeviceBatch(batch, self.device, is_test, self.config["Ls"])
 
-    def train_async(self, batch, lr, logits=None, next_batch=None):
+    def train_async(self, batch, lr, logits=None, next_batch=None, after_next=None):
         """Enqueue one step (model.py:208-234) without reading the loss back.
 
         next_batch (optional, what an input pipeline knows anyway): its destination index (use
         counts, segment offsets -- a function of the ids only) is built on a second stream while
         this step computes, so the next step starts directly with the fused kernel.  The two
         streams are ordered by HOST waits on events that are complete by the time they are
-        needed (device-side event waits between queues cost more than the work they would hide)."""
+        needed (device-side event waits between queues cost more than the work they would hide).
+
+        after_next (optional): the batch after next_batch.  Its index is built TWO steps ahead.  With one batch ahead
+        the index of batch t+1 can only run once k_fwd_bwd of step t has left the GPU (that kernel fills every CU), and
+        step t+1 is launched when the host has seen it finish: kernel -> index (12 us) -> host wake-up -> launch is a
+        path as long as the step's own kernels, so shortening either alone changes nothing.  Two ahead, the index a
+        step waits for was finished during the previous step and the main stream never idles."""
         db = self.device_batch(batch)
         ws = self._workspace(db.B, db.Sn)
         out = L.StepOut(self._out.data_ptr(), self._out.data_ptr() + 4, None if logits is None else logits.data_ptr(), None)
@@ -540,29 +556,41 @@ class Model(object):
                 self._idx_event[k].synchronize()       # the side stream finished this batch's index
         self._idx_ready[k] = None
         main = torch.cuda.current_stream(self.device)
-        ndb = None
-        if next_batch is not None:
-            # everything queued so far -- the previous step (last user of the other index slot) and
-            # whatever produced the next batch's arrays -- must be done before the side stream reads them
-            ndb = self.device_batch(next_batch)
+        NS = L.INDEX_SLOTS
+        ahead = []      # (batch, slot) whose index is not there yet
+        for j, nb in enumerate((next_batch, after_next)):
+            if nb is None:
+                continue
+            kk = (k + 1 + j) % NS
+            ndb = self.device_batch(nb)
+            if self._idx_ready[kk] is ndb:
+                continue
+            if self._idx_ready[kk] is not None:
+                raise RuntimeError("train_async: the batches announced ahead must be trained in that order "
+                                   "(the destination index of another batch is already counted into the state)")
+            ahead.append((ndb, kk))
+        if ahead:
+            # everything queued so far -- the previous steps (last users of the free index slots) and whatever produced
+            # the announced batches' arrays -- must be done before the side stream reads them
             self._pre_event.record(main)
         hp = self.hparams(lr, k, 1 if pre else 0)
         self._train_call(db, hp, out, ws)
-        if ndb is not None:
+        if ahead:
             if self._side is None:
                 # (high priority: the index kernels are short and the NEXT step cannot start without them; left at
                 #  the default they trail behind the 2400 workgroups of the row-sum / update launches they share
-                #  the chip with -- k_fwd_bwd itself leaves them no registers to run beside it)
+                #  the GPU with -- measured: no difference either way)
                 self._side = concurrent_streams(self.device, 1, priority=int(os.environ.get("TLSAN_SIDE_PRIORITY", "-1")))[0]
             if dev_wait:
                 self._side.wait_event(self._pre_event)
             else:
                 self._pre_event.synchronize()
-            L.check(self.lib.tlsan_batch_index(C.byref(self.dims), C.byref(ndb.c), self.state.data_ptr(), 1 - k,
-                                               C.c_void_p(self._side.cuda_stream)), "tlsan_batch_index")
-            self._idx_event[1 - k].record(self._side)
-            self._idx_ready[1 - k] = ndb
-        self._idx_slot = 1 - k
+            for ndb, kk in ahead:
+                L.check(self.lib.tlsan_batch_index(C.byref(self.dims), C.byref(ndb.c), self.state.data_ptr(), kk,
+                                                   C.c_void_p(self._side.cuda_stream)), "tlsan_batch_index")
+                self._idx_event[kk].record(self._side)
+                self._idx_ready[kk] = ndb
+        self._idx_slot = (k + 1) % L.INDEX_SLOTS
         self._step += 1
         return db
 
@@ -634,9 +662,10 @@ class Model(object):
                         g["usert_emb"].data_ptr(), g["cate_emb"].data_ptr(), gd.data_ptr())
         out = L.StepOut(self._out.data_ptr(), self._out.data_ptr() + 4, logits.data_ptr(), self._out.data_ptr() + 8)
         # (an index slot at rest: the other one may hold the index prefetched for an announced next batch)
-        slot = self._idx_slot if self._idx_ready[self._idx_slot] is None else 1 - self._idx_slot
-        if self._idx_ready[slot] is not None:
-            raise RuntimeError("grads: both index slots are in use")
+        free = [k for k in range(L.INDEX_SLOTS) if self._idx_ready[k] is None]
+        if not free:
+            raise RuntimeError("grads: every index slot holds a prefetched index")
+        slot = free[0]
         hp = self.hparams(lr, slot, 0)
         L.check(self.lib.tlsan_grads(C.byref(self.dims), C.byref(self.cparams), C.byref(db.c), C.byref(hp),
                                      C.byref(go), C.byref(out), self.state.data_ptr(), ws.data_ptr(), ws.numel(),

@@ -146,20 +146,6 @@ def eval_prec_recall(model, test_set, config):
     return prec, recall
 
 
-def _lookahead(it):
-    """(item, next_item_or_None) pairs: the step is told its successor so the successor's
-    destination index can be built while it runs (Model.train_async(next_batch=))."""
-    it = iter(it)
-    try:
-        cur = next(it)
-    except StopIteration:
-        return
-    for nxt in it:
-        yield cur, nxt
-        cur = nxt
-    yield cur, None
-
-
 def train(args, data=None):
     """data (optional): (train PackedSet, test PackedSet, (U, I, C), item_cate_list) already in memory
     (tlsan_amd.build_dataset.build_packed) instead of --dataset."""
@@ -195,11 +181,12 @@ def train(args, data=None):
     done = False
     for _ in range(args.max_epochs):
         train_set.shuffle(rng)  # train.py:191
-        for batch, nxt in _lookahead(model.device_batch(b) for _, b in train_batches()):
+        for batch, nxt, nxt2 in _lookahead2(model.device_batch(b) for _, b in train_batches()):
             # the reference reads the loss back every step (model.py:229-234); the sum is all the driver
             # uses, so it is accumulated on the device and read at the evaluation points only
-            last = nxt is None or (args.max_steps and model.global_step.eval() + 1 >= args.max_steps)
-            model.train_async(batch, lr, next_batch=None if last else nxt)
+            left = (args.max_steps - model.global_step.eval() - 1) if args.max_steps else 2     # steps after this one
+            model.train_async(batch, lr, next_batch=nxt if (nxt is not None and left >= 1) else None,
+                              after_next=nxt2 if (nxt2 is not None and left >= 2) else None)
             loss_sum += model._out[0]
             step = model.global_step.eval()
             if args.display_freq and step % args.display_freq == 0:    # train.py:194-195 (add_summary)
