@@ -89,9 +89,12 @@ struct Ws {  // carve-up of the caller's scratch buffer
 static int ru4(int x) { return (x + 3) / 4 * 4; }
 // the dK product rides in k_fwd_bwd for D <= 128 (Geo::FUSE_DK); its launch then has at most this many workgroups
 // (each loops over its passes), so that the per-workgroup partials stay a few tens of MB at any batch size
-static bool fused_dk(int D) { return TLSAN_EXP_FUSE_DK != 0 && D <= 128; }
-#define FWD_TRAIN_GRID_MAX 1024
-static int fwd_train_grid(int ngroups) { return ngroups < FWD_TRAIN_GRID_MAX ? ngroups : FWD_TRAIN_GRID_MAX; }
+// ... when there is at most one partial per CU: more of them (d = 64 at 8192 sequences: 512) make the reduction in
+// k_dense_finalize the long pole of its launch (77 -> 91 us/step), and the separate k_dk_partial launch (<= 64 partials)
+// is the better deal again
+#define FUSED_DK_MAX_GROUPS 256
+static bool fused_dk(int D, int ngroups) { return TLSAN_EXP_FUSE_DK != 0 && D <= 128 && ngroups <= FUSED_DK_MAX_GROUPS; }
+static int fwd_train_grid(int ngroups) { return ngroups; }    // (fused: ngroups <= FUSED_DK_MAX_GROUPS, one pass per workgroup)
 
 static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base, Ws* w) {
   size_t o = 0;
@@ -103,7 +106,8 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
   w->ngroups = (B + 15) / 16;  // partial records: one per workgroup pass (16 samples with k_fwd_bwd2, NSB otherwise)
   // dK partials: one per batch split of k_dk_partial, or (fused into the forward/backward kernel, D <= 128) one per
   // workgroup of that launch
-  w->nsplit = fused_dk(s.D) ? fwd_train_grid((B + s.NSB - 1) / s.NSB) : dk_nsplit(B);
+  const int ngroups = (B + s.NSB - 1) / s.NSB;
+  w->nsplit = fused_dk(s.D, ngroups) ? fwd_train_grid(ngroups) : dk_nsplit(B);
   w->nbK = (s.D * s.D + 255) / 256;
   w->nbS = (L.n_dense - s.D * s.D + 15) / 16;
   w->nfin = w->nbK + w->nbS;
@@ -115,7 +119,14 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
   w->gLong = (float*)take(sizeof(float) * B * D);
   w->gDB = (float*)take(sizeof(float) * B * D);
   w->partials = (float*)take(sizeof(float) * w->ngroups * s.NPB);
-  w->Kp = (float*)take(sizeof(float) * w->nsplit * D * D);
+  // (sized so that the workspace of a batch also holds every smaller batch: the fused form of a smaller batch can
+  //  need more partials than the split form of a larger one)
+  int kp_slots = dk_nsplit(B);
+  if (TLSAN_EXP_FUSE_DK != 0 && s.D <= 128) {
+    const int fmax = ngroups < FUSED_DK_MAX_GROUPS ? ngroups : FUSED_DK_MAX_GROUPS;
+    if (fmax > kp_slots) kp_slots = fmax;
+  }
+  w->Kp = (float*)take(sizeof(float) * kp_slots * D * D);
   w->gd = (float*)take(sizeof(float) * L.n_dense);
   w->sqd = (float*)take(sizeof(float) * w->nfin);
   w->scal = (float*)take(sizeof(float) * 4);
@@ -514,7 +525,7 @@ int tlsan_state_recategorize(const tlsan_dims* d, const tlsan_params* p, void* s
 
 static int launch_fwd(const Shape& s, bool train, const FwdArgs& a, hipStream_t hs) {
   int grid = a.ngroups < 4096 ? a.ngroups : 4096;
-  if (train && fused_dk(s.D)) grid = fwd_train_grid(a.ngroups);
+  if (train && a.fuse_dk) grid = fwd_train_grid(a.ngroups);
   hipError_t e;
   const bool lstream = a.Ls > TLSAN_LS_MAX;  // long windows are streamed, short ones stay in registers
   if (s.D == 64) e = tlsan_launch_fwd_bwd_d64(train, lstream, a, grid, hs);
@@ -622,11 +633,12 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   }
   const int grp = s.NSB;  // samples per workgroup pass of the fused kernel (= per partial record)
   a.ngroups = (b->B + grp - 1) / grp;
+  a.fuse_dk = fused_dk(s.D, a.ngroups) ? 1 : 0;
   prof_mark(1, hs);
   if ((rc = launch_fwd(s, true, a, hs))) return rc;
   prof_mark(2, hs);
   // --- dense-parameter gradients (D <= 128: the dK partials were left by k_fwd_bwd, one per workgroup)
-  if (!fused_dk(s.D)) {
+  if (!a.fuse_dk) {
     const int spw = dk_spw(b->B), nq = (s.D / 64) * (s.D / 64);
     const dim3 grid(nq * w.nsplit), blk(DK_WAVES * 64);
 #define DK_LAUNCH(DD)                                                                                           \

@@ -405,7 +405,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   float* sA = smem;                   // [NSB][LSTR]  long -> dbridge
   float* sB = sA + NSB * LSTR;        // [NSB][LSTR]  bridge -> dlong
   float* sL = sB + NSB * LSTR;        // [NSB][LSTR]  long, kept for the fused dK product (TRAIN && FUSE_DK)
-  float* sS = sL + ((TRAIN && G::FUSE_DK) ? NSB * LSTR : 0);  // [NW][4] scalar staging
+  float* sS = sL + ((TRAIN && G::FUSE_DK && a.fuse_dk) ? NSB * LSTR : 0);  // [NW][4] scalar staging  (sL exists in launches that fuse: tlsan_attn_inst.h)
   float* sH = sS + NW * 4;            // [NSB][2*LS] hist_t and usert*hist_t of the pass
   float* sW = sH + NSB * 2 * LSC;     // [2][WB] attention weights (W1,b1,W2,b2) of both blocks
   int* sP = (int*)(sW + (USE_SW ? 2 * WB : 0));  // [NSB][PSTR] destination-sorted row of every use
@@ -746,8 +746,12 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
       *(f32x4*)(sA + srow * LSTR + chb[kb]) = long4[kb];
-      if constexpr (TRAIN && G::FUSE_DK) *(f32x4*)(sL + srow * LSTR + chb[kb]) = long4[kb];
-      else if (TRAIN && vs) *(f32x4*)(a.gLong + (size_t)bidx * D + chb[kb]) = long4[kb];
+      if constexpr (TRAIN && G::FUSE_DK) {
+        if (a.fuse_dk) *(f32x4*)(sL + srow * LSTR + chb[kb]) = long4[kb];
+        else if (vs) *(f32x4*)(a.gLong + (size_t)bidx * D + chb[kb]) = long4[kb];
+      } else if (TRAIN && vs) {
+        *(f32x4*)(a.gLong + (size_t)bidx * D + chb[kb]) = long4[kb];
+      }
     }
     // rows the short block needs that depend only on ids: issue now, consume after P2
     f32x4 uemb[NB], iemb[NB];
@@ -1135,7 +1139,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             for (int kb = 0; kb < NB; ++kb) {
               *(f32x4*)(sA + srow * LSTR + chb[kb]) = dx[kb];  // dbridge
               if (vs) {
-                if constexpr (!G::FUSE_DK) *(f32x4*)(a.gDB + (size_t)bidx * D + chb[kb]) = dx[kb];
+                if (!G::FUSE_DK || !a.fuse_dk) *(f32x4*)(a.gDB + (size_t)bidx * D + chb[kb]) = dx[kb];
                 dk0[kb] += dx[kb];
               }
             }
@@ -1199,6 +1203,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         for (int i = 0; i < 4; ++i) sB[(16 * rt + 4 * q + i) * LSTR + 16 * kt + r] = acc0[i];
       }
       if constexpr (G::FUSE_DK) {
+       if (a.fuse_dk) {
         // ---- dK partial of this pass: C[k][j] = sum over the 16 samples of long[s][k] * dbridge[s][j]
         // (A from sL, B from sA: both [sample][channel] rows in the LDS).  Samples are the K dimension: 4 k-steps of
         // 4 samples.  A wavefront owns half of a 64 x 64 quadrant: lane (q, r) reads channels 4r .. 4r+3 of sample
@@ -1239,6 +1244,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             if (!first) v += *(const f32x4*)dst;
             *(f32x4*)dst = v;
           }
+      }
       }
       TLSAN_STAMP(8);
       __syncthreads();
