@@ -294,6 +294,7 @@ def main():
     loss = float(model.last_loss.item()) if sharded else float(model._out[0].item())
     if sharded and model.static_rows:
         model.check_static_overflow()     # a batch that did not fit the fixed exchange voids the run: raise, print nothing
+    static_rows = bool(sharded and model.static_rows)
     also = also_mm = None
     if args.also_bf16 and not sharded and args.table_dtype == "f32" and not use_graph:
         # same batches, same step count with (a) the tables stored as bf16 -- the storage BASELINE.json configs[2] names --
@@ -301,6 +302,9 @@ def main():
         # bf16, fp32 products and sums; logits then agree with the fp32 oracle to ~1e-3 of their scale, not 1e-4).
         # Reported beside the fp32 headline, never instead of it.
         def variant(table_dtype, matrix_dtype, what):
+            import gc
+            gc.collect()                  # (the previous model's buffers and streams go before the next one is built)
+            torch.cuda.synchronize()
             mv = Model(cfg, icl, device=dev, l2_mode=args.l2_mode, table_dtype=table_dtype, matrix_dtype=matrix_dtype)
             for s in range(args.warmup):
                 mv.train_async(dbs[s % len(dbs)], lr, next_batch=dbs[(s + 1) % len(dbs)], after_next=dbs[(s + 2) % len(dbs)])
@@ -327,6 +331,9 @@ def main():
                                  "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": round(k_b),
                                  "kernel_ms": round(kms, 5)},
                     "final_loss": round(float(mv._out[0].item()), 6)}
+        # one model at a time: with the measured model still alive the variants' steps were occasionally 1.3-4x longer
+        # (same kernel times; 2 of 6 runs), without it never in 10
+        model = stepper = None
         also = variant("bf16", "f32", "item/user/category tables bf16, fp32 arithmetic, stochastic rounding on update")
         also_mm = variant("bf16", "bf16", "bf16 tables + bf16 matrix products (operands rounded to bf16, fp32 accumulate); "
                                           "parity: tests/test_gpu_parity.py::test_bf16_matrix_products")
@@ -379,7 +386,7 @@ def main():
                                       "lazy (reference's dense-L2 update as W = P*W_stored; only used rows touched)"),
                        "global_batch": B * world, "parallelism": "1 process/GPU, tables %s"
                        % ("on one GPU" if not sharded else "row-sharded (id %% N), RCCL all-to-all + one all-reduce" +
-                          (", static-shape exchanges, plans two batches ahead" if model.static_rows else "") +
+                          (", static-shape exchanges, plans two batches ahead" if static_rows else "") +
                           (", bf16 rows on the wire (fp32 weights at the owners)" if args.wire_dtype == "bf16" else ""))},
             "roofline": {"bound": "hbm", "kernel": "k_fwd_bwd", "achieved": None if achieved is None else round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -399,7 +406,7 @@ def main():
                       if use_graph else ("eager, %d launches/step on the main stream + the destination index (2 launches) of the "
                                          "batch %s on a second stream" % (3 if lib_fused else 4, "after next" if args.prefetch >= 2 else "next")
                                          if (args.prefetch and not sharded) else "eager"),
-            "static_overflow_checked": True if (sharded and model.static_rows) else None,
+            "static_overflow_checked": True if (sharded and static_rows) else None,
             "final_loss": round(loss, 6),
         }
         if also is not None:
