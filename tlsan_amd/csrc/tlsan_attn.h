@@ -411,6 +411,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   int* sP = (int*)(sW + (USE_SW ? 2 * WB : 0));  // [NSB][PSTR] destination-sorted row of every use
   float* sT = (float*)(sP + (TRAIN ? NSB * PSTR : 0));  // per-wave transpose scratch / staging
   constexpr bool KEEP_A = G::KEEP_A && TRAIN && !LSTREAM;
+  constexpr bool LPF = NB == 1;                 // streamed windows: the next position's row is prefetched
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int q = lane >> 4, r = lane & 15;
   const int s_loc = r / CPS, col = r % CPS;
@@ -629,19 +630,24 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           }
         }
         const int pend = min(base + NLc, pmax1);
+        // the row of position p + 1 is fetched while position p is processed (left to the top of its own iteration,
+        // every position waited out a full gather: most of a streamed window's time)
+        // (d = 256 has no registers for it: 567 -> 642 us at Ls = 90 with the prefetch, so it keeps the fetch in place;
+        //  d = 128: 268 -> 241 us)
+        f32x4 xn[NB];
+        float scxn = 0.0f, scen = 0.0f;
+        if constexpr (LPF) fetch_lrow(base, xn, scxn, scen);
         for (int p = base; p < pend; ++p) {
           f32x4 xv[NB], z[NB], m2[NB];
-          float scx, sce;
-          if constexpr (G::AT_USE && !LSTREAM) {  // weight fragments from LDS at the use
-            const int zz = opaque_zero(p);
-            if constexpr (G::AT_USE_T) {
-              load_frag_T<DH, NB, MM>(w1W1 + zz, q, r, FT1);
-              load_bias<DH, NB>(w1b1 + zz, q, b1);
-              load_frag_T<DH, NB, MM>(w1W2 + zz, q, r, FT2);
-              load_bias<DH, NB>(w1b2 + zz, q, b2);
-            }
+          float scx = scxn, sce = scen;
+          (void)sce;
+          if constexpr (LPF) {
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) xv[kb] = xn[kb];
+            if (p + 1 < pend) fetch_lrow(p + 1, xn, scxn, scen);
+          } else {
+            fetch_lrow(p, xv, scx, sce);
           }
-          fetch_lrow(p, xv, scx, sce);
           const bool vp = p < n_l;
 #pragma unroll
           for (int kb = 0; kb < NB; ++kb) xv[kb] = vp ? xv[kb] * scx : (f32x4)(0.0f);
@@ -1272,23 +1278,20 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           for (int base = 0; base < pmax1; base += NLc) {  // wave-uniform
             load_lchunk(base);
             const int pend = min(base + NLc, pmax1);
+            f32x4 en[NB];                 // (the next position's row, in flight while this one is processed)
+            float scxn = 0.0f, scen = 0.0f;
+            if constexpr (LPF) fetch_lrow(base, en, scxn, scen);
             for (int p = base; p < pend; ++p) {
               const bool vp = p < n_l;
               f32x4 ev[NB], xv[NB], z1[NB], zr[NB], m2[NB], av[NB], dx[NB];
-              float scx, sce;
-          if constexpr (G::AT_USE && !LSTREAM) {  // weight fragments from LDS at the use
-            const int zz = opaque_zero(p);
-            if constexpr (G::AT_USE_T) {
-              load_frag_T<DH, NB, MM>(w1W1 + zz, q, r, FT1);
-              load_bias<DH, NB>(w1b1 + zz, q, b1);
-              load_frag_T<DH, NB, MM>(w1W2 + zz, q, r, FT2);
-              load_bias<DH, NB>(w1b2 + zz, q, b2);
-            }
-            load_frag_N<DH, NB, MM>(w1W1 + zz, q, r, FN1);
-            load_frag_N<DH, NB, MM>(w1W2 + zz, q, r, FN2);
-          }
-
-              fetch_lrow(p, ev, scx, sce);
+              float scx = scxn, sce = scen;
+              if constexpr (LPF) {
+#pragma unroll
+                for (int kb = 0; kb < NB; ++kb) ev[kb] = en[kb];
+                if (p + 1 < pend) fetch_lrow(p + 1, en, scxn, scen);
+              } else {
+                fetch_lrow(p, ev, scx, sce);
+              }
 #pragma unroll
               for (int kb = 0; kb < NB; ++kb) {
                 ev[kb] = vp ? ev[kb] : (f32x4)(0.0f);
