@@ -552,6 +552,18 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       lut = a.p.usert_emb[(size_t)uid * a.p.ld_usert + t];
       lct = a.p.item_cate[lid];
     };
+    // the NEXT chunk's entries, loaded while the current chunk is processed (its categories one position later, when
+    // the ids have arrived) and taken over at the chunk boundary: no dependent id -> category -> row trip per chunk
+    int nlid = 0, nlct = 0;
+    float nlht = 0.0f, nlut = 0.0f;
+    auto stage_lchunk_ids = [&](int base) {
+      const int t = min(base + kkl, Ls - 1);
+      nlid = a.b.hist_i[(size_t)bb * Ls + t];
+      nlht = a.b.hist_t[(size_t)bb * Ls + t];
+      nlut = a.p.usert_emb[(size_t)uid * a.p.ld_usert + t];
+    };
+    auto stage_lchunk_cats = [&]() { nlct = a.p.item_cate[nlid]; };
+    auto take_lchunk = [&]() { lid = nlid; lct = nlct; lht = nlht; lut = nlut; };
     auto fetch_lrow = [&](int p, f32x4 (&xr)[NB], float& scx, float& sce) {  // position p of the loaded chunk
       const int k = p % NLc;
       const int it = sample_pick<CPS>(lid, k / CPS, k % CPS, s_loc), ct = sample_pick<CPS>(lct, k / CPS, k % CPS, s_loc);
@@ -618,8 +630,14 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         Zl[kb] = (f32x4)(0.0f);
         long4[kb] = (f32x4)(0.0f);
       }
+      if constexpr (LPF) { stage_lchunk_ids(0); stage_lchunk_cats(); }
       for (int base = 0; base < pmax1; base += NLc) {  // wave-uniform
-        load_lchunk(base);
+        if constexpr (LPF) {
+          take_lchunk();
+          if (base + NLc < pmax1) stage_lchunk_ids(base + NLc);
+        } else {
+          load_lchunk(base);
+        }
         if constexpr (TRAIN) {
           const int t = base + kkl;
           if (t < Ls) {
@@ -645,6 +663,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) xv[kb] = xn[kb];
             if (p + 1 < pend) fetch_lrow(p + 1, xn, scxn, scen);
+            if (p == base + 1 && base + NLc < pmax1) stage_lchunk_cats();   // (the next chunk's ids are here by now)
           } else {
             fetch_lrow(p, xv, scx, sce);
           }
@@ -1275,8 +1294,14 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         if constexpr (LSTREAM) {
           AccSet<NB> acc;
           acc.zero();
+          if constexpr (LPF) { stage_lchunk_ids(0); stage_lchunk_cats(); }
           for (int base = 0; base < pmax1; base += NLc) {  // wave-uniform
-            load_lchunk(base);
+            if constexpr (LPF) {
+              take_lchunk();
+              if (base + NLc < pmax1) stage_lchunk_ids(base + NLc);
+            } else {
+              load_lchunk(base);
+            }
             const int pend = min(base + NLc, pmax1);
             f32x4 en[NB];                 // (the next position's row, in flight while this one is processed)
             float scxn = 0.0f, scen = 0.0f;
@@ -1289,6 +1314,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
                 for (int kb = 0; kb < NB; ++kb) ev[kb] = en[kb];
                 if (p + 1 < pend) fetch_lrow(p + 1, en, scxn, scen);
+                if (p == base + 1 && base + NLc < pmax1) stage_lchunk_cats();
               } else {
                 fetch_lrow(p, ev, scx, sce);
               }
