@@ -383,6 +383,9 @@ __device__ __forceinline__ void online_step(f32x4 (&mx)[NB], f32x4 (&Z)[NB], f32
     }
 }
 
+#ifndef TLSAN_EXP_LCH
+#define TLSAN_EXP_LCH 1
+#endif
 // LSTREAM: the long block is streamed like the short one (any Ls <= TLSAN_LS_CAP); otherwise its
 // Ls <= TLSAN_LS_MAX positions stay in registers between forward and backward.
 template <int D, int DH, bool TRAIN, bool LSTREAM, int DT = TLSAN_TABLE_F32, bool DROP = false, int MM = TLSAN_MATRIX_F32>
@@ -412,6 +415,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   float* sT = (float*)(sP + (TRAIN ? NSB * PSTR : 0));  // per-wave transpose scratch / staging
   constexpr bool KEEP_A = G::KEEP_A && TRAIN && !LSTREAM;
   constexpr bool LPF = NB == 1;                 // streamed windows: the next position's row is prefetched
+  // ... and the next chunk's ids / weights / categories are loaded a chunk ahead (d = 256 in fp32 has no registers for
+  // either: 568 -> 618 us at Ls = 90 with this one; with bf16 matrix operands it has: 328 -> 321 us)
+  constexpr bool LCH = TLSAN_EXP_LCH != 0 && (NB == 1 || MM == TLSAN_MATRIX_BF16);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int q = lane >> 4, r = lane & 15;
   const int s_loc = r / CPS, col = r % CPS;
@@ -630,9 +636,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         Zl[kb] = (f32x4)(0.0f);
         long4[kb] = (f32x4)(0.0f);
       }
-      if constexpr (LPF) { stage_lchunk_ids(0); stage_lchunk_cats(); }
+      if constexpr (LCH) { stage_lchunk_ids(0); stage_lchunk_cats(); }
       for (int base = 0; base < pmax1; base += NLc) {  // wave-uniform
-        if constexpr (LPF) {
+        if constexpr (LCH) {
           take_lchunk();
           if (base + NLc < pmax1) stage_lchunk_ids(base + NLc);
         } else {
@@ -663,9 +669,11 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) xv[kb] = xn[kb];
             if (p + 1 < pend) fetch_lrow(p + 1, xn, scxn, scen);
-            if (p == base + 1 && base + NLc < pmax1) stage_lchunk_cats();   // (the next chunk's ids are here by now)
           } else {
             fetch_lrow(p, xv, scx, sce);
+          }
+          if constexpr (LCH) {
+            if (p == base + 1 && base + NLc < pmax1) stage_lchunk_cats();   // (the next chunk's ids are here by now)
           }
           const bool vp = p < n_l;
 #pragma unroll
@@ -1294,9 +1302,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         if constexpr (LSTREAM) {
           AccSet<NB> acc;
           acc.zero();
-          if constexpr (LPF) { stage_lchunk_ids(0); stage_lchunk_cats(); }
+          if constexpr (LCH) { stage_lchunk_ids(0); stage_lchunk_cats(); }
           for (int base = 0; base < pmax1; base += NLc) {  // wave-uniform
-            if constexpr (LPF) {
+            if constexpr (LCH) {
               take_lchunk();
               if (base + NLc < pmax1) stage_lchunk_ids(base + NLc);
             } else {
@@ -1314,9 +1322,11 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
                 for (int kb = 0; kb < NB; ++kb) ev[kb] = en[kb];
                 if (p + 1 < pend) fetch_lrow(p + 1, en, scxn, scen);
-                if (p == base + 1 && base + NLc < pmax1) stage_lchunk_cats();
               } else {
                 fetch_lrow(p, ev, scx, sce);
+              }
+              if constexpr (LCH) {
+                if (p == base + 1 && base + NLc < pmax1) stage_lchunk_cats();
               }
 #pragma unroll
               for (int kb = 0; kb < NB; ++kb) {
