@@ -224,6 +224,14 @@ __device__ __forceinline__ f32x4 gather_item4c(const FwdArgs& a, int it, int ct,
 }
 
 template <int DT = TLSAN_TABLE_F32>
+__device__ __forceinline__ typename TblRaw<DT>::type gather_item4c_raw(const FwdArgs& a, int it, int ct, int c) {
+  const bool item = c < a.di;
+  const float* base = item ? a.p.item_emb : a.p.cate_emb;
+  const size_t idx = item ? (size_t)it * a.p.ld_item + c : (size_t)ct * a.dc + (c - a.di);
+  return tbl_ld4_raw<DT>(base, idx);
+}
+
+template <int DT = TLSAN_TABLE_F32>
 __device__ __forceinline__ f32x4 gather_item4(const FwdArgs& a, int it, int c) {
   return gather_item4c<DT>(a, it, a.p.item_cate[it], c);
 }
@@ -579,6 +587,16 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb) xr[kb] = gather_item4c<DT>(a, it, ct, chb[kb]);
     };
+    using raw4 = typename TblRaw<DT>::type;
+    auto fetch_lrow_raw = [&](int p, raw4 (&xr)[NB], float& scx, float& sce) {  // the same, the row as loaded (widened at its use)
+      const int k = p % NLc;
+      const int it = sample_pick<CPS>(lid, k / CPS, k % CPS, s_loc), ct = sample_pick<CPS>(lct, k / CPS, k % CPS, s_loc);
+      const float uth = sample_pick<CPS>(lut, k / CPS, k % CPS, s_loc) * sample_pick<CPS>(lht, k / CPS, k % CPS, s_loc);
+      scx = (gamma * P * P) * uth;
+      sce = (gamma * P) * uth;
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) xr[kb] = gather_item4c_raw<DT>(a, it, ct, chb[kb]);
+    };
     // session ids (and their categories) are fetched once, one per lane of the sample
     // (lane k = q*CPS + col holds entry k of the current chunk of NL entries), then broadcast
     // with a cross-lane read: no dependent index loads inside the position loops.
@@ -658,17 +676,17 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         // every position waited out a full gather: most of a streamed window's time)
         // (d = 256 has no registers for it: 567 -> 642 us at Ls = 90 with the prefetch, so it keeps the fetch in place;
         //  d = 128: 268 -> 241 us)
-        f32x4 xn[NB];
+        raw4 xn[NB];
         float scxn = 0.0f, scen = 0.0f;
-        if constexpr (LPF) fetch_lrow(base, xn, scxn, scen);
+        if constexpr (LPF) fetch_lrow_raw(base, xn, scxn, scen);
         for (int p = base; p < pend; ++p) {
           f32x4 xv[NB], z[NB], m2[NB];
           float scx = scxn, sce = scen;
           (void)sce;
           if constexpr (LPF) {
 #pragma unroll
-            for (int kb = 0; kb < NB; ++kb) xv[kb] = xn[kb];
-            if (p + 1 < pend) fetch_lrow(p + 1, xn, scxn, scen);
+            for (int kb = 0; kb < NB; ++kb) xv[kb] = tbl_cvt<DT>(xn[kb]);
+            if (p + 1 < pend) fetch_lrow_raw(p + 1, xn, scxn, scen);
           } else {
             fetch_lrow(p, xv, scx, sce);
           }
@@ -1311,17 +1329,17 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
               load_lchunk(base);
             }
             const int pend = min(base + NLc, pmax1);
-            f32x4 en[NB];                 // (the next position's row, in flight while this one is processed)
+            raw4 en[NB];                  // (the next position's row, in flight while this one is processed)
             float scxn = 0.0f, scen = 0.0f;
-            if constexpr (LPF) fetch_lrow(base, en, scxn, scen);
+            if constexpr (LPF) fetch_lrow_raw(base, en, scxn, scen);
             for (int p = base; p < pend; ++p) {
               const bool vp = p < n_l;
               f32x4 ev[NB], xv[NB], z1[NB], zr[NB], m2[NB], av[NB], dx[NB];
               float scx = scxn, sce = scen;
               if constexpr (LPF) {
 #pragma unroll
-                for (int kb = 0; kb < NB; ++kb) ev[kb] = en[kb];
-                if (p + 1 < pend) fetch_lrow(p + 1, en, scxn, scen);
+                for (int kb = 0; kb < NB; ++kb) ev[kb] = tbl_cvt<DT>(en[kb]);
+                if (p + 1 < pend) fetch_lrow_raw(p + 1, en, scxn, scen);
               } else {
                 fetch_lrow(p, ev, scx, sce);
               }

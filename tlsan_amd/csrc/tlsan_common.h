@@ -82,6 +82,28 @@ __device__ __forceinline__ f32x4 tbl_ld4(const float* __restrict__ base, size_t 
   r[3] = __uint_as_float(v.y & 0xffff0000u);
   return r;
 }
+// the same in two steps -- the load as it comes from memory, the widening later -- for loads that are issued ahead of
+// their use: arithmetic right behind the load would make the wave wait for it there
+template <int DT> struct TblRaw { using type = f32x4; };
+template <> struct TblRaw<TLSAN_TABLE_BF16> { using type = uint2; };
+template <int DT>
+__device__ __forceinline__ typename TblRaw<DT>::type tbl_ld4_raw(const float* __restrict__ base, size_t idx) {
+  if constexpr (DT == TLSAN_TABLE_F32) return *(const f32x4*)(base + idx);
+  else return *(const uint2*)((const uint16_t*)base + idx);
+}
+template <int DT>
+__device__ __forceinline__ f32x4 tbl_cvt(typename TblRaw<DT>::type v) {
+  if constexpr (DT == TLSAN_TABLE_F32) {
+    return v;
+  } else {
+    f32x4 r;
+    r[0] = __uint_as_float(v.x << 16);
+    r[1] = __uint_as_float(v.x & 0xffff0000u);
+    r[2] = __uint_as_float(v.y << 16);
+    r[3] = __uint_as_float(v.y & 0xffff0000u);
+    return r;
+  }
+}
 // 32 well-mixed bits from (element index, stream): the random bits of the stochastic rounding
 __device__ __forceinline__ uint32_t tbl_hash(uint32_t x, uint32_t stream) {
   x ^= stream * 0x9e3779b9u;
