@@ -252,10 +252,14 @@ typedef struct {
 int tlsan_batch_pack(const tlsan_packed* set, const int32_t* order, int32_t lo, const tlsan_batch* out,
                      int32_t Ls, int32_t is_test, void* stream);
 
-/* Build the destination index of batch `b` into index slot `slot` (0 or 1) of the state: the two
+/* Build the destination index of batch `b` into index slot `slot` (0 .. 2) of the state: the two
  * launches a step otherwise starts with.  Independent of the parameters, so an input pipeline can
- * run it for the NEXT batch on another stream while the current step computes; the caller orders
- * it after the last step that used the same slot and before the step that consumes it. */
+ * run it for the next batches on another stream while the current step computes; the caller orders
+ * it after the last step that used the same slot and before the step that consumes it.
+ * slot | TLSAN_INDEX_FOR_LAZY_SGD: the index will be consumed by a lazy-L2 SGD train step only, which reaches the
+ * user table's offsets through the batch's ids and the used-row records -- they are then written for the used rows
+ * only (10 M users: 80 MB less per step).  An index built that way must not feed tlsan_grads or a dense-L2 step. */
+#define TLSAN_INDEX_FOR_LAZY_SGD 0x100
 int tlsan_batch_index(const tlsan_dims* dims, const tlsan_batch* b, void* state, int32_t slot, void* stream);
 
 /* Gradients only (no update) -- what `tf.gradients(self.loss, trainables)` (model.py:198)

@@ -14,6 +14,7 @@ NORM_TF18, NORM_DEDUP = 0, 1
 TABLE_F32, TABLE_BF16 = 0, 1
 MATRIX_F32, MATRIX_BF16 = 0, 1
 L2_DENSE, L2_LAZY = 0, 1
+INDEX_FOR_LAZY_SGD = 0x100   # TLSAN_INDEX_FOR_LAZY_SGD (include/tlsan.h)
 INDEX_SLOTS = 3   # TLSAN_INDEX_SLOTS (csrc/tlsan_update.h): destination-index slots of the state
 SN_CAP = 96     # TLSAN_SN_CAP (csrc/tlsan_common.h): longest session of a training batch
 

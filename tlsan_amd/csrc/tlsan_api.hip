@@ -571,7 +571,7 @@ int tlsan_forward(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch*
 
 // destination index of a batch into slot k: use counts per destination row -> first sorted position
 // of every row (+ records of the used rows)
-static int build_index(const tlsan_dims* d, const tlsan_batch* b, const St& st, int k, hipStream_t hs) {
+static int build_index(const tlsan_dims* d, const tlsan_batch* b, const St& st, int k, hipStream_t hs, bool sparse_users = false) {
   int rc;
   CountArgs ca;
   memset(&ca, 0, sizeof(ca));
@@ -594,6 +594,9 @@ static int build_index(const tlsan_dims* d, const tlsan_batch* b, const St& st, 
   sa.urec[0] = st.urec_item[k]; sa.urec[2] = st.urec_user[k];
   sa.hot_n[0] = &st.hdr->n_hot[k]; sa.hot_list[0] = st.hot_list[k];
   sa.total[0] = sa.total[1] = sa.total[2] = 1;
+  // the user table of a lazy-L2 SGD step: its consumers reach off / cur through the batch's ids or the used-row records
+  // only (the dense sweeps and tlsan_grads read the offsets of every row)
+  sa.sparse = sparse_users ? (1 << 2) : 0;
   sa.n_uniq[0] = &st.hdr->n_uniq[k][0]; sa.n_uniq[1] = nullptr; sa.n_uniq[2] = &st.hdr->n_uniq[k][1];
   if ((rc = launch_scan(sa, nscan, st.scan_bsum[k], hs))) return rc;
   if (uc_by_list(d, b)) {
@@ -612,7 +615,7 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   const int k = hp->index_slot;
   int rc;
   prof_mark(0, hs);
-  if (!hp->index_prebuilt && (rc = build_index(d, b, st, k, hs))) return rc;
+  if (!hp->index_prebuilt && (rc = build_index(d, b, st, k, hs, presum != nullptr))) return rc;
   // --- fused forward + backward
   FwdArgs a;
   fill_fwd(a, d, s, p, b, w, L);
@@ -753,10 +756,12 @@ int tlsan_batch_index(const tlsan_dims* d, const tlsan_batch* b, void* state, in
   int rc = shape_of(d, &s);
   if (rc) return rc;
   if ((rc = check_batch(d, b, true))) return rc;
+  const bool lazy_sgd = (slot & TLSAN_INDEX_FOR_LAZY_SGD) != 0;
+  slot &= ~TLSAN_INDEX_FOR_LAZY_SGD;
   if (slot < 0 || slot >= TLSAN_INDEX_SLOTS) return fail(TLSAN_E_BADARG, "index slot must be 0 .. %d", TLSAN_INDEX_SLOTS - 1);
   if (!state) return fail(TLSAN_E_WORKSPACE, "state is NULL");
   carve_state(d, (char*)state, &st);
-  return build_index(d, b, st, slot, (hipStream_t)stream);
+  return build_index(d, b, st, slot, (hipStream_t)stream, lazy_sgd);
 }
 
 static int check_slot(const tlsan_params* q, const char* name) {

@@ -124,6 +124,9 @@ struct ScanArgs {
   int32_t total[3];    // != 0: off has n+1 entries, off[n] = sum of all counts
   long long* bsum;     // optional [gridDim.x]: per-chunk packed sums (k_scan_block_sums) -- large tables
   int32_t* hot_n[3]; int32_t* hot_list[3];   // optional (with urec): slots of the rows with more than AP_HOT uses
+  int32_t sparse;      // bit t set: off / cur of table t are written for the rows with cnt > 0 only -- the user table of a
+                       // batch's destination index, which is reached through the batch's ids and the used-row records
+                       // only (10 M users: 80 MB of writes per step otherwise; the item offsets are walked per category)
 };
 #define SCAN_TWO_LEVEL_BLOCKS 16  // tables of more chunks than this take the two-launch form
 
@@ -145,11 +148,16 @@ __global__ __launch_bounds__(1024) void k_scan_block_sums(ScanArgs a) {
   const int n = a.n[which];
   const int i0 = ((int)blockIdx.x - a.blk0[which]) * 4096 + tid * 4;
   long long part = 0;
+  int c4[4] = {0, 0, 0, 0};
+  if (i0 + 3 < n) {                      // (chunks start at multiples of 4096: 16-byte aligned)
+    const int4 v = *(const int4*)(cnt + i0);
+    c4[0] = v.x; c4[1] = v.y; c4[2] = v.z; c4[3] = v.w;
+  } else {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int c = (i0 + k < n) ? cnt[i0 + k] : 0;
-    part += (long long)c + ((long long)(c > 0) << 32);
+    for (int k = 0; k < 4; ++k) c4[k] = (i0 + k < n) ? cnt[i0 + k] : 0;
   }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) part += (long long)c4[k] + ((long long)(c4[k] > 0) << 32);
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
   if (lane == 0) wsum[wave] = part;
@@ -221,8 +229,10 @@ __global__ __launch_bounds__(1024) void k_index_scan(ScanArgs a) {
   for (int k = 0; k < 4; ++k) {
     if (i0 + k < n) {
       const int o = (int)(run & 0xffffffffLL);
-      off[i0 + k] = o;
-      if (cur) cur[i0 + k] = o;
+      if (!((a.sparse >> which) & 1) || v[k] > 0) {
+        off[i0 + k] = o;
+        if (cur) cur[i0 + k] = o;
+      }
       if (uniq && v[k] > 0) uniq[(int)(run >> 32)] = i0 + k;
       if (urec && v[k] > 0) urec[(int)(run >> 32)] = make_int4(i0 + k, o, v[k], 0);
       if (urec && a.hot_n[which] && v[k] > AP_HOT) {

@@ -586,7 +586,8 @@ class Model(object):
             else:
                 self._pre_event.synchronize()
             for ndb, kk in ahead:
-                L.check(self.lib.tlsan_batch_index(C.byref(self.dims), C.byref(ndb.c), self.state.data_ptr(), kk,
+                flag = L.INDEX_FOR_LAZY_SGD if (self.l2_mode == L.L2_LAZY and self.optimizer == "sgd") else 0
+                L.check(self.lib.tlsan_batch_index(C.byref(self.dims), C.byref(ndb.c), self.state.data_ptr(), kk | flag,
                                                    C.c_void_p(self._side.cuda_stream)), "tlsan_batch_index")
                 self._idx_event[kk].record(self._side)
                 self._idx_ready[kk] = ndb
