@@ -207,8 +207,14 @@ __global__ __launch_bounds__(1024) void k_index_scan(ScanArgs a) {
   // ---- own chunk
   const int i0 = base + tid * 4;
   int v[4];
+  const bool full = i0 + 3 < n;          // (chunks start at multiples of 4096: 16-byte accesses)
+  if (full) {
+    const int4 t = *(const int4*)(cnt + i0);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) v[k] = (i0 + k < n) ? cnt[i0 + k] : 0;
+    for (int k = 0; k < 4; ++k) v[k] = (i0 + k < n) ? cnt[i0 + k] : 0;
+  }
   const long long tsum = pack(v[0]) + pack(v[1]) + pack(v[2]) + pack(v[3]);
   long long inc = tsum;
 #pragma unroll
@@ -225,11 +231,18 @@ __global__ __launch_bounds__(1024) void k_index_scan(ScanArgs a) {
   int32_t* cur = a.cur[which];
   int32_t* uniq = a.uniq[which];
   int4* urec = a.urec[which];
+  const bool dense4 = full && !((a.sparse >> which) & 1);   // the four offsets as one 16-byte store each
+  if (dense4) {
+    const int o0 = (int)(run & 0xffffffffLL);
+    const int4 o4 = make_int4(o0, o0 + v[0], o0 + v[0] + v[1], o0 + v[0] + v[1] + v[2]);
+    *(int4*)(off + i0) = o4;
+    if (cur) *(int4*)(cur + i0) = o4;
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     if (i0 + k < n) {
       const int o = (int)(run & 0xffffffffLL);
-      if (!((a.sparse >> which) & 1) || v[k] > 0) {
+      if (!dense4 && (!((a.sparse >> which) & 1) || v[k] > 0)) {
         off[i0 + k] = o;
         if (cur) cur[i0 + k] = o;
       }
