@@ -612,7 +612,15 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     // row of session entry t0 + dt of the wavefront's sample s_sel (n_sel entries; its chunk must be loaded): normally
     // the lane's own sample and dt = 0; while one half of the lanes helps with a long session (HELP, see P3) both halves
     // fetch for that sample, the helping half the odd entry (t0, s_sel, n_sel and `two` are wave-uniform, dt per lane)
-    auto fetch_row_of = [&](int t0, int dt, bool two, f32x4 (&xr)[NB], int s_sel, int n_sel) {
+    // (the row comes back as loaded, with a flag: scaling or masking it right behind the load would make the wavefront
+    //  wait for it there instead of where it is used -- see use_row)
+    using srow4 = typename TblRaw<DT>::type;
+    struct RowPF { srow4 r[NB]; bool v; };
+    auto use_row = [&](const RowPF& o, f32x4 (&xr)[NB]) {
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) xr[kb] = o.v ? tbl_cvt<DT>(o.r[kb]) * P : (f32x4)(0.0f);
+    };
+    auto fetch_row_of = [&](int t0, int dt, bool two, RowPF& o, int s_sel, int n_sel) {
       const int k = t0 % NL;
       int it = sample_pick<CPS>(sid, k / CPS, k % CPS, s_sel), ct = sample_pick<CPS>(scat, k / CPS, k % CPS, s_sel);
       if (two) {
@@ -621,16 +629,16 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         it = dt ? it1 : it;
         ct = dt ? ct1 : ct;
       }
-      const bool vt = t0 + dt < n_sel;
+      o.v = t0 + dt < n_sel;
 #pragma unroll
-      for (int kb = 0; kb < NB; ++kb) {
-        const f32x4 v = gather_item4c<DT>(a, it, ct, chb[kb]) * P;
-        xr[kb] = vt ? v : (f32x4)(0.0f);
-      }
+      for (int kb = 0; kb < NB; ++kb) o.r[kb] = gather_item4c_raw<DT>(a, it, ct, chb[kb]);
     };
-    auto fetch_row = [&](int t, f32x4 (&xr)[NB]) { fetch_row_of(t, 0, false, xr, s_loc, n_s); };
+    auto fetch_row = [&](int t, RowPF& o) { fetch_row_of(t, 0, false, o, s_loc, n_s); };
     int spos0 = 0;  // position of session use kk (first chunk): one returning atomic per use
-    f32x4 xnext[NB];
+    RowPF xnext;
+    xnext.v = false;
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) xnext.r[kb] = srow4{};
     const int pmax2e = wave_max_samples<CPS>(n_s + 1);
     int ucat = 0, ct_i = 0;   // category of the user's row / of the candidate: fetched with the window's ids
     if constexpr (LSTREAM) {
@@ -974,8 +982,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         load_bias<DH, NB>(w2b2 + zz, q, b2);
       }
 
-#pragma unroll
-      for (int kb = 0; kb < NB; ++kb) xv[kb] = xnext[kb];
+      use_row(xnext, xv);
       if (u + 1 < nsess) {  // prefetch the next row while this one is processed
         if (!h_on && (p % NL) == 0) load_chunk(p);
         const Sel e2 = sel_of(u + 1);
@@ -1106,9 +1113,13 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         AccSet<NB> acc;
         acc.zero();
         if (pmax2 - 1 > NL) load_chunk(0);  // (wave-uniform) the forward loop moved past chunk 0
-        f32x4 xn2[NB];
+        f32x4 xbr[NB];      // position 0: the bridge row (LDS)
 #pragma unroll
-        for (int kb = 0; kb < NB; ++kb) xn2[kb] = *(const f32x4*)(sB + srow * LSTR + chb[kb]);
+        for (int kb = 0; kb < NB; ++kb) xbr[kb] = *(const f32x4*)(sB + srow * LSTR + chb[kb]);
+        RowPF xn2;          // positions 1..: the session row fetched one step ahead
+        xn2.v = false;
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) xn2.r[kb] = srow4{};
         for (int p = 0; p <= nsess; ++p) {  // wave-uniform trip count: the bridge, then the session steps
           const Sel e = sel_of(p > 0 ? p - 1 : 0);
           const int s_sel = e.s, t = e.t0 + e.dt;
@@ -1128,8 +1139,12 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             load_frag_N<DH, NB, MM>(w2W2 + zz, q, r, FN2);
           }
 
+          if (p == 0) {
 #pragma unroll
-          for (int kb = 0; kb < NB; ++kb) xv[kb] = xn2[kb];
+            for (int kb = 0; kb < NB; ++kb) xv[kb] = xbr[kb];
+          } else {
+            use_row(xn2, xv);
+          }
           if (p < nsess) {  // the row of the next session step
             if (!h_on && p > 0 && (p % NL) == 0) load_chunk(p);
             const Sel e2 = sel_of(p);
