@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--graph", type=int, default=0, help="replay hipGraph-captured steps instead of eager launches (single-GPU path)")
     ap.add_argument("--prefetch", type=int, default=2,
                     help="eager mode: build the destination index of the next batch(es) on a second stream: 1 = one step ahead, 2 = two")
-    ap.add_argument("--event-every", type=int, default=8,
+    ap.add_argument("--event-every", type=int, default=10,
                     help="every Nth timed step carries the HIP events that bracket k_fwd_bwd (graph mode: runs eagerly)")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded (multi-GPU) code path even at N=1")
     ap.add_argument("--wire-dtype", default="f32", choices=["f32", "bf16"],

@@ -40,14 +40,16 @@ static int g_prof_stride = 1;  // record every g_prof_stride-th step (tlsan_prof
 static int g_prof_tick = 0;    // steps seen since the ring was enabled
 static hipEvent_t* g_prof_ev = nullptr;  // [PROF_MAX_STEPS][PROF_MARKS], created on first enable
 static void prof_mark(int mark, hipStream_t hs) {
-  if (g_prof_level == 0 || g_prof_n >= PROF_MAX_STEPS || (g_prof_tick % g_prof_stride) != 0) return;
+  // (the sampled step of every stride is the middle one: not the first step after the caller's fence, whose kernel
+  //  starts on an idle GPU and runs 5-8 % longer than the others)
+  if (g_prof_level == 0 || g_prof_n >= PROF_MAX_STEPS || (g_prof_tick % g_prof_stride) != g_prof_stride / 2) return;
   if (g_prof_level == 1 && mark != 1 && mark != 2) return;
   (void)hipEventRecord(g_prof_ev[g_prof_n * PROF_MARKS + mark], hs);
 }
 
 static void prof_step_done() {
   if (g_prof_level == 0) return;
-  if ((g_prof_tick % g_prof_stride) == 0 && g_prof_n < PROF_MAX_STEPS) ++g_prof_n;
+  if ((g_prof_tick % g_prof_stride) == g_prof_stride / 2 && g_prof_n < PROF_MAX_STEPS) ++g_prof_n;
   ++g_prof_tick;
 }
 
