@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TLSAN_ABI_VERSION 12
+#define TLSAN_ABI_VERSION 13
 
 enum {
   TLSAN_OK = 0,
@@ -150,6 +150,13 @@ typedef struct {
   float* logits;  /* [B]  model.py:137 (may be NULL)                                       */
   float* sq_rows; /* [1]  sum of squares of every per-use embedding-gradient row (the sparse
                      part of TF-1.8's global norm); may be NULL                              */
+  /* Optional (may be NULL; ABI 13): a word in HOST-visible memory (hipHostMalloc) into which the step's first
+   * kernel stores `started_value` when it begins to run -- everything queued on the stream before the step has
+   * completed by then.  A caller that must know this (to reuse an index slot on another stream) polls the word
+   * instead of recording an event between two steps: an event is a barrier packet in the queue and costs the next
+   * kernel ~5 us. */
+  uint32_t* started;
+  uint32_t started_value;
 } tlsan_step_out;
 
 int tlsan_abi_version(void);

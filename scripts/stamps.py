@@ -39,7 +39,12 @@ for i, n in enumerate(["P5 pos1: maps+exp", "P5 pos1: bwd_compute", "P5 pos1: bw
     print("%-24s mean %8.0f p50 %8.0f max %8.0f" % (n, fd[:, :, i][ok].mean(), np.median(fd[:, :, i][ok]), fd[:, :, i][ok].max()))
 full = (raw[:, :, 9] > 0) & (raw[:, :, 18] > 0)     # waves whose window is full (position 9 ran)
 def seg(nm, lo, hi, sel=None):
-    dd = (raw[:, :, hi] - raw[:, :, lo])[ok if sel is None else sel]
+    # (a stamp a wavefront never reached stays 0: such waves are left out of the segment, not read as a time)
+    use = (ok if sel is None else sel) & (raw[:, :, hi] > 0) & (raw[:, :, lo] > 0)
+    if not use.any():
+        print("%-44s (no wavefront reached both stamps)" % nm)
+        return
+    dd = (raw[:, :, hi] - raw[:, :, lo])[use]
     print("%-44s mean %8.0f p50 %8.0f max %8.0f" % (nm, dd.mean(), np.median(dd), dd.max()))
 seg("P1: loads issued -> rows in registers", 0, 21)
 seg("P1: weight fragments from the LDS", 21, 22)

@@ -609,8 +609,11 @@ def test_bf16_tables(l2_mode):
                 a, r = stored[k].reshape(q[k].shape), q[k]
                 if k in BF16_TABLES:
                     ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(r), 1e-30))) - 7)
-                    # (lazy: reading the parameters folds the table scale in, a second stochastic rounding)
-                    assert (np.abs(a - r) <= ulp * ((2 if l2_mode == "lazy" else 1) + 1e-3) + 1e-12).all(), k
+                    # (lazy: reading the parameters folds the table scale in, a second stochastic rounding; with the
+                    #  speculative update, TLSAN_SPEC_UPDATE=1, a clipped step is applied with coefficient 1 and then
+                    #  corrected: a third)
+                    nround = (3 if os.environ.get("TLSAN_SPEC_UPDATE", "0") != "0" else 2) if l2_mode == "lazy" else 1
+                    assert (np.abs(a - r) <= ulp * (nround + 1e-3) + 1e-12).all(), k
                     assert np.array_equal(a.astype(np.float32), _bf16_round(a)), k        # representable in bf16
                     bias = ((a - r) / ulp).mean()
                     assert abs(bias) < 0.06, (k, bias)                                    # unbiased: E[stored] = exact

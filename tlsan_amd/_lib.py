@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # (TLSAN_LIB_PATH: a diagnostic build of the same library, e.g. the -DTLSAN_STAMPS=1 variant of scripts/stamps.py)
 LIB_PATH = os.environ.get("TLSAN_LIB_PATH") or os.path.join(HERE, "libtlsan_hip.so")
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 NORM_TF18, NORM_DEDUP = 0, 1
 TABLE_F32, TABLE_BF16 = 0, 1
 MATRIX_F32, MATRIX_BF16 = 0, 1
@@ -79,7 +79,8 @@ class ShardOptimizer(C.Structure):
 
 
 class StepOut(C.Structure):
-    _fields_ = [("loss", C.c_void_p), ("gnorm", C.c_void_p), ("logits", C.c_void_p), ("sq_rows", C.c_void_p)]
+    _fields_ = [("loss", C.c_void_p), ("gnorm", C.c_void_p), ("logits", C.c_void_p), ("sq_rows", C.c_void_p),
+                ("started", C.c_void_p), ("started_value", C.c_uint32)]   # (host-visible word + value: include/tlsan.h)
 
 
 class GradsOut(C.Structure):

@@ -422,6 +422,10 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   int* sP = (int*)(sW + (USE_SW ? 2 * WB : 0));  // [NSB][PSTR] destination-sorted row of every use
   float* sT = (float*)(sP + (TRAIN ? NSB * PSTR : 0));  // per-wave transpose scratch / staging
   constexpr bool KEEP_A = G::KEEP_A && TRAIN && !LSTREAM;
+#ifndef TLSAN_EXP_PIPE5
+#define TLSAN_EXP_PIPE5 1
+#endif
+  constexpr bool PIPE5 = TLSAN_EXP_PIPE5 != 0 && KEEP_A && !DROP && NBUF == 1;   // long backward as a skewed software pipeline (see P5)
   constexpr bool LPF = NB == 1;                 // streamed windows: the next position's row is prefetched
   // ... and the next chunk's ids / weights / categories are loaded a chunk ahead (d = 256 in fp32 has no registers for
   // either: 568 -> 618 us at Ls = 90 with this one; with bf16 matrix operands it has: 328 -> 321 us)
@@ -437,6 +441,11 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   for (int kb = 0; kb < NB; ++kb) chb[kb] = col * CW + 16 * kb + 4 * q;
   const bool lead = (q == 0) && (col == 0);  // one lane per sample
 
+  if constexpr (TRAIN) {
+    // (tlsan_step_out.started: this kernel running means everything queued before the step is complete)
+    if (a.started != nullptr && blockIdx.x == 0 && tid == 0)
+      __hip_atomic_store(a.started, a.started_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   const float* dn = a.p.dense;
   const float gamma = dn[a.lay.gamma];
   const float P = a.p.scale ? *a.p.scale : 1.0f;  // tables hold W / P (lazy L2 decay)
@@ -496,6 +505,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   do {                                                                                       \
     if (a.stamps != nullptr && lane == 0) sStamp[k] = __builtin_amdgcn_s_memtime();          \
   } while (0)
+  if (a.stamps != nullptr && lane < 32) sStamp[lane] = 0;   // (a stamp the wavefront never reaches reads 0, not what the LDS held)
 #else
 #define TLSAN_STAMP(k) do { } while (0)
 #endif
@@ -1100,8 +1110,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           const int c = chb[kb];
           // user use: [user_emb half] -> Gu (grouped by user), [u_cate half] -> Gc (grouped by category)
           float* up = (c < a.di) ? a.Gu + (size_t)pos_u * a.WU + c : a.Gc + (size_t)pos_c * a.dc + (c - a.di);
-          *(f32x4*)up = dout[kb];
-          *(f32x4*)(a.Gi + (size_t)pos_t * D + c) = gi;  // candidate use
+          st4_out(up, dout[kb]);
+          st4_out(a.Gi + (size_t)pos_t * D + c, gi);  // candidate use
           sq_acc += dot4(dout[kb], dout[kb]) + dot4(gi, gi);
         }
       }
@@ -1214,7 +1224,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             if (lead) a.Gb[pos] = 0.0f;
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) {
-              *(f32x4*)(a.Gi + (size_t)pos * D + chb[kb]) = dx[kb];
+              st4_out(a.Gi + (size_t)pos * D + chb[kb], dx[kb]);
               sq_acc += dot4(dx[kb], dx[kb]);
             }
           }
@@ -1308,7 +1318,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             for (int tb = 0; tb < 4; ++tb) v[tb] = acc[x][tb][i];
             float* dst = kp + (size_t)(M0 + 4 * (4 * q + i) + ta0 + x) * D + N0 + 4 * r;
             if (!first) v += *(const f32x4*)dst;
-            *(f32x4*)dst = v;
+            st4_out(dst, v);
           }
       }
       }
@@ -1405,7 +1415,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
                 for (int kb = 0; kb < NB; ++kb) {
                   const f32x4 de = dx[kb] * sce;
-                  *(f32x4*)(a.Gi + (size_t)pos * D + chb[kb]) = de;
+                  st4_out(a.Gi + (size_t)pos * D + chb[kb], de);
                   sq_acc += dot4(de, de);
                 }
                 if (lead) {
@@ -1432,6 +1442,148 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         AccSet<NB> acc;
         acc.zero();
         float dsp[LS];  // per-lane partials of d loss / d scale[p]; reduced after the loop
+        if constexpr (PIPE5) {
+        // ---- software pipeline, skewed by one position: iteration p runs the map chain of position p and the two dW
+        // products of position p - 1 (whose transposed operands it reads back from the LDS first).  Left to itself
+        // the compiler emits every position as map (4 MFMAs) -> wait -> vector code -> map -> ... -> LDS round trip ->
+        // dW (8 MFMAs), one dependent chain of ~1.1 k cycles with the matrix pipe idle between the links; here the
+        // MFMA sequence of an iteration is  z1(p) . dm1(p) . dW1(p-1) . dxm(p) . dW2(p-1)  -- each group's inputs were
+        // produced at least one group earlier, so the groups issue back to back and the vector code, the LDS writes of
+        // this position's tiles and the LDS reads of the previous one's run in their shadow.  One transpose buffer
+        // suffices: LDS operations of a wavefront execute in order, so the reads of p - 1 (top of the iteration) precede
+        // the writes of p.  The groups are pinned with sched_barrier (the scheduler would re-cluster each chain).
+        static_assert(!PIPE5 || (NB == 1 && MM == MM), "one 16-channel block per column");
+        f32x4 ta[NB], tb[NB];   // transposed tiles of the previous position: (x, dz1), then (m1, dm2)
+        auto read_tiles = [&](int t0, int t1) {
+#pragma unroll
+          for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              const int rofs = (4 * q + s) * TSTR + r;
+              ta[kb][s] = T[(t0 * NB + kb) * 16 * TSTR + rofs];
+              tb[kb][s] = T[(t1 * NB + kb) * 16 * TSTR + rofs];
+            }
+        };
+        auto dw_prod = [&](f32x4 (&dW)[NB][NB]) {
+#pragma unroll
+          for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+            for (int jb = 0; jb < NB; ++jb) dW[kb][jb] = mm_mma<MM>(mm_pack<MM>(ta[kb]), mm_pack<MM>(tb[jb]), dW[kb][jb]);
+        };
+        // a map as two half-chains whose sum is taken a group later (the sum right behind the chain would wait for it)
+        auto map_issue = [&](const opd (&F)[NB][NB], const f32x4 (&v)[NB], f32x4 (&h0)[NB], f32x4 (&h1)[NB], const f32x4* bias) {
+          if constexpr (MM == TLSAN_MATRIX_F32) {
+#pragma unroll
+            for (int ob = 0; ob < NB; ++ob) {
+              h0[ob] = bias ? TLSAN_MFMA(F[ob][0][0], v[0][0], bias[ob]) : TLSAN_MFMA(F[ob][0][0], v[0][0], (f32x4)(0.0f));
+              h1[ob] = TLSAN_MFMA(F[ob][0][2], v[0][2], (f32x4)(0.0f));
+              h0[ob] = TLSAN_MFMA(F[ob][0][1], v[0][1], h0[ob]);
+              h1[ob] = TLSAN_MFMA(F[ob][0][3], v[0][3], h1[ob]);
+            }
+          } else {
+#pragma unroll
+            for (int ob = 0; ob < NB; ++ob) {
+              h0[ob] = bias ? mm_mma<MM>(F[ob][0], mm_pack<MM>(v[0]), bias[ob]) : mm_mma<MM>(F[ob][0], mm_pack<MM>(v[0]), (f32x4)(0.0f));
+              h1[ob] = (f32x4)(0.0f);
+            }
+          }
+        };
+        const int wofs = r * TSTR + 4 * q;
+#pragma unroll
+        for (int p = 0; p < LS; ++p) dsp[p] = 0.0f;
+        int posp_c = sP[srow * PSTR];
+        float uth_c = sH[srow * 2 * LSC + LSC];
+        f32x4 av_c[NB];
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) av_c[kb] = *(const f32x4*)(sAw + kb * 256);
+#pragma unroll
+        for (int p = 0; p <= LS; ++p) {
+          if (p < LS && p < pmax1) {   // wave-uniform
+            const bool vp = p < n_l;
+            if (p == 1) TLSAN_STAMP(16);
+            if (p == 2) TLSAN_STAMP(17);
+            if (p == 9) TLSAN_STAMP(18);
+            const int posp = posp_c;
+            const float uth = uth_c;
+            const float scp = (gamma * P * P) * uth;  // x = e_stored * scp
+            const float sce = (gamma * P) * uth;      // d x / d e_true
+            f32x4 xv[NB], av[NB], z1[NB], m1[NB], dm2[NB], dz1[NB], dx[NB], ha[NB], hb[NB], hc[NB], hd[NB];
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+              xv[kb] = e1[p][kb] * scp;
+              av[kb] = av_c[kb];
+            }
+            if (p >= 1) read_tiles(0, 1);                            // x, dz1 of p - 1
+            if (p + 1 < LS) {                                        // the next position's LDS operands, a whole iteration ahead
+              posp_c = sP[srow * PSTR + p + 1];
+              uth_c = sH[srow * 2 * LSC + LSC + p + 1];
+#pragma unroll
+              for (int kb = 0; kb < NB; ++kb) av_c[kb] = *(const f32x4*)(sAw + ((p + 1) * NB + kb) * 256);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            map_issue(FT1, xv, ha, hb, b1);                          // G1: z1(p)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) dm2[kb] = av[kb] * dlong[kb] * (xv[kb] - long4[kb]);  // softmax-over-positions backward
+            __builtin_amdgcn_sched_barrier(0);
+            map_issue(FN2, dm2, hc, hd, nullptr);                    // G2: dm1(p) = dm2 . W2^T
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+              z1[kb] = ha[kb] + hb[kb];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) m1[kb][i] = fmaxf(z1[kb][i], 0.0f);
+              acc.db2[kb] += dm2[kb];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (p >= 1) {
+              dw_prod(acc.dW1);                                      // G3: dW1(p-1) += x^T dz1
+              read_tiles(2, 3);                                      //     m1, dm2 of p - 1 (before this position's tiles overwrite them)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+              const f32x4 dm1 = hc[kb] + hd[kb];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) dz1[kb][i] = z1[kb][i] > 0.0f ? dm1[i] : 0.0f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            map_issue(FN1, dz1, ha, hb, nullptr);                    // G4: dxm(p) = dz1 . W1^T
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {                        // this position's tiles (behind the reads above: in-order DS)
+              *(f32x4*)(T + (0 * NB + kb) * 16 * TSTR + wofs) = xv[kb];
+              *(f32x4*)(T + (1 * NB + kb) * 16 * TSTR + wofs) = dz1[kb];
+              *(f32x4*)(T + (2 * NB + kb) * 16 * TSTR + wofs) = m1[kb];
+              *(f32x4*)(T + (3 * NB + kb) * 16 * TSTR + wofs) = dm2[kb];
+              acc.db1[kb] += dz1[kb];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (p >= 1) dw_prod(acc.dW2);                            // G5: dW2(p-1) += m1^T dm2
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+              dx[kb] = av[kb] * dlong[kb] + (ha[kb] + hb[kb]);
+              dsp[p] += dot4(dx[kb], e1[p][kb]);
+            }
+            if (p == 1) TLSAN_STAMP(15);
+            if (vs && vp) {
+              if (lead) a.Gb[posp] = 0.0f;
+#pragma unroll
+              for (int kb = 0; kb < NB; ++kb) {
+                const f32x4 de = dx[kb] * sce;
+                st4_out(a.Gi + (size_t)posp * D + chb[kb], de);
+                sq_acc += dot4(de, de);
+              }
+            }
+          } else if (p >= 1 && p == pmax1) {   // drain: the dW products of the last position
+            read_tiles(0, 1);
+            dw_prod(acc.dW1);
+            read_tiles(2, 3);
+            dw_prod(acc.dW2);
+          }
+        }
+        } else {
 #pragma unroll
         for (int p = 0; p < LS; ++p) {
           dsp[p] = 0.0f;
@@ -1524,7 +1676,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #if TLSAN_EXP_ABL & 1
                 asm volatile("" :: "v"(de), "v"(pos));   // (timing experiment: no gradient-row stores in the long backward)
 #else
-                *(f32x4*)(a.Gi + (size_t)pos * D + chb[kb]) = de;
+                st4_out(a.Gi + (size_t)pos * D + chb[kb], de);
 #endif
                 sq_acc += dot4(de, de);
               }
@@ -1532,6 +1684,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           }
         }
         if (NBUF > 1 && pmax1 > 0) bwd_dw<NB, TSTR, MM>(T + ((pmax1 - 1) & 1) * TB, q, r, acc.dW1, acc.dW2);
+        }
         TLSAN_STAMP(19);
         // usert_emb / gamma gradients.  Branch-free: every lane of a sample forms the same ten sums (vector-ALU
         // cross-lane steps only, independent chains), the sample's hist_t / usert*hist_t rows come from the LDS
@@ -1564,7 +1717,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             const int n4 = (a.WU - a.di) >> 2;
 #pragma unroll
             for (int k = 0; k < NG; ++k)
-              if (k < n4) *(f32x4*)(gu + 4 * k) = gt4[k];
+              if (k < n4) st4_out(gu + 4 * k, gt4[k]);
           }
         }
         TLSAN_STAMP(20);

@@ -104,6 +104,23 @@ __device__ __forceinline__ f32x4 tbl_cvt(typename TblRaw<DT>::type v) {
     return r;
   }
 }
+// 16-byte store that is written through to memory and leaves the XCD's L2 (sc1): for the kernel's bulk outputs
+// (per-use gradient rows, dK partials), which the NEXT kernel reads -- written through while the kernel computes,
+// they are not left dirty in the L2 for the end-of-kernel release to write back (MI355X_MICROARCH.md: a dependent
+// kernel boundary costs + B / 6 TB/s for B dirty bytes; this kernel is nowhere near a bandwidth limit while it runs)
+#ifndef TLSAN_EXP_WT
+#define TLSAN_EXP_WT 0
+#endif
+__device__ __forceinline__ void st4_out(float* p, f32x4 v) {
+#if TLSAN_EXP_WT
+  // (the s_nop: a vector write to the data registers of a store wider than 64 bits needs one wait state behind it --
+  //  the compiler's hazard recogniser cannot see into the statement, and the next instruction may well reuse them)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(v));
+#else
+  *(f32x4*)p = v;
+#endif
+}
+
 // 32 well-mixed bits from (element index, stream): the random bits of the stochastic rounding
 __device__ __forceinline__ uint32_t tbl_hash(uint32_t x, uint32_t stream) {
   x ^= stream * 0x9e3779b9u;
@@ -118,7 +135,7 @@ __device__ __forceinline__ uint32_t tbl_hash(uint32_t x, uint32_t stream) {
 template <int DT>
 __device__ __forceinline__ void tbl_st4(float* __restrict__ base, size_t idx, f32x4& w, uint32_t stream) {
   if constexpr (DT == TLSAN_TABLE_F32) {
-    *(f32x4*)(base + idx) = w;
+    st4_out(base + idx, w);   // (read next by another kernel: written through, not left dirty in the L2)
     return;
   }
   const uint32_t h0 = tbl_hash((uint32_t)idx, stream), h1 = tbl_hash((uint32_t)idx + 0x68bc21ebu, stream ^ 0x2545f491u);
@@ -302,6 +319,39 @@ __device__ __forceinline__ void map_apply(const typename MMT<MM>::opd (&F)[NB][N
   }
 }
 
+// out = F (x) v  with no bias: the accumulators start from the instruction's inline constant 0 (no register zeroing)
+template <int NB, int MM = TLSAN_MATRIX_F32>
+__device__ __forceinline__ void map_apply0(const typename MMT<MM>::opd (&F)[NB][NB], const f32x4 (&v)[NB], f32x4 (&out)[NB]) {
+  if constexpr (MM == TLSAN_MATRIX_F32) {
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob) {
+      f32x4 acc0 = TLSAN_MFMA(F[ob][0][0], v[0][0], (f32x4)(0.0f));
+      f32x4 acc1 = TLSAN_MFMA(F[ob][0][2], v[0][2], (f32x4)(0.0f));
+      acc0 = TLSAN_MFMA(F[ob][0][1], v[0][1], acc0);
+      acc1 = TLSAN_MFMA(F[ob][0][3], v[0][3], acc1);
+#pragma unroll
+      for (int ib = 1; ib < NB; ++ib) {
+        acc0 = TLSAN_MFMA(F[ob][ib][0], v[ib][0], acc0);
+        acc1 = TLSAN_MFMA(F[ob][ib][2], v[ib][2], acc1);
+        acc0 = TLSAN_MFMA(F[ob][ib][1], v[ib][1], acc0);
+        acc1 = TLSAN_MFMA(F[ob][ib][3], v[ib][3], acc1);
+      }
+      out[ob] = acc0 + acc1;
+    }
+  } else {
+    typename MMT<MM>::opd pv[NB];
+#pragma unroll
+    for (int ib = 0; ib < NB; ++ib) pv[ib] = mm_pack<MM>(v[ib]);
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob) {
+      f32x4 acc = mm_mma<MM>(F[ob][0], pv[0], (f32x4)(0.0f));
+#pragma unroll
+      for (int ib = 1; ib < NB; ++ib) acc = mm_mma<MM>(F[ob][ib], pv[ib], acc);
+      out[ob] = acc;
+    }
+  }
+}
+
 // ---- cross-lane helpers without the LDS ------------------------------------------------------------------
 // __shfl / __shfl_xor compile to ds_bpermute_b32: an LDS round trip each, and hipcc waits lgkmcnt(0) after
 // every one that sits in its own basic block -- the ten dependent 5-step sums at the end of the long backward
@@ -446,6 +496,8 @@ struct FwdArgs {
   uint32_t drop_seed, drop_thr;   // kept iff hash < drop_thr (keep_prob * 2^32); drop_thr == 0: no dropout
   float drop_inv;                 // 1 / keep_prob
   uint32_t drop_sample0;          // index of this batch's first sample in the pattern (a rank's share of a global batch)
+  uint32_t* started;              // optional host-visible word: workgroup 0 stores started_val there when the kernel begins
+  uint32_t started_val;
 };
 
 // Keep / drop pattern of tf.nn.dropout as the scale the element is multiplied with (0 or 1/keep_prob):
