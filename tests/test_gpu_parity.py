@@ -380,6 +380,37 @@ def test_train_driver_on_real_clothing(tmp_path):
     assert {"P@1", "P@50", "R@20"} <= {r[1] for r in ev}
 
 
+def test_chunked_evaluation_equals_the_reference_batches():
+    """The driver evaluates in launches of train.EVAL_CHUNK rows and forms the reference's per-batch aggregation
+    (train.py:86-118, test batch 128) from slices of the per-row results: same AUC, same cumulative P@k / R@k
+    counters as feeding the kernels 128 rows at a time."""
+    import os
+    from tlsan_amd import train as T
+    from tlsan_amd.input import DataInputTest, load_packed
+    from tlsan_amd.model import KS, Model
+    ds = os.path.join(os.path.dirname(__file__), "golden", "packed_clothing.npz")
+    _, test_set, (U, I, Cc), icl = load_packed(ds)
+    cfg = {n: d for n, _, d in T.FLAGS}
+    cfg.update(user_count=U, item_count=I, cate_count=Cc, quiet=True)
+    a, b = Model(cfg, icl, seed=3), Model(cfg, icl, seed=3)
+    assert len(test_set) > T.EVAL_CHUNK // 4
+    for rounds in range(2):                              # (the counters are cumulative: two evaluation rounds)
+        auc_a = T.eval_auc(a, test_set, cfg)
+        pa, ra = T.eval_prec_recall(a, test_set, cfg)
+        s = 0.0
+        for _, batch in DataInputTest(test_set, cfg["test_batch_size"], cfg["Ls"]):
+            s += b.eval_auc(None, batch) * len(batch[0])
+        auc_b = s / len(test_set)
+        for _, batch in DataInputTest(test_set, cfg["test_batch_size"], cfg["Ls"]):
+            b.eval_prec(None, batch)
+        pb = [getattr(b, "prec_%d" % k).eval() for k in KS]
+        for _, batch in DataInputTest(test_set, cfg["test_batch_size"], cfg["Ls"]):
+            b.eval_recall(None, batch)
+        rb = [getattr(b, "recall_%d" % k).eval() for k in KS]
+        assert auc_a == auc_b
+        assert list(pa) == list(pb) and list(ra) == list(rb)
+
+
 @pytest.mark.parametrize("d,Ls,Sn,B", [(128, 20, 3, 37), (128, 90, 5, 21), (64, 33, 2, 50), (256, 16, 2, 9), (256, 90, 4, 19)])
 def test_long_windows_streamed(d, Ls, Sn, B):
     """Ls > 10 (BASELINE configs 3/4: seq <= 90): the long block is streamed with an online
@@ -527,6 +558,73 @@ def test_full_scale_properties():
     coef = min(1.0, cfg["max_gradient_norm"] / m.last_gnorm())
     ib1 = m.get_params()["item_b"].astype(np.float64)
     assert abs((ib0 - ib1).sum() - coef * dl_sum) < 1e-5 * max(1.0, abs(dl_sum)) + 1e-7
+
+
+@pytest.mark.parametrize("matrix_dtype", ["f32", "bf16"])
+def test_full_scale_bf16(matrix_dtype):
+    """BASELINE.json configs[2] in the precision it names -- bf16 table storage (and, second case, bf16 matrix
+    operands) -- at its own size (U=39991, I=22048, C=673, d=128, batch 4096), where the oracle is too slow:
+      * determinism: two runs of 3 steps leave bitwise equal tables and losses (stochastic rounding included);
+      * the L2 term and the clip norm follow the STORED values: the loss a step reports equals the BCE of its logits
+        plus reg/2 * ||P * stored tables||^2 recomputed from the tables themselves, after three updates whose changes
+        of the sum of squares were only ever accumulated incrementally;
+      * lazy L2 is dense L2 within the stochastic-rounding bound: every element within a few bf16 ulps, no bias;
+      * untouched rows are not written in lazy mode."""
+    import torch
+    from tlsan_amd import synth
+    cfg = synth.make_config("electronics")
+    icl = synth.item_cate_list(cfg)
+    batches = synth.make_batches(cfg, 4, 4096, seed=78)
+    reg = cfg["regulation_rate"]
+    runs = {}
+    for mode in ("lazy", "lazy", "dense"):
+        m = _model(cfg, icl, l2_mode=mode, table_dtype="bf16", matrix_dtype=matrix_dtype)
+        assert m.item_emb.dtype == torch.bfloat16
+        before_user = m.user_emb.clone()
+        losses = [m.train(None, b, 1.0) for b in batches[:3]]
+        assert all(np.isfinite(losses))
+        if mode == "lazy":
+            touched = np.zeros(cfg["user_count"], bool)
+            for b in batches[:3]:
+                touched[np.asarray(b[0])] = True
+            same = (m.user_emb == before_user).all(dim=1).cpu().numpy()
+            assert same[~touched].all()
+            # bookkeeping of the stored values: BCE of the next batch's logits + the L2 term from the tables as stored
+            b = batches[3]
+            li, _, _, _ = m.forward(b, is_test=False)
+            x = li.double().cpu().numpy()
+            y = np.asarray(b[2], np.float64)
+            bce = (np.maximum(x, 0) - x * y + np.log1p(np.exp(-np.abs(x)))).mean()
+            P = m.table_scale()
+            sq = sum(float((t.double() * P).pow(2).sum().item()) for t in (m.item_emb, m.user_emb, m.cate_emb, m.usert_emb))
+            want = bce + reg * 0.5 * sq
+            got = m.train(None, b, 1.0)
+            assert abs(got - want) < 2e-5 * max(1.0, abs(want)), (got, want)
+            losses.append(got)
+        runs[mode if mode not in runs else mode + "2"] = dict(params=m.get_params(), losses=losses)
+    for k in runs["lazy"]["params"]:
+        assert np.array_equal(runs["lazy"]["params"][k], runs["lazy2"]["params"][k]), k
+    assert runs["lazy"]["losses"] == runs["lazy2"]["losses"]
+    assert np.allclose(runs["lazy"]["losses"][:3], runs["dense"]["losses"], rtol=2e-3, atol=0)
+    # (the lazy run took one step more than the dense one above: compare fresh runs of three steps each)
+    pl = _model(cfg, icl, l2_mode="lazy", table_dtype="bf16", matrix_dtype=matrix_dtype)
+    pd = _model(cfg, icl, l2_mode="dense", table_dtype="bf16", matrix_dtype=matrix_dtype)
+    for b in batches[:3]:
+        pl.train_async(b, 1.0)
+        pd.train_async(b, 1.0)
+    ql, qd = pl.get_params(), pd.get_params()
+    for k in ("item_emb", "user_emb", "cate_emb"):
+        a, d_ = np.asarray(ql[k], np.float64), np.asarray(qd[k], np.float64)
+        # (ulp of the element, not below the ulp of 0.01: an element that crosses zero has no meaningful own ulp)
+        ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(d_), 0.01))) - 7)
+        # dense: every element rounded once per step; lazy: touched rows once per step, the scale folded in at the read
+        # (two trajectories whose roundings differ also see slightly different gradients: a tail of a few more ulps)
+        dev = np.abs(a - d_) / ulp
+        assert (dev <= 6.0).mean() > 0.999 and dev.max() <= 24.0, (k, dev.max(), (dev <= 6.0).mean())
+        assert abs(((a - d_) / ulp).mean()) < 0.05, k
+    for k in ("usert_emb", "item_b", "gamma"):
+        a, d_ = np.asarray(ql[k], np.float64), np.asarray(qd[k], np.float64)
+        assert np.abs(a - d_).max() <= 2e-3 * np.abs(d_).max() + 1e-6, k
 
 
 def test_periodic_scale_fold_in_long_lazy_runs():

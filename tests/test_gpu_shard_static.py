@@ -57,11 +57,37 @@ def _one_rank_worker(port, ret):
 
         l0, p0 = run(False, 1)
         for name, args in (("static, one ahead", (True, 1)), ("static, two ahead", (True, 2)), ("static, none ahead", (True, 0)),
-                           ("static, fixed capacity", (2560, 2)), ("static, graphs", (True, 1, True))):
+                           ("static, fixed capacity", (2560, 2)), ("static, graphs", (True, 1, True)),
+                           # (the eager steps leave a plan for the batch after next in the slot the first graph plans into)
+                           ("static, graphs behind steps that announced two ahead", (True, 2, True))):
             l1, p1 = run(*args)
             assert l1 == l0, (name, l0, l1)
             for k in p0:
                 assert np.array_equal(p0[k], p1[k]), (name, k)
+
+        # an announcement that is not honoured: the plans built for it are taken out of their slots again (their
+        # destination index is counted into the slot's state; a second plan on top of it would double every count)
+        order = [0, 3, 1, 2, 0, 1]
+
+        def run_order(static):
+            m = ShardedModel(cfg, icl, device="cuda:0", l2_mode="lazy", static_rows=static)
+            dbs = [m.device_batch(b) for b in batches]
+            losses = []
+            for i, k in enumerate(order):
+                kw = {}
+                if static and i == 0:
+                    kw = dict(next_batch=dbs[1], after_next=dbs[2])     # ... and then batch 3 is trained
+                m.train_async(dbs[k], 0.7, **kw)
+                losses.append(float(m.last_loss.item()))
+            if static:
+                m.check_static_overflow()
+            return losses, m.gather_params()
+
+        la, pa = run_order(False)
+        lb, pb = run_order(True)
+        assert la == lb, ("abandoned announcement", la, lb)
+        for k in pa:
+            assert np.array_equal(pa[k], pb[k]), ("abandoned announcement", k)
 
         # a batch that needs more rows of an owner than the exchange holds is reported, not silently truncated
         m = ShardedModel(cfg, icl, device="cuda:0", l2_mode="lazy", static_rows=64)

@@ -563,7 +563,7 @@ static int launch_fwd(const Shape& s, bool train, const FwdArgs& a, hipStream_t 
   else if (s.D == 128) e = tlsan_launch_fwd_bwd_d128(train, lstream, a, grid, hs);
   else e = tlsan_launch_fwd_bwd_d256(train, lstream, a, grid, hs);
   if (e == hipErrorNotSupported)
-    return fail(TLSAN_E_UNSUPPORTED, "bf16 tables / bf16 matrix products are built for windows up to %d positions and without dropout", TLSAN_LS_MAX);
+    return fail(TLSAN_E_UNSUPPORTED, "dropout > 0 is built for fp32 tables and fp32 matrix products (and for train steps only)");
   if (e != hipSuccess) return fail(TLSAN_E_LAUNCH, "k_fwd_bwd: %s", hipGetErrorString(e));
   return TLSAN_OK;
 }

@@ -21,12 +21,16 @@ static hipError_t launch_variant_dt(const FwdArgs& a, int grid, hipStream_t st) 
   //  workgroups fit a CU's LDS -- 8192 sequences, not fused: 77 us/step with it left out, 95 with it)
   const size_t smem = fwd_smem_bytes<D, DH>(TRAIN, LSTREAM, a.fuse_dk != 0);
   auto k = k_fwd_bwd<D, DH, TRAIN, LSTREAM, DT, DROP, MM>;
-  if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  static size_t smem_set = 0;   // (per kernel variant: the attribute is raised once, not on every launch)
+  if (smem > 48 * 1024 && smem > smem_set) {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    smem_set = smem;
+  }
   hipLaunchKernelGGL(k, dim3(grid), dim3(Geo<D, DH>::NW * 64), smem, st, a);
   return hipGetLastError();
 }
 
-// bf16 table storage: window in registers or streamed; bf16 matrix products: window in registers only
+// bf16 table storage and bf16 matrix products: window in registers or streamed; neither with dropout
 template <int D, int DH, bool TRAIN, bool LSTREAM>
 static hipError_t launch_variant(const FwdArgs& a, int grid, hipStream_t st) {
   if (a.p.matrix_dtype == TLSAN_MATRIX_BF16) {  // bf16 matrix products: either window form, either table storage, no dropout

@@ -49,6 +49,7 @@ from . import _lib as L
 from .model import DENSE_KEYS, TABLE_KEYS, DeviceBatch, Model, _Var, _Writer, concurrent_streams
 
 
+_STATE_HDR_BYTES = 256   # sizeof(StateHdr), csrc/tlsan_update.h: what tlsan_state_reindex keeps
 _STATIC_SLOTS = 4     # routing plans of the static-shape step: the current batch and up to two announced successors
 
 
@@ -753,6 +754,7 @@ class ShardedModel:
         side, side2 = concurrent_streams(self.device, 2)     # on hardware queues of their own (see there)
         st = dict(cap=cap, n=n, kcap=kcap, B=db.B,
                   status=torch.zeros(1, dtype=torch.int32, device=dev),
+                  status_host=torch.zeros(1, dtype=torch.int32).pin_memory(), status_step=0,   # mirror of `status`, copied behind every plan
                   stamp=torch.ones(1, dtype=torch.int32, device=dev),           # uint32 on the device side; never 0
                   gf=torch.zeros(n, W, dtype=torch.float32, device=dev),
                   vals=torch.zeros(n, W, dtype=torch.float32, device=dev) if G > 1 else None,
@@ -760,9 +762,14 @@ class ShardedModel:
                   slots=[None] * _STATIC_SLOTS, next=0, side=side, side2=side2,
                   fork=torch.cuda.Event(),
                   side_group=None, checked=0, graphs=0, warm=False)
-        if G > 1:
+        if G > 1 and (_staged(self.group) or os.environ.get("TLSAN_SIDE_COMM", "0") == "1"):
             # the next batch's id exchange runs on the side stream while the main stream's collectives are in
-            # flight: a communicator of its own keeps the two sequences independent
+            # flight: a communicator of its own keeps the two sequences independent.  Two RCCL communicators with
+            # kernels in flight on one device are only safe if every rank's GPU schedules them in a compatible
+            # order, which has never been exercised on hardware (the pool's boxes have one GPU): over RCCL this is
+            # opt-in (TLSAN_SIDE_COMM=1); by default the id exchange of a plan built ahead is issued by the step that
+            # uses it, on the main stream (one more small all-to-all on the critical path, no second communicator).
+            # The host-staged gloo exchange of the tests is serial either way and keeps the side group.
             ranks = list(range(G)) if self.group is None else dist.get_process_group_ranks(self.group)
             st["side_group"] = dist.new_group(ranks, backend=dist.get_backend(self.group))
             # communicators are set up at their first collective: do that here, on every rank at the same point, not in
@@ -841,12 +848,29 @@ class ShardedModel:
         sl["views"][id(db)] = (db, out)
         return out
 
+    def _static_discard(self, sl, stream):
+        """A plan that was built into the slot and never trained (an announcement that was abandoned, a restore, a
+        capture over a slot an eager step had planned): its destination index is still counted into the slot's
+        state -- tlsan_batch_index only ADDS to the use counters, the step that consumes a plan counts them back to
+        zero -- so a second plan on top would double every count and the row sums would run past their segments.
+        Clear everything behind the state's header (the category index is rebuilt by every plan anyway), after
+        whatever the abandoned plan still has in flight."""
+        if sl["pending"] and not torch.cuda.is_current_stream_capturing():
+            stream.wait_event(sl["done"][0])
+            stream.wait_event(sl["done"][1])
+        with torch.cuda.stream(stream):
+            sl["state"][_STATE_HDR_BYTES:].zero_()
+        sl["pending"] = sl["fresh"] = False
+        sl["db"] = None
+
     def _static_plan(self, db, k, stream, group, stream2=None):
         """Routing plan of `db` into slot k, destination index included: device work only, queued on `stream`
         (the destination index on `stream2` when given: it needs the plan's compact ids, the category index needs its
         category map -- two independent tails; the slot's `done` events then mark their ends)."""
         st, r = self._st, self.router
         sl = st["slots"][k]
+        if sl["fresh"]:          # an unconsumed plan sits in the slot: take its index out first
+            self._static_discard(sl, stream)
         sp = C.c_void_p(stream.cuda_stream)
         nk = int(db.keys.numel())
         cp, cb = self._static_views(sl, db)
@@ -855,15 +879,27 @@ class ShardedModel:
                                                  sl["n_uniq"].data_ptr(), sl["sendbuf"].data_ptr(), st["cap"],
                                                  sl["cate_c"].data_ptr(), sl["comp"].data_ptr(), None,
                                                  st["status"].data_ptr(), sp), "tlsan_route_plan_static")
+        if not torch.cuda.is_current_stream_capturing():
+            # the overflow word travels to pinned host memory behind the plan that may have raised it (on the plan's own
+            # stream: nothing on the step's critical path); the next steps look at the copy without synchronising
+            with torch.cuda.stream(stream):
+                st["status_host"].copy_(st["status"], non_blocking=True)
         dims = st["dims"]
         if stream2 is not None:
             stream2.wait_stream(stream)
             L.check(self.lib.tlsan_batch_index(C.byref(dims), C.byref(cb), sl["state"].data_ptr(), 0,
                                                C.c_void_p(stream2.cuda_stream)), "tlsan_batch_index")
             sl["done"][1].record(stream2)
+        sl["ids_sent"] = True
         if self.world > 1:
-            with torch.cuda.stream(stream):
-                a2a(sl["recvbuf"].view(-1), sl["sendbuf"].view(-1), None, None, group)
+            if group is None and stream != torch.cuda.current_stream(self.device) and not _staged(self.group):
+                # plan built ahead on a side stream and no communicator of its own for it (the default, see
+                # _static_setup): the id exchange is left to the step that uses the plan, on the main stream, in the
+                # main communicator's program order
+                sl["ids_sent"] = False
+            else:
+                with torch.cuda.stream(stream):
+                    a2a(sl["recvbuf"].view(-1), sl["sendbuf"].view(-1), None, None, group if group is not None else self.group)
         L.check(self.lib.tlsan_state_recategorize(C.byref(dims), C.byref(cp), sl["state"].data_ptr(), sp), "tlsan_state_recategorize")
         if stream2 is None:
             L.check(self.lib.tlsan_batch_index(C.byref(dims), C.byref(cb), sl["state"].data_ptr(), 0, sp), "tlsan_batch_index")
@@ -890,6 +926,14 @@ class ShardedModel:
         NS = _STATIC_SLOTS
         main = torch.cuda.current_stream(self.device)
         capturing = torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            # an exchange that overflowed (a plan needed more rows of one owner than `cap`) truncates the step on the
+            # device: seen here one or two steps later through the pinned copy -- not at the next 1024-step check
+            need = int(st["status_host"][0])
+            if need > st["cap"]:
+                raise RuntimeError("static_rows: a batch planned around step %d needed %d rows of one owner, the exchange "
+                                   "holds %d per pair: the steps since then are wrong; rebuild the model with static_rows >= %d"
+                                   % (self._step, need, st["cap"], need))
         k = st["next"]
         sl = st["slots"][k]
         if sl["db"] is not db or not sl["fresh"]:      # not announced by an earlier step: plan it now, in line
@@ -903,6 +947,9 @@ class ShardedModel:
                 main.wait_event(sl["done"][1])
             sl["pending"] = False
         sl["fresh"] = False
+        if G > 1 and not sl.get("ids_sent", True):     # (plan built ahead without a side communicator: see _static_plan)
+            a2a(sl["recvbuf"].view(-1), sl["sendbuf"].view(-1), None, None, self.group)
+            sl["ids_sent"] = True
         st["next"] = (k + 1) % NS
         ahead = [(self.device_batch(b), (k + 1 + j) % NS) for j, b in enumerate((next_batch, after_next)) if b is not None]
         ahead = [(b, kk) for b, kk in ahead if not (st["slots"][kk]["db"] is b and st["slots"][kk]["fresh"])]
@@ -1007,7 +1054,9 @@ class ShardedModel:
             sl["pending"] = False
         if st["slots"][k0]["db"] is not db or not st["slots"][k0]["fresh"]:   # the recorded step expects its plan in place
             self._static_plan(db, k0, main, self.group)
-        st["slots"][k1]["fresh"] = False                      # ... and builds the next one itself, every time
+        if st["slots"][k1]["fresh"]:                          # (an eager step announced a batch into k1: the graph builds the
+            self._static_discard(st["slots"][k1], main)       #  next plan itself, every replay -- not on top of that one)
+        st["slots"][k1]["fresh"] = False
         self._static_views(st["slots"][k0], db)               # ctypes structs are built outside the capture
         self._static_views(st["slots"][k1], ndb)
         torch.cuda.synchronize(self.device)
@@ -1269,7 +1318,12 @@ class ShardedModel:
         if self._st is not None:       # static-shape step: no plan is pending, the stamps restart
             self._st["stamp"].fill_(1)
             self._st["next"] = 0
+            main = torch.cuda.current_stream(self.device)
+            main.wait_stream(self._st["side"])
+            main.wait_stream(self._st["side2"])
             for sl in self._st["slots"]:
+                if sl["fresh"]:            # a plan nobody will train: its counters must not meet the next plan's
+                    self._static_discard(sl, main)
                 sl["db"] = None
                 sl["fresh"] = sl["pending"] = False
 

@@ -218,7 +218,7 @@ class Model(object):
             raise ValueError("init must be 'numpy' or 'device'")
         # matrix_dtype: arithmetic of the fused kernel's matrix products -- "f32": exact fp32 MFMA (the reference's
         # precision); "bf16": operands rounded to bfloat16, fp32 products and sums (include/tlsan.h,
-        # tlsan_params.matrix_dtype).  An extension for BASELINE.json configs[2]; windows up to 10, no dropout.
+        # tlsan_params.matrix_dtype).  An extension for BASELINE.json configs[2]; any window the kernels take (in registers or streamed), no dropout.
         if matrix_dtype not in ("f32", "bf16"):
             raise ValueError("matrix_dtype must be 'f32' or 'bf16'")
         self.matrix_dtype = matrix_dtype
@@ -714,6 +714,13 @@ class Model(object):
         li, lj, _, _ = self.forward(batch, is_test=True)
         return float(((li - lj) > 0).float().mean().item())
 
+    def pairs_ranked_right(self, batch):
+        """Per test row: logit(pos) - logit(neg) > 0 (bool tensor on the device) -- what eval_auc averages.  A row's
+        value does not depend on which other rows share its batch, so the driver evaluates in large launches and forms
+        the reference's per-batch means from slices (train.eval_auc)."""
+        li, lj, _, _ = self.forward(batch, is_test=True)
+        return (li - lj) > 0
+
     def label_ranks(self, batch):
         """rank of the positive item among all items for each test row (model.py:140-156)."""
         li, lj, ut, db = self.forward(batch, is_test=True, want_u_t=True)
@@ -724,20 +731,21 @@ class Model(object):
                 "tlsan_eval_ranks")
         return ranks
 
-    def _hits(self, batch):
-        r = self.label_ranks(batch).cpu().numpy()
+    def _hits(self, batch, ranks=None):
+        r = self.label_ranks(batch).cpu().numpy() if ranks is None else np.asarray(ranks)
         return np.array([(r < k).sum() for k in KS], np.int64), len(r)
 
-    def eval_prec(self, sess, batch):
+    def eval_prec(self, sess, batch, ranks=None):
         """Streaming precision_at_k update ops (model.py:265-281); counters are cumulative over
-        every call, like the reference's never-reset local variables (train.py:75-76,82)."""
-        h, n = self._hits(batch)
+        every call, like the reference's never-reset local variables (train.py:75-76,82).
+        ranks (optional): the label ranks of this batch's rows, already computed (label_ranks on a larger launch)."""
+        h, n = self._hits(batch, ranks)
         self._hits_p += h
         self._n_p += n
         return [self._hits_p[i] / (k * self._n_p) for i, k in enumerate(KS)]
 
-    def eval_recall(self, sess, batch):
-        h, n = self._hits(batch)
+    def eval_recall(self, sess, batch, ranks=None):
+        h, n = self._hits(batch, ranks)
         self._hits_r += h
         self._n_r += n
         return [self._hits_r[i] / self._n_r for i in range(len(KS))]

@@ -115,30 +115,53 @@ def epoch_rng(seed=1234):
     return random.Random(seed)
 
 
-def _test_batches(test_set, config):
+# Evaluation launches: the reference feeds its test set in batches of test_batch_size (128) and aggregates per batch
+# (train.py:86-118).  What a test row contributes -- whether its pair is ranked right, the rank of its label -- does
+# not depend on the rows it shares a batch with (padded session slots are masked), so the kernels run on chunks of
+# EVAL_CHUNK rows (the all-items ranking reaches 39 % of the fp32 matrix peak at 4096 rows per launch and 6 % at 128)
+# and the reference's per-batch aggregation is formed from slices of the per-row results: same numbers, same order.
+EVAL_CHUNK = 4096
+
+
+def _test_batches(test_set, config, batch_size=None):
+    bs = batch_size or config["test_batch_size"]
     if isinstance(test_set, PackedSet):
-        return DataInputTest(test_set, config["test_batch_size"], config["Ls"])
+        return DataInputTest(test_set, bs, config["Ls"])
     from .device_input import DeviceDataInputTest
-    return DeviceDataInputTest(test_set, config["test_batch_size"], config["Ls"])
+    return DeviceDataInputTest(test_set, bs, config["Ls"])
+
+
+def _per_row(model, test_set, config, fn):
+    """fn(batch) -> per-row device tensor, over the whole test set in chunks of EVAL_CHUNK rows; one host copy."""
+    import torch
+    chunk = max(EVAL_CHUNK, config["test_batch_size"]) // config["test_batch_size"] * config["test_batch_size"]
+    parts = [fn(batch) for _, batch in _test_batches(test_set, config, chunk)]
+    return torch.cat(parts).cpu().numpy()
 
 
 def eval_auc(model, test_set, config):
     """train.py:86-96: batch AUCs weighted by batch length."""
-    s = 0.0
-    for _, batch in _test_batches(test_set, config):
-        s += model.eval_auc(None, batch) * len(batch[0] if isinstance(batch, tuple) else batch)
+    ok = _per_row(model, test_set, config, model.pairs_ranked_right)
+    s, bs = 0.0, config["test_batch_size"]
+    for lo in range(0, len(ok), bs):
+        part = ok[lo:lo + bs]
+        auc_b = float(np.float32(part.sum()) / np.float32(len(part)))      # model.py:263: a float32 mean of 0/1
+        s += auc_b * len(part)
     res = s / len(test_set)
     model.eval_writer.add_summary(("AUC", res), global_step=model.global_step.eval())     # train.py:91-94
     return res
 
 
 def eval_prec_recall(model, test_set, config):
-    """train.py:98-118: one pass for precision, one for recall (cumulative counters, as the reference)."""
-    for _, batch in _test_batches(test_set, config):
-        model.eval_prec(None, batch)
+    """train.py:98-118: one pass for precision, one for recall (cumulative counters, as the reference); the label
+    ranks both passes need are computed once."""
+    ranks = _per_row(model, test_set, config, model.label_ranks)
+    bs = config["test_batch_size"]
+    for lo in range(0, len(ranks), bs):
+        model.eval_prec(None, None, ranks=ranks[lo:lo + bs])
     prec = [getattr(model, "prec_%d" % k).eval() for k in KS]
-    for _, batch in _test_batches(test_set, config):
-        model.eval_recall(None, batch)
+    for lo in range(0, len(ranks), bs):
+        model.eval_recall(None, None, ranks=ranks[lo:lo + bs])
     recall = [getattr(model, "recall_%d" % k).eval() for k in KS]
     step = model.global_step.eval()
     model.eval_writer.add_summary([("P@%d" % k, v) for k, v in zip(KS, prec)] +                 # train.py:103-106
