@@ -56,7 +56,8 @@ def main():
             r = T.train(args, data=(train_set, test_set, (U, I, C), z["item_cate_list"].astype(np.int32)))
             res.append(dict(seed=seed, init_auc=r["init_auc"], best_auc=r["best_auc"], final_auc=r["final_auc"],
                             steps=r["steps"], seconds=round(r["seconds"], 1),
-                            best_step=max(r["history"], key=lambda h: h[2])[0] if r["history"] else None))
+                            best_step=max(r["history"], key=lambda h: h[2])[0] if r["history"] else None,
+                            curve=[[int(h[0]), round(float(h[2]), 5)] for h in r["history"]]))   # (step, test AUC) at every evaluation
             print("# %s seed %d: best %.4f (step %s) final %.4f init %.4f, %d steps in %.0f s"
                   % (name, seed, r["best_auc"], res[-1]["best_step"], r["final_auc"], r["init_auc"], r["steps"], r["seconds"]),
                   file=sys.stderr, flush=True)
