@@ -289,7 +289,7 @@ def main():
     nprof = min(args.steps, 4096)
     lib.tlsan_profile_stride(1 if use_graph else args.event_every)   # graph mode: only the eager steps reach the marks
     lib.tlsan_profile_enable(args.profile_level)
-    run(nprof, args.warmup, timed=True)
+    run(nprof, args.warmup + args.steps, timed=True)     # (continues the batch cycle: the next two batches are announced)
     fence()
     buf = (ctypes.c_float * (nprof * 5))()
     nrec = lib.tlsan_profile_collect(buf, nprof)
@@ -326,7 +326,7 @@ def main():
             lib.tlsan_profile_stride(args.event_every)      # (kernel time: a pass of its own, as for the headline)
             lib.tlsan_profile_enable(args.profile_level)
             for s in range(args.steps):
-                k = (args.warmup + s) % len(dbs)
+                k = (args.warmup + args.steps + s) % len(dbs)
                 mv.train_async(dbs[k], lr, next_batch=dbs[(k + 1) % len(dbs)], after_next=dbs[(k + 2) % len(dbs)])
             torch.cuda.synchronize()
             pb = (ctypes.c_float * (nprof * 5))()

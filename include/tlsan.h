@@ -178,6 +178,7 @@ int tlsan_state_init(const tlsan_dims* dims, const tlsan_params* p, void* state,
 /* Address (inside `state`) of the table scale P maintained by TLSAN_L2_LAZY steps. */
 const float* tlsan_state_scale(const void* state);
 
+
 /* Fold the scale into the tables (stored *= P, P = 1).  Call before reading the tables as plain
  * parameters (checkpoint) or when P gets small (long lazy runs: P ~ exp(-sum lr c reg)). */
 int tlsan_state_renorm(const tlsan_dims* dims, const tlsan_params* p, void* state, void* stream);

@@ -168,8 +168,7 @@ struct St {  // persistent state
   int32_t *cate_off, *cate_cnt, *cate_cur, *cate_items;   // static CSR category -> items
   StateHdr* hdr;
   double *S_part, *S_total;
-  double* S_spec;                                         // speculative lazy step: per-workgroup changes of the sum of squares, zero at rest
-  int n_spec;
+  DeltaRec* S_delta;                                      // per-workgroup changes of the sum of squares, tagged by step (tlsan_update.h)
   long long* scan_bsum[TLSAN_INDEX_SLOTS];                                // per-chunk sums of the index scan (large tables), per slot
   int32_t* uc_list[TLSAN_INDEX_SLOTS];                                    // samples of every category (u_cate uses), UC_LIST_CAP each
   double* Rc64;                                           // category sums of a split PRESUM pass, zero at rest
@@ -203,8 +202,7 @@ static void carve_state(const tlsan_dims* d, char* base, St* s) {
   s->cate_cur = (int32_t*)take(4 * (size_t)d->cate_count);
   s->cate_items = (int32_t*)take(4 * (size_t)d->item_count);
   s->S_part = (double*)take(8 * (size_t)(s->nbI + s->nbU + s->nbC));
-  s->n_spec = s->nbI + s->nbU + s->nbC + AP_HOT_CAP + 2;   // (+ the hot-row workgroups; lazy block counts round up once per table)
-  s->S_spec = (double*)take(8 * (size_t)s->n_spec);
+  s->S_delta = (DeltaRec*)take(sizeof(DeltaRec) * (size_t)(s->nbI + s->nbU + s->nbC));
   for (int k = 0; k < TLSAN_INDEX_SLOTS; ++k) s->uc_list[k] = (int32_t*)take(4 * (size_t)UC_LIST_CAP);
   s->Rc64 = (double*)take(8 * (size_t)d->cate_count * d->d_cate);
   for (int k = 0; k < TLSAN_INDEX_SLOTS; ++k) s->hot_list[k] = (int32_t*)take(4 * (size_t)AP_HOT_CAP);
@@ -305,7 +303,7 @@ static void fill_apply(ApplyArgs& A, const tlsan_dims* d, const Shape& s, const 
   A.hot_n = st.hdr ? &st.hdr->n_hot[k] : nullptr; A.hot_list = st.hot_list[k]; A.nbH = 0;
   A.gd = w.gd;
   A.Rc = w.Rc; A.Ri = w.Ri; A.Rb = w.Rb; A.Ru = w.Ru;
-  A.part_out = st.S_part; A.hdr = st.hdr;
+  A.part_out = st.S_part; A.delta_out = st.S_delta; A.hdr = st.hdr;
   A.urec_item = st.urec_item[k]; A.urec_user = st.urec_user[k];
   if (hp) { A.lr = hp->lr; A.reg = hp->reg; }
   A.nbI = st.nbI; A.nbU = st.nbU; A.nbC = st.nbC; A.nbD = (L.n_dense + 255) / 256;
@@ -348,31 +346,6 @@ static int launch_update_lazy(ApplyArgs A, int B, int Sn, hipStream_t hs) {
     else hipLaunchKernelGGL((k_update_lazy<false, TLSAN_TABLE_F32>), g1, blk, 0, hs, A, nbC16);
   }
   CHECK_LAUNCH("k_update_lazy");
-  return TLSAN_OK;
-}
-
-// the launch behind the speculative row-sum + update launch: commit of the step, and the correction of a clipped one
-#define COMMIT_FIX_BLOCKS 64
-static int launch_step_commit(ApplyArgs A, const St& st, int B, int Sn, hipStream_t hs) {
-  lazy_blocks(A, B, Sn);
-  CommitArgs c;
-  c.S_spec = st.S_spec;
-  c.n_spec = A.C + A.nbI + A.nbU + AP_HOT_CAP;
-  if (c.n_spec > st.n_spec) return fail(TLSAN_E_WORKSPACE, "S_spec too small (%d > %d)", c.n_spec, st.n_spec);
-  c.S_total = st.S_total;
-  c.count_step = 1;
-  c.nbC16 = (A.C + 15) / 16;
-  c.part_fix = st.S_part;
-  const dim3 g1(1 + COMMIT_FIX_BLOCKS), blk(256);
-  const bool wide = apply_wide(A);
-  if (A.p.table_dtype == TLSAN_TABLE_BF16) {
-    if (wide) hipLaunchKernelGGL((k_step_commit<true, TLSAN_TABLE_BF16>), g1, blk, 0, hs, A, c);
-    else hipLaunchKernelGGL((k_step_commit<false, TLSAN_TABLE_BF16>), g1, blk, 0, hs, A, c);
-  } else {
-    if (wide) hipLaunchKernelGGL((k_step_commit<true, TLSAN_TABLE_F32>), g1, blk, 0, hs, A, c);
-    else hipLaunchKernelGGL((k_step_commit<false, TLSAN_TABLE_F32>), g1, blk, 0, hs, A, c);
-  }
-  CHECK_LAUNCH("k_step_commit");
   return TLSAN_OK;
 }
 
@@ -488,7 +461,7 @@ int tlsan_state_init(const tlsan_dims* d, const tlsan_params* p, void* state, vo
   if ((rc = launch_apply(AP_SUMSQ, false, A, false, 0, 0, hs))) return rc;
   hipLaunchKernelGGL(k_reduce_double, dim3(1), dim3(256), 0, hs, st.S_part, st.nbI + st.nbU + st.nbC, st.S_total);
   CHECK_LAUNCH("k_reduce_double");
-  // from here on S_part carries per-step CHANGES (consumed and cleared by k_dense_finalize)
+  // (per-step CHANGES of the sum travel as tagged records in S_delta, folded by the next step's k_dense_finalize)
   if (hipMemsetAsync(st.S_part, 0, 8 * (size_t)(st.nbI + st.nbU + st.nbC), hs) != hipSuccess) return fail(TLSAN_E_LAUNCH, "memset S_part");
   return TLSAN_OK;
 }
@@ -506,6 +479,8 @@ int tlsan_state_renorm(const tlsan_dims* d, const tlsan_params* p, void* state, 
   const tlsan_params q = norm_params(p, d);
   hipStream_t hs = (hipStream_t)stream;
   const int dt = q.table_dtype;
+  // (changes of the sum of squares the last update left as records: part of St before St is rescaled)
+  hipLaunchKernelGGL(k_fold_delta, dim3(1), dim3(256), 0, hs, st.S_delta, st.nbI + st.nbU + st.nbC, st.hdr, st.S_total);
   hipLaunchKernelGGL(k_scale_table, dim3(1024), dim3(256), 0, hs, q.item_emb, d->item_count, d->d_item, q.ld_item, st.hdr, dt, 0x1b873593u);
   hipLaunchKernelGGL(k_scale_table, dim3(1024), dim3(256), 0, hs, q.user_emb, d->user_count, d->d_item, q.ld_user, st.hdr, dt, 0xcc9e2d51u);
   hipLaunchKernelGGL(k_scale_table, dim3(256), dim3(256), 0, hs, q.usert_emb, d->user_count, d->Ls, q.ld_usert, st.hdr, TLSAN_TABLE_F32, 0u);
@@ -641,7 +616,7 @@ static int build_index(const tlsan_dims* d, const tlsan_batch* b, const St& st, 
 static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params* p, const tlsan_batch* b,
                         const tlsan_hparams* hp, bool update, const tlsan_step_out* out, const Ws& w, const St& st,
                         const tlsan_dense_layout& L, hipStream_t hs, const ApplyArgs* presum = nullptr,
-                        float* gd_out = nullptr, bool spec = false) {
+                        float* gd_out = nullptr) {
   const bool commit = update && hp->l2_mode == TLSAN_L2_LAZY;
   const int k = hp->index_slot;
   int rc;
@@ -692,7 +667,7 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   memset(&f, 0, sizeof(f));
   f.lay = L; f.partials = w.partials; f.nrec = (b->B + grp - 1) / grp; f.Kp = w.Kp; f.nsplit = w.nsplit;
   f.gd = gd_out ? gd_out : w.gd; f.sqd = w.sqd; f.scal = w.scal;
-  f.S_part = st.S_part; f.n_spart = st.nbI + st.nbU + st.nbC; f.S_total = st.S_total;
+  f.S_delta = st.S_delta; f.n_spart = st.nbI + st.nbU + st.nbC; f.S_total = st.S_total;
   f.hdr = st.hdr; f.lr = hp->lr; f.reg = hp->reg; f.clip = hp->clip; f.inv_B = 1.0f / (float)b->B;
   f.norm_mode = hp->norm_mode; f.commit = commit ? 1 : 0; f.count_step = update ? 1 : 0;
   f.out_loss = out ? out->loss : nullptr;
@@ -706,29 +681,6 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
     A.nbH = AP_HOT_CAP;   // hot item rows: a workgroup each, leading the grid
     const dim3 grid(w.nfin + 1 + A.nbH + A.nbC + A.nbI + A.nbU);
     const bool wide = apply_wide(A);
-    if (spec) {
-      // the update rides with the row sums (coefficient 1; k_step_commit follows): see k_finalize_presum<SPEC>
-      f.spec = 1; f.dense = A.p.dense; f.dense_KT = A.p.dense_KT; f.D = s.D;
-      A.part_out = st.S_spec;
-      const bool bf = A.p.table_dtype == TLSAN_TABLE_BF16;
-#define SP_LAUNCH(DD, HH)                                                                                                            \
-  do {                                                                                                                                \
-    if (bf) {                                                                                                                         \
-      if (wide) hipLaunchKernelGGL((k_finalize_presum<DD, HH, true, false, true, TLSAN_TABLE_BF16>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);   \
-      else hipLaunchKernelGGL((k_finalize_presum<DD, HH, false, false, true, TLSAN_TABLE_BF16>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);       \
-    } else {                                                                                                                          \
-      if (wide) hipLaunchKernelGGL((k_finalize_presum<DD, HH, true, false, true, TLSAN_TABLE_F32>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);    \
-      else hipLaunchKernelGGL((k_finalize_presum<DD, HH, false, false, true, TLSAN_TABLE_F32>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);        \
-    }                                                                                                                                 \
-  } while (0)
-      if (s.D == 64) SP_LAUNCH(64, 8);
-      else if (s.D == 128) SP_LAUNCH(128, 16);
-      else SP_LAUNCH(256, 32);
-#undef SP_LAUNCH
-      CHECK_LAUNCH("k_finalize_presum<SPEC>");
-      prof_mark(4, hs);
-      return TLSAN_OK;
-    }
 #define FP_LAUNCH(DD, HH)                                                                                         \
   do {                                                                                                            \
     if (A.csplit > 1) {                                                                                           \
@@ -859,15 +811,10 @@ int tlsan_train_step_opt(const tlsan_dims* d, const tlsan_params* p, const tlsan
       A.oalpha = (float)((double)hp->lr * sqrt(1.0 - pow((double)opt->beta2, opt->step)) / (1.0 - pow((double)opt->beta1, opt->step)));
   }
   static const int split = [] { const char* v = getenv("TLSAN_APPLY_SPLIT"); return v ? atoi(v) : 1; }();
-  // (TLSAN_SPEC_UPDATE=0: the three-launch form -- row sums, then k_update_lazy once the coefficient is known)
-  static const int spec_on = [] { const char* v = getenv("TLSAN_SPEC_UPDATE"); return v ? atoi(v) : 0; }();
   if (hp->l2_mode == TLSAN_L2_LAZY && split) {
     category_split(A, d, b);
-    const bool spec = spec_on && A.csplit == 1;   // (a split category has no single workgroup that could update its row)
-    if ((rc = run_backward(d, s, p, b, hp, true, out, w, st, L, hs, &A, nullptr, spec))) return rc;
-    if (spec) {
-      if ((rc = launch_step_commit(A, st, b->B, b->Sn, hs))) return rc;
-    } else if ((rc = launch_update_lazy(A, b->B, b->Sn, hs))) return rc;
+    if ((rc = run_backward(d, s, p, b, hp, true, out, w, st, L, hs, &A))) return rc;
+    if ((rc = launch_update_lazy(A, b->B, b->Sn, hs))) return rc;
   } else {
     if ((rc = run_backward(d, s, p, b, hp, true, out, w, st, L, hs))) return rc;
     if (hp->norm_mode == TLSAN_NORM_DEDUP && (rc = clip_dedup(A, hp, out, w, st, b, hs))) return rc;

@@ -22,15 +22,24 @@ struct StateHdr {
   double St;               // sum of squares of the four STORED tables (true value: P^2 * St)
   float coef;              // global-norm clip coefficient of the current step (model.py:201)
   uint32_t nstep;          // update steps taken (salt of the stochastic rounding of bf16 tables)
-  int32_t spart_n;         // leading entries of S_part the last update may have written (the rest is zero)
+  int32_t spart_n;         // leading records of S_delta the last update may have written
   int32_t n_hot[TLSAN_INDEX_SLOTS];        // [index slot] item rows with more than AP_HOT uses (k_index_scan; listed in the state)
-  float P_next;            // speculative lazy step (k_finalize_presum<SPEC>): the scale k_step_commit makes current
+  uint32_t folded;         // the step (nstep) whose S_delta records are already part of St (a step is folded once)
   float pad0[15];
   // ---- its own 128-B line: hammered by atomics, must not share a line with anything that is read
   int32_t ticket;          // arrival counter of k_dense_finalize: the last workgroup writes the step summary
   int32_t pad1[31];
 };
 static_assert(sizeof(StateHdr) == 256, "StateHdr layout");
+
+// A workgroup's change of the stored tables' sum of squares, tagged with the step that made it (StateHdr::nstep after
+// that step).  The next step's finalize adds up the records of the previous step, once (StateHdr::folded), and ignores
+// older ones: nothing is ever cleared.  (Round 2 kept plain doubles that the finalize cleared as it consumed them;
+// tlsan_state_renorm then rescaled a sum that lacked the last step's changes.)
+struct DeltaRec {
+  double v;
+  unsigned long long tag;
+};
 
 #define AP_HOT 48        // item rows with more uses than this are summed by a workgroup of their own ...
 #define AP_HOT_CAP 64    // ... when there are at most this many (the head of a Zipf distribution: a handful)
@@ -346,7 +355,7 @@ struct FinArgs {
   float* gd;              // [n_dense] reduced dense gradients
   float* sqd;             // [nbK + nbS] per-block sum of gd^2
   float* scal;            // [0] = sum of per-sample BCE, [1] = sum of squares of per-use rows
-  double* S_part;         // per-row-block changes of the regularised tables' sum of squares
+  const DeltaRec* S_delta; // per-workgroup changes of the regularised tables' sum of squares, tagged by step
   int32_t n_spart;
   double* S_total;
   // step summary (written by the last workgroup to arrive)
@@ -356,9 +365,6 @@ struct FinArgs {
   int32_t commit;          // lazy L2 update: advance the table scale P (P_prev keeps the old value)
   int32_t count_step;      // an update follows (train step, not tlsan_grads): advance hdr->nstep
   float* out_loss; float* out_gnorm; float* out_sq;
-  // speculative lazy step: the dense parameters are updated here with coefficient 1 (k_step_commit corrects a clipped step)
-  int32_t spec;
-  float* dense; float* dense_KT; int32_t D;
 };
 
 // The step's scalars, computed once by the last workgroup of k_dense_finalize instead of by every
@@ -404,13 +410,8 @@ __device__ __forceinline__ void step_summary(const FinArgs& a, int nsqd, double*
     const float coef = a.clip / fmaxf(norm, a.clip);
     a.hdr->coef = coef;
     a.hdr->P_prev = P;
-    if (a.spec) {
-      // the row workgroups of this launch still read P and nstep: k_step_commit (the next launch) makes these current
-      a.hdr->P_next = P * (1.0f - a.lr * coef * a.reg);
-    } else {
-      if (a.count_step) a.hdr->nstep += 1;
-      if (a.commit) a.hdr->P = P * (1.0f - a.lr * coef * a.reg);
-    }
+    if (a.count_step) a.hdr->nstep += 1;
+    if (a.commit) a.hdr->P = P * (1.0f - a.lr * coef * a.reg);
     if (a.norm_mode == TLSAN_NORM_TF18 && a.out_gnorm) *a.out_gnorm = norm;
     if (a.out_loss) *a.out_loss = sc0 * a.inv_B + a.reg * (float)(0.5 * St);
     if (a.out_sq) *a.out_sq = sc1;
@@ -438,6 +439,39 @@ __device__ __forceinline__ double block_sum_double(const double* __restrict__ v,
   return sh[0];
 }
 
+// The apply kernels leave per-workgroup CHANGES of the tables' sum of squares (DeltaRec, tagged by step): add the records
+// of the last update to the running sum, once (StateHdr::folded).  One 256-thread workgroup, fixed order.
+__device__ __forceinline__ void fold_delta(const DeltaRec* __restrict__ recs, int n_spart, StateHdr* hdr, double* S_total, double* shd) {
+  const int tid = threadIdx.x;
+  const unsigned long long tag = hdr->nstep;     // (the records of the last update; this step's summary has not run yet)
+  // (a step's records are added once: a gradient-only call between two updates finds them folded)
+  const int np = hdr->folded == (uint32_t)tag ? 0 : min(n_spart, hdr->spart_n);
+  double s = 0.0;
+  for (int k0 = tid; k0 < np; k0 += 256 * 8) {     // 8 records in flight (clamped addresses, masked sum), fixed order
+    DeltaRec t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = recs[k0 + 256 * u < np ? k0 + 256 * u : k0];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (k0 + 256 * u < np && t[u].tag == tag) ? t[u].v : 0.0;
+  }
+  shd[tid] = s;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (tid < o) shd[tid] += shd[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    pub_f64(S_total, *S_total + shd[0]);
+    hdr->folded = (uint32_t)tag;
+  }
+}
+
+// (tlsan_state_renorm: the sum of squares must be complete before it is rescaled)
+__global__ __launch_bounds__(256) void k_fold_delta(const DeltaRec* recs, int n_spart, StateHdr* hdr, double* S_total) {
+  __shared__ double shd[256];
+  fold_delta(recs, n_spart, hdr, S_total, shd);
+}
+
 // Grid: [0, nbK) blocks reduce the D*D kernel gradient over the batch splits (one thread per
 // entry); [nbK, nbK+nbS) blocks reduce the small parameters over the per-pass partial records
 // with 16 lanes per parameter (lane l sums records l, l+16, ...; fixed xor tree after);
@@ -453,10 +487,7 @@ __device__ __forceinline__ void dense_finalize_block(const FinArgs& a, int nbK, 
     // and clear them (consumed exactly once)
     // (only the entries the last update can have written: a lazy update of a 10^7-row table leaves
     //  a few thousand, not rows / 16)
-    const int np = min(a.n_spart, a.hdr->spart_n);
-    const double s = block_sum_double(a.S_part, np, shd);
-    for (int k = tid; k < np; k += 256) a.S_part[k] = 0.0;
-    if (tid == 0) pub_f64(a.S_total, *a.S_total + s);
+    fold_delta(a.S_delta, a.n_spart, a.hdr, a.S_total, shd);
     __syncthreads();  // shd is reused below
   }
   float g = 0.0f;
@@ -483,11 +514,6 @@ __device__ __forceinline__ void dense_finalize_block(const FinArgs& a, int nbK, 
       g = (g0 + g1) + (g2 + g3);
       a.gd[L.K + idx] = g;
       owner = true;
-      if (a.spec) {
-        const float wn = a.dense[L.K + idx] - a.lr * g;
-        a.dense[L.K + idx] = wn;
-        a.dense_KT[(size_t)(idx % D) * D + idx / D] = wn;
-      }
     }
   } else {
     const int m = (blk - nbK) * 16 + (tid >> 4), rl = tid & 15;
@@ -533,7 +559,6 @@ __device__ __forceinline__ void dense_finalize_block(const FinArgs& a, int nbK, 
       if (rl == 0) {
         a.gd[n] = g;
         owner = true;
-        if (a.spec) a.dense[n] -= a.lr * g;
       }
     }
   }
@@ -609,9 +634,7 @@ __global__ void k_transpose_K(const float* __restrict__ K, float* __restrict__ K
 
 // ------------------------------------------------------------------------------------------
 enum { AP_UPDATE = 0, AP_GRADS = 1, AP_SUMSQ = 2, AP_ROWNORM = 3,
-       AP_PRESUM = 4,    // PRESUM: only the exact per-row sums, left in Rc / Ri / Rb / Ru for k_update_lazy
-       AP_SPEC = 5 };    // SPEC: the sums as PRESUM leaves them AND the lazy update with clip coefficient 1 (k_step_commit
-                         // corrects the rows of a step whose norm turned out above the clip -- one step in some hundreds)
+       AP_PRESUM = 4 };  // PRESUM: only the exact per-row sums, left in Rc / Ri / Rb / Ru for k_update_lazy
 
 struct ApplyArgs {
   tlsan_params p;
@@ -637,8 +660,8 @@ struct ApplyArgs {
   // workgroups lead the grid, the item-row workgroups leave those rows to them (when the list did not overflow)
   const int32_t* hot_n; const int32_t* hot_list; int32_t nbH;
   double* Rc64;            // [C][dc], zero at rest (state)
-  double* part_out;        // UPDATE: change of the stored tables' sum of squares per workgroup;
-                           // SUMSQ: sum of squares; ROWNORM: sum g^2
+  double* part_out;        // SUMSQ: sum of squares per workgroup; ROWNORM: sum g^2
+  DeltaRec* delta_out;     // UPDATE: change of the stored tables' sum of squares per workgroup, tagged with the step
   StateHdr* hdr;           // P, P_prev, coef (read); spart_n (written by an update)
   const int32_t* n_uniq_item; const int32_t* n_uniq_user;   // used-row counts of this step's index slot
   float lr, reg;
@@ -693,6 +716,18 @@ __device__ __forceinline__ void combine_groups(double (&acc)[NCH][4]) {
       acc[ch][i] += __shfl_xor(acc[ch][i], 16);
       acc[ch][i] += __shfl_xor(acc[ch][i], 32);
     }
+}
+
+__device__ __forceinline__ void block_delta_store(double part, double* shd, DeltaRec* dst, unsigned long long tag) {
+  __syncthreads();
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) part += __shfl_xor(part, o);
+  if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    dst->v = shd[0] + shd[1] + shd[2] + shd[3];
+    dst->tag = tag;
+  }
 }
 
 __device__ __forceinline__ void block_part_store(double part, double* shd, double* dst) {
@@ -818,10 +853,7 @@ struct ApCtx {
 template <int MODE, bool LAZY, int NCH, int DT, bool CSPLIT = false>
 __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx& x, double* shd, double* shp,
                                                  int* sh_pos, int* sh_lo, int* sh_n, int* sh_wtot) {
-  constexpr bool RESET = MODE == AP_UPDATE || MODE == AP_GRADS || MODE == AP_PRESUM || MODE == AP_SPEC;  // counters are zero at rest
-  constexpr bool SUMS = MODE == AP_PRESUM || MODE == AP_SPEC;   // leaves the exact row sums in Rc / Ri / Rb / Ru
-  constexpr int UM = MODE == AP_SPEC ? AP_UPDATE : MODE;         // the element arithmetic (SPEC: the lazy update, coefficient 1)
-  static_assert(!(MODE == AP_SPEC && CSPLIT), "a split category has no single owner to update it");
+  constexpr bool RESET = MODE == AP_UPDATE || MODE == AP_GRADS || MODE == AP_PRESUM;  // counters are zero at rest
   const int tid = x.tid, wave = x.wave, lane = x.lane, grp = x.grp, l16 = x.l16, gid = x.gid;
   int c = x.blk, split = 0, nsplit = 1;
   if constexpr (MODE == AP_PRESUM && CSPLIT) {  // (a compile-time variant: the common single-workgroup case pays nothing)
@@ -928,7 +960,7 @@ __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx
     }
   }
   AP_STAMP(3);
-  if constexpr (SUMS) {
+  if constexpr (MODE == AP_PRESUM) {
     if (wave == 0 && grp == 0) {
 #pragma unroll
       for (int ch = 0; ch < NCH; ++ch) {
@@ -942,15 +974,13 @@ __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx
             f32x4 g;
 #pragma unroll
             for (int i = 0; i < 4; ++i) g[i] = (float)acc[ch][i];
-            st4_out(a.Rc + wrow + 4 * c4, g);
+            *(f32x4*)(a.Rc + wrow + 4 * c4) = g;
           }
         }
       }
     }
-    if constexpr (MODE == AP_PRESUM) {
-      if (tid == 0 && split == 0 && nu > 0) a.cnt_uc[c] = 0;
-      return;
-    }
+    if (tid == 0 && split == 0 && nu > 0) a.cnt_uc[c] = 0;
+    return;
   }
   if (wave == 0 && grp == 0) {
 #pragma unroll
@@ -963,11 +993,11 @@ __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float wi = w[ch][i];
-          g[i] = apply_elem<UM, LAZY>(wi, (float)acc[ch][i], x.P, x.invP, a.reg, x.step, x.lazy_scale, pe);
+          g[i] = apply_elem<MODE, LAZY>(wi, (float)acc[ch][i], x.P, x.invP, a.reg, x.step, x.lazy_scale, pe);
           w[ch][i] = wi;
         }
         if constexpr (MODE == AP_GRADS) *(f32x4*)(a.go.cate_emb + (size_t)c * a.dc + 4 * c4) = g;
-        if constexpr (UM == AP_UPDATE && !LAZY) {
+        if constexpr (MODE == AP_UPDATE && !LAZY) {
           if (a.opt != TLSAN_OPT_SGD) {
             f32x4 m1 = *(const f32x4*)(a.s1.cate_emb + wrow + 4 * c4), m2 = *(const f32x4*)(a.s2.cate_emb + wrow + 4 * c4);
 #pragma unroll
@@ -980,7 +1010,7 @@ __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx
             *(f32x4*)(a.s2.cate_emb + wrow + 4 * c4) = m2;
           }
         }
-        if constexpr (UM == AP_UPDATE) {
+        if constexpr (MODE == AP_UPDATE) {
           tbl_st4<DT>(a.p.cate_emb, wrow + 4 * c4, w[ch], x.salt ^ 0x3c6ef372u);
 #pragma unroll
           for (int i = 0; i < 4; ++i) part += (double)w[ch][i] * (double)w[ch][i] - (double)w0[i] * (double)w0[i];
@@ -993,7 +1023,8 @@ __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx
   if constexpr (RESET) {
     if (tid == 0 && nu > 0) a.cnt_uc[c] = 0;
   }
-  if constexpr (MODE != AP_GRADS) block_part_store(part, shp, &a.part_out[x.blk]);
+  if constexpr (MODE == AP_UPDATE) block_delta_store(part, shp, &a.delta_out[x.blk], x.salt);
+  else if constexpr (MODE != AP_GRADS) block_part_store(part, shp, &a.part_out[x.blk]);
 }
 
 // ================= 16 item rows or 16 user rows per workgroup (one row per 16-lane group) =========
@@ -1001,9 +1032,7 @@ __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx
 // in flight per group; longer segments are finished by the whole wavefront.
 template <int MODE, bool LAZY, bool IS_ITEM, int NCH, int OWN, int DT>
 __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx& x, int slot0, double* shp) {
-  constexpr bool RESET = MODE == AP_UPDATE || MODE == AP_GRADS || MODE == AP_PRESUM || MODE == AP_SPEC;
-  constexpr bool SUMS = MODE == AP_PRESUM || MODE == AP_SPEC;
-  constexpr int UM = MODE == AP_SPEC ? AP_UPDATE : MODE;
+  constexpr bool RESET = MODE == AP_UPDATE || MODE == AP_GRADS || MODE == AP_PRESUM;
   const int lane = x.lane, grp = x.grp, l16 = x.l16;
   const int slot = slot0 + x.gid;
   int row = 0, off = 0, n = 0;
@@ -1015,7 +1044,7 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
     const int4 r = (IS_ITEM ? a.urec_item : a.urec_user)[slot];  // (row, first position, uses)
     vr = slot < nuq;
     if (vr) { row = r.x; off = r.y; n = r.z; }
-    if constexpr (SUMS && IS_ITEM) {
+    if constexpr (MODE == AP_PRESUM && IS_ITEM) {
       if (a.nbH > 0 && n > AP_HOT && *a.hot_n <= AP_HOT_CAP) { vr = false; n = 0; }   // a hot-row workgroup sums it
     }
   } else {
@@ -1111,9 +1140,9 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
     }
   }
   AP_STAMP(3);
-  if constexpr (SUMS) {
+  if constexpr (MODE == AP_PRESUM) {
     if (vr) {
-      const bool by_row = MODE == AP_PRESUM && a.presum_rows != 0;  // (workgroup-uniform)
+      const bool by_row = a.presum_rows != 0;  // (workgroup-uniform)
       float* R = IS_ITEM ? a.Ri + (size_t)slot * a.di : a.Ru + (size_t)slot * a.WU;
       if (by_row) R = IS_ITEM ? a.go.item_emb + (size_t)row * a.go.ld_item : a.go.user_emb + (size_t)row * a.go.ld_user;
 #pragma unroll
@@ -1124,7 +1153,7 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
 #pragma unroll
           for (int i = 0; i < 4; ++i) g[i] = (float)acc[ch][i];
           if (!by_row || 4 * c4 < a.di) {
-            st4_out(R + 4 * c4, g);
+            *(f32x4*)(R + 4 * c4) = g;
           } else {  // usert_emb columns of a user row
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -1136,9 +1165,9 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
       }
       if (l16 == 0) {
         if (IS_ITEM) (by_row ? a.go.item_b[(size_t)row * a.go.ld_itemb] : a.Rb[slot]) = (float)bacc;
-        if (MODE == AP_PRESUM && n > 0) (IS_ITEM ? a.cnt_item : a.cnt_user)[row] = 0;
+        if (n > 0) (IS_ITEM ? a.cnt_item : a.cnt_user)[row] = 0;
       }
-      if (MODE == AP_PRESUM && a.presum_rows == 2) {
+      if (a.presum_rows == 2) {
         // fused rows [item_emb | item_b | pad] / [user_emb | usert_emb | pad] of one width (the sharded step):
         // a row is written by exactly one of the two views -- clear the rest of it, so that the caller's
         // buffer need not be zeroed
@@ -1146,7 +1175,7 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
         for (int c = first + l16; c < width; c += 16) R[c] = 0.0f;
       }
     }
-    if constexpr (MODE == AP_PRESUM) return;
+    return;
   }
   if (vr) {
     // column cc of the row: cc < di -> item_emb / user_emb;  user rows, di <= cc < di+Ls -> usert_emb
@@ -1161,10 +1190,10 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float wi = w[ch][i];
-          g[i] = apply_elem<UM, LAZY>(wi, (float)acc[ch][i], x.P, x.invP, a.reg, x.step, x.lazy_scale, pe);
+          g[i] = apply_elem<MODE, LAZY>(wi, (float)acc[ch][i], x.P, x.invP, a.reg, x.step, x.lazy_scale, pe);
           w[ch][i] = wi;
         }
-        if constexpr (UM == AP_UPDATE && !LAZY) {
+        if constexpr (MODE == AP_UPDATE && !LAZY) {
           if (a.opt != TLSAN_OPT_SGD) {
             float* S1 = IS_ITEM ? a.s1.item_emb + (size_t)row * a.s1.ld_item : a.s1.user_emb + (size_t)row * a.s1.ld_user;
             float* S2 = IS_ITEM ? a.s2.item_emb + (size_t)row * a.s2.ld_item : a.s2.user_emb + (size_t)row * a.s2.ld_user;
@@ -1183,7 +1212,7 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
           if (!a.go.sparse || n > 0)
             *(f32x4*)((IS_ITEM ? a.go.item_emb + (size_t)row * a.go.ld_item : a.go.user_emb + (size_t)row * a.go.ld_user) + cc) = g;
         }
-        if constexpr (UM == AP_UPDATE) {
+        if constexpr (MODE == AP_UPDATE) {
           tbl_st4<DT>(Wtab, wrow + cc, w[ch], x.salt ^ (IS_ITEM ? 0x85ebca6bu : 0xc2b2ae35u));
 #pragma unroll
           for (int i = 0; i < 4; ++i) part += (double)w[ch][i] * (double)w[ch][i] - (double)w0[i] * (double)w0[i];
@@ -1197,11 +1226,11 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
           if (p < a.Ls) {
             float wi = w[ch][i];
             const float w00 = wi;
-            const float gg = apply_elem<UM, LAZY>(wi, (float)acc[ch][i], x.P, x.invP, a.reg, x.step, x.lazy_scale, part);
+            const float gg = apply_elem<MODE, LAZY>(wi, (float)acc[ch][i], x.P, x.invP, a.reg, x.step, x.lazy_scale, part);
             if constexpr (MODE == AP_GRADS) {
               if (!a.go.sparse || n > 0) a.go.usert_emb[(size_t)row * a.go.ld_usert + p] = gg;
             }
-            if constexpr (UM == AP_UPDATE && !LAZY) {
+            if constexpr (MODE == AP_UPDATE && !LAZY) {
               if (a.opt != TLSAN_OPT_SGD) {
                 float* q1 = a.s1.usert_emb + (size_t)row * a.s1.ld_usert + p;
                 float* q2 = a.s2.usert_emb + (size_t)row * a.s2.ld_usert + p;
@@ -1213,7 +1242,7 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
                 *q1 = a1; *q2 = a2;
               }
             }
-            if constexpr (UM == AP_UPDATE) Trow[p] = wi;
+            if constexpr (MODE == AP_UPDATE) Trow[p] = wi;
           }
         }
       }
@@ -1224,7 +1253,7 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
         if (!a.go.sparse || n > 0) a.go.item_b[(size_t)row * a.go.ld_itemb] = g;
       }
       if constexpr (MODE == AP_ROWNORM) part += (double)g * (double)g;
-      if constexpr (UM == AP_UPDATE) {
+      if constexpr (MODE == AP_UPDATE) {
         bool sgd = true;
         if constexpr (!LAZY) sgd = a.opt == TLSAN_OPT_SGD;
         if (sgd) {
@@ -1246,15 +1275,13 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
       if (n > 0 && l16 == 0) (IS_ITEM ? a.cnt_item : a.cnt_user)[row] = 0;
     }
   }
-  if constexpr (MODE != AP_GRADS) block_part_store(part, shp, &a.part_out[x.blk]);
+  if constexpr (MODE == AP_UPDATE) block_delta_store(part, shp, &a.delta_out[x.blk], x.salt);
+  else if constexpr (MODE != AP_GRADS) block_part_store(part, shp, &a.part_out[x.blk]);
 }
 
 // ================= one hot item row per workgroup (PRESUM) =================
-// SPEC: the row is also updated here (lazy update with coefficient 1, as apply_rows_block<AP_SPEC>); the change of the
-// stored table's sum of squares goes to *part_dst
-template <int NCH, bool SPEC = false, int DT = TLSAN_TABLE_F32>
-__device__ __forceinline__ void presum_hot_block(const ApplyArgs& a, int h, double* shd, double* shp, const ApCtx* x = nullptr,
-                                                 double* part_dst = nullptr) {
+template <int NCH>
+__device__ __forceinline__ void presum_hot_block(const ApplyArgs& a, int h, double* shd, double* shp) {
   const int nh = *a.hot_n;
   if (nh > AP_HOT_CAP || h >= nh) return;  // (workgroup-uniform) list overflowed: the item-row workgroups kept the rows
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, grp = lane >> 4, l16 = lane & 15, gid = wave * 4 + grp;
@@ -1262,16 +1289,6 @@ __device__ __forceinline__ void presum_hot_block(const ApplyArgs& a, int h, doub
   const int4 r = a.urec_item[slot];
   const int row = r.x, off = r.y, n = r.z;
   const int W4 = a.di / 4;
-  f32x4 w[NCH];
-  float wb = 0.0f;
-  if constexpr (SPEC) {   // (with the gradient rows: nothing below waits for a load of its own)
-    if (wave == 0 && grp == 0) {
-#pragma unroll
-      for (int ch = 0; ch < NCH; ++ch)
-        if (l16 + 16 * ch < W4) w[ch] = tbl_ld4<DT>(a.p.item_emb, (size_t)row * a.p.ld_item + 4 * (l16 + 16 * ch));
-      if (l16 == 0) wb = a.p.item_b[(size_t)row * a.p.ld_itemb];
-    }
-  }
   double acc[NCH][4];
   zero_acc(acc);
   for (int k = off + gid; k < off + n; k += 16 * AP_OWN) {
@@ -1307,9 +1324,8 @@ __device__ __forceinline__ void presum_hot_block(const ApplyArgs& a, int h, doub
   }
   if (lane == 0) shp[wave] = tb;
   __syncthreads();
-  double part = 0.0;
   if (wave == 0 && grp == 0) {
-    const bool by_row = !SPEC && a.presum_rows != 0;
+    const bool by_row = a.presum_rows != 0;
     float* R = by_row ? a.go.item_emb + (size_t)row * a.go.ld_item : a.Ri + (size_t)slot * a.di;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
@@ -1322,29 +1338,16 @@ __device__ __forceinline__ void presum_hot_block(const ApplyArgs& a, int h, doub
           for (int w_ = 0; w_ < 4; ++w_) s += shd[((w_ * 16 + l16) * NCH + ch) * 4 + i];
           g[i] = (float)s;
         }
-        st4_out(R + 4 * c4, g);
-        if constexpr (SPEC) {
-          const f32x4 w0 = w[ch];
-          w[ch] = w0 - x->lazy_scale * g;
-          tbl_st4<DT>(a.p.item_emb, (size_t)row * a.p.ld_item + 4 * c4, w[ch], x->salt ^ 0x85ebca6bu);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) part += (double)w[ch][i] * (double)w[ch][i] - (double)w0[i] * (double)w0[i];
-        }
+        *(f32x4*)(R + 4 * c4) = g;
       }
     }
     if (l16 == 0) {
       const float gb = (float)((shp[0] + shp[1]) + (shp[2] + shp[3]));
       (by_row ? a.go.item_b[(size_t)row * a.go.ld_itemb] : a.Rb[slot]) = gb;
-      if constexpr (SPEC) a.p.item_b[(size_t)row * a.p.ld_itemb] = wb - x->step * gb;  // not regularised, never scaled
       a.cnt_item[row] = 0;
     }
     if (a.presum_rows == 2)
       for (int c = a.di + 1 + l16; c < a.go.ld_item; c += 16) R[c] = 0.0f;
-  }
-  if constexpr (SPEC) {   // (16 lanes of wavefront 0 hold the partial)
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) part += __shfl_xor(part, o);
-    if (tid == 0) *part_dst = part;
   }
 }
 
@@ -1421,21 +1424,9 @@ __global__ __launch_bounds__(256) void k_apply(ApplyArgs a) {
 //                       PRESUM mode (exact per-row sums -> Rc / Ri / Rb / Ru, counters reset)
 //   k_update_lazy     : elementwise w -= scale * sum for the used rows + the dense parameters
 // Same arithmetic per element as k_apply<AP_UPDATE, lazy> (the sums are rounded to float there too).
-// SPEC (the lazy-L2 SGD step, TF18 norm, one workgroup per category): the row workgroups also APPLY the update, with the
-// clip coefficient taken as 1 -- which it is unless the step's global norm exceeds the clip (about one step in 400 on the
-// reference's protocol) -- and the finalize workgroups update the dense parameters they reduce the same way.
-// The coefficient is only known when the last finalize workgroup has arrived; instead of a third launch that waits for
-// it (k_update_lazy: 6.5 us + a kernel boundary per step), k_step_commit follows: one workgroup that makes the new table
-// scale current and folds the changes of the tables' sum of squares, plus -- when the step was clipped -- the correction
-// w += (lr / P_1 - lr c / P_c) * sum over the rows of the step (their sums are still in Rc / Ri / Rb / Ru).
-// During this launch the state header's P and nstep are only read (the summary writes P_next).
-// (five workgroups per CU, as the sum-only form gets by itself: left alone the SPEC form of the narrow tables takes 100
-//  registers -- four per CU, and 2 us more for the launch)
-template <int D, int DH, bool WIDE, bool CSPLIT = false, bool SPEC = false, int DT = TLSAN_TABLE_F32>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? 2 : 5))) void k_finalize_presum(FinArgs f, int nbK, int nbS, ApplyArgs a) {
+template <int D, int DH, bool WIDE, bool CSPLIT = false>
+__global__ __launch_bounds__(256) void k_finalize_presum(FinArgs f, int nbK, int nbS, ApplyArgs a) {
   constexpr int NC = WIDE ? 2 : 1, NI = WIDE ? 2 : 1, NU = WIDE ? 4 : 2;
-  constexpr int APM = SPEC ? AP_SPEC : AP_PRESUM;
-  constexpr int ADT = SPEC ? DT : TLSAN_TABLE_F32;   // (PRESUM does not touch the tables)
   __shared__ double shd[4 * 16 * NC * 4 > 256 ? 4 * 16 * NC * 4 : 256];
   __shared__ double shp[4];
   __shared__ int sh_pos[AP_CAP];
@@ -1455,168 +1446,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? 2 : 
   x.tid = threadIdx.x; x.wave = x.tid >> 6; x.lane = x.tid & 63; x.grp = x.lane >> 4; x.l16 = x.lane & 15;
   x.gid = x.wave * 4 + x.grp;
   x.blk = blockIdx.x - nfin;
-  x.P = 1.0f; x.invP = 1.0f; x.step = 0.0f; x.lazy_scale = 0.0f; x.salt = 0u; x.coef = 0.0f;
-  if constexpr (SPEC) {
-    x.P = a.hdr->P;   // (stable for the whole launch: see above)
-    x.invP = 1.0f / x.P;
-    x.step = a.lr;
-    x.lazy_scale = x.step / (x.P * (1.0f - x.step * a.reg));
-    x.salt = a.hdr->nstep;
-    x.coef = 1.0f;
-  }
+  x.P = 1.0f; x.invP = 1.0f; x.step = 0.0f; x.lazy_scale = 0.0f; x.salt = 0u;
   if (x.blk < a.nbH) {   // hot item rows lead the grid (no debug stamps)
-    if constexpr (SPEC) presum_hot_block<NI, true, ADT>(a, x.blk, shd, shp, &x, &a.part_out[a.nbC + a.nbI + a.nbU + x.blk]);
-    else presum_hot_block<NI>(a, x.blk, shd, shp);
+    presum_hot_block<NI>(a, x.blk, shd, shp);
     return;
   }
   x.blk -= a.nbH;
   unsigned long long* stp = a.stamps ? a.stamps + (size_t)x.blk * 8 : nullptr;
   if (stp && x.tid == 0) { stp[0] = __builtin_amdgcn_s_memtime(); stp[4] = __builtin_amdgcn_s_memrealtime(); }
   const int blk = x.blk;
-  if (blk < a.nbC) apply_cate_block<APM, true, NC, ADT, CSPLIT>(a, x, shd, shp, sh_pos, sh_lo, sh_n, sh_wtot);
-  else if (blk < a.nbC + a.nbI) apply_rows_block<APM, true, true, NI, AP_OWN, ADT>(a, x, (blk - a.nbC) * AP_ROWS_PB, shp);
-  else apply_rows_block<APM, true, false, NU, AP_OWN / 2, ADT>(a, x, (blk - a.nbC - a.nbI) * AP_ROWS_PB, shp);
+  if (blk < a.nbC) apply_cate_block<AP_PRESUM, true, NC, TLSAN_TABLE_F32, CSPLIT>(a, x, shd, shp, sh_pos, sh_lo, sh_n, sh_wtot);
+  else if (blk < a.nbC + a.nbI) apply_rows_block<AP_PRESUM, true, true, NI, AP_OWN, TLSAN_TABLE_F32>(a, x, (blk - a.nbC) * AP_ROWS_PB, shp);
+  else apply_rows_block<AP_PRESUM, true, false, NU, AP_OWN / 2, TLSAN_TABLE_F32>(a, x, (blk - a.nbC - a.nbI) * AP_ROWS_PB, shp);
   if (stp && x.tid == 0) { stp[6] = __builtin_amdgcn_s_memtime(); stp[5] = __builtin_amdgcn_s_memrealtime(); }
-}
-
-// The launch behind k_finalize_presum<SPEC>.  Workgroup 0 (always): the step's commit -- P <- P_next, nstep, and the
-// changes of the stored tables' sum of squares that the row workgroups left in S_spec, summed in a fixed order into
-// S_total and cleared.  Workgroups 1 ..: nothing, unless the step was clipped (coef < 1, read from the header): then they
-// walk the used rows, the categories and the dense parameters (strided over the virtual blocks of k_update_lazy's grid)
-// and add the difference between the update that was applied and the one that was due.  Their own changes of the sum of
-// squares go the old way (S_part, folded by the next step's finalize).
-struct CommitArgs {
-  double* S_spec; int32_t n_spec;
-  double* S_total;
-  int32_t count_step;
-  int32_t nbC16;
-  double* part_fix;   // [nbC16 + nbI + nbU]
-};
-template <bool WIDE, int DT>
-__global__ __launch_bounds__(256) void k_step_commit(ApplyArgs a, CommitArgs c) {
-  constexpr int NC = WIDE ? 2 : 1, NI = WIDE ? 2 : 1, NU = WIDE ? 4 : 2;
-  __shared__ double shd[256];
-  __shared__ double shp[4];
-  const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, gid = tid >> 4;
-  const float coef = a.hdr->coef;
-  const bool clipped = coef != 1.0f;
-  const int nvb = c.nbC16 + a.nbI + a.nbU;
-  if (blockIdx.x == 0) {
-    // one round trip: every load of the commit is issued before anything is used (16 entries per thread in flight)
-    const float Pn = a.hdr->P_next;
-    const uint32_t ns = a.hdr->nstep;
-    const double St0 = *c.S_total;
-    double sum = 0.0;
-    for (int k0 = tid; k0 < c.n_spec; k0 += 256 * 16) {
-      double t[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) t[u] = c.S_spec[k0 + 256 * u < c.n_spec ? k0 + 256 * u : k0];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        if (k0 + 256 * u < c.n_spec) {
-          sum += t[u];
-          if (t[u] != 0.0) c.S_spec[k0 + 256 * u] = 0.0;   // zero at rest
-        }
-      }
-    }
-    // fixed-order sum over the workgroup: lanes by xor tree, wavefronts in order
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) sum += __shfl_xor(sum, o);
-    if (lane == 0) shp[tid >> 6] = sum;
-    __syncthreads();
-    if (tid == 0) {
-      a.hdr->P = Pn;
-      if (c.count_step) a.hdr->nstep = ns + 1;
-      a.hdr->spart_n = clipped ? nvb : 0;
-      *c.S_total = St0 + ((shp[0] + shp[1]) + (shp[2] + shp[3]));
-    }
-    return;
-  }
-  if (!clipped) return;
-  // ---- the clipped step (rare): w_due - w_applied = (lr / P_1 - lr c / P_c) * sum,  P_1 = P (1 - lr reg),  P_c = P_next
-  const float P = a.hdr->P_prev, Pc = a.hdr->P_next;
-  const float dscale = a.lr / (P * (1.0f - a.lr * a.reg)) - a.lr * coef / Pc;   // what to add back, per unit of row sum
-  const float dstep = a.lr - a.lr * coef;                                         // the same for unscaled parameters
-  const uint32_t salt = __float_as_uint(Pc) ^ 0x9e3779b9u;                        // (bf16 tables: a stream of its own)
-  const int nfix = gridDim.x - 1;
-  for (int vb = blockIdx.x - 1; vb < nvb + a.nbD; vb += nfix) {
-    double part = 0.0;
-    if (vb < c.nbC16) {
-      const int cc = vb * 16 + gid;
-      if (cc < a.C) {
-        const size_t wrow = (size_t)cc * a.dc;
-#pragma unroll
-        for (int ch = 0; ch < NC; ++ch)
-          if (4 * (l16 + 16 * ch) < a.dc) {
-            const f32x4 w0 = tbl_ld4<DT>(a.p.cate_emb, wrow + 4 * (l16 + 16 * ch));
-            const f32x4 g = *(const f32x4*)(a.Rc + wrow + 4 * (l16 + 16 * ch));
-            f32x4 w = w0 + dscale * g;
-            tbl_st4<DT>(a.p.cate_emb, wrow + 4 * (l16 + 16 * ch), w, salt ^ 0x3c6ef372u);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) part += (double)w[i] * (double)w[i] - (double)w0[i] * (double)w0[i];
-          }
-      }
-    } else if (vb < c.nbC16 + a.nbI) {
-      const int slot = (vb - c.nbC16) * AP_ROWS_PB + gid;
-      if (slot < *a.n_uniq_item) {
-        const int row = a.urec_item[slot].x;
-        const size_t wrow = (size_t)row * a.p.ld_item;
-#pragma unroll
-        for (int ch = 0; ch < NI; ++ch)
-          if (4 * (l16 + 16 * ch) < a.di) {
-            const f32x4 w0 = tbl_ld4<DT>(a.p.item_emb, wrow + 4 * (l16 + 16 * ch));
-            const f32x4 g = *(const f32x4*)(a.Ri + (size_t)slot * a.di + 4 * (l16 + 16 * ch));
-            f32x4 w = w0 + dscale * g;
-            tbl_st4<DT>(a.p.item_emb, wrow + 4 * (l16 + 16 * ch), w, salt ^ 0x85ebca6bu);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) part += (double)w[i] * (double)w[i] - (double)w0[i] * (double)w0[i];
-          }
-        if (l16 == 0) a.p.item_b[(size_t)row * a.p.ld_itemb] += dstep * a.Rb[slot];
-      }
-    } else if (vb < nvb) {
-      const int slot = (vb - c.nbC16 - a.nbI) * AP_ROWS_PB + gid;
-      if (slot < *a.n_uniq_user) {
-        const int row = a.urec_user[slot].x;
-        const size_t wrow = (size_t)row * a.p.ld_user;
-        float* Trow = a.p.usert_emb + (size_t)row * a.p.ld_usert;
-#pragma unroll
-        for (int ch = 0; ch < NU; ++ch) {
-          const int cc = 4 * (l16 + 16 * ch);
-          if (cc >= a.WU) continue;
-          const f32x4 g = *(const f32x4*)(a.Ru + (size_t)slot * a.WU + cc);
-          if (cc < a.di) {
-            const f32x4 w0 = tbl_ld4<DT>(a.p.user_emb, wrow + cc);
-            f32x4 w = w0 + dscale * g;
-            tbl_st4<DT>(a.p.user_emb, wrow + cc, w, salt ^ 0xc2b2ae35u);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) part += (double)w[i] * (double)w[i] - (double)w0[i] * (double)w0[i];
-          } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const int p = cc + i - a.di;
-              if (p < a.Ls) {
-                const float w0 = Trow[p], wn = w0 + dscale * g[i];
-                Trow[p] = wn;
-                part += (double)wn * (double)wn - (double)w0 * (double)w0;
-              }
-            }
-          }
-        }
-      }
-    } else {
-      const int nd = (vb - nvb) * 256 + tid;
-      if (nd < a.lay.n_dense) {
-        const float wn = a.p.dense[nd] + dstep * a.gd[nd];
-        a.p.dense[nd] = wn;
-        if (nd >= a.lay.K && nd < a.lay.k0) {
-          const int idx = nd - a.lay.K;
-          a.p.dense_KT[(size_t)(idx % a.D) * a.D + idx / a.D] = wn;
-        }
-      }
-      continue;
-    }
-    block_part_store(part, shp, &c.part_fix[vb]);
-  }
 }
 
 // split category sums (Rc64, exact doubles) -> float output, and back to zero at rest (tlsan_grads)
@@ -1749,7 +1591,7 @@ __global__ __launch_bounds__(256) void k_update_lazy(ApplyArgs a, int nbC16) {
     }
     return;
   }
-  block_part_store(part, shp, &a.part_out[blk]);
+  block_delta_store(part, shp, &a.delta_out[blk], salt);
 }
 
 
