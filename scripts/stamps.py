@@ -36,7 +36,10 @@ f = raw[:, :, 12:16]
 fd = np.diff(f, axis=2)
 ok = (f[:, :, 0] > 0)
 for i, n in enumerate(["P5 pos1: maps+exp", "P5 pos1: bwd_compute", "P5 pos1: bwd_dw"]):
-    print("%-24s mean %8.0f p50 %8.0f max %8.0f" % (n, fd[:, :, i][ok].mean(), np.median(fd[:, :, i][ok]), fd[:, :, i][ok].max()))
+    sel = ok & (f[:, :, i + 1] > 0)      # (the pipelined long backward has no such sub-stamps: they stay 0)
+    if sel.any():
+        print("%-24s mean %8.0f p50 %8.0f max %8.0f" % (n, fd[:, :, i][sel].mean(), np.median(fd[:, :, i][sel]), fd[:, :, i][sel].max()))
+ok = raw[:, :, 16] > 0                   # waves that ran position 1 of the long backward
 full = (raw[:, :, 9] > 0) & (raw[:, :, 18] > 0)     # waves whose window is full (position 9 ran)
 def seg(nm, lo, hi, sel=None):
     # (a stamp a wavefront never reached stays 0: such waves are left out of the segment, not read as a time)
