@@ -482,6 +482,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #ifndef TLSAN_EXP_BALANCE
 #define TLSAN_EXP_BALANCE 1
 #endif
+#ifndef TLSAN_EXP_LHELP
+#define TLSAN_EXP_LHELP 1   // streamed windows: a long window is shared by the wavefront's two halves (see P1)
+#endif
 #ifndef TLSAN_EXP_FLIP
 #define TLSAN_EXP_FLIP 0
 #endif
@@ -528,14 +531,16 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       const int cand = g * NSB + r;
       const bool cv = cand < B;
       const int cl = cv ? min(a.b.sl[cand], Ls) : 0, cs = cv ? min(a.b.sl_new[cand], Sn) : 0;
-      const int key = cv ? (((cs << 12) | (cl << 4) | (15 - r)) + 1) : -r;   // distinct; larger = heavier
+      // (streamed windows: the window length decides -- up to 90 positions against a session's few -- and the longest
+      //  is paired with the shortest: the short one's half of the wavefront then helps with the long one, LHELP)
+      const int key = cv ? (((LSTREAM ? ((cl << 12) | (cs << 4)) : ((cs << 12) | (cl << 4))) | (15 - r)) + 1) : -r;   // distinct; larger = heavier
       int rank = 0;
 #pragma unroll
       for (int j = 0; j < 16; ++j) rank += (__builtin_amdgcn_readlane(key, j) > key) ? 1 : 0;
       int* sPerm = (int*)T;                       // (the wave's own scratch: free until P3)
       // (windows held in registers, two samples per wavefront: the wavefront with the k-th longest session also takes
       // the k-th shortest -- its lanes then share the long one, see HELP in P3)
-      const int slot = (TLSAN_EXP_FOLD != 0 && SPW == 2 && !LSTREAM && !DROP) ? (rank < 8 ? 2 * rank : 2 * (15 - rank) + 1) : rank;
+      const int slot = (TLSAN_EXP_FOLD != 0 && SPW == 2 && (!LSTREAM || TLSAN_EXP_LHELP != 0) && !DROP) ? (rank < 8 ? 2 * rank : 2 * (15 - rank) + 1) : rank;
       if (q == 0) sPerm[slot] = r;
       wave_lds_fence();
       bidx = g * NSB + sPerm[srow];
@@ -563,6 +568,29 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     int posv[(TRAIN && LSTREAM) ? LS + 3 : 1];   // (streamed window: the three single uses, drawn by the lead lane)
     int upos = 0;                                // (window in registers: the cursor draw of this lane's use slot)
     const int pmax1 = wave_max_samples<CPS>(n_l);
+    // ---- LHELP (streamed windows): a long window is shared by the wavefront's two halves, as a long session is in the
+    // short block (HELP, P3).  The launch ends with its slowest workgroup, and with streamed windows that is the one
+    // that holds one of the batch's few 90-entry windows (1 % of the synthetic histories, mean length 14): its wavefront
+    // walks 90 positions with half of its lanes idle behind a short partner.  From the (even) position g_lo2 where the
+    // shorter window has ended, the helping half takes the odd positions of the longer one: MFMA columns = (position
+    // 2j | position 2j+1) x 8 heads of ONE sample; the helper keeps a partial online-softmax state that is merged with
+    // one row_ror:8 step after the loop, and in the backward it reads the sample's statistics and output gradient
+    // across the row once, at the switch.  Steps of the wavefront: g_lo2 + ceil((g_hi - g_lo2) / 2) instead of g_hi.
+    constexpr bool LHELP = TLSAN_EXP_LHELP != 0 && LSTREAM && SPW == 2 && !DROP;
+    int g_lo2 = 0, g_hi = 0, g_L = 0;
+    bool g_on = false;
+    if constexpr (LHELP) {
+      const int nl0 = __builtin_amdgcn_readlane(n_l, 0), nl1 = __builtin_amdgcn_readlane(n_l, CPS);
+      g_lo2 = (min(nl0, nl1) + 1) & ~1;      // (even: the pairs (2j, 2j+1) then never straddle a chunk of ids)
+      g_hi = max(nl0, nl1);
+      g_L = nl0 >= nl1 ? 0 : 1;
+      g_on = g_hi - g_lo2 >= 2;
+    }
+    const bool ghelper = LHELP && g_on && s_loc != g_L;
+    // position cursor p (wave-uniform; even once shared): shared step?  (macros, not lambdas: a closure that captures
+    // another closure made hipcc keep both on the stack, and every call re-read g_lo2 / g_on from scratch memory)
+#define L_SHARED(p) (LHELP && g_on && (p) >= g_lo2)
+#define L_ADV(p) (L_SHARED(p) ? 2 : 1)
     // ---- streamed long block (LSTREAM): ids, scales and positions live one per lane of the sample
     // (lane kk = entry base + kk of the current chunk) and are broadcast with cross-lane reads
     constexpr int NLc = 4 * CPS;
@@ -588,10 +616,29 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     };
     auto stage_lchunk_cats = [&]() { nlct = a.p.item_cate[nlid]; };
     auto take_lchunk = [&]() { lid = nlid; lct = nlct; lht = nlht; lut = nlut; };
-    auto fetch_lrow = [&](int p, f32x4 (&xr)[NB], float& scx, float& sce) {  // position p of the loaded chunk
+    // entry of the loaded chunk for position cursor p: the lane's own sample's entry p, or -- shared step -- the longer
+    // window's entry p (its own half) / p + 1 (the helping half)
+    auto pick_lentry = [&](int p, int& it, int& ct, float& uth) {
       const int k = p % NLc;
-      const int it = sample_pick<CPS>(lid, k / CPS, k % CPS, s_loc), ct = sample_pick<CPS>(lct, k / CPS, k % CPS, s_loc);
-      const float uth = sample_pick<CPS>(lut, k / CPS, k % CPS, s_loc) * sample_pick<CPS>(lht, k / CPS, k % CPS, s_loc);
+      const int ss = L_SHARED(p) ? g_L : s_loc;
+      it = sample_pick<CPS>(lid, k / CPS, k % CPS, ss);
+      ct = sample_pick<CPS>(lct, k / CPS, k % CPS, ss);
+      uth = sample_pick<CPS>(lut, k / CPS, k % CPS, ss) * sample_pick<CPS>(lht, k / CPS, k % CPS, ss);
+      if constexpr (LHELP) {
+        if (L_SHARED(p)) {   // (wave-uniform)
+          const int k1 = k + 1;    // (p even, NLc even: the same chunk)
+          const int it1 = sample_pick<CPS>(lid, k1 / CPS, k1 % CPS, ss), ct1 = sample_pick<CPS>(lct, k1 / CPS, k1 % CPS, ss);
+          const float uth1 = sample_pick<CPS>(lut, k1 / CPS, k1 % CPS, ss) * sample_pick<CPS>(lht, k1 / CPS, k1 % CPS, ss);
+          it = ghelper ? it1 : it;
+          ct = ghelper ? ct1 : ct;
+          uth = ghelper ? uth1 : uth;
+        }
+      }
+    };
+    auto fetch_lrow = [&](int p, f32x4 (&xr)[NB], float& scx, float& sce) {  // position p of the loaded chunk
+      int it, ct;
+      float uth;
+      pick_lentry(p, it, ct, uth);
       scx = (gamma * P * P) * uth;  // x = e_stored * scx
       sce = (gamma * P) * uth;      // d x / d e_true
 #pragma unroll
@@ -599,9 +646,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     };
     using raw4 = typename TblRaw<DT>::type;
     auto fetch_lrow_raw = [&](int p, raw4 (&xr)[NB], float& scx, float& sce) {  // the same, the row as loaded (widened at its use)
-      const int k = p % NLc;
-      const int it = sample_pick<CPS>(lid, k / CPS, k % CPS, s_loc), ct = sample_pick<CPS>(lct, k / CPS, k % CPS, s_loc);
-      const float uth = sample_pick<CPS>(lut, k / CPS, k % CPS, s_loc) * sample_pick<CPS>(lht, k / CPS, k % CPS, s_loc);
+      int it, ct;
+      float uth;
+      pick_lentry(p, it, ct, uth);
       scx = (gamma * P * P) * uth;
       sce = (gamma * P) * uth;
 #pragma unroll
@@ -697,21 +744,34 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         raw4 xn[NB];
         float scxn = 0.0f, scen = 0.0f;
         if constexpr (LPF) fetch_lrow_raw(base, xn, scxn, scen);
-        for (int p = base; p < pend; ++p) {
+        for (int p = base; p < pend; p += L_ADV(p)) {
+          if constexpr (LHELP) {
+            if (g_on && p == g_lo2 && ghelper) {   // the helping half parks its own (finished) state and starts a partial one
+#pragma unroll
+              for (int kb = 0; kb < NB; ++kb) {
+                *(f32x4*)(T + ((0 * NB + kb) * 64 + lane) * 4) = mx1[kb];
+                *(f32x4*)(T + ((1 * NB + kb) * 64 + lane) * 4) = Zl[kb];
+                *(f32x4*)(T + ((2 * NB + kb) * 64 + lane) * 4) = long4[kb];
+                mx1[kb] = (f32x4)(TLSAN_NEG);
+                Zl[kb] = (f32x4)(0.0f);
+                long4[kb] = (f32x4)(0.0f);
+              }
+            }
+          }
           f32x4 xv[NB], z[NB], m2[NB];
           float scx = scxn, sce = scen;
           (void)sce;
           if constexpr (LPF) {
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) xv[kb] = tbl_cvt<DT>(xn[kb]);
-            if (p + 1 < pend) fetch_lrow_raw(p + 1, xn, scxn, scen);
+            if (p + L_ADV(p) < pend) fetch_lrow_raw(p + L_ADV(p), xn, scxn, scen);
           } else {
             fetch_lrow(p, xv, scx, sce);
           }
           if constexpr (LCH) {
-            if (p == base + 1 && base + NLc < pmax1) stage_lchunk_cats();   // (the next chunk's ids are here by now)
+            if (p == base + 2 && base + NLc < pmax1) stage_lchunk_cats();   // (the next chunk's ids are here by now)
           }
-          const bool vp = p < n_l;
+          const bool vp = L_SHARED(p) ? p + (ghelper ? 1 : 0) < g_hi : p < n_l;
 #pragma unroll
           for (int kb = 0; kb < NB; ++kb) xv[kb] = vp ? xv[kb] * scx : (f32x4)(0.0f);
           if constexpr (DROP) {
@@ -732,6 +792,28 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           }
           map_apply<NB, MM>(FT2, b2, z, m2);
           if (vp) online_step<NB>(mx1, Zl, long4, m2, xv);
+        }
+      }
+      if constexpr (LHELP) {
+        if (g_on) {   // merge the helper's partial state into the sample's, give the helper its own state back
+          wave_lds_fence();
+#pragma unroll
+          for (int kb = 0; kb < NB; ++kb) {
+            const f32x4 own_mx = *(const f32x4*)(T + ((0 * NB + kb) * 64 + lane) * 4);
+            const f32x4 own_Z = *(const f32x4*)(T + ((1 * NB + kb) * 64 + lane) * 4);
+            const f32x4 own_N = *(const f32x4*)(T + ((2 * NB + kb) * 64 + lane) * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float o_mx = dpp_f32<TLSAN_DPP_ROR(8)>(mx1[kb][i]), o_Z = dpp_f32<TLSAN_DPP_ROR(8)>(Zl[kb][i]);
+              const float o_N = dpp_f32<TLSAN_DPP_ROR(8)>(long4[kb][i]);
+              const float mn = fmaxf(mx1[kb][i], o_mx);
+              const float sa = __expf(mx1[kb][i] - mn), sb = __expf(o_mx - mn);
+              mx1[kb][i] = ghelper ? own_mx[i] : mn;
+              Zl[kb][i] = ghelper ? own_Z[i] : Zl[kb][i] * sa + o_Z * sb;
+              long4[kb][i] = ghelper ? own_N[i] : long4[kb][i] * sa + o_N * sb;
+            }
+          }
+          wave_lds_fence();
         }
       }
 #pragma unroll
@@ -1357,19 +1439,38 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             raw4 en[NB];                  // (the next position's row, in flight while this one is processed)
             float scxn = 0.0f, scen = 0.0f;
             if constexpr (LPF) fetch_lrow_raw(base, en, scxn, scen);
-            for (int p = base; p < pend; ++p) {
-              const bool vp = p < n_l;
+            for (int p = base; p < pend; p += L_ADV(p)) {
+              // (LHELP) shared step: both halves work on the longer window -- its own half on entry p, the helping half
+              // on p + 1, with that sample's statistics, output and output gradient (read across the row at the switch)
+              const bool shared = L_SHARED(p), oth = shared && ghelper;
+              const int my_p = p + (oth ? 1 : 0), my_row = oth ? wave * SPW + g_L : srow;
+              const bool vp = shared ? my_p < g_hi : p < n_l;
+              if constexpr (LHELP) {
+                if (g_on && p == g_lo2) {
+#pragma unroll
+                  for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                      const float o_mx = dpp_f32<TLSAN_DPP_ROR(8)>(mx1[kb][i]), o_iz = dpp_f32<TLSAN_DPP_ROR(8)>(iz1[kb][i]);
+                      const float o_out = dpp_f32<TLSAN_DPP_ROR(8)>(long4[kb][i]), o_do = dpp_f32<TLSAN_DPP_ROR(8)>(dlong[kb][i]);
+                      mx1[kb][i] = ghelper ? o_mx : mx1[kb][i];       // (the helper's own window is done: its statistics are not needed again)
+                      iz1[kb][i] = ghelper ? o_iz : iz1[kb][i];
+                      long4[kb][i] = ghelper ? o_out : long4[kb][i];
+                      dlong[kb][i] = ghelper ? o_do : dlong[kb][i];
+                    }
+                }
+              }
               f32x4 ev[NB], xv[NB], z1[NB], zr[NB], m2[NB], av[NB], dx[NB];
               float scx = scxn, sce = scen;
               if constexpr (LPF) {
 #pragma unroll
                 for (int kb = 0; kb < NB; ++kb) ev[kb] = tbl_cvt<DT>(en[kb]);
-                if (p + 1 < pend) fetch_lrow_raw(p + 1, en, scxn, scen);
+                if (p + L_ADV(p) < pend) fetch_lrow_raw(p + L_ADV(p), en, scxn, scen);
               } else {
                 fetch_lrow(p, ev, scx, sce);
               }
               if constexpr (LCH) {
-                if (p == base + 1 && base + NLc < pmax1) stage_lchunk_cats();
+                if (p == base + 2 && base + NLc < pmax1) stage_lchunk_cats();
               }
 #pragma unroll
               for (int kb = 0; kb < NB; ++kb) {
@@ -1409,8 +1510,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
               for (int kb = 0; kb < NB; ++kb) dsp += dot4(dx[kb], ev[kb]);
               const float ds = sample_sum<CPS>(dsp) * P;  // d loss / d scale[p]
-              if (vs && vp) {
-                const int pos = sP[srow * PSTR + p];
+              if ((vs || oth) && vp) {
+                const int pos = sP[my_row * PSTR + my_p];
                 if (lead) a.Gb[pos] = 0.0f;
 #pragma unroll
                 for (int kb = 0; kb < NB; ++kb) {
@@ -1419,10 +1520,10 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
                   sq_acc += dot4(de, de);
                 }
                 if (lead) {
-                  const float gt = ds * (gamma * sH[srow * 2 * LSC + p]);  // d / d usert_emb[u][p]
-                  a.Gu[(size_t)sP[srow * PSTR + P_USR] * a.WU + a.di + p] = gt;
+                  const float gt = ds * (gamma * sH[my_row * 2 * LSC + my_p]);  // d / d usert_emb[u][p]
+                  a.Gu[(size_t)sP[my_row * PSTR + P_USR] * a.WU + a.di + my_p] = gt;
                   sq_acc += gt * gt;
-                  dgam += ds * (P * sH[srow * 2 * LSC + LSC + p]);
+                  dgam += ds * (P * sH[my_row * 2 * LSC + LSC + my_p]);
                 }
               }
             }
