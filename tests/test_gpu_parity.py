@@ -103,6 +103,44 @@ def test_train_step_matches_oracle(norm_mode, clip):
     assert np.array_equal(m.dense_KT.cpu().numpy(), got["dense_K"].T)
 
 
+@pytest.mark.parametrize("d,Ls,l2_mode", [(128, 10, "dense"), (128, 10, "lazy"), (64, 10, "lazy"), (128, 24, "lazy"), (256, 16, "dense")])
+def test_category_segments_match_oracle(d, Ls, l2_mode):
+    """Many categories (>= 2048, BASELINE.json configs[4] has 10 k): the category half of every item use's gradient row is
+    written into the category's own segment (FwdArgs.cseg / ApplyArgs.cseg) instead of beside the item half, and the
+    category blocks of the apply pass sum that segment instead of walking the category's items.  Same numbers as the
+    oracle: gradients, three training steps (window in registers and streamed, dense and lazy L2), bitwise reproducible."""
+    cfg = make_config(U=70, I=2600, C=2100, d=d, Ls=Ls, regulation_rate=1e-3)
+    p = _p32(random_params(cfg, seed=91))
+    _, cat = random_batch(cfg, B=8, Sn=3, seed=0)
+    batches = [random_batch(cfg, B=41, Sn=2 + s, seed=900 + s)[0] for s in range(3)]
+    for b in batches:          # (several uses per item and per category: ids folded onto 150 items; u_cate hits their categories)
+        for k in ("hist_i", "hist_i_new", "i"):
+            b[k] %= 150
+        b["u_cate"][:] = cat[b["i"]]
+    m = _model(cfg, cat, p, l2_mode=l2_mode)
+    g = m.grads(_tuple(batches[0]))
+    _, _, ref_g, _ = orc.backward(p, cat, batches[0], 8, cfg["regulation_rate"])
+    for k in ref_g:
+        a, r = np.asarray(g["grads"][k], np.float64).reshape(ref_g[k].shape), ref_g[k]
+        assert np.abs(a - r).max() < 2e-4 * np.abs(r).max() + 1e-6, k
+    runs = []
+    for rep in range(2):
+        mm = _model(cfg, cat, p, l2_mode=l2_mode)
+        losses = [mm.train(None, _tuple(b), 0.6) for b in batches]
+        runs.append((losses, mm.get_params()))
+    assert runs[0][0] == runs[1][0]
+    for k in runs[0][1]:
+        assert np.array_equal(runs[0][1][k], runs[1][1][k]), k
+    q = dict(p)
+    for b, l in zip(batches, runs[0][0]):
+        lo, q, _ = orc.train_step(q, cat, b, 8, cfg["regulation_rate"], lr=0.6)
+        assert abs(l - lo) < 2e-4 * max(1.0, abs(lo))
+    for k in q:
+        du = np.asarray(runs[0][1][k], np.float64).reshape(p[k].shape) - p[k]
+        dr = q[k] - p[k]
+        assert np.abs(du - dr).max() < 5e-4 * (np.abs(dr).max() + 1e-9) + 5e-7, k
+
+
 def test_multi_step_tracks_oracle_and_is_deterministic():
     cfg = make_config(U=25, I=35, C=5, d=64, regulation_rate=5e-5)
     p = _p32(random_params(cfg, seed=21))

@@ -95,6 +95,7 @@ static int ru4(int x) { return (x + 3) / 4 * 4; }
 // k_dense_finalize the long pole of its launch (77 -> 91 us/step), and the separate k_dk_partial launch (<= 64 partials)
 // is the better deal again
 #define FUSED_DK_MAX_GROUPS 256
+#define TLSAN_CSEG_MIN_CATES 2048    // tables with at least this many categories take the category-segment path (cate_seg below)
 static bool fused_dk(int D, int ngroups) { return TLSAN_EXP_FUSE_DK != 0 && D <= 128 && ngroups <= FUSED_DK_MAX_GROUPS; }
 static int fwd_train_grid(int ngroups) { return ngroups; }    // (fused: ngroups <= FUSED_DK_MAX_GROUPS, one pass per workgroup)
 
@@ -117,7 +118,8 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
   w->Gi = (float*)take(sizeof(float) * (NI + 1) * D);
   w->Gb = (float*)take(sizeof(float) * (NI + 1));
   w->Gu = (float*)take(sizeof(float) * (size_t)(B + 1) * w->WU);
-  w->Gc = (float*)take(sizeof(float) * (size_t)(B + 1) * d->d_cate);
+  // (CSEG: one row per u_cate use AND per item use -- sized for it whenever the table shape can take that path)
+  w->Gc = (float*)take(sizeof(float) * (size_t)(B + 1 + (d->cate_count >= TLSAN_CSEG_MIN_CATES ? NI : 0)) * d->d_cate);
   w->gLong = (float*)take(sizeof(float) * B * D);
   w->gDB = (float*)take(sizeof(float) * B * D);
   w->partials = (float*)take(sizeof(float) * w->ngroups * s.NPB);
@@ -157,6 +159,30 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
 // fused kernel cost more than the extra launch on the index stream): more than 32 samples per category
 static inline bool uc_by_list(const tlsan_dims* d, const tlsan_batch* b) {
   return b && b->B <= UC_LIST_CAP && (long)b->B > 32L * d->cate_count;
+}
+// many categories (the 10 k of BASELINE.json configs[4]): the category half of every item use's gradient row is written
+// into the category's own segment of Gc (FwdArgs.cseg) -- a category block of the apply pass then sums one contiguous
+// segment instead of walking the category's items for their segments (500 items per category at 5 M items, of which a
+// batch uses five: k_finalize_presum 196 us at that shape).  With few categories the cursor draws would pile up on few
+// addresses (as the u_cate uses did, uc_by_list): the item walk stays.
+// tlsan_batch_index gets no parameters: the item -> category map the state's category index was built from
+// (tlsan_state_init / _reindex / _recategorize) is remembered per state, for the category counts of CSEG
+#include <mutex>
+#include <unordered_map>
+static std::mutex g_cate_mu;
+static std::unordered_map<const void*, const int32_t*> g_cate_of_state;
+static void remember_item_cate(const void* state, const int32_t* item_cate) {
+  std::lock_guard<std::mutex> lk(g_cate_mu);
+  g_cate_of_state[state] = item_cate;
+}
+static const int32_t* item_cate_of(const void* state) {
+  std::lock_guard<std::mutex> lk(g_cate_mu);
+  auto it = g_cate_of_state.find(state);
+  return it == g_cate_of_state.end() ? nullptr : it->second;
+}
+static inline bool cate_seg(const tlsan_dims* d, const tlsan_batch* b) {
+  static const int on = [] { const char* v = getenv("TLSAN_CSEG"); return v ? atoi(v) : 1; }();
+  return on && d->cate_count >= TLSAN_CSEG_MIN_CATES && !uc_by_list(d, b);
 }
 struct St {  // persistent state
   // two index slots (a batch's destination index depends only on its ids, so it lives with the
@@ -298,6 +324,7 @@ static void fill_apply(ApplyArgs& A, const tlsan_dims* d, const Shape& s, const 
   A.n_uniq_item = st.hdr ? &st.hdr->n_uniq[k][0] : nullptr; A.n_uniq_user = st.hdr ? &st.hdr->n_uniq[k][1] : nullptr;
   A.cate_off = st.cate_off; A.cate_cnt = st.cate_cnt; A.cate_items = st.cate_items;
   A.uc_list = uc_by_list(d, b) ? st.uc_list[k] : nullptr;
+  A.cseg = (b && cate_seg(d, b)) ? 1 : 0;
   A.Rc64 = st.Rc64;
   A.csplit = 1; A.cpass = 256;
   A.hot_n = st.hdr ? &st.hdr->n_hot[k] : nullptr; A.hot_list = st.hot_list[k]; A.nbH = 0;
@@ -403,6 +430,7 @@ static int scan_compact_impl(const int32_t* cnt, int32_t n, int32_t* prefix, int
 // static CSR category -> items from p->item_cate (counting sort with the generic index kernels)
 static int build_cate_csr(const tlsan_dims* d, const tlsan_params* p, const St& st, hipStream_t hs) {
   const int I = d->item_count, C = d->cate_count;
+  remember_item_cate(st.hdr, p->item_cate);
   GIdxArgs gi;
   gi.dest = p->item_cate; gi.n = I; gi.nrows = C; gi.cnt = st.cate_cnt; gi.cur = st.cate_cur; gi.list = st.cate_items;
   if (I <= CSR_SMALL_MAXN && C <= CSR_SMALL_MAXROWS) {   // one launch (the sharded step rebuilds this every step)
@@ -578,12 +606,16 @@ int tlsan_forward(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch*
 // destination index of a batch into slot k: use counts per destination row -> first sorted position
 // of every row (+ records of the used rows)
 static int build_index(const tlsan_dims* d, const tlsan_batch* b, const St& st, int k, hipStream_t hs, bool sparse_users = false) {
+  const bool cseg = cate_seg(d, b);
+  const int32_t* item_cate = cseg ? item_cate_of(st.hdr) : nullptr;
+  if (cseg && !item_cate) return fail(TLSAN_E_BADARG, "the state's item -> category map is unknown (tlsan_state_init first)");
   int rc;
   CountArgs ca;
   memset(&ca, 0, sizeof(ca));
   ca.b = *b; ca.Ls = d->Ls;
   ca.n_hot = &st.hdr->n_hot[k];
   ca.cnt_item = st.cnt_item[k]; ca.cnt_user = st.cnt_user[k]; ca.cnt_uc = st.cnt_uc[k];
+  ca.item_cate = item_cate; ca.cseg = cseg ? 1 : 0;
   const int nthr = b->B * (d->Ls + b->Sn + 2);
   hipLaunchKernelGGL(k_count, dim3((nthr + 255) / 256), dim3(256), 0, hs, ca);
   CHECK_LAUNCH("k_count");
@@ -630,6 +662,7 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   a.Gi = w.Gi; a.Gb = w.Gb; a.Gu = w.Gu; a.Gc = w.Gc; a.WU = w.WU;
   a.cur_item = st.cur_item[k]; a.cur_user = st.cur_user[k]; a.cur_uc = st.cur_uc[k];
   a.uc_by_sample = uc_by_list(d, b) ? 1 : 0;
+  a.cseg = cate_seg(d, b) ? 1 : 0;
   a.gLong = w.gLong; a.gDB = w.gDB; a.partials = w.partials; a.Kp = w.Kp;
   if (hp->dropout != 0.0f) {
     if (!(hp->dropout > 0.0f && hp->dropout < 1.0f)) return fail(TLSAN_E_BADARG, "dropout must be in [0, 1)");

@@ -409,8 +409,10 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   constexpr int NBUF = G::NBUF;               // 2: dW of position p overlaps position p+1
   constexpr int WB = 2 * DH * DH + 2 * DH;    // floats of one attention block's weights
   constexpr bool USE_SW = G::USE_SW;          // attention weights staged in LDS (when they fit)
-  constexpr int PSTR = LSC + TLSAN_SN_CAP + 4;  // per-sample position slots: long, session, 3 singles
-  constexpr int P_TGT = LSC + TLSAN_SN_CAP, P_USR = P_TGT + 1, P_UC = P_TGT + 2;
+  // per-sample position slots: long, session (the batch's padded session length, rounded up to 4), 3 singles
+  const int SNS = (a.b.Sn + 3) & ~3;
+  const int PSTR = LSC + SNS + 4;
+  const int P_TGT = LSC + SNS, P_USR = P_TGT + 1, P_UC = P_TGT + 2;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;                   // [NSB][LSTR]  long -> dbridge
@@ -420,7 +422,10 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   float* sH = sS + NW * 4;            // [NSB][2*LS] hist_t and usert*hist_t of the pass
   float* sW = sH + NSB * 2 * LSC;     // [2][WB] attention weights (W1,b1,W2,b2) of both blocks
   int* sP = (int*)(sW + (USE_SW ? 2 * WB : 0));  // [NSB][PSTR] destination-sorted row of every use
-  float* sT = (float*)(sP + (TRAIN ? NSB * PSTR : 0));  // per-wave transpose scratch / staging
+  // CSEG (FwdArgs.cseg, many categories): the category half of an item use's gradient row goes to the category's own
+  // segment of Gc -- its position, drawn from the category's cursor, sits in sPc beside the item position in sP
+  int* sPc = sP + (TRAIN ? NSB * PSTR : 0);      // [NSB][PSTR], only when a.cseg
+  float* sT = (float*)(sPc + ((TRAIN && a.cseg) ? NSB * PSTR : 0));  // per-wave transpose scratch / staging
   constexpr bool KEEP_A = G::KEEP_A && TRAIN && !LSTREAM;
 #ifndef TLSAN_EXP_PIPE5
 #define TLSAN_EXP_PIPE5 1
@@ -440,6 +445,11 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
   for (int kb = 0; kb < NB; ++kb) chb[kb] = col * CW + 16 * kb + 4 * q;
   const bool lead = (q == 0) && (col == 0);  // one lane per sample
+  // where channels [c, c+4) of an item use's gradient row go: the use's row of Gi, or (CSEG, category half) the use's
+  // row in its category's segment of Gc
+  auto use_dst = [&](int pos, int cpos, int c) -> float* {
+    return (a.cseg && c >= a.di) ? a.Gc + (size_t)cpos * a.dc + (c - a.di) : a.Gi + (size_t)pos * D + c;
+  };
 
   if constexpr (TRAIN) {
     // (tlsan_step_out.started: this kernel running means everything queued before the step is complete)
@@ -567,6 +577,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     f32x4 e1[LS][NB], long4[NB], mx1[NB], iz1[NB];
     int posv[(TRAIN && LSTREAM) ? LS + 3 : 1];   // (streamed window: the three single uses, drawn by the lead lane)
     int upos = 0;                                // (window in registers: the cursor draw of this lane's use slot)
+    int ucpos = 0, cposv = 0, scpos0 = 0;        // (CSEG: the category-cursor draws of the same uses)
     const int pmax1 = wave_max_samples<CPS>(n_l);
     // ---- LHELP (streamed windows): a long window is shared by the wavefront's two halves, as a long session is in the
     // short block (HELP, P3).  The launch ends with its slowest workgroup, and with streamed windows that is the one
@@ -709,6 +720,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       load_bias<DH, NB>(w1b2, q, b2);
       if constexpr (TRAIN) {
         posv[LS] = (lead && vs) ? atomicAdd(&a.cur_item[it_i], 1) : 0;
+        cposv = (lead && vs && a.cseg) ? atomicAdd(&a.cur_uc[ct_i], 1) : 0;
         posv[LS + 1] = (lead && vs) ? atomicAdd(&a.cur_user[uid], 1) : 0;
         // (a per-lane copy of the flag: a scalar branch here would split the batch of returning atomics)
         posv[LS + 2] = (lead && vs && (a.uc_by_sample + opaque_zero(lane)) == 0) ? atomicAdd(&a.cur_uc[a.b.u_cate[bb]], 1) : bidx;
@@ -732,6 +744,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           if (t < Ls) {
             const bool vt = vs && t < n_l;
             sP[srow * PSTR + t] = vt ? atomicAdd(&a.cur_item[lid], 1) : 0;
+            if (a.cseg) sPc[srow * PSTR + t] = vt ? atomicAdd(&a.cur_uc[lct], 1) : 0;
             sH[srow * 2 * LSC + t] = vt ? lht : 0.0f;
             sH[srow * 2 * LSC + LSC + t] = vt ? lut * lht : 0.0f;
           }
@@ -871,6 +884,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         int32_t* cur = kku <= LS ? a.cur_item : (kku == LS + 1 ? a.cur_user : a.cur_uc);
         const bool act = vs && (is_long ? kku < n_l : (kku < LS + 2 || (kku == LS + 2 && a.uc_by_sample == 0)));
         upos = act ? atomicAdd(cur + id, 1) : (kku == LS + 2 ? bidx : 0);   // (u_cate rows in sample order: position = sample)
+        if (a.cseg) ucpos = (act && kku <= LS) ? atomicAdd(&a.cur_uc[is_long ? ct_k : ct_i], 1) : 0;
         if constexpr (SESS_EARLY) spos0 = (vs && kk < n_s) ? atomicAdd(&a.cur_item[sid], 1) : 0;
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -971,10 +985,12 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           sP[srow * PSTR + P_TGT] = posv[LS];
           sP[srow * PSTR + P_USR] = posv[LS + 1];
           sP[srow * PSTR + P_UC] = posv[LS + 2];
+          if (a.cseg) sPc[srow * PSTR + P_TGT] = cposv;
         }
       } else {
         const int kku = q * CPS + col;   // use slot of this lane (P_TGT, P_USR, P_UC are consecutive)
         if (kku < LS + 3) sP[srow * PSTR + (kku < LS ? kku : P_TGT + (kku - LS))] = upos;
+        if (a.cseg && kku <= LS) sPc[srow * PSTR + (kku < LS ? kku : P_TGT)] = ucpos;
       }
     }
     opd FT1[NB][NB], FT2[NB][NB];
@@ -985,7 +1001,10 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     load_bias<DH, NB>(w2b2, q, b2);
     if constexpr (!SESS_EARLY) {
       load_chunk(0);
-      if constexpr (TRAIN) spos0 = (vs && kk < n_s) ? atomicAdd(&a.cur_item[sid], 1) : 0;
+      if constexpr (TRAIN) {
+        spos0 = (vs && kk < n_s) ? atomicAdd(&a.cur_item[sid], 1) : 0;
+        if (a.cseg) scpos0 = (vs && kk < n_s) ? atomicAdd(&a.cur_uc[scat], 1) : 0;
+      }
       if (pmax2 > 1) fetch_row(0, xnext);
     }
     TLSAN_STAMP(24);
@@ -1141,9 +1160,14 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       }
     if constexpr (TRAIN) {  // publish the session positions (the atomics are long back by now)
       if (vs && kk < n_s) sP[srow * PSTR + LSC + kk] = spos0;
+      if (a.cseg && vs && kk < n_s) sPc[srow * PSTR + LSC + kk] = scpos0;
       for (int base = NL; base < pmax2 - 1; base += NL) {  // sessions longer than one chunk (rare)
         const int t = base + kk;
-        if (vs && t < n_s) sP[srow * PSTR + LSC + t] = atomicAdd(&a.cur_item[a.b.hist_i_new[(size_t)bb * Sn + t]], 1);
+        if (vs && t < n_s) {
+          const int sidt = a.b.hist_i_new[(size_t)bb * Sn + t];
+          sP[srow * PSTR + LSC + t] = atomicAdd(&a.cur_item[sidt], 1);
+          if (a.cseg) sPc[srow * PSTR + LSC + t] = atomicAdd(&a.cur_uc[a.p.item_cate[sidt]], 1);
+        }
       }
     }
     TLSAN_STAMP(25);
@@ -1177,6 +1201,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       const float sg = logit >= 0.0f ? rden : en * rden;
       const float dl = vs ? (sg - yv) * a.inv_B : 0.0f;
       const int pos_t = sP[srow * PSTR + P_TGT], pos_u = sP[srow * PSTR + P_USR], pos_c = sP[srow * PSTR + P_UC];
+      const int cpos_t = a.cseg ? sPc[srow * PSTR + P_TGT] : 0;
       if (lead && vs) {
         a.Gb[pos_t] = dl;  // per-use item_b gradient
         loss_acc += lb;
@@ -1193,7 +1218,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           // user use: [user_emb half] -> Gu (grouped by user), [u_cate half] -> Gc (grouped by category)
           float* up = (c < a.di) ? a.Gu + (size_t)pos_u * a.WU + c : a.Gc + (size_t)pos_c * a.dc + (c - a.di);
           st4_out(up, dout[kb]);
-          st4_out(a.Gi + (size_t)pos_t * D + c, gi);  // candidate use
+          st4_out(use_dst(pos_t, cpos_t, c), gi);  // candidate use
           sq_acc += dot4(dout[kb], dout[kb]) + dot4(gi, gi);
         }
       }
@@ -1303,10 +1328,11 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             }
           } else if ((vs || oth) && vt) {
             const int pos = sP[(wave * SPW + s_sel) * PSTR + LSC + t];
+            const int cpos = a.cseg ? sPc[(wave * SPW + s_sel) * PSTR + LSC + t] : 0;
             if (lead) a.Gb[pos] = 0.0f;
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) {
-              st4_out(a.Gi + (size_t)pos * D + chb[kb], dx[kb]);
+              st4_out(use_dst(pos, cpos, chb[kb]), dx[kb]);
               sq_acc += dot4(dx[kb], dx[kb]);
             }
           }
@@ -1512,11 +1538,12 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
               const float ds = sample_sum<CPS>(dsp) * P;  // d loss / d scale[p]
               if ((vs || oth) && vp) {
                 const int pos = sP[my_row * PSTR + my_p];
+                const int cpos = a.cseg ? sPc[my_row * PSTR + my_p] : 0;
                 if (lead) a.Gb[pos] = 0.0f;
 #pragma unroll
                 for (int kb = 0; kb < NB; ++kb) {
                   const f32x4 de = dx[kb] * sce;
-                  st4_out(a.Gi + (size_t)pos * D + chb[kb], de);
+                  st4_out(use_dst(pos, cpos, chb[kb]), de);
                   sq_acc += dot4(de, de);
                 }
                 if (lead) {
@@ -1592,7 +1619,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         const int wofs = r * TSTR + 4 * q;
 #pragma unroll
         for (int p = 0; p < LS; ++p) dsp[p] = 0.0f;
-        int posp_c = sP[srow * PSTR];
+        int posp_c = sP[srow * PSTR], cposp_c = a.cseg ? sPc[srow * PSTR] : 0;
         float uth_c = sH[srow * 2 * LSC + LSC];
         f32x4 av_c[NB];
 #pragma unroll
@@ -1604,7 +1631,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             if (p == 1) TLSAN_STAMP(16);
             if (p == 2) TLSAN_STAMP(17);
             if (p == 9) TLSAN_STAMP(18);
-            const int posp = posp_c;
+            const int posp = posp_c, cposp = cposp_c;
             const float uth = uth_c;
             const float scp = (gamma * P * P) * uth;  // x = e_stored * scp
             const float sce = (gamma * P) * uth;      // d x / d e_true
@@ -1617,6 +1644,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             if (p >= 1) read_tiles(0, 1);                            // x, dz1 of p - 1
             if (p + 1 < LS) {                                        // the next position's LDS operands, a whole iteration ahead
               posp_c = sP[srow * PSTR + p + 1];
+              if (a.cseg) cposp_c = sPc[srow * PSTR + p + 1];
               uth_c = sH[srow * 2 * LSC + LSC + p + 1];
 #pragma unroll
               for (int kb = 0; kb < NB; ++kb) av_c[kb] = *(const f32x4*)(sAw + ((p + 1) * NB + kb) * 256);
@@ -1673,7 +1701,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
               for (int kb = 0; kb < NB; ++kb) {
                 const f32x4 de = dx[kb] * sce;
-                st4_out(a.Gi + (size_t)posp * D + chb[kb], de);
+                st4_out(use_dst(posp, cposp, chb[kb]), de);
                 sq_acc += dot4(de, de);
               }
             }
@@ -1701,6 +1729,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             }
 #endif
             const int posp = sP[srow * PSTR + p];   // (read with the position's other LDS operands; used by its stores)
+            const int cposp = a.cseg ? sPc[srow * PSTR + p] : 0;
             const float uth = sH[srow * 2 * LSC + LSC + p];
             const float scp = (gamma * P * P) * uth;  // x = e_stored * scp
             const float sce = (gamma * P) * uth;      // d x / d e_true
@@ -1777,7 +1806,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #if TLSAN_EXP_ABL & 1
                 asm volatile("" :: "v"(de), "v"(pos));   // (timing experiment: no gradient-row stores in the long backward)
 #else
-                st4_out(a.Gi + (size_t)pos * D + chb[kb], de);
+                st4_out(use_dst(pos, cposp, chb[kb]), de);
 #endif
                 sq_acc += dot4(de, de);
               }

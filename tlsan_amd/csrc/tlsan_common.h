@@ -487,6 +487,8 @@ struct FwdArgs {
   int32_t uc_by_sample;   // != 0: Gc rows are written in SAMPLE order (row b = sample b) and the index holds the
                           // samples of every category (uc_list, k_uc_fill): no cursor is drawn for the u_cate use
   int32_t fuse_dk;  // != 0: this launch forms the dK partials itself (Geo::FUSE_DK builds; chosen per launch, tlsan_api.hip)
+  int32_t cseg;     // != 0 (many categories): the category half of every item use's gradient row is written into the
+                    // category's own segment of Gc (position drawn from cur_uc), not beside the item half in Gi
   float* gLong;     // [B, D]   long-term summaries (A operand of dK)   -- written only when the dK product is NOT fused
   float* gDB;       // [B, D]   d loss / d bridge     (B operand of dK)
   float* Kp;        // fused dK (Geo::FUSE_DK): [gridDim.x][D*D] partial products long^T . dbridge, one per workgroup

@@ -48,6 +48,10 @@ struct CountArgs {
   tlsan_batch b;
   int32_t Ls;
   int32_t* cnt_item; int32_t* cnt_user; int32_t* cnt_uc;  // persistent, zero at rest
+  // CSEG (many categories): every item use also counts into its item's category -- the category half of its gradient row
+  // will sit in that category's segment of Gc, next to the u_cate uses (ApplyArgs.cseg)
+  const int32_t* item_cate;
+  int32_t cseg;
 };
 
 // Use counts per destination row: one thread per (sample, slot); slots [0,Ls) long positions,
@@ -61,12 +65,22 @@ __global__ void k_count(CountArgs a) {
   if (t >= B * S) return;
   const int b = t / S, slot = t - b * S;
   if (slot < Ls) {
-    if (slot < min(a.b.sl[b], Ls)) atomicAdd(&a.cnt_item[a.b.hist_i[(size_t)b * Ls + slot]], 1);
+    if (slot < min(a.b.sl[b], Ls)) {
+      const int id = a.b.hist_i[(size_t)b * Ls + slot];
+      atomicAdd(&a.cnt_item[id], 1);
+      if (a.cseg) atomicAdd(&a.cnt_uc[a.item_cate[id]], 1);
+    }
   } else if (slot < Ls + Sn) {
     const int k = slot - Ls;
-    if (k < min(a.b.sl_new[b], Sn)) atomicAdd(&a.cnt_item[a.b.hist_i_new[(size_t)b * Sn + k]], 1);
+    if (k < min(a.b.sl_new[b], Sn)) {
+      const int id = a.b.hist_i_new[(size_t)b * Sn + k];
+      atomicAdd(&a.cnt_item[id], 1);
+      if (a.cseg) atomicAdd(&a.cnt_uc[a.item_cate[id]], 1);
+    }
   } else if (slot == Ls + Sn) {
-    atomicAdd(&a.cnt_item[a.b.i[b]], 1);
+    const int id = a.b.i[b];
+    atomicAdd(&a.cnt_item[id], 1);
+    if (a.cseg) atomicAdd(&a.cnt_uc[a.item_cate[id]], 1);
   } else {
     atomicAdd(&a.cnt_user[a.b.u[b]], 1);
     atomicAdd(&a.cnt_uc[a.b.u_cate[b]], 1);
@@ -647,6 +661,9 @@ struct ApplyArgs {
   const int4* urec_item; const int4* urec_user;   // lazy L2: (row, first position, uses) of the rows used this step
   const int32_t* cate_off; const int32_t* cate_cnt; const int32_t* cate_items;  // static CSR
   const int32_t* uc_list;  // optional: samples of every category (segments off_uc); then Gc is in sample order
+  int32_t cseg;            // != 0 (many categories): a category's segment of Gc holds its u_cate uses AND the category halves
+                           // of its items' uses (k_fwd_bwd, FwdArgs.cseg): the category blocks sum that one segment and
+                           // do not walk the category's items
   const float* gd;
   float* Rc; float* Ri; float* Rb; float* Ru;   // PRESUM -> k_update_lazy: summed rows [C][dc], [slot][di], [slot], [slot][WU]
   int32_t presum_rows;     // PRESUM: write the item / user sums to the rows of `go` instead (tlsan_grads with reg = 0)
@@ -872,7 +889,9 @@ __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx
   double part = 0.0;
   int nu = 0;
   if constexpr (MODE != AP_SUMSQ) {
-    const int i0 = a.cate_off[c], ni = a.cate_cnt[c];
+    // (CSEG: nothing to walk -- the category halves of the items' uses sit in this category's segment of Gc, with the
+    //  u_cate uses: `nu` below counts both)
+    const int i0 = a.cseg ? 0 : a.cate_off[c], ni = a.cseg ? 0 : a.cate_cnt[c];
     int ou = a.off_uc[c];
     const int nu_all = a.off_uc[c + 1] - ou;
     nu = nu_all;
