@@ -215,6 +215,76 @@ def test_c4_movies_tv_window_90_sharded_over_two_ranks():
     assert all(ret.get(r) == "ok" for r in range(world)), dict(ret)
 
 
+# ------------------------------------------------------------------------------------------- C5, sharded
+def _c5_sharded_worker(rank, world, port, ret):
+    import gc
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tlsan_amd import synth
+        from tlsan_amd.dist import ShardedModel
+        cfg = synth.make_config("electronics", Ls=90, hidden_units=256, itemid_embedding_size=128, userid_embedding_size=128,
+                                cateid_embedding_size=128, user_count=10_000_000, item_count=5_000_000, cate_count=10_000)
+        icl = synth.item_cate_list(cfg)
+        B = 1024
+        per_step = [[synth.make_batches(cfg, 1, B, seed=500 + 10 * s + r)[0] for r in range(world)] for s in range(3)]
+
+        def run(static):
+            m = ShardedModel(cfg, icl, device="cuda:0", l2_mode="lazy", static_rows=static, init="device", seed=11)
+            dbs = [m.device_batch(per[rank]) for per in per_step]
+            rows0 = m.shard[:4096].clone()
+            losses = []
+            for s, db in enumerate(dbs):
+                kw = dict(after_next=dbs[s + 2] if s + 2 < len(dbs) else None) if static else {}
+                m.train_async(db, 1.0, next_batch=dbs[s + 1] if s + 1 < len(dbs) else None, **kw)
+                losses.append(float(m.last_loss.item()))
+            if static:
+                m.check_static_overflow()
+            changed = int((m.shard[:4096] != rows0).any(dim=1).sum().item())   # (before the fold, which rescales every row)
+            m.fold_scale()
+            torch.cuda.synchronize()
+            # (the shard stays on the device: 7.5 M rows of 220 floats per rank -- compare digests, keep a slice)
+            digest = [float(m.shard.double().sum().item()), float(m.shard.double().pow(2).sum().item()),
+                      float(m.cate_emb.double().sum().item()), float(m.dense.double().sum().item())]
+            head = m.shard[:4096].cpu().numpy().copy()
+            del m, dbs
+            gc.collect()
+            torch.cuda.empty_cache()
+            return losses, digest, head, changed
+        l1, d1, h1, c1 = run(False)
+        l2, d2, h2, c2 = run(False)
+        assert l1 == l2 and d1 == d2 and np.array_equal(h1, h2)          # bitwise reproducible
+        l3, d3, h3, c3 = run(True)
+        assert l3 == l1 and d3 == d1 and np.array_equal(h3, h1)          # static-shape exchanges: the same step, bit for bit
+        assert np.isfinite(l1).all() and l1[0] > 100.0                   # the L2 term of 10^7 usert rows at -1
+        assert 0 < c1 < 4096                                             # lazy L2: only rows that received a gradient moved
+        ret[rank] = "ok"
+    except Exception:
+        import traceback
+        ret[rank] = "FAIL: " + traceback.format_exc()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_c5_tables_sharded_over_two_ranks():
+    """BASELINE.json configs[4] (10 M users / 5 M items / 10 k categories, d = 256, window 90) through the SHARDED step: two
+    ranks (two processes on cuda:0, gloo), each holding half of the rows (7.5 M fused rows of 220 floats), 1024
+    sequences per rank and step.  Properties (the oracle cannot run this size): bitwise reproducible; the static-shape
+    step (fixed-size exchanges, plans two batches ahead) equals the sized one bit for bit; lazy L2 leaves rows without
+    a gradient alone."""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_c5_sharded_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(1500)
+    assert all(ret.get(r) == "ok" for r in range(world)), dict(ret)
+
+
 # ------------------------------------------------------------------------------------------- multi-GPU over RCCL
 def _nccl_worker(rank, world, port, ret):
     import torch.distributed as dist

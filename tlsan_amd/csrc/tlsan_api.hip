@@ -334,6 +334,7 @@ static void fill_apply(ApplyArgs& A, const tlsan_dims* d, const Shape& s, const 
   A.urec_item = st.urec_item[k]; A.urec_user = st.urec_user[k];
   if (hp) { A.lr = hp->lr; A.reg = hp->reg; }
   A.nbI = st.nbI; A.nbU = st.nbU; A.nbC = st.nbC; A.nbD = (L.n_dense + 255) / 256;
+  if (A.cseg) A.nbC = (A.C + AP_ROWS_PB - 1) / AP_ROWS_PB;     // (16 categories per workgroup: apply_cseg_block)
   A.stamps = g_stamps ? g_stamps + TLSAN_APPLY_STAMP_OFF : nullptr;
 }
 
@@ -710,7 +711,7 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
     // lazy update: the exact row sums of the apply pass share the launch (they wait for nothing it produces)
     ApplyArgs A = *presum;
     lazy_blocks(A, b->B, b->Sn);
-    A.nbC = A.C * A.csplit;
+    A.nbC = A.cseg ? (A.C + AP_ROWS_PB - 1) / AP_ROWS_PB : A.C * A.csplit;
     A.nbH = AP_HOT_CAP;   // hot item rows: a workgroup each, leading the grid
     const dim3 grid(w.nfin + 1 + A.nbH + A.nbC + A.nbI + A.nbU);
     const bool wide = apply_wide(A);

@@ -1298,6 +1298,135 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
   else if constexpr (MODE != AP_GRADS) block_part_store(part, shp, &a.part_out[x.blk]);
 }
 
+// ================= CSEG: 16 category rows per workgroup (one per 16-lane group) =================
+// With ApplyArgs.cseg a category's gradient is ONE contiguous segment of Gc (its u_cate uses and the category halves of
+// its items' uses), so category rows are summed like item and user rows -- a 16-lane group per row, OWN rows in flight,
+// the wavefront finishing long segments -- instead of by a workgroup each (10 k categories: 10 k workgroups of a
+// few uses, each with the list machinery of apply_cate_block).  Block b handles categories [16 b, 16 b + 16).
+template <int MODE, bool LAZY, int NCH, int OWN, int DT>
+__device__ __forceinline__ void apply_cseg_block(const ApplyArgs& a, const ApCtx& x, int c0, double* shp) {
+  constexpr bool RESET = MODE == AP_UPDATE || MODE == AP_GRADS || MODE == AP_PRESUM;
+  const int lane = x.lane, grp = x.grp, l16 = x.l16;
+  const int c = c0 + x.gid;
+  const bool vr = c < a.C;
+  const int cc = vr ? c : 0;
+  const int W4 = a.dc / 4;
+  int off = 0, n = 0;
+  if constexpr (MODE != AP_SUMSQ) {
+    off = a.off_uc[cc];
+    n = vr ? a.off_uc[cc + 1] - off : 0;
+  }
+  const size_t wrow = (size_t)cc * a.dc;
+  f32x4 w[NCH];
+  if constexpr (MODE != AP_PRESUM) {
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+      if (l16 + 16 * ch < W4) w[ch] = tbl_ld4<DT>(a.p.cate_emb, wrow + 4 * (l16 + 16 * ch));
+  }
+  double acc[NCH][4];
+  zero_acc(acc);
+  double part = 0.0;
+  if constexpr (MODE != AP_SUMSQ) {
+    const int n_own = min(n, OWN);
+    {
+      f32x4 v[OWN][NCH];
+      const int last = max(n_own - 1, 0);
+#pragma unroll
+      for (int u = 0; u < OWN; ++u) {
+        const float* src = a.Gc + (size_t)(off + min(u, last)) * a.dc;  // (the buffer carries a pad row)
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+          if (l16 + 16 * ch < W4) v[u][ch] = *(const f32x4*)(src + 4 * (l16 + 16 * ch));
+      }
+#pragma unroll
+      for (int u = 0; u < OWN; ++u)
+        if (u < n_own) {
+#pragma unroll
+          for (int ch = 0; ch < NCH; ++ch)
+            if (l16 + 16 * ch < W4) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc[ch][i] += exact_term(v[u][ch][i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int ng = __shfl(n, g * 16);
+      if (ng > OWN) {  // wave-uniform: the four groups split the rest of group g's segment
+        const int og = __shfl(off, g * 16);
+        double t[NCH][4];
+        zero_acc(t);
+        seg_accum<NCH>(a.Gc, a.dc, og + OWN + grp, og + ng, 4, W4, l16, t);
+        combine_groups(t);
+        if (grp == g) {
+#pragma unroll
+          for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[ch][i] += t[ch][i];
+        }
+      }
+    }
+  }
+  if constexpr (MODE == AP_PRESUM) {
+    if (vr) {
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        const int c4 = l16 + 16 * ch;
+        if (c4 < W4) {
+          f32x4 g;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) g[i] = (float)acc[ch][i];
+          *(f32x4*)(a.Rc + wrow + 4 * c4) = g;
+        }
+      }
+      if (l16 == 0 && n > 0) a.cnt_uc[c] = 0;
+    }
+    return;
+  }
+  if (vr) {
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int c4 = l16 + 16 * ch;
+      if (c4 >= W4) continue;
+      f32x4 g;
+      const f32x4 w0 = w[ch];
+      double pe = 0.0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float wi = w[ch][i];
+        g[i] = apply_elem<MODE, LAZY>(wi, (float)acc[ch][i], x.P, x.invP, a.reg, x.step, x.lazy_scale, pe);
+        w[ch][i] = wi;
+      }
+      if constexpr (MODE == AP_GRADS) *(f32x4*)(a.go.cate_emb + (size_t)c * a.dc + 4 * c4) = g;
+      if constexpr (MODE == AP_UPDATE && !LAZY) {
+        if (a.opt != TLSAN_OPT_SGD) {
+          f32x4 m1 = *(const f32x4*)(a.s1.cate_emb + wrow + 4 * c4), m2 = *(const f32x4*)(a.s2.cate_emb + wrow + 4 * c4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float wi = w0[i], a1 = m1[i], a2 = m2[i];
+            opt_elem(x.oc, wi, x.coef * g[i], a1, a2);
+            w[ch][i] = wi; m1[i] = a1; m2[i] = a2;
+          }
+          *(f32x4*)(a.s1.cate_emb + wrow + 4 * c4) = m1;
+          *(f32x4*)(a.s2.cate_emb + wrow + 4 * c4) = m2;
+        }
+      }
+      if constexpr (MODE == AP_UPDATE) {
+        tbl_st4<DT>(a.p.cate_emb, wrow + 4 * c4, w[ch], x.salt ^ 0x3c6ef372u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part += (double)w[ch][i] * (double)w[ch][i] - (double)w0[i] * (double)w0[i];
+      } else {
+        part += pe;
+      }
+    }
+    if constexpr (RESET) {
+      if (l16 == 0 && n > 0) a.cnt_uc[c] = 0;
+    }
+  }
+  if constexpr (MODE == AP_UPDATE) block_delta_store(part, shp, &a.delta_out[x.blk], x.salt);
+  else if constexpr (MODE != AP_GRADS) block_part_store(part, shp, &a.part_out[x.blk]);
+}
+
 // ================= one hot item row per workgroup (PRESUM) =================
 template <int NCH>
 __device__ __forceinline__ void presum_hot_block(const ApplyArgs& a, int h, double* shd, double* shp) {
@@ -1396,7 +1525,8 @@ __global__ __launch_bounds__(256) void k_apply(ApplyArgs a) {
   x.oc.opt = a.opt; x.oc.lr = a.lr; x.oc.b1 = a.ob1; x.oc.b2 = a.ob2; x.oc.eps = a.oeps; x.oc.alpha = a.oalpha;
   const int blk = x.blk;
   if (blk < a.nbC) {
-    apply_cate_block<MODE, LAZY, NC, DT>(a, x, shd, shp, sh_pos, sh_lo, sh_n, sh_wtot);
+    if (a.cseg) apply_cseg_block<MODE, LAZY, NC, AP_OWN, DT>(a, x, blk * AP_ROWS_PB, shp);   // (nbC = ceil(C / 16) then)
+    else apply_cate_block<MODE, LAZY, NC, DT>(a, x, shd, shp, sh_pos, sh_lo, sh_n, sh_wtot);
   } else if (blk < a.nbC + a.nbI) {
     apply_rows_block<MODE, LAZY, true, NI, AP_OWN, DT>(a, x, (blk - a.nbC) * AP_ROWS_PB, shp);
   } else if (blk < a.nbC + a.nbI + a.nbU) {
@@ -1474,7 +1604,10 @@ __global__ __launch_bounds__(256) void k_finalize_presum(FinArgs f, int nbK, int
   unsigned long long* stp = a.stamps ? a.stamps + (size_t)x.blk * 8 : nullptr;
   if (stp && x.tid == 0) { stp[0] = __builtin_amdgcn_s_memtime(); stp[4] = __builtin_amdgcn_s_memrealtime(); }
   const int blk = x.blk;
-  if (blk < a.nbC) apply_cate_block<AP_PRESUM, true, NC, TLSAN_TABLE_F32, CSPLIT>(a, x, shd, shp, sh_pos, sh_lo, sh_n, sh_wtot);
+  if (blk < a.nbC) {
+    if (!CSPLIT && a.cseg) apply_cseg_block<AP_PRESUM, true, NC, AP_OWN, TLSAN_TABLE_F32>(a, x, blk * AP_ROWS_PB, shp);
+    else apply_cate_block<AP_PRESUM, true, NC, TLSAN_TABLE_F32, CSPLIT>(a, x, shd, shp, sh_pos, sh_lo, sh_n, sh_wtot);
+  }
   else if (blk < a.nbC + a.nbI) apply_rows_block<AP_PRESUM, true, true, NI, AP_OWN, TLSAN_TABLE_F32>(a, x, (blk - a.nbC) * AP_ROWS_PB, shp);
   else apply_rows_block<AP_PRESUM, true, false, NU, AP_OWN / 2, TLSAN_TABLE_F32>(a, x, (blk - a.nbC - a.nbI) * AP_ROWS_PB, shp);
   if (stp && x.tid == 0) { stp[6] = __builtin_amdgcn_s_memtime(); stp[5] = __builtin_amdgcn_s_memrealtime(); }

@@ -262,7 +262,7 @@ class ShardedModel:
     """Model surface (train / eval_auc / ...) over row-sharded tables; see module docstring."""
 
     def __init__(self, config, item_cate_list, device="cuda:0", seed=1234, group=None, l2_mode="dense", static_rows=False,
-                 wire_dtype="f32"):
+                 wire_dtype="f32", init="numpy"):
         """l2_mode: "dense" -- every owner decays every one of its rows every step, as the reference's dense L2
         gradient does; "lazy" (sgd) -- the same update kept as W = P * W_stored with one scale P that all ranks
         advance alike, so an owner touches only the rows whose gradients arrived (tlsan_shard_apply_lazy).
@@ -383,7 +383,33 @@ class ShardedModel:
         self.global_epoch_step = _Var(lambda: self._epoch)
         self.train_writer = _Writer(os.path.join(config.get("model_dir", "."), "train"))
         self.eval_writer = _Writer(os.path.join(config.get("model_dir", "."), "eval"))
-        self.set_params(Model.init_params(config, seed))   # identical on every rank (numpy, seeded)
+        if init == "device":
+            # the same distributions drawn on the device, shard by shard (tables of 10^7 rows: the host draw of the whole
+            # model on every rank takes minutes and tens of GB); NOT the values of Model(init="numpy") on one GPU
+            self._init_on_device(config, seed)
+        elif init == "numpy":
+            self.set_params(Model.init_params(config, seed))   # identical on every rank (numpy, seeded)
+        else:
+            raise ValueError("init must be 'numpy' or 'device'")
+
+    def _init_on_device(self, config, seed):
+        di, Ls, cI = self.di, self.Ls, self.cI
+        g = torch.Generator(device=self.device)
+        g.manual_seed(int(seed) * 1000003 + self.rank)
+        n_i = len(range(self.rank, self.I, self.world))
+        n_u = len(range(self.rank, self.U, self.world))
+        self.shard.zero_()
+        li, lu = float(np.sqrt(6.0 / (self.I + di))), float(np.sqrt(6.0 / (self.U + di)))
+        self.shard[:n_i, :di].uniform_(-li, li, generator=g)
+        self.shard[cI:cI + n_u, :di].uniform_(-lu, lu, generator=g)
+        self.shard[cI:cI + n_u, di:di + Ls] = -1.0
+        small = dict(config, item_count=1, user_count=1)
+        p = Model.init_params(small, seed)          # cate_emb and the dense weights: the host stream, the same on every rank
+        self.cate_emb.copy_(torch.as_tensor(np.asarray(p["cate_emb"], np.float32)))
+        self._P.fill_(1.0)
+        self._pack_dense(p)
+        self._refresh_squares()
+        self._reset_step_state()
 
     # ------------------------------------------------------------------ helpers
     def _pack_dense(self, p):
@@ -806,7 +832,7 @@ class ShardedModel:
                       table=torch.zeros(n, pitch, dtype=torch.uint8, device=dev) if G > 1 else None,
                       recv_rows=torch.full((n,), -1, dtype=torch.int32, device=dev),
                       state=torch.zeros(int(nst), dtype=torch.uint8, device=dev), db=None, views={},
-                      done=(torch.cuda.Event(), torch.cuda.Event()), pending=False, fresh=False)
+                      done=(torch.cuda.Event(), torch.cuda.Event()), planned=torch.cuda.Event(), pending=False, fresh=False)
             sl["state"][:4].view(torch.float32).fill_(1.0)     # table scale P = 1 (the owners apply the decay)
             st["slots"][k] = sl
         self._st = st
@@ -885,8 +911,13 @@ class ShardedModel:
             with torch.cuda.stream(stream):
                 st["status_host"].copy_(st["status"], non_blocking=True)
         dims = st["dims"]
+        # the category index of the compact table first (host order only: it also tells the library which item -> category
+        # map the slot's state belongs to, which the destination index of a table with thousands of categories counts by);
+        # the destination index waits for the plan, not for it
+        sl["planned"].record(stream)
+        L.check(self.lib.tlsan_state_recategorize(C.byref(dims), C.byref(cp), sl["state"].data_ptr(), sp), "tlsan_state_recategorize")
         if stream2 is not None:
-            stream2.wait_stream(stream)
+            stream2.wait_event(sl["planned"])
             L.check(self.lib.tlsan_batch_index(C.byref(dims), C.byref(cb), sl["state"].data_ptr(), 0,
                                                C.c_void_p(stream2.cuda_stream)), "tlsan_batch_index")
             sl["done"][1].record(stream2)
@@ -900,7 +931,6 @@ class ShardedModel:
             else:
                 with torch.cuda.stream(stream):
                     a2a(sl["recvbuf"].view(-1), sl["sendbuf"].view(-1), None, None, group if group is not None else self.group)
-        L.check(self.lib.tlsan_state_recategorize(C.byref(dims), C.byref(cp), sl["state"].data_ptr(), sp), "tlsan_state_recategorize")
         if stream2 is None:
             L.check(self.lib.tlsan_batch_index(C.byref(dims), C.byref(cb), sl["state"].data_ptr(), 0, sp), "tlsan_batch_index")
         else:
