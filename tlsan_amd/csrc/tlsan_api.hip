@@ -119,7 +119,8 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
   w->Gb = (float*)take(sizeof(float) * (NI + 1));
   w->Gu = (float*)take(sizeof(float) * (size_t)(B + 1) * w->WU);
   // (CSEG: one row per u_cate use AND per item use -- sized for it whenever the table shape can take that path)
-  w->Gc = (float*)take(sizeof(float) * (size_t)(B + 1 + (d->cate_count >= TLSAN_CSEG_MIN_CATES ? NI : 0)) * d->d_cate);
+  static const int cseg_min = [] { const char* v = getenv("TLSAN_CSEG_MIN"); return v ? atoi(v) : TLSAN_CSEG_MIN_CATES; }();
+  w->Gc = (float*)take(sizeof(float) * (size_t)(B + 1 + (d->cate_count >= cseg_min ? NI : 0)) * d->d_cate);
   w->gLong = (float*)take(sizeof(float) * B * D);
   w->gDB = (float*)take(sizeof(float) * B * D);
   w->partials = (float*)take(sizeof(float) * w->ngroups * s.NPB);
@@ -182,7 +183,8 @@ static const int32_t* item_cate_of(const void* state) {
 }
 static inline bool cate_seg(const tlsan_dims* d, const tlsan_batch* b) {
   static const int on = [] { const char* v = getenv("TLSAN_CSEG"); return v ? atoi(v) : 1; }();
-  return on && d->cate_count >= TLSAN_CSEG_MIN_CATES && !uc_by_list(d, b);
+  static const int min_cates = [] { const char* v = getenv("TLSAN_CSEG_MIN"); return v ? atoi(v) : TLSAN_CSEG_MIN_CATES; }();   // (experiments)
+  return on && d->cate_count >= min_cates && !uc_by_list(d, b);
 }
 struct St {  // persistent state
   // two index slots (a batch's destination index depends only on its ids, so it lives with the

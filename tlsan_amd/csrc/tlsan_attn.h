@@ -396,9 +396,13 @@ __device__ __forceinline__ void online_step(f32x4 (&mx)[NB], f32x4 (&Z)[NB], f32
 #endif
 // LSTREAM: the long block is streamed like the short one (any Ls <= TLSAN_LS_CAP); otherwise its
 // Ls <= TLSAN_LS_MAX positions stay in registers between forward and backward.
-template <int D, int DH, bool TRAIN, bool LSTREAM, int DT = TLSAN_TABLE_F32, bool DROP = false, int MM = TLSAN_MATRIX_F32>
+// CSEG (FwdArgs.cseg, tables with thousands of categories): the category half of every item use's gradient row goes to
+// the category's own segment of Gc.  A compile-time variant: as a run-time flag its tests sat inside the pipelined
+// loops of the variant that does not need it (C3 shape: 61.0 -> 62.9 us/step).
+template <int D, int DH, bool TRAIN, bool LSTREAM, int DT = TLSAN_TABLE_F32, bool DROP = false, int MM = TLSAN_MATRIX_F32, bool CSEG = false>
 __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   static_assert(!DROP || TRAIN, "dropout: train steps only");
+  static_assert(!CSEG || TRAIN, "category segments: train steps only");
   using G = Geo<D, DH>;
   using opd = typename MMT<MM>::opd;   // an operand of one 16-deep contraction (tlsan_common.h)
   constexpr int NB = G::NB, CPS = G::CPS, SPW = G::SPW, NW = G::NW, NSB = G::NSB;
@@ -410,7 +414,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   constexpr int WB = 2 * DH * DH + 2 * DH;    // floats of one attention block's weights
   constexpr bool USE_SW = G::USE_SW;          // attention weights staged in LDS (when they fit)
   // per-sample position slots: long, session (the batch's padded session length, rounded up to 4), 3 singles
-  const int SNS = (a.b.Sn + 3) & ~3;
+  // (CSEG keeps two such arrays and sizes them by the batch; otherwise the slot count is a compile-time constant)
+  const int SNS = CSEG ? ((a.b.Sn + 3) & ~3) : TLSAN_SN_CAP;
   const int PSTR = LSC + SNS + 4;
   const int P_TGT = LSC + SNS, P_USR = P_TGT + 1, P_UC = P_TGT + 2;
 
@@ -425,7 +430,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   // CSEG (FwdArgs.cseg, many categories): the category half of an item use's gradient row goes to the category's own
   // segment of Gc -- its position, drawn from the category's cursor, sits in sPc beside the item position in sP
   int* sPc = sP + (TRAIN ? NSB * PSTR : 0);      // [NSB][PSTR], only when a.cseg
-  float* sT = (float*)(sPc + ((TRAIN && a.cseg) ? NSB * PSTR : 0));  // per-wave transpose scratch / staging
+  float* sT = (float*)(sPc + ((TRAIN && CSEG) ? NSB * PSTR : 0));  // per-wave transpose scratch / staging
   constexpr bool KEEP_A = G::KEEP_A && TRAIN && !LSTREAM;
 #ifndef TLSAN_EXP_PIPE5
 #define TLSAN_EXP_PIPE5 1
@@ -448,7 +453,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   // where channels [c, c+4) of an item use's gradient row go: the use's row of Gi, or (CSEG, category half) the use's
   // row in its category's segment of Gc
   auto use_dst = [&](int pos, int cpos, int c) -> float* {
-    return (a.cseg && c >= a.di) ? a.Gc + (size_t)cpos * a.dc + (c - a.di) : a.Gi + (size_t)pos * D + c;
+    return (CSEG && c >= a.di) ? a.Gc + (size_t)cpos * a.dc + (c - a.di) : a.Gi + (size_t)pos * D + c;
   };
 
   if constexpr (TRAIN) {
@@ -720,7 +725,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       load_bias<DH, NB>(w1b2, q, b2);
       if constexpr (TRAIN) {
         posv[LS] = (lead && vs) ? atomicAdd(&a.cur_item[it_i], 1) : 0;
-        cposv = (lead && vs && a.cseg) ? atomicAdd(&a.cur_uc[ct_i], 1) : 0;
+        cposv = (lead && vs && CSEG) ? atomicAdd(&a.cur_uc[ct_i], 1) : 0;
         posv[LS + 1] = (lead && vs) ? atomicAdd(&a.cur_user[uid], 1) : 0;
         // (a per-lane copy of the flag: a scalar branch here would split the batch of returning atomics)
         posv[LS + 2] = (lead && vs && (a.uc_by_sample + opaque_zero(lane)) == 0) ? atomicAdd(&a.cur_uc[a.b.u_cate[bb]], 1) : bidx;
@@ -744,7 +749,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           if (t < Ls) {
             const bool vt = vs && t < n_l;
             sP[srow * PSTR + t] = vt ? atomicAdd(&a.cur_item[lid], 1) : 0;
-            if (a.cseg) sPc[srow * PSTR + t] = vt ? atomicAdd(&a.cur_uc[lct], 1) : 0;
+            if constexpr (CSEG) sPc[srow * PSTR + t] = vt ? atomicAdd(&a.cur_uc[lct], 1) : 0;
             sH[srow * 2 * LSC + t] = vt ? lht : 0.0f;
             sH[srow * 2 * LSC + LSC + t] = vt ? lut * lht : 0.0f;
           }
@@ -884,7 +889,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         int32_t* cur = kku <= LS ? a.cur_item : (kku == LS + 1 ? a.cur_user : a.cur_uc);
         const bool act = vs && (is_long ? kku < n_l : (kku < LS + 2 || (kku == LS + 2 && a.uc_by_sample == 0)));
         upos = act ? atomicAdd(cur + id, 1) : (kku == LS + 2 ? bidx : 0);   // (u_cate rows in sample order: position = sample)
-        if (a.cseg) ucpos = (act && kku <= LS) ? atomicAdd(&a.cur_uc[is_long ? ct_k : ct_i], 1) : 0;
+        if constexpr (CSEG) ucpos = (act && kku <= LS) ? atomicAdd(&a.cur_uc[is_long ? ct_k : ct_i], 1) : 0;
         if constexpr (SESS_EARLY) spos0 = (vs && kk < n_s) ? atomicAdd(&a.cur_item[sid], 1) : 0;
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -985,12 +990,12 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           sP[srow * PSTR + P_TGT] = posv[LS];
           sP[srow * PSTR + P_USR] = posv[LS + 1];
           sP[srow * PSTR + P_UC] = posv[LS + 2];
-          if (a.cseg) sPc[srow * PSTR + P_TGT] = cposv;
+          if constexpr (CSEG) sPc[srow * PSTR + P_TGT] = cposv;
         }
       } else {
         const int kku = q * CPS + col;   // use slot of this lane (P_TGT, P_USR, P_UC are consecutive)
         if (kku < LS + 3) sP[srow * PSTR + (kku < LS ? kku : P_TGT + (kku - LS))] = upos;
-        if (a.cseg && kku <= LS) sPc[srow * PSTR + (kku < LS ? kku : P_TGT)] = ucpos;
+        if (CSEG && kku <= LS) sPc[srow * PSTR + (kku < LS ? kku : P_TGT)] = ucpos;
       }
     }
     opd FT1[NB][NB], FT2[NB][NB];
@@ -1003,7 +1008,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       load_chunk(0);
       if constexpr (TRAIN) {
         spos0 = (vs && kk < n_s) ? atomicAdd(&a.cur_item[sid], 1) : 0;
-        if (a.cseg) scpos0 = (vs && kk < n_s) ? atomicAdd(&a.cur_uc[scat], 1) : 0;
+        if constexpr (CSEG) scpos0 = (vs && kk < n_s) ? atomicAdd(&a.cur_uc[scat], 1) : 0;
       }
       if (pmax2 > 1) fetch_row(0, xnext);
     }
@@ -1160,13 +1165,13 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       }
     if constexpr (TRAIN) {  // publish the session positions (the atomics are long back by now)
       if (vs && kk < n_s) sP[srow * PSTR + LSC + kk] = spos0;
-      if (a.cseg && vs && kk < n_s) sPc[srow * PSTR + LSC + kk] = scpos0;
+      if (CSEG && vs && kk < n_s) sPc[srow * PSTR + LSC + kk] = scpos0;
       for (int base = NL; base < pmax2 - 1; base += NL) {  // sessions longer than one chunk (rare)
         const int t = base + kk;
         if (vs && t < n_s) {
           const int sidt = a.b.hist_i_new[(size_t)bb * Sn + t];
           sP[srow * PSTR + LSC + t] = atomicAdd(&a.cur_item[sidt], 1);
-          if (a.cseg) sPc[srow * PSTR + LSC + t] = atomicAdd(&a.cur_uc[a.p.item_cate[sidt]], 1);
+          if constexpr (CSEG) sPc[srow * PSTR + LSC + t] = atomicAdd(&a.cur_uc[a.p.item_cate[sidt]], 1);
         }
       }
     }
@@ -1201,7 +1206,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       const float sg = logit >= 0.0f ? rden : en * rden;
       const float dl = vs ? (sg - yv) * a.inv_B : 0.0f;
       const int pos_t = sP[srow * PSTR + P_TGT], pos_u = sP[srow * PSTR + P_USR], pos_c = sP[srow * PSTR + P_UC];
-      const int cpos_t = a.cseg ? sPc[srow * PSTR + P_TGT] : 0;
+      const int cpos_t = CSEG ? sPc[srow * PSTR + P_TGT] : 0;
       if (lead && vs) {
         a.Gb[pos_t] = dl;  // per-use item_b gradient
         loss_acc += lb;
@@ -1328,7 +1333,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             }
           } else if ((vs || oth) && vt) {
             const int pos = sP[(wave * SPW + s_sel) * PSTR + LSC + t];
-            const int cpos = a.cseg ? sPc[(wave * SPW + s_sel) * PSTR + LSC + t] : 0;
+            const int cpos = CSEG ? sPc[(wave * SPW + s_sel) * PSTR + LSC + t] : 0;
             if (lead) a.Gb[pos] = 0.0f;
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) {
@@ -1538,7 +1543,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
               const float ds = sample_sum<CPS>(dsp) * P;  // d loss / d scale[p]
               if ((vs || oth) && vp) {
                 const int pos = sP[my_row * PSTR + my_p];
-                const int cpos = a.cseg ? sPc[my_row * PSTR + my_p] : 0;
+                const int cpos = CSEG ? sPc[my_row * PSTR + my_p] : 0;
                 if (lead) a.Gb[pos] = 0.0f;
 #pragma unroll
                 for (int kb = 0; kb < NB; ++kb) {
@@ -1619,7 +1624,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         const int wofs = r * TSTR + 4 * q;
 #pragma unroll
         for (int p = 0; p < LS; ++p) dsp[p] = 0.0f;
-        int posp_c = sP[srow * PSTR], cposp_c = a.cseg ? sPc[srow * PSTR] : 0;
+        int posp_c = sP[srow * PSTR], cposp_c = CSEG ? sPc[srow * PSTR] : 0;
         float uth_c = sH[srow * 2 * LSC + LSC];
         f32x4 av_c[NB];
 #pragma unroll
@@ -1644,7 +1649,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             if (p >= 1) read_tiles(0, 1);                            // x, dz1 of p - 1
             if (p + 1 < LS) {                                        // the next position's LDS operands, a whole iteration ahead
               posp_c = sP[srow * PSTR + p + 1];
-              if (a.cseg) cposp_c = sPc[srow * PSTR + p + 1];
+              if constexpr (CSEG) cposp_c = sPc[srow * PSTR + p + 1];
               uth_c = sH[srow * 2 * LSC + LSC + p + 1];
 #pragma unroll
               for (int kb = 0; kb < NB; ++kb) av_c[kb] = *(const f32x4*)(sAw + ((p + 1) * NB + kb) * 256);
@@ -1729,7 +1734,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             }
 #endif
             const int posp = sP[srow * PSTR + p];   // (read with the position's other LDS operands; used by its stores)
-            const int cposp = a.cseg ? sPc[srow * PSTR + p] : 0;
+            const int cposp = CSEG ? sPc[srow * PSTR + p] : 0;
             const float uth = sH[srow * 2 * LSC + LSC + p];
             const float scp = (gamma * P * P) * uth;  // x = e_stored * scp
             const float sce = (gamma * P) * uth;      // d x / d e_true
