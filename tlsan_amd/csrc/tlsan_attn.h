@@ -419,11 +419,19 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   const int PSTR = LSC + SNS + 4;
   const int P_TGT = LSC + SNS, P_USR = P_TGT + 1, P_UC = P_TGT + 2;
 
+#ifndef TLSAN_EXP_FUSE_CONST
+#define TLSAN_EXP_FUSE_CONST 0      // (experiment: 1 = a.fuse_dk taken as true at compile time, only valid for launches that fuse: -0.2 us/step, not worth a variant)
+#endif
+#if TLSAN_EXP_FUSE_CONST
+#define FUSE_RT true
+#else
+#define FUSE_RT (a.fuse_dk != 0)
+#endif
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;                   // [NSB][LSTR]  long -> dbridge
   float* sB = sA + NSB * LSTR;        // [NSB][LSTR]  bridge -> dlong
   float* sL = sB + NSB * LSTR;        // [NSB][LSTR]  long, kept for the fused dK product (TRAIN && FUSE_DK)
-  float* sS = sL + ((TRAIN && G::FUSE_DK && a.fuse_dk) ? NSB * LSTR : 0);  // [NW][4] scalar staging  (sL exists in launches that fuse: tlsan_attn_inst.h)
+  float* sS = sL + ((TRAIN && G::FUSE_DK && FUSE_RT) ? NSB * LSTR : 0);  // [NW][4] scalar staging  (sL exists in launches that fuse: tlsan_attn_inst.h)
   float* sH = sS + NW * 4;            // [NSB][2*LS] hist_t and usert*hist_t of the pass
   float* sW = sH + NSB * 2 * LSC;     // [2][WB] attention weights (W1,b1,W2,b2) of both blocks
   int* sP = (int*)(sW + (USE_SW ? 2 * WB : 0));  // [NSB][PSTR] destination-sorted row of every use
@@ -917,7 +925,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     for (int kb = 0; kb < NB; ++kb) {
       *(f32x4*)(sA + srow * LSTR + chb[kb]) = long4[kb];
       if constexpr (TRAIN && G::FUSE_DK) {
-        if (a.fuse_dk) *(f32x4*)(sL + srow * LSTR + chb[kb]) = long4[kb];
+        if (FUSE_RT) *(f32x4*)(sL + srow * LSTR + chb[kb]) = long4[kb];
         else if (vs) *(f32x4*)(a.gLong + (size_t)bidx * D + chb[kb]) = long4[kb];
       } else if (TRAIN && vs) {
         *(f32x4*)(a.gLong + (size_t)bidx * D + chb[kb]) = long4[kb];
@@ -1183,11 +1191,13 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     for (int kb = 0; kb < NB; ++kb) {
       ut4[kb] = short4[kb] + uemb[kb];
       part += dot4(ut4[kb], iemb[kb]);
-      if (a.u_t != nullptr && vs) *(f32x4*)(a.u_t + (size_t)bidx * D + chb[kb]) = ut4[kb];
+      if constexpr (!TRAIN) {   // (evaluation's output: not a branch of the training kernel)
+        if (a.u_t != nullptr && vs) *(f32x4*)(a.u_t + (size_t)bidx * D + chb[kb]) = ut4[kb];
+      }
     }
     const float logit = sample_sum<CPS>(part) + ib_i;  // model.py:137
     if (lead && vs && a.logits_i != nullptr) a.logits_i[bidx] = logit;
-    if (a.b.j != nullptr && a.logits_j != nullptr) {  // second candidate (eval_auc's negative)
+    if (!TRAIN && a.b.j != nullptr && a.logits_j != nullptr) {  // second candidate (eval_auc's negative; never in a train step)
       const int it_j = a.b.j[bb];
       float pj = 0.0f;
 #pragma unroll
@@ -1327,7 +1337,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             for (int kb = 0; kb < NB; ++kb) {
               *(f32x4*)(sA + srow * LSTR + chb[kb]) = dx[kb];  // dbridge
               if (vs) {
-                if (!G::FUSE_DK || !a.fuse_dk) *(f32x4*)(a.gDB + (size_t)bidx * D + chb[kb]) = dx[kb];
+                if (!G::FUSE_DK || !FUSE_RT) *(f32x4*)(a.gDB + (size_t)bidx * D + chb[kb]) = dx[kb];
                 dk0[kb] += dx[kb];
               }
             }
@@ -1392,7 +1402,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         for (int i = 0; i < 4; ++i) sB[(16 * rt + 4 * q + i) * LSTR + 16 * kt + r] = acc0[i];
       }
       if constexpr (G::FUSE_DK) {
-       if (a.fuse_dk) {
+       if (FUSE_RT) {
         // ---- dK partial of this pass: C[k][j] = sum over the 16 samples of long[s][k] * dbridge[s][j]
         // (A from sL, B from sA: both [sample][channel] rows in the LDS).  Samples are the K dimension: 4 k-steps of
         // 4 samples.  A wavefront owns half of a 64 x 64 quadrant: lane (q, r) reads channels 4r .. 4r+3 of sample
