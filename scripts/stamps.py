@@ -9,8 +9,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tlsan_amd import _lib as L, synth
 from tlsan_amd.model import Model
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-cfg = synth.make_config("electronics")
+# python scripts/stamps.py [B] [d=128 Ls=10 U=.. I=.. C=..]   (the shape arguments of scripts/shape_bench.py)
+pos = [a for a in sys.argv[1:] if "=" not in a]
+kw = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
+B = int(pos[0]) if pos else int(kw.get("B", 4096))
+if kw:
+    d = int(kw.get("d", 128))
+    cfg = synth.make_config("electronics", Ls=int(kw.get("Ls", 10)), hidden_units=d, itemid_embedding_size=d // 2, userid_embedding_size=d // 2,
+                            cateid_embedding_size=d // 2, user_count=int(kw.get("U", 39991)), item_count=int(kw.get("I", 22048)),
+                            cate_count=int(kw.get("C", 673)))
+else:
+    cfg = synth.make_config("electronics")
 m = Model(cfg, synth.item_cate_list(cfg), l2_mode="lazy", matrix_dtype=os.environ.get("MM", "f32"), table_dtype=os.environ.get("TD", "f32"))
 lib = L.load()
 db_host = synth.make_batches(cfg, 1, B, seed=7)[0]
@@ -99,9 +108,10 @@ for k in arr + [11]:
 cp = np.stack(cp, 1)
 print("critical path of the median workgroup (P1 P2 P3 P4 P5 end):", np.median(cp, 0).astype(int))
 sl_new = np.asarray(db_host[7])
+sl_long = np.asarray(db_host[6])
 for b in order[:6]:
-    extra = ""
     extra = "  sessions " + str(sorted(sl_new[16 * b:16 * b + 16].tolist(), reverse=True)[:6])
+    extra += "  windows " + str(sorted(sl_long[16 * b:16 * b + 16].tolist(), reverse=True)[:6])
     print("  workgroup #%d:" % b, cp[b].astype(int), extra)
 p1 = d[:, :, 0]
 print("P1 percentiles:", np.percentile(p1, [1, 10, 25, 50, 75, 90, 99, 100]).astype(int))

@@ -445,6 +445,10 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #endif
   constexpr bool PIPE5 = TLSAN_EXP_PIPE5 != 0 && KEEP_A && !DROP && NBUF == 1;   // long backward as a skewed software pipeline (see P5)
   constexpr bool LPF = NB == 1;                 // streamed windows: the next position's row is prefetched
+#ifndef TLSAN_EXP_SPIPE
+#define TLSAN_EXP_SPIPE 1
+#endif
+  constexpr bool SPIPE = TLSAN_EXP_SPIPE != 0 && LSTREAM && TRAIN && NB == 1 && !DROP && TLSAN_EXP_LCH != 0;   // streamed long backward as a software pipeline (see P5)
   // ... and the next chunk's ids / weights / categories are loaded a chunk ahead (d = 256 in fp32 has no registers for
   // either: 568 -> 618 us at Ls = 90 with this one; with bf16 matrix operands it has: 328 -> 321 us)
   constexpr bool LCH = TLSAN_EXP_LCH != 0 && (NB == 1 || MM == TLSAN_MATRIX_BF16);
@@ -1465,9 +1469,274 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         load_bias<DH, NB>(w1b2, q, b2);
         load_frag_N<DH, NB, MM>(w1W1, q, r, FN1);
         load_frag_N<DH, NB, MM>(w1W2, q, r, FN2);
+        // ---- pieces of the software-pipelined loops below (PIPE5: window in registers, SPIPE: streamed window)
+        static_assert(!(PIPE5 || SPIPE) || NB == 1, "one 16-channel block per column");
+        f32x4 ta[NB], tb[NB];   // transposed tiles of the previous position: (x, dz1), then (m1, dm2)
+        auto read_tiles = [&](int t0, int t1) {
+#pragma unroll
+          for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              const int rofs = (4 * q + s) * TSTR + r;
+              ta[kb][s] = T[(t0 * NB + kb) * 16 * TSTR + rofs];
+              tb[kb][s] = T[(t1 * NB + kb) * 16 * TSTR + rofs];
+            }
+        };
+        auto dw_prod = [&](f32x4 (&dW)[NB][NB]) {
+#pragma unroll
+          for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+            for (int jb = 0; jb < NB; ++jb) dW[kb][jb] = mm_mma<MM>(mm_pack<MM>(ta[kb]), mm_pack<MM>(tb[jb]), dW[kb][jb]);
+        };
+        // a map as two half-chains whose sum is taken a group later (the sum right behind the chain would wait for it)
+        auto map_issue = [&](const opd (&F)[NB][NB], const f32x4 (&v)[NB], f32x4 (&h0)[NB], f32x4 (&h1)[NB], const f32x4* bias) {
+          if constexpr (MM == TLSAN_MATRIX_F32) {
+#pragma unroll
+            for (int ob = 0; ob < NB; ++ob) {
+              h0[ob] = bias ? TLSAN_MFMA(F[ob][0][0], v[0][0], bias[ob]) : TLSAN_MFMA(F[ob][0][0], v[0][0], (f32x4)(0.0f));
+              h1[ob] = TLSAN_MFMA(F[ob][0][2], v[0][2], (f32x4)(0.0f));
+              h0[ob] = TLSAN_MFMA(F[ob][0][1], v[0][1], h0[ob]);
+              h1[ob] = TLSAN_MFMA(F[ob][0][3], v[0][3], h1[ob]);
+            }
+          } else {
+#pragma unroll
+            for (int ob = 0; ob < NB; ++ob) {
+              h0[ob] = bias ? mm_mma<MM>(F[ob][0], mm_pack<MM>(v[0]), bias[ob]) : mm_mma<MM>(F[ob][0], mm_pack<MM>(v[0]), (f32x4)(0.0f));
+              h1[ob] = (f32x4)(0.0f);
+            }
+          }
+        };
         if constexpr (LSTREAM) {
           AccSet<NB> acc;
           acc.zero();
+          if constexpr (SPIPE) {
+          // ---- software pipeline over the positions of the streamed window, three stages deep: an iteration runs the
+          // FORWARD recomputation of position pF (z1 = x W1 + b1, m2 = relu(z1) W2 + b2, a = exp(m2 - max) / sum), the
+          // BACKWARD maps of the position before it (pB) and the two dW products of the one before that, whose
+          // transposed operands it reads back from the LDS first.  MFMA groups of an iteration, each one's inputs made at
+          // least a group earlier:  z1(pF) . dm1(pB) . m2(pF) . dW1 . dxm(pB) . dW2  -- 24 MFMAs back to back with the vector
+          // code, the exponentials, the LDS traffic and the row stores in their shadow, where the plain loop below runs
+          // six dependent map / product chains and an LDS round trip per position one after the other.  The row of the
+          // position after pF is in flight meanwhile.  First iteration: no pB yet (zero operands, nothing stored, the tiles
+          // zeroed below); last: pF past the window (a zero row).  LHELP's switch (P1): the forward side's statistics
+          // (max, 1/sum) and the backward side's (output, output gradient) change hands an iteration apart.
+          const int wofs = r * TSTR + 4 * q;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) *(f32x4*)(T + t * 16 * TSTR + wofs) = (f32x4)(0.0f);
+          // The whole window's ids, weights and categories, one entry per lane and chunk of NLc, are loaded HERE: inside
+          // the loop the only vector-memory operations are one row fetch at the top of an iteration and the row stores
+          // at its end, with the fetched row taken over just before those stores.  vmcnt retires in order and the
+          // stores sit in branches, so any wait for a load that is older than a store waits for the store as well:
+          // with the chunk loads (and their register hand-over) inside the loop every iteration began by waiting out
+          // the previous one's stores, a full round trip to memory.
+          constexpr int NCH = (TLSAN_LS_CAP + NLc - 1) / NLc;
+          int lidA[NCH], lctA[NCH];
+          float luhA[NCH];                      // usert_emb[u][t] * hist_t[t]
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            const int t = min(c * NLc + kkl, Ls - 1);
+            lidA[c] = a.b.hist_i[(size_t)bb * Ls + t];
+            luhA[c] = a.b.hist_t[(size_t)bb * Ls + t] * a.p.usert_emb[(size_t)uid * a.p.ld_usert + t];
+          }
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) lctA[c] = a.p.item_cate[lidA[c]];
+          raw4 en[NB];
+          float scxn = 0.0f, scen = 0.0f;
+          // entry p of the window (shared step: the longer window's entry p / p + 1) -> the row's gather goes out
+          auto fetch_entry = [&](int p) {
+            const int c = p / NLc, k = p % NLc;   // (wave-uniform)
+            int idc = lidA[0], ctc = lctA[0];
+            float uhc = luhA[0];
+#pragma unroll
+            for (int j = 1; j < NCH; ++j) {
+              idc = c == j ? lidA[j] : idc;
+              ctc = c == j ? lctA[j] : ctc;
+              uhc = c == j ? luhA[j] : uhc;
+            }
+            const int ss = L_SHARED(p) ? g_L : s_loc;
+            int it = sample_pick<CPS>(idc, k / CPS, k % CPS, ss), ct = sample_pick<CPS>(ctc, k / CPS, k % CPS, ss);
+            float uth = sample_pick<CPS>(uhc, k / CPS, k % CPS, ss);
+            if constexpr (LHELP) {
+              if (L_SHARED(p)) {   // (wave-uniform; p even, NLc even: the same chunk)
+                const int k1 = k + 1;
+                const int it1 = sample_pick<CPS>(idc, k1 / CPS, k1 % CPS, ss), ct1 = sample_pick<CPS>(ctc, k1 / CPS, k1 % CPS, ss);
+                const float uth1 = sample_pick<CPS>(uhc, k1 / CPS, k1 % CPS, ss);
+                it = ghelper ? it1 : it;
+                ct = ghelper ? ct1 : ct;
+                uth = ghelper ? uth1 : uth;
+              }
+            }
+            scxn = (gamma * P * P) * uth;  // x = e_stored * scxn
+            scen = (gamma * P) * uth;      // d x / d e_true
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) en[kb] = gather_item4c_raw<DT>(a, it, ct, chb[kb]);
+          };
+          f32x4 mxf[NB], izf[NB];               // the forward side's copy of the window's statistics
+          f32x4 xvF[NB], evF[NB], z1F[NB], avF[NB];
+#pragma unroll
+          for (int kb = 0; kb < NB; ++kb) {
+            mxf[kb] = mx1[kb];
+            izf[kb] = iz1[kb];
+            z1F[kb] = avF[kb] = (f32x4)(0.0f);
+          }
+          float sceF = 0.0f;
+          bool vpF = false, stF = false;        // forward-stage position: valid for this lane / one this lane stores a row for
+          int slotF = 0;                        // ... at my_row * PSTR + my_p of the position tables
+          // what a fetched row becomes for position p (taken over at the END of the iteration that fetched it)
+          auto take_row = [&](int p) {
+            const bool sh = L_SHARED(p), oth = sh && ghelper;
+            const int my_p = p + (oth ? 1 : 0);
+            vpF = p < pmax1 && (sh ? my_p < g_hi : p < n_l);
+            stF = (vs || oth) && vpF;
+            slotF = (oth ? wave * SPW + g_L : srow) * PSTR + my_p;
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+              evF[kb] = vpF ? tbl_cvt<DT>(en[kb]) : (f32x4)(0.0f);
+              xvF[kb] = evF[kb] * scxn;
+            }
+            sceF = scen;
+          };
+          f32x4 xvB[NB], evB[NB];               // the backward stage's row (scaled / as stored)
+#pragma unroll
+          for (int kb = 0; kb < NB; ++kb) xvB[kb] = evB[kb] = (f32x4)(0.0f);
+          float sceB = 0.0f;
+          bool stBk = false;
+          int slotBk = 0;
+          fetch_entry(0);
+          take_row(0);
+          int pB = -1, pF = 0;
+          while (pB < pmax1) {                  // wave-uniform
+            if constexpr (LHELP) {
+              if (g_on && pB == g_lo2) {        // backward side: the helping half takes over the longer window's output and gradient
+#pragma unroll
+                for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+                  for (int i = 0; i < 4; ++i) {
+                    const float o_out = dpp_f32<TLSAN_DPP_ROR(8)>(long4[kb][i]), o_do = dpp_f32<TLSAN_DPP_ROR(8)>(dlong[kb][i]);
+                    long4[kb][i] = ghelper ? o_out : long4[kb][i];
+                    dlong[kb][i] = ghelper ? o_do : dlong[kb][i];
+                  }
+              }
+              if (g_on && pF == g_lo2) {        // forward side: ... and its statistics
+#pragma unroll
+                for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+                  for (int i = 0; i < 4; ++i) {
+                    const float o_mx = dpp_f32<TLSAN_DPP_ROR(8)>(mxf[kb][i]), o_iz = dpp_f32<TLSAN_DPP_ROR(8)>(izf[kb][i]);
+                    mxf[kb][i] = ghelper ? o_mx : mxf[kb][i];
+                    izf[kb][i] = ghelper ? o_iz : izf[kb][i];
+                  }
+              }
+            }
+            // what the forward stage left for this iteration's backward stage, and the forward stage's own position
+            f32x4 z1[NB], av[NB], m1[NB], dm2[NB], dz1[NB], dx[NB], ha[NB], hb[NB], hc[NB], hd[NB];
+            const float sce = sceB;
+            const bool stB = stBk;
+            const float mkF = vpF ? 1.0f : 0.0f;
+            const int slotB = slotBk;
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+              z1[kb] = z1F[kb];
+              av[kb] = avF[kb];
+            }
+            const int pL = pF + L_ADV(pF);
+            fetch_entry(pL);                                         // the row after the forward stage's: in flight over the whole iteration
+            read_tiles(0, 1);                                        // x, dz1 of the position before pB
+            const int posp = sP[stB ? slotB : 0], cposp = CSEG ? sPc[stB ? slotB : 0] : 0;
+            __builtin_amdgcn_sched_barrier(0);
+            map_issue(FT1, xvF, ha, hb, b1);                         // G1: z1(pF)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) dm2[kb] = av[kb] * dlong[kb] * (xvB[kb] - long4[kb]);  // softmax-over-positions backward
+            __builtin_amdgcn_sched_barrier(0);
+            map_issue(FN2, dm2, hc, hd, nullptr);                    // G2: dm1(pB) = dm2 . W2^T
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 zrF[NB];
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+              z1F[kb] = ha[kb] + hb[kb];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                zrF[kb][i] = fmaxf(z1F[kb][i], 0.0f);
+                m1[kb][i] = fmaxf(z1[kb][i], 0.0f);
+              }
+              acc.db2[kb] += dm2[kb];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            map_issue(FT2, zrF, ha, hb, b2);                         // G3: m2(pF)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+              const f32x4 dm1 = hc[kb] + hd[kb];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) dz1[kb][i] = z1[kb][i] > 0.0f ? dm1[i] : 0.0f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            dw_prod(acc.dW1);                                        // G4: dW1 += x^T dz1 of the position before pB
+            read_tiles(2, 3);                                        //     its m1, dm2 (before this position's tiles overwrite them)
+            __builtin_amdgcn_sched_barrier(0);
+            map_issue(FN1, dz1, hc, hd, nullptr);                    // G5: dxm(pB) = dz1 . W1^T
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i)   // (m2 <= max on valid positions: the clamp changes nothing there; no branch around the exponentials)
+                avF[kb][i] = __expf(fminf((ha[kb][i] + hb[kb][i]) - mxf[kb][i], 0.0f)) * (izf[kb][i] * mkF);
+              *(f32x4*)(T + (0 * NB + kb) * 16 * TSTR + wofs) = xvB[kb];  // pB's tiles (behind the reads above: in-order DS)
+              *(f32x4*)(T + (1 * NB + kb) * 16 * TSTR + wofs) = dz1[kb];
+              *(f32x4*)(T + (2 * NB + kb) * 16 * TSTR + wofs) = m1[kb];
+              *(f32x4*)(T + (3 * NB + kb) * 16 * TSTR + wofs) = dm2[kb];
+              acc.db1[kb] += dz1[kb];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            dw_prod(acc.dW2);                                        // G6: dW2 += m1^T dm2 of the position before pB
+            __builtin_amdgcn_sched_barrier(0);
+            float dsp = 0.0f;
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+              dx[kb] = av[kb] * dlong[kb] + (hc[kb] + hd[kb]);
+              dsp += dot4(dx[kb], evB[kb]);
+            }
+            const float ds = sample_sum<CPS>(dsp) * P;  // d loss / d scale[pB]
+            // the forward stage's row moves on to the backward stage; the fetched row takes its place -- BEFORE the stores
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+              xvB[kb] = xvF[kb];
+              evB[kb] = evF[kb];
+            }
+            sceB = sceF;
+            stBk = stF;
+            slotBk = slotF;
+            // (the empty asm reads the fetched registers HERE: left alone the compiler sinks the take-over below the
+            //  branches of the stores, and its wait for the fetch then covers the stores as well)
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) asm volatile("" : "+v"(en[kb]));
+            take_row(pL);
+            __builtin_amdgcn_sched_barrier(0);
+            if (stB) {
+              if (lead) a.Gb[posp] = 0.0f;
+#pragma unroll
+              for (int kb = 0; kb < NB; ++kb) {
+                const f32x4 de = dx[kb] * sce;
+                st4_out(use_dst(posp, cposp, chb[kb]), de);
+                sq_acc += dot4(de, de);
+              }
+              if (lead) {
+                const int rowB = slotB / PSTR, my_p = slotB - rowB * PSTR;
+                const float gt = ds * (gamma * sH[rowB * 2 * LSC + my_p]);  // d / d usert_emb[u][p]
+                a.Gu[(size_t)sP[rowB * PSTR + P_USR] * a.WU + a.di + my_p] = gt;
+                sq_acc += gt * gt;
+                dgam += ds * (P * sH[rowB * 2 * LSC + LSC + my_p]);
+              }
+            }
+            pB = pF;
+            pF = pL;
+          }
+          read_tiles(0, 1);                     // drain: the dW products of the last position
+          dw_prod(acc.dW1);
+          read_tiles(2, 3);
+          dw_prod(acc.dW2);
+          } else {
           if constexpr (LCH) { stage_lchunk_ids(0); stage_lchunk_cats(); }
           for (int base = 0; base < pmax1; base += NLc) {  // wave-uniform
             if constexpr (LCH) {
@@ -1570,6 +1839,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
               }
             }
           }
+          }
           if (lead && vs)  // padded long slots and the row's alignment padding
             for (int p = a.di + n_l; p < a.WU; ++p) a.Gu[(size_t)sP[srow * PSTR + P_USR] * a.WU + p] = 0.0f;
           if constexpr (G::SPLIT) {
@@ -1595,42 +1865,6 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         // this position's tiles and the LDS reads of the previous one's run in their shadow.  One transpose buffer
         // suffices: LDS operations of a wavefront execute in order, so the reads of p - 1 (top of the iteration) precede
         // the writes of p.  The groups are pinned with sched_barrier (the scheduler would re-cluster each chain).
-        static_assert(!PIPE5 || (NB == 1 && MM == MM), "one 16-channel block per column");
-        f32x4 ta[NB], tb[NB];   // transposed tiles of the previous position: (x, dz1), then (m1, dm2)
-        auto read_tiles = [&](int t0, int t1) {
-#pragma unroll
-          for (int kb = 0; kb < NB; ++kb)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-              const int rofs = (4 * q + s) * TSTR + r;
-              ta[kb][s] = T[(t0 * NB + kb) * 16 * TSTR + rofs];
-              tb[kb][s] = T[(t1 * NB + kb) * 16 * TSTR + rofs];
-            }
-        };
-        auto dw_prod = [&](f32x4 (&dW)[NB][NB]) {
-#pragma unroll
-          for (int kb = 0; kb < NB; ++kb)
-#pragma unroll
-            for (int jb = 0; jb < NB; ++jb) dW[kb][jb] = mm_mma<MM>(mm_pack<MM>(ta[kb]), mm_pack<MM>(tb[jb]), dW[kb][jb]);
-        };
-        // a map as two half-chains whose sum is taken a group later (the sum right behind the chain would wait for it)
-        auto map_issue = [&](const opd (&F)[NB][NB], const f32x4 (&v)[NB], f32x4 (&h0)[NB], f32x4 (&h1)[NB], const f32x4* bias) {
-          if constexpr (MM == TLSAN_MATRIX_F32) {
-#pragma unroll
-            for (int ob = 0; ob < NB; ++ob) {
-              h0[ob] = bias ? TLSAN_MFMA(F[ob][0][0], v[0][0], bias[ob]) : TLSAN_MFMA(F[ob][0][0], v[0][0], (f32x4)(0.0f));
-              h1[ob] = TLSAN_MFMA(F[ob][0][2], v[0][2], (f32x4)(0.0f));
-              h0[ob] = TLSAN_MFMA(F[ob][0][1], v[0][1], h0[ob]);
-              h1[ob] = TLSAN_MFMA(F[ob][0][3], v[0][3], h1[ob]);
-            }
-          } else {
-#pragma unroll
-            for (int ob = 0; ob < NB; ++ob) {
-              h0[ob] = bias ? mm_mma<MM>(F[ob][0], mm_pack<MM>(v[0]), bias[ob]) : mm_mma<MM>(F[ob][0], mm_pack<MM>(v[0]), (f32x4)(0.0f));
-              h1[ob] = (f32x4)(0.0f);
-            }
-          }
-        };
         const int wofs = r * TSTR + 4 * q;
 #pragma unroll
         for (int p = 0; p < LS; ++p) dsp[p] = 0.0f;
