@@ -427,18 +427,39 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #else
 #define FUSE_RT (a.fuse_dk != 0)
 #endif
+  // FLAT (streamed windows): the window positions of the workgroup's 16 samples form ONE list that is dealt out evenly
+  // to its 16 column groups (a wavefront's lanes that share a sample slot) -- see P1.  Its entries, the per-sample
+  // softmax statistics and the long-term vectors live in the LDS, where any group can reach them.
+#ifndef TLSAN_EXP_FLAT
+#define TLSAN_EXP_FLAT 1
+#endif
+  constexpr bool FLAT = TLSAN_EXP_FLAT != 0 && LSTREAM && NB == 1 && !DROP;
+  constexpr int NF = FLAT ? NSB * TLSAN_LS_CAP : 0;      // entries of the flat list (every window at the cap)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;                   // [NSB][LSTR]  long -> dbridge
-  float* sB = sA + NSB * LSTR;        // [NSB][LSTR]  bridge -> dlong
-  float* sL = sB + NSB * LSTR;        // [NSB][LSTR]  long, kept for the fused dK product (TRAIN && FUSE_DK)
-  float* sS = sL + ((TRAIN && G::FUSE_DK && FUSE_RT) ? NSB * LSTR : 0);  // [NW][4] scalar staging  (sL exists in launches that fuse: tlsan_attn_inst.h)
-  float* sH = sS + NW * 4;            // [NSB][2*LS] hist_t and usert*hist_t of the pass
+  float* sB0 = sA + NSB * LSTR;       // [NSB][LSTR]  bridge -> dlong  (FLAT: placed in front of sT instead, see sPart)
+  float* sL = FLAT ? sB0 : sB0 + NSB * LSTR;   // [NSB][LSTR]  long, kept for the fused dK product (TRAIN && FUSE_DK) and for FLAT's backward
+  float* sS = sL + ((TRAIN && ((G::FUSE_DK && FUSE_RT) || FLAT)) ? NSB * LSTR : 0);  // [NW][4] scalar staging  (sL exists in launches that fuse: tlsan_attn_inst.h)
+  float* sH = sS + NW * 4;            // [NSB][2*LS] hist_t and usert*hist_t of the pass  (FLAT: [2][NF], by flat index)
   float* sW = sH + NSB * 2 * LSC;     // [2][WB] attention weights (W1,b1,W2,b2) of both blocks
   int* sP = (int*)(sW + (USE_SW ? 2 * WB : 0));  // [NSB][PSTR] destination-sorted row of every use
   // CSEG (FwdArgs.cseg, many categories): the category half of an item use's gradient row goes to the category's own
   // segment of Gc -- its position, drawn from the category's cursor, sits in sPc beside the item position in sP
   int* sPc = sP + (TRAIN ? NSB * PSTR : 0);      // [NSB][PSTR], only when a.cseg
-  float* sT = (float*)(sPc + ((TRAIN && CSEG) ? NSB * PSTR : 0));  // per-wave transpose scratch / staging
+  int* sFid = sPc + ((TRAIN && CSEG) ? NSB * PSTR : 0);   // FLAT: [NF] item id, category, (slot << 8 | position) of every list entry,
+  int* sFct = sFid + NF;                                  //       its destination rows (TRAIN), and below the per-sample statistics
+  int* sFst = sFct + NF;
+  int* sFpos = sFst + NF;
+  int* sFcpos = sFpos + (TRAIN ? NF : 0);
+  float* sMx = (float*)(sFcpos + ((TRAIN && CSEG) ? NF : 0));   // [NSB][LSTR] per-channel max of the window's scores
+  float* sIz = sMx + ((FLAT && TRAIN) ? NSB * LSTR : 0);         // [NSB][LSTR] 1 / sum of exponentials
+  float* sB = FLAT ? sIz + (TRAIN ? NSB * LSTR : 0) : sB0;
+  float* sT = FLAT ? sB + NSB * LSTR : (float*)sFid;  // per-wave transpose scratch / staging
+  // FLAT: the partial softmax states of P1, 32 slots of [3][D], lie over sB and sT (neither is touched before P2)
+  float* sPart = sB;
+  static_assert(!FLAT || 32 * 3 * D <= NSB * LSTR + NW * G::WSCR, "partial states must fit sB + sT");
+  float* sFht = sH;
+  float* sFuh = sH + NF;
   constexpr bool KEEP_A = G::KEEP_A && TRAIN && !LSTREAM;
 #ifndef TLSAN_EXP_PIPE5
 #define TLSAN_EXP_PIPE5 1
@@ -541,6 +562,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #endif
 
   for (int g = blockIdx.x; g < a.ngroups; g += gridDim.x) {
+    if constexpr (FLAT) {
+      if (g != blockIdx.x) __syncthreads();   // (the partial states of P1 lie over sT, which the previous pass read to its end)
+    }
     TLSAN_STAMP(0);
 #if TLSAN_STAMPS
     if (a.stamps != nullptr && lane == 0) sStamp[28] = __builtin_amdgcn_s_memrealtime();   // (100 MHz, one clock for the whole device)
@@ -554,23 +578,34 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     // of the batch, so results stay bitwise reproducible.
     static_assert(NSB == 16, "one candidate per lane of a row");
     int bidx;
+    int offv = 0, f_total = 0;   // FLAT: lane r = where slot r's window starts in the flat list; the list's length
     {
       const int cand = g * NSB + r;
       const bool cv = cand < B;
       const int cl = cv ? min(a.b.sl[cand], Ls) : 0, cs = cv ? min(a.b.sl_new[cand], Sn) : 0;
       // (streamed windows: the window length decides -- up to 90 positions against a session's few -- and the longest
       //  is paired with the shortest: the short one's half of the wavefront then helps with the long one, LHELP)
-      const int key = cv ? (((LSTREAM ? ((cl << 12) | (cs << 4)) : ((cs << 12) | (cl << 4))) | (15 - r)) + 1) : -r;   // distinct; larger = heavier
+      const int key = cv ? ((((LSTREAM && !FLAT) ? ((cl << 12) | (cs << 4)) : ((cs << 12) | (cl << 4))) | (15 - r)) + 1) : -r;   // distinct; larger = heavier
       int rank = 0;
 #pragma unroll
       for (int j = 0; j < 16; ++j) rank += (__builtin_amdgcn_readlane(key, j) > key) ? 1 : 0;
       int* sPerm = (int*)T;                       // (the wave's own scratch: free until P3)
       // (windows held in registers, two samples per wavefront: the wavefront with the k-th longest session also takes
       // the k-th shortest -- its lanes then share the long one, see HELP in P3)
-      const int slot = (TLSAN_EXP_FOLD != 0 && SPW == 2 && (!LSTREAM || TLSAN_EXP_LHELP != 0) && !DROP) ? (rank < 8 ? 2 * rank : 2 * (15 - rank) + 1) : rank;
+      const int slot = (TLSAN_EXP_FOLD != 0 && SPW == 2 && (!LSTREAM || TLSAN_EXP_LHELP != 0 || FLAT) && !DROP) ? (rank < 8 ? 2 * rank : 2 * (15 - rank) + 1) : rank;
       if (q == 0) sPerm[slot] = r;
+      if (FLAT && q == 0) sPerm[16 + slot] = cl;
       wave_lds_fence();
       bidx = g * NSB + sPerm[srow];
+      if constexpr (FLAT) {   // every wavefront works out the whole list's layout for itself: no barrier
+        const int nlj = sPerm[16 + r];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int x = __builtin_amdgcn_readlane(nlj, j);
+          offv += (j < r) ? x : 0;
+          f_total += x;
+        }
+      }
       wave_lds_fence();
     }
 #else
@@ -726,7 +761,197 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     for (int kb = 0; kb < NB; ++kb) xnext.r[kb] = srow4{};
     const int pmax2e = wave_max_samples<CPS>(n_s + 1);
     int ucat = 0, ct_i = 0;   // category of the user's row / of the candidate: fetched with the window's ids
-    if constexpr (LSTREAM) {
+    if constexpr (FLAT) {
+      // ---- FLAT: streamed windows as ONE work list per workgroup.  Window lengths are heavy-tailed (synthetic
+      // histories: mean 14, 1 % at the cap of 90; real ones likewise) and a launch ends with its slowest wavefront:
+      // with a window per column group -- even with a long one shared by a wavefront's two halves -- the wavefront
+      // that holds a 90-entry window walks ~50 positions while the others of its workgroup walk ~15 and wait at the
+      // barrier.  Here the (sample, position) pairs of the workgroup's 16 windows, in sample order, form a list of
+      // f_total entries; column group j (slot j: its lanes) takes entries [j T, (j + 1) T), T = ceil(f_total / 16).
+      // Forward: a group keeps an online-softmax state per run of entries of one sample and leaves it in the LDS
+      // (slot sample + group: runs are enumerated in order, so the sum is unique); after a barrier each sample's own
+      // lanes merge its runs in order.  Backward (P5): positions are independent given the sample's statistics,
+      // output and output gradient, which every group reads from the LDS.  Results are a fixed function of the batch.
+      ucat = a.b.u_cate[bb];
+      ct_i = a.p.item_cate[it_i];
+      opd FT1[NB][NB], FT2[NB][NB];
+      f32x4 b1[NB], b2[NB];
+      load_frag_T<DH, NB, MM>(w1W1, q, r, FT1);
+      load_frag_T<DH, NB, MM>(w1W2, q, r, FT2);
+      load_bias<DH, NB>(w1b1, q, b1);
+      load_bias<DH, NB>(w1b2, q, b2);
+      if constexpr (TRAIN) {
+        posv[LS] = (lead && vs) ? atomicAdd(&a.cur_item[it_i], 1) : 0;
+        cposv = (lead && vs && CSEG) ? atomicAdd(&a.cur_uc[ct_i], 1) : 0;
+        posv[LS + 1] = (lead && vs) ? atomicAdd(&a.cur_user[uid], 1) : 0;
+        posv[LS + 2] = (lead && vs && (a.uc_by_sample + opaque_zero(lane)) == 0) ? atomicAdd(&a.cur_uc[a.b.u_cate[bb]], 1) : bidx;
+      }
+      const int wv = __builtin_amdgcn_readfirstlane(wave);
+      int offm = __builtin_amdgcn_readlane(offv, wv * SPW);   // where this lane's own window starts in the list
+#pragma unroll
+      for (int sx = 1; sx < SPW; ++sx) {
+        const int x = __builtin_amdgcn_readlane(offv, wv * SPW + sx);
+        offm = (s_loc == sx) ? x : offm;
+      }
+      // the wavefront's own windows -> the list (lane kkl of a sample's lanes: entry base + kkl), with the cursor draws
+      for (int base = 0; base < pmax1; base += NLc) {  // wave-uniform
+        const int t = base + kkl, tc = min(t, Ls - 1);
+        const int id = a.b.hist_i[(size_t)bb * Ls + tc];
+        const float ht = a.b.hist_t[(size_t)bb * Ls + tc], ut = a.p.usert_emb[(size_t)uid * a.p.ld_usert + tc];
+        const int ct = a.p.item_cate[id];
+        if (t < n_l) {
+          const int i = offm + t;
+          sFid[i] = id;
+          sFct[i] = ct;
+          sFst[i] = (srow << 8) | t;
+          sFht[i] = ht;
+          sFuh[i] = ut * ht;
+          if constexpr (TRAIN) {
+            sFpos[i] = atomicAdd(&a.cur_item[id], 1);
+            if constexpr (CSEG) sFcpos[i] = atomicAdd(&a.cur_uc[ct], 1);
+          }
+        }
+      }
+      __syncthreads();
+      const int FTn = (f_total + NSB - 1) / NSB;               // entries per column group (wave-uniform)
+      const int i0 = srow * FTn, iend = min(i0 + FTn, f_total);
+      const int ilast = max(f_total - 1, 0);
+      struct Ent { int id, ct, st; float uh; };
+      auto read_ent = [&](int idx, Ent& e) {
+        const int ic = min(idx, ilast);
+        e.id = sFid[ic];
+        e.ct = sFct[ic];
+        e.st = sFst[ic];
+        e.uh = sFuh[ic];
+      };
+      auto issue = [&](const Ent& e, raw4 (&row)[NB]) {
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) row[kb] = gather_item4c_raw<DT>(a, e.id, e.ct, chb[kb]);
+      };
+      f32x4 smx[NB], sZ[NB], sN[NB];
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) {
+        smx[kb] = (f32x4)(TLSAN_NEG);
+        sZ[kb] = sN[kb] = (f32x4)(0.0f);
+      }
+      int s_prev = -1;
+      // one entry: both maps, one online-softmax step into the state of the current run (a fresh one where the sample
+      // changes), the state left in the run's slot.  No branches: an entry past the group's share changes nothing.
+      auto compute = [&](int idx, int st, const f32x4 (&xv)[NB]) {
+        const bool v = idx < iend;
+        const float mk = v ? 1.0f : 0.0f;
+        const int s_cur = st >> 8;
+        const bool fresh = v && s_cur != s_prev;
+        f32x4 z[NB], m2[NB];
+        map_apply<NB, MM>(FT1, b1, xv, z);
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) z[kb][i] = fmaxf(z[kb][i], 0.0f);
+        map_apply<NB, MM>(FT2, b2, z, m2);
+        const int slot = v ? s_cur + srow : 31;
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float mx0 = fresh ? TLSAN_NEG : smx[kb][i], Z0 = fresh ? 0.0f : sZ[kb][i], N0 = fresh ? 0.0f : sN[kb][i];
+            const float m2m = v ? m2[kb][i] : TLSAN_NEG;
+            const float mn = fmaxf(mx0, m2m);
+            const float so = __expf(mx0 - mn), ev = __expf(m2m - mn) * mk;
+            sZ[kb][i] = Z0 * so + ev;
+            sN[kb][i] = N0 * so + ev * xv[kb][i];
+            smx[kb][i] = mn;
+          }
+          float* ps = sPart + slot * 3 * D + chb[kb];
+          *(f32x4*)(ps) = smx[kb];
+          *(f32x4*)(ps + D) = sZ[kb];
+          *(f32x4*)(ps + 2 * D) = sN[kb];
+        }
+        s_prev = v ? s_cur : s_prev;
+      };
+      auto take = [&](int idx, const Ent& e, const raw4 (&row)[NB], f32x4 (&xv)[NB]) {
+        const float scx = (idx < iend) ? (gamma * P * P) * e.uh : 0.0f;
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) xv[kb] = tbl_cvt<DT>(row[kb]) * scx;
+      };
+      if (FTn > 0) {   // wave-uniform
+        // two rows in flight (A, B), each fetched two entries ahead of its use; the entry after that read from the list
+        Ent eA, eB, nA, nB;
+        raw4 rA[NB], rB[NB];
+        read_ent(i0, eA);
+        read_ent(i0 + 1, eB);
+        issue(eA, rA);
+        issue(eB, rB);
+        read_ent(i0 + 2, nA);
+        read_ent(i0 + 3, nB);
+        for (int k = 0; k < FTn; k += 2) {
+          f32x4 xa[NB], xb[NB];
+          take(i0 + k, eA, rA, xa);
+          const int stA = eA.st;
+          eA = nA;
+          issue(eA, rA);
+          read_ent(i0 + k + 4, nA);
+          compute(i0 + k, stA, xa);
+          take(i0 + k + 1, eB, rB, xb);
+          const int stB = eB.st;
+          eB = nB;
+          issue(eB, rB);
+          read_ent(i0 + k + 5, nB);
+          compute(i0 + k + 1, stB, xb);
+        }
+      }
+      __syncthreads();
+      // the sample's own lanes merge its runs, in list order
+      int gf = 0, gl = -1;
+      if (n_l > 0) {
+        gf = offm / FTn;
+        gl = (offm + n_l - 1) / FTn;
+      }
+      int glo = __builtin_amdgcn_readlane(gf, 0), ghi = __builtin_amdgcn_readlane(gl, 0);
+#pragma unroll
+      for (int sx = 1; sx < SPW; ++sx) {
+        const int f1 = __builtin_amdgcn_readlane(gf, sx * CPS), l1 = __builtin_amdgcn_readlane(gl, sx * CPS);
+        const bool e0 = ghi < glo, e1 = l1 < f1;   // (a sample without entries has no runs)
+        glo = e0 ? f1 : (e1 ? glo : min(glo, f1));
+        ghi = e0 ? l1 : (e1 ? ghi : max(ghi, l1));
+      }
+      f32x4 Zl[NB];
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) {
+        mx1[kb] = (f32x4)(TLSAN_NEG);
+        Zl[kb] = (f32x4)(0.0f);
+        long4[kb] = (f32x4)(0.0f);
+      }
+      for (int gs = glo; gs <= ghi; ++gs) {  // wave-uniform
+        const bool in = gs >= gf && gs <= gl;
+        const int slot = in ? srow + gs : 31;
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+          const float* ps = sPart + slot * 3 * D + chb[kb];
+          const f32x4 pm = *(const f32x4*)(ps), pZ = *(const f32x4*)(ps + D), pN = *(const f32x4*)(ps + 2 * D);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float mn = fmaxf(mx1[kb][i], pm[i]);
+            const float sa = __expf(mx1[kb][i] - mn), sb = __expf(pm[i] - mn);
+            mx1[kb][i] = in ? mn : mx1[kb][i];
+            Zl[kb][i] = in ? Zl[kb][i] * sa + pZ[i] * sb : Zl[kb][i];
+            long4[kb][i] = in ? long4[kb][i] * sa + pN[i] * sb : long4[kb][i];
+          }
+        }
+      }
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          iz1[kb][i] = Zl[kb][i] > 0.0f ? fast_rcp(Zl[kb][i]) : 0.0f;  // samples past the batch: no position
+          long4[kb][i] *= iz1[kb][i];
+        }
+        if constexpr (TRAIN) {
+          *(f32x4*)(sMx + srow * LSTR + chb[kb]) = mx1[kb];
+          *(f32x4*)(sIz + srow * LSTR + chb[kb]) = iz1[kb];
+        }
+      }
+    } else if constexpr (LSTREAM) {
       ucat = a.b.u_cate[bb];
       ct_i = a.p.item_cate[it_i];
       opd FT1[NB][NB], FT2[NB][NB];
@@ -929,8 +1154,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     for (int kb = 0; kb < NB; ++kb) {
       *(f32x4*)(sA + srow * LSTR + chb[kb]) = long4[kb];
       if constexpr (TRAIN && G::FUSE_DK) {
-        if (FUSE_RT) *(f32x4*)(sL + srow * LSTR + chb[kb]) = long4[kb];
-        else if (vs) *(f32x4*)(a.gLong + (size_t)bidx * D + chb[kb]) = long4[kb];
+        if (FUSE_RT || FLAT) *(f32x4*)(sL + srow * LSTR + chb[kb]) = long4[kb];
+        if (!FUSE_RT && vs) *(f32x4*)(a.gLong + (size_t)bidx * D + chb[kb]) = long4[kb];
       } else if (TRAIN && vs) {
         *(f32x4*)(a.gLong + (size_t)bidx * D + chb[kb]) = long4[kb];
       }
@@ -1509,7 +1734,184 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         if constexpr (LSTREAM) {
           AccSet<NB> acc;
           acc.zero();
-          if constexpr (SPIPE) {
+          if constexpr (FLAT) {
+          // ---- FLAT (see P1): this column group's share of the workgroup's list, through the three-stage software
+          // pipeline described under SPIPE below -- an iteration runs the FORWARD recomputation of entry k, the BACKWARD
+          // maps of entry k - 1 and the dW products of entry k - 2, with the row of entry k + 1 in flight.  An entry's
+          // sample can be any of the workgroup's: its statistics, output and output gradient come from the LDS (read at
+          // the top of the iteration that runs its forward stage; the backward stage's pair rides along a stage).
+          // Vector-memory operations of an iteration: the row fetch at its top, the row stores at its end, the fetched
+          // row taken over just before those stores (why: see SPIPE).
+          const int wofs = r * TSTR + 4 * q;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) *(f32x4*)(T + t * 16 * TSTR + wofs) = (f32x4)(0.0f);
+          const int FTn = (f_total + NSB - 1) / NSB;
+          const int i0 = srow * FTn, iend = min(i0 + FTn, f_total);
+          const int ilast = max(f_total - 1, 0);
+          if (FTn > 0) {   // wave-uniform
+          raw4 en[NB];
+          int idN, ctN, stN, stL, stF = 0, stB = 0;   // entry after the one in flight / in flight / forward stage / backward stage
+          float uhN, uhL;
+          {
+            const int ic = min(i0, ilast), ic1 = min(i0 + 1, ilast);
+            const int id0 = sFid[ic], ct0 = sFct[ic];
+            stL = sFst[ic];
+            uhL = sFuh[ic];
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) en[kb] = gather_item4c_raw<DT>(a, id0, ct0, chb[kb]);
+            idN = sFid[ic1];
+            ctN = sFct[ic1];
+            stN = sFst[ic1];
+            uhN = sFuh[ic1];
+          }
+          f32x4 xvF[NB], evF[NB], z1F[NB], avF[NB], xvB[NB], evB[NB], loB[NB], dlB[NB];
+#pragma unroll
+          for (int kb = 0; kb < NB; ++kb) z1F[kb] = avF[kb] = xvB[kb] = evB[kb] = loB[kb] = dlB[kb] = (f32x4)(0.0f);
+          float sceF = 0.0f, sceB = 0.0f;
+          bool vF = false, vB = false;
+          int posuB = 0;
+          auto take_row = [&](int idx) {   // the fetched row becomes the forward stage's entry
+            vF = idx < iend;
+            const float uth = vF ? uhL : 0.0f;
+            stF = stL;
+            sceF = (gamma * P) * uth;      // d x / d e_true
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+              evF[kb] = vF ? tbl_cvt<DT>(en[kb]) : (f32x4)(0.0f);
+              xvF[kb] = evF[kb] * ((gamma * P * P) * uth);  // x = e_stored * scale
+            }
+          };
+          take_row(i0);
+          for (int k = 0; k <= FTn; ++k) {      // wave-uniform
+            f32x4 z1[NB], av[NB], m1[NB], dm2[NB], dz1[NB], dx[NB], ha[NB], hb[NB], hc[NB], hd[NB], mxf[NB], izf[NB], loF[NB], dlF[NB];
+            const float sce = sceB;
+            const bool stv = vB;
+            const float mkF = vF ? 1.0f : 0.0f;
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+              z1[kb] = z1F[kb];
+              av[kb] = avF[kb];
+            }
+            // the row after the forward stage's goes out; the list entry after that is read
+            {
+#pragma unroll
+              for (int kb = 0; kb < NB; ++kb) en[kb] = gather_item4c_raw<DT>(a, idN, ctN, chb[kb]);
+              stL = stN;
+              uhL = uhN;
+              const int ic2 = min(i0 + k + 2, ilast);
+              idN = sFid[ic2];
+              ctN = sFct[ic2];
+              stN = sFst[ic2];
+              uhN = sFuh[ic2];
+            }
+            // backward stage's entry: where its rows go; forward stage's entry: its sample's vectors
+            const int ib = max(min(i0 + k - 1, ilast), 0);
+            const int posp = sFpos[ib], cposp = CSEG ? sFcpos[ib] : 0;
+            const float htB = sFht[ib], uhB = sFuh[ib];
+            const int sF = stF >> 8;
+            const int posuF = sP[sF * PSTR + P_USR];
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+              mxf[kb] = *(const f32x4*)(sMx + sF * LSTR + chb[kb]);
+              izf[kb] = *(const f32x4*)(sIz + sF * LSTR + chb[kb]);
+              loF[kb] = *(const f32x4*)(sL + sF * LSTR + chb[kb]);
+              dlF[kb] = *(const f32x4*)(sB + sF * LSTR + chb[kb]);
+            }
+            read_tiles(0, 1);                                        // x, dz1 of entry k - 2
+            __builtin_amdgcn_sched_barrier(0);
+            map_issue(FT1, xvF, ha, hb, b1);                         // G1: z1(k)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) dm2[kb] = av[kb] * dlB[kb] * (xvB[kb] - loB[kb]);  // softmax-over-positions backward
+            __builtin_amdgcn_sched_barrier(0);
+            map_issue(FN2, dm2, hc, hd, nullptr);                    // G2: dm1(k - 1) = dm2 . W2^T
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 zrF[NB];
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+              z1F[kb] = ha[kb] + hb[kb];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                zrF[kb][i] = fmaxf(z1F[kb][i], 0.0f);
+                m1[kb][i] = fmaxf(z1[kb][i], 0.0f);
+              }
+              acc.db2[kb] += dm2[kb];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            map_issue(FT2, zrF, ha, hb, b2);                         // G3: m2(k)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+              const f32x4 dm1 = hc[kb] + hd[kb];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) dz1[kb][i] = z1[kb][i] > 0.0f ? dm1[i] : 0.0f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            dw_prod(acc.dW1);                                        // G4: dW1 += x^T dz1 of entry k - 2
+            read_tiles(2, 3);                                        //     its m1, dm2 (before this entry's tiles overwrite them)
+            __builtin_amdgcn_sched_barrier(0);
+            map_issue(FN1, dz1, hc, hd, nullptr);                    // G5: dxm(k - 1) = dz1 . W1^T
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i)   // (m2 <= max on valid entries: the clamp changes nothing there; no branch around the exponentials)
+                avF[kb][i] = __expf(fminf((ha[kb][i] + hb[kb][i]) - mxf[kb][i], 0.0f)) * (izf[kb][i] * mkF);
+              *(f32x4*)(T + (0 * NB + kb) * 16 * TSTR + wofs) = xvB[kb];  // entry k - 1's tiles (behind the reads above: in-order DS)
+              *(f32x4*)(T + (1 * NB + kb) * 16 * TSTR + wofs) = dz1[kb];
+              *(f32x4*)(T + (2 * NB + kb) * 16 * TSTR + wofs) = m1[kb];
+              *(f32x4*)(T + (3 * NB + kb) * 16 * TSTR + wofs) = dm2[kb];
+              acc.db1[kb] += dz1[kb];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            dw_prod(acc.dW2);                                        // G6: dW2 += m1^T dm2 of entry k - 2
+            __builtin_amdgcn_sched_barrier(0);
+            float dsp = 0.0f;
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+              dx[kb] = av[kb] * dlB[kb] + (hc[kb] + hd[kb]);
+              dsp += dot4(dx[kb], evB[kb]);
+            }
+            const float ds = sample_sum<CPS>(dsp) * P;  // d loss / d scale of entry k - 1
+            const int tB = stB & 255, posu = posuB;
+            // the forward stage's entry moves on to the backward stage; the fetched row takes its place -- BEFORE the stores
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+              xvB[kb] = xvF[kb];
+              evB[kb] = evF[kb];
+              loB[kb] = loF[kb];
+              dlB[kb] = dlF[kb];
+            }
+            sceB = sceF;
+            vB = vF;
+            stB = stF;
+            posuB = posuF;
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) asm volatile("" : "+v"(en[kb]));   // (the fetched registers are read HERE, see SPIPE)
+            take_row(i0 + k + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (stv) {
+              if (lead) a.Gb[posp] = 0.0f;
+#pragma unroll
+              for (int kb = 0; kb < NB; ++kb) {
+                const f32x4 de = dx[kb] * sce;
+                st4_out(use_dst(posp, cposp, chb[kb]), de);
+                sq_acc += dot4(de, de);
+              }
+              if (lead) {
+                const float gt = ds * (gamma * htB);  // d / d usert_emb[u][position]
+                a.Gu[(size_t)posu * a.WU + a.di + tB] = gt;
+                sq_acc += gt * gt;
+                dgam += ds * (P * uhB);
+              }
+            }
+          }
+          read_tiles(0, 1);                     // drain: the dW products of the last entry
+          dw_prod(acc.dW1);
+          read_tiles(2, 3);
+          dw_prod(acc.dW2);
+          }
+          } else if constexpr (SPIPE) {
           // ---- software pipeline over the positions of the streamed window, three stages deep: an iteration runs the
           // FORWARD recomputation of position pF (z1 = x W1 + b1, m2 = relu(z1) W2 + b2, a = exp(m2 - max) / sum), the
           // BACKWARD maps of the position before it (pB) and the two dW products of the one before that, whose

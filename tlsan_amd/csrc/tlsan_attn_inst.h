@@ -6,13 +6,20 @@
 #define TLSAN_STAMPS 0
 #endif
 
+#ifndef TLSAN_EXP_FLAT
+#define TLSAN_EXP_FLAT 1
+#endif
+// (mirrors the carve-up at the top of k_fwd_bwd; flat = the FLAT variant of the streamed windows, tlsan_attn.h)
 template <int D, int DH>
-static size_t fwd_smem_bytes(bool train, bool lstream, bool fuse_dk, int Sn, bool cseg) {
+static size_t fwd_smem_bytes(bool train, bool lstream, bool fuse_dk, int Sn, bool cseg, bool drop) {
   using G = Geo<D, DH>;
+  const bool flat = TLSAN_EXP_FLAT != 0 && lstream && G::NB == 1 && !drop;
   const int lsc = lstream ? TLSAN_LS_CAP : TLSAN_LS_MAX;
   const int pstr = lsc + (cseg ? ((Sn + 3) & ~3) : TLSAN_SN_CAP) + 4;      // position slots per sample (k_fwd_bwd: PSTR), twice with CSEG
-  return sizeof(float) * ((train ? G::NSB * pstr * (cseg ? 2 : 1) : 0) + 2 * G::NSB * G::LSTR + ((train && G::FUSE_DK && fuse_dk) ? G::NSB * G::LSTR : 0) + G::NW * 4 + G::NSB * 2 * lsc + (G::USE_SW ? 2 * (2 * DH * DH + 2 * DH) : 0) + G::NW * G::WSCR +
+  const int nf = flat ? G::NSB * TLSAN_LS_CAP : 0;
+  return sizeof(float) * ((train ? G::NSB * pstr * (cseg ? 2 : 1) : 0) + 2 * G::NSB * G::LSTR + ((train && ((G::FUSE_DK && fuse_dk) || flat)) ? G::NSB * G::LSTR : 0) + G::NW * 4 + G::NSB * 2 * lsc + (G::USE_SW ? 2 * (2 * DH * DH + 2 * DH) : 0) + G::NW * G::WSCR +
                           ((G::KEEP_A && train && !lstream) ? G::NW * TLSAN_LS_MAX * G::NB * 256 : 0) +
+                          nf * (3 + (train ? 1 : 0) + ((train && cseg) ? 1 : 0)) + ((flat && train) ? 2 * G::NSB * G::LSTR : 0) +
                           (TLSAN_STAMPS ? G::NW * 32 * 2 : 0) /* diagnostic stamps */);
 }
 
@@ -23,7 +30,7 @@ static hipError_t launch_variant_dt(const FwdArgs& a, int grid, hipStream_t st) 
   }
   // (the copy of `long` for the fused dK product only in launches that fuse: at d = 64 it is what decides whether two
   //  workgroups fit a CU's LDS -- 8192 sequences, not fused: 77 us/step with it left out, 95 with it)
-  const size_t smem = fwd_smem_bytes<D, DH>(TRAIN, LSTREAM, a.fuse_dk != 0, a.b.Sn, a.cseg != 0);
+  const size_t smem = fwd_smem_bytes<D, DH>(TRAIN, LSTREAM, a.fuse_dk != 0, a.b.Sn, a.cseg != 0, DROP);
   auto k = k_fwd_bwd<D, DH, TRAIN, LSTREAM, DT, DROP, MM, CSEG>;
   static size_t smem_set = 0;   // (per kernel variant: the attribute is raised once, not on every launch)
   if (smem > 48 * 1024 && smem > smem_set) {
