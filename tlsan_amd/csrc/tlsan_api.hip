@@ -155,6 +155,16 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
   w->bytes = o;
 }
 
+#define BAL_CAP (1 << 14)      // batches up to this many samples are ranked for the fused kernel's workgroups (BalArgs, tlsan_update.h)
+// Streamed windows only: with windows in registers a workgroup's time hardly depends on its samples (C3 shape: 33.3 us
+// median, 35.9 us slowest) and evenly loaded workgroups ran no faster (bench 61.0 vs 61.1 us/step; Amazon session
+// lengths 65.6 vs 66.2), with streamed windows it is proportional to their total length (d = 64, Ls = 90: 98 -> 87
+// us/step; d = 256 at the C5 shape 496 -> 471; d = 128: the kernel alone 94 -> 72 us, 104 -> 93 beside the index build
+// of the batch after next).  (TLSAN_BALANCE=0: workgroup g takes samples [16 g, 16 g + 16) as they come; 2: always)
+static bool balanced(const tlsan_dims* d, const tlsan_batch* b) {
+  static const int on = [] { const char* v = getenv("TLSAN_BALANCE"); return v ? atoi(v) : 1; }();
+  return on != 0 && b && b->B > 16 && b->B <= BAL_CAP && (d->Ls > TLSAN_LS_MAX || on == 2);
+}
 #define UC_LIST_CAP (1 << 18)  // batches up to this many samples may keep a per-category sample list in the state
 // ... and do when a category sees many of the batch's samples (cursor atomics on few addresses inside the
 // fused kernel cost more than the extra launch on the index stream): more than 32 samples per category
@@ -198,6 +208,7 @@ struct St {  // persistent state
   double *S_part, *S_total;
   DeltaRec* S_delta;                                      // per-workgroup changes of the sum of squares, tagged by step (tlsan_update.h)
   long long* scan_bsum[TLSAN_INDEX_SLOTS];                                // per-chunk sums of the index scan (large tables), per slot
+  int32_t* perm[TLSAN_INDEX_SLOTS];                                       // samples of every workgroup of the fused kernel (BalArgs), BAL_CAP each
   int32_t* uc_list[TLSAN_INDEX_SLOTS];                                    // samples of every category (u_cate uses), UC_LIST_CAP each
   double* Rc64;                                           // category sums of a split PRESUM pass, zero at rest
   int32_t* hot_list[TLSAN_INDEX_SLOTS];                                   // slots (urec_item) of the hot item rows, AP_HOT_CAP each
@@ -237,6 +248,7 @@ static void carve_state(const tlsan_dims* d, char* base, St* s) {
   for (int k = 0; k < TLSAN_INDEX_SLOTS; ++k)
     s->scan_bsum[k] = (long long*)take(8 * ((size_t)(d->item_count + 4095) / 4096 + (d->cate_count + 4095) / 4096 +
                                             (d->user_count + 4095) / 4096));
+  for (int k = 0; k < TLSAN_INDEX_SLOTS; ++k) s->perm[k] = (int32_t*)take(4 * (size_t)BAL_CAP);
   s->S_total = base ? &s->hdr->St : nullptr;
   s->bytes = o;
 }
@@ -422,7 +434,8 @@ static int launch_scan(ScanArgs& sa, int nscan, long long* bsum, hipStream_t hs)
     hipLaunchKernelGGL(k_scan_block_sums, dim3(nscan), dim3(1024), 0, hs, sa);
     CHECK_LAUNCH("k_scan_block_sums");
   }
-  hipLaunchKernelGGL(k_index_scan, dim3(nscan), dim3(1024), 0, hs, sa);
+  sa.bal.blk = nscan;
+  hipLaunchKernelGGL(k_index_scan, dim3(nscan + (sa.bal.perm ? 1 : 0)), dim3(1024), 0, hs, sa);
   CHECK_LAUNCH("k_index_scan");
   return TLSAN_OK;
 }
@@ -639,6 +652,12 @@ static int build_index(const tlsan_dims* d, const tlsan_batch* b, const St& st, 
   // only (the dense sweeps and tlsan_grads read the offsets of every row)
   sa.sparse = sparse_users ? (1 << 2) : 0;
   sa.n_uniq[0] = &st.hdr->n_uniq[k][0]; sa.n_uniq[1] = nullptr; sa.n_uniq[2] = &st.hdr->n_uniq[k][1];
+  if (balanced(d, b)) {
+    sa.bal.sl = b->sl; sa.bal.sl_new = b->sl_new;
+    sa.bal.B = b->B; sa.bal.Ls = d->Ls; sa.bal.Sn = b->Sn;
+    sa.bal.by_window = d->Ls > TLSAN_LS_MAX ? 1 : 0;
+    sa.bal.perm = st.perm[k];
+  }
   if ((rc = launch_scan(sa, nscan, st.scan_bsum[k], hs))) return rc;
   if (uc_by_list(d, b)) {
     hipLaunchKernelGGL(k_uc_fill, dim3((b->B + 255) / 256), dim3(256), 0, hs, b->u_cate, b->B, st.cur_uc[k], st.uc_list[k]);
@@ -664,6 +683,7 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   if (out && out->started) { a.started = out->started; a.started_val = out->started_value; }
   a.Gi = w.Gi; a.Gb = w.Gb; a.Gu = w.Gu; a.Gc = w.Gc; a.WU = w.WU;
   a.cur_item = st.cur_item[k]; a.cur_user = st.cur_user[k]; a.cur_uc = st.cur_uc[k];
+  a.perm = balanced(d, b) ? st.perm[k] : nullptr;
   a.uc_by_sample = uc_by_list(d, b) ? 1 : 0;
   a.cseg = cate_seg(d, b) ? 1 : 0;
   a.gLong = w.gLong; a.gDB = w.gDB; a.partials = w.partials; a.Kp = w.Kp;

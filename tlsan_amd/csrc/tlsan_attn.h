@@ -580,7 +580,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     int bidx;
     int offv = 0, f_total = 0;   // FLAT: lane r = where slot r's window starts in the flat list; the list's length
     {
-      const int cand = g * NSB + r;
+      const int cand = a.perm != nullptr ? a.perm[g * NSB + r] : g * NSB + r;   // (the batch's samples ranked and dealt out: BalArgs)
       const bool cv = cand < B;
       const int cl = cv ? min(a.b.sl[cand], Ls) : 0, cs = cv ? min(a.b.sl_new[cand], Sn) : 0;
       // (streamed windows: the window length decides -- up to 90 positions against a session's few -- and the longest
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       if (q == 0) sPerm[slot] = r;
       if (FLAT && q == 0) sPerm[16 + slot] = cl;
       wave_lds_fence();
-      bidx = g * NSB + sPerm[srow];
+      bidx = __shfl(cand, sPerm[srow], 16);   // (candidate of lane sPerm[srow] of the row)
       if constexpr (FLAT) {   // every wavefront works out the whole list's layout for itself: no barrier
         const int nlj = sPerm[16 + r];
 #pragma unroll

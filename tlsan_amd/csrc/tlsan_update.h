@@ -136,6 +136,82 @@ __global__ void k_batch_pack(PackArgs a) {
   }
 }
 
+// Which samples share a workgroup of the fused kernel (ScanArgs.bal; one extra block of the index scan's launch).
+// The kernel's launch is one workgroup of 16 samples per CU and ends with its slowest workgroup; sample costs are
+// heavy-tailed (window length when windows are streamed, session length otherwise).  The batch is ranked by that
+// cost (stable counting sort, descending) and dealt out in snake order: round j hands one sample to every group,
+// walking the groups forwards on even rounds and backwards on odd ones, so every group gets one sample of each
+// sixteenth of the ranking.  perm[16 g + j] = sample j of group g (>= B: none).  A fixed function of the batch.
+struct BalArgs {
+  const int32_t* sl; const int32_t* sl_new;
+  int32_t B, Ls, Sn, by_window;
+  int32_t blk;        // index of the block that does this (the first one behind the scan's blocks)
+  int32_t* perm;      // NULL: no balancing
+};
+#define BAL_KEYS 97     // costs 0 .. 96 (TLSAN_LS_CAP / TLSAN_SN_CAP)
+
+__device__ __forceinline__ void balance_block(const BalArgs& b) {   // 1024 threads = 16 wavefronts
+  __shared__ int wcnt[16][BAL_KEYS];   // samples of every cost per wavefront -> where the wavefront's first one of that cost ranks
+  __shared__ int start[BAL_KEYS];      // rank of the first sample of every cost
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int B = b.B, G = (B + 15) / 16;
+  const int CH = (B + 1023) / 1024, nper = 64 * CH;   // wavefront w owns samples [w nper, (w + 1) nper), 64 per round
+  for (int o = tid; o < 16 * BAL_KEYS; o += 1024) (&wcnt[0][0])[o] = 0;
+  __syncthreads();
+  auto key_of = [&](int i) {
+    const int v = b.by_window ? min(b.sl[i], b.Ls) : min(b.sl_new[i], b.Sn);
+    return min(max(v, 0), BAL_KEYS - 1);
+  };
+  for (int c = 0; c < CH; ++c) {
+    const int i = wave * nper + c * 64 + lane;
+    if (i < B) atomicAdd(&wcnt[wave][key_of(i)], 1);
+  }
+  __syncthreads();
+  if (tid < BAL_KEYS) {
+    int run = 0;
+    for (int w = 0; w < 16; ++w) {
+      const int x = wcnt[w][tid];
+      wcnt[w][tid] = run;
+      run += x;
+    }
+    start[tid] = run;   // (the cost's total, for the moment)
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int k = BAL_KEYS - 1; k >= 0; --k) {   // descending: the costliest samples rank first
+      const int x = start[k];
+      start[k] = run;
+      run += x;
+    }
+  }
+  __syncthreads();
+  auto place = [&](int rank, int sample) {
+    const int j = rank / G, idx = rank - j * G;
+    const int g = (j & 1) ? G - 1 - idx : idx;
+    b.perm[g * 16 + j] = sample;
+  };
+  volatile int* mine = &wcnt[wave][0];   // (wave-private from here on: DS operations of a wavefront execute in order)
+  for (int c = 0; c < CH; ++c) {
+    const int i = wave * nper + c * 64 + lane;
+    const bool v = i < B;
+    const int k = v ? key_of(i) : BAL_KEYS;   // (7 bits; the lanes past the batch form a group of their own)
+    // lanes of this round with the same cost: seven ballots, one per bit of the cost
+    unsigned long long m = ~0ull;
+#pragma unroll
+    for (int bit = 0; bit < 7; ++bit) {
+      const unsigned long long bb = __ballot((k >> bit) & 1);
+      m &= ((k >> bit) & 1) ? bb : ~bb;
+    }
+    const unsigned long long below = m & ((1ull << lane) - 1ull);
+    const int kk = v ? k : 0;
+    const int base = start[kk] + mine[kk];                 // ranks taken by earlier wavefronts and earlier rounds
+    if (v) place(base + __popcll(below), i);               // within a cost and a round: lane order = sample order
+    if (v && below == 0ull) mine[k] = mine[k] + __popcll(m);   // the group's first lane counts the round in
+  }
+  if (B + tid < 16 * G) place(B + tid, B);   // (a last group that is not full)
+}
+
 struct ScanArgs {
   const int32_t* cnt[3];
   int32_t* off[3];
@@ -151,6 +227,7 @@ struct ScanArgs {
   int32_t sparse;      // bit t set: off / cur of table t are written for the rows with cnt > 0 only -- the user table of a
                        // batch's destination index, which is reached through the batch's ids and the used-row records
                        // only (10 M users: 80 MB of writes per step otherwise; the item offsets are walked per category)
+  BalArgs bal;         // optional (bal.perm): one more block ranks the batch's samples for the fused kernel's workgroups
 };
 #define SCAN_TWO_LEVEL_BLOCKS 16  // tables of more chunks than this take the two-launch form
 
@@ -195,6 +272,10 @@ __global__ __launch_bounds__(1024) void k_scan_block_sums(ScanArgs a) {
 }
 
 __global__ __launch_bounds__(1024) void k_index_scan(ScanArgs a) {
+  if (a.bal.perm != nullptr && (int)blockIdx.x == a.bal.blk) {
+    balance_block(a.bal);
+    return;
+  }
   __shared__ long long wsum[16];
   __shared__ long long prefix;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
