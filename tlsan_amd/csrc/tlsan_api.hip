@@ -80,7 +80,7 @@ static int shape_of(const tlsan_dims* d, Shape* s) {
 #define EVAL_DENSE_MAX ((size_t)256 << 20)  // all-items scoring materialises all_emb (model.py:89-90) up to this size
 struct Ws {  // carve-up of the caller's scratch buffer
   float *Rc, *Ri, *Rb, *Ru;  // summed rows of the split lazy update
-  float *Gi, *Gb, *Gu, *Gc, *gLong, *gDB, *partials, *Kp, *gd, *sqd, *scal, *logits, *s_label;
+  float *Gi, *Gb, *Gu, *Gc, *gLong, *gDB, *gStat, *partials, *Kp, *gd, *sqd, *scal, *logits, *s_label;
   float* all_emb;  // evaluation: dense [I, D] item matrix (NULL when it would exceed EVAL_DENSE_MAX bytes)
   double* rownorm_part;
   double* rownorm;
@@ -123,6 +123,8 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
   w->Gc = (float*)take(sizeof(float) * (size_t)(B + 1 + (d->cate_count >= cseg_min ? NI : 0)) * d->d_cate);
   w->gLong = (float*)take(sizeof(float) * B * D);
   w->gDB = (float*)take(sizeof(float) * B * D);
+  // streamed windows at d = 256: per-sample softmax statistics of the long block (k_fwd_bwd, FLATG: no room in the LDS)
+  w->gStat = (float*)take((D > 128 && d->Ls > TLSAN_LS_MAX) ? sizeof(float) * (size_t)B * 2 * D : 0);
   w->partials = (float*)take(sizeof(float) * w->ngroups * s.NPB);
   // (sized so that the workspace of a batch also holds every smaller batch: the fused form of a smaller batch can
   //  need more partials than the split form of a larger one)
@@ -686,7 +688,7 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   a.perm = balanced(d, b) ? st.perm[k] : nullptr;
   a.uc_by_sample = uc_by_list(d, b) ? 1 : 0;
   a.cseg = cate_seg(d, b) ? 1 : 0;
-  a.gLong = w.gLong; a.gDB = w.gDB; a.partials = w.partials; a.Kp = w.Kp;
+  a.gLong = w.gLong; a.gDB = w.gDB; a.gStat = w.gStat; a.partials = w.partials; a.Kp = w.Kp;
   if (hp->dropout != 0.0f) {
     if (!(hp->dropout > 0.0f && hp->dropout < 1.0f)) return fail(TLSAN_E_BADARG, "dropout must be in [0, 1)");
     if (a.p.table_dtype != TLSAN_TABLE_F32) return fail(TLSAN_E_UNSUPPORTED, "dropout > 0 is built for fp32 tables");

@@ -412,12 +412,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   constexpr int TB = G::TBUF;                 // floats of one transpose buffer
   constexpr int NBUF = G::NBUF;               // 2: dW of position p overlaps position p+1
   constexpr int WB = 2 * DH * DH + 2 * DH;    // floats of one attention block's weights
-  constexpr bool USE_SW = G::USE_SW;          // attention weights staged in LDS (when they fit)
   // per-sample position slots: long, session (the batch's padded session length, rounded up to 4), 3 singles
   // (CSEG keeps two such arrays and sizes them by the batch; otherwise the slot count is a compile-time constant)
-  const int SNS = CSEG ? ((a.b.Sn + 3) & ~3) : TLSAN_SN_CAP;
-  const int PSTR = LSC + SNS + 4;
-  const int P_TGT = LSC + SNS, P_USR = P_TGT + 1, P_UC = P_TGT + 2;
 
 #ifndef TLSAN_EXP_FUSE_CONST
 #define TLSAN_EXP_FUSE_CONST 0      // (experiment: 1 = a.fuse_dk taken as true at compile time, only valid for launches that fuse: -0.2 us/step, not worth a variant)
@@ -433,13 +429,22 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #ifndef TLSAN_EXP_FLAT
 #define TLSAN_EXP_FLAT 1
 #endif
-  constexpr bool FLAT = TLSAN_EXP_FLAT != 0 && LSTREAM && NB == 1 && !DROP;
+  constexpr bool FLAT = TLSAN_EXP_FLAT != 0 && LSTREAM && !DROP;
   constexpr int NF = FLAT ? NSB * TLSAN_LS_CAP : 0;      // entries of the flat list (every window at the cap)
+  // NB > 1 (d = 256): the LDS has no room for the per-sample statistics and long-term vectors beside the list -- they
+  // go through global memory (FwdArgs.gStat, gLong: 32 KB per workgroup, L2-resident), the attention weights are
+  // read from `dense` instead of an LDS copy, and the position tables keep session slots only
+  constexpr bool FLATG = FLAT && NB > 1;
+  constexpr bool USE_SW = G::USE_SW && !FLATG;          // attention weights staged in LDS (when they fit)
+  constexpr int LSCP = FLAT ? 0 : LSC;                  // long slots of the position tables (FLAT: the list holds them)
+  const int SNS = (CSEG || FLATG) ? ((a.b.Sn + 3) & ~3) : TLSAN_SN_CAP;
+  const int PSTR = LSCP + SNS + 4;
+  const int P_TGT = LSCP + SNS, P_USR = P_TGT + 1, P_UC = P_TGT + 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;                   // [NSB][LSTR]  long -> dbridge
   float* sB0 = sA + NSB * LSTR;       // [NSB][LSTR]  bridge -> dlong  (FLAT: placed in front of sT instead, see sPart)
   float* sL = FLAT ? sB0 : sB0 + NSB * LSTR;   // [NSB][LSTR]  long, kept for the fused dK product (TRAIN && FUSE_DK) and for FLAT's backward
-  float* sS = sL + ((TRAIN && ((G::FUSE_DK && FUSE_RT) || FLAT)) ? NSB * LSTR : 0);  // [NW][4] scalar staging  (sL exists in launches that fuse: tlsan_attn_inst.h)
+  float* sS = sL + ((TRAIN && ((G::FUSE_DK && FUSE_RT) || (FLAT && !FLATG))) ? NSB * LSTR : 0);  // [NW][4] scalar staging  (sL exists in launches that fuse: tlsan_attn_inst.h)
   float* sH = sS + NW * 4;            // [NSB][2*LS] hist_t and usert*hist_t of the pass  (FLAT: [2][NF], by flat index)
   float* sW = sH + NSB * 2 * LSC;     // [2][WB] attention weights (W1,b1,W2,b2) of both blocks
   int* sP = (int*)(sW + (USE_SW ? 2 * WB : 0));  // [NSB][PSTR] destination-sorted row of every use
@@ -452,8 +457,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   int* sFpos = sFst + NF;
   int* sFcpos = sFpos + (TRAIN ? NF : 0);
   float* sMx = (float*)(sFcpos + ((TRAIN && CSEG) ? NF : 0));   // [NSB][LSTR] per-channel max of the window's scores
-  float* sIz = sMx + ((FLAT && TRAIN) ? NSB * LSTR : 0);         // [NSB][LSTR] 1 / sum of exponentials
-  float* sB = FLAT ? sIz + (TRAIN ? NSB * LSTR : 0) : sB0;
+  float* sIz = sMx + ((FLAT && !FLATG && TRAIN) ? NSB * LSTR : 0);   // [NSB][LSTR] 1 / sum of exponentials
+  int* sBx = (int*)(sIz + ((FLAT && !FLATG && TRAIN) ? NSB * LSTR : 0));   // FLATG: [NSB] the slots' samples (rows of gStat / gLong)
+  float* sB = FLAT ? (float*)(sBx + (FLATG ? NSB : 0)) : sB0;
   float* sT = FLAT ? sB + NSB * LSTR : (float*)sFid;  // per-wave transpose scratch / staging
   // FLAT: the partial softmax states of P1, 32 slots of [3][D], lie over sB and sT (neither is touched before P2)
   float* sPart = sB;
@@ -874,6 +880,21 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) xv[kb] = tbl_cvt<DT>(row[kb]) * scx;
       };
+#ifndef TLSAN_EXP_F1_PF
+#define TLSAN_EXP_F1_PF 0     // (d = 256: 1 = two rows in flight in the list's forward pass as at d <= 128; no faster there -- the
+                              //  kernel is bound by its matrix work and its spilled registers: C5 shape 439 vs 430 us/step with both off)
+#endif
+      if (FTn > 0 && NB > 1 && TLSAN_EXP_F1_PF == 0) {
+        for (int k = 0; k < FTn; ++k) {
+          Ent e;
+          raw4 rw[NB];
+          f32x4 xa[NB];
+          read_ent(i0 + k, e);
+          issue(e, rw);
+          take(i0 + k, e, rw, xa);
+          compute(i0 + k, e.st, xa);
+        }
+      } else
       if (FTn > 0) {   // wave-uniform
         // two rows in flight (A, B), each fetched two entries ahead of its use; the entry after that read from the list
         Ent eA, eB, nA, nB;
@@ -946,10 +967,18 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           iz1[kb][i] = Zl[kb][i] > 0.0f ? fast_rcp(Zl[kb][i]) : 0.0f;  // samples past the batch: no position
           long4[kb][i] *= iz1[kb][i];
         }
-        if constexpr (TRAIN) {
+        if constexpr (TRAIN && FLATG) {
+          if (vs) {
+            *(f32x4*)(a.gStat + (size_t)bidx * 2 * D + chb[kb]) = mx1[kb];
+            *(f32x4*)(a.gStat + (size_t)bidx * 2 * D + D + chb[kb]) = iz1[kb];
+          }
+        } else if constexpr (TRAIN) {
           *(f32x4*)(sMx + srow * LSTR + chb[kb]) = mx1[kb];
           *(f32x4*)(sIz + srow * LSTR + chb[kb]) = iz1[kb];
         }
+      }
+      if constexpr (TRAIN && FLATG) {
+        if (lead) sBx[srow] = bb;
       }
     } else if constexpr (LSTREAM) {
       ucat = a.b.u_cate[bb];
@@ -1401,14 +1430,14 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         short4[kb][i] *= Zs[kb][i];
       }
     if constexpr (TRAIN) {  // publish the session positions (the atomics are long back by now)
-      if (vs && kk < n_s) sP[srow * PSTR + LSC + kk] = spos0;
-      if (CSEG && vs && kk < n_s) sPc[srow * PSTR + LSC + kk] = scpos0;
+      if (vs && kk < n_s) sP[srow * PSTR + LSCP + kk] = spos0;
+      if (CSEG && vs && kk < n_s) sPc[srow * PSTR + LSCP + kk] = scpos0;
       for (int base = NL; base < pmax2 - 1; base += NL) {  // sessions longer than one chunk (rare)
         const int t = base + kk;
         if (vs && t < n_s) {
           const int sidt = a.b.hist_i_new[(size_t)bb * Sn + t];
-          sP[srow * PSTR + LSC + t] = atomicAdd(&a.cur_item[sidt], 1);
-          if constexpr (CSEG) sPc[srow * PSTR + LSC + t] = atomicAdd(&a.cur_uc[a.p.item_cate[sidt]], 1);
+          sP[srow * PSTR + LSCP + t] = atomicAdd(&a.cur_item[sidt], 1);
+          if constexpr (CSEG) sPc[srow * PSTR + LSCP + t] = atomicAdd(&a.cur_uc[a.p.item_cate[sidt]], 1);
         }
       }
     }
@@ -1571,8 +1600,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
               }
             }
           } else if ((vs || oth) && vt) {
-            const int pos = sP[(wave * SPW + s_sel) * PSTR + LSC + t];
-            const int cpos = CSEG ? sPc[(wave * SPW + s_sel) * PSTR + LSC + t] : 0;
+            const int pos = sP[(wave * SPW + s_sel) * PSTR + LSCP + t];
+            const int cpos = CSEG ? sPc[(wave * SPW + s_sel) * PSTR + LSCP + t] : 0;
             if (lead) a.Gb[pos] = 0.0f;
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) {
@@ -1734,7 +1763,121 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         if constexpr (LSTREAM) {
           AccSet<NB> acc;
           acc.zero();
-          if constexpr (FLAT) {
+          if constexpr (FLATG) {
+          // ---- FLAT at d = 256 (see P1): this column group's share of the workgroup's list, one entry after the other
+          // (the three-stage pipeline of d <= 128 below does not fit the registers).  The next entry's row, statistics
+          // and long-term vector are fetched at the top of an iteration and taken over just before its stores.
+          const int FTn = (f_total + NSB - 1) / NSB;
+          const int i0 = srow * FTn, iend = min(i0 + FTn, f_total);
+          const int ilast = max(f_total - 1, 0);
+          if (FTn > 0) {   // wave-uniform
+          raw4 en[NB];
+          f32x4 mxn[NB], izn[NB], lon[NB];
+          int stN = 0;
+          float uhN = 0.0f;
+          auto fetch = [&](int idx) {
+            const int ic = min(idx, ilast);
+            const int id = sFid[ic], ct = sFct[ic];
+            stN = sFst[ic];
+            uhN = sFuh[ic];
+            const int sb = sBx[stN >> 8];
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) en[kb] = gather_item4c_raw<DT>(a, id, ct, chb[kb]);
+            const float* gs = a.gStat + (size_t)sb * 2 * D;
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+              mxn[kb] = *(const f32x4*)(gs + chb[kb]);
+              izn[kb] = *(const f32x4*)(gs + D + chb[kb]);
+              lon[kb] = *(const f32x4*)(a.gLong + (size_t)sb * D + chb[kb]);
+            }
+          };
+          f32x4 ev[NB], mxc[NB], izc[NB], loc[NB];
+          float uhc = 0.0f;
+          int stc = 0;
+          bool vc = false;
+          auto take = [&](int idx) {
+            vc = idx < iend;
+            stc = stN;
+            uhc = vc ? uhN : 0.0f;
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+              ev[kb] = vc ? tbl_cvt<DT>(en[kb]) : (f32x4)(0.0f);
+              mxc[kb] = mxn[kb];
+              izc[kb] = izn[kb];
+              loc[kb] = lon[kb];
+            }
+          };
+#ifndef TLSAN_EXP_FG_PF
+#define TLSAN_EXP_FG_PF 0     // (1: the next entry's row / statistics in flight over the iteration, taken over before the stores)
+#endif
+          if (TLSAN_EXP_FG_PF) {
+            fetch(i0);
+            take(i0);
+          }
+          for (int k = 0; k < FTn; ++k) {       // wave-uniform
+            if (TLSAN_EXP_FG_PF) {
+              fetch(i0 + k + 1);
+            } else {
+              fetch(i0 + k);
+              take(i0 + k);
+            }
+            const int ic = min(i0 + k, ilast);
+            const int sc = stc >> 8, tcur = stc & 255;
+            const int posp = sFpos[ic], cposp = CSEG ? sFcpos[ic] : 0;
+            const float htc = sFht[ic];
+            const int posu = sP[sc * PSTR + P_USR];
+            const float scx = (gamma * P * P) * uhc, sce = (gamma * P) * uhc;
+            const float mk = vc ? 1.0f : 0.0f;
+            f32x4 dl[NB], xv[NB], z1[NB], zr[NB], m2[NB], av[NB], dx[NB];
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+              dl[kb] = *(const f32x4*)(sB + sc * LSTR + chb[kb]);
+              xv[kb] = ev[kb] * scx;
+            }
+            map_apply<NB, MM>(FT1, b1, xv, z1);
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) zr[kb][i] = fmaxf(z1[kb][i], 0.0f);
+            map_apply<NB, MM>(FT2, b2, zr, m2);
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) av[kb][i] = __expf(fminf(m2[kb][i] - mxc[kb][i], 0.0f)) * (izc[kb][i] * mk);
+            bwd_compute<NB, TSTR, false, MM>(FN2, FN1, xv, z1, av, loc, dl, T, q, r, acc.db1, acc.db2, dx);
+            bwd_dw<NB, TSTR, MM>(T, q, r, acc.dW1, acc.dW2);
+            float dsp = 0.0f;
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) dsp += dot4(dx[kb], ev[kb]);
+            const float ds = sample_sum<CPS>(dsp) * P;  // d loss / d scale of this entry
+            const bool vst = vc;
+            const float uhs = uhc;
+            // the fetched entry is taken over BEFORE the stores (a wait for a load that is older than a store waits for
+            // the store as well: see SPIPE)
+            if (TLSAN_EXP_FG_PF) {
+#pragma unroll
+              for (int kb = 0; kb < NB; ++kb) asm volatile("" : "+v"(en[kb]), "+v"(mxn[kb]), "+v"(izn[kb]), "+v"(lon[kb]));
+              take(i0 + k + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (vst) {
+              if (lead) a.Gb[posp] = 0.0f;
+#pragma unroll
+              for (int kb = 0; kb < NB; ++kb) {
+                const f32x4 de = dx[kb] * sce;
+                st4_out(use_dst(posp, cposp, chb[kb]), de);
+                sq_acc += dot4(de, de);
+              }
+              if (lead) {
+                const float gt = ds * (gamma * htc);  // d / d usert_emb[u][position]
+                a.Gu[(size_t)posu * a.WU + a.di + tcur] = gt;
+                sq_acc += gt * gt;
+                dgam += ds * (P * uhs);
+              }
+            }
+          }
+          }
+          } else if constexpr (FLAT) {
           // ---- FLAT (see P1): this column group's share of the workgroup's list, through the three-stage software
           // pipeline described under SPIPE below -- an iteration runs the FORWARD recomputation of entry k, the BACKWARD
           // maps of entry k - 1 and the dW products of entry k - 2, with the row of entry k + 1 in flight.  An entry's

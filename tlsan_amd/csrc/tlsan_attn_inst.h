@@ -13,13 +13,15 @@
 template <int D, int DH>
 static size_t fwd_smem_bytes(bool train, bool lstream, bool fuse_dk, int Sn, bool cseg, bool drop) {
   using G = Geo<D, DH>;
-  const bool flat = TLSAN_EXP_FLAT != 0 && lstream && G::NB == 1 && !drop;
+  const bool flat = TLSAN_EXP_FLAT != 0 && lstream && !drop;
+  const bool flatg = flat && G::NB > 1;      // (d = 256: statistics / long vectors in global memory, no LDS copy of the weights, no long slots)
   const int lsc = lstream ? TLSAN_LS_CAP : TLSAN_LS_MAX;
-  const int pstr = lsc + (cseg ? ((Sn + 3) & ~3) : TLSAN_SN_CAP) + 4;      // position slots per sample (k_fwd_bwd: PSTR), twice with CSEG
+  const int pstr = (flat ? 0 : lsc) + ((cseg || flatg) ? ((Sn + 3) & ~3) : TLSAN_SN_CAP) + 4;      // position slots per sample (k_fwd_bwd: PSTR), twice with CSEG
   const int nf = flat ? G::NSB * TLSAN_LS_CAP : 0;
-  return sizeof(float) * ((train ? G::NSB * pstr * (cseg ? 2 : 1) : 0) + 2 * G::NSB * G::LSTR + ((train && ((G::FUSE_DK && fuse_dk) || flat)) ? G::NSB * G::LSTR : 0) + G::NW * 4 + G::NSB * 2 * lsc + (G::USE_SW ? 2 * (2 * DH * DH + 2 * DH) : 0) + G::NW * G::WSCR +
+  return sizeof(float) * ((train ? G::NSB * pstr * (cseg ? 2 : 1) : 0) + 2 * G::NSB * G::LSTR + ((train && ((G::FUSE_DK && fuse_dk) || (flat && !flatg))) ? G::NSB * G::LSTR : 0) + G::NW * 4 + G::NSB * 2 * lsc +
+                          ((G::USE_SW && !flatg) ? 2 * (2 * DH * DH + 2 * DH) : 0) + G::NW * G::WSCR +
                           ((G::KEEP_A && train && !lstream) ? G::NW * TLSAN_LS_MAX * G::NB * 256 : 0) +
-                          nf * (3 + (train ? 1 : 0) + ((train && cseg) ? 1 : 0)) + ((flat && train) ? 2 * G::NSB * G::LSTR : 0) +
+                          nf * (3 + (train ? 1 : 0) + ((train && cseg) ? 1 : 0)) + ((flat && !flatg && train) ? 2 * G::NSB * G::LSTR : 0) + (flatg ? G::NSB : 0) +
                           (TLSAN_STAMPS ? G::NW * 32 * 2 : 0) /* diagnostic stamps */);
 }
 

@@ -492,6 +492,7 @@ struct FwdArgs {
                     // category's own segment of Gc (position drawn from cur_uc), not beside the item half in Gi
   float* gLong;     // [B, D]   long-term summaries (A operand of dK)   -- written only when the dK product is NOT fused
   float* gDB;       // [B, D]   d loss / d bridge     (B operand of dK)
+  float* gStat;     // [B, 2, D] streamed windows at d = 256: per-channel max and 1 / sum of the long block's scores (P1 -> P5)
   float* Kp;        // fused dK (Geo::FUSE_DK): [gridDim.x][D*D] partial products long^T . dbridge, one per workgroup
   float* partials;  // [ngroups, NPB]
   unsigned long long* stamps;  // diagnostic only (NULL in production): [gridDim.x*8 waves][16]
