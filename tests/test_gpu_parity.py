@@ -449,10 +449,13 @@ def test_chunked_evaluation_equals_the_reference_batches():
         assert list(pa) == list(pb) and list(ra) == list(rb)
 
 
-@pytest.mark.parametrize("d,Ls,Sn,B", [(128, 20, 3, 37), (128, 90, 5, 21), (64, 33, 2, 50), (256, 16, 2, 9), (256, 90, 4, 19)])
+@pytest.mark.parametrize("d,Ls,Sn,B", [(128, 20, 3, 37), (128, 90, 5, 21), (64, 33, 2, 50), (256, 16, 2, 9), (256, 90, 4, 19),
+                                       (128, 40, 3, 300), (64, 90, 2, 131), (256, 33, 2, 70)])
 def test_long_windows_streamed(d, Ls, Sn, B):
     """Ls > 10 (BASELINE configs 3/4: seq <= 90): the long block is streamed with an online
-    softmax; forward, one training step (dense and lazy L2) and eval against the oracle."""
+    softmax; forward, one training step (dense and lazy L2) and eval against the oracle.
+    (The larger batches: several workgroup passes, a last one that is not full, the samples ranked by window length and
+    dealt out to the passes, each pass's windows walked as one list whose runs are merged through the LDS.)"""
     cfg = make_config(U=50, I=150, C=8, d=d, Ls=Ls, regulation_rate=1e-3)
     p = _p32(random_params(cfg, seed=Ls + d))
     b, cat = random_batch(cfg, B=B, Sn=Sn, seed=Ls)
@@ -910,16 +913,18 @@ def test_dropout_training_matches_oracle(d, rate, Ls):
     assert np.abs(li.cpu().numpy() - ref).max() < LOGIT_TOL
 
 
-@pytest.mark.parametrize("d", [64, 128])
-def test_empty_histories(d):
+@pytest.mark.parametrize("d,Ls", [(64, 10), (128, 10), (128, 24), (64, 40)])
+def test_empty_histories(d, Ls):
     """sl = 0 (no long-term history; the reference's placeholders allow it although build_dataset.py never
     emits it): every position is masked, exp_mask leaves -1e30 everywhere (model.py:384, 480-483), the
     softmax is uniform over rows that are all zero -> the long summary is exactly 0 and nothing flows back
     into the window.  Mixed with ordinary samples, forward and one train step against the oracle."""
-    cfg = make_config(U=30, I=50, C=7, d=d, regulation_rate=1e-3)
+    cfg = make_config(U=30, I=50, C=7, d=d, Ls=Ls, regulation_rate=1e-3)
     p = _p32(random_params(cfg, seed=95))
     b, cat = random_batch(cfg, B=41, Sn=3, seed=96)
     b["sl"][::3] = 0
+    if Ls > 10:
+        b["sl"][16:32] = 0          # (streamed windows: a whole workgroup pass without a single window entry)
     ar = np.arange(cfg["Ls"])[None, :]
     b["hist_i"] = np.where(ar < b["sl"][:, None], b["hist_i"], 0)
     b["hist_t"] = np.where(ar < b["sl"][:, None], b["hist_t"], 0).astype(np.float32)

@@ -634,8 +634,9 @@ static int build_index(const tlsan_dims* d, const tlsan_batch* b, const St& st, 
   ca.n_hot = &st.hdr->n_hot[k];
   ca.cnt_item = st.cnt_item[k]; ca.cnt_user = st.cnt_user[k]; ca.cnt_uc = st.cnt_uc[k];
   ca.item_cate = item_cate; ca.cseg = cseg ? 1 : 0;
-  const int nthr = b->B * (d->Ls + b->Sn + 2);
-  hipLaunchKernelGGL(k_count, dim3((nthr + 255) / 256), dim3(256), 0, hs, ca);
+  ca.ncate = d->cate_count;
+  const int nthr = b->B * (d->Ls + b->Sn + 1);
+  hipLaunchKernelGGL(k_count, dim3((b->B + 255) / 256 + (nthr + 255) / 256), dim3(256), 0, hs, ca);
   CHECK_LAUNCH("k_count");
   ScanArgs sa;
   memset(&sa, 0, sizeof(sa));
@@ -662,7 +663,7 @@ static int build_index(const tlsan_dims* d, const tlsan_batch* b, const St& st, 
   }
   if ((rc = launch_scan(sa, nscan, st.scan_bsum[k], hs))) return rc;
   if (uc_by_list(d, b)) {
-    hipLaunchKernelGGL(k_uc_fill, dim3((b->B + 255) / 256), dim3(256), 0, hs, b->u_cate, b->B, st.cur_uc[k], st.uc_list[k]);
+    hipLaunchKernelGGL(k_uc_fill, dim3((b->B + 255) / 256), dim3(256), 0, hs, b->u_cate, b->B, d->cate_count, st.cur_uc[k], st.uc_list[k]);
     CHECK_LAUNCH("k_uc_fill");
   }
   return TLSAN_OK;

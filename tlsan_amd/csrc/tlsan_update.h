@@ -52,16 +52,42 @@ struct CountArgs {
   // will sit in that category's segment of Gc, next to the u_cate uses (ApplyArgs.cseg)
   const int32_t* item_cate;
   int32_t cseg;
+  int32_t ncate;        // categories (rows of cnt_uc)
 };
 
 // Use counts per destination row: one thread per (sample, slot); slots [0,Ls) long positions,
-// [Ls,Ls+Sn) session positions, Ls+Sn candidate, Ls+Sn+1 the user use (user row + u_cate row).
+// [Ls,Ls+Sn) session positions, Ls+Sn candidate; the first `nbs` blocks take the samples' single uses instead (user
+// row + u_cate row), 256 samples each.
 // Category rows find their item-side gradients through the segments of their items (see k_apply),
-// so only the u_cate uses are counted per category.
-__global__ void k_count(CountArgs a) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int B = a.b.B, Ls = a.Ls, Sn = a.b.Sn, S = Ls + Sn + 2;
-  if (t == 0 && a.n_hot) *a.n_hot = 0;
+// so only the u_cate uses are counted per category -- through a histogram in the LDS when the table is small:
+// atomics on ONE address execute one after the other (~100 ns each across the XCDs), and with few categories (15 in
+// Movies-TV: 273 samples per category) the 4096 u_cate counts alone took 30 us of this kernel's 50.
+#define COUNT_LDS_CATES 4096
+__global__ __launch_bounds__(256) void k_count(CountArgs a) {
+  __shared__ int hist[COUNT_LDS_CATES];
+  const int B = a.b.B, Ls = a.Ls, Sn = a.b.Sn, S = Ls + Sn + 1;
+  const int nbs = (B + 255) / 256;
+  if ((int)blockIdx.x < nbs) {   // ---- one thread per sample: the user use
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b == 0 && a.n_hot) *a.n_hot = 0;
+    const bool small = a.ncate <= COUNT_LDS_CATES;
+    if (small) {
+      for (int c = threadIdx.x; c < a.ncate; c += 256) hist[c] = 0;
+      __syncthreads();
+    }
+    if (b < B) {
+      atomicAdd(&a.cnt_user[a.b.u[b]], 1);
+      if (small) atomicAdd(&hist[a.b.u_cate[b]], 1);
+      else atomicAdd(&a.cnt_uc[a.b.u_cate[b]], 1);
+    }
+    if (small) {
+      __syncthreads();
+      for (int c = threadIdx.x; c < a.ncate; c += 256)
+        if (hist[c] != 0) atomicAdd(&a.cnt_uc[c], hist[c]);
+    }
+    return;
+  }
+  const int t = (blockIdx.x - nbs) * 256 + threadIdx.x;
   if (t >= B * S) return;
   const int b = t / S, slot = t - b * S;
   if (slot < Ls) {
@@ -77,13 +103,10 @@ __global__ void k_count(CountArgs a) {
       atomicAdd(&a.cnt_item[id], 1);
       if (a.cseg) atomicAdd(&a.cnt_uc[a.item_cate[id]], 1);
     }
-  } else if (slot == Ls + Sn) {
+  } else {
     const int id = a.b.i[b];
     atomicAdd(&a.cnt_item[id], 1);
     if (a.cseg) atomicAdd(&a.cnt_uc[a.item_cate[id]], 1);
-  } else {
-    atomicAdd(&a.cnt_user[a.b.u[b]], 1);
-    atomicAdd(&a.cnt_uc[a.b.u_cate[b]], 1);
   }
 }
 
@@ -96,9 +119,26 @@ __global__ void k_count(CountArgs a) {
 // Samples of every category for the u_cate uses (counting sort by category, after the scan): the
 // fused kernel then writes those gradient rows in sample order and draws no cursor for them -- with
 // few categories (15 in Movies-TV) 4096 returning atomics on 15 addresses cost it 20 us.
-__global__ void k_uc_fill(const int32_t* __restrict__ u_cate, int B, int32_t* cur_uc, int32_t* uc_list) {
+// (the cursor draws of a block's 256 samples go through the LDS as well when the table is small: one returning atomic
+//  per block and category instead of one per sample -- 13 -> 4 us with 15 categories)
+__global__ __launch_bounds__(256) void k_uc_fill(const int32_t* __restrict__ u_cate, int B, int ncate, int32_t* cur_uc, int32_t* uc_list) {
+  __shared__ int hist[COUNT_LDS_CATES];
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < B) uc_list[atomicAdd(&cur_uc[u_cate[b]], 1)] = b;
+  if (ncate > COUNT_LDS_CATES) {
+    if (b < B) uc_list[atomicAdd(&cur_uc[u_cate[b]], 1)] = b;
+    return;
+  }
+  for (int c = threadIdx.x; c < ncate; c += 256) hist[c] = 0;
+  __syncthreads();
+  const int c = b < B ? u_cate[b] : 0;
+  const int rank = b < B ? atomicAdd(&hist[c], 1) : 0;
+  __syncthreads();
+  for (int k = threadIdx.x; k < ncate; k += 256) {
+    const int n = hist[k];
+    if (n != 0) hist[k] = atomicAdd(&cur_uc[k], n);   // the block's first position in the category
+  }
+  __syncthreads();
+  if (b < B) uc_list[hist[c] + rank] = b;
 }
 
 struct PackArgs {
