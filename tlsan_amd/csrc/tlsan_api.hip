@@ -99,6 +99,13 @@ static int ru4(int x) { return (x + 3) / 4 * 4; }
 static bool fused_dk(int D, int ngroups) { return TLSAN_EXP_FUSE_DK != 0 && D <= 128 && ngroups <= FUSED_DK_MAX_GROUPS; }
 static int fwd_train_grid(int ngroups) { return ngroups; }    // (fused: ngroups <= FUSED_DK_MAX_GROUPS, one pass per workgroup)
 
+// windows longer than this are streamed (the list form of the long block); shorter ones stay in registers
+static int stream_above() {
+  static const int v = [] { const char* e = getenv("TLSAN_STREAM_ABOVE"); return e ? atoi(e) : TLSAN_LS_MAX; }();
+  return v < TLSAN_LS_MAX ? v : TLSAN_LS_MAX;
+}
+static bool streamed(int Ls) { return Ls > stream_above(); }
+
 static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base, Ws* w) {
   size_t o = 0;
   auto take = [&](size_t n) { char* p = base ? base + o : nullptr; o += al(n); return p; };
@@ -124,7 +131,7 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
   w->gLong = (float*)take(sizeof(float) * B * D);
   w->gDB = (float*)take(sizeof(float) * B * D);
   // streamed windows at d = 256: per-sample softmax statistics of the long block (k_fwd_bwd, FLATG: no room in the LDS)
-  w->gStat = (float*)take((D > 128 && d->Ls > TLSAN_LS_MAX) ? sizeof(float) * (size_t)B * 2 * D : 0);
+  w->gStat = (float*)take((D > 128 && streamed(d->Ls)) ? sizeof(float) * (size_t)B * 2 * D : 0);
   w->partials = (float*)take(sizeof(float) * w->ngroups * s.NPB);
   // (sized so that the workspace of a batch also holds every smaller batch: the fused form of a smaller batch can
   //  need more partials than the split form of a larger one)
@@ -165,13 +172,14 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
 // of the batch after next).  (TLSAN_BALANCE=0: workgroup g takes samples [16 g, 16 g + 16) as they come; 2: always)
 static bool balanced(const tlsan_dims* d, const tlsan_batch* b) {
   static const int on = [] { const char* v = getenv("TLSAN_BALANCE"); return v ? atoi(v) : 1; }();
-  return on != 0 && b && b->B > 16 && b->B <= BAL_CAP && (d->Ls > TLSAN_LS_MAX || on == 2);
+  return on != 0 && b && b->B > 16 && b->B <= BAL_CAP && (streamed(d->Ls) || on == 2);
 }
 #define UC_LIST_CAP (1 << 18)  // batches up to this many samples may keep a per-category sample list in the state
 // ... and do when a category sees many of the batch's samples (cursor atomics on few addresses inside the
 // fused kernel cost more than the extra launch on the index stream): more than 32 samples per category
 static inline bool uc_by_list(const tlsan_dims* d, const tlsan_batch* b) {
-  return b && b->B <= UC_LIST_CAP && (long)b->B > 32L * d->cate_count;
+  static const long per = [] { const char* v = getenv("TLSAN_UC_LIST_PER"); return v ? atol(v) : 32L; }();   // (A/B knob)
+  return b && b->B <= UC_LIST_CAP && (long)b->B > per * d->cate_count;
 }
 // many categories (the 10 k of BASELINE.json configs[4]): the category half of every item use's gradient row is written
 // into the category's own segment of Gc (FwdArgs.cseg) -- a category block of the apply pass then sums one contiguous
@@ -579,7 +587,7 @@ static int launch_fwd(const Shape& s, bool train, const FwdArgs& a, hipStream_t 
   int grid = a.ngroups < 4096 ? a.ngroups : 4096;
   if (train && a.fuse_dk) grid = fwd_train_grid(a.ngroups);
   hipError_t e;
-  const bool lstream = a.Ls > TLSAN_LS_MAX;  // long windows are streamed, short ones stay in registers
+  const bool lstream = streamed(a.Ls);  // long windows are streamed, short ones stay in registers
   if (s.D == 64) e = tlsan_launch_fwd_bwd_d64(train, lstream, a, grid, hs);
   else if (s.D == 128) e = tlsan_launch_fwd_bwd_d128(train, lstream, a, grid, hs);
   else e = tlsan_launch_fwd_bwd_d256(train, lstream, a, grid, hs);
@@ -658,7 +666,7 @@ static int build_index(const tlsan_dims* d, const tlsan_batch* b, const St& st, 
   if (balanced(d, b)) {
     sa.bal.sl = b->sl; sa.bal.sl_new = b->sl_new;
     sa.bal.B = b->B; sa.bal.Ls = d->Ls; sa.bal.Sn = b->Sn;
-    sa.bal.by_window = d->Ls > TLSAN_LS_MAX ? 1 : 0;
+    sa.bal.by_window = streamed(d->Ls) ? 1 : 0;
     sa.bal.perm = st.perm[k];
   }
   if ((rc = launch_scan(sa, nscan, st.scan_bsum[k], hs))) return rc;

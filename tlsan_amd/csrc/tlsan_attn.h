@@ -1506,10 +1506,17 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         f32x4 xbr[NB];      // position 0: the bridge row (LDS)
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) xbr[kb] = *(const f32x4*)(sB + srow * LSTR + chb[kb]);
-        RowPF xn2;          // positions 1..: the session row fetched one step ahead
+        RowPF xn2;          // positions 1..: the session row fetched one step ahead ...
         xn2.v = false;
+        f32x4 xnv[NB];      // ... and taken over at the END of the step that fetched it, before that step's stores: a wait
+                            // for a load that is older than a store waits for the store as well (vmcnt retires in order,
+                            // the stores sit in branches), so taken at the top of its own step it waited out the
+                            // previous step's stores
 #pragma unroll
-        for (int kb = 0; kb < NB; ++kb) xn2.r[kb] = srow4{};
+        for (int kb = 0; kb < NB; ++kb) {
+          xn2.r[kb] = srow4{};
+          xnv[kb] = (f32x4)(0.0f);
+        }
         for (int p = 0; p <= nsess; ++p) {  // wave-uniform trip count: the bridge, then the session steps
           const Sel e = sel_of(p > 0 ? p - 1 : 0);
           const int s_sel = e.s, t = e.t0 + e.dt;
@@ -1533,7 +1540,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) xv[kb] = xbr[kb];
           } else {
-            use_row(xn2, xv);
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) xv[kb] = xnv[kb];
           }
           if (p < nsess) {  // the row of the next session step
             if (!h_on && p > 0 && (p % NL) == 0) load_chunk(p);
@@ -1590,6 +1598,12 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           bwd_compute<NB, TSTR, DROP, MM>(FN2, FN1, xv, z1, av, outs, douts, Tp, q, r, acc.db1, acc.db2, dx, k1, k2);
           if (NBUF == 1) bwd_dw<NB, TSTR, MM>(Tp, q, r, acc.dW1, acc.dW2);
           else if (p > 0) bwd_dw<NB, TSTR, MM>(T + ((p - 1) & 1) * TB, q, r, acc.dW1, acc.dW2);
+          if (p < nsess) {   // (wave-uniform)
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) asm volatile("" : "+v"(xn2.r[kb]));   // (the fetched registers are read HERE)
+            use_row(xn2, xnv);
+            __builtin_amdgcn_sched_barrier(0);
+          }
           if (p == 0) {
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) {
