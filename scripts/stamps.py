@@ -58,6 +58,14 @@ def seg(nm, lo, hi, sel=None):
         return
     dd = (raw[:, :, hi] - raw[:, :, lo])[use]
     print("%-44s mean %8.0f p50 %8.0f max %8.0f" % (nm, dd.mean(), np.median(dd), dd.max()))
+if "Ls" in kw and int(kw["Ls"]) > 10:   # streamed windows (the list form)
+    anyw = raw[:, :, 0] > 0
+    seg("list: ids -> LDS, cursor draws, barrier", 0, 21, anyw)
+    seg("list: forward loop", 21, 22, anyw)
+    seg("list: barrier, merge of the runs, statistics", 22, 23, anyw)
+    seg("list backward: entry -> loop", 9, 16, anyw)
+    seg("list backward: loop", 16, 18, anyw)
+    seg("list backward: drain, padding, staging", 18, 10, anyw)
 seg("P1: loads issued -> rows in registers", 0, 21)
 seg("P1: weight fragments from the LDS", 21, 22)
 seg("P1: long forward (maps, softmax)", 22, 23)

@@ -819,6 +819,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         }
       }
       __syncthreads();
+      TLSAN_STAMP(21);
       const int FTn = (f_total + NSB - 1) / NSB;               // entries per column group (wave-uniform)
       const int i0 = srow * FTn, iend = min(i0 + FTn, f_total);
       const int ilast = max(f_total - 1, 0);
@@ -880,6 +881,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) xv[kb] = tbl_cvt<DT>(row[kb]) * scx;
       };
+#ifndef TLSAN_EXP_F1_ROWS
+#define TLSAN_EXP_F1_ROWS 4   // rows in flight in the list's forward pass (d <= 128)
+#endif
 #ifndef TLSAN_EXP_F1_PF
 #define TLSAN_EXP_F1_PF 0     // (d = 256: 1 = two rows in flight in the list's forward pass as at d <= 128; no faster there -- the
                               //  kernel is bound by its matrix work and its spilled registers: C5 shape 439 vs 430 us/step with both off)
@@ -896,31 +900,33 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         }
       } else
       if (FTn > 0) {   // wave-uniform
-        // two rows in flight (A, B), each fetched two entries ahead of its use; the entry after that read from the list
-        Ent eA, eB, nA, nB;
-        raw4 rA[NB], rB[NB];
-        read_ent(i0, eA);
-        read_ent(i0 + 1, eB);
-        issue(eA, rA);
-        issue(eB, rB);
-        read_ent(i0 + 2, nA);
-        read_ent(i0 + 3, nB);
-        for (int k = 0; k < FTn; k += 2) {
-          f32x4 xa[NB], xb[NB];
-          take(i0 + k, eA, rA, xa);
-          const int stA = eA.st;
-          eA = nA;
-          issue(eA, rA);
-          read_ent(i0 + k + 4, nA);
-          compute(i0 + k, stA, xa);
-          take(i0 + k + 1, eB, rB, xb);
-          const int stB = eB.st;
-          eB = nB;
-          issue(eB, rB);
-          read_ent(i0 + k + 5, nB);
-          compute(i0 + k + 1, stB, xb);
+        // NPF rows in flight, each fetched NPF entries ahead of its use (the item table does not fit an XCD's L2: a
+        // gather is ~2 k cycles away, an entry's own work a few hundred); the entry after that is read from the list
+        // meanwhile.  No stores in this loop: the compiler's own vmcnt counting keeps the later rows in flight.
+        constexpr int NPF = NB == 1 ? TLSAN_EXP_F1_ROWS : 2;
+        Ent eU[NPF], nU[NPF];
+        raw4 rU[NPF][NB];
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) read_ent(i0 + u, eU[u]);
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+          issue(eU[u], rU[u]);
+          read_ent(i0 + NPF + u, nU[u]);
+        }
+        for (int k = 0; k < FTn; k += NPF) {
+#pragma unroll
+          for (int u = 0; u < NPF; ++u) {
+            f32x4 xa[NB];
+            take(i0 + k + u, eU[u], rU[u], xa);
+            const int stU = eU[u].st;
+            eU[u] = nU[u];
+            issue(eU[u], rU[u]);
+            read_ent(i0 + k + u + 2 * NPF, nU[u]);
+            compute(i0 + k + u, stU, xa);
+          }
         }
       }
+      TLSAN_STAMP(22);
       __syncthreads();
       // the sample's own lanes merge its runs, in list order
       int gf = 0, gl = -1;
@@ -1906,40 +1912,51 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           const int i0 = srow * FTn, iend = min(i0 + FTn, f_total);
           const int ilast = max(f_total - 1, 0);
           if (FTn > 0) {   // wave-uniform
-          raw4 en[NB];
-          int idN, ctN, stN, stL, stF = 0, stB = 0;   // entry after the one in flight / in flight / forward stage / backward stage
-          float uhN, uhL;
-          {
-            const int ic = min(i0, ilast), ic1 = min(i0 + 1, ilast);
-            const int id0 = sFid[ic], ct0 = sFct[ic];
-            stL = sFst[ic];
-            uhL = sFuh[ic];
-#pragma unroll
-            for (int kb = 0; kb < NB; ++kb) en[kb] = gather_item4c_raw<DT>(a, id0, ct0, chb[kb]);
-            idN = sFid[ic1];
-            ctN = sFct[ic1];
-            stN = sFst[ic1];
-            uhN = sFuh[ic1];
-          }
+          // TWO rows in flight (E0, E1: entry j in E[j & 1]), the loop unrolled by two so that each buffer's fetch and
+          // take-over are straight-line code: iteration k fetches entry k + 2 at its top and takes entry k + 1 over just
+          // before its stores -- a gather is ~2 k cycles away (the item table does not fit an XCD's L2), an iteration is
+          // ~1.6 k, and with one row in flight every iteration waited for the fetch it had issued itself.
+          struct RowBuf { raw4 r[NB]; int st; float uh; };
+          RowBuf E0, E1;
+          int idN, ctN, stN, stF = 0, stB = 0;   // entry after the ones in flight / forward stage / backward stage
+          float uhN;
           f32x4 xvF[NB], evF[NB], z1F[NB], avF[NB], xvB[NB], evB[NB], loB[NB], dlB[NB];
 #pragma unroll
           for (int kb = 0; kb < NB; ++kb) z1F[kb] = avF[kb] = xvB[kb] = evB[kb] = loB[kb] = dlB[kb] = (f32x4)(0.0f);
           float sceF = 0.0f, sceB = 0.0f;
           bool vF = false, vB = false;
           int posuB = 0;
-          auto take_row = [&](int idx) {   // the fetched row becomes the forward stage's entry
+          auto fetch_into = [&](RowBuf& E) {    // the entry read from the list last goes out; the one after it is read
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) E.r[kb] = gather_item4c_raw<DT>(a, idN, ctN, chb[kb]);
+            E.st = stN;
+            E.uh = uhN;
+          };
+          auto read_next = [&](int idx) {
+            const int ic = min(idx, ilast);
+            idN = sFid[ic];
+            ctN = sFct[ic];
+            stN = sFst[ic];
+            uhN = sFuh[ic];
+          };
+          auto take_row = [&](int idx, const RowBuf& E) {   // a fetched row becomes the forward stage's entry
             vF = idx < iend;
-            const float uth = vF ? uhL : 0.0f;
-            stF = stL;
+            const float uth = vF ? E.uh : 0.0f;
+            stF = E.st;
             sceF = (gamma * P) * uth;      // d x / d e_true
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) {
-              evF[kb] = vF ? tbl_cvt<DT>(en[kb]) : (f32x4)(0.0f);
+              evF[kb] = vF ? tbl_cvt<DT>(E.r[kb]) : (f32x4)(0.0f);
               xvF[kb] = evF[kb] * ((gamma * P * P) * uth);  // x = e_stored * scale
             }
           };
-          take_row(i0);
-          for (int k = 0; k <= FTn; ++k) {      // wave-uniform
+          read_next(i0);
+          fetch_into(E0);
+          read_next(i0 + 1);
+          fetch_into(E1);
+          read_next(i0 + 2);
+          take_row(i0, E0);
+          auto body = [&](int k, RowBuf& Ef, RowBuf& Et) __attribute__((always_inline)) {
             f32x4 z1[NB], av[NB], m1[NB], dm2[NB], dz1[NB], dx[NB], ha[NB], hb[NB], hc[NB], hd[NB], mxf[NB], izf[NB], loF[NB], dlF[NB];
             const float sce = sceB;
             const bool stv = vB;
@@ -1949,18 +1966,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
               z1[kb] = z1F[kb];
               av[kb] = avF[kb];
             }
-            // the row after the forward stage's goes out; the list entry after that is read
-            {
-#pragma unroll
-              for (int kb = 0; kb < NB; ++kb) en[kb] = gather_item4c_raw<DT>(a, idN, ctN, chb[kb]);
-              stL = stN;
-              uhL = uhN;
-              const int ic2 = min(i0 + k + 2, ilast);
-              idN = sFid[ic2];
-              ctN = sFct[ic2];
-              stN = sFst[ic2];
-              uhN = sFuh[ic2];
-            }
+            fetch_into(Ef);                                          // entry k + 2
+            read_next(i0 + k + 3);
             // backward stage's entry: where its rows go; forward stage's entry: its sample's vectors
             const int ib = max(min(i0 + k - 1, ilast), 0);
             const int posp = sFpos[ib], cposp = CSEG ? sFcpos[ib] : 0;
@@ -2031,7 +2038,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             }
             const float ds = sample_sum<CPS>(dsp) * P;  // d loss / d scale of entry k - 1
             const int tB = stB & 255, posu = posuB;
-            // the forward stage's entry moves on to the backward stage; the fetched row takes its place -- BEFORE the stores
+            // the forward stage's entry moves on to the backward stage; entry k + 1's row takes its place -- BEFORE the stores
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) {
               xvB[kb] = xvF[kb];
@@ -2044,8 +2051,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             stB = stF;
             posuB = posuF;
 #pragma unroll
-            for (int kb = 0; kb < NB; ++kb) asm volatile("" : "+v"(en[kb]));   // (the fetched registers are read HERE, see SPIPE)
-            take_row(i0 + k + 1);
+            for (int kb = 0; kb < NB; ++kb) asm volatile("" : "+v"(Et.r[kb]));   // (the fetched registers are read HERE, see SPIPE)
+            take_row(i0 + k + 1, Et);
             __builtin_amdgcn_sched_barrier(0);
             if (stv) {
               if (lead) a.Gb[posp] = 0.0f;
@@ -2062,7 +2069,13 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
                 dgam += ds * (P * uhB);
               }
             }
+          };
+          TLSAN_STAMP(16);
+          for (int k = 0; k <= FTn; k += 2) {   // wave-uniform (an odd count runs one empty iteration more)
+            body(k, E0, E1);
+            body(k + 1, E1, E0);
           }
+          TLSAN_STAMP(18);
           read_tiles(0, 1);                     // drain: the dW products of the last entry
           dw_prod(acc.dW1);
           read_tiles(2, 3);
