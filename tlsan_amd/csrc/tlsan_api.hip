@@ -230,6 +230,8 @@ struct St {  // persistent state
   long long* scan_bsum[TLSAN_INDEX_SLOTS];                                // per-chunk sums of the index scan (large tables), per slot
   int32_t* perm[TLSAN_INDEX_SLOTS];                                       // samples of every workgroup of the fused kernel (BalArgs), BAL_CAP each
   int32_t* dk_ticket;                                                     // per dK tile: slices arrived (FinArgs.dk_ticket), zero at rest
+  int32_t* scan_ticket;                                                   // [index slot] arrivals of k_scan_block_sums (ScanArgs.bs_ticket), zero at rest
+  int32_t* flag_user[TLSAN_INDEX_SLOTS];                                  // 256-row pieces of the user table that hold a count (ScanArgs.flag), zero at rest
   int32_t* uc_list[TLSAN_INDEX_SLOTS];                                    // samples of every category (u_cate uses), UC_LIST_CAP each
   double* Rc64;                                           // category sums of a split PRESUM pass, zero at rest
   int32_t* hot_list[TLSAN_INDEX_SLOTS];                                   // slots (urec_item) of the hot item rows, AP_HOT_CAP each
@@ -271,6 +273,8 @@ static void carve_state(const tlsan_dims* d, char* base, St* s) {
                                             (d->user_count + 4095) / 4096));
   for (int k = 0; k < TLSAN_INDEX_SLOTS; ++k) s->perm[k] = (int32_t*)take(4 * (size_t)BAL_CAP);
   s->dk_ticket = (int32_t*)take(4 * 256);
+  s->scan_ticket = (int32_t*)take(4 * 64);
+  for (int k = 0; k < TLSAN_INDEX_SLOTS; ++k) s->flag_user[k] = (int32_t*)take(4 * (((size_t)d->user_count + 255) / 256));
   s->S_total = base ? &s->hdr->St : nullptr;
   s->bytes = o;
 }
@@ -655,6 +659,7 @@ static int build_index(const tlsan_dims* d, const tlsan_batch* b, const St& st, 
   ca.cnt_item = st.cnt_item[k]; ca.cnt_user = st.cnt_user[k]; ca.cnt_uc = st.cnt_uc[k];
   ca.item_cate = item_cate; ca.cseg = cseg ? 1 : 0;
   ca.ncate = d->cate_count;
+  ca.flag_user = st.flag_user[k];
   const int nthr = b->B * (d->Ls + b->Sn + 1);
   hipLaunchKernelGGL(k_count, dim3((b->B + 255) / 256 + (nthr + 255) / 256), dim3(256), 0, hs, ca);
   CHECK_LAUNCH("k_count");
@@ -671,9 +676,13 @@ static int build_index(const tlsan_dims* d, const tlsan_batch* b, const St& st, 
   sa.urec[0] = st.urec_item[k]; sa.urec[2] = st.urec_user[k];
   sa.hot_n[0] = &st.hdr->n_hot[k]; sa.hot_list[0] = st.hot_list[k];
   sa.total[0] = sa.total[1] = sa.total[2] = 1;
+  sa.flag[2] = st.flag_user[k];
+  // (sa.bs_ticket = st.scan_ticket + k: the sums scanned by the last block of k_scan_block_sums, one prefix read per scan
+  //  block -- measured slower: 3663 publishing atomics on consecutive words, 134 -> 162 us/step at 10 M / 5 M rows)
   // the user table of a lazy-L2 SGD step: its consumers reach off / cur through the batch's ids or the used-row records
   // only (the dense sweeps and tlsan_grads read the offsets of every row)
-  sa.sparse = sparse_users ? (1 << 2) : 0;
+  // (category segments: nothing walks the item offsets per category either -- 5 M items: 40 MB of writes per step less)
+  sa.sparse = sparse_users ? ((1 << 2) | (cseg ? 1 : 0)) : 0;
   sa.n_uniq[0] = &st.hdr->n_uniq[k][0]; sa.n_uniq[1] = nullptr; sa.n_uniq[2] = &st.hdr->n_uniq[k][1];
   if (balanced(d, b)) {
     sa.bal.sl = b->sl; sa.bal.sl_new = b->sl_new;

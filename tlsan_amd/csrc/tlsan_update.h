@@ -53,6 +53,7 @@ struct CountArgs {
   const int32_t* item_cate;
   int32_t cseg;
   int32_t ncate;        // categories (rows of cnt_uc)
+  int32_t* flag_user;   // optional: [ceil(U / 256)] set where a user row of that 256-row piece is counted (ScanArgs.flag)
 };
 
 // Use counts per destination row: one thread per (sample, slot); slots [0,Ls) long positions,
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(256) void k_count(CountArgs a) {
     }
     if (b < B) {
       atomicAdd(&a.cnt_user[a.b.u[b]], 1);
+      if (a.flag_user) a.flag_user[a.b.u[b] >> 8] = 1;
       if (small) atomicAdd(&hist[a.b.u_cate[b]], 1);
       else atomicAdd(&a.cnt_uc[a.b.u_cate[b]], 1);
     }
@@ -267,6 +269,11 @@ struct ScanArgs {
   int32_t sparse;      // bit t set: off / cur of table t are written for the rows with cnt > 0 only -- the user table of a
                        // batch's destination index, which is reached through the batch's ids and the used-row records
                        // only (10 M users: 80 MB of writes per step otherwise; the item offsets are walked per category)
+  // optional per table: [ceil(n / 256)] marks of the 256-row pieces that hold a count (set by k_count, cleared here: zero
+  // at rest).  A wavefront of either scan kernel covers exactly one piece and skips an unmarked one without reading it:
+  // 4096 samples mark at most 4096 pieces of a 10 M-row user table's 39 k (40 MB of counters per pass otherwise)
+  int32_t* flag[3];
+  int32_t* bs_ticket;   // optional (with bsum): arrival counter of k_scan_block_sums, zero at rest -- its last block scans the sums
   BalArgs bal;         // optional (bal.perm): one more block ranks the batch's samples for the fused kernel's workgroups
 };
 #define SCAN_TWO_LEVEL_BLOCKS 16  // tables of more chunks than this take the two-launch form
@@ -290,7 +297,9 @@ __global__ __launch_bounds__(1024) void k_scan_block_sums(ScanArgs a) {
   const int i0 = ((int)blockIdx.x - a.blk0[which]) * 4096 + tid * 4;
   long long part = 0;
   int c4[4] = {0, 0, 0, 0};
-  if (i0 + 3 < n) {                      // (chunks start at multiples of 4096: 16-byte aligned)
+  const bool marked = a.flag[which] == nullptr || i0 >= n || a.flag[which][i0 >> 8] != 0;   // (wave-uniform)
+  if (!marked) {
+  } else if (i0 + 3 < n) {               // (chunks start at multiples of 4096: 16-byte aligned)
     const int4 v = *(const int4*)(cnt + i0);
     c4[0] = v.x; c4[1] = v.y; c4[2] = v.z; c4[3] = v.w;
   } else {
@@ -303,12 +312,51 @@ __global__ __launch_bounds__(1024) void k_scan_block_sums(ScanArgs a) {
   for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
   if (lane == 0) wsum[wave] = part;
   __syncthreads();
+  __shared__ int s_last;
   if (tid == 0) {
     long long t = 0;
 #pragma unroll
     for (int w = 0; w < 16; ++w) t += wsum[w];
-    a.bsum[blockIdx.x] = t;
+    if (a.bs_ticket == nullptr) {
+      a.bsum[blockIdx.x] = t;
+    } else {   // published with a returning atomic: the last block to arrive reads every sum with device-scope loads
+      const unsigned long long old = atomicExch((unsigned long long*)&a.bsum[blockIdx.x], (unsigned long long)t);
+      asm volatile("" ::"v"(old));
+      s_last = atomicAdd(a.bs_ticket, 1) == (int)gridDim.x - 1;
+    }
   }
+  if (a.bs_ticket == nullptr) return;
+  __syncthreads();
+  if (!s_last) return;
+  // ---- the last block: the sums of every table's chunks -> exclusive prefixes, in place (k_index_scan then reads ONE
+  // value per block where every block used to add up all the sums before its own: 3663 chunks of a 10 M + 5 M-row index,
+  // 54 MB of reads)
+  __shared__ long long carry;
+  for (int t = 0; t < 3; ++t) {
+    const int b0 = a.blk0[t], b1 = t < 2 ? a.blk0[t + 1] : (int)gridDim.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int k0 = b0; k0 < b1; k0 += 1024) {
+      const int k = k0 + tid;
+      const long long v = k < b1 ? __hip_atomic_load(&a.bsum[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      long long inc = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const long long x = __shfl_up(inc, o);
+        if (lane >= o) inc += x;
+      }
+      if (lane == 63) wsum[wave] = inc;
+      __syncthreads();
+      long long pre = carry + inc - v;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) pre += (w < wave) ? wsum[w] : 0;
+      if (k < b1) a.bsum[k] = pre;
+      __syncthreads();
+      if (tid == 1023) carry = pre + v;
+      __syncthreads();
+    }
+  }
+  if (tid == 0) *a.bs_ticket = 0;   // zero at rest
 }
 
 __global__ __launch_bounds__(1024) void k_index_scan(ScanArgs a) {
@@ -328,7 +376,9 @@ __global__ __launch_bounds__(1024) void k_index_scan(ScanArgs a) {
   auto pack = [](int c) { return (long long)c + ((long long)(c > 0) << 32); };
   // ---- packed sum over cnt[0, base)
   long long part = 0;
-  if (a.bsum != nullptr) {
+  if (a.bsum != nullptr && a.bs_ticket != nullptr) {
+    part = tid == 0 ? a.bsum[blockIdx.x] : 0;   // (k_scan_block_sums left the exclusive prefix of this block's table)
+  } else if (a.bsum != nullptr) {
     for (int k = a.blk0[which] + tid; k < (int)blockIdx.x; k += 1024) part += a.bsum[k];
   } else {
     for (int k = tid * 4; k < base; k += 4096) {
@@ -351,9 +401,11 @@ __global__ __launch_bounds__(1024) void k_index_scan(ScanArgs a) {
   __syncthreads();
   // ---- own chunk
   const int i0 = base + tid * 4;
-  int v[4];
+  int v[4] = {0, 0, 0, 0};
   const bool full = i0 + 3 < n;          // (chunks start at multiples of 4096: 16-byte accesses)
-  if (full) {
+  const bool marked = a.flag[which] == nullptr || i0 >= n || a.flag[which][i0 >> 8] != 0;   // (wave-uniform: a wavefront = one 256-row piece)
+  if (!marked) {
+  } else if (full) {
     const int4 t = *(const int4*)(cnt + i0);
     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
   } else {
@@ -404,6 +456,7 @@ __global__ __launch_bounds__(1024) void k_index_scan(ScanArgs a) {
       }
     }
   }
+  if (a.flag[which] != nullptr && marked && lane == 0 && i0 < n) a.flag[which][i0 >> 8] = 0;   // zero at rest
 }
 
 // ------------------------------------------------------------------------------------------
