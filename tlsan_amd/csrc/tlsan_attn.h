@@ -1514,6 +1514,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         for (int kb = 0; kb < NB; ++kb) xbr[kb] = *(const f32x4*)(sB + srow * LSTR + chb[kb]);
         RowPF xn2;          // positions 1..: the session row fetched one step ahead ...
         xn2.v = false;
+        // (d = 256 keeps the take-over at the top of the row's own step: eight more live registers there cost the streamed
+        //  bf16 variants 12 %: 241 -> 270 us/step at d = 256, Ls = 90)
+        constexpr bool P3TAKE = NB == 1;
         f32x4 xnv[NB];      // ... and taken over at the END of the step that fetched it, before that step's stores: a wait
                             // for a load that is older than a store waits for the store as well (vmcnt retires in order,
                             // the stores sit in branches), so taken at the top of its own step it waited out the
@@ -1545,9 +1548,11 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           if (p == 0) {
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) xv[kb] = xbr[kb];
-          } else {
+          } else if constexpr (P3TAKE) {
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) xv[kb] = xnv[kb];
+          } else {
+            use_row(xn2, xv);
           }
           if (p < nsess) {  // the row of the next session step
             if (!h_on && p > 0 && (p % NL) == 0) load_chunk(p);
@@ -1604,7 +1609,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           bwd_compute<NB, TSTR, DROP, MM>(FN2, FN1, xv, z1, av, outs, douts, Tp, q, r, acc.db1, acc.db2, dx, k1, k2);
           if (NBUF == 1) bwd_dw<NB, TSTR, MM>(Tp, q, r, acc.dW1, acc.dW2);
           else if (p > 0) bwd_dw<NB, TSTR, MM>(T + ((p - 1) & 1) * TB, q, r, acc.dW1, acc.dW2);
-          if (p < nsess) {   // (wave-uniform)
+          if (P3TAKE && p < nsess) {   // (wave-uniform)
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) asm volatile("" : "+v"(xn2.r[kb]));   // (the fetched registers are read HERE)
             use_row(xn2, xnv);
