@@ -1004,3 +1004,18 @@ def test_dk_product_in_the_tail_launch():
                         "test_gradients or test_train_step_matches_oracle or test_multi_step_tracks_oracle_and_is_deterministic or test_full_size_batch_matches_oracle"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_user_index_from_a_sort_of_the_batch():
+    """Tables of 65 536 users or more take the user side of a batch's destination index from a sort of the batch's user ids
+    (UsortArgs, one block of the scan's launch) instead of counters and a scan over the table.  TLSAN_USORT_MIN=1 (read
+    once per process) sends every table that way: the oracle tests of train steps -- small user tables, so batches full
+    of repeated users -- must hold."""
+    import subprocess, sys
+    env = dict(os.environ, TLSAN_USORT_MIN="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-m", "gpu", "-q", "-x", "-k",
+                        "test_train_step_matches_oracle or test_multi_step_tracks_oracle_and_is_deterministic or test_lazy_l2_matches_dense_oracle "
+                        "or test_full_size_batch_matches_oracle or test_long_windows_streamed or test_graph_replay_equals_eager or test_prefetched_index_equals_inline"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -461,7 +461,8 @@ static int launch_scan(ScanArgs& sa, int nscan, long long* bsum, hipStream_t hs)
     CHECK_LAUNCH("k_scan_block_sums");
   }
   sa.bal.blk = nscan;
-  hipLaunchKernelGGL(k_index_scan, dim3(nscan + (sa.bal.perm ? 1 : 0)), dim3(1024), 0, hs, sa);
+  sa.us.blk = nscan + (sa.bal.perm ? 1 : 0);
+  hipLaunchKernelGGL(k_index_scan, dim3(nscan + (sa.bal.perm ? 1 : 0) + (sa.us.u ? 1 : 0)), dim3(1024), 0, hs, sa);
   CHECK_LAUNCH("k_index_scan");
   return TLSAN_OK;
 }
@@ -660,6 +661,10 @@ static int build_index(const tlsan_dims* d, const tlsan_batch* b, const St& st, 
   ca.item_cate = item_cate; ca.cseg = cseg ? 1 : 0;
   ca.ncate = d->cate_count;
   ca.flag_user = st.flag_user[k];
+  // the user side from a sort of the batch's ids (UsortArgs) when only the used rows are wanted and the table is large
+  static const int usort_min = [] { const char* v = getenv("TLSAN_USORT_MIN"); return v ? atoi(v) : (1 << 16); }();
+  const bool usort = sparse_users && b->B <= USORT_MAX && d->user_count >= usort_min;
+  ca.skip_users = usort ? 1 : 0;
   const int nthr = b->B * (d->Ls + b->Sn + 1);
   hipLaunchKernelGGL(k_count, dim3((b->B + 255) / 256 + (nthr + 255) / 256), dim3(256), 0, hs, ca);
   CHECK_LAUNCH("k_count");
@@ -672,6 +677,11 @@ static int build_index(const tlsan_dims* d, const tlsan_batch* b, const St& st, 
   sa.blk0[0] = 0;
   sa.blk0[1] = (sa.n[0] + 4095) / 4096;
   sa.blk0[2] = sa.blk0[1] + (sa.n[1] + 4095) / 4096;
+  if (usort) {
+    sa.n[2] = 0;
+    sa.us.u = b->u; sa.us.B = b->B; sa.us.U = d->user_count;
+    sa.us.cur = st.cur_user[k]; sa.us.off = st.off_user[k]; sa.us.urec = st.urec_user[k]; sa.us.n_uniq = &st.hdr->n_uniq[k][1];
+  }
   const int nscan = sa.blk0[2] + (sa.n[2] + 4095) / 4096;
   sa.urec[0] = st.urec_item[k]; sa.urec[2] = st.urec_user[k];
   sa.hot_n[0] = &st.hdr->n_hot[k]; sa.hot_list[0] = st.hot_list[k];

@@ -54,6 +54,7 @@ struct CountArgs {
   int32_t cseg;
   int32_t ncate;        // categories (rows of cnt_uc)
   int32_t* flag_user;   // optional: [ceil(U / 256)] set where a user row of that 256-row piece is counted (ScanArgs.flag)
+  int32_t skip_users;   // != 0: the user side of the index comes from a sort of the batch's user ids (UsortArgs): no counts
 };
 
 // Use counts per destination row: one thread per (sample, slot); slots [0,Ls) long positions,
@@ -77,8 +78,10 @@ __global__ __launch_bounds__(256) void k_count(CountArgs a) {
       __syncthreads();
     }
     if (b < B) {
-      atomicAdd(&a.cnt_user[a.b.u[b]], 1);
-      if (a.flag_user) a.flag_user[a.b.u[b] >> 8] = 1;
+      if (!a.skip_users) {
+        atomicAdd(&a.cnt_user[a.b.u[b]], 1);
+        if (a.flag_user) a.flag_user[a.b.u[b] >> 8] = 1;
+      }
       if (small) atomicAdd(&hist[a.b.u_cate[b]], 1);
       else atomicAdd(&a.cnt_uc[a.b.u_cate[b]], 1);
     }
@@ -254,6 +257,75 @@ __device__ __forceinline__ void balance_block(const BalArgs& b) {   // 1024 thre
   if (B + tid < 16 * G) place(B + tid, B);   // (a last group that is not full)
 }
 
+// The user side of a batch's destination index WITHOUT a pass over the user table (one more block of the scan's launch):
+// a batch holds B user uses (one per sample), so the used rows, their counts and first positions come from a sort of the
+// B ids -- bitonic, in the LDS, B <= USORT_MAX -- where the counting form reads (and two scan kernels walk) a counter per
+// table row: 10 M users are 2442 of a 10 M + 5 M-row index's 3666 scan blocks.  Writes exactly what the scan writes
+// for a table with `sparse` set: cur / off of the used rows, their records (ascending), their number, off[U].
+#define USORT_MAX 8192
+struct UsortArgs {
+  const int32_t* u; int32_t B, U;
+  int32_t* cur; int32_t* off; int4* urec; int32_t* n_uniq;
+  int32_t blk;        // index of the block that does this; u == NULL: none
+};
+
+__device__ __forceinline__ void usort_block(const UsortArgs& a) {   // 1024 threads
+  __shared__ int key[USORT_MAX];
+  __shared__ int ustart[USORT_MAX];
+  __shared__ int wtot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int N = 1024;
+  while (N < a.B) N <<= 1;
+  for (int i = tid; i < N; i += 1024) key[i] = i < a.B ? a.u[i] : 0x7fffffff;
+  __syncthreads();
+  for (int k = 2; k <= N; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < N / 2; t += 1024) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
+        const bool up = (i & k) == 0;
+        const int x = key[i], y = key[p];
+        if ((x > y) == up) { key[i] = y; key[p] = x; }
+      }
+      __syncthreads();
+    }
+  // runs of equal ids: a thread takes CH consecutive sorted entries
+  const int CH = N / 1024, i0 = tid * CH;
+  int mine = 0;
+  for (int c = 0; c < CH; ++c) {
+    const int i = i0 + c;
+    mine += (i < a.B && (i == 0 || key[i] != key[i - 1])) ? 1 : 0;
+  }
+  int inc = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wtot[wave] = inc;
+  __syncthreads();
+  int j = inc - mine, nu = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    j += (w < wave) ? wtot[w] : 0;
+    nu += wtot[w];
+  }
+  for (int c = 0; c < CH; ++c) {
+    const int i = i0 + c;
+    if (i < a.B && (i == 0 || key[i] != key[i - 1])) ustart[j++] = i;
+  }
+  __syncthreads();
+  for (int r = tid; r < nu; r += 1024) {
+    const int st = ustart[r], row = key[st], cnt = (r + 1 < nu ? ustart[r + 1] : a.B) - st;
+    a.urec[r] = make_int4(row, st, cnt, 0);
+    a.cur[row] = st;
+    a.off[row] = st;
+  }
+  if (tid == 0) {
+    *a.n_uniq = nu;
+    a.off[a.U] = a.B;
+  }
+}
+
 struct ScanArgs {
   const int32_t* cnt[3];
   int32_t* off[3];
@@ -275,6 +347,7 @@ struct ScanArgs {
   int32_t* flag[3];
   int32_t* bs_ticket;   // optional (with bsum): arrival counter of k_scan_block_sums, zero at rest -- its last block scans the sums
   BalArgs bal;         // optional (bal.perm): one more block ranks the batch's samples for the fused kernel's workgroups
+  UsortArgs us;        // optional (us.u): one more block builds the user side of the index from a sort of the batch's ids
 };
 #define SCAN_TWO_LEVEL_BLOCKS 16  // tables of more chunks than this take the two-launch form
 
@@ -362,6 +435,10 @@ __global__ __launch_bounds__(1024) void k_scan_block_sums(ScanArgs a) {
 __global__ __launch_bounds__(1024) void k_index_scan(ScanArgs a) {
   if (a.bal.perm != nullptr && (int)blockIdx.x == a.bal.blk) {
     balance_block(a.bal);
+    return;
+  }
+  if (a.us.u != nullptr && (int)blockIdx.x == a.us.blk) {
+    usort_block(a.us);
     return;
   }
   __shared__ long long wsum[16];
