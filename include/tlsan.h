@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TLSAN_ABI_VERSION 13
+#define TLSAN_ABI_VERSION 14
 
 enum {
   TLSAN_OK = 0,
@@ -266,9 +266,13 @@ int tlsan_batch_pack(const tlsan_packed* set, const int32_t* order, int32_t lo, 
  * it after the last step that used the same slot and before the step that consumes it.
  * slot | TLSAN_INDEX_FOR_LAZY_SGD: the index will be consumed by a lazy-L2 SGD train step only, which reaches the
  * user table's offsets through the batch's ids and the used-row records -- they are then written for the used rows
- * only (10 M users: 80 MB less per step).  An index built that way must not feed tlsan_grads or a dense-L2 step. */
+ * only (10 M users: 80 MB less per step).  An index built that way must not feed tlsan_grads or a dense-L2 step.
+ * item_cate: params->item_cate of the tables the step will run on (tables with thousands of categories count item
+ * uses per category as well; may be NULL below TLSAN_CSEG_MIN categories -- the only parameter-side input, and it is
+ * not a trainable). */
 #define TLSAN_INDEX_FOR_LAZY_SGD 0x100
-int tlsan_batch_index(const tlsan_dims* dims, const tlsan_batch* b, void* state, int32_t slot, void* stream);
+int tlsan_batch_index(const tlsan_dims* dims, const tlsan_batch* b, const int32_t* item_cate, void* state, int32_t slot,
+                      void* stream);
 
 /* Gradients only (no update) -- what `tf.gradients(self.loss, trainables)` (model.py:198)
  * returns, with duplicate ids summed and reg*W added for the four regularised tables.

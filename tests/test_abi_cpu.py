@@ -25,7 +25,7 @@ def test_header_symbols_exported():
     assert declared == set(L.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.tlsan_abi_version() == L.ABI_VERSION == 13
+    assert lib.tlsan_abi_version() == L.ABI_VERSION == 14
 
 
 def test_dense_layout_and_sizes():

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # (TLSAN_LIB_PATH: a diagnostic build of the same library, e.g. the -DTLSAN_STAMPS=1 variant of scripts/stamps.py)
 LIB_PATH = os.environ.get("TLSAN_LIB_PATH") or os.path.join(HERE, "libtlsan_hip.so")
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 NORM_TF18, NORM_DEDUP = 0, 1
 TABLE_F32, TABLE_BF16 = 0, 1
 MATRIX_F32, MATRIX_BF16 = 0, 1
@@ -132,7 +132,7 @@ def load():
     lib.tlsan_train_step_opt.restype = C.c_int
     lib.tlsan_batch_pack.argtypes = [P(Packed), C.c_void_p, C.c_int32, P(Batch), C.c_int32, C.c_int32, C.c_void_p]
     lib.tlsan_batch_pack.restype = C.c_int
-    lib.tlsan_batch_index.argtypes = [P(Dims), P(Batch), C.c_void_p, C.c_int32, C.c_void_p]
+    lib.tlsan_batch_index.argtypes = [P(Dims), P(Batch), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.tlsan_batch_index.restype = C.c_int
     lib.tlsan_grads.argtypes = [P(Dims), P(Params), P(Batch), P(HParams), P(GradsOut), P(StepOut),
                                 C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]

@@ -98,8 +98,14 @@ static int ru4(int x) { return (x + 3) / 4 * 4; }
 #ifndef TLSAN_DK_TAIL_DEFAULT
 #define TLSAN_DK_TAIL_DEFAULT 0
 #endif
-#define TLSAN_CSEG_MIN_CATES 2048    // tables with at least this many categories take the category-segment path (cate_seg below)
-static bool fused_dk(int D, int ngroups) { return TLSAN_EXP_FUSE_DK != 0 && D <= 128 && ngroups <= FUSED_DK_MAX_GROUPS; }
+// tables with at least this many categories take the category-segment path (cate_seg below; TLSAN_CSEG_MIN=<n> for tests
+// and experiments, read once per process)
+#define TLSAN_CSEG_MIN_CATES 2048
+static int cseg_min_cates() {
+  static const int v = [] { const char* e = getenv("TLSAN_CSEG_MIN"); return e ? atoi(e) : TLSAN_CSEG_MIN_CATES; }();
+  return v;
+}
+static bool fused_dk(int D, int ngroups) { return D <= 128 && ngroups <= FUSED_DK_MAX_GROUPS; }
 static int fwd_train_grid(int ngroups) { return ngroups; }    // (fused: ngroups <= FUSED_DK_MAX_GROUPS, one pass per workgroup)
 
 // dK in the tail launch (FinArgs.dk_gemm): the fused kernel leaves the [B, D] operands, DK_KS finalize blocks per 16 x 16
@@ -108,12 +114,8 @@ static bool dk_tail(int D) {
   static const int on = [] { const char* v = getenv("TLSAN_DK_TAIL"); return v ? atoi(v) : TLSAN_DK_TAIL_DEFAULT; }();
   return on != 0 && D <= 128;
 }
-// windows longer than this are streamed (the list form of the long block); shorter ones stay in registers
-static int stream_above() {
-  static const int v = [] { const char* e = getenv("TLSAN_STREAM_ABOVE"); return e ? atoi(e) : TLSAN_LS_MAX; }();
-  return v < TLSAN_LS_MAX ? v : TLSAN_LS_MAX;
-}
-static bool streamed(int Ls) { return Ls > stream_above(); }
+// windows longer than TLSAN_LS_MAX are streamed (the list form of the long block); shorter ones stay in registers
+static bool streamed(int Ls) { return Ls > TLSAN_LS_MAX; }
 
 static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base, Ws* w) {
   size_t o = 0;
@@ -135,8 +137,7 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
   w->Gb = (float*)take(sizeof(float) * (NI + 1));
   w->Gu = (float*)take(sizeof(float) * (size_t)(B + 1) * w->WU);
   // (CSEG: one row per u_cate use AND per item use -- sized for it whenever the table shape can take that path)
-  static const int cseg_min = [] { const char* v = getenv("TLSAN_CSEG_MIN"); return v ? atoi(v) : TLSAN_CSEG_MIN_CATES; }();
-  w->Gc = (float*)take(sizeof(float) * (size_t)(B + 1 + (d->cate_count >= cseg_min ? NI : 0)) * d->d_cate);
+  w->Gc = (float*)take(sizeof(float) * (size_t)(B + 1 + (d->cate_count >= cseg_min_cates() ? NI : 0)) * d->d_cate);
   w->gLong = (float*)take(sizeof(float) * B * D);
   w->gDB = (float*)take(sizeof(float) * B * D);
   // streamed windows at d = 256: per-sample softmax statistics of the long block (k_fwd_bwd, FLATG: no room in the LDS)
@@ -145,7 +146,7 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
   // (sized so that the workspace of a batch also holds every smaller batch: the fused form of a smaller batch can
   //  need more partials than the split form of a larger one)
   int kp_slots = dk_nsplit(B);
-  if (TLSAN_EXP_FUSE_DK != 0 && s.D <= 128) {
+  if (s.D <= 128) {
     const int fmax = ngroups < FUSED_DK_MAX_GROUPS ? ngroups : FUSED_DK_MAX_GROUPS;
     if (fmax > kp_slots) kp_slots = fmax;
   }
@@ -179,42 +180,26 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
 // median, 35.9 us slowest) and evenly loaded workgroups ran no faster (bench 61.0 vs 61.1 us/step; Amazon session
 // lengths 65.6 vs 66.2), with streamed windows it is proportional to their total length (d = 64, Ls = 90: 98 -> 87
 // us/step; d = 256 at the C5 shape 496 -> 471; d = 128: the kernel alone 94 -> 72 us, 104 -> 93 beside the index build
-// of the batch after next).  (TLSAN_BALANCE=0: workgroup g takes samples [16 g, 16 g + 16) as they come; 2: always)
+// of the batch after next).
 static bool balanced(const tlsan_dims* d, const tlsan_batch* b) {
-  static const int on = [] { const char* v = getenv("TLSAN_BALANCE"); return v ? atoi(v) : 1; }();
-  return on != 0 && b && b->B > 16 && b->B <= BAL_CAP && (streamed(d->Ls) || on == 2);
+  return b && b->B > 16 && b->B <= BAL_CAP && streamed(d->Ls);
 }
 #define UC_LIST_CAP (1 << 18)  // batches up to this many samples may keep a per-category sample list in the state
 // ... and do when a category sees many of the batch's samples (cursor atomics on few addresses inside the
 // fused kernel cost more than the extra launch on the index stream): more than 32 samples per category
 static inline bool uc_by_list(const tlsan_dims* d, const tlsan_batch* b) {
-  static const long per = [] { const char* v = getenv("TLSAN_UC_LIST_PER"); return v ? atol(v) : 32L; }();   // (A/B knob)
-  return b && b->B <= UC_LIST_CAP && (long)b->B > per * d->cate_count;
+  return b && b->B <= UC_LIST_CAP && (long)b->B > 32L * d->cate_count;
 }
 // many categories (the 10 k of BASELINE.json configs[4]): the category half of every item use's gradient row is written
 // into the category's own segment of Gc (FwdArgs.cseg) -- a category block of the apply pass then sums one contiguous
 // segment instead of walking the category's items for their segments (500 items per category at 5 M items, of which a
 // batch uses five: k_finalize_presum 196 us at that shape).  With few categories the cursor draws would pile up on few
 // addresses (as the u_cate uses did, uc_by_list): the item walk stays.
-// tlsan_batch_index gets no parameters: the item -> category map the state's category index was built from
-// (tlsan_state_init / _reindex / _recategorize) is remembered per state, for the category counts of CSEG
-#include <mutex>
-#include <unordered_map>
-static std::mutex g_cate_mu;
-static std::unordered_map<const void*, const int32_t*> g_cate_of_state;
-static void remember_item_cate(const void* state, const int32_t* item_cate) {
-  std::lock_guard<std::mutex> lk(g_cate_mu);
-  g_cate_of_state[state] = item_cate;
-}
-static const int32_t* item_cate_of(const void* state) {
-  std::lock_guard<std::mutex> lk(g_cate_mu);
-  auto it = g_cate_of_state.find(state);
-  return it == g_cate_of_state.end() ? nullptr : it->second;
-}
+// (the category counts of CSEG need the item -> category map: tlsan_batch_index takes it as an argument -- round 3 kept
+//  a process-global registry state -> map filled by tlsan_state_init, which a re-allocated map or a recycled state
+//  address left stale)
 static inline bool cate_seg(const tlsan_dims* d, const tlsan_batch* b) {
-  static const int on = [] { const char* v = getenv("TLSAN_CSEG"); return v ? atoi(v) : 1; }();
-  static const int min_cates = [] { const char* v = getenv("TLSAN_CSEG_MIN"); return v ? atoi(v) : TLSAN_CSEG_MIN_CATES; }();   // (experiments)
-  return on && d->cate_count >= min_cates && !uc_by_list(d, b);
+  return d->cate_count >= cseg_min_cates() && !uc_by_list(d, b);
 }
 struct St {  // persistent state
   // two index slots (a batch's destination index depends only on its ids, so it lives with the
@@ -391,6 +376,9 @@ static bool apply_wide(const ApplyArgs& A) { return A.di > 64 || A.dc > 64 || A.
 // few, large categories: several workgroups per category in the row-sum pass, about 128 uses each
 // (estimated from the batch shape; up to 64 per category), every one with its share of the items
 static void category_split(ApplyArgs& A, const tlsan_dims* d, const tlsan_batch* b) {
+  // category segments (A.cseg) sum a category as ONE contiguous segment, 16 categories per workgroup
+  // (apply_cseg_block): there is nothing to split, and the split kernels decode blocks as (category, share)
+  if (A.cseg) return;
   const long uses = ((long)b->B * (d->Ls + b->Sn + 2) + d->cate_count - 1) / d->cate_count;
   const int per = (d->item_count + d->cate_count - 1) / d->cate_count;
   if (uses > 512) {
@@ -417,8 +405,7 @@ static int launch_update_lazy(ApplyArgs A, int B, int Sn, hipStream_t hs) {
   return TLSAN_OK;
 }
 
-static int launch_apply(int mode, bool lazy, ApplyArgs A, bool with_dense, int B, int Sn, hipStream_t hs) {
-  if (lazy) lazy_blocks(A, B, Sn);
+static int launch_apply(int mode, ApplyArgs A, bool with_dense, hipStream_t hs) {
   const dim3 g1(A.nbC + A.nbI + A.nbU + (with_dense ? A.nbD : 0)), blk(256);
   const bool wide = apply_wide(A);
   const bool bf16 = A.p.table_dtype == TLSAN_TABLE_BF16;
@@ -433,10 +420,7 @@ static int launch_apply(int mode, bool lazy, ApplyArgs A, bool with_dense, int B
     }                                                                                                        \
   } while (0)
   switch (mode) {
-    case AP_UPDATE:
-      if (lazy) AP_LAUNCH(AP_UPDATE, true);
-      else AP_LAUNCH(AP_UPDATE, false);
-      break;
+    case AP_UPDATE: AP_LAUNCH(AP_UPDATE, false); break;
     case AP_GRADS: AP_LAUNCH(AP_GRADS, false); break;
     case AP_SUMSQ: AP_LAUNCH(AP_SUMSQ, false); break;
     default: AP_LAUNCH(AP_ROWNORM, false); break;
@@ -473,7 +457,6 @@ static int scan_compact_impl(const int32_t* cnt, int32_t n, int32_t* prefix, int
 // static CSR category -> items from p->item_cate (counting sort with the generic index kernels)
 static int build_cate_csr(const tlsan_dims* d, const tlsan_params* p, const St& st, hipStream_t hs) {
   const int I = d->item_count, C = d->cate_count;
-  remember_item_cate(st.hdr, p->item_cate);
   GIdxArgs gi;
   gi.dest = p->item_cate; gi.n = I; gi.nrows = C; gi.cnt = st.cate_cnt; gi.cur = st.cate_cur; gi.list = st.cate_items;
   if (I <= CSR_SMALL_MAXN && C <= CSR_SMALL_MAXROWS) {   // one launch (the sharded step rebuilds this every step)
@@ -529,7 +512,7 @@ int tlsan_state_init(const tlsan_dims* d, const tlsan_params* p, void* state, vo
   static const float one = 1.0f;  // table scale P = 1
   if (hipMemcpyAsync(&st.hdr->P, &one, sizeof(float), hipMemcpyHostToDevice, hs) != hipSuccess) return fail(TLSAN_E_LAUNCH, "init P");
   if ((rc = build_cate_csr(d, p, st, hs))) return rc;
-  if ((rc = launch_apply(AP_SUMSQ, false, A, false, 0, 0, hs))) return rc;
+  if ((rc = launch_apply(AP_SUMSQ, A, false, hs))) return rc;
   hipLaunchKernelGGL(k_reduce_double, dim3(1), dim3(256), 0, hs, st.S_part, st.nbI + st.nbU + st.nbC, st.S_total);
   CHECK_LAUNCH("k_reduce_double");
   // (per-step CHANGES of the sum travel as tagged records in S_delta, folded by the next step's k_dense_finalize)
@@ -567,7 +550,7 @@ int tlsan_state_renorm(const tlsan_dims* d, const tlsan_params* p, void* state, 
     ApplyArgs A;
     fill_apply(A, d, s, p, nullptr, nullptr, w, st, L);
     // (per-step changes still pending in S_part are already part of the stored values: overwritten)
-    if ((rc = launch_apply(AP_SUMSQ, false, A, false, 0, 0, hs))) return rc;
+    if ((rc = launch_apply(AP_SUMSQ, A, false, hs))) return rc;
     hipLaunchKernelGGL(k_reduce_double, dim3(1), dim3(256), 0, hs, st.S_part, st.nbI + st.nbU + st.nbC, st.S_total);
     CHECK_LAUNCH("k_reduce_double");
     if (hipMemsetAsync(st.S_part, 0, 8 * (size_t)(st.nbI + st.nbU + st.nbC), hs) != hipSuccess) return fail(TLSAN_E_LAUNCH, "memset S_part");
@@ -648,17 +631,17 @@ int tlsan_forward(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch*
 
 // destination index of a batch into slot k: use counts per destination row -> first sorted position
 // of every row (+ records of the used rows)
-static int build_index(const tlsan_dims* d, const tlsan_batch* b, const St& st, int k, hipStream_t hs, bool sparse_users = false) {
+static int build_index(const tlsan_dims* d, const tlsan_batch* b, const int32_t* item_cate, const St& st, int k, hipStream_t hs,
+                       bool sparse_users = false) {
   const bool cseg = cate_seg(d, b);
-  const int32_t* item_cate = cseg ? item_cate_of(st.hdr) : nullptr;
-  if (cseg && !item_cate) return fail(TLSAN_E_BADARG, "the state's item -> category map is unknown (tlsan_state_init first)");
+  if (cseg && !item_cate) return fail(TLSAN_E_BADARG, "tables with %d categories count item uses per category: item_cate is NULL", d->cate_count);
   int rc;
   CountArgs ca;
   memset(&ca, 0, sizeof(ca));
   ca.b = *b; ca.Ls = d->Ls;
   ca.n_hot = &st.hdr->n_hot[k];
   ca.cnt_item = st.cnt_item[k]; ca.cnt_user = st.cnt_user[k]; ca.cnt_uc = st.cnt_uc[k];
-  ca.item_cate = item_cate; ca.cseg = cseg ? 1 : 0;
+  ca.item_cate = cseg ? item_cate : nullptr; ca.cseg = cseg ? 1 : 0;
   ca.ncate = d->cate_count;
   ca.flag_user = st.flag_user[k];
   // the user side from a sort of the batch's ids (UsortArgs) when only the used rows are wanted and the table is large
@@ -717,7 +700,7 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   const int k = hp->index_slot;
   int rc;
   prof_mark(0, hs);
-  if (!hp->index_prebuilt && (rc = build_index(d, b, st, k, hs, presum != nullptr))) return rc;
+  if (!hp->index_prebuilt && (rc = build_index(d, b, p->item_cate, st, k, hs, presum != nullptr))) return rc;
   // --- fused forward + backward
   FwdArgs a;
   fill_fwd(a, d, s, p, b, w, L);
@@ -834,7 +817,7 @@ static int clip_dedup(const ApplyArgs& A, const tlsan_hparams* hp, const tlsan_s
                       const St& st, const tlsan_batch* b, hipStream_t hs) {
   ApplyArgs R = A;
   R.part_out = w.rownorm_part;
-  int rc = launch_apply(AP_ROWNORM, false, R, false, b->B, b->Sn, hs);
+  int rc = launch_apply(AP_ROWNORM, R, false, hs);
   if (rc) return rc;
   hipLaunchKernelGGL(k_clip_dedup, dim3(1), dim3(256), 0, hs, w.rownorm_part, st.nbI + st.nbU + st.nbC, w.sqd, w.nfin,
                      st.hdr, hp->clip, out ? out->gnorm : nullptr);
@@ -861,7 +844,7 @@ int tlsan_batch_pack(const tlsan_packed* set, const int32_t* order, int32_t lo, 
   return TLSAN_OK;
 }
 
-int tlsan_batch_index(const tlsan_dims* d, const tlsan_batch* b, void* state, int32_t slot, void* stream) {
+int tlsan_batch_index(const tlsan_dims* d, const tlsan_batch* b, const int32_t* item_cate, void* state, int32_t slot, void* stream) {
   Shape s; St st;
   int rc = shape_of(d, &s);
   if (rc) return rc;
@@ -871,7 +854,7 @@ int tlsan_batch_index(const tlsan_dims* d, const tlsan_batch* b, void* state, in
   if (slot < 0 || slot >= TLSAN_INDEX_SLOTS) return fail(TLSAN_E_BADARG, "index slot must be 0 .. %d", TLSAN_INDEX_SLOTS - 1);
   if (!state) return fail(TLSAN_E_WORKSPACE, "state is NULL");
   carve_state(d, (char*)state, &st);
-  return build_index(d, b, st, slot, (hipStream_t)stream, lazy_sgd);
+  return build_index(d, b, item_cate, st, slot, (hipStream_t)stream, lazy_sgd);
 }
 
 static int check_slot(const tlsan_params* q, const char* name) {
@@ -913,15 +896,14 @@ int tlsan_train_step_opt(const tlsan_dims* d, const tlsan_params* p, const tlsan
     if (opt->kind == TLSAN_OPT_ADAM)  // adam.py: lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)
       A.oalpha = (float)((double)hp->lr * sqrt(1.0 - pow((double)opt->beta2, opt->step)) / (1.0 - pow((double)opt->beta1, opt->step)));
   }
-  static const int split = [] { const char* v = getenv("TLSAN_APPLY_SPLIT"); return v ? atoi(v) : 1; }();
-  if (hp->l2_mode == TLSAN_L2_LAZY && split) {
+  if (hp->l2_mode == TLSAN_L2_LAZY) {   // row sums beside the finalize, then the short elementwise update
     category_split(A, d, b);
     if ((rc = run_backward(d, s, p, b, hp, true, out, w, st, L, hs, &A))) return rc;
     if ((rc = launch_update_lazy(A, b->B, b->Sn, hs))) return rc;
   } else {
     if ((rc = run_backward(d, s, p, b, hp, true, out, w, st, L, hs))) return rc;
     if (hp->norm_mode == TLSAN_NORM_DEDUP && (rc = clip_dedup(A, hp, out, w, st, b, hs))) return rc;
-    if ((rc = launch_apply(AP_UPDATE, hp->l2_mode == TLSAN_L2_LAZY, A, true, b->B, b->Sn, hs))) return rc;
+    if ((rc = launch_apply(AP_UPDATE, A, true, hs))) return rc;
   }
   prof_mark(5, hs);
   prof_step_done();
@@ -965,7 +947,7 @@ int tlsan_grads(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch* b
   }
   if ((rc = run_backward(d, s, p, b, hp, false, out, w, st, L, hs))) return rc;
   if (hp->norm_mode == TLSAN_NORM_DEDUP && (rc = clip_dedup(A, hp, out, w, st, b, hs))) return rc;
-  if ((rc = launch_apply(AP_GRADS, false, A, true, b->B, b->Sn, hs))) return rc;
+  if ((rc = launch_apply(AP_GRADS, A, true, hs))) return rc;
   prof_mark(5, hs);
   prof_step_done();
   return TLSAN_OK;

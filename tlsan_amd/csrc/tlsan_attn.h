@@ -391,9 +391,6 @@ __device__ __forceinline__ void online_step(f32x4 (&mx)[NB], f32x4 (&Z)[NB], f32
     }
 }
 
-#ifndef TLSAN_EXP_LCH
-#define TLSAN_EXP_LCH 1
-#endif
 // LSTREAM: the long block is streamed like the short one (any Ls <= TLSAN_LS_CAP); otherwise its
 // Ls <= TLSAN_LS_MAX positions stay in registers between forward and backward.
 // CSEG (FwdArgs.cseg, tables with thousands of categories): the category half of every item use's gradient row goes to
@@ -409,27 +406,15 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   constexpr int LS = LSTREAM ? 1 : TLSAN_LS_MAX;             // positions held in registers
   constexpr int LSC = LSTREAM ? TLSAN_LS_CAP : TLSAN_LS_MAX;  // position slots in the LDS tables
   constexpr int LSTR = G::LSTR, TSTR = G::TSTR, CW = G::CW;
-  constexpr int TB = G::TBUF;                 // floats of one transpose buffer
-  constexpr int NBUF = G::NBUF;               // 2: dW of position p overlaps position p+1
   constexpr int WB = 2 * DH * DH + 2 * DH;    // floats of one attention block's weights
   // per-sample position slots: long, session (the batch's padded session length, rounded up to 4), 3 singles
   // (CSEG keeps two such arrays and sizes them by the batch; otherwise the slot count is a compile-time constant)
 
-#ifndef TLSAN_EXP_FUSE_CONST
-#define TLSAN_EXP_FUSE_CONST 0      // (experiment: 1 = a.fuse_dk taken as true at compile time, only valid for launches that fuse: -0.2 us/step, not worth a variant)
-#endif
-#if TLSAN_EXP_FUSE_CONST
-#define FUSE_RT true
-#else
-#define FUSE_RT (a.fuse_dk != 0)
-#endif
+  const bool FUSE_RT = a.fuse_dk != 0;   // (this launch forms the dK partials itself; as a compile-time constant: -0.2 us/step, not worth a variant)
   // FLAT (streamed windows): the window positions of the workgroup's 16 samples form ONE list that is dealt out evenly
   // to its 16 column groups (a wavefront's lanes that share a sample slot) -- see P1.  Its entries, the per-sample
   // softmax statistics and the long-term vectors live in the LDS, where any group can reach them.
-#ifndef TLSAN_EXP_FLAT
-#define TLSAN_EXP_FLAT 1
-#endif
-  constexpr bool FLAT = TLSAN_EXP_FLAT != 0 && LSTREAM && !DROP;
+  constexpr bool FLAT = LSTREAM && !DROP;   // (dropout keeps a window per column group: its pattern is indexed by (sample, position))
   constexpr int NF = FLAT ? NSB * TLSAN_LS_CAP : 0;      // entries of the flat list (every window at the cap)
   // NB > 1 (d = 256): the LDS has no room for the per-sample statistics and long-term vectors beside the list -- they
   // go through global memory (FwdArgs.gStat, gLong: 32 KB per workgroup, L2-resident), the attention weights are
@@ -467,18 +452,11 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   float* sFht = sH;
   float* sFuh = sH + NF;
   constexpr bool KEEP_A = G::KEEP_A && TRAIN && !LSTREAM;
-#ifndef TLSAN_EXP_PIPE5
-#define TLSAN_EXP_PIPE5 1
-#endif
-  constexpr bool PIPE5 = TLSAN_EXP_PIPE5 != 0 && KEEP_A && !DROP && NBUF == 1;   // long backward as a skewed software pipeline (see P5)
+  constexpr bool PIPE5 = KEEP_A && !DROP;       // long backward as a skewed software pipeline (see P5)
   constexpr bool LPF = NB == 1;                 // streamed windows: the next position's row is prefetched
-#ifndef TLSAN_EXP_SPIPE
-#define TLSAN_EXP_SPIPE 1
-#endif
-  constexpr bool SPIPE = TLSAN_EXP_SPIPE != 0 && LSTREAM && TRAIN && NB == 1 && !DROP && TLSAN_EXP_LCH != 0;   // streamed long backward as a software pipeline (see P5)
   // ... and the next chunk's ids / weights / categories are loaded a chunk ahead (d = 256 in fp32 has no registers for
   // either: 568 -> 618 us at Ls = 90 with this one; with bf16 matrix operands it has: 328 -> 321 us)
-  constexpr bool LCH = TLSAN_EXP_LCH != 0 && (NB == 1 || MM == TLSAN_MATRIX_BF16);
+  constexpr bool LCH = NB == 1 || MM == TLSAN_MATRIX_BF16;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int q = lane >> 4, r = lane & 15;
   const int s_loc = r / CPS, col = r % CPS;
@@ -515,41 +493,6 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   const float *w1W1 = wb1, *w1b1 = wb1 + DH * DH, *w1W2 = w1b1 + DH, *w1b2 = w1W2 + DH * DH;
   const float *w2W1 = wb2, *w2b1 = w2W1 + DH * DH, *w2W2 = w2b1 + DH, *w2b2 = w2W2 + DH * DH;
 
-#ifndef TLSAN_EXP_PRIO
-#define TLSAN_EXP_PRIO 0
-#endif
-#ifndef TLSAN_EXP_STAGGER
-#define TLSAN_EXP_STAGGER 0
-#endif
-#ifndef TLSAN_EXP_FAKECAT
-#define TLSAN_EXP_FAKECAT 0
-#endif
-#ifndef TLSAN_EXP_SESS_EARLY
-#define TLSAN_EXP_SESS_EARLY 0
-#endif
-#ifndef TLSAN_EXP_FOLD
-#define TLSAN_EXP_FOLD 1
-#endif
-#ifndef TLSAN_EXP_HELP
-#define TLSAN_EXP_HELP 1
-#endif
-#ifndef TLSAN_EXP_BALANCE
-#define TLSAN_EXP_BALANCE 1
-#endif
-#ifndef TLSAN_EXP_LHELP
-#define TLSAN_EXP_LHELP 1   // streamed windows: a long window is shared by the wavefront's two halves (see P1)
-#endif
-#ifndef TLSAN_EXP_FLIP
-#define TLSAN_EXP_FLIP 0
-#endif
-#ifndef TLSAN_EXP_ABL
-#define TLSAN_EXP_ABL 0   // timing-only ablations (wrong results): 1 no row stores in P5, 2 no position read, 4 no dW products in P5
-#endif
-  if constexpr (TLSAN_EXP_PRIO != 0 && NW == 8) {
-    // the second-dispatched half of an 8-wave workgroup loses the VALU arbitration to its SIMD partner on every
-    // segment (MI355X_MICROARCH.md, two waves per SIMD, item 4): one static priority raise, no flips
-    if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(TLSAN_EXP_PRIO);
-  }
   // diagnostic cycle stamps: only in a -DTLSAN_STAMPS=1 build (scripts/stamps.py loads it through TLSAN_LIB_PATH;
   // the production kernel carries no stamp code).  Kept in the LDS while the pass runs -- a global store per stamp
   // would sit in front of every later vmcnt(0) wait and distort what it measures -- and copied out at the end.
@@ -575,7 +518,6 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #if TLSAN_STAMPS
     if (a.stamps != nullptr && lane == 0) sStamp[28] = __builtin_amdgcn_s_memrealtime();   // (100 MHz, one clock for the whole device)
 #endif
-#if TLSAN_EXP_BALANCE
     // Which sample a slot of the pass takes.  The 16 samples are ranked by cost (session length first, then window
     // length) and dealt out in that order: the two waves of a SIMD do not run alike -- the first-dispatched half of
     // the workgroup wins the issue arbitration and runs its phases ~30 % faster (MI355X_MICROARCH.md, two waves per
@@ -589,8 +531,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       const int cand = a.perm != nullptr ? a.perm[g * NSB + r] : g * NSB + r;   // (the batch's samples ranked and dealt out: BalArgs)
       const bool cv = cand < B;
       const int cl = cv ? min(a.b.sl[cand], Ls) : 0, cs = cv ? min(a.b.sl_new[cand], Sn) : 0;
-      // (streamed windows: the window length decides -- up to 90 positions against a session's few -- and the longest
-      //  is paired with the shortest: the short one's half of the wavefront then helps with the long one, LHELP)
+      // (a window per column group -- streamed windows with dropout -- : the window length decides, up to 90 positions
+      //  against a session's few)
       const int key = cv ? ((((LSTREAM && !FLAT) ? ((cl << 12) | (cs << 4)) : ((cs << 12) | (cl << 4))) | (15 - r)) + 1) : -r;   // distinct; larger = heavier
       int rank = 0;
 #pragma unroll
@@ -598,7 +540,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       int* sPerm = (int*)T;                       // (the wave's own scratch: free until P3)
       // (windows held in registers, two samples per wavefront: the wavefront with the k-th longest session also takes
       // the k-th shortest -- its lanes then share the long one, see HELP in P3)
-      const int slot = (TLSAN_EXP_FOLD != 0 && SPW == 2 && (!LSTREAM || TLSAN_EXP_LHELP != 0 || FLAT) && !DROP) ? (rank < 8 ? 2 * rank : 2 * (15 - rank) + 1) : rank;
+      const int slot = (SPW == 2 && !DROP) ? (rank < 8 ? 2 * rank : 2 * (15 - rank) + 1) : rank;
       if (q == 0) sPerm[slot] = r;
       if (FLAT && q == 0) sPerm[16 + slot] = cl;
       wave_lds_fence();
@@ -614,9 +556,6 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       }
       wave_lds_fence();
     }
-#else
-    const int bidx = g * NSB + srow;
-#endif
     const bool vs = bidx < B;
     DropCtx dc;
     dc.seed = a.drop_seed; dc.thr = a.drop_thr; dc.inv = a.drop_inv; dc.sbase = 2u * ((uint32_t)bidx + a.drop_sample0);
@@ -637,29 +576,6 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     int upos = 0;                                // (window in registers: the cursor draw of this lane's use slot)
     int ucpos = 0, cposv = 0, scpos0 = 0;        // (CSEG: the category-cursor draws of the same uses)
     const int pmax1 = wave_max_samples<CPS>(n_l);
-    // ---- LHELP (streamed windows): a long window is shared by the wavefront's two halves, as a long session is in the
-    // short block (HELP, P3).  The launch ends with its slowest workgroup, and with streamed windows that is the one
-    // that holds one of the batch's few 90-entry windows (1 % of the synthetic histories, mean length 14): its wavefront
-    // walks 90 positions with half of its lanes idle behind a short partner.  From the (even) position g_lo2 where the
-    // shorter window has ended, the helping half takes the odd positions of the longer one: MFMA columns = (position
-    // 2j | position 2j+1) x 8 heads of ONE sample; the helper keeps a partial online-softmax state that is merged with
-    // one row_ror:8 step after the loop, and in the backward it reads the sample's statistics and output gradient
-    // across the row once, at the switch.  Steps of the wavefront: g_lo2 + ceil((g_hi - g_lo2) / 2) instead of g_hi.
-    constexpr bool LHELP = TLSAN_EXP_LHELP != 0 && LSTREAM && SPW == 2 && !DROP;
-    int g_lo2 = 0, g_hi = 0, g_L = 0;
-    bool g_on = false;
-    if constexpr (LHELP) {
-      const int nl0 = __builtin_amdgcn_readlane(n_l, 0), nl1 = __builtin_amdgcn_readlane(n_l, CPS);
-      g_lo2 = (min(nl0, nl1) + 1) & ~1;      // (even: the pairs (2j, 2j+1) then never straddle a chunk of ids)
-      g_hi = max(nl0, nl1);
-      g_L = nl0 >= nl1 ? 0 : 1;
-      g_on = g_hi - g_lo2 >= 2;
-    }
-    const bool ghelper = LHELP && g_on && s_loc != g_L;
-    // position cursor p (wave-uniform; even once shared): shared step?  (macros, not lambdas: a closure that captures
-    // another closure made hipcc keep both on the stack, and every call re-read g_lo2 / g_on from scratch memory)
-#define L_SHARED(p) (LHELP && g_on && (p) >= g_lo2)
-#define L_ADV(p) (L_SHARED(p) ? 2 : 1)
     // ---- streamed long block (LSTREAM): ids, scales and positions live one per lane of the sample
     // (lane kk = entry base + kk of the current chunk) and are broadcast with cross-lane reads
     constexpr int NLc = 4 * CPS;
@@ -685,24 +601,12 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     };
     auto stage_lchunk_cats = [&]() { nlct = a.p.item_cate[nlid]; };
     auto take_lchunk = [&]() { lid = nlid; lct = nlct; lht = nlht; lut = nlut; };
-    // entry of the loaded chunk for position cursor p: the lane's own sample's entry p, or -- shared step -- the longer
-    // window's entry p (its own half) / p + 1 (the helping half)
+    // entry p of the lane's own sample, from the loaded chunk
     auto pick_lentry = [&](int p, int& it, int& ct, float& uth) {
       const int k = p % NLc;
-      const int ss = L_SHARED(p) ? g_L : s_loc;
-      it = sample_pick<CPS>(lid, k / CPS, k % CPS, ss);
-      ct = sample_pick<CPS>(lct, k / CPS, k % CPS, ss);
-      uth = sample_pick<CPS>(lut, k / CPS, k % CPS, ss) * sample_pick<CPS>(lht, k / CPS, k % CPS, ss);
-      if constexpr (LHELP) {
-        if (L_SHARED(p)) {   // (wave-uniform)
-          const int k1 = k + 1;    // (p even, NLc even: the same chunk)
-          const int it1 = sample_pick<CPS>(lid, k1 / CPS, k1 % CPS, ss), ct1 = sample_pick<CPS>(lct, k1 / CPS, k1 % CPS, ss);
-          const float uth1 = sample_pick<CPS>(lut, k1 / CPS, k1 % CPS, ss) * sample_pick<CPS>(lht, k1 / CPS, k1 % CPS, ss);
-          it = ghelper ? it1 : it;
-          ct = ghelper ? ct1 : ct;
-          uth = ghelper ? uth1 : uth;
-        }
-      }
+      it = sample_pick<CPS>(lid, k / CPS, k % CPS, s_loc);
+      ct = sample_pick<CPS>(lct, k / CPS, k % CPS, s_loc);
+      uth = sample_pick<CPS>(lut, k / CPS, k % CPS, s_loc) * sample_pick<CPS>(lht, k / CPS, k % CPS, s_loc);
     };
     auto fetch_lrow = [&](int p, f32x4 (&xr)[NB], float& scx, float& sce) {  // position p of the loaded chunk
       int it, ct;
@@ -727,7 +631,6 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     // (lane k = q*CPS + col holds entry k of the current chunk of NL entries), then broadcast
     // with a cross-lane read: no dependent index loads inside the position loops.
     constexpr int NL = 4 * CPS;
-    constexpr bool SESS_EARLY = TLSAN_EXP_SESS_EARLY != 0 && !LSTREAM;
     const int kk = q * CPS + col;
     int sid = 0, scat = 0;
     auto load_chunk = [&](int base) {
@@ -765,7 +668,6 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     xnext.v = false;
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) xnext.r[kb] = srow4{};
-    const int pmax2e = wave_max_samples<CPS>(n_s + 1);
     int ucat = 0, ct_i = 0;   // category of the user's row / of the candidate: fetched with the window's ids
     if constexpr (FLAT) {
       // ---- FLAT: streamed windows as ONE work list per workgroup.  Window lengths are heavy-tailed (synthetic
@@ -881,14 +783,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) xv[kb] = tbl_cvt<DT>(row[kb]) * scx;
       };
-#ifndef TLSAN_EXP_F1_ROWS
-#define TLSAN_EXP_F1_ROWS 4   // rows in flight in the list's forward pass (d <= 128)
-#endif
-#ifndef TLSAN_EXP_F1_PF
-#define TLSAN_EXP_F1_PF 0     // (d = 256: 1 = two rows in flight in the list's forward pass as at d <= 128; no faster there -- the
-                              //  kernel is bound by its matrix work and its spilled registers: C5 shape 439 vs 430 us/step with both off)
-#endif
-      if (FTn > 0 && NB > 1 && TLSAN_EXP_F1_PF == 0) {
+      // (d = 256: one row at a time -- two in flight as at d <= 128 were no faster there, the kernel is bound by its
+      //  matrix work and its spilled registers: C5 shape 439 vs 430 us/step)
+      if (FTn > 0 && NB > 1) {
         for (int k = 0; k < FTn; ++k) {
           Ent e;
           raw4 rw[NB];
@@ -903,7 +800,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         // NPF rows in flight, each fetched NPF entries ahead of its use (the item table does not fit an XCD's L2: a
         // gather is ~2 k cycles away, an entry's own work a few hundred); the entry after that is read from the list
         // meanwhile.  No stores in this loop: the compiler's own vmcnt counting keeps the later rows in flight.
-        constexpr int NPF = NB == 1 ? TLSAN_EXP_F1_ROWS : 2;
+        constexpr int NPF = 4;
         Ent eU[NPF], nU[NPF];
         raw4 rU[NPF][NB];
 #pragma unroll
@@ -1034,34 +931,21 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         raw4 xn[NB];
         float scxn = 0.0f, scen = 0.0f;
         if constexpr (LPF) fetch_lrow_raw(base, xn, scxn, scen);
-        for (int p = base; p < pend; p += L_ADV(p)) {
-          if constexpr (LHELP) {
-            if (g_on && p == g_lo2 && ghelper) {   // the helping half parks its own (finished) state and starts a partial one
-#pragma unroll
-              for (int kb = 0; kb < NB; ++kb) {
-                *(f32x4*)(T + ((0 * NB + kb) * 64 + lane) * 4) = mx1[kb];
-                *(f32x4*)(T + ((1 * NB + kb) * 64 + lane) * 4) = Zl[kb];
-                *(f32x4*)(T + ((2 * NB + kb) * 64 + lane) * 4) = long4[kb];
-                mx1[kb] = (f32x4)(TLSAN_NEG);
-                Zl[kb] = (f32x4)(0.0f);
-                long4[kb] = (f32x4)(0.0f);
-              }
-            }
-          }
+        for (int p = base; p < pend; ++p) {
           f32x4 xv[NB], z[NB], m2[NB];
           float scx = scxn, sce = scen;
           (void)sce;
           if constexpr (LPF) {
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) xv[kb] = tbl_cvt<DT>(xn[kb]);
-            if (p + L_ADV(p) < pend) fetch_lrow_raw(p + L_ADV(p), xn, scxn, scen);
+            if (p + 1 < pend) fetch_lrow_raw(p + 1, xn, scxn, scen);
           } else {
             fetch_lrow(p, xv, scx, sce);
           }
           if constexpr (LCH) {
             if (p == base + 2 && base + NLc < pmax1) stage_lchunk_cats();   // (the next chunk's ids are here by now)
           }
-          const bool vp = L_SHARED(p) ? p + (ghelper ? 1 : 0) < g_hi : p < n_l;
+          const bool vp = p < n_l;
 #pragma unroll
           for (int kb = 0; kb < NB; ++kb) xv[kb] = vp ? xv[kb] * scx : (f32x4)(0.0f);
           if constexpr (DROP) {
@@ -1082,28 +966,6 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           }
           map_apply<NB, MM>(FT2, b2, z, m2);
           if (vp) online_step<NB>(mx1, Zl, long4, m2, xv);
-        }
-      }
-      if constexpr (LHELP) {
-        if (g_on) {   // merge the helper's partial state into the sample's, give the helper its own state back
-          wave_lds_fence();
-#pragma unroll
-          for (int kb = 0; kb < NB; ++kb) {
-            const f32x4 own_mx = *(const f32x4*)(T + ((0 * NB + kb) * 64 + lane) * 4);
-            const f32x4 own_Z = *(const f32x4*)(T + ((1 * NB + kb) * 64 + lane) * 4);
-            const f32x4 own_N = *(const f32x4*)(T + ((2 * NB + kb) * 64 + lane) * 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const float o_mx = dpp_f32<TLSAN_DPP_ROR(8)>(mx1[kb][i]), o_Z = dpp_f32<TLSAN_DPP_ROR(8)>(Zl[kb][i]);
-              const float o_N = dpp_f32<TLSAN_DPP_ROR(8)>(long4[kb][i]);
-              const float mn = fmaxf(mx1[kb][i], o_mx);
-              const float sa = __expf(mx1[kb][i] - mn), sb = __expf(o_mx - mn);
-              mx1[kb][i] = ghelper ? own_mx[i] : mn;
-              Zl[kb][i] = ghelper ? own_Z[i] : Zl[kb][i] * sa + o_Z * sb;
-              long4[kb][i] = ghelper ? own_N[i] : long4[kb][i] * sa + o_N * sb;
-            }
-          }
-          wave_lds_fence();
         }
       }
 #pragma unroll
@@ -1137,22 +999,16 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       const float ut_k = a.p.usert_emb[(size_t)uid * a.p.ld_usert + kc];
       ucat = a.b.u_cate[bb];
       ct_i = a.p.item_cate[it_i];   // (with the stage that already waits for the sample's scalars: no trip of its own later)
-      // (SESS_EARLY) the short block's first chunk of ids, their categories, the cursor draws and the first session
-      // row depend on the ids only: each of their three dependent loads rides with the long block's stage of the
-      // same depth, instead of three round trips of their own at the start of P3
-      if constexpr (SESS_EARLY) sid = (Sn > 0) ? a.b.hist_i_new[(size_t)bb * Sn + min(kk, max(Sn - 1, 0))] : 0;
+      // (round 2 measured the short block's first ids / categories / cursor draws / first row riding with these stages
+      //  instead of three trips of their own at the start of P3: no gain, profiles/r02_ab)
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (SESS_EARLY) scat = a.p.item_cate[sid];
-      const int ct_k = TLSAN_EXP_FAKECAT ? (id_k & 511) : a.p.item_cate[id_k];
+      const int ct_k = a.p.item_cate[id_k];
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int p = 0; p < LS; ++p) {
         const int it = sample_pick<CPS>(id_k, p / CPS, p % CPS, s_loc), ct = sample_pick<CPS>(ct_k, p / CPS, p % CPS, s_loc);
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) e1[p][kb] = gather_item4c<DT>(a, it, ct, chb[kb]);
-      }
-      if constexpr (SESS_EARLY) {
-        if (pmax2e > 1) fetch_row(0, xnext);
       }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (TRAIN) {
@@ -1162,7 +1018,6 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         const bool act = vs && (is_long ? kku < n_l : (kku < LS + 2 || (kku == LS + 2 && a.uc_by_sample == 0)));
         upos = act ? atomicAdd(cur + id, 1) : (kku == LS + 2 ? bidx : 0);   // (u_cate rows in sample order: position = sample)
         if constexpr (CSEG) ucpos = (act && kku <= LS) ? atomicAdd(&a.cur_uc[is_long ? ct_k : ct_i], 1) : 0;
-        if constexpr (SESS_EARLY) spos0 = (vs && kk < n_s) ? atomicAdd(&a.cur_item[sid], 1) : 0;
       }
       __builtin_amdgcn_sched_barrier(0);
       // padded slots: scale 0 (model.py:384 gives them weight exactly 0; their clamped rows are finite table rows),
@@ -1276,14 +1131,12 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     load_frag_T<DH, NB, MM>(w2W2, q, r, FT2);
     load_bias<DH, NB>(w2b1, q, b1);
     load_bias<DH, NB>(w2b2, q, b2);
-    if constexpr (!SESS_EARLY) {
-      load_chunk(0);
-      if constexpr (TRAIN) {
-        spos0 = (vs && kk < n_s) ? atomicAdd(&a.cur_item[sid], 1) : 0;
-        if constexpr (CSEG) scpos0 = (vs && kk < n_s) ? atomicAdd(&a.cur_uc[scat], 1) : 0;
-      }
-      if (pmax2 > 1) fetch_row(0, xnext);
+    load_chunk(0);
+    if constexpr (TRAIN) {
+      spos0 = (vs && kk < n_s) ? atomicAdd(&a.cur_item[sid], 1) : 0;
+      if constexpr (CSEG) scpos0 = (vs && kk < n_s) ? atomicAdd(&a.cur_uc[scat], 1) : 0;
     }
+    if (pmax2 > 1) fetch_row(0, xnext);
     TLSAN_STAMP(24);
     f32x4 mx[NB], Zs[NB], short4[NB];
     {
@@ -1321,7 +1174,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     // and the two are merged with one cross-lane step (lane r <-> r ^ 8: row_ror:8) -- forward here, and in the
     // backward the helper reads the sample's statistics / output gradient the same way.  Session steps of the
     // wavefront: lo + ceil((hi - lo) / 2) instead of hi.
-    constexpr bool HELP = TLSAN_EXP_HELP != 0 && SPW == 2 && !DROP;
+    constexpr bool HELP = SPW == 2 && !DROP;
     int h_lo = 0, h_hi = 0, h_L = 0;
     bool h_on = false;
     if constexpr (HELP) {
@@ -1605,10 +1458,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
               for (int i = 0; i < 4; ++i) av[kb][i] = vt ? __expf(m2[kb][i] - mx[kb][i]) * Zs[kb][i] : 0.0f;
             }
           }
-          float* Tp = T + (NBUF > 1 ? (p & 1) * TB : 0);
-          bwd_compute<NB, TSTR, DROP, MM>(FN2, FN1, xv, z1, av, outs, douts, Tp, q, r, acc.db1, acc.db2, dx, k1, k2);
-          if (NBUF == 1) bwd_dw<NB, TSTR, MM>(Tp, q, r, acc.dW1, acc.dW2);
-          else if (p > 0) bwd_dw<NB, TSTR, MM>(T + ((p - 1) & 1) * TB, q, r, acc.dW1, acc.dW2);
+          bwd_compute<NB, TSTR, DROP, MM>(FN2, FN1, xv, z1, av, outs, douts, T, q, r, acc.db1, acc.db2, dx, k1, k2);
+          bwd_dw<NB, TSTR, MM>(T, q, r, acc.dW1, acc.dW2);
           if (P3TAKE && p < nsess) {   // (wave-uniform)
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) asm volatile("" : "+v"(xn2.r[kb]));   // (the fetched registers are read HERE)
@@ -1635,7 +1486,6 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             }
           }
         }
-        if (NBUF > 1) bwd_dw<NB, TSTR, MM>(T + (nsess & 1) * TB, q, r, acc.dW1, acc.dW2);
         TLSAN_STAMP(27);
         if constexpr (G::SPLIT) {  // two halves through the (smaller) staging area
           stage_part<NB, CPS, true, 0>(acc, dk0, T, lane);
@@ -1732,11 +1582,6 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       __syncthreads();
       TLSAN_STAMP(9);
       // ---------------------------------------------------------------- P5: long backward
-      if constexpr (TLSAN_EXP_STAGGER != 0 && NW == 8) {
-        // SIMD partners (waves w and w + 4) leave the barrier in lockstep and would want the matrix pipe, the LDS and
-        // the VALU at the same moments of every position: start the younger half a fraction of a position later
-        if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_sleep(TLSAN_EXP_STAGGER);
-      }
       {
         f32x4 dlong[NB], dummy[NB];
 #pragma unroll
@@ -1748,8 +1593,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         load_bias<DH, NB>(w1b2, q, b2);
         load_frag_N<DH, NB, MM>(w1W1, q, r, FN1);
         load_frag_N<DH, NB, MM>(w1W2, q, r, FN2);
-        // ---- pieces of the software-pipelined loops below (PIPE5: window in registers, SPIPE: streamed window)
-        static_assert(!(PIPE5 || SPIPE) || NB == 1, "one 16-channel block per column");
+        // ---- pieces of the software-pipelined loops below (PIPE5: window in registers; FLAT: the streamed windows' list)
+        static_assert(!PIPE5 || NB == 1, "one 16-channel block per column");
         f32x4 ta[NB], tb[NB];   // transposed tiles of the previous position: (x, dz1), then (m1, dm2)
         auto read_tiles = [&](int t0, int t1) {
 #pragma unroll
@@ -1832,20 +1677,11 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
               loc[kb] = lon[kb];
             }
           };
-#ifndef TLSAN_EXP_FG_PF
-#define TLSAN_EXP_FG_PF 0     // (1: the next entry's row / statistics in flight over the iteration, taken over before the stores)
-#endif
-          if (TLSAN_EXP_FG_PF) {
-            fetch(i0);
-            take(i0);
-          }
+          // (the next entry's row / statistics in flight over the iteration, taken over before the stores: measured, no
+          //  faster at d = 256)
           for (int k = 0; k < FTn; ++k) {       // wave-uniform
-            if (TLSAN_EXP_FG_PF) {
-              fetch(i0 + k + 1);
-            } else {
-              fetch(i0 + k);
-              take(i0 + k);
-            }
+            fetch(i0 + k);
+            take(i0 + k);
             const int ic = min(i0 + k, ilast);
             const int sc = stc >> 8, tcur = stc & 255;
             const int posp = sFpos[ic], cposp = CSEG ? sFcpos[ic] : 0;
@@ -1877,13 +1713,6 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             const float ds = sample_sum<CPS>(dsp) * P;  // d loss / d scale of this entry
             const bool vst = vc;
             const float uhs = uhc;
-            // the fetched entry is taken over BEFORE the stores (a wait for a load that is older than a store waits for
-            // the store as well: see SPIPE)
-            if (TLSAN_EXP_FG_PF) {
-#pragma unroll
-              for (int kb = 0; kb < NB; ++kb) asm volatile("" : "+v"(en[kb]), "+v"(mxn[kb]), "+v"(izn[kb]), "+v"(lon[kb]));
-              take(i0 + k + 1);
-            }
             __builtin_amdgcn_sched_barrier(0);
             if (vst) {
               if (lead) a.Gb[posp] = 0.0f;
@@ -1903,13 +1732,22 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           }
           }
           } else if constexpr (FLAT) {
-          // ---- FLAT (see P1): this column group's share of the workgroup's list, through the three-stage software
-          // pipeline described under SPIPE below -- an iteration runs the FORWARD recomputation of entry k, the BACKWARD
-          // maps of entry k - 1 and the dW products of entry k - 2, with the row of entry k + 1 in flight.  An entry's
-          // sample can be any of the workgroup's: its statistics, output and output gradient come from the LDS (read at
-          // the top of the iteration that runs its forward stage; the backward stage's pair rides along a stage).
+          // ---- FLAT (see P1): this column group's share of the workgroup's list, through a software pipeline three
+          // stages deep -- an iteration runs the FORWARD recomputation of entry k (z1 = x W1 + b1, m2 = relu(z1) W2 + b2,
+          // a = exp(m2 - max) / sum), the BACKWARD maps of entry k - 1 and the two dW products of entry k - 2, whose
+          // transposed operands it reads back from the LDS first, with the rows of entries k + 1 and k + 2 in flight.
+          // MFMA groups of an iteration, each one's inputs made at least a group earlier:
+          //   z1(k) . dm1(k-1) . m2(k) . dW1(k-2) . dxm(k-1) . dW2(k-2)
+          // -- 24 MFMAs back to back with the vector code, the exponentials, the LDS traffic and the row stores in their
+          // shadow, where a plain loop runs six dependent map / product chains and an LDS round trip per entry one after
+          // the other.  First iteration: no backward entry yet (zero operands, nothing stored, the tiles zeroed below);
+          // last: the forward entry past the share (a zero row).  An entry's sample can be any of the workgroup's: its
+          // statistics, output and output gradient come from the LDS (read at the top of the iteration that runs its
+          // forward stage; the backward stage's pair rides along a stage).
           // Vector-memory operations of an iteration: the row fetch at its top, the row stores at its end, the fetched
-          // row taken over just before those stores (why: see SPIPE).
+          // row taken over just BEFORE those stores: vmcnt retires in order and the stores sit in branches the compiler
+          // cannot count, so any wait for a load that is older than a store waits for the store as well -- taken over at
+          // the top of its own iteration, every row waited out the previous iteration's stores, a full round trip.
           const int wofs = r * TSTR + 4 * q;
 #pragma unroll
           for (int t = 0; t < 4; ++t) *(f32x4*)(T + t * 16 * TSTR + wofs) = (f32x4)(0.0f);
@@ -2056,7 +1894,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             stB = stF;
             posuB = posuF;
 #pragma unroll
-            for (int kb = 0; kb < NB; ++kb) asm volatile("" : "+v"(Et.r[kb]));   // (the fetched registers are read HERE, see SPIPE)
+            for (int kb = 0; kb < NB; ++kb) asm volatile("" : "+v"(Et.r[kb]));   // (the fetched registers are read HERE: left alone the compiler sinks the take-over below the stores' branches)
             take_row(i0 + k + 1, Et);
             __builtin_amdgcn_sched_barrier(0);
             if (stv) {
@@ -2086,233 +1924,6 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           read_tiles(2, 3);
           dw_prod(acc.dW2);
           }
-          } else if constexpr (SPIPE) {
-          // ---- software pipeline over the positions of the streamed window, three stages deep: an iteration runs the
-          // FORWARD recomputation of position pF (z1 = x W1 + b1, m2 = relu(z1) W2 + b2, a = exp(m2 - max) / sum), the
-          // BACKWARD maps of the position before it (pB) and the two dW products of the one before that, whose
-          // transposed operands it reads back from the LDS first.  MFMA groups of an iteration, each one's inputs made at
-          // least a group earlier:  z1(pF) . dm1(pB) . m2(pF) . dW1 . dxm(pB) . dW2  -- 24 MFMAs back to back with the vector
-          // code, the exponentials, the LDS traffic and the row stores in their shadow, where the plain loop below runs
-          // six dependent map / product chains and an LDS round trip per position one after the other.  The row of the
-          // position after pF is in flight meanwhile.  First iteration: no pB yet (zero operands, nothing stored, the tiles
-          // zeroed below); last: pF past the window (a zero row).  LHELP's switch (P1): the forward side's statistics
-          // (max, 1/sum) and the backward side's (output, output gradient) change hands an iteration apart.
-          const int wofs = r * TSTR + 4 * q;
-#pragma unroll
-          for (int t = 0; t < 4; ++t) *(f32x4*)(T + t * 16 * TSTR + wofs) = (f32x4)(0.0f);
-          // The whole window's ids, weights and categories, one entry per lane and chunk of NLc, are loaded HERE: inside
-          // the loop the only vector-memory operations are one row fetch at the top of an iteration and the row stores
-          // at its end, with the fetched row taken over just before those stores.  vmcnt retires in order and the
-          // stores sit in branches, so any wait for a load that is older than a store waits for the store as well:
-          // with the chunk loads (and their register hand-over) inside the loop every iteration began by waiting out
-          // the previous one's stores, a full round trip to memory.
-          constexpr int NCH = (TLSAN_LS_CAP + NLc - 1) / NLc;
-          int lidA[NCH], lctA[NCH];
-          float luhA[NCH];                      // usert_emb[u][t] * hist_t[t]
-#pragma unroll
-          for (int c = 0; c < NCH; ++c) {
-            const int t = min(c * NLc + kkl, Ls - 1);
-            lidA[c] = a.b.hist_i[(size_t)bb * Ls + t];
-            luhA[c] = a.b.hist_t[(size_t)bb * Ls + t] * a.p.usert_emb[(size_t)uid * a.p.ld_usert + t];
-          }
-#pragma unroll
-          for (int c = 0; c < NCH; ++c) lctA[c] = a.p.item_cate[lidA[c]];
-          raw4 en[NB];
-          float scxn = 0.0f, scen = 0.0f;
-          // entry p of the window (shared step: the longer window's entry p / p + 1) -> the row's gather goes out
-          auto fetch_entry = [&](int p) {
-            const int c = p / NLc, k = p % NLc;   // (wave-uniform)
-            int idc = lidA[0], ctc = lctA[0];
-            float uhc = luhA[0];
-#pragma unroll
-            for (int j = 1; j < NCH; ++j) {
-              idc = c == j ? lidA[j] : idc;
-              ctc = c == j ? lctA[j] : ctc;
-              uhc = c == j ? luhA[j] : uhc;
-            }
-            const int ss = L_SHARED(p) ? g_L : s_loc;
-            int it = sample_pick<CPS>(idc, k / CPS, k % CPS, ss), ct = sample_pick<CPS>(ctc, k / CPS, k % CPS, ss);
-            float uth = sample_pick<CPS>(uhc, k / CPS, k % CPS, ss);
-            if constexpr (LHELP) {
-              if (L_SHARED(p)) {   // (wave-uniform; p even, NLc even: the same chunk)
-                const int k1 = k + 1;
-                const int it1 = sample_pick<CPS>(idc, k1 / CPS, k1 % CPS, ss), ct1 = sample_pick<CPS>(ctc, k1 / CPS, k1 % CPS, ss);
-                const float uth1 = sample_pick<CPS>(uhc, k1 / CPS, k1 % CPS, ss);
-                it = ghelper ? it1 : it;
-                ct = ghelper ? ct1 : ct;
-                uth = ghelper ? uth1 : uth;
-              }
-            }
-            scxn = (gamma * P * P) * uth;  // x = e_stored * scxn
-            scen = (gamma * P) * uth;      // d x / d e_true
-#pragma unroll
-            for (int kb = 0; kb < NB; ++kb) en[kb] = gather_item4c_raw<DT>(a, it, ct, chb[kb]);
-          };
-          f32x4 mxf[NB], izf[NB];               // the forward side's copy of the window's statistics
-          f32x4 xvF[NB], evF[NB], z1F[NB], avF[NB];
-#pragma unroll
-          for (int kb = 0; kb < NB; ++kb) {
-            mxf[kb] = mx1[kb];
-            izf[kb] = iz1[kb];
-            z1F[kb] = avF[kb] = (f32x4)(0.0f);
-          }
-          float sceF = 0.0f;
-          bool vpF = false, stF = false;        // forward-stage position: valid for this lane / one this lane stores a row for
-          int slotF = 0;                        // ... at my_row * PSTR + my_p of the position tables
-          // what a fetched row becomes for position p (taken over at the END of the iteration that fetched it)
-          auto take_row = [&](int p) {
-            const bool sh = L_SHARED(p), oth = sh && ghelper;
-            const int my_p = p + (oth ? 1 : 0);
-            vpF = p < pmax1 && (sh ? my_p < g_hi : p < n_l);
-            stF = (vs || oth) && vpF;
-            slotF = (oth ? wave * SPW + g_L : srow) * PSTR + my_p;
-#pragma unroll
-            for (int kb = 0; kb < NB; ++kb) {
-              evF[kb] = vpF ? tbl_cvt<DT>(en[kb]) : (f32x4)(0.0f);
-              xvF[kb] = evF[kb] * scxn;
-            }
-            sceF = scen;
-          };
-          f32x4 xvB[NB], evB[NB];               // the backward stage's row (scaled / as stored)
-#pragma unroll
-          for (int kb = 0; kb < NB; ++kb) xvB[kb] = evB[kb] = (f32x4)(0.0f);
-          float sceB = 0.0f;
-          bool stBk = false;
-          int slotBk = 0;
-          fetch_entry(0);
-          take_row(0);
-          int pB = -1, pF = 0;
-          while (pB < pmax1) {                  // wave-uniform
-            if constexpr (LHELP) {
-              if (g_on && pB == g_lo2) {        // backward side: the helping half takes over the longer window's output and gradient
-#pragma unroll
-                for (int kb = 0; kb < NB; ++kb)
-#pragma unroll
-                  for (int i = 0; i < 4; ++i) {
-                    const float o_out = dpp_f32<TLSAN_DPP_ROR(8)>(long4[kb][i]), o_do = dpp_f32<TLSAN_DPP_ROR(8)>(dlong[kb][i]);
-                    long4[kb][i] = ghelper ? o_out : long4[kb][i];
-                    dlong[kb][i] = ghelper ? o_do : dlong[kb][i];
-                  }
-              }
-              if (g_on && pF == g_lo2) {        // forward side: ... and its statistics
-#pragma unroll
-                for (int kb = 0; kb < NB; ++kb)
-#pragma unroll
-                  for (int i = 0; i < 4; ++i) {
-                    const float o_mx = dpp_f32<TLSAN_DPP_ROR(8)>(mxf[kb][i]), o_iz = dpp_f32<TLSAN_DPP_ROR(8)>(izf[kb][i]);
-                    mxf[kb][i] = ghelper ? o_mx : mxf[kb][i];
-                    izf[kb][i] = ghelper ? o_iz : izf[kb][i];
-                  }
-              }
-            }
-            // what the forward stage left for this iteration's backward stage, and the forward stage's own position
-            f32x4 z1[NB], av[NB], m1[NB], dm2[NB], dz1[NB], dx[NB], ha[NB], hb[NB], hc[NB], hd[NB];
-            const float sce = sceB;
-            const bool stB = stBk;
-            const float mkF = vpF ? 1.0f : 0.0f;
-            const int slotB = slotBk;
-#pragma unroll
-            for (int kb = 0; kb < NB; ++kb) {
-              z1[kb] = z1F[kb];
-              av[kb] = avF[kb];
-            }
-            const int pL = pF + L_ADV(pF);
-            fetch_entry(pL);                                         // the row after the forward stage's: in flight over the whole iteration
-            read_tiles(0, 1);                                        // x, dz1 of the position before pB
-            const int posp = sP[stB ? slotB : 0], cposp = CSEG ? sPc[stB ? slotB : 0] : 0;
-            __builtin_amdgcn_sched_barrier(0);
-            map_issue(FT1, xvF, ha, hb, b1);                         // G1: z1(pF)
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int kb = 0; kb < NB; ++kb) dm2[kb] = av[kb] * dlong[kb] * (xvB[kb] - long4[kb]);  // softmax-over-positions backward
-            __builtin_amdgcn_sched_barrier(0);
-            map_issue(FN2, dm2, hc, hd, nullptr);                    // G2: dm1(pB) = dm2 . W2^T
-            __builtin_amdgcn_sched_barrier(0);
-            f32x4 zrF[NB];
-#pragma unroll
-            for (int kb = 0; kb < NB; ++kb) {
-              z1F[kb] = ha[kb] + hb[kb];
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                zrF[kb][i] = fmaxf(z1F[kb][i], 0.0f);
-                m1[kb][i] = fmaxf(z1[kb][i], 0.0f);
-              }
-              acc.db2[kb] += dm2[kb];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            map_issue(FT2, zrF, ha, hb, b2);                         // G3: m2(pF)
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int kb = 0; kb < NB; ++kb) {
-              const f32x4 dm1 = hc[kb] + hd[kb];
-#pragma unroll
-              for (int i = 0; i < 4; ++i) dz1[kb][i] = z1[kb][i] > 0.0f ? dm1[i] : 0.0f;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            dw_prod(acc.dW1);                                        // G4: dW1 += x^T dz1 of the position before pB
-            read_tiles(2, 3);                                        //     its m1, dm2 (before this position's tiles overwrite them)
-            __builtin_amdgcn_sched_barrier(0);
-            map_issue(FN1, dz1, hc, hd, nullptr);                    // G5: dxm(pB) = dz1 . W1^T
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int kb = 0; kb < NB; ++kb) {
-#pragma unroll
-              for (int i = 0; i < 4; ++i)   // (m2 <= max on valid positions: the clamp changes nothing there; no branch around the exponentials)
-                avF[kb][i] = __expf(fminf((ha[kb][i] + hb[kb][i]) - mxf[kb][i], 0.0f)) * (izf[kb][i] * mkF);
-              *(f32x4*)(T + (0 * NB + kb) * 16 * TSTR + wofs) = xvB[kb];  // pB's tiles (behind the reads above: in-order DS)
-              *(f32x4*)(T + (1 * NB + kb) * 16 * TSTR + wofs) = dz1[kb];
-              *(f32x4*)(T + (2 * NB + kb) * 16 * TSTR + wofs) = m1[kb];
-              *(f32x4*)(T + (3 * NB + kb) * 16 * TSTR + wofs) = dm2[kb];
-              acc.db1[kb] += dz1[kb];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            dw_prod(acc.dW2);                                        // G6: dW2 += m1^T dm2 of the position before pB
-            __builtin_amdgcn_sched_barrier(0);
-            float dsp = 0.0f;
-#pragma unroll
-            for (int kb = 0; kb < NB; ++kb) {
-              dx[kb] = av[kb] * dlong[kb] + (hc[kb] + hd[kb]);
-              dsp += dot4(dx[kb], evB[kb]);
-            }
-            const float ds = sample_sum<CPS>(dsp) * P;  // d loss / d scale[pB]
-            // the forward stage's row moves on to the backward stage; the fetched row takes its place -- BEFORE the stores
-#pragma unroll
-            for (int kb = 0; kb < NB; ++kb) {
-              xvB[kb] = xvF[kb];
-              evB[kb] = evF[kb];
-            }
-            sceB = sceF;
-            stBk = stF;
-            slotBk = slotF;
-            // (the empty asm reads the fetched registers HERE: left alone the compiler sinks the take-over below the
-            //  branches of the stores, and its wait for the fetch then covers the stores as well)
-#pragma unroll
-            for (int kb = 0; kb < NB; ++kb) asm volatile("" : "+v"(en[kb]));
-            take_row(pL);
-            __builtin_amdgcn_sched_barrier(0);
-            if (stB) {
-              if (lead) a.Gb[posp] = 0.0f;
-#pragma unroll
-              for (int kb = 0; kb < NB; ++kb) {
-                const f32x4 de = dx[kb] * sce;
-                st4_out(use_dst(posp, cposp, chb[kb]), de);
-                sq_acc += dot4(de, de);
-              }
-              if (lead) {
-                const int rowB = slotB / PSTR, my_p = slotB - rowB * PSTR;
-                const float gt = ds * (gamma * sH[rowB * 2 * LSC + my_p]);  // d / d usert_emb[u][p]
-                a.Gu[(size_t)sP[rowB * PSTR + P_USR] * a.WU + a.di + my_p] = gt;
-                sq_acc += gt * gt;
-                dgam += ds * (P * sH[rowB * 2 * LSC + LSC + my_p]);
-              }
-            }
-            pB = pF;
-            pF = pL;
-          }
-          read_tiles(0, 1);                     // drain: the dW products of the last position
-          dw_prod(acc.dW1);
-          read_tiles(2, 3);
-          dw_prod(acc.dW2);
           } else {
           if constexpr (LCH) { stage_lchunk_ids(0); stage_lchunk_cats(); }
           for (int base = 0; base < pmax1; base += NLc) {  // wave-uniform
@@ -2326,33 +1937,14 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             raw4 en[NB];                  // (the next position's row, in flight while this one is processed)
             float scxn = 0.0f, scen = 0.0f;
             if constexpr (LPF) fetch_lrow_raw(base, en, scxn, scen);
-            for (int p = base; p < pend; p += L_ADV(p)) {
-              // (LHELP) shared step: both halves work on the longer window -- its own half on entry p, the helping half
-              // on p + 1, with that sample's statistics, output and output gradient (read across the row at the switch)
-              const bool shared = L_SHARED(p), oth = shared && ghelper;
-              const int my_p = p + (oth ? 1 : 0), my_row = oth ? wave * SPW + g_L : srow;
-              const bool vp = shared ? my_p < g_hi : p < n_l;
-              if constexpr (LHELP) {
-                if (g_on && p == g_lo2) {
-#pragma unroll
-                  for (int kb = 0; kb < NB; ++kb)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                      const float o_mx = dpp_f32<TLSAN_DPP_ROR(8)>(mx1[kb][i]), o_iz = dpp_f32<TLSAN_DPP_ROR(8)>(iz1[kb][i]);
-                      const float o_out = dpp_f32<TLSAN_DPP_ROR(8)>(long4[kb][i]), o_do = dpp_f32<TLSAN_DPP_ROR(8)>(dlong[kb][i]);
-                      mx1[kb][i] = ghelper ? o_mx : mx1[kb][i];       // (the helper's own window is done: its statistics are not needed again)
-                      iz1[kb][i] = ghelper ? o_iz : iz1[kb][i];
-                      long4[kb][i] = ghelper ? o_out : long4[kb][i];
-                      dlong[kb][i] = ghelper ? o_do : dlong[kb][i];
-                    }
-                }
-              }
+            for (int p = base; p < pend; ++p) {
+              const bool vp = p < n_l;
               f32x4 ev[NB], xv[NB], z1[NB], zr[NB], m2[NB], av[NB], dx[NB];
               float scx = scxn, sce = scen;
               if constexpr (LPF) {
 #pragma unroll
                 for (int kb = 0; kb < NB; ++kb) ev[kb] = tbl_cvt<DT>(en[kb]);
-                if (p + L_ADV(p) < pend) fetch_lrow_raw(p + L_ADV(p), en, scxn, scen);
+                if (p + 1 < pend) fetch_lrow_raw(p + 1, en, scxn, scen);
               } else {
                 fetch_lrow(p, ev, scx, sce);
               }
@@ -2397,9 +1989,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
               for (int kb = 0; kb < NB; ++kb) dsp += dot4(dx[kb], ev[kb]);
               const float ds = sample_sum<CPS>(dsp) * P;  // d loss / d scale[p]
-              if ((vs || oth) && vp) {
-                const int pos = sP[my_row * PSTR + my_p];
-                const int cpos = CSEG ? sPc[my_row * PSTR + my_p] : 0;
+              if (vs && vp) {
+                const int pos = sP[srow * PSTR + p];
+                const int cpos = CSEG ? sPc[srow * PSTR + p] : 0;
                 if (lead) a.Gb[pos] = 0.0f;
 #pragma unroll
                 for (int kb = 0; kb < NB; ++kb) {
@@ -2408,10 +2000,10 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
                   sq_acc += dot4(de, de);
                 }
                 if (lead) {
-                  const float gt = ds * (gamma * sH[my_row * 2 * LSC + my_p]);  // d / d usert_emb[u][p]
-                  a.Gu[(size_t)sP[my_row * PSTR + P_USR] * a.WU + a.di + my_p] = gt;
+                  const float gt = ds * (gamma * sH[srow * 2 * LSC + p]);  // d / d usert_emb[u][p]
+                  a.Gu[(size_t)sP[srow * PSTR + P_USR] * a.WU + a.di + p] = gt;
                   sq_acc += gt * gt;
-                  dgam += ds * (P * sH[my_row * 2 * LSC + LSC + my_p]);
+                  dgam += ds * (P * sH[srow * 2 * LSC + LSC + p]);
                 }
               }
             }
@@ -2547,13 +2139,6 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             if (p == 1) TLSAN_STAMP(16);
             if (p == 2) TLSAN_STAMP(17);
             if (p == 9) TLSAN_STAMP(18);
-#if TLSAN_EXP_FLIP
-            // SIMD partners (waves w, w + 4) take turns at the higher issue priority, position by position
-            if (NW == 8) {
-              if ((__builtin_amdgcn_readfirstlane(wave) >> 2) == (p & 1)) __builtin_amdgcn_s_setprio(1);
-              else __builtin_amdgcn_s_setprio(0);
-            }
-#endif
             const int posp = sP[srow * PSTR + p];   // (read with the position's other LDS operands; used by its stores)
             const int cposp = CSEG ? sPc[srow * PSTR + p] : 0;
             const float uth = sH[srow * 2 * LSC + LSC + p];
@@ -2607,39 +2192,23 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
                   av[kb][i] = vp ? __expf(m2[kb][i] - mx1[kb][i]) * iz1[kb][i] : 0.0f;
             }
             if (p == 1) TLSAN_STAMP(13);
-            float* Tp = T + (NBUF > 1 ? (p & 1) * TB : 0);
-            bwd_compute<NB, TSTR, DROP, MM>(FN2, FN1, xv, z1, av, long4, dlong, Tp, q, r, acc.db1, acc.db2, dx, k1, k2);
+            bwd_compute<NB, TSTR, DROP, MM>(FN2, FN1, xv, z1, av, long4, dlong, T, q, r, acc.db1, acc.db2, dx, k1, k2);
             if (p == 1) TLSAN_STAMP(14);
-#if !(TLSAN_EXP_ABL & 4)
-            if (NBUF == 1) bwd_dw<NB, TSTR, MM>(Tp, q, r, acc.dW1, acc.dW2);
-            else if (p > 0) bwd_dw<NB, TSTR, MM>(T + ((p - 1) & 1) * TB, q, r, acc.dW1, acc.dW2);
-#endif
+            bwd_dw<NB, TSTR, MM>(T, q, r, acc.dW1, acc.dW2);
             if (p == 1) TLSAN_STAMP(15);
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) dsp[p] += dot4(dx[kb], e1[p][kb]);
             if (vs && vp) {
-#if TLSAN_EXP_ABL & 2
-              const int pos = bidx * 10 + p;   // (timing experiment: no position read)
-#else
-              const int pos = posp;
-#endif
-#if !(TLSAN_EXP_ABL & 1)
-              if (lead) a.Gb[pos] = 0.0f;
-#endif
+              if (lead) a.Gb[posp] = 0.0f;
 #pragma unroll
               for (int kb = 0; kb < NB; ++kb) {
                 const f32x4 de = dx[kb] * sce;
-#if TLSAN_EXP_ABL & 1
-                asm volatile("" :: "v"(de), "v"(pos));   // (timing experiment: no gradient-row stores in the long backward)
-#else
-                st4_out(use_dst(pos, cposp, chb[kb]), de);
-#endif
+                st4_out(use_dst(posp, cposp, chb[kb]), de);
                 sq_acc += dot4(de, de);
               }
             }
           }
         }
-        if (NBUF > 1 && pmax1 > 0) bwd_dw<NB, TSTR, MM>(T + ((pmax1 - 1) & 1) * TB, q, r, acc.dW1, acc.dW2);
         }
         TLSAN_STAMP(19);
         // usert_emb / gamma gradients.  Branch-free: every lane of a sample forms the same ten sums (vector-ALU

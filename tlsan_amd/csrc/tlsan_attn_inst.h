@@ -1,19 +1,18 @@
 // tlsan_attn_inst.h -- per-D instantiation + launcher of k_fwd_bwd (one translation unit per D
 // so the big kernels compile in parallel).
 #pragma once
+#include <atomic>
 #include "tlsan_attn.h"
+#define TLSAN_MAX_DEVICES 16   // devices one process may drive (per-device launch attributes below)
 #ifndef TLSAN_STAMPS
 #define TLSAN_STAMPS 0
 #endif
 
-#ifndef TLSAN_EXP_FLAT
-#define TLSAN_EXP_FLAT 1
-#endif
 // (mirrors the carve-up at the top of k_fwd_bwd; flat = the FLAT variant of the streamed windows, tlsan_attn.h)
 template <int D, int DH>
 static size_t fwd_smem_bytes(bool train, bool lstream, bool fuse_dk, int Sn, bool cseg, bool drop) {
   using G = Geo<D, DH>;
-  const bool flat = TLSAN_EXP_FLAT != 0 && lstream && !drop;
+  const bool flat = lstream && !drop;
   const bool flatg = flat && G::NB > 1;      // (d = 256: statistics / long vectors in global memory, no LDS copy of the weights, no long slots)
   const int lsc = lstream ? TLSAN_LS_CAP : TLSAN_LS_MAX;
   const int pstr = (flat ? 0 : lsc) + ((cseg || flatg) ? ((Sn + 3) & ~3) : TLSAN_SN_CAP) + 4;      // position slots per sample (k_fwd_bwd: PSTR), twice with CSEG
@@ -34,10 +33,17 @@ static hipError_t launch_variant_dt(const FwdArgs& a, int grid, hipStream_t st) 
   //  workgroups fit a CU's LDS -- 8192 sequences, not fused: 77 us/step with it left out, 95 with it)
   const size_t smem = fwd_smem_bytes<D, DH>(TRAIN, LSTREAM, a.fuse_dk != 0, a.b.Sn, a.cseg != 0, DROP);
   auto k = k_fwd_bwd<D, DH, TRAIN, LSTREAM, DT, DROP, MM, CSEG>;
-  static size_t smem_set = 0;   // (per kernel variant: the attribute is raised once, not on every launch)
-  if (smem > 48 * 1024 && smem > smem_set) {
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    smem_set = smem;
+  // (per kernel variant AND device: the attribute is raised once, not on every launch; relaxed atomics -- two threads
+  //  racing on a first launch both raise it, which is harmless)
+  static std::atomic<size_t> smem_set[TLSAN_MAX_DEVICES];
+  if (smem > 48 * 1024) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::atomic<size_t>* slot = (dev >= 0 && dev < TLSAN_MAX_DEVICES) ? &smem_set[dev] : nullptr;
+    if (slot == nullptr || smem > slot->load(std::memory_order_relaxed)) {
+      (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (slot != nullptr) slot->store(smem, std::memory_order_relaxed);
+    }
   }
   hipLaunchKernelGGL(k, dim3(grid), dim3(Geo<D, DH>::NW * 64), smem, st, a);
   return hipGetLastError();

@@ -104,22 +104,9 @@ __device__ __forceinline__ f32x4 tbl_cvt(typename TblRaw<DT>::type v) {
     return r;
   }
 }
-// 16-byte store that is written through to memory and leaves the XCD's L2 (sc1): for the kernel's bulk outputs
-// (per-use gradient rows, dK partials), which the NEXT kernel reads -- written through while the kernel computes,
-// they are not left dirty in the L2 for the end-of-kernel release to write back (MI355X_MICROARCH.md: a dependent
-// kernel boundary costs + B / 6 TB/s for B dirty bytes; this kernel is nowhere near a bandwidth limit while it runs)
-#ifndef TLSAN_EXP_WT
-#define TLSAN_EXP_WT 0
-#endif
-__device__ __forceinline__ void st4_out(float* p, f32x4 v) {
-#if TLSAN_EXP_WT
-  // (the s_nop: a vector write to the data registers of a store wider than 64 bits needs one wait state behind it --
-  //  the compiler's hazard recogniser cannot see into the statement, and the next instruction may well reuse them)
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(v));
-#else
-  *(f32x4*)p = v;
-#endif
-}
+// 16-byte store of one of the kernels' bulk outputs (per-use gradient rows, dK partials, row sums, table rows).
+// (Round 3 measured these as write-through stores, `global_store_dwordx4 ... sc1`: no gain, profiles/r03_ab_summary.md.)
+__device__ __forceinline__ void st4_out(float* p, f32x4 v) { *(f32x4*)p = v; }
 
 // 32 well-mixed bits from (element index, stream): the random bits of the stochastic rounding
 __device__ __forceinline__ uint32_t tbl_hash(uint32_t x, uint32_t stream) {
@@ -184,24 +171,11 @@ struct Geo {
   // wake-up -> launch of the next step -- so a shorter tail only made the GPU wait for the host.  With the index built
   // TWO steps ahead (Model.train_async(after_next=)) that path is gone and the main stream's chain is the step:
   // 70.0 us without the fusion, 66.7 us with it (profiles/r02_ab/r02_ab_fuse2.txt).
-#ifndef TLSAN_EXP_FUSE_DK
-#define TLSAN_EXP_FUSE_DK 1
-#endif
-  static constexpr bool FUSE_DK = TLSAN_EXP_FUSE_DK != 0 && D_ <= 128;
-#ifndef TLSAN_EXP_TSTR
-#define TLSAN_EXP_TSTR 20
-#endif
-  static constexpr int TSTR = TLSAN_EXP_TSTR;   // LDS row stride of the 16x16 transpose tiles
+  static constexpr bool FUSE_DK = D_ <= 128;
+  static constexpr int TSTR = 20;                   // LDS row stride of the 16x16 transpose tiles
   // per-wave LDS scratch (floats): 4*NB transpose tiles, or the staged gradient accumulators
-  static constexpr int TBUF = 4 * NB * 16 * TSTR;   // one buffer: x, dz1, m1, dm2 tiles
-#ifndef TLSAN_EXP_NBUF
-#define TLSAN_EXP_NBUF 1
-#endif
-  static constexpr int NBUF = TLSAN_EXP_NBUF;       // (double-buffering the tiles bought nothing measurable)
-#ifndef TLSAN_EXP_KEEP_A
-#define TLSAN_EXP_KEEP_A 1
-#endif
-  static constexpr bool KEEP_A = NB == 1 && TLSAN_EXP_KEEP_A;   // long block's softmax weights kept in LDS for the backward
+  static constexpr int TBUF = 4 * NB * 16 * TSTR;   // one buffer: x, dz1, m1, dm2 tiles (double-buffering them bought nothing)
+  static constexpr bool KEEP_A = NB == 1;           // long block's softmax weights kept in LDS for the backward
   static constexpr bool USE_SW = true;              // attention weights staged in LDS
   // NB > 1 (d = 256): six 16-register weight fragments cannot stay in registers for a whole phase:
   // the window-in-registers variants re-read them from LDS at every position (behind a value the
@@ -209,7 +183,7 @@ struct Geo {
   // registers (spilled): re-reading per position measured slower there (707 vs 659 us at Ls=90).
   static constexpr bool AT_USE = NB > 1;
   static constexpr bool AT_USE_T = true;            // (forward fragments as well: d=256, Ls=10: 239 us/step vs 261 without)
-  static constexpr int WSCR_T = NBUF * TBUF;
+  static constexpr int WSCR_T = TBUF;
   // staged gradient accumulators: all 2 NB^2 + 3 NB vectors at once, or (NB > 1, to fit the LDS) in two
   // halves {dW1, db1, dk0} / {dW2, db2}
   static constexpr bool SPLIT = NB > 1;

@@ -544,12 +544,9 @@ __global__ __launch_bounds__(1024) void k_index_scan(ScanArgs a) {
 // quadrant for its samples from two coalesced 16-B loads per MFMA k-step: lane (q, r) reads
 // channels 4r..4r+3 of sample s0+q from both operands, and float t of the load feeds MFMA tile t,
 // i.e. tile ta x tb covers rows 4m+ta, columns 4n+tb -- 16 independent accumulators per k-step
-// and the float4 write-out is contiguous again.  The 8 wavefronts are summed through LDS in a
+// and the float4 write-out is contiguous again.  The wavefronts are summed through LDS in a
 // fixed order, so a launch leaves nsplit (<= DK_SPLITS_MAX) partial matrices for k_dense_finalize.
-#ifndef TLSAN_EXP_DKW
-#define TLSAN_EXP_DKW 4
-#endif
-#define DK_WAVES TLSAN_EXP_DKW   // wavefronts per workgroup: 4 -> 64 splits x (D/64)^2 quadrants = 256 workgroups at B = 4096, one
+#define DK_WAVES 4   // wavefronts per workgroup: 4 -> 64 splits x (D/64)^2 quadrants = 256 workgroups at B = 4096, one
                                  // wavefront per SIMD on every CU (8 left half the chip idle with two wavefronts per SIMD)
 #define DK_SPLITS_MAX (256 / DK_WAVES)
 static inline int dk_nsplit(int B) { const int n = (B + DK_WAVES * 16 - 1) / (DK_WAVES * 16); return n < DK_SPLITS_MAX ? n : DK_SPLITS_MAX; }

@@ -616,7 +616,7 @@ class ShardedModel:
             self._side_event = [torch.cuda.Event(), torch.cuda.Event()]
         sst = C.c_void_p(self._side.cuda_stream)
         L.check(self.lib.tlsan_state_recategorize(C.byref(dims), C.byref(cp), st8.data_ptr(), sst), "tlsan_state_recategorize")
-        L.check(self.lib.tlsan_batch_index(C.byref(dims), C.byref(cb), st8.data_ptr(), 0, sst), "tlsan_batch_index")
+        L.check(self.lib.tlsan_batch_index(C.byref(dims), C.byref(cb), cp.item_cate, st8.data_ptr(), 0, sst), "tlsan_batch_index")
         ev = self._side_event[self._next_slot]
         ev.record(self._side)
         nsl["prep_event"] = ev
@@ -911,14 +911,13 @@ class ShardedModel:
             with torch.cuda.stream(stream):
                 st["status_host"].copy_(st["status"], non_blocking=True)
         dims = st["dims"]
-        # the category index of the compact table first (host order only: it also tells the library which item -> category
-        # map the slot's state belongs to, which the destination index of a table with thousands of categories counts by);
-        # the destination index waits for the plan, not for it
+        # the category index of the compact table; the destination index waits for the plan, not for it (it is handed the
+        # compact table's item -> category map itself, which the plan wrote)
         sl["planned"].record(stream)
         L.check(self.lib.tlsan_state_recategorize(C.byref(dims), C.byref(cp), sl["state"].data_ptr(), sp), "tlsan_state_recategorize")
         if stream2 is not None:
             stream2.wait_event(sl["planned"])
-            L.check(self.lib.tlsan_batch_index(C.byref(dims), C.byref(cb), sl["state"].data_ptr(), 0,
+            L.check(self.lib.tlsan_batch_index(C.byref(dims), C.byref(cb), cp.item_cate, sl["state"].data_ptr(), 0,
                                                C.c_void_p(stream2.cuda_stream)), "tlsan_batch_index")
             sl["done"][1].record(stream2)
         sl["ids_sent"] = True
@@ -932,7 +931,7 @@ class ShardedModel:
                 with torch.cuda.stream(stream):
                     a2a(sl["recvbuf"].view(-1), sl["sendbuf"].view(-1), None, None, group if group is not None else self.group)
         if stream2 is None:
-            L.check(self.lib.tlsan_batch_index(C.byref(dims), C.byref(cb), sl["state"].data_ptr(), 0, sp), "tlsan_batch_index")
+            L.check(self.lib.tlsan_batch_index(C.byref(dims), C.byref(cb), cp.item_cate, sl["state"].data_ptr(), 0, sp), "tlsan_batch_index")
         else:
             sl["done"][0].record(stream)
         sl["pending"] = stream2 is not None

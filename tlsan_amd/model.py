@@ -87,6 +87,7 @@ OPTIMIZERS = {"sgd": (L.OPT_SGD, 0.0, 0.0, 0.0), "adam": (L.OPT_ADAM, 0.9, 0.999
 
 
 _STREAM_CACHE = {}
+_STARTED_WORDS = []   # pinned words that kernels of queued steps write (Model._started): never freed
 
 
 def concurrent_streams(device, want=1, pool=6, **stream_kw):
@@ -126,16 +127,9 @@ def concurrent_streams(device, want=1, pool=6, **stream_kw):
         with torch.cuda.stream(c):
             x.add_(1.0)
     chosen = []
-    dbg = os.environ.get("TLSAN_DEBUG_STREAMS") == "1"
-    for k, c in enumerate(cands):
+    for c in cands:
         if len(chosen) < want:
-            ok_main = overlaps(main, c)
-            t_main = (ev[0].elapsed_time(ev[2]), ev[0].elapsed_time(ev[1]))
-            ok = ok_main and all(overlaps(o, c) for o in chosen)
-            if dbg:
-                print("concurrent_streams: candidate %d vs main: tiny kernel done after %.3f ms, spin %.3f ms -> %s"
-                      % (k, t_main[0], t_main[1], "taken" if ok else "shares a queue"), file=sys.stderr)
-            if ok:
+            if overlaps(main, c) and all(overlaps(o, c) for o in chosen):
                 chosen.append(c)
     for c in cands:                     # fewer independent queues than asked for: take what there is
         if len(chosen) < want and c not in chosen:
@@ -292,6 +286,9 @@ class Model(object):
         self._pre_event = torch.cuda.Event()
         # host-visible word the first kernel of a step writes its sequence number into (train_async)
         self._started = torch.zeros(16, dtype=torch.int32).pin_memory()
+        # (a step still queued when the Model is dropped writes this word when it starts: the pinned block must not be
+        #  recycled under it -- the word outlives the Model, 64 bytes per Model ever built)
+        _STARTED_WORDS.append(self._started)
         self._started_addr = self._started.data_ptr()
         self._started_word = C.c_uint32.from_address(self._started_addr)
         self._start_seq = 0
@@ -554,7 +551,9 @@ class Model(object):
             raise RuntimeError("train_async: the batch announced as next_batch must be the next one trained "
                                "(its destination index is already counted into the state)")
         pre = self._idx_ready[k] is db
-        dev_wait = os.environ.get("TLSAN_DEVICE_WAIT", "0") == "1"
+        # streams are ordered by HOST waits on events that are complete by the time they are needed (a device-side
+        # cross-queue wait costs ~8 us on this stack: measured, worse); under stream capture the host cannot wait
+        dev_wait = torch.cuda.is_current_stream_capturing()
         if pre:
             if dev_wait:
                 torch.cuda.current_stream(self.device).wait_event(self._idx_event[k])
@@ -580,7 +579,8 @@ class Model(object):
         # a barrier packet between the previous step's last kernel and this step's first one (measured: the fused
         # kernel starts 6.6 us after its predecessor ends instead of < 2); instead the step's first kernel stores a
         # sequence number into a pinned host word when it begins to run (tlsan_step_out.started), and the host polls it.
-        flag_wait = bool(ahead) and not dev_wait and os.environ.get("TLSAN_FLAG_WAIT", "1") != "0"
+        # (under stream capture nothing runs, so the word would never change: events are the capturable path)
+        flag_wait = bool(ahead) and not dev_wait
         if ahead and not flag_wait:
             self._pre_event.record(main)
         if flag_wait:
@@ -594,21 +594,23 @@ class Model(object):
                 # (high priority: the index kernels are short and the NEXT step cannot start without them; left at
                 #  the default they trail behind the 2400 workgroups of the row-sum / update launches they share
                 #  the GPU with -- measured: no difference either way)
-                self._side = concurrent_streams(self.device, 1, priority=int(os.environ.get("TLSAN_SIDE_PRIORITY", "-1")))[0]
+                self._side = concurrent_streams(self.device, 1, priority=-1)[0]
             if dev_wait:
                 self._side.wait_event(self._pre_event)
-            elif flag_wait:
-                word, want, t0 = self._started_word, self._start_seq, None
+            else:
+                word, want, t0, polls = self._started_word, self._start_seq, None, 0
                 while word.value != want:
+                    polls += 1
+                    if polls & 255:
+                        continue
+                    time.sleep(0)            # (every 256 polls: let another Python thread have the GIL)
                     if t0 is None:
                         t0 = time.perf_counter()
                     elif time.perf_counter() - t0 > 30.0:
                         raise RuntimeError("train_async: the step's first kernel did not start within 30 s")
-            else:
-                self._pre_event.synchronize()
             for ndb, kk in ahead:
                 flag = L.INDEX_FOR_LAZY_SGD if (self.l2_mode == L.L2_LAZY and self.optimizer == "sgd") else 0
-                L.check(self.lib.tlsan_batch_index(C.byref(self.dims), C.byref(ndb.c), self.state.data_ptr(), kk | flag,
+                L.check(self.lib.tlsan_batch_index(C.byref(self.dims), C.byref(ndb.c), self.cparams.item_cate, self.state.data_ptr(), kk | flag,
                                                    C.c_void_p(self._side.cuda_stream)), "tlsan_batch_index")
                 self._idx_event[kk].record(self._side)
                 self._idx_ready[kk] = ndb
