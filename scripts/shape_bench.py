@@ -16,17 +16,13 @@ dbs = [m.device_batch(b) for b in synth.make_batches(cfg, 4, B, seed=1234, sessi
 AH = int(kw.get("ahead", 2))      # destination indices built this many steps ahead (0: inside the step)
 def step(s):
     m.train_async(dbs[s % 4], 1.0, next_batch=dbs[(s + 1) % 4] if AH >= 1 else None, after_next=dbs[(s + 2) % 4] if AH >= 2 else None)
-import contextlib
-# hp=1: the steps on a high-priority stream of their own (the index stream then takes TLSAN_SIDE_PRIORITY=0)
-ctx = torch.cuda.stream(torch.cuda.Stream(priority=-1)) if kw.get("hp") == "1" else contextlib.nullcontext()
-with ctx:
-    for s in range(10):
-        step(s)
-    torch.cuda.synchronize()
-    N = 100
-    t0 = time.perf_counter()
-    for s in range(10, 10 + N):
-        step(s)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / N
+for s in range(10):
+    step(s)
+torch.cuda.synchronize()
+N = 100
+t0 = time.perf_counter()
+for s in range(10, 10 + N):
+    step(s)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / N
 print("d=%d Ls=%d B=%d%s: %.1f us/step, %.2f M seq/s, loss %.4f" % (d, Ls, B, "".join(" %s=%s" % (k, kw[k]) for k in ("sess", "td", "mm") if k in kw), dt * 1e6, B / dt / 1e6, float(m._out[0].item())))

@@ -26,8 +26,10 @@ db_host = synth.make_batches(cfg, 1, B, seed=7)[0]
 db = m.device_batch(db_host)
 for _ in range(5):
     m.train_async(db, 1.0)
-nblk = (B + 15) // 16
-NWV = 8   # wavefronts per workgroup
+# (TLSAN_NW4=2 with d = 128 and the window in registers: 4-wavefront workgroups of 8 samples)
+NW4 = os.environ.get("TLSAN_NW4", "1") == "2" and cfg["hidden_units"] == 128 and cfg["Ls"] <= 10
+NSB, NWV = (8, 4) if NW4 else (16, 4 if cfg["hidden_units"] == 64 else 8)   # samples / wavefronts per workgroup
+nblk = (B + NSB - 1) // NSB
 st = torch.zeros((1 << 20) + 8 * 8192, dtype=torch.int64, device="cuda")   # k_apply stamps live from entry 2^20 on
 lib.tlsan_debug_stamps(st.data_ptr())
 m.train_async(db, 1.0)
@@ -66,23 +68,24 @@ if "Ls" in kw and int(kw["Ls"]) > 10:   # streamed windows (the list form)
     seg("list backward: entry -> loop", 9, 16, anyw)
     seg("list backward: loop", 16, 18, anyw)
     seg("list backward: drain, padding, staging", 18, 10, anyw)
-seg("P1: loads issued -> rows in registers", 0, 21)
-seg("P1: weight fragments from the LDS", 21, 22)
-seg("P1: long forward (maps, softmax)", 22, 23)
+else:                                   # (windows in registers: these stamps mean something else in the list form)
+    seg("P1: loads issued -> rows in registers", 0, 21)
+    seg("P1: weight fragments from the LDS", 21, 22)
+    seg("P1: long forward (maps, softmax)", 22, 23)
 seg("P1: store long, issue P3's row loads + bridge B", 23, 1)
 seg("P3: frags + first session loads", 4, 24)
 seg("P3: forward positions + normalise", 24, 25)
 seg("P3: logit, BCE, candidate / user stores", 25, 26)
 seg("P3: backward positions", 26, 27)
 seg("P3: stage accumulators + dlong B loads", 27, 6)
-seg("P5: entry -> start of position 1 (frags, pos 0)", 9, 16)
-seg("P5 pos1: start -> row scaled (LDS read of uth)", 16, 12)
-seg("P5 pos1: after dW -> start of position 2 (stores)", 15, 17)
-seg("P5: position 1 in all", 16, 17)
-seg("P5: positions 2..8 (7 positions)", 17, 18, full)
-seg("P5: position 9 + last dW", 18, 19, full)
-seg("P5: dsp reductions + Gu stores", 19, 20)
-seg("P5: stage accumulators (to stamp 10)", 20, 10)
+if not ("Ls" in kw and int(kw["Ls"]) > 10):
+    seg("P5: entry -> start of position 1 (frags, pos 0)", 9, 16)
+    seg("P5 pos1: after dW -> start of position 2 (stores)", 15, 17)
+    seg("P5: position 1 in all", 16, 17)
+    seg("P5: positions 2..8 (7 positions)", 17, 18, full)
+    seg("P5: position 9 + last dW", 18, 19, full)
+    seg("P5: dsp reductions + Gu stores", 19, 20)
+    seg("P5: stage accumulators (to stamp 10)", 20, 10)
 # the workgroup's critical path: a barrier releases when its slowest wavefront arrives
 arr = [1, 3, 6, 8, 10]   # stamps taken on arrival at the five barriers
 rel0 = s[:, :, 0].min(1)
@@ -118,13 +121,13 @@ print("critical path of the median workgroup (P1 P2 P3 P4 P5 end):", np.median(c
 sl_new = np.asarray(db_host[7])
 sl_long = np.asarray(db_host[6])
 for b in order[:6]:
-    extra = "  sessions " + str(sorted(sl_new[16 * b:16 * b + 16].tolist(), reverse=True)[:6])
-    extra += "  windows " + str(sorted(sl_long[16 * b:16 * b + 16].tolist(), reverse=True)[:6])
+    extra = "  sessions " + str(sorted(sl_new[NSB * b:NSB * b + NSB].tolist(), reverse=True)[:6])
+    extra += "  windows " + str(sorted(sl_long[NSB * b:NSB * b + NSB].tolist(), reverse=True)[:6])
     print("  workgroup #%d:" % b, cp[b].astype(int), extra)
 p1 = d[:, :, 0]
 print("P1 percentiles:", np.percentile(p1, [1, 10, 25, 50, 75, 90, 99, 100]).astype(int))
 print("P1 mean by XCD (block%8):", [int(p1[x::8].mean()) for x in range(8)])
-print("P1 mean by wave:", [int(p1[:, w].mean()) for w in range(8)])
+print("P1 mean by wave:", [int(p1[:, w].mean()) for w in range(NWV)])
 blk = p1.mean(1)
 print("P1 block-mean percentiles:", np.percentile(blk, [0, 10, 50, 90, 100]).astype(int))
 start = s[:, :, 0] - s[:, :, 0].min()

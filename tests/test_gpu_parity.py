@@ -1037,3 +1037,20 @@ def test_user_index_from_a_sort_of_the_batch():
                         "or test_full_size_batch_matches_oracle or test_long_windows_streamed or test_graph_replay_equals_eager or test_prefetched_index_equals_inline"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("nw4", ["0", "2"])
+def test_both_workgroup_geometries_of_d128(nw4):
+    """d = 128 with the window in registers runs as 8-wavefront workgroups of 16 samples, or -- batches of up to 1024
+    sequences, where those would leave most CUs idle -- as 4-wavefront workgroups of 8 (Geo<128, 16, 4>).  The other
+    tests see whichever their batch size selects; here TLSAN_NW4 (read once per process) forces each of the two over
+    the oracle tests of forward, gradients and train steps, and over the full-size property test."""
+    import subprocess, sys
+    env = dict(os.environ, TLSAN_NW4=nw4)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-m", "gpu", "-q", "-x", "-k",
+                        "test_forward_logits or test_gradients or test_train_step_matches_oracle or test_lazy_l2_matches_dense_oracle "
+                        "or test_multi_step_tracks_oracle_and_is_deterministic or test_full_size_batch_matches_oracle or test_full_scale_properties "
+                        "or test_bf16_tables or test_bf16_matrix_products or test_graph_replay_equals_eager or test_one_hot_row_takes_every_use"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

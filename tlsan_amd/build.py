@@ -1,5 +1,6 @@
-"""Build libtlsan_hip.so (gfx950) in-tree with hipcc.  No torch, no cmake: four translation
-units compiled in parallel, one link.  `python -m tlsan_amd.build` or `build()`."""
+"""Build libtlsan_hip.so (gfx950) in-tree with hipcc.  No torch, no cmake: five translation
+units (the C ABI with every kernel but the fused one; k_fwd_bwd for d = 64 / 128 / 128 as 8-sample workgroups / 256)
+compiled in parallel, one link.  `python -m tlsan_amd.build` or `build()`."""
 from __future__ import annotations
 
 import os
@@ -11,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libtlsan_hip.so")
-SOURCES = ["tlsan_api.hip", "tlsan_attn_d64.hip", "tlsan_attn_d128.hip", "tlsan_attn_d256.hip"]
+SOURCES = ["tlsan_api.hip", "tlsan_attn_d64.hip", "tlsan_attn_d128.hip", "tlsan_attn_d128w4.hip", "tlsan_attn_d256.hip"]
 HEADERS = ["tlsan_common.h", "tlsan_attn.h", "tlsan_attn_inst.h", "tlsan_update.h", "tlsan_eval.h", "tlsan_rows.h", "tlsan_shard.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC] + \
         os.environ.get("TLSAN_HIPCC_EXTRA", "").split()   # (experiments: extra compiler flags)
@@ -53,7 +54,7 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed for %s:\n%s" % (s, r.stderr[-4000:]))
         return o
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=5) as ex:
         list(ex.map(run, jobs))
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):

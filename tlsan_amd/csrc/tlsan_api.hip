@@ -14,6 +14,7 @@
 hipError_t tlsan_launch_fwd_bwd_d64(bool train, bool lstream, const FwdArgs& a, int grid, hipStream_t st);
 hipError_t tlsan_launch_fwd_bwd_d128(bool train, bool lstream, const FwdArgs& a, int grid, hipStream_t st);
 hipError_t tlsan_launch_fwd_bwd_d256(bool train, bool lstream, const FwdArgs& a, int grid, hipStream_t st);
+hipError_t tlsan_launch_fwd_bwd_d128w4(const FwdArgs& a, int grid, hipStream_t st);   // training, 8-sample workgroups
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, ...) {
@@ -85,7 +86,7 @@ struct Ws {  // carve-up of the caller's scratch buffer
   double* rownorm_part;
   double* rownorm;
   size_t bytes;
-  int ngroups, nsplit, nfin, nbK, nbS, WU;
+  int ngroups, nfin, nbK, nbS, WU;
 };
 
 static int ru4(int x) { return (x + 3) / 4 * 4; }
@@ -106,6 +107,17 @@ static int cseg_min_cates() {
   return v;
 }
 static bool fused_dk(int D, int ngroups) { return D <= 128 && ngroups <= FUSED_DK_MAX_GROUPS; }
+// Samples per workgroup pass of a TRAINING launch of the fused kernel (= per partial record): the width's NSB, or 8 at
+// d = 128 (4-wavefront workgroups: Geo<128, 16, 4>) with the window in registers and no dropout, when the batch is so
+// small that 16-sample workgroups would leave three quarters of the CUs idle -- a wavefront then runs alone on its SIMD
+// (profiles/r04_nw4_ab.md; at larger batches the 16-sample workgroups are faster).
+// TLSAN_NW4 (A/B measurements; read once): 0 never, 1 as described, 2 always.
+static int train_group(const Shape& s, const tlsan_dims* d, const tlsan_batch* b, const tlsan_hparams* hp) {
+  static const int mode = [] { const char* e = getenv("TLSAN_NW4"); return e ? atoi(e) : 1; }();
+  if (s.D != 128 || d->Ls > TLSAN_LS_MAX || (hp && hp->dropout != 0.0f) || mode == 0) return s.NSB;
+  if (mode == 1 && (b->B + s.NSB - 1) / s.NSB > 64) return s.NSB;
+  return 8;
+}
 static int fwd_train_grid(int ngroups) { return ngroups; }    // (fused: ngroups <= FUSED_DK_MAX_GROUPS, one pass per workgroup)
 
 // dK in the tail launch (FinArgs.dk_gemm): the fused kernel leaves the [B, D] operands, DK_KS finalize blocks per 16 x 16
@@ -124,11 +136,10 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
   tlsan_dense_layout L;
   tlsan_dense_layout_of(d, &L);
   w->WU = ru4(d->d_item + d->Ls);
-  w->ngroups = (B + 15) / 16;  // partial records: one per workgroup pass (16 samples with k_fwd_bwd2, NSB otherwise)
+  w->ngroups = (B + 7) / 8;  // partial records: one per workgroup pass (the smallest pass any launch may take: train_group)
   // dK partials: one per batch split of k_dk_partial, or (fused into the forward/backward kernel, D <= 128) one per
-  // workgroup of that launch
+  // workgroup of that launch -- which of the two, and how many, is the launch's choice (run_backward)
   const int ngroups = (B + s.NSB - 1) / s.NSB;
-  w->nsplit = fused_dk(s.D, ngroups) ? fwd_train_grid(ngroups) : dk_nsplit(B);
   w->nbK = (s.D * s.D + 255) / 256 * (dk_tail(s.D) ? DK_KS : 1);   // (dK in the tail launch: DK_KS blocks per tile)
   w->nbS = (L.n_dense - s.D * s.D + 15) / 16;
   w->nfin = w->nbK + w->nbS;
@@ -147,7 +158,8 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
   //  need more partials than the split form of a larger one)
   int kp_slots = dk_nsplit(B);
   if (s.D <= 128) {
-    const int fmax = ngroups < FUSED_DK_MAX_GROUPS ? ngroups : FUSED_DK_MAX_GROUPS;
+    const int ng8 = s.D == 128 ? (B + 7) / 8 : ngroups;    // (8-sample workgroups: twice the groups)
+    const int fmax = ng8 < FUSED_DK_MAX_GROUPS ? ng8 : FUSED_DK_MAX_GROUPS;
     if (fmax > kp_slots) kp_slots = fmax;
   }
   if (dk_tail(s.D) && kp_slots < DK_KS) kp_slots = DK_KS;   // (the slices' tiles of the tail product)
@@ -583,12 +595,13 @@ int tlsan_state_recategorize(const tlsan_dims* d, const tlsan_params* p, void* s
   return build_cate_csr(d, p, st, (hipStream_t)stream);
 }
 
-static int launch_fwd(const Shape& s, bool train, const FwdArgs& a, hipStream_t hs) {
+static int launch_fwd(const Shape& s, bool train, const FwdArgs& a, hipStream_t hs, int grp = 0) {
   int grid = a.ngroups < 4096 ? a.ngroups : 4096;
   if (train && a.fuse_dk) grid = fwd_train_grid(a.ngroups);
   hipError_t e;
   const bool lstream = streamed(a.Ls);  // long windows are streamed, short ones stay in registers
-  if (s.D == 64) e = tlsan_launch_fwd_bwd_d64(train, lstream, a, grid, hs);
+  if (train && s.D == 128 && grp == 8) e = tlsan_launch_fwd_bwd_d128w4(a, grid, hs);
+  else if (s.D == 64) e = tlsan_launch_fwd_bwd_d64(train, lstream, a, grid, hs);
   else if (s.D == 128) e = tlsan_launch_fwd_bwd_d128(train, lstream, a, grid, hs);
   else e = tlsan_launch_fwd_bwd_d256(train, lstream, a, grid, hs);
   if (e == hipErrorNotSupported)
@@ -722,19 +735,20 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
     a.drop_seed = hp->dropout_seed;
     a.drop_sample0 = hp->dropout_sample0;
   }
-  const int grp = s.NSB;  // samples per workgroup pass of the fused kernel (= per partial record)
+  const int grp = train_group(s, d, b, hp);  // samples per workgroup pass of the fused kernel (= per partial record)
   a.ngroups = (b->B + grp - 1) / grp;
   a.fuse_dk = fused_dk(s.D, a.ngroups) ? 1 : 0;
   // dK in the tail launch: the fused kernel leaves the [B, D] operands, the finalize blocks form the product (FinArgs.dk_gemm)
   const bool dkt = dk_tail(s.D);
   if (dkt) a.fuse_dk = 0;
   prof_mark(1, hs);
-  if ((rc = launch_fwd(s, true, a, hs))) return rc;
+  if ((rc = launch_fwd(s, true, a, hs, grp))) return rc;
   prof_mark(2, hs);
+  const int nsplit = a.fuse_dk ? fwd_train_grid(a.ngroups) : dk_nsplit(b->B);   // dK partials the finalize sums
   // --- dense-parameter gradients (D <= 128: the dK partials were left by k_fwd_bwd, one per workgroup)
   if (!a.fuse_dk && !dkt) {
     const int spw = dk_spw(b->B), nq = (s.D / 64) * (s.D / 64);
-    const dim3 grid(nq * w.nsplit), blk(DK_WAVES * 64);
+    const dim3 grid(nq * nsplit), blk(DK_WAVES * 64);
 #define DK_LAUNCH(DD)                                                                                           \
   do {                                                                                                          \
     (void)hipFuncSetAttribute((const void*)k_dk_partial<DD>, hipFuncAttributeMaxDynamicSharedMemorySize, DK_SMEM_BYTES); \
@@ -749,7 +763,7 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   prof_mark(3, hs);
   FinArgs f;
   memset(&f, 0, sizeof(f));
-  f.lay = L; f.partials = w.partials; f.nrec = (b->B + grp - 1) / grp; f.Kp = w.Kp; f.nsplit = w.nsplit;
+  f.lay = L; f.partials = w.partials; f.nrec = (b->B + grp - 1) / grp; f.Kp = w.Kp; f.nsplit = nsplit;
   f.gd = gd_out ? gd_out : w.gd; f.sqd = w.sqd; f.scal = w.scal;
   f.S_delta = st.S_delta; f.n_spart = st.nbI + st.nbU + st.nbC; f.S_total = st.S_total;
   f.hdr = st.hdr; f.lr = hp->lr; f.reg = hp->reg; f.clip = hp->clip; f.inv_B = 1.0f / (float)b->B;

@@ -396,11 +396,14 @@ __device__ __forceinline__ void online_step(f32x4 (&mx)[NB], f32x4 (&Z)[NB], f32
 // CSEG (FwdArgs.cseg, tables with thousands of categories): the category half of every item use's gradient row goes to
 // the category's own segment of Gc.  A compile-time variant: as a run-time flag its tests sat inside the pipelined
 // loops of the variant that does not need it (C3 shape: 61.0 -> 62.9 us/step).
-template <int D, int DH, bool TRAIN, bool LSTREAM, int DT = TLSAN_TABLE_F32, bool DROP = false, int MM = TLSAN_MATRIX_F32, bool CSEG = false>
+// NWV (0 = the width's default): wavefronts per workgroup, see Geo.  The register budget is that of two wavefronts per
+// SIMD either way (__launch_bounds__(512)): an 8-wavefront workgroup fills a CU, two 4-wavefront ones share it.
+template <int D, int DH, bool TRAIN, bool LSTREAM, int DT = TLSAN_TABLE_F32, bool DROP = false, int MM = TLSAN_MATRIX_F32, bool CSEG = false, int NWV = 0>
 __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   static_assert(!DROP || TRAIN, "dropout: train steps only");
   static_assert(!CSEG || TRAIN, "category segments: train steps only");
-  using G = Geo<D, DH>;
+  using G = Geo<D, DH, NWV>;
+  static_assert(G::NSB == 16 || (G::NSB == 8 && !LSTREAM), "8-sample workgroups: windows in registers only");
   using opd = typename MMT<MM>::opd;   // an operand of one 16-deep contraction (tlsan_common.h)
   constexpr int NB = G::NB, CPS = G::CPS, SPW = G::SPW, NW = G::NW, NSB = G::NSB;
   constexpr int LS = LSTREAM ? 1 : TLSAN_LS_MAX;             // positions held in registers
@@ -422,7 +425,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   constexpr bool FLATG = FLAT && NB > 1;
   constexpr bool USE_SW = G::USE_SW && !FLATG;          // attention weights staged in LDS (when they fit)
   constexpr int LSCP = FLAT ? 0 : LSC;                  // long slots of the position tables (FLAT: the list holds them)
-  const int SNS = (CSEG || FLATG) ? ((a.b.Sn + 3) & ~3) : TLSAN_SN_CAP;
+  // (8-sample workgroups size them by the batch as well: two workgroups must fit a CU's LDS)
+  const int SNS = (CSEG || FLATG || NSB < 16) ? ((a.b.Sn + 3) & ~3) : TLSAN_SN_CAP;
   const int PSTR = LSCP + SNS + 4;
   const int P_TGT = LSCP + SNS, P_USR = P_TGT + 1, P_UC = P_TGT + 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -524,24 +528,25 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     // SIMD) -- so it gets the longest samples, and a wavefront's two samples have similar lengths (its trip counts
     // are the longer one's).  Any assignment gives the same sums up to fp32 rounding; this one is a fixed function
     // of the batch, so results stay bitwise reproducible.
-    static_assert(NSB == 16, "one candidate per lane of a row");
+    // (lane r of a row speaks for candidate r % NSB: with 8 samples per pass the upper half of a row repeats the lower)
     int bidx;
     int offv = 0, f_total = 0;   // FLAT: lane r = where slot r's window starts in the flat list; the list's length
     {
-      const int cand = a.perm != nullptr ? a.perm[g * NSB + r] : g * NSB + r;   // (the batch's samples ranked and dealt out: BalArgs)
+      const int rc = r % NSB;
+      const int cand = a.perm != nullptr ? a.perm[g * NSB + rc] : g * NSB + rc;   // (the batch's samples ranked and dealt out: BalArgs)
       const bool cv = cand < B;
       const int cl = cv ? min(a.b.sl[cand], Ls) : 0, cs = cv ? min(a.b.sl_new[cand], Sn) : 0;
       // (a window per column group -- streamed windows with dropout -- : the window length decides, up to 90 positions
       //  against a session's few)
-      const int key = cv ? ((((LSTREAM && !FLAT) ? ((cl << 12) | (cs << 4)) : ((cs << 12) | (cl << 4))) | (15 - r)) + 1) : -r;   // distinct; larger = heavier
+      const int key = cv ? ((((LSTREAM && !FLAT) ? ((cl << 12) | (cs << 4)) : ((cs << 12) | (cl << 4))) | (15 - rc)) + 1) : -rc;   // distinct; larger = heavier
       int rank = 0;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) rank += (__builtin_amdgcn_readlane(key, j) > key) ? 1 : 0;
+      for (int j = 0; j < NSB; ++j) rank += (__builtin_amdgcn_readlane(key, j) > key) ? 1 : 0;
       int* sPerm = (int*)T;                       // (the wave's own scratch: free until P3)
       // (windows held in registers, two samples per wavefront: the wavefront with the k-th longest session also takes
       // the k-th shortest -- its lanes then share the long one, see HELP in P3)
-      const int slot = (SPW == 2 && !DROP) ? (rank < 8 ? 2 * rank : 2 * (15 - rank) + 1) : rank;
-      if (q == 0) sPerm[slot] = r;
+      const int slot = (SPW == 2 && !DROP) ? (rank < NSB / 2 ? 2 * rank : 2 * (NSB - 1 - rank) + 1) : rank;
+      if (q == 0 && r < NSB) sPerm[slot] = r;
       if (FLAT && q == 0) sPerm[16 + slot] = cl;
       wave_lds_fence();
       bidx = __shfl(cand, sPerm[srow], 16);   // (candidate of lane sPerm[srow] of the row)
@@ -1067,14 +1072,16 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 
     // B fragments of the bridge GEMM (K^T rows, L2-resident) do not depend on the barrier:
     // fetch them first so their latency overlaps the wait for the slowest wavefront
-    opd bfr[G::TPW][D / 16];
-#pragma unroll
-    for (int t = 0; t < G::TPW; ++t) {
+    // (only the first tile's: with two tiles per wavefront -- 8-sample workgroups -- the second's are fetched while the
+    //  first is computed; all of them up front were 64 registers across the barrier and P1's tail spilled)
+    opd bfr[D / 16];
+    auto load_B = [&](const float* Bmat, int t, opd (&dst)[D / 16]) {
       const int ct = (wave * G::TPW + t) % G::NT;
-      const float* Brow = a.p.dense_KT + (size_t)(16 * ct + r) * D + 4 * q;
+      const float* Brow = Bmat + (size_t)(16 * ct + r) * D + 4 * q;
 #pragma unroll
-      for (int kc = 0; kc < D / 16; ++kc) bfr[t][kc] = mm_pack<MM>(*(const f32x4*)(Brow + 16 * kc));
-    }
+      for (int kc = 0; kc < D / 16; ++kc) dst[kc] = mm_pack<MM>(*(const f32x4*)(Brow + 16 * kc));
+    };
+    load_B(a.p.dense_KT, 0, bfr);
     TLSAN_STAMP(1);
     __syncthreads();
     TLSAN_STAMP(2);
@@ -1083,25 +1090,32 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
     for (int t = 0; t < G::TPW; ++t) {
       const int task = wave * G::TPW + t, rt = task / G::NT, ct = task % G::NT;
+      opd bnx[D / 16];
+      if (t + 1 < G::TPW) load_B(a.p.dense_KT, t + 1, bnx);
       f32x4 acc0 = (f32x4)(dn[a.lay.k0 + 16 * ct + r]), acc1 = (f32x4)(0.0f);
-      const float* Arow = sA + (16 * rt + r) * LSTR + 4 * q;
+      const float* Arow = sA + (NSB >= 16 ? 16 * rt + r : (16 * rt + r) % NSB) * LSTR + 4 * q;   // (NSB = 8: rows 8..15 of the tile repeat 0..7, their results are dropped)
 #pragma unroll
       for (int kc = 0; kc < D / 16; kc += 2) {
         const opd av0 = mm_pack<MM>(*(const f32x4*)(Arow + 16 * kc)), av1 = mm_pack<MM>(*(const f32x4*)(Arow + 16 * kc + 16));
         if constexpr (MM == TLSAN_MATRIX_F32) {
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            acc0 = TLSAN_MFMA(av0[s], bfr[t][kc][s], acc0);
-            acc1 = TLSAN_MFMA(av1[s], bfr[t][kc + 1][s], acc1);
+            acc0 = TLSAN_MFMA(av0[s], bfr[kc][s], acc0);
+            acc1 = TLSAN_MFMA(av1[s], bfr[kc + 1][s], acc1);
           }
         } else {
-          acc0 = mm_mma<MM>(av0, bfr[t][kc], acc0);
-          acc1 = mm_mma<MM>(av1, bfr[t][kc + 1], acc1);
+          acc0 = mm_mma<MM>(av0, bfr[kc], acc0);
+          acc1 = mm_mma<MM>(av1, bfr[kc + 1], acc1);
         }
       }
       acc0 += acc1;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) sB[(16 * rt + 4 * q + i) * LSTR + 16 * ct + r] = acc0[i];
+      for (int i = 0; i < 4; ++i)
+        if (NSB >= 16 || 4 * q < NSB) sB[(16 * rt + 4 * q + i) * LSTR + 16 * ct + r] = acc0[i];
+      if (t + 1 < G::TPW) {
+#pragma unroll
+        for (int kc = 0; kc < D / 16; ++kc) bfr[kc] = bnx[kc];
+      }
     }
     TLSAN_STAMP(3);
     __syncthreads();
@@ -1497,13 +1511,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           stage_accs<NB, CPS, true>(acc, dk0, T, lane);
         }
       }
-#pragma unroll
-      for (int t = 0; t < G::TPW; ++t) {  // B fragments of the dlong GEMM (K rows), before the barrier
-        const int kt = (wave * G::TPW + t) % G::NT;
-        const float* Brow = dn + a.lay.K + (size_t)(16 * kt + r) * D + 4 * q;
-#pragma unroll
-        for (int jc = 0; jc < D / 16; ++jc) bfr[t][jc] = mm_pack<MM>(*(const f32x4*)(Brow + 16 * jc));
-      }
+      load_B(dn + a.lay.K, 0, bfr);  // B fragments of the dlong GEMM (K rows), before the barrier
       TLSAN_STAMP(6);
       __syncthreads();
       TLSAN_STAMP(7);
@@ -1514,30 +1522,37 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
       for (int t = 0; t < G::TPW; ++t) {
         const int task = wave * G::TPW + t, rt = task / G::NT, kt = task % G::NT;
+        opd bnx[D / 16];
+        if (t + 1 < G::TPW) load_B(dn + a.lay.K, t + 1, bnx);
         f32x4 acc0 = (f32x4)(0.0f), acc1 = (f32x4)(0.0f);
-        const float* Arow = sA + (16 * rt + r) * LSTR + 4 * q;
+        const float* Arow = sA + (NSB >= 16 ? 16 * rt + r : (16 * rt + r) % NSB) * LSTR + 4 * q;
 #pragma unroll
         for (int jc = 0; jc < D / 16; jc += 2) {
           const opd av0 = mm_pack<MM>(*(const f32x4*)(Arow + 16 * jc)), av1 = mm_pack<MM>(*(const f32x4*)(Arow + 16 * jc + 16));
           if constexpr (MM == TLSAN_MATRIX_F32) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-              acc0 = TLSAN_MFMA(av0[s], bfr[t][jc][s], acc0);
-              acc1 = TLSAN_MFMA(av1[s], bfr[t][jc + 1][s], acc1);
+              acc0 = TLSAN_MFMA(av0[s], bfr[jc][s], acc0);
+              acc1 = TLSAN_MFMA(av1[s], bfr[jc + 1][s], acc1);
             }
           } else {
-            acc0 = mm_mma<MM>(av0, bfr[t][jc], acc0);
-            acc1 = mm_mma<MM>(av1, bfr[t][jc + 1], acc1);
+            acc0 = mm_mma<MM>(av0, bfr[jc], acc0);
+            acc1 = mm_mma<MM>(av1, bfr[jc + 1], acc1);
           }
         }
         acc0 += acc1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) sB[(16 * rt + 4 * q + i) * LSTR + 16 * kt + r] = acc0[i];
+        for (int i = 0; i < 4; ++i)
+          if (NSB >= 16 || 4 * q < NSB) sB[(16 * rt + 4 * q + i) * LSTR + 16 * kt + r] = acc0[i];
+        if (t + 1 < G::TPW) {
+#pragma unroll
+          for (int jc = 0; jc < D / 16; ++jc) bfr[jc] = bnx[jc];
+        }
       }
       if constexpr (G::FUSE_DK) {
        if (FUSE_RT) {
         // ---- dK partial of this pass: C[k][j] = sum over the 16 samples of long[s][k] * dbridge[s][j]
-        // (A from sL, B from sA: both [sample][channel] rows in the LDS).  Samples are the K dimension: 4 k-steps of
+        // (A from sL, B from sA: both [sample][channel] rows in the LDS).  Samples are the K dimension: NSB / 4 k-steps of
         // 4 samples.  A wavefront owns half of a 64 x 64 quadrant: lane (q, r) reads channels 4r .. 4r+3 of sample
         // 4*step + q from both operands as 16-B pieces, and element t of a piece feeds tile t -- tile (ta, tb) holds
         // rows 4m + ta, columns 4n + tb of the quadrant -- so the accumulators of one (ta, i) are four consecutive
@@ -1554,7 +1569,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
           for (int tb = 0; tb < 4; ++tb) acc[x][tb] = (f32x4)(0.0f);
 #pragma unroll
-        for (int step = 0; step < 4; ++step) {
+        for (int step = 0; step < NSB / 4; ++step) {
           const f32x4 va = *(const f32x4*)(sL + (4 * step + q) * LSTR + M0 + 4 * r);
           const f32x4 vb = *(const f32x4*)(sA + (4 * step + q) * LSTR + N0 + 4 * r);
 #pragma unroll

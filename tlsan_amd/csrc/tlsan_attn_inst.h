@@ -9,13 +9,13 @@
 #endif
 
 // (mirrors the carve-up at the top of k_fwd_bwd; flat = the FLAT variant of the streamed windows, tlsan_attn.h)
-template <int D, int DH>
+template <int D, int DH, int NWV = 0>
 static size_t fwd_smem_bytes(bool train, bool lstream, bool fuse_dk, int Sn, bool cseg, bool drop) {
-  using G = Geo<D, DH>;
+  using G = Geo<D, DH, NWV>;
   const bool flat = lstream && !drop;
   const bool flatg = flat && G::NB > 1;      // (d = 256: statistics / long vectors in global memory, no LDS copy of the weights, no long slots)
   const int lsc = lstream ? TLSAN_LS_CAP : TLSAN_LS_MAX;
-  const int pstr = (flat ? 0 : lsc) + ((cseg || flatg) ? ((Sn + 3) & ~3) : TLSAN_SN_CAP) + 4;      // position slots per sample (k_fwd_bwd: PSTR), twice with CSEG
+  const int pstr = (flat ? 0 : lsc) + ((cseg || flatg || G::NSB < 16) ? ((Sn + 3) & ~3) : TLSAN_SN_CAP) + 4;      // position slots per sample (k_fwd_bwd: PSTR), twice with CSEG
   const int nf = flat ? G::NSB * TLSAN_LS_CAP : 0;
   return sizeof(float) * ((train ? G::NSB * pstr * (cseg ? 2 : 1) : 0) + 2 * G::NSB * G::LSTR + ((train && ((G::FUSE_DK && fuse_dk) || (flat && !flatg))) ? G::NSB * G::LSTR : 0) + G::NW * 4 + G::NSB * 2 * lsc +
                           ((G::USE_SW && !flatg) ? 2 * (2 * DH * DH + 2 * DH) : 0) + G::NW * G::WSCR +
@@ -24,15 +24,15 @@ static size_t fwd_smem_bytes(bool train, bool lstream, bool fuse_dk, int Sn, boo
                           (TLSAN_STAMPS ? G::NW * 32 * 2 : 0) /* diagnostic stamps */);
 }
 
-template <int D, int DH, bool TRAIN, bool LSTREAM, int DT, bool DROP = false, int MM = TLSAN_MATRIX_F32, bool CSEG = false>
+template <int D, int DH, bool TRAIN, bool LSTREAM, int DT, bool DROP = false, int MM = TLSAN_MATRIX_F32, bool CSEG = false, int NWV = 0>
 static hipError_t launch_variant_dt(const FwdArgs& a, int grid, hipStream_t st) {
   if constexpr (TRAIN && !CSEG) {   // tables with thousands of categories: the variant with category segments
-    if (a.cseg) return launch_variant_dt<D, DH, TRAIN, LSTREAM, DT, DROP, MM, true>(a, grid, st);
+    if (a.cseg) return launch_variant_dt<D, DH, TRAIN, LSTREAM, DT, DROP, MM, true, NWV>(a, grid, st);
   }
   // (the copy of `long` for the fused dK product only in launches that fuse: at d = 64 it is what decides whether two
   //  workgroups fit a CU's LDS -- 8192 sequences, not fused: 77 us/step with it left out, 95 with it)
-  const size_t smem = fwd_smem_bytes<D, DH>(TRAIN, LSTREAM, a.fuse_dk != 0, a.b.Sn, a.cseg != 0, DROP);
-  auto k = k_fwd_bwd<D, DH, TRAIN, LSTREAM, DT, DROP, MM, CSEG>;
+  const size_t smem = fwd_smem_bytes<D, DH, NWV>(TRAIN, LSTREAM, a.fuse_dk != 0, a.b.Sn, a.cseg != 0, DROP);
+  auto k = k_fwd_bwd<D, DH, TRAIN, LSTREAM, DT, DROP, MM, CSEG, NWV>;
   // (per kernel variant AND device: the attribute is raised once, not on every launch; relaxed atomics -- two threads
   //  racing on a first launch both raise it, which is harmless)
   static std::atomic<size_t> smem_set[TLSAN_MAX_DEVICES];
@@ -45,7 +45,7 @@ static hipError_t launch_variant_dt(const FwdArgs& a, int grid, hipStream_t st) 
       if (slot != nullptr) slot->store(smem, std::memory_order_relaxed);
     }
   }
-  hipLaunchKernelGGL(k, dim3(grid), dim3(Geo<D, DH>::NW * 64), smem, st, a);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(Geo<D, DH, NWV>::NW * 64), smem, st, a);
   return hipGetLastError();
 }
 
@@ -72,4 +72,17 @@ template <int D, int DH>
 static hipError_t launch_fwd_bwd_impl(bool train, bool lstream, const FwdArgs& a, int grid, hipStream_t st) {
   if (train) return lstream ? launch_variant<D, DH, true, true>(a, grid, st) : launch_variant<D, DH, true, false>(a, grid, st);
   return lstream ? launch_variant<D, DH, false, true>(a, grid, st) : launch_variant<D, DH, false, false>(a, grid, st);
+}
+
+// training step with the window in registers, no dropout, as NWV-wavefront workgroups (d = 128: 4 wavefronts, 8 samples)
+template <int D, int DH, int NWV>
+static hipError_t launch_train_nw(const FwdArgs& a, int grid, hipStream_t st) {
+  if (a.drop_thr != 0) return hipErrorNotSupported;
+  const bool tb = a.p.table_dtype == TLSAN_TABLE_BF16;
+  if (a.p.matrix_dtype == TLSAN_MATRIX_BF16) {
+    if (tb) return launch_variant_dt<D, DH, true, false, TLSAN_TABLE_BF16, false, TLSAN_MATRIX_BF16, false, NWV>(a, grid, st);
+    return launch_variant_dt<D, DH, true, false, TLSAN_TABLE_F32, false, TLSAN_MATRIX_BF16, false, NWV>(a, grid, st);
+  }
+  if (tb) return launch_variant_dt<D, DH, true, false, TLSAN_TABLE_BF16, false, TLSAN_MATRIX_F32, false, NWV>(a, grid, st);
+  return launch_variant_dt<D, DH, true, false, TLSAN_TABLE_F32, false, TLSAN_MATRIX_F32, false, NWV>(a, grid, st);
 }

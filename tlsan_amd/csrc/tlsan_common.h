@@ -146,7 +146,13 @@ __device__ __forceinline__ int opaque_zero(int x) {
   return z;
 }
 
-template <int D_, int DH_>
+// NW_: wavefronts per workgroup (0 = the default of the width).  d = 128 also runs as 4-wavefront workgroups of 8 samples
+// (Geo<128, 16, 4>), two of which fit a CU.  Measured in round 4 (profiles/r04_nw4_ab.md): at 4096 sequences -- two such
+// workgroups per CU instead of one of eight wavefronts -- the kernel is 15 % SLOWER (43.3 vs 37.7 us: the bridge GEMMs'
+// tiles are half empty, and starting one of a CU's two workgroups late never shortens the launch: a wavefront is bound
+// by its own dependent chain, not by its SIMD partner being in the same phase); it pays for small batches only, where
+// it puts a wavefront alone on a SIMD (B = 256: 45.6 -> 42.2 us/step, 1024: 53.7 -> 52.4), and is used there.
+template <int D_, int DH_, int NW_ = 0>
 struct Geo {
   static constexpr int D = D_;
   static constexpr int DH = DH_;                // channels per head (d / num_heads)
@@ -154,9 +160,9 @@ struct Geo {
   static constexpr int NB = CW / 16;            // 16-channel blocks per column
   static constexpr int CPS = D / CW;            // columns per sample
   static constexpr int SPW = 16 / CPS;          // samples per wavefront
-  static constexpr int NW = D_ == 64 ? 4 : 8;   // wavefronts per workgroup
+  static constexpr int NW = NW_ != 0 ? NW_ : (D_ == 64 ? 4 : 8);   // wavefronts per workgroup
   static constexpr int NSB = NW * SPW;          // samples per workgroup pass
-  static constexpr int RT = NSB / 16;           // 16-row tiles of the bridge GEMM
+  static constexpr int RT = (NSB + 15) / 16;    // 16-row tiles of the bridge GEMM (NSB = 8: one tile, half of its rows unused)
   static constexpr int NT = D / 16;             // 16-col tiles of the bridge GEMM
   static constexpr int TPW = RT * NT / NW;      // bridge tiles per wavefront
   static constexpr int LSTR = D + 4;            // LDS row stride of [sample][channel] buffers
