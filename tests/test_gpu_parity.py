@@ -1025,12 +1025,12 @@ def test_dk_product_in_the_tail_launch():
 
 
 def test_user_index_from_a_sort_of_the_batch():
-    """Tables of 65 536 users or more take the user side of a batch's destination index from a sort of the batch's user ids
-    (UsortArgs, one block of the scan's launch) instead of counters and a scan over the table.  TLSAN_USORT_MIN=1 (read
-    once per process) sends every table that way: the oracle tests of train steps -- small user tables, so batches full
-    of repeated users -- must hold."""
+    """Tables of 65 536 users or more take the user side of a batch's destination index from a partitioned counting sort of
+    the batch's user ids (IsortArgs: three short launches whose blocks keep a bucket's counters in the LDS) instead of
+    counters and a scan over the table.  TLSAN_ISORT_MIN=1 (read once per process) sends every table that way: the oracle
+    tests of train steps -- small user tables, so batches full of repeated users -- must hold."""
     import subprocess, sys
-    env = dict(os.environ, TLSAN_USORT_MIN="1")
+    env = dict(os.environ, TLSAN_ISORT_MIN="1")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-m", "gpu", "-q", "-x", "-k",
                         "test_train_step_matches_oracle or test_multi_step_tracks_oracle_and_is_deterministic or test_lazy_l2_matches_dense_oracle "
@@ -1039,18 +1039,55 @@ def test_user_index_from_a_sort_of_the_batch():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("nw4", ["0", "2"])
-def test_both_workgroup_geometries_of_d128(nw4):
-    """d = 128 with the window in registers runs as 8-wavefront workgroups of 16 samples, or -- batches of up to 1024
-    sequences, where those would leave most CUs idle -- as 4-wavefront workgroups of 8 (Geo<128, 16, 4>).  The other
-    tests see whichever their batch size selects; here TLSAN_NW4 (read once per process) forces each of the two over
-    the oracle tests of forward, gradients and train steps, and over the full-size property test."""
+_ISORT_DIGEST = r'''
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+from tests.helpers import make_config, random_batch, random_params
+from tlsan_amd.model import Model
+h = hashlib.sha256()
+for d, Ls, I, C in ((128, 10, 70000, 2100), (64, 33, 9000, 300), (128, 10, 300, 40)):
+    cfg = make_config(U=500, I=I, C=C, d=d, Ls=Ls, regulation_rate=1e-3)
+    p = {k: np.asarray(v, np.float32) for k, v in random_params(cfg, seed=11).items()}
+    _, cat = random_batch(cfg, B=8, Sn=3, seed=0)
+    m = Model(cfg, cat, l2_mode="lazy")
+    m.set_params(p)
+    bs = [random_batch(cfg, B=700, Sn=1 + s, seed=40 + s)[0] for s in range(4)]
+    for b in bs[:2]:                 # (collisions: ids folded onto a few hundred rows, some of them hot)
+        for k in ("hist_i", "hist_i_new", "i"):
+            b[k] %%= 257
+    tup = lambda b: (b["u"], b["i"], b["y"], b["hist_i"], b["hist_i_new"], b["hist_t"], b["sl"], b["sl_new"], b["u_cate"])
+    dbs = [m.device_batch(tup(b)) for b in bs]
+    for s in range(len(dbs)):        # (announced one / two ahead: the index of the batches after this one is built on the side stream)
+        m.train_async(dbs[s], 0.7, next_batch=dbs[s + 1] if s + 1 < len(dbs) else None, after_next=dbs[s + 2] if s + 2 < len(dbs) else None)
+    h.update(np.float32(m._out[0].item()).tobytes())
+    got = m.get_params()
+    for k in sorted(got):
+        h.update(np.ascontiguousarray(got[k]).tobytes())
+print("DIGEST", h.hexdigest())
+'''
+
+
+def test_item_index_from_a_counting_sort_of_the_batch():
+    """The item-side twin of the test above.  Item tables of 65 536 rows or more, in a lazy-L2 SGD step with category
+    segments, take the item side of a batch's destination index from a partitioned counting sort of the batch's item ids
+    (IsortArgs: buckets of consecutive ids, a bucket's counters in the LDS) instead of a global counter per table row
+    and two scans over them.  TLSAN_ISORT_MIN=1 with TLSAN_CSEG_MIN=1 (both read once per process) sends every table
+    that way: the oracle tests of lazy train steps must hold, and -- first positions are assigned in id order either
+    way -- four steps on three table shapes must leave the SAME BITS as the counter path (losses and every parameter)."""
     import subprocess, sys
-    env = dict(os.environ, TLSAN_NW4=nw4)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TLSAN_ISORT_MIN="1", TLSAN_CSEG_MIN="1")
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-m", "gpu", "-q", "-x", "-k",
-                        "test_forward_logits or test_gradients or test_train_step_matches_oracle or test_lazy_l2_matches_dense_oracle "
-                        "or test_multi_step_tracks_oracle_and_is_deterministic or test_full_size_batch_matches_oracle or test_full_scale_properties "
-                        "or test_bf16_tables or test_bf16_matrix_products or test_graph_replay_equals_eager or test_one_hot_row_takes_every_use"],
-                       cwd=root, env=env, capture_output=True, text=True, timeout=1800)
+                        "test_lazy_l2_matches_dense_oracle or test_lazy_is_deterministic or test_category_segments_match_oracle "
+                        "or test_full_size_batch_matches_oracle or test_long_windows_streamed or test_one_hot_row_takes_every_use "
+                        "or test_prefetched_index_equals_inline or test_periodic_scale_fold"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    digests = []
+    for isort_min in ("1", str(1 << 30)):
+        env = dict(os.environ, TLSAN_ISORT_MIN=isort_min, TLSAN_CSEG_MIN="1")
+        r = subprocess.run([sys.executable, "-c", _ISORT_DIGEST % root], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        digests.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1])
+    assert digests[0] == digests[1], digests

@@ -210,6 +210,15 @@ static inline bool uc_by_list(const tlsan_dims* d, const tlsan_batch* b) {
 // (the category counts of CSEG need the item -> category map: tlsan_batch_index takes it as an argument -- round 3 kept
 //  a process-global registry state -> map filled by tlsan_state_init, which a re-allocated map or a recycled state
 //  address left stale)
+// Tables of at least this many rows take their side of a lazy-SGD step's index from a sort of the batch's ids instead of
+// a counter per row -- when its consumers reach it through ids and records only: the user table (UsortArgs: a bucket
+// sort inside one block), the item table with category segments (IsortArgs: a partitioned counting sort, tlsan_update.h).
+// TLSAN_ISORT_MIN=<rows> for tests (read once per process; it also sizes the state).
+static int isort_min_rows() {
+  static const int v = [] { const char* e = getenv("TLSAN_ISORT_MIN"); return e ? atoi(e) : (1 << 16); }();
+  return v;
+}
+static bool isort_rows_ok(int rows) { return rows >= isort_min_rows() && (long)rows <= (long)IS_MAXB * IS_BSZ; }
 static inline bool cate_seg(const tlsan_dims* d, const tlsan_batch* b) {
   return d->cate_count >= cseg_min_cates() && !uc_by_list(d, b);
 }
@@ -232,6 +241,9 @@ struct St {  // persistent state
   int32_t* uc_list[TLSAN_INDEX_SLOTS];                                    // samples of every category (u_cate uses), UC_LIST_CAP each
   double* Rc64;                                           // category sums of a split PRESUM pass, zero at rest
   int32_t* hot_list[TLSAN_INDEX_SLOTS];                                   // slots (urec_item) of the hot item rows, AP_HOT_CAP each
+  // the item side of the index from a partitioned counting sort of the batch's ids (IsortArgs; tables of isort_min_rows() rows or more)
+  int32_t *is_bh[TLSAN_INDEX_SLOTS], *is_ids[TLSAN_INDEX_SLOTS], *is_bstart[TLSAN_INDEX_SLOTS], *is_nd[TLSAN_INDEX_SLOTS];
+  int4* is_tmp[TLSAN_INDEX_SLOTS];
   size_t bytes;
   int nbI, nbU, nbC;
 };
@@ -272,6 +284,16 @@ static void carve_state(const tlsan_dims* d, char* base, St* s) {
   s->dk_ticket = (int32_t*)take(4 * 256);
   s->scan_ticket = (int32_t*)take(4 * 64);
   for (int k = 0; k < TLSAN_INDEX_SLOTS; ++k) s->flag_user[k] = (int32_t*)take(4 * (((size_t)d->user_count + 255) / 256));
+  {
+    const bool on = isort_rows_ok(d->item_count);
+    for (int k = 0; k < TLSAN_INDEX_SLOTS; ++k) {
+      s->is_bh[k] = (int32_t*)take(on ? 4 * (size_t)(ISORT_MAX_SLOTS / IS_BLK_SLOTS) * IS_MAXB : 0);
+      s->is_ids[k] = (int32_t*)take(on ? 4 * (size_t)ISORT_MAX_SLOTS : 0);
+      s->is_bstart[k] = (int32_t*)take(on ? 4 * (size_t)(IS_MAXB + 1) : 0);
+      s->is_nd[k] = (int32_t*)take(on ? 4 * (size_t)IS_MAXB : 0);
+      s->is_tmp[k] = (int4*)take(on ? 16 * (size_t)ISORT_MAX_SLOTS : 0);
+    }
+  }
   s->S_total = base ? &s->hdr->St : nullptr;
   s->bytes = o;
 }
@@ -458,7 +480,8 @@ static int launch_scan(ScanArgs& sa, int nscan, long long* bsum, hipStream_t hs)
   }
   sa.bal.blk = nscan;
   sa.us.blk = nscan + (sa.bal.perm ? 1 : 0);
-  hipLaunchKernelGGL(k_index_scan, dim3(nscan + (sa.bal.perm ? 1 : 0) + (sa.us.u ? 1 : 0)), dim3(1024), 0, hs, sa);
+  sa.is.blk = sa.us.blk + (sa.us.u ? 1 : 0);       // (the finishing blocks of the item side's counting sort come last)
+  hipLaunchKernelGGL(k_index_scan, dim3(sa.is.blk + (sa.is.on ? sa.is.nfin : 0)), dim3(1024), 0, hs, sa);
   CHECK_LAUNCH("k_index_scan");
   return TLSAN_OK;
 }
@@ -657,26 +680,60 @@ static int build_index(const tlsan_dims* d, const tlsan_batch* b, const int32_t*
   ca.item_cate = cseg ? item_cate : nullptr; ca.cseg = cseg ? 1 : 0;
   ca.ncate = d->cate_count;
   ca.flag_user = st.flag_user[k];
-  // the user side from a sort of the batch's ids (UsortArgs) when only the used rows are wanted and the table is large
-  static const int usort_min = [] { const char* v = getenv("TLSAN_USORT_MIN"); return v ? atoi(v) : (1 << 16); }();
-  const bool usort = sparse_users && b->B <= USORT_MAX && d->user_count >= usort_min;
-  ca.skip_users = usort ? 1 : 0;
+  // a table's side from a sort of the batch's ids when only the used rows are wanted and the table is large: the user
+  // table (UsortArgs); the item table (IsortArgs) when a lazy-SGD step with category segments consumes the index (it
+  // reaches item offsets / cursors through ids and records only)
   const int nthr = b->B * (d->Ls + b->Sn + 1);
-  hipLaunchKernelGGL(k_count, dim3((b->B + 255) / 256 + (nthr + 255) / 256), dim3(256), 0, hs, ca);
-  CHECK_LAUNCH("k_count");
+  const bool usort = sparse_users && b->B <= USORT_MAX && d->user_count >= isort_min_rows();
+  const bool isort = sparse_users && cseg && nthr <= ISORT_MAX_SLOTS && isort_rows_ok(d->item_count);
+  ca.skip_users = usort ? 1 : 0;
   ScanArgs sa;
   memset(&sa, 0, sizeof(sa));
+  if (isort) {
+    IsortArgs& ia = sa.is;
+    ia.on = 1;
+    ia.b = *b; ia.Ls = d->Ls;
+    ia.nbu = (b->B + 1023) / 1024;   // (k_count's sample blocks: k_count does not run)
+    ia.n = d->item_count;
+    ia.shift = 0;   // few, full buckets: up to IS_BSZ ids each, at least 64 of them
+    while (((ia.n - 1) >> ia.shift) >= IS_MAXB || ((1 << ia.shift) < IS_BSZ && ((ia.n - 1) >> ia.shift) >= 64)) ++ia.shift;
+    ia.nb = ((ia.n - 1) >> ia.shift) + 1;
+    ia.nslots = nthr;
+    ia.nblk = (nthr + IS_BLK_SLOTS - 1) / IS_BLK_SLOTS;
+    ia.bh = st.is_bh[k]; ia.ids = st.is_ids[k]; ia.bstart = st.is_bstart[k]; ia.nd = st.is_nd[k]; ia.tmp = st.is_tmp[k];
+    ia.cur = st.cur_item[k]; ia.off = st.off_item[k]; ia.urec = st.urec_item[k];
+    ia.n_uniq = &st.hdr->n_uniq[k][0]; ia.hot_n = &st.hdr->n_hot[k]; ia.hot_list = st.hot_list[k];
+    ia.item_cate = item_cate; ia.cnt_uc = st.cnt_uc[k];
+    ia.nfin = (ia.nb + 15) / 16;
+    hipLaunchKernelGGL(k_isort_hist, dim3(ia.nbu + ia.nblk), dim3(1024), 0, hs, ia, ca);
+    CHECK_LAUNCH("k_isort_hist");
+    hipLaunchKernelGGL(k_isort_scatter, dim3(ia.nblk), dim3(1024), 0, hs, ia);
+    CHECK_LAUNCH("k_isort_scatter");
+    UsortArgs ua;   // (the user side's sort rides in this launch: as long as a bucket block, and needed by nothing before the step)
+    memset(&ua, 0, sizeof(ua));
+    if (usort) {
+      ua.u = b->u; ua.B = b->B; ua.U = d->user_count;
+      ua.cur = st.cur_user[k]; ua.off = st.off_user[k]; ua.urec = st.urec_user[k]; ua.n_uniq = &st.hdr->n_uniq[k][1];
+    }
+    hipLaunchKernelGGL(k_isort_bucket, dim3(ia.nb + (usort ? 1 : 0)), dim3(1024), 0, hs, ia, ua);
+    CHECK_LAUNCH("k_isort_bucket");
+  } else {
+    hipLaunchKernelGGL(k_count, dim3((b->B + 255) / 256 + (nthr + 255) / 256), dim3(256), 0, hs, ca);
+    CHECK_LAUNCH("k_count");
+  }
   sa.cnt[0] = st.cnt_item[k]; sa.cnt[1] = st.cnt_uc[k]; sa.cnt[2] = st.cnt_user[k];
   sa.off[0] = st.off_item[k]; sa.off[1] = st.off_uc[k]; sa.off[2] = st.off_user[k];
   sa.cur[0] = st.cur_item[k]; sa.cur[1] = st.cur_uc[k]; sa.cur[2] = st.cur_user[k];
-  sa.n[0] = d->item_count; sa.n[1] = d->cate_count; sa.n[2] = d->user_count;
+  sa.n[0] = isort ? 0 : d->item_count; sa.n[1] = d->cate_count; sa.n[2] = d->user_count;
   sa.blk0[0] = 0;
   sa.blk0[1] = (sa.n[0] + 4095) / 4096;
   sa.blk0[2] = sa.blk0[1] + (sa.n[1] + 4095) / 4096;
   if (usort) {
     sa.n[2] = 0;
-    sa.us.u = b->u; sa.us.B = b->B; sa.us.U = d->user_count;
-    sa.us.cur = st.cur_user[k]; sa.us.off = st.off_user[k]; sa.us.urec = st.urec_user[k]; sa.us.n_uniq = &st.hdr->n_uniq[k][1];
+    if (!isort) {   // (with the items sorted as well, k_isort_bucket's launch had it)
+      sa.us.u = b->u; sa.us.B = b->B; sa.us.U = d->user_count;
+      sa.us.cur = st.cur_user[k]; sa.us.off = st.off_user[k]; sa.us.urec = st.urec_user[k]; sa.us.n_uniq = &st.hdr->n_uniq[k][1];
+    }
   }
   const int nscan = sa.blk0[2] + (sa.n[2] + 4095) / 4096;
   sa.urec[0] = st.urec_item[k]; sa.urec[2] = st.urec_user[k];

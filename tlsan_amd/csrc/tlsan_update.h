@@ -54,7 +54,7 @@ struct CountArgs {
   int32_t cseg;
   int32_t ncate;        // categories (rows of cnt_uc)
   int32_t* flag_user;   // optional: [ceil(U / 256)] set where a user row of that 256-row piece is counted (ScanArgs.flag)
-  int32_t skip_users;   // != 0: the user side of the index comes from a sort of the batch's user ids (UsortArgs): no counts
+  int32_t skip_users;   // != 0: the user side of the index comes from the counting sort of the batch's user ids (IsortArgs): no counts
 };
 
 // Use counts per destination row: one thread per (sample, slot); slots [0,Ls) long positions,
@@ -65,31 +65,36 @@ struct CountArgs {
 // atomics on ONE address execute one after the other (~100 ns each across the XCDs), and with few categories (15 in
 // Movies-TV: 273 samples per category) the 4096 u_cate counts alone took 30 us of this kernel's 50.
 #define COUNT_LDS_CATES 4096
+// one thread per sample (b; nthr threads in the block): the user use and the u_cate use
+__device__ __forceinline__ void count_samples_block(const CountArgs& a, int* hist, int b, int nthr) {
+  const int B = a.b.B;
+  if (b == 0 && a.n_hot) *a.n_hot = 0;
+  const bool small = a.ncate <= COUNT_LDS_CATES;
+  if (small) {
+    for (int c = threadIdx.x; c < a.ncate; c += nthr) hist[c] = 0;
+    __syncthreads();
+  }
+  if (b < B) {
+    if (!a.skip_users) {
+      atomicAdd(&a.cnt_user[a.b.u[b]], 1);
+      if (a.flag_user) a.flag_user[a.b.u[b] >> 8] = 1;
+    }
+    if (small) atomicAdd(&hist[a.b.u_cate[b]], 1);
+    else atomicAdd(&a.cnt_uc[a.b.u_cate[b]], 1);
+  }
+  if (small) {
+    __syncthreads();
+    for (int c = threadIdx.x; c < a.ncate; c += nthr)
+      if (hist[c] != 0) atomicAdd(&a.cnt_uc[c], hist[c]);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_count(CountArgs a) {
   __shared__ int hist[COUNT_LDS_CATES];
   const int B = a.b.B, Ls = a.Ls, Sn = a.b.Sn, S = Ls + Sn + 1;
   const int nbs = (B + 255) / 256;
   if ((int)blockIdx.x < nbs) {   // ---- one thread per sample: the user use
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b == 0 && a.n_hot) *a.n_hot = 0;
-    const bool small = a.ncate <= COUNT_LDS_CATES;
-    if (small) {
-      for (int c = threadIdx.x; c < a.ncate; c += 256) hist[c] = 0;
-      __syncthreads();
-    }
-    if (b < B) {
-      if (!a.skip_users) {
-        atomicAdd(&a.cnt_user[a.b.u[b]], 1);
-        if (a.flag_user) a.flag_user[a.b.u[b] >> 8] = 1;
-      }
-      if (small) atomicAdd(&hist[a.b.u_cate[b]], 1);
-      else atomicAdd(&a.cnt_uc[a.b.u_cate[b]], 1);
-    }
-    if (small) {
-      __syncthreads();
-      for (int c = threadIdx.x; c < a.ncate; c += 256)
-        if (hist[c] != 0) atomicAdd(&a.cnt_uc[c], hist[c]);
-    }
+    count_samples_block(a, hist, blockIdx.x * 256 + threadIdx.x, 256);
     return;
   }
   const int t = (blockIdx.x - nbs) * 256 + threadIdx.x;
@@ -257,12 +262,20 @@ __device__ __forceinline__ void balance_block(const BalArgs& b) {   // 1024 thre
   if (B + tid < 16 * G) place(B + tid, B);   // (a last group that is not full)
 }
 
-// The user side of a batch's destination index WITHOUT a pass over the user table (one more block of the scan's launch):
-// a batch holds B user uses (one per sample), so the used rows, their counts and first positions come from a sort of the
-// B ids -- bitonic, in the LDS, B <= USORT_MAX -- where the counting form reads (and two scan kernels walk) a counter per
-// table row: 10 M users are 2442 of a 10 M + 5 M-row index's 3666 scan blocks.  Writes exactly what the scan writes
-// for a table with `sparse` set: cur / off of the used rows, their records (ascending), their number, off[U].
-#define USORT_MAX 8192
+// ------------------------------------------------------------------------------------------
+// The USER side of a batch's destination index without a pass over the user table (one more block of the scan's
+// launch): a batch holds B user uses (one per sample), so the used rows, their counts and first positions come from a
+// sort of the B ids, B <= USORT_MAX, where the counting form reads (and two scan kernels walk) a counter per table row:
+// 10 M users are 2442 of a 10 M + 5 M-row index's 3666 scan blocks.  Writes exactly what the scan writes for a table
+// with `sparse` set: cur / off of the used rows, their records (ascending), their number, off[U].
+// Round 3 sorted with a bitonic network: 78 barrier-separated phases, ~45 us for ONE block -- and a block that sits on a
+// CU that long keeps the fused kernel of the next step, which needs every CU's whole LDS, from placing its last
+// workgroup (k_fwd_bwd 45 -> 72 us every other step at 10 M users / 5 M items).  Now a bucket sort in eight phases:
+// 1024 buckets of consecutive ids (counted, scanned, filled through LDS cursors), then every id ranks itself inside
+// its bucket by counting (smaller ids, and equal ones that came earlier in the bucket) -- a handful of compares per id
+// for ids that are spread over the table, O(bucket) each if a batch repeats one user thousands of times.
+#define USORT_MAX 4096
+#define USORT_NB 1024
 struct UsortArgs {
   const int32_t* u; int32_t B, U;
   int32_t* cur; int32_t* off; int4* urec; int32_t* n_uniq;
@@ -270,27 +283,76 @@ struct UsortArgs {
 };
 
 __device__ __forceinline__ void usort_block(const UsortArgs& a) {   // 1024 threads
-  __shared__ int key[USORT_MAX];
-  __shared__ int ustart[USORT_MAX];
+  __shared__ int key[USORT_MAX];      // the ids: as they come, later sorted
+  __shared__ int srt[USORT_MAX];      // grouped by bucket
+  __shared__ int ustart[USORT_MAX];   // bucket counts | cursors, later the first sorted position of every run
+  __shared__ int bst[USORT_NB];       // first position of every bucket
   __shared__ int wtot[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int N = 1024;
-  while (N < a.B) N <<= 1;
-  for (int i = tid; i < N; i += 1024) key[i] = i < a.B ? a.u[i] : 0x7fffffff;
+  constexpr int CH = USORT_MAX / 1024;
+  int shift = 0;
+  while (((a.U - 1) >> shift) >= USORT_NB) ++shift;
+  int* bcnt = ustart;                 // [USORT_NB] uses per bucket
+  int* bcur = ustart + USORT_NB;      // [USORT_NB] fill cursors
+  bcnt[tid] = 0;
+  int x[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int i = c * 1024 + tid;
+    x[c] = i < a.B ? a.u[i] : -1;
+  }
   __syncthreads();
-  for (int k = 2; k <= N; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < N / 2; t += 1024) {
-        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
-        const bool up = (i & k) == 0;
-        const int x = key[i], y = key[p];
-        if ((x > y) == up) { key[i] = y; key[p] = x; }
-      }
-      __syncthreads();
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+    if (x[c] >= 0) atomicAdd(&bcnt[x[c] >> shift], 1);
+  __syncthreads();
+  {   // exclusive scan of the bucket counts (one per thread)
+    const int v = bcnt[tid];
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(inc, o);
+      if (lane >= o) inc += t;
     }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    int pre = inc - v;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) pre += (w < wave) ? wtot[w] : 0;
+    bst[tid] = pre;
+    bcur[tid] = pre;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+    if (x[c] >= 0) srt[atomicAdd(&bcur[x[c] >> shift], 1)] = x[c];
+  __syncthreads();
+  // every entry of srt ranks itself inside its bucket
+  int dst[CH], val[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int p = c * 1024 + tid;
+    dst[c] = -1;
+    if (p < a.B) {
+      const int v = srt[p], bk = v >> shift, s0 = bst[bk], n = bcnt[bk];
+      int rank = 0;
+      for (int j = s0; j < s0 + n; ++j) {
+        const int y = srt[j];
+        rank += (y < v || (y == v && j < p)) ? 1 : 0;
+      }
+      dst[c] = s0 + rank;
+      val[c] = v;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+    if (dst[c] >= 0) key[dst[c]] = val[c];
+  __syncthreads();
   // runs of equal ids: a thread takes CH consecutive sorted entries
-  const int CH = N / 1024, i0 = tid * CH;
+  const int i0 = tid * CH;
   int mine = 0;
+#pragma unroll
   for (int c = 0; c < CH; ++c) {
     const int i = i0 + c;
     mine += (i < a.B && (i == 0 || key[i] != key[i - 1])) ? 1 : 0;
@@ -309,6 +371,7 @@ __device__ __forceinline__ void usort_block(const UsortArgs& a) {   // 1024 thre
     j += (w < wave) ? wtot[w] : 0;
     nu += wtot[w];
   }
+#pragma unroll
   for (int c = 0; c < CH; ++c) {
     const int i = i0 + c;
     if (i < a.B && (i == 0 || key[i] != key[i - 1])) ustart[j++] = i;
@@ -323,6 +386,231 @@ __device__ __forceinline__ void usort_block(const UsortArgs& a) {   // 1024 thre
   if (tid == 0) {
     *a.n_uniq = nu;
     a.off[a.U] = a.B;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// The ITEM side of a batch's destination index without a counter per table row (round 4): a partitioned counting sort of
+// the batch's item uses (window, session, candidate).  With millions of items the counting form costs a global atomic
+// per use on a table that does not fit the caches and two passes over every counter (k_scan_block_sums + k_index_scan:
+// 16 + 41 us for 5 M items on an otherwise idle GPU); here the work is proportional to the batch.  The ids are split
+// into buckets of 2^shift consecutive ids (at most IS_MAXB buckets of at most IS_BSZ ids: tables up to 16 M rows), and a
+// bucket's counters live in the LDS:
+//   k_isort_hist      blocks of IS_BLK_SLOTS use slots: LDS histogram over the buckets -> one row of `bh` per block
+//                     (its leading blocks take the samples' single uses, as k_count's do)
+//   k_isort_scatter   same blocks: a bucket's first position = uses of lower buckets + this bucket's uses in earlier
+//                     blocks (column sums of bh, read by every block from the L2); ids scattered into their bucket's
+//                     range of `ids` (order inside a bucket: whatever the LDS atomics give -- it does not matter)
+//   k_isort_bucket    one block per bucket: counts of its ids in the LDS, scanned -> for every used id its first sorted
+//                     position (cur / off, written for used rows only) and its record (id, first, uses) at the
+//                     bucket's own range of `tmp`; category segments: uses added to the id's category counter, one
+//                     atomic per used ROW instead of one per use
+//   isort_finish      (blocks of k_index_scan's launch, beside the category scan) records compacted into urec in id
+//                     order, hot rows listed, n_uniq, off[I]
+// Writes what the scan writes for a table with `sparse` set -- a fixed function of the batch (records ascending by id;
+// the hot list's order is the atomics', as before).  Consumers must reach off / cur through ids or records only: the
+// lazy-L2 SGD step with category segments (tlsan_api.hip: build_index).
+#define IS_MAXB 2048
+#define IS_BSZ 8192
+#define IS_BLK_SLOTS 4096
+#define ISORT_MAX_SLOTS (1 << 20)
+struct IsortArgs {
+  int32_t on;               // 0: the item side is counted per row (k_count)
+  tlsan_batch b; int32_t Ls;
+  int32_t nbu;              // leading blocks of k_isort_hist that take the samples' single uses (1024 samples each)
+  int32_t n, shift, nb;     // rows of the table; nb buckets of 2^shift ids
+  int32_t nslots, nblk;     // B * (Ls + Sn + 1) use slots in nblk blocks of IS_BLK_SLOTS
+  int32_t* bh;              // [nblk][nb] uses per block and bucket
+  int32_t* ids;             // [<= nslots] the valid slots' ids, grouped by bucket
+  int32_t* bstart;          // [nb + 1] first position of every bucket
+  int32_t* nd;              // [nb] used rows of every bucket
+  int4* tmp;                // [<= nslots] records, at the bucket's own positions
+  int32_t* cur; int32_t* off; int4* urec; int32_t* n_uniq;
+  int32_t* hot_n; int32_t* hot_list;                           // rows with more than AP_HOT uses
+  const int32_t* item_cate; int32_t* cnt_uc;                   // category segments: uses counted into the row's category
+  int32_t blk, nfin;        // k_index_scan's launch: first finishing block, their number (16 buckets each)
+};
+
+// item id of use slot t (k_count's enumeration: sample-major; long positions, session positions, the candidate), -1: padding
+__device__ __forceinline__ int isort_slot_id(const IsortArgs& a, int t) {
+  if (t >= a.nslots) return -1;
+  const tlsan_batch& b = a.b;
+  const int Ls = a.Ls, Sn = b.Sn, S = Ls + Sn + 1;
+  const int smp = t / S, slot = t - smp * S;
+  if (slot < Ls) return slot < min(b.sl[smp], Ls) ? b.hist_i[(size_t)smp * Ls + slot] : -1;
+  if (slot < Ls + Sn) return (slot - Ls) < min(b.sl_new[smp], Sn) ? b.hist_i_new[(size_t)smp * Sn + (slot - Ls)] : -1;
+  return b.i[smp];
+}
+#define IS_PT (IS_BLK_SLOTS / 1024)   // slots per thread
+
+__global__ __launch_bounds__(1024) void k_isort_hist(IsortArgs a, CountArgs ca) {
+  __shared__ int h[COUNT_LDS_CATES > IS_MAXB ? COUNT_LDS_CATES : IS_MAXB];
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < a.nbu) {     // the samples' single uses (u_cate row; user row unless sorted)
+    count_samples_block(ca, h, blockIdx.x * 1024 + tid, 1024);
+    return;
+  }
+  const int blk = (int)blockIdx.x - a.nbu;
+  h[tid] = 0;
+  h[tid + 1024] = 0;
+  __syncthreads();
+  int id[IS_PT];
+#pragma unroll
+  for (int k = 0; k < IS_PT; ++k) id[k] = isort_slot_id(a, blk * IS_BLK_SLOTS + k * 1024 + tid);
+#pragma unroll
+  for (int k = 0; k < IS_PT; ++k)
+    if (id[k] >= 0) atomicAdd(&h[id[k] >> a.shift], 1);
+  __syncthreads();
+  for (int c = tid; c < a.nb; c += 1024) a.bh[(size_t)blk * a.nb + c] = h[c];
+}
+
+__global__ __launch_bounds__(1024) void k_isort_scatter(IsortArgs a) {
+  __shared__ int base[IS_MAXB];
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x;
+  // the ids first: their loads fly while the column sums are formed
+  int id[IS_PT];
+#pragma unroll
+  for (int k = 0; k < IS_PT; ++k) id[k] = isort_slot_id(a, blk * IS_BLK_SLOTS + k * 1024 + tid);
+  // thread t owns buckets 2t and 2t + 1 (consecutive: the exclusive scan over the threads' pairs is the scan over buckets)
+  int below[2] = {0, 0}, total[2] = {0, 0};
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int c = 2 * tid + e;
+    if (c < a.nb) {
+      const int32_t* col = a.bh + c;
+      for (int j0 = 0; j0 < a.nblk; j0 += 8) {   // 8 loads in flight
+        int v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = col[(size_t)min(j0 + u, a.nblk - 1) * a.nb];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int xx = (j0 + u < a.nblk) ? v[u] : 0;
+          total[e] += xx;
+          below[e] += (j0 + u < blk) ? xx : 0;
+        }
+      }
+    }
+  }
+  const int tsum = total[0] + total[1];
+  int inc = tsum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int start = inc - tsum;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) start += (w < wave) ? wsum[w] : 0;
+  base[2 * tid] = start + below[0];
+  base[2 * tid + 1] = start + total[0] + below[1];
+  if (blk == 0) {
+    if (2 * tid < a.nb) a.bstart[2 * tid] = start;
+    if (2 * tid + 1 < a.nb) a.bstart[2 * tid + 1] = start + total[0];
+    if (2 * tid == a.nb - 1 || 2 * tid + 1 == a.nb - 1) a.bstart[a.nb] = start + tsum;   // (the last bucket's owner: nothing lies behind it)
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < IS_PT; ++k)
+    if (id[k] >= 0) a.ids[atomicAdd(&base[id[k] >> a.shift], 1)] = id[k];
+}
+
+// (its FIRST block, when us.u is set, is the user side's sort: independent of everything here and the longest block of
+//  the launch -- dispatched first it runs beside the bucket blocks; inside k_index_scan's launch it was the long pole)
+__global__ __launch_bounds__(1024) void k_isort_bucket(IsortArgs a, UsortArgs us) {
+  const int ub = us.u != nullptr ? 1 : 0;
+  if (ub && blockIdx.x == 0) {
+    usort_block(us);
+    return;
+  }
+  __shared__ int h[IS_BSZ];
+  __shared__ long long wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = (int)blockIdx.x - ub;
+  const int lo = a.bstart[b], n = a.bstart[b + 1] - lo;
+  if (n == 0) {   // (block-uniform)
+    if (tid == 0) a.nd[b] = 0;
+    return;
+  }
+  const int id0 = b << a.shift;
+  constexpr int PER = IS_BSZ / 1024;
+#pragma unroll
+  for (int e = 0; e < PER; ++e) h[e * 1024 + tid] = 0;
+  __syncthreads();
+  for (int j = tid; j < n; j += 1024) atomicAdd(&h[a.ids[lo + j] - id0], 1);
+  __syncthreads();
+  int c[PER];
+  long long tsum = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    c[k] = h[tid * PER + k];
+    tsum += (long long)c[k] + ((long long)(c[k] > 0) << 32);
+  }
+  long long inc = tsum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const long long t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  long long run = inc - tsum;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) run += (w < wave) ? wsum[w] : 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    if (c[k] > 0) {
+      const int id = id0 + tid * PER + k, first = lo + (int)(run & 0xffffffffLL);
+      a.cur[id] = first;
+      a.off[id] = first;
+      a.tmp[lo + (int)(run >> 32)] = make_int4(id, first, c[k], 0);
+      if (a.cnt_uc != nullptr) atomicAdd(&a.cnt_uc[a.item_cate[id]], c[k]);
+      run += (long long)c[k] + (1LL << 32);
+    }
+  }
+  if (tid == 1023) a.nd[b] = (int)(run >> 32);
+}
+
+// one finishing block (k_index_scan's launch): 16 buckets, one per wavefront -- records to their place in urec
+__device__ __forceinline__ void isort_finish_block(const IsortArgs& a, int j) {
+  __shared__ int dbase[IS_MAXB];
+  __shared__ int wtot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int v0 = 2 * tid < a.nb ? a.nd[2 * tid] : 0, v1 = 2 * tid + 1 < a.nb ? a.nd[2 * tid + 1] : 0;
+  int inc = v0 + v1;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wtot[wave] = inc;
+  __syncthreads();
+  int pre = inc - (v0 + v1), nu = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    pre += (w < wave) ? wtot[w] : 0;
+    nu += wtot[w];
+  }
+  dbase[2 * tid] = pre;
+  dbase[2 * tid + 1] = pre + v0;
+  __syncthreads();
+  const int bb = j * 16 + wave;
+  if (bb < a.nb) {
+    const int n = a.nd[bb], d0 = dbase[bb];
+    const int4* src = a.tmp + a.bstart[bb];
+    for (int r = lane; r < n; r += 64) {
+      const int4 rec = src[r];
+      a.urec[d0 + r] = rec;
+      if (rec.z > AP_HOT) {
+        const int hh = atomicAdd(a.hot_n, 1);
+        if (hh < AP_HOT_CAP) a.hot_list[hh] = d0 + r;
+      }
+    }
+  }
+  if (j == 0 && tid == 0) {
+    *a.n_uniq = nu;
+    a.off[a.n] = a.bstart[a.nb];
   }
 }
 
@@ -348,6 +636,7 @@ struct ScanArgs {
   int32_t* bs_ticket;   // optional (with bsum): arrival counter of k_scan_block_sums, zero at rest -- its last block scans the sums
   BalArgs bal;         // optional (bal.perm): one more block ranks the batch's samples for the fused kernel's workgroups
   UsortArgs us;        // optional (us.u): one more block builds the user side of the index from a sort of the batch's ids
+  IsortArgs is;        // optional (is.on): is.nfin more blocks finish the item side built by the k_isort_* launches
 };
 #define SCAN_TWO_LEVEL_BLOCKS 16  // tables of more chunks than this take the two-launch form
 
@@ -439,6 +728,10 @@ __global__ __launch_bounds__(1024) void k_index_scan(ScanArgs a) {
   }
   if (a.us.u != nullptr && (int)blockIdx.x == a.us.blk) {
     usort_block(a.us);
+    return;
+  }
+  if (a.is.on != 0 && (int)blockIdx.x >= a.is.blk) {
+    isort_finish_block(a.is, (int)blockIdx.x - a.is.blk);
     return;
   }
   __shared__ long long wsum[16];
