@@ -243,6 +243,29 @@ def main():
     lr = 1.0
     lib = L.load()
 
+    def committed_traffic(key):
+        """HBM-side bytes per launch of k_fwd_bwd come from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in separate runs,
+        FETCH doubled per MI355X_MICROARCH.md); counters cannot be read from inside this process, so the line carries the
+        committed measurement WITH its provenance (profiles/traffic.json, scripts/refresh_profiles.sh).  key: None (the
+        fp32 headline) / 'bf16_tables' / 'bf16_mfma'.  Only for the bench's own shape."""
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if not (os.path.exists(tpath) and args.workload == "electronics" and B == cfg["train_batch_size"] and not sharded):
+            return None, None
+        try:
+            tj = json.load(open(tpath))
+            node = tj if key is None else tj.get(key)
+            if not node or "k_fwd_bwd_hbm_bytes_per_launch" not in node:
+                return None, None
+            t = node["k_fwd_bwd_hbm_bytes_per_launch"]
+            src = {"bytes": t, "source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH "
+                   "doubled; not measured by this run)", "round": tj.get("round"),
+                   "FETCH_SIZE_KB": node.get("FETCH_SIZE_KB"), "WRITE_SIZE_KB": node.get("WRITE_SIZE_KB")}
+            if key is None and "step" in tj:
+                src["step_hbm_bytes"] = tj["step"].get("hbm_bytes_per_step")
+            return t, src
+        except Exception:
+            return None, None
+
     use_graph = bool(args.graph) and not sharded
     # (Geo::FUSE_DK + fused_dk() in tlsan_api.hip: the dK product rides in k_fwd_bwd -- no k_dk_partial launch -- for
     #  d <= 128 and at most 256 sample groups per launch)
@@ -277,19 +300,27 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    run(args.warmup, 0)
+    # the destination indices are built two batches ahead: the first steps behind a fence still build their own (and
+    # their successors') -- a few untimed steps beyond --warmup let that pipeline fill, so that a short timed window
+    # (the round-end driver times 20 steps after 5) reads the steady state (round 3: 65.8 us/step there, 61.3 over 200)
+    fill = 4 if (args.prefetch >= 2 or (sharded and model.static_rows)) and not use_graph else 0
+    run(args.warmup + fill, 0)
+    fence_warm = args.warmup + fill
+    if fill:          # (no fence between the fill steps and the timed ones would be better still; the contract wants one)
+        torch.cuda.synchronize()
     fence()
     t0 = time.perf_counter()
-    run(args.steps, args.warmup, timed=False)
+    run(args.steps, fence_warm, timed=False)
     fence()
     dt = time.perf_counter() - t0
-    # the kernel's own duration: HIP events around k_fwd_bwd on its stream (tlsan_profile_*), live, in a pass of the SAME
-    # steps right behind the timed ones -- an event is a barrier packet in the queue and costs the step that carries it
-    # ~6 us, so the timed steps carry none (round 2 had them on every 10th timed step)
+    # the kernel's own duration: a pair of HIP events ATTACHED TO k_fwd_bwd's dispatch on its stream (hipExtLaunchKernelGGL
+    # through tlsan_profile_*: the dispatch's own begin / end time stamps, which is what a rocprofv3 kernel trace reports),
+    # live, in a pass of the SAME steps right behind the timed ones.  (Rounds 2-3 recorded two events AROUND the launch:
+    # barrier packets of their own that read ~3 us longer than the trace and cost the step that carried them ~6 us.)
     nprof = min(args.steps, 4096)
     lib.tlsan_profile_stride(1 if use_graph else args.event_every)   # graph mode: only the eager steps reach the marks
     lib.tlsan_profile_enable(args.profile_level)
-    run(nprof, args.warmup + args.steps, timed=True)     # (continues the batch cycle: the next two batches are announced)
+    run(nprof, fence_warm + args.steps, timed=True)     # (continues the batch cycle: the next two batches are announced)
     fence()
     buf = (ctypes.c_float * (nprof * 5))()
     nrec = lib.tlsan_profile_collect(buf, nprof)
@@ -309,73 +340,61 @@ def main():
         # and fp32 arithmetic, (b) bf16 tables AND bf16 matrix products (v_mfma_f32_16x16x16_bf16: operands rounded to
         # bf16, fp32 products and sums; logits then agree with the fp32 oracle to ~1e-3 of their scale, not 1e-4).
         # Reported beside the fp32 headline, never instead of it.
-        def variant(table_dtype, matrix_dtype, what):
+        def variant(table_dtype, matrix_dtype, what, tkey):
             import gc
             gc.collect()                  # (the previous model's buffers and streams go before the next one is built)
             torch.cuda.synchronize()
             mv = Model(cfg, icl, device=dev, l2_mode=args.l2_mode, table_dtype=table_dtype, matrix_dtype=matrix_dtype)
-            for s in range(args.warmup):
+            for s in range(fence_warm):
                 mv.train_async(dbs[s % len(dbs)], lr, next_batch=dbs[(s + 1) % len(dbs)], after_next=dbs[(s + 2) % len(dbs)])
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for s in range(args.steps):
-                k = (args.warmup + s) % len(dbs)
+                k = (fence_warm + s) % len(dbs)
                 mv.train_async(dbs[k], lr, next_batch=dbs[(k + 1) % len(dbs)], after_next=dbs[(k + 2) % len(dbs)])
             torch.cuda.synchronize()
             dtv = time.perf_counter() - t1
             lib.tlsan_profile_stride(args.event_every)      # (kernel time: a pass of its own, as for the headline)
             lib.tlsan_profile_enable(args.profile_level)
             for s in range(args.steps):
-                k = (args.warmup + args.steps + s) % len(dbs)
+                k = (fence_warm + args.steps + s) % len(dbs)
                 mv.train_async(dbs[k], lr, next_batch=dbs[(k + 1) % len(dbs)], after_next=dbs[(k + 2) % len(dbs)])
             torch.cuda.synchronize()
             pb = (ctypes.c_float * (nprof * 5))()
             nr = lib.tlsan_profile_collect(pb, nprof)
             lib.tlsan_profile_enable(0)
             kms = float(np.frombuffer(pb, dtype=np.float32)[: nr * 5].reshape(nr, 5)[:, 1].mean()) if nr > 0 else float("nan")
-            abv = [synth.algorithmic_bytes(cfg, host_batches[(args.warmup + s) % len(host_batches)], 2) for s in range(args.steps)]
+            abv = [synth.algorithmic_bytes(cfg, host_batches[(fence_warm + s) % len(host_batches)], 2) for s in range(args.steps)]
             step_b, k_b = float(np.mean([x["train_step"] for x in abv])), float(np.mean([x["fwd_bwd_kernel"] for x in abv]))
             ach = k_b / (kms * 1e-3) / 1e9
             return {"value": round(args.steps * B / dtv, 1), "unit": "user-sequences/s", "ms_per_step": round(dtv / args.steps * 1e3, 4),
                     "what": what, "step_algorithmic_bytes": round(step_b),
                     "step_frac": round(step_b / (dtv / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
                     "roofline": {"bound": "hbm", "kernel": "k_fwd_bwd", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": round(k_b),
+                                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": committed_traffic(tkey)[0],
+                                 "traffic_source": committed_traffic(tkey)[1], "algorithmic_bytes_per_launch": round(k_b),
                                  "kernel_ms": round(kms, 5)},
                     "final_loss": round(float(mv._out[0].item()), 6)}
         # one model at a time: with the measured model still alive the variants' steps were occasionally 1.3-4x longer
         # (same kernel times; 2 of 6 runs), without it never in 10
         model = stepper = None
-        also = variant("bf16", "f32", "item/user/category tables bf16, fp32 arithmetic, stochastic rounding on update")
+        also = variant("bf16", "f32", "item/user/category tables bf16, fp32 arithmetic, stochastic rounding on update", "bf16_tables")
         also_mm = variant("bf16", "bf16", "bf16 tables + bf16 matrix products (operands rounded to bf16, fp32 accumulate); "
-                                          "parity: tests/test_gpu_parity.py::test_bf16_matrix_products")
+                                          "parity: tests/test_gpu_parity.py::test_bf16_matrix_products", "bf16_mfma")
     if not np.isfinite(loss):
         raise SystemExit("bench.py: non-finite loss %r" % loss)
 
     if rank == 0:
         seqs = args.steps * B * world
         eb = 2 if (args.table_dtype == "bf16" and not sharded) else 4   # e = bytes per table element
-        ab = [synth.algorithmic_bytes(cfg, host_batches[(args.warmup + s) % len(host_batches)], eb) for s in range(args.steps)]
+        ab = [synth.algorithmic_bytes(cfg, host_batches[(fence_warm + s) % len(host_batches)], eb) for s in range(args.steps)]
         k_bytes = float(np.mean([a["fwd_bwd_kernel"] for a in ab]))
         l2 = args.l2_mode
         step_bytes = float(np.mean([a["train_step"] for a in ab])) + (synth.dense_sweep_bytes(cfg) if l2 == "dense" else 0)
-        k_flops = float(np.mean([synth.algorithmic_flops(cfg, host_batches[(args.warmup + s) % len(host_batches)]) for s in range(args.steps)]))
+        k_flops = float(np.mean([synth.algorithmic_flops(cfg, host_batches[(fence_warm + s) % len(host_batches)]) for s in range(args.steps)]))
         k_ms = float(seg[:, 1].mean()) if nrec else float("nan")
         achieved = k_bytes / (k_ms * 1e-3) / 1e9 if nrec else None
-        # HBM-side bytes per launch of the dominant kernel come from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in
-        # separate runs, FETCH doubled per MI355X_MICROARCH.md); counters cannot be read from inside this process, so
-        # the line carries the committed measurement WITH its provenance (profiles/traffic.json, scripts/refresh_profiles.sh)
-        traffic = traffic_src = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and args.workload == "electronics" and B == cfg["train_batch_size"] and eb == 4 and not sharded:
-            try:
-                tj = json.load(open(tpath))
-                traffic = tj.get("k_fwd_bwd_hbm_bytes_per_launch")
-                traffic_src = {"bytes": traffic, "source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
-                               "passes, FETCH doubled; not measured by this run)", "round": tj.get("round"),
-                               "FETCH_SIZE_KB": tj.get("FETCH_SIZE_KB"), "WRITE_SIZE_KB": tj.get("WRITE_SIZE_KB")}
-            except Exception:
-                traffic = traffic_src = None
+        traffic, traffic_src = committed_traffic(None) if eb == 4 else (None, None)
         out = {
             "metric": "user-sequences/sec (train step: fwd+bwd+update), Electronics-scale",
             "value": round(seqs / dt, 1),
@@ -383,6 +402,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "pipeline_fill_steps": fill,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
@@ -405,6 +425,8 @@ def main():
                          "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": round(k_bytes), "kernel_ms": round(k_ms, 5),
+                         "kernel_ms_how": "HIP events attached to the kernel's dispatch (hipExtLaunchKernelGGL): its own begin / end time "
+                                          "stamps, as in a rocprofv3 kernel trace; every %dth step of a pass behind the timed steps" % args.event_every,
                          "step_algorithmic_bytes": round(step_bytes),
                          "step_frac": round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
             # the designated roofline is HBM (north_star); at d=128 in exact fp32 the same kernel's maps

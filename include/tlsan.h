@@ -202,6 +202,14 @@ int tlsan_forward(const tlsan_dims* dims, const tlsan_params* p, const tlsan_bat
                   float* logits_i, float* logits_j, float* u_t,
                   void* ws, size_t ws_bytes, void* stream);
 
+/* The same, and the two attention-weight tensors the reference keeps on the model (model.py:122: self.att0, self.att1 =
+ * `soft` of feature_wise_attention, model.py:386-394, heads split along the batch axis) when non-NULL:
+ *   att0[num_heads * B, Ls, d / num_heads]      long-term block, row h * B + b; exactly 0 past sl[b]
+ *   att1[num_heads * B, 1 + Sn, d / num_heads]  short-term block, position 0 = the bridge; exactly 0 past 1 + sl_new[b] */
+int tlsan_forward_att(const tlsan_dims* dims, const tlsan_params* p, const tlsan_batch* b,
+                      float* logits_i, float* logits_j, float* u_t, float* att0, float* att1,
+                      void* ws, size_t ws_bytes, void* stream);
+
 /* One optimisation step -- replaces `sess.run([self.loss, self.train_op])`
  * (model.py:208-234): forward, BCE + L2 loss, backward, global-norm clip, SGD update of
  * every trainable, deterministic (bitwise reproducible) scatter-add of the embedding

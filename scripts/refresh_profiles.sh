@@ -8,11 +8,15 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_stats -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/${tag}_bench_under_rocprof.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/${tag}_$c -- python3 $R/scripts/pmc_run.py > /dev/null 2>&1
+  # the same in the precisions BASELINE.json configs[2] names: bf16 tables, bf16 tables + bf16 matrix operands
+  rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/${tag}_${c}_bf16t -- python3 $R/scripts/pmc_run.py 4096 td=bf16 > /dev/null 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/${tag}_${c}_bf16mm -- python3 $R/scripts/pmc_run.py 4096 td=bf16 mm=bf16 > /dev/null 2>&1
 done
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $R/gpurun_out/${tag}_sq1 -- python3 $R/scripts/pmc_run.py > /dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT --output-format csv -d $R/gpurun_out/${tag}_sq2 -- python3 $R/scripts/pmc_run.py > /dev/null 2>&1
 cd $R
 python3 scripts/pmc_summary.py gpurun_out/${tag}_FETCH_SIZE gpurun_out/${tag}_WRITE_SIZE gpurun_out/${tag}_sq1 gpurun_out/${tag}_sq2 > gpurun_out/${tag}_pmc_summary.txt 2>&1
+python3 scripts/traffic_json.py ${tag#r} gpurun_out/${tag} > gpurun_out/${tag}_traffic.json 2>&1
 python3 bench.py > gpurun_out/${tag}_bench.log 2>&1
 tail -1 gpurun_out/${tag}_bench.log > gpurun_out/${tag}_bench_line.json
 python3 scripts/kstats.py gpurun_out/${tag}_stats 8

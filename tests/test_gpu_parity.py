@@ -1091,3 +1091,57 @@ def test_item_index_from_a_counting_sort_of_the_batch():
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         digests.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1])
     assert digests[0] == digests[1], digests
+
+
+@pytest.mark.parametrize("d,Ls", [(128, 10), (64, 10), (128, 33), (256, 10)])
+def test_dropout_with_bf16_tables(d, Ls):
+    """config['dropout'] > 0 with table_dtype='bf16' (round 3 refused the combination): the gradients equal the oracle's
+    at the stored (bf16-rounded) tables under the same keep / drop pattern, and a training step is reproducible."""
+    rate = 0.3
+    cfg = make_config(U=40, I=60, C=9, d=d, regulation_rate=1e-3, dropout=rate, Ls=Ls)
+    p = _p32(random_params(cfg, seed=95))
+    for k in BF16_TABLES:
+        p[k] = _bf16_round(p[k]).astype(np.float64)
+    b, cat = random_batch(cfg, B=37, Sn=3, seed=951)
+    m = _model(cfg, cat, p, l2_mode="lazy", table_dtype="bf16")
+    seed = m.dropout_seed()
+    g = m.grads(_tuple(b))
+    loss, _, ref_g, _ = orc.backward(p, cat, b, 8, cfg["regulation_rate"], dropout=(rate, seed))
+    plain = orc.loss_fn(p, cat, b, 8, cfg["regulation_rate"])
+    assert abs(plain - loss) > 1e-5                        # the pattern matters
+    assert abs(g["loss"] - loss) < 1e-4 * max(1.0, abs(loss))
+    for k in ref_g:
+        a, r = np.asarray(g["grads"][k], np.float64).reshape(ref_g[k].shape), ref_g[k]
+        assert np.abs(a - r).max() < 3e-4 * np.abs(r).max() + 1e-6, k
+    outs = []
+    for rep in range(2):
+        mm = _model(cfg, cat, p, l2_mode="lazy", table_dtype="bf16")
+        mm.train(None, _tuple(b), 0.6)
+        outs.append(mm.get_params())
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+@pytest.mark.parametrize("d,Ls,B,Sn", [(128, 10, 37, 4), (64, 10, 50, 0), (256, 10, 21, 3), (128, 33, 40, 2), (64, 90, 19, 5), (256, 20, 18, 1)])
+def test_attention_weights_match_oracle(d, Ls, B, Sn):
+    """The reference keeps the two attention-weight tensors on the model (model.py:122: self.att0, self.att1 = `soft` of
+    feature_wise_attention, :386-394, heads split along the batch axis).  Model.forward(want_att=True) leaves them as
+    [H*B, Ls, d/H] and [H*B, 1+Sn, d/H], row h*B + b -- windows in registers and streamed, sessions of every length
+    including none, exactly 0 on masked positions."""
+    cfg = make_config(U=50, I=80, C=8, d=d, Ls=Ls)
+    p = _p32(random_params(cfg, seed=d + Ls))
+    b, cat = random_batch(cfg, B=B, Sn=Sn, seed=Ls + B, test=True)
+    b["sl"][:3] = [Ls, 1, max(1, Ls - 1)]
+    m = _model(cfg, cat, p)
+    li, lj, _, _ = m.forward(_tuple(b, test=True), is_test=True, want_att=True)
+    ref = orc.forward(p, cat, dict(b, y=np.zeros(B)), 8)
+    assert np.abs(li.cpu().numpy() - ref["logits"]).max() < LOGIT_TOL
+    H = 8
+    for got, want, T, length in ((m.att0, ref["att0"], Ls, b["sl"]), (m.att1, ref["att1"], Sn + 1, b["sl_new"] + 1)):
+        w = np.asarray(want).transpose(2, 0, 1, 3).reshape(H * B, T, d // H)      # [B, T, H, dh] -> row h*B + b
+        g = got.cpu().numpy()
+        assert g.shape == w.shape
+        assert np.abs(g - w).max() < 2e-5, np.abs(g - w).max()
+        masked = np.arange(T)[None, :] >= np.tile(np.asarray(length), H)[:, None]  # [H*B, T]
+        assert (g[masked] == 0.0).all()                                            # masked positions: exactly 0
+        assert np.abs(g.sum(1) - 1.0).max() < 1e-5                                 # a softmax over positions per channel

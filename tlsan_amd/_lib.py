@@ -21,7 +21,7 @@ SN_CAP = 96     # TLSAN_SN_CAP (csrc/tlsan_common.h): longest session of a train
 EXPORTS = [
     "tlsan_abi_version", "tlsan_last_error", "tlsan_dense_layout_of", "tlsan_workspace_bytes",
     "tlsan_state_bytes", "tlsan_state_init", "tlsan_state_reindex", "tlsan_state_recategorize", "tlsan_state_scale",
-    "tlsan_state_renorm", "tlsan_sync_derived", "tlsan_forward",
+    "tlsan_state_renorm", "tlsan_sync_derived", "tlsan_forward", "tlsan_forward_att",
     "tlsan_train_step", "tlsan_train_step_opt", "tlsan_batch_pack", "tlsan_batch_index", "tlsan_grads", "tlsan_eval_ranks", "tlsan_eval_label_scores", "tlsan_eval_counts_shard", "tlsan_profile_enable", "tlsan_profile_stride",
     "tlsan_profile_collect", "tlsan_debug_stamps", "tlsan_rows_apply_workspace", "tlsan_rows_apply", "tlsan_scan_compact",
     "tlsan_route_plan", "tlsan_shard_gather", "tlsan_shard_summary", "tlsan_shard_apply_workspace", "tlsan_shard_apply",
@@ -125,6 +125,8 @@ def load():
     lib.tlsan_state_renorm.restype = C.c_int
     lib.tlsan_forward.argtypes = [P(Dims), P(Params), P(Batch), C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.tlsan_forward_att.argtypes = [P(Dims), P(Params), P(Batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_size_t, C.c_void_p]
     lib.tlsan_train_step.argtypes = [P(Dims), P(Params), P(Batch), P(HParams), P(StepOut),
                                      C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.tlsan_train_step_opt.argtypes = [P(Dims), P(Params), P(Batch), P(HParams), P(Optimizer), P(StepOut),
@@ -207,7 +209,7 @@ def load():
     lib.tlsan_shard_apply.restype = C.c_int
     lib.tlsan_debug_stamps.argtypes = [C.c_void_p]
     lib.tlsan_debug_stamps.restype = C.c_int
-    for name in ("tlsan_dense_layout_of", "tlsan_state_init", "tlsan_sync_derived", "tlsan_forward",
+    for name in ("tlsan_dense_layout_of", "tlsan_state_init", "tlsan_sync_derived", "tlsan_forward", "tlsan_forward_att",
                  "tlsan_train_step", "tlsan_grads", "tlsan_eval_ranks"):
         getattr(lib, name).restype = C.c_int
     if lib.tlsan_abi_version() != ABI_VERSION:

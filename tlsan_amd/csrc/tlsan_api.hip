@@ -11,10 +11,11 @@
 #include "tlsan_update.h"
 #include "tlsan_shard.h"
 
-hipError_t tlsan_launch_fwd_bwd_d64(bool train, bool lstream, const FwdArgs& a, int grid, hipStream_t st);
-hipError_t tlsan_launch_fwd_bwd_d128(bool train, bool lstream, const FwdArgs& a, int grid, hipStream_t st);
-hipError_t tlsan_launch_fwd_bwd_d256(bool train, bool lstream, const FwdArgs& a, int grid, hipStream_t st);
-hipError_t tlsan_launch_fwd_bwd_d128w4(const FwdArgs& a, int grid, hipStream_t st);   // training, 8-sample workgroups
+struct LaunchEvents { hipEvent_t start, stop; };   // optional time stamps of the dispatch (tlsan_attn_inst.h)
+hipError_t tlsan_launch_fwd_bwd_d64(bool train, bool lstream, const FwdArgs& a, int grid, hipStream_t st, LaunchEvents ev);
+hipError_t tlsan_launch_fwd_bwd_d128(bool train, bool lstream, const FwdArgs& a, int grid, hipStream_t st, LaunchEvents ev);
+hipError_t tlsan_launch_fwd_bwd_d256(bool train, bool lstream, const FwdArgs& a, int grid, hipStream_t st, LaunchEvents ev);
+hipError_t tlsan_launch_fwd_bwd_d128w4(const FwdArgs& a, int grid, hipStream_t st, LaunchEvents ev);   // training, 8-sample workgroups
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, ...) {
@@ -44,8 +45,19 @@ static void prof_mark(int mark, hipStream_t hs) {
   // (the sampled step of every stride is the middle one: not the first step after the caller's fence, whose kernel
   //  starts on an idle GPU and runs 5-8 % longer than the others)
   if (g_prof_level == 0 || g_prof_n >= PROF_MAX_STEPS || (g_prof_tick % g_prof_stride) != g_prof_stride / 2) return;
-  if (g_prof_level == 1 && mark != 1 && mark != 2) return;
+  if (g_prof_level == 1) return;   // (the kernel's own events: prof_kernel_events)
   (void)hipEventRecord(g_prof_ev[g_prof_n * PROF_MARKS + mark], hs);
+}
+
+// level 1 (the fused kernel's own duration): the two events ride on the kernel's dispatch packet (hipExtLaunchKernelGGL) --
+// its begin / end time stamps, what a kernel trace reports -- instead of being recorded around it as barrier packets of
+// their own, which read ~3 us longer and delay the step that carries them
+static LaunchEvents prof_kernel_events() {
+  LaunchEvents ev = {nullptr, nullptr};
+  if (g_prof_level != 1 || g_prof_n >= PROF_MAX_STEPS || (g_prof_tick % g_prof_stride) != g_prof_stride / 2) return ev;
+  ev.start = g_prof_ev[g_prof_n * PROF_MARKS + 1];
+  ev.stop = g_prof_ev[g_prof_n * PROF_MARKS + 2];
+  return ev;
 }
 
 static void prof_step_done() {
@@ -623,12 +635,14 @@ static int launch_fwd(const Shape& s, bool train, const FwdArgs& a, hipStream_t 
   if (train && a.fuse_dk) grid = fwd_train_grid(a.ngroups);
   hipError_t e;
   const bool lstream = streamed(a.Ls);  // long windows are streamed, short ones stay in registers
-  if (train && s.D == 128 && grp == 8) e = tlsan_launch_fwd_bwd_d128w4(a, grid, hs);
-  else if (s.D == 64) e = tlsan_launch_fwd_bwd_d64(train, lstream, a, grid, hs);
-  else if (s.D == 128) e = tlsan_launch_fwd_bwd_d128(train, lstream, a, grid, hs);
-  else e = tlsan_launch_fwd_bwd_d256(train, lstream, a, grid, hs);
+  LaunchEvents ev = {nullptr, nullptr};
+  if (train) ev = prof_kernel_events();
+  if (train && s.D == 128 && grp == 8) e = tlsan_launch_fwd_bwd_d128w4(a, grid, hs, ev);
+  else if (s.D == 64) e = tlsan_launch_fwd_bwd_d64(train, lstream, a, grid, hs, ev);
+  else if (s.D == 128) e = tlsan_launch_fwd_bwd_d128(train, lstream, a, grid, hs, ev);
+  else e = tlsan_launch_fwd_bwd_d256(train, lstream, a, grid, hs, ev);
   if (e == hipErrorNotSupported)
-    return fail(TLSAN_E_UNSUPPORTED, "dropout > 0 is built for fp32 tables and fp32 matrix products (and for train steps only)");
+    return fail(TLSAN_E_UNSUPPORTED, "dropout > 0 is built for fp32 matrix products (and for train steps only)");
   if (e != hipSuccess) return fail(TLSAN_E_LAUNCH, "k_fwd_bwd: %s", hipGetErrorString(e));
   return TLSAN_OK;
 }
@@ -647,6 +661,11 @@ static void fill_fwd(FwdArgs& a, const tlsan_dims* d, const Shape& s, const tlsa
 
 int tlsan_forward(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch* b, float* logits_i, float* logits_j,
                   float* u_t, void* ws, size_t ws_bytes, void* stream) {
+  return tlsan_forward_att(d, p, b, logits_i, logits_j, u_t, nullptr, nullptr, ws, ws_bytes, stream);
+}
+
+int tlsan_forward_att(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch* b, float* logits_i, float* logits_j,
+                      float* u_t, float* att0, float* att1, void* ws, size_t ws_bytes, void* stream) {
   Shape s;
   int rc = shape_of(d, &s);
   if (rc) return rc;
@@ -662,6 +681,7 @@ int tlsan_forward(const tlsan_dims* d, const tlsan_params* p, const tlsan_batch*
   a.logits_i = logits_i;
   a.logits_j = logits_j;
   a.u_t = u_t;
+  a.att0 = att0; a.att1 = att1;
   return launch_fwd(s, false, a, (hipStream_t)stream);
 }
 
@@ -784,7 +804,6 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   a.gLong = w.gLong; a.gDB = w.gDB; a.gStat = w.gStat; a.partials = w.partials; a.Kp = w.Kp;
   if (hp->dropout != 0.0f) {
     if (!(hp->dropout > 0.0f && hp->dropout < 1.0f)) return fail(TLSAN_E_BADARG, "dropout must be in [0, 1)");
-    if (a.p.table_dtype != TLSAN_TABLE_F32) return fail(TLSAN_E_UNSUPPORTED, "dropout > 0 is built for fp32 tables");
     const float keep = (float)(1.0 - (double)hp->dropout);
     const double t = (double)keep * 4294967296.0;
     a.drop_thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;

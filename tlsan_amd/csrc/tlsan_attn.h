@@ -34,7 +34,8 @@ __device__ __forceinline__ void fwa_forward(const typename MMT<MM>::opd (&FT1)[N
                                             const f32x4 (&e)[NPOS][NB], const float (&sc)[NPOS],
                                             int n_valid, int pmax, f32x4 (&mx)[NB],
                                             f32x4 (&Z)[NB], f32x4 (&out)[NB], float* __restrict__ sAw,
-                                            const DropCtx& dc = DropCtx{}, int net = 0, const int* chb = nullptr) {
+                                            const DropCtx& dc = DropCtx{}, int net = 0, const int* chb = nullptr,
+                                            f32x4 (*aout)[NB] = nullptr) {
   f32x4 a[NPOS][NB];
 #pragma unroll
   for (int kb = 0; kb < NB; ++kb) mx[kb] = (f32x4)(TLSAN_NEG);
@@ -101,6 +102,7 @@ __device__ __forceinline__ void fwa_forward(const typename MMT<MM>::opd (&FT1)[N
       a[p][kb] = a[p][kb] * Z[kb];
       out[kb] += a[p][kb] * (e[p][kb] * sc[p]);  // model.py:387
       if (sAw != nullptr) *(f32x4*)(sAw + (p * NB + kb) * 256) = a[p][kb];  // [position][lane] float4s
+      if (aout != nullptr) aout[p][kb] = a[p][kb];                            // (evaluation: FwdArgs.att0)
     }
 }
 
@@ -448,7 +450,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   float* sMx = (float*)(sFcpos + ((TRAIN && CSEG) ? NF : 0));   // [NSB][LSTR] per-channel max of the window's scores
   float* sIz = sMx + ((FLAT && !FLATG && TRAIN) ? NSB * LSTR : 0);   // [NSB][LSTR] 1 / sum of exponentials
   int* sBx = (int*)(sIz + ((FLAT && !FLATG && TRAIN) ? NSB * LSTR : 0));   // FLATG: [NSB] the slots' samples (rows of gStat / gLong)
-  float* sB = FLAT ? (float*)(sBx + (FLATG ? NSB : 0)) : sB0;
+  int* sSb = sBx + (FLATG ? NSB : 0);                   // evaluation, FLAT: [NSB] the slots' samples (rows of FwdArgs.att0)
+  float* sB = FLAT ? (float*)(sSb + ((!TRAIN && FLAT) ? NSB : 0)) : sB0;
   float* sT = FLAT ? sB + NSB * LSTR : (float*)sFid;  // per-wave transpose scratch / staging
   // FLAT: the partial softmax states of P1, 32 slots of [3][D], lie over sB and sT (neither is touched before P2)
   float* sPart = sB;
@@ -477,6 +480,10 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     return (CSEG && c >= a.di) ? a.Gc + (size_t)cpos * a.dc + (c - a.di) : a.Gi + (size_t)pos * D + c;
   };
 
+  // channels [ch, ch + 4) of position p of sample b in an attention-weight tensor of T positions (FwdArgs.att0 / att1)
+  auto att_at = [&](float* base, int T_, int b, int p, int ch) -> float* {
+    return base + (((size_t)(ch / DH) * a.b.B + b) * T_ + p) * DH + (ch % DH);
+  };
   if constexpr (TRAIN) {
     // (tlsan_step_out.started: this kernel running means everything queued before the step is complete)
     if (a.started != nullptr && blockIdx.x == 0 && tid == 0)
@@ -699,6 +706,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         posv[LS + 1] = (lead && vs) ? atomicAdd(&a.cur_user[uid], 1) : 0;
         posv[LS + 2] = (lead && vs && (a.uc_by_sample + opaque_zero(lane)) == 0) ? atomicAdd(&a.cur_uc[a.b.u_cate[bb]], 1) : bidx;
       }
+      if constexpr (!TRAIN) {
+        if (lead) sSb[srow] = bidx;    // (FwdArgs.att0: whose scores a list entry's are)
+      }
       const int wv = __builtin_amdgcn_readfirstlane(wave);
       int offm = __builtin_amdgcn_readlane(offv, wv * SPW);   // where this lane's own window starts in the list
 #pragma unroll
@@ -763,6 +773,13 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) z[kb][i] = fmaxf(z[kb][i], 0.0f);
         map_apply<NB, MM>(FT2, b2, z, m2);
+        if constexpr (!TRAIN) {   // attention weights wanted: the raw scores now, normalised by the sample's own lanes after the merge
+          if (a.att0 != nullptr && v) {
+            const int bs = sSb[s_cur];
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) *(f32x4*)att_at(a.att0, Ls, bs, st & 255, chb[kb]) = m2[kb];
+          }
+        }
         const int slot = v ? s_cur + srow : 31;
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) {
@@ -887,6 +904,24 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       }
       if constexpr (TRAIN && FLATG) {
         if (lead) sBx[srow] = bb;
+      }
+      if constexpr (!TRAIN) {
+        // (the raw scores were stored by whichever column groups walked this sample's entries, all before the barrier above)
+        if (a.att0 != nullptr && vs) {
+          for (int p = 0; p < Ls; ++p) {
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+              float* pa = att_at(a.att0, Ls, bidx, p, chb[kb]);
+              f32x4 w = (f32x4)(0.0f);
+              if (p < n_l) {
+                const f32x4 raw = *(const f32x4*)pa;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) w[i] = __expf(raw[i] - mx1[kb][i]) * iz1[kb][i];
+              }
+              *(f32x4*)pa = w;
+            }
+          }
+        }
       }
     } else if constexpr (LSTREAM) {
       ucat = a.b.u_cate[bb];
@@ -1042,7 +1077,19 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       load_bias<DH, NB>(w1b1, q, b1);
       load_bias<DH, NB>(w1b2, q, b2);
       TLSAN_STAMP(22);
-      fwa_forward<NB, LS, DROP, MM>(FT1, b1, FT2, b2, e1, sc1, n_l, pmax1, mx1, iz1, long4, KEEP_A ? sAw : nullptr, dc, 0, chb);
+      f32x4 att_r[TRAIN ? 1 : LS][NB];
+      fwa_forward<NB, LS, DROP, MM>(FT1, b1, FT2, b2, e1, sc1, n_l, pmax1, mx1, iz1, long4, KEEP_A ? sAw : nullptr, dc, 0, chb,
+                                    TRAIN ? nullptr : att_r);
+      if constexpr (!TRAIN) {
+        if (a.att0 != nullptr && vs) {
+#pragma unroll
+          for (int p = 0; p < LS; ++p)
+            if (p < Ls) {
+#pragma unroll
+              for (int kb = 0; kb < NB; ++kb) *(f32x4*)att_at(a.att0, Ls, bidx, p, chb[kb]) = att_r[p][kb];
+            }
+        }
+      }
     }
     TLSAN_STAMP(23);
 #pragma unroll
@@ -1174,6 +1221,12 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         for (int kb = 0; kb < NB; ++kb) z[kb] *= drop_scale4(dc, 1, 0, 1, chb[kb]);
       }
       map_apply<NB, MM>(FT2, b2, z, mx);  // position 0 is always valid: running max = its score
+      if constexpr (!TRAIN) {
+        if (a.att1 != nullptr && vs) {
+#pragma unroll
+          for (int kb = 0; kb < NB; ++kb) *(f32x4*)att_at(a.att1, Sn + 1, bidx, 0, chb[kb]) = mx[kb];   // (raw, normalised below)
+        }
+      }
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb) {
         Zs[kb] = (f32x4)(1.0f);
@@ -1197,6 +1250,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       h_hi = max(ns0, ns1);
       h_L = ns0 >= ns1 ? 0 : 1;
       h_on = (h_hi - h_lo >= 2) && h_hi <= NL;   // (sessions beyond one chunk of ids: rare, left to the plain loop)
+      if constexpr (!TRAIN) h_on = h_on && a.att1 == nullptr;   // (attention weights wanted: every lane stays with its own sample)
     }
     const int nsess = h_on ? h_lo + (h_hi - h_lo + 1) / 2 : pmax2 - 1;   // session steps of this wavefront
     const bool helper = HELP && h_on && s_loc != h_L;
@@ -1260,6 +1314,12 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         for (int kb = 0; kb < NB; ++kb) z[kb] *= drop_scale4(dc, 1, p, 1, chb[kb]);
       }
       map_apply<NB, MM>(FT2, b2, z, m2);
+      if constexpr (!TRAIN) {
+        if (a.att1 != nullptr && vs && vt) {
+#pragma unroll
+          for (int kb = 0; kb < NB; ++kb) *(f32x4*)att_at(a.att1, Sn + 1, bidx, p, chb[kb]) = m2[kb];
+        }
+      }
       if (vt) {
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb)
@@ -1302,6 +1362,23 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         Zs[kb][i] = fast_rcp(Zs[kb][i]);
         short4[kb][i] *= Zs[kb][i];
       }
+    if constexpr (!TRAIN) {
+      if (a.att1 != nullptr && vs) {   // raw scores -> weights (model.py:386), zero past the session
+        for (int p = 0; p <= Sn; ++p) {
+#pragma unroll
+          for (int kb = 0; kb < NB; ++kb) {
+            float* pa = att_at(a.att1, Sn + 1, bidx, p, chb[kb]);
+            f32x4 w = (f32x4)(0.0f);
+            if (p <= n_s) {
+              const f32x4 raw = *(const f32x4*)pa;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) w[i] = __expf(raw[i] - mx[kb][i]) * Zs[kb][i];
+            }
+            *(f32x4*)pa = w;
+          }
+        }
+      }
+    }
     if constexpr (TRAIN) {  // publish the session positions (the atomics are long back by now)
       if (vs && kk < n_s) sP[srow * PSTR + LSCP + kk] = spos0;
       if (CSEG && vs && kk < n_s) sPc[srow * PSTR + LSCP + kk] = scpos0;

@@ -2,8 +2,10 @@
 // so the big kernels compile in parallel).
 #pragma once
 #include <atomic>
+#include <hip/hip_ext.h>
 #include "tlsan_attn.h"
 #define TLSAN_MAX_DEVICES 16   // devices one process may drive (per-device launch attributes below)
+struct LaunchEvents { hipEvent_t start, stop; };   // optional time stamps of the dispatch (tlsan_profile_*), or NULLs
 #ifndef TLSAN_STAMPS
 #define TLSAN_STAMPS 0
 #endif
@@ -21,13 +23,14 @@ static size_t fwd_smem_bytes(bool train, bool lstream, bool fuse_dk, int Sn, boo
                           ((G::USE_SW && !flatg) ? 2 * (2 * DH * DH + 2 * DH) : 0) + G::NW * G::WSCR +
                           ((G::KEEP_A && train && !lstream) ? G::NW * TLSAN_LS_MAX * G::NB * 256 : 0) +
                           nf * (3 + (train ? 1 : 0) + ((train && cseg) ? 1 : 0)) + ((flat && !flatg && train) ? 2 * G::NSB * G::LSTR : 0) + (flatg ? G::NSB : 0) +
+                          ((flat && !train) ? G::NSB : 0) /* evaluation: the slots' samples (sSb) */ +
                           (TLSAN_STAMPS ? G::NW * 32 * 2 : 0) /* diagnostic stamps */);
 }
 
 template <int D, int DH, bool TRAIN, bool LSTREAM, int DT, bool DROP = false, int MM = TLSAN_MATRIX_F32, bool CSEG = false, int NWV = 0>
-static hipError_t launch_variant_dt(const FwdArgs& a, int grid, hipStream_t st) {
+static hipError_t launch_variant_dt(const FwdArgs& a, int grid, hipStream_t st, LaunchEvents ev) {
   if constexpr (TRAIN && !CSEG) {   // tables with thousands of categories: the variant with category segments
-    if (a.cseg) return launch_variant_dt<D, DH, TRAIN, LSTREAM, DT, DROP, MM, true, NWV>(a, grid, st);
+    if (a.cseg) return launch_variant_dt<D, DH, TRAIN, LSTREAM, DT, DROP, MM, true, NWV>(a, grid, st, ev);
   }
   // (the copy of `long` for the fused dK product only in launches that fuse: at d = 64 it is what decides whether two
   //  workgroups fit a CU's LDS -- 8192 sequences, not fused: 77 us/step with it left out, 95 with it)
@@ -45,44 +48,50 @@ static hipError_t launch_variant_dt(const FwdArgs& a, int grid, hipStream_t st) 
       if (slot != nullptr) slot->store(smem, std::memory_order_relaxed);
     }
   }
-  hipLaunchKernelGGL(k, dim3(grid), dim3(Geo<D, DH, NWV>::NW * 64), smem, st, a);
+  // (ev: optional pair of events attached to THIS dispatch -- its own begin / end time stamps, what a kernel trace
+  //  reports -- instead of two events recorded around it, which are barrier packets of their own and read 3 us long)
+  if (ev.start != nullptr) hipExtLaunchKernelGGL(k, dim3(grid), dim3(Geo<D, DH, NWV>::NW * 64), smem, st, ev.start, ev.stop, 0, a);
+  else hipLaunchKernelGGL(k, dim3(grid), dim3(Geo<D, DH, NWV>::NW * 64), smem, st, a);
   return hipGetLastError();
 }
 
-// bf16 table storage and bf16 matrix products: window in registers or streamed; neither with dropout
+// bf16 table storage and bf16 matrix products: window in registers or streamed; dropout with fp32 matrix products only
 template <int D, int DH, bool TRAIN, bool LSTREAM>
-static hipError_t launch_variant(const FwdArgs& a, int grid, hipStream_t st) {
+static hipError_t launch_variant(const FwdArgs& a, int grid, hipStream_t st, LaunchEvents ev) {
   if (a.p.matrix_dtype == TLSAN_MATRIX_BF16) {  // bf16 matrix products: either window form, either table storage, no dropout
     if (a.drop_thr != 0) return hipErrorNotSupported;
-    if (a.p.table_dtype == TLSAN_TABLE_BF16) return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_BF16, false, TLSAN_MATRIX_BF16>(a, grid, st);
-    return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_F32, false, TLSAN_MATRIX_BF16>(a, grid, st);
+    if (a.p.table_dtype == TLSAN_TABLE_BF16) return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_BF16, false, TLSAN_MATRIX_BF16>(a, grid, st, ev);
+    return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_F32, false, TLSAN_MATRIX_BF16>(a, grid, st, ev);
   }
   if (a.p.table_dtype == TLSAN_TABLE_BF16) {
-    if (a.drop_thr != 0) return hipErrorNotSupported;
-    return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_BF16>(a, grid, st);
+    if (a.drop_thr != 0) {   // dropout on bf16 tables: training, fp32 matrix products
+      if constexpr (TRAIN) return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_BF16, true>(a, grid, st, ev);
+      else return hipErrorNotSupported;
+    }
+    return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_BF16>(a, grid, st, ev);
   }
   if (a.drop_thr != 0) {  // dropout: training, fp32 tables
-    if constexpr (TRAIN) return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_F32, true>(a, grid, st);
+    if constexpr (TRAIN) return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_F32, true>(a, grid, st, ev);
     else return hipErrorNotSupported;
   }
-  return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_F32>(a, grid, st);
+  return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_F32>(a, grid, st, ev);
 }
 
 template <int D, int DH>
-static hipError_t launch_fwd_bwd_impl(bool train, bool lstream, const FwdArgs& a, int grid, hipStream_t st) {
-  if (train) return lstream ? launch_variant<D, DH, true, true>(a, grid, st) : launch_variant<D, DH, true, false>(a, grid, st);
-  return lstream ? launch_variant<D, DH, false, true>(a, grid, st) : launch_variant<D, DH, false, false>(a, grid, st);
+static hipError_t launch_fwd_bwd_impl(bool train, bool lstream, const FwdArgs& a, int grid, hipStream_t st, LaunchEvents ev) {
+  if (train) return lstream ? launch_variant<D, DH, true, true>(a, grid, st, ev) : launch_variant<D, DH, true, false>(a, grid, st, ev);
+  return lstream ? launch_variant<D, DH, false, true>(a, grid, st, ev) : launch_variant<D, DH, false, false>(a, grid, st, ev);
 }
 
 // training step with the window in registers, no dropout, as NWV-wavefront workgroups (d = 128: 4 wavefronts, 8 samples)
 template <int D, int DH, int NWV>
-static hipError_t launch_train_nw(const FwdArgs& a, int grid, hipStream_t st) {
+static hipError_t launch_train_nw(const FwdArgs& a, int grid, hipStream_t st, LaunchEvents ev) {
   if (a.drop_thr != 0) return hipErrorNotSupported;
   const bool tb = a.p.table_dtype == TLSAN_TABLE_BF16;
   if (a.p.matrix_dtype == TLSAN_MATRIX_BF16) {
-    if (tb) return launch_variant_dt<D, DH, true, false, TLSAN_TABLE_BF16, false, TLSAN_MATRIX_BF16, false, NWV>(a, grid, st);
-    return launch_variant_dt<D, DH, true, false, TLSAN_TABLE_F32, false, TLSAN_MATRIX_BF16, false, NWV>(a, grid, st);
+    if (tb) return launch_variant_dt<D, DH, true, false, TLSAN_TABLE_BF16, false, TLSAN_MATRIX_BF16, false, NWV>(a, grid, st, ev);
+    return launch_variant_dt<D, DH, true, false, TLSAN_TABLE_F32, false, TLSAN_MATRIX_BF16, false, NWV>(a, grid, st, ev);
   }
-  if (tb) return launch_variant_dt<D, DH, true, false, TLSAN_TABLE_BF16, false, TLSAN_MATRIX_F32, false, NWV>(a, grid, st);
-  return launch_variant_dt<D, DH, true, false, TLSAN_TABLE_F32, false, TLSAN_MATRIX_F32, false, NWV>(a, grid, st);
+  if (tb) return launch_variant_dt<D, DH, true, false, TLSAN_TABLE_BF16, false, TLSAN_MATRIX_F32, false, NWV>(a, grid, st, ev);
+  return launch_variant_dt<D, DH, true, false, TLSAN_TABLE_F32, false, TLSAN_MATRIX_F32, false, NWV>(a, grid, st, ev);
 }

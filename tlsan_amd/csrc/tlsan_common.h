@@ -456,6 +456,10 @@ struct FwdArgs {
   float* logits_i;
   float* logits_j;
   float* u_t;
+  // evaluation only, optional: the two attention-weight tensors the reference keeps on the model (model.py:122,
+  // 386-394: `soft` of feature_wise_attention, heads split along the batch axis)
+  float* att0;      // [H * B, Ls, d / H]        long-term block:  row h * B + b
+  float* att1;      // [H * B, 1 + Sn, d / H]    short-term block (position 0 = the bridge)
   // training only.  Per-use gradient rows are written at DESTINATION-SORTED positions: the
   // kernel draws the position of each use from the fill cursor of its destination row
   // (cursor = exclusive scan of the per-row use counts), so k_apply_* read contiguous segments.

@@ -230,8 +230,8 @@ class Model(object):
         self.dropout = float(config.get("dropout", 0.0))           # model.py:116-118, 428-431
         if not 0.0 <= self.dropout < 1.0:
             raise ValueError("dropout must be in [0, 1)")
-        if self.dropout > 0.0 and (table_dtype != "f32" or matrix_dtype != "f32"):
-            raise NotImplementedError("dropout > 0 is built for fp32 tables and fp32 matrix products")
+        if self.dropout > 0.0 and matrix_dtype != "f32":
+            raise NotImplementedError("dropout > 0 is built for fp32 matrix products")
         self._seed = int(seed)
         self.optimizer = config.get("optimizer", "sgd")           # model.py:188-195
         if self.optimizer not in OPTIMIZERS:
@@ -700,15 +700,25 @@ class Model(object):
         return dict(grads=res, loss=float(o[0]), gnorm=float(o[1]), logits=logits.cpu().numpy())
 
     # ------------------------------------------------------------------ evaluation
-    def forward(self, batch, is_test=True, want_u_t=False):
-        """logits for candidate i (and j when the batch has one) -- `sess.run(self.logits)`."""
+    def forward(self, batch, is_test=True, want_u_t=False, want_att=False):
+        """logits for candidate i (and j when the batch has one) -- `sess.run(self.logits)`.
+        want_att: also leave the reference's two attention-weight tensors (model.py:122, 386-394) on the model:
+        self.att0 [H*B, Ls, d/H] and self.att1 [H*B, 1+Sn, d/H], row h*B + b (`sess.run([model.att0, model.att1])`)."""
         db = self.device_batch(batch, is_test)
         li = torch.empty(db.B, dtype=torch.float32, device=self.device)
         lj = torch.empty(db.B, dtype=torch.float32, device=self.device) if db.j is not None else None
         ut = torch.empty(db.B, self.config["hidden_units"], dtype=torch.float32, device=self.device) if want_u_t else None
-        L.check(self.lib.tlsan_forward(C.byref(self.dims), C.byref(self.cparams), C.byref(db.c), li.data_ptr(),
-                                       None if lj is None else lj.data_ptr(), None if ut is None else ut.data_ptr(),
-                                       None, 0, self._stream()), "tlsan_forward")
+        a0 = a1 = None
+        if want_att:
+            H, dh = self.config["num_heads"], self.config["hidden_units"] // self.config["num_heads"]
+            a0 = torch.empty(H * db.B, self.config["Ls"], dh, dtype=torch.float32, device=self.device)
+            a1 = torch.empty(H * db.B, 1 + db.Sn, dh, dtype=torch.float32, device=self.device)
+        L.check(self.lib.tlsan_forward_att(C.byref(self.dims), C.byref(self.cparams), C.byref(db.c), li.data_ptr(),
+                                           None if lj is None else lj.data_ptr(), None if ut is None else ut.data_ptr(),
+                                           None if a0 is None else a0.data_ptr(), None if a1 is None else a1.data_ptr(),
+                                           None, 0, self._stream()), "tlsan_forward")
+        if want_att:
+            self.att0, self.att1 = a0, a1
         return li, lj, ut, db
 
     def eval_auc(self, sess, batch):
