@@ -470,6 +470,64 @@ int tlsan_shard_apply_lazy_static(float* shard, int32_t ld, int32_t cI, int32_t 
                                   double* sumsq_out, float* sumsq_f32, float* scale,
                                   void* ws, size_t ws_bytes, void* stream);
 
+/* ---- the static-shape step in as few host calls as there are collectives (round 4) -------------------------------
+ * tlsan_amd/dist.py issued the step as ~15 Python-level calls (ctypes with 10-27 arguments each, torch events, a
+ * stream-scoped copy): at one rank the HOST took 100 us per step for 77 us of kernels -- every rank of a multi-GPU run
+ * would have been bound by its Python thread.  The two entry points below run the same launches from argument blocks
+ * that are built once per (plan slot, batch): one call per segment between two collectives.
+ *
+ * tlsan_shard_step_static(s, phases, stream): the main stream's launches, `phases` = any contiguous run of
+ *   TLSAN_PHASE_GATHER  tlsan_shard_gather_static / _wire_bf16 (s->wire)       -- then the row all-to-all
+ *   TLSAN_PHASE_GRADS   tlsan_grads on the compact table                        -- then the all-reduce of s->flat
+ *   TLSAN_PHASE_SUMMARY tlsan_shard_summary_opt                                 -- then the gradient all-to-all
+ *   TLSAN_PHASE_APPLY   tlsan_shard_apply_lazy_static
+ *   (one rank: all four in one call).  `plans` (optional) are issued behind the call's last launch -- they run on their own
+ *   streams, and their slots were last used by earlier steps: with s->out.started set (a pinned host word the fused
+ *   kernel stores s->out.started_value into when it begins to run; values count up from step to step) the call first
+ *   waits, on the HOST, until the word has reached s->plans_after -- "step plans_after has started" = every step before
+ *   it is complete -- instead of ordering the side streams behind an event recorded on the main stream (a barrier
+ *   packet in the main queue: ~6 us of idle GPU per step).  Without the word the plans carry ev_fork.
+ * tlsan_shard_plan_static(p): a batch's routing plan, category index and destination index on p->stream / p->stream2
+ *   (tlsan_route_plan_static, the overflow word's copy to pinned memory, tlsan_state_recategorize, tlsan_batch_index),
+ *   ordered by the caller's HIP events (raw hipEvent_t / hipStream_t handles; NULL events are skipped):
+ *     stream waits ev_fork; ev_planned recorded behind the route plan; stream2 waits ev_planned, builds the index,
+ *     records ev_done1; ev_done0 recorded on stream last when record_done0 != 0 (the caller records it itself when it
+ *     puts the id all-to-all there).  stream2 == NULL: the index follows on stream. */
+#define TLSAN_PHASE_GATHER 1
+#define TLSAN_PHASE_GRADS 2
+#define TLSAN_PHASE_SUMMARY 4
+#define TLSAN_PHASE_APPLY 8
+typedef struct {
+  const int32_t* keys; int32_t n_keys, R, G; const int32_t* cate_by_key;
+  int32_t *flags, *rank, *uniq, *n_uniq, *sendbuf; int32_t cap;
+  int32_t *cate_c, *comp, *status;
+  int32_t* status_host;                  /* optional PINNED host word: status is copied there behind the plan */
+  const tlsan_dims* dims; const tlsan_params* cp; const tlsan_batch* cb; void* state;
+  void *stream, *stream2;                /* hipStream_t */
+  void *ev_fork, *ev_planned, *ev_done0, *ev_done1;   /* hipEvent_t or NULL */
+  int32_t record_done0;
+} tlsan_static_plan;
+typedef struct {
+  /* gather */
+  const float* shard; int32_t ld, R, W; const int32_t* recvbuf; int32_t cap, G; void* rows_out; int32_t* recv_rows;
+  uint64_t* slots64; uint32_t* stamp;
+  int32_t wire, d_emb, tail, pitch;      /* wire != 0: tlsan_shard_gather_wire_bf16(d_emb, tail, pitch) */
+  /* grads */
+  const tlsan_dims* dims; const tlsan_params* cp; const tlsan_batch* cb; tlsan_hparams hp; tlsan_grads_out go; tlsan_step_out out;
+  void* state; void* ws; size_t ws_bytes;
+  /* summary */
+  float* flat; int32_t n_dense, n_cate; float lr, reg, clip; const double* S_cate; float* dense; float* dense_KT;
+  const tlsan_dims* dims_full; float* step_dev; float* loss_out; float* gnorm_out; const tlsan_shard_optimizer* opt;
+  /* apply */
+  int32_t cI, reg_item, reg_user; const float* vals; int32_t ldv, marked; float gscale; float* cate_emb; int32_t C, dc;
+  const float* g_cate; double* sumsq_out; float* sumsq_f32; float* scale; void* lws; size_t lws_bytes;
+  /* plans: issued once the pinned word out.started has reached this value (steps count up; see below) */
+  uint32_t plans_after;
+} tlsan_static_step;
+int tlsan_shard_plan_static(const tlsan_static_plan* p);
+int tlsan_shard_step_static(const tlsan_static_step* s, int32_t phases, const tlsan_static_plan* const* plans, int32_t n_plans,
+                            void* stream);
+
 /* Exclusive prefix sum + compaction of a device int32 array (the id-routing step of the sharded
  * path): prefix[k] = sum(cnt[0..k)), uniq = ascending list of k with cnt[k] > 0 and
  * prefix_nz[k]... see below.  For 0/1 flags, prefix[k] is the compact index of k.

@@ -8,17 +8,17 @@ dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cu
 from tlsan_amd import synth
 from tlsan_amd.dist import ShardedModel
 cfg = synth.make_config("electronics")
-m = ShardedModel(cfg, synth.item_cate_list(cfg))
+m = ShardedModel(cfg, synth.item_cate_list(cfg), l2_mode="lazy", static_rows=True)
 dbs = [m.device_batch(b) for b in synth.make_batches(cfg, 4, 4096, seed=1)]
 for s in range(12):
-    m.train_async(dbs[s % 4], 1.0, next_batch=dbs[(s + 1) % 4])
+    m.train_async(dbs[s % 4], 1.0, next_batch=dbs[(s + 1) % 4], after_next=dbs[(s + 2) % 4])
 torch.cuda.synchronize()
 N = 300
 pr = cProfile.Profile()
 t0 = time.perf_counter()
 pr.enable()
 for s in range(N):
-    m.train_async(dbs[s % 4], 1.0, next_batch=dbs[(s + 1) % 4])
+    m.train_async(dbs[s % 4], 1.0, next_batch=dbs[(s + 1) % 4], after_next=dbs[(s + 2) % 4])
 pr.disable()
 t1 = time.perf_counter()
 torch.cuda.synchronize()

@@ -27,6 +27,7 @@ EXPORTS = [
     "tlsan_route_plan", "tlsan_shard_gather", "tlsan_shard_summary", "tlsan_shard_apply_workspace", "tlsan_shard_apply",
     "tlsan_shard_summary_opt", "tlsan_shard_apply_opt", "tlsan_shard_apply_lazy_workspace", "tlsan_shard_apply_lazy",
     "tlsan_route_plan_static", "tlsan_shard_gather_static", "tlsan_shard_apply_lazy_static", "tlsan_shard_gather_wire_bf16",
+    "tlsan_shard_plan_static", "tlsan_shard_step_static",
 ]
 PROF_SEGMENTS = ("index_build", "fwd_bwd", "dk_partial", "dense_finalize", "apply_rows")
 
@@ -88,6 +89,35 @@ class GradsOut(C.Structure):
                 ("item_emb", "item_b", "user_emb", "usert_emb", "cate_emb", "dense")] + \
                [(n, C.c_int32) for n in ("ld_item", "ld_itemb", "ld_user", "ld_usert", "sparse")]
 
+
+class StaticPlan(C.Structure):      # tlsan_static_plan (include/tlsan.h)
+    _fields_ = [("keys", C.c_void_p), ("n_keys", C.c_int32), ("R", C.c_int32), ("G", C.c_int32), ("cate_by_key", C.c_void_p),
+                ("flags", C.c_void_p), ("rank", C.c_void_p), ("uniq", C.c_void_p), ("n_uniq", C.c_void_p), ("sendbuf", C.c_void_p),
+                ("cap", C.c_int32), ("cate_c", C.c_void_p), ("comp", C.c_void_p), ("status", C.c_void_p), ("status_host", C.c_void_p),
+                ("dims", C.POINTER(Dims)), ("cp", C.POINTER(Params)), ("cb", C.POINTER(Batch)), ("state", C.c_void_p),
+                ("stream", C.c_void_p), ("stream2", C.c_void_p),
+                ("ev_fork", C.c_void_p), ("ev_planned", C.c_void_p), ("ev_done0", C.c_void_p), ("ev_done1", C.c_void_p),
+                ("record_done0", C.c_int32)]
+
+
+class StaticStep(C.Structure):      # tlsan_static_step (include/tlsan.h)
+    _fields_ = [("shard", C.c_void_p), ("ld", C.c_int32), ("R", C.c_int32), ("W", C.c_int32), ("recvbuf", C.c_void_p),
+                ("cap", C.c_int32), ("G", C.c_int32), ("rows_out", C.c_void_p), ("recv_rows", C.c_void_p),
+                ("slots64", C.c_void_p), ("stamp", C.c_void_p),
+                ("wire", C.c_int32), ("d_emb", C.c_int32), ("tail", C.c_int32), ("pitch", C.c_int32),
+                ("dims", C.POINTER(Dims)), ("cp", C.POINTER(Params)), ("cb", C.POINTER(Batch)), ("hp", HParams), ("go", GradsOut),
+                ("out", StepOut), ("state", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
+                ("flat", C.c_void_p), ("n_dense", C.c_int32), ("n_cate", C.c_int32), ("lr", C.c_float), ("reg", C.c_float),
+                ("clip", C.c_float), ("S_cate", C.c_void_p), ("dense", C.c_void_p), ("dense_KT", C.c_void_p),
+                ("dims_full", C.POINTER(Dims)), ("step_dev", C.c_void_p), ("loss_out", C.c_void_p), ("gnorm_out", C.c_void_p),
+                ("opt", C.POINTER(ShardOptimizer)),
+                ("cI", C.c_int32), ("reg_item", C.c_int32), ("reg_user", C.c_int32), ("vals", C.c_void_p), ("ldv", C.c_int32),
+                ("marked", C.c_int32), ("gscale", C.c_float), ("cate_emb", C.c_void_p), ("C", C.c_int32), ("dc", C.c_int32),
+                ("g_cate", C.c_void_p), ("sumsq_out", C.c_void_p), ("sumsq_f32", C.c_void_p), ("scale", C.c_void_p),
+                ("lws", C.c_void_p), ("lws_bytes", C.c_size_t), ("plans_after", C.c_uint32)]
+
+
+PHASE_GATHER, PHASE_GRADS, PHASE_SUMMARY, PHASE_APPLY = 1, 2, 4, 8
 
 _lib = None
 
@@ -200,6 +230,10 @@ def load():
                                                   C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                                   C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.tlsan_shard_apply_lazy_static.restype = C.c_int
+    lib.tlsan_shard_plan_static.argtypes = [P(StaticPlan)]
+    lib.tlsan_shard_plan_static.restype = C.c_int
+    lib.tlsan_shard_step_static.argtypes = [P(StaticStep), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.tlsan_shard_step_static.restype = C.c_int
     lib.tlsan_shard_apply_workspace.argtypes = [C.c_int32, C.c_int32]
     lib.tlsan_shard_apply_workspace.restype = C.c_size_t
     lib.tlsan_shard_apply.argtypes = [C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,

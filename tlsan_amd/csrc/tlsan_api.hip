@@ -1,6 +1,7 @@
 // tlsan_api.hip -- the C ABI declared in include/tlsan.h: argument checking, workspace carving
 // and kernel sequencing.  No allocation, no synchronisation; everything is enqueued on the
 // caller's stream (so a whole step can be captured into a hipGraph).
+#include <chrono>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1504,6 +1505,72 @@ int tlsan_profile_enable(int level) {
   g_prof_level = level;
   g_prof_n = 0;
   g_prof_tick = 0;
+  return TLSAN_OK;
+}
+
+int tlsan_shard_plan_static(const tlsan_static_plan* p) {
+  if (!p || !p->dims || !p->cp || !p->cb || !p->state) return fail(TLSAN_E_BADARG, "tlsan_shard_plan_static: NULL argument");
+  hipStream_t s1 = (hipStream_t)p->stream, s2 = (hipStream_t)p->stream2;
+  if (p->ev_fork && hipStreamWaitEvent(s1, (hipEvent_t)p->ev_fork, 0) != hipSuccess) return fail(TLSAN_E_LAUNCH, "wait(fork)");
+  int rc = tlsan_route_plan_static(p->keys, p->n_keys, p->R, p->G, p->cate_by_key, p->flags, p->rank, p->uniq, p->n_uniq,
+                                   p->sendbuf, p->cap, p->cate_c, p->comp, nullptr, p->status, p->stream);
+  if (rc) return rc;
+  if (p->status_host && hipMemcpyAsync(p->status_host, p->status, 4, hipMemcpyDeviceToHost, s1) != hipSuccess)
+    return fail(TLSAN_E_LAUNCH, "copy of the overflow word");
+  if (p->ev_planned && hipEventRecord((hipEvent_t)p->ev_planned, s1) != hipSuccess) return fail(TLSAN_E_LAUNCH, "record(planned)");
+  if ((rc = tlsan_state_recategorize(p->dims, p->cp, p->state, p->stream))) return rc;
+  if (p->stream2 != nullptr) {
+    if (p->ev_planned && hipStreamWaitEvent(s2, (hipEvent_t)p->ev_planned, 0) != hipSuccess) return fail(TLSAN_E_LAUNCH, "wait(planned)");
+    if ((rc = tlsan_batch_index(p->dims, p->cb, p->cp->item_cate, p->state, 0, p->stream2))) return rc;
+    if (p->ev_done1 && hipEventRecord((hipEvent_t)p->ev_done1, s2) != hipSuccess) return fail(TLSAN_E_LAUNCH, "record(done1)");
+  } else {
+    if ((rc = tlsan_batch_index(p->dims, p->cb, p->cp->item_cate, p->state, 0, p->stream))) return rc;
+  }
+  if (p->record_done0 && p->ev_done0 && hipEventRecord((hipEvent_t)p->ev_done0, s1) != hipSuccess) return fail(TLSAN_E_LAUNCH, "record(done0)");
+  return TLSAN_OK;
+}
+
+int tlsan_shard_step_static(const tlsan_static_step* s, int32_t phases, const tlsan_static_plan* const* plans, int32_t n_plans,
+                            void* stream) {
+  if (!s) return fail(TLSAN_E_BADARG, "tlsan_shard_step_static: NULL argument");
+  int rc;
+  if (phases & TLSAN_PHASE_GATHER) {
+    if (s->wire) rc = tlsan_shard_gather_wire_bf16(s->shard, s->ld, s->R, s->d_emb, s->tail, s->recvbuf, s->cap, s->G, s->rows_out,
+                                                   s->pitch, s->recv_rows, s->slots64, s->stamp, stream);
+    else rc = tlsan_shard_gather_static(s->shard, s->ld, s->R, s->W, s->recvbuf, s->cap, s->G, (float*)s->rows_out, s->recv_rows,
+                                        s->slots64, s->stamp, stream);
+    if (rc) return rc;
+  }
+  if (phases & TLSAN_PHASE_GRADS) {
+    if ((rc = tlsan_grads(s->dims, s->cp, s->cb, &s->hp, &s->go, &s->out, s->state, s->ws, s->ws_bytes, stream))) return rc;
+  }
+  if (phases & TLSAN_PHASE_SUMMARY) {
+    if ((rc = tlsan_shard_summary_opt(s->flat, s->n_dense, s->n_cate, s->G, s->lr, s->reg, s->clip, s->S_cate, s->dense, s->dense_KT,
+                                      s->dims_full, s->step_dev, s->loss_out, s->gnorm_out, s->opt, stream)))
+      return rc;
+  }
+  if (phases & TLSAN_PHASE_APPLY) {
+    if ((rc = tlsan_shard_apply_lazy_static(const_cast<float*>(s->shard), s->ld, s->cI, s->R, s->W, s->reg_item, s->reg_user, s->vals,
+                                            s->ldv, s->recv_rows, s->cap, s->G, s->slots64, s->stamp, s->marked, s->gscale,
+                                            s->step_dev, s->cate_emb, s->C, s->dc, s->g_cate, s->sumsq_out, s->sumsq_f32, s->scale,
+                                            s->lws, s->lws_bytes, stream)))
+      return rc;
+  }
+  if (plans && n_plans > 0) {
+    // The plans go to slots that earlier steps were the last to use: wait (on the host) until the pinned word says that
+    // step `plans_after` has started -- everything queued before that step is then complete.  No event on the main stream.
+    if (s->out.started != nullptr) {
+      volatile uint32_t* w = (volatile uint32_t*)s->out.started;
+      const auto t0 = std::chrono::steady_clock::now();
+      unsigned long polls = 0;
+      while ((int32_t)(*w - s->plans_after) < 0) {
+        if ((++polls & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
+          return fail(TLSAN_E_LAUNCH, "tlsan_shard_step_static: step %u did not start within 30 s", s->plans_after);
+      }
+    }
+    for (int k = 0; k < n_plans; ++k)
+      if (plans[k] && (rc = tlsan_shard_plan_static(plans[k]))) return rc;
+  }
   return TLSAN_OK;
 }
 

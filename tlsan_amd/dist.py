@@ -40,6 +40,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import time
 
 import numpy as np
 import torch
@@ -262,7 +263,7 @@ class ShardedModel:
     """Model surface (train / eval_auc / ...) over row-sharded tables; see module docstring."""
 
     def __init__(self, config, item_cate_list, device="cuda:0", seed=1234, group=None, l2_mode="dense", static_rows=False,
-                 wire_dtype="f32", init="numpy"):
+                 wire_dtype="f32", init="numpy", deferred_ids=False):
         """l2_mode: "dense" -- every owner decays every one of its rows every step, as the reference's dense L2
         gradient does; "lazy" (sgd) -- the same update kept as W = P * W_stored with one scale P that all ranks
         advance alike, so an owner touches only the rows whose gradients arrived (tlsan_shard_apply_lazy).
@@ -271,7 +272,10 @@ class ShardedModel:
           static_rows (lazy only): False -- exchange sizes follow the batch (the host reads them once per step);
         True or an int -- every (source, owner) pair exchanges a FIXED number of row slots (the int, or 1.5 x what
         the first batch needs, agreed over the ranks), no size reaches the host, and a step can be recorded in a HIP
-        graph (capture_step / replay).  A batch that needs more slots than that raises at the next host check."""
+        graph (capture_step / replay).  A batch that needs more slots than that raises at the next host check.
+          deferred_ids (static_rows): plans built ahead never carry their own id all-to-all -- the step that uses a plan
+        issues it, on the main stream -- which is what runs by default over RCCL (no second communicator); True forces
+        the same under the gloo exchange of the tests, whose default keeps a side group."""
         if l2_mode not in ("dense", "lazy"):
             raise ValueError("l2_mode must be 'dense' or 'lazy'")
         self.lazy = l2_mode == "lazy"
@@ -287,6 +291,7 @@ class ShardedModel:
         # every step.  Gradients travel back in fp32.
         self.wire_dtype = wire_dtype
         self.static_rows = static_rows
+        self.deferred_ids = bool(deferred_ids)
         self._st = None            # static-shape buffers (made at the first training batch)
         if not dist.is_initialized():
             raise RuntimeError("ShardedModel needs torch.distributed to be initialised (one process per GPU)")
@@ -788,7 +793,13 @@ class ShardedModel:
                   slots=[None] * _STATIC_SLOTS, next=0, side=side, side2=side2,
                   fork=torch.cuda.Event(),
                   side_group=None, checked=0, graphs=0, warm=False)
-        if G > 1 and (_staged(self.group) or os.environ.get("TLSAN_SIDE_COMM", "0") == "1"):
+        st["fork"].record()
+        from .model import _STARTED_WORDS
+        st["started"] = torch.zeros(16, dtype=torch.int32).pin_memory()
+        _STARTED_WORDS.append(st["started"])          # (a queued step writes it when it starts: it outlives the model)
+        st["started_word"] = C.c_uint32.from_address(st["started"].data_ptr())
+        st["start_seq"] = 0
+        if G > 1 and not self.deferred_ids and (_staged(self.group) or os.environ.get("TLSAN_SIDE_COMM", "0") == "1"):
             # the next batch's id exchange runs on the side stream while the main stream's collectives are in
             # flight: a communicator of its own keeps the two sequences independent.  Two RCCL communicators with
             # kernels in flight on one device are only safe if every rank's GPU schedules them in a compatible
@@ -834,6 +845,9 @@ class ShardedModel:
                       state=torch.zeros(int(nst), dtype=torch.uint8, device=dev), db=None, views={},
                       done=(torch.cuda.Event(), torch.cuda.Event()), planned=torch.cuda.Event(), pending=False, fresh=False)
             sl["state"][:4].view(torch.float32).fill_(1.0)     # table scale P = 1 (the owners apply the decay)
+            sl["plan_args"], sl["step_args"] = {}, {}
+            for ev in sl["done"] + (sl["planned"],):            # (a torch event gets its handle at its first record: the
+                ev.record()                                     #  library's argument blocks hold the raw handles)
             st["slots"][k] = sl
         self._st = st
         return st
@@ -874,6 +888,44 @@ class ShardedModel:
         sl["views"][id(db)] = (db, out)
         return out
 
+    def _static_step_args(self, sl, db):
+        """tlsan_static_step of (slot, batch): every pointer of the step's four launches (cached; lr, the dropout seed and
+        the sample offset are filled in per step)."""
+        hit = sl["step_args"].get(id(db))
+        if hit is not None and hit[0] is db and hit[2] is self._ws:     # (the workspace may have been re-allocated)
+            return hit[1]
+        if len(sl["step_args"]) >= 16:
+            sl["step_args"].clear()
+        st = self._st
+        G, W, di, Ls, Cc = self.world, self.W, self.di, self.Ls, self.C
+        cp, cb = self._static_views(sl, db)
+        n_dense, n_cate = self.lay.n_dense, Cc * self.dc
+        flat, gf = self._flat, st["gf"]
+        fp, g0 = flat.data_ptr(), gf.data_ptr()
+        tail = fp + 4 * (n_dense + n_cate)
+        rb = (sl["recvbuf"] if G > 1 else sl["sendbuf"]).data_ptr()
+        ss = L.StaticStep()
+        ss.shard, ss.ld, ss.R, ss.W, ss.recvbuf, ss.cap, ss.G = self.shard.data_ptr(), W, self.router.R, W, rb, st["cap"], G
+        ss.rows_out, ss.recv_rows = sl["rows"].data_ptr(), sl["recv_rows"].data_ptr()
+        ss.slots64, ss.stamp = self._slots64.data_ptr(), st["stamp"].data_ptr()
+        ss.wire, ss.d_emb, ss.tail, ss.pitch = (1 if st["wire"] else 0), di, st["tail"], st["pitch"]
+        ss.dims, ss.cp, ss.cb = C.pointer(st["dims"]), C.pointer(cp), C.pointer(cb)
+        ss.hp = L.HParams(1.0, 0.0, self.clip, L.NORM_TF18, L.L2_DENSE, 0, 1, self.dropout, 0, 0)
+        ss.go = L.GradsOut(g0, g0 + 4 * di, g0, g0 + 4 * di, fp + 4 * n_dense, fp, W, W, W, W, 2)
+        ss.out = L.StepOut(tail, self._gn_local.data_ptr(), None, tail + 4)
+        ss.state, ss.ws, ss.ws_bytes = sl["state"].data_ptr(), self._ws.data_ptr(), self._ws.numel()
+        ss.flat, ss.n_dense, ss.n_cate, ss.lr, ss.reg, ss.clip = fp, n_dense, n_cate, 1.0, self.reg, self.clip
+        ss.S_cate, ss.dense, ss.dense_KT = self._sq.data_ptr() + 8, self.dense.data_ptr(), self.dense_KT.data_ptr()
+        ss.dims_full, ss.step_dev = C.pointer(self.dims_full), self._step_dev.data_ptr()
+        ss.loss_out, ss.gnorm_out, ss.opt = self.last_loss.data_ptr(), self.last_gnorm.data_ptr(), C.pointer(self._sopt_lazy)
+        ss.cI, ss.reg_item, ss.reg_user = self.cI, di, di + Ls
+        ss.vals, ss.ldv, ss.marked, ss.gscale = (st["vals"] if G > 1 else gf).data_ptr(), W, 1, 1.0 / G
+        ss.cate_emb, ss.C, ss.dc, ss.g_cate = self.cate_emb.data_ptr(), Cc, self.dc, fp + 4 * n_dense
+        ss.sumsq_out, ss.sumsq_f32, ss.scale = self._sq.data_ptr(), tail + 8, self._P.data_ptr()
+        ss.lws, ss.lws_bytes = st["lws"].data_ptr(), st["lws"].numel()
+        sl["step_args"][id(db)] = (db, ss, self._ws)
+        return ss
+
     def _static_discard(self, sl, stream):
         """A plan that was built into the slot and never trained (an announcement that was abandoned, a restore, a
         capture over a slot an eager step had planned): its destination index is still counted into the slot's
@@ -889,54 +941,80 @@ class ShardedModel:
         sl["pending"] = sl["fresh"] = False
         sl["db"] = None
 
-    def _static_plan(self, db, k, stream, group, stream2=None):
-        """Routing plan of `db` into slot k, destination index included: device work only, queued on `stream`
-        (the destination index on `stream2` when given: it needs the plan's compact ids, the category index needs its
-        category map -- two independent tails; the slot's `done` events then mark their ends)."""
+    def _static_plan_args(self, sl, db, stream, group, stream2):
+        """tlsan_static_plan of (slot, batch, streams): the pointers are constants of the combination (cached)."""
         st, r = self._st, self.router
-        sl = st["slots"][k]
-        if sl["fresh"]:          # an unconsumed plan sits in the slot: take its index out first
-            self._static_discard(sl, stream)
-        sp = C.c_void_p(stream.cuda_stream)
-        nk = int(db.keys.numel())
+        key = (id(db), stream.cuda_stream, None if stream2 is None else stream2.cuda_stream)
+        hit = sl["plan_args"].get(key)
+        if hit is not None and hit[0] is db:
+            return hit[1]
+        if len(sl["plan_args"]) >= 16:
+            sl["plan_args"].clear()
         cp, cb = self._static_views(sl, db)
-        L.check(self.lib.tlsan_route_plan_static(db.keys.data_ptr(), nk, r.R, r.G, self.cate_by_key.data_ptr(),
-                                                 self._flags.data_ptr(), sl["rank"].data_ptr(), sl["uniq"].data_ptr(),
-                                                 sl["n_uniq"].data_ptr(), sl["sendbuf"].data_ptr(), st["cap"],
-                                                 sl["cate_c"].data_ptr(), sl["comp"].data_ptr(), None,
-                                                 st["status"].data_ptr(), sp), "tlsan_route_plan_static")
-        if not torch.cuda.is_current_stream_capturing():
-            # the overflow word travels to pinned host memory behind the plan that may have raised it (on the plan's own
-            # stream: nothing on the step's critical path); the next steps look at the copy without synchronising
-            with torch.cuda.stream(stream):
-                st["status_host"].copy_(st["status"], non_blocking=True)
-        dims = st["dims"]
-        # the category index of the compact table; the destination index waits for the plan, not for it (it is handed the
-        # compact table's item -> category map itself, which the plan wrote)
-        sl["planned"].record(stream)
-        L.check(self.lib.tlsan_state_recategorize(C.byref(dims), C.byref(cp), sl["state"].data_ptr(), sp), "tlsan_state_recategorize")
-        if stream2 is not None:
-            stream2.wait_event(sl["planned"])
-            L.check(self.lib.tlsan_batch_index(C.byref(dims), C.byref(cb), cp.item_cate, sl["state"].data_ptr(), 0,
-                                               C.c_void_p(stream2.cuda_stream)), "tlsan_batch_index")
-            sl["done"][1].record(stream2)
+        ids_here = self._static_ids_in_plan(stream, group)
+        pa = L.StaticPlan(db.keys.data_ptr(), int(db.keys.numel()), r.R, r.G, self.cate_by_key.data_ptr(),
+                          self._flags.data_ptr(), sl["rank"].data_ptr(), sl["uniq"].data_ptr(), sl["n_uniq"].data_ptr(),
+                          sl["sendbuf"].data_ptr(), st["cap"], sl["cate_c"].data_ptr(), sl["comp"].data_ptr(),
+                          st["status"].data_ptr(), st["status_host"].data_ptr(),
+                          C.pointer(st["dims"]), C.pointer(cp), C.pointer(cb), sl["state"].data_ptr(),
+                          stream.cuda_stream, None if stream2 is None else stream2.cuda_stream,
+                          None, sl["planned"].cuda_event, sl["done"][0].cuda_event if stream2 is not None else None,
+                          sl["done"][1].cuda_event if stream2 is not None else None,
+                          1 if (stream2 is not None and not ids_here) else 0)
+        sl["plan_args"][key] = (db, pa)
+        return pa
+
+    def _static_ids_in_plan(self, stream, group):
+        """Does the plan carry its own id all-to-all (on `stream`)?  Over several ranks: yes when it is built in line on
+        the main stream, or ahead on a side stream with a communicator of its own (or over the host-staged gloo exchange
+        of the tests, which is serial anyway); a plan built ahead WITHOUT one (the default over RCCL, see _static_setup;
+        deferred_ids=True forces it anywhere) leaves the exchange to the step that uses it, in the main communicator's
+        program order."""
+        if self.world == 1:
+            return False
+        if stream == torch.cuda.current_stream(self.device):
+            return True
+        if self.deferred_ids:
+            return False
+        return group is not None or _staged(self.group)
+
+    def _static_plan_tail(self, sl, stream, group, stream2):
+        """What follows the plan's launches on the host: the id exchange, when the plan carries it, and the event behind it."""
+        ids_here = self._static_ids_in_plan(stream, group)
         sl["ids_sent"] = True
         if self.world > 1:
-            if group is None and stream != torch.cuda.current_stream(self.device) and not _staged(self.group):
-                # plan built ahead on a side stream and no communicator of its own for it (the default, see
-                # _static_setup): the id exchange is left to the step that uses the plan, on the main stream, in the
-                # main communicator's program order
+            if not ids_here:
                 sl["ids_sent"] = False
             else:
                 with torch.cuda.stream(stream):
                     a2a(sl["recvbuf"].view(-1), sl["sendbuf"].view(-1), None, None, group if group is not None else self.group)
-        if stream2 is None:
-            L.check(self.lib.tlsan_batch_index(C.byref(dims), C.byref(cb), cp.item_cate, sl["state"].data_ptr(), 0, sp), "tlsan_batch_index")
-        else:
-            sl["done"][0].record(stream)
+                if stream2 is not None:
+                    sl["done"][0].record(stream)
+
+    def _static_plan(self, db, k, stream, group, stream2=None, defer=False):
+        """Routing plan of `db` into slot k, destination index included: device work only, queued on `stream`
+        (the destination index on `stream2` when given: it needs the plan's compact ids, the category index needs its
+        category map -- two independent tails; the slot's `done` events then mark their ends).  One library call
+        (tlsan_shard_plan_static); defer=True returns its argument block instead of issuing it (the step's own call
+        issues it behind its forward/backward kernel) -- only for plans whose id exchange is not part of the plan."""
+        st, r = self._st, self.router
+        sl = st["slots"][k]
+        if sl["fresh"]:          # an unconsumed plan sits in the slot: take its index out first
+            self._static_discard(sl, stream)
+        pa = self._static_plan_args(sl, db, stream, group, stream2)
+        # (the overflow word travels to pinned host memory behind the plan that may have raised it, on the plan's own
+        #  stream; the next steps look at the copy without synchronising.  Not part of a recording.)
+        pa.status_host = None if torch.cuda.is_current_stream_capturing() else st["status_host"].data_ptr()
+        if not defer:
+            L.check(self.lib.tlsan_shard_plan_static(C.byref(pa)), "tlsan_shard_plan_static")
+            self._static_plan_tail(sl, stream, group, stream2)
         sl["pending"] = stream2 is not None
         sl["db"] = db
         sl["fresh"] = True      # (a step consumes its plan: the destination index counts down to zero)
+        if defer:
+            sl["ids_sent"] = self.world == 1
+            return pa
+        return None
 
     def check_static_overflow(self):
         """Host check of the static exchange (synchronises): raises when a batch needed more row slots of one owner
@@ -972,8 +1050,10 @@ class ShardedModel:
             self._static_plan(db, k, main, self.group)
         elif sl["pending"]:
             if not capturing:                    # (recorded steps join their side work at their own end)
-                main.wait_event(sl["done"][0])
-                main.wait_event(sl["done"][1])
+                # a HOST wait: announced two batches ahead the plan is long done, and a device-side wait is a barrier packet
+                # in the main queue (~6 us of idle GPU each; the single-GPU Model waits on the host for the same reason)
+                sl["done"][0].synchronize()
+                sl["done"][1].synchronize()
             sl["pending"] = False
         sl["fresh"] = False
         if G > 1 and not sl.get("ids_sent", True):     # (plan built ahead without a side communicator: see _static_plan)
@@ -982,71 +1062,85 @@ class ShardedModel:
         st["next"] = (k + 1) % NS
         ahead = [(self.device_batch(b), (k + 1 + j) % NS) for j, b in enumerate((next_batch, after_next)) if b is not None]
         ahead = [(b, kk) for b, kk in ahead if not (st["slots"][kk]["db"] is b and st["slots"][kk]["fresh"])]
-        if ahead:
+        use_flag = bool(ahead) and not capturing       # (see tlsan_shard_step_static: no event on the main stream)
+        if ahead and not use_flag:
             st["fork"].record(main)      # everything before this step: the slots the new plans go to are free from here
 
-        def plan_ahead():
-            # plans and indices of the announced batches on two more streams, beside this step from its start
-            st["side"].wait_event(st["fork"])
-            for b, kk in ahead:
-                self._static_plan(b, kk, st["side"], st["side_group"], st["side2"])
-
-        # Where in the host's launch order the plans go (the device-side dependencies are the same): after the
-        # forward/backward.  That kernel fills the GPU, so a plan can only run beside the small kernels around it;
-        # queued ahead of it, the plan delays it.  One rank, same box: eager 110 us either way, graph replay 113 us with
-        # the plan queued after the kernel, 153 us before.
-        cp, cb = self._static_views(sl, db)
-        dims, n = st["dims"], st["n"]
+        # The step is issued in as few library calls as there are collectives in it (tlsan_shard_step_static: one at one
+        # rank) from an argument block that is a constant of (slot, batch) -- as ~15 Python-level calls the HOST took
+        # 100 us per step for 77 us of kernels.  Where the plans of the announced batches go in the launch order (the
+        # device-side dependencies are the same either way): behind the forward/backward.  That kernel fills the GPU,
+        # so a plan can only run beside the small kernels around it; queued ahead of it, the plan delays it (one rank,
+        # same box: graph replay 113 us with the plan queued after the kernel, 153 us before).
+        ss = self._static_step_args(sl, db)
+        ss.hp.lr = float(lr); ss.lr = float(lr)
+        ss.hp.dropout_seed = self.dropout_seed() if self.dropout > 0.0 else 0
+        ss.hp.dropout_sample0 = int(sample0)
         sp = C.c_void_p(main.cuda_stream)
-        rb = (sl["recvbuf"] if G > 1 else sl["sendbuf"]).data_ptr()
-        if st["wire"]:
-            st["cate_bf16"].copy_(self.cate_emb)      # (round to nearest even; the table is small and replicated)
-            L.check(self.lib.tlsan_shard_gather_wire_bf16(self.shard.data_ptr(), W, self.router.R, di, st["tail"], rb, st["cap"], G,
-                                                          sl["rows"].data_ptr(), st["pitch"], sl["recv_rows"].data_ptr(),
-                                                          self._slots64.data_ptr(), st["stamp"].data_ptr(), sp),
-                    "tlsan_shard_gather_wire_bf16")
-        else:
-            L.check(self.lib.tlsan_shard_gather_static(self.shard.data_ptr(), W, self.router.R, W, rb, st["cap"], G,
-                                                       sl["rows"].data_ptr(), sl["recv_rows"].data_ptr(),
-                                                       self._slots64.data_ptr(), st["stamp"].data_ptr(), sp),
-                    "tlsan_shard_gather_static")
-        if G > 1:
-            a2a(sl["table"].view(-1), sl["rows"].view(-1), None, None, self.group)
         n_dense, n_cate = self.lay.n_dense, Cc * self.dc
         flat, gf = self._flat, st["gf"]
-        fp, g0 = flat.data_ptr(), gf.data_ptr()
-        go = L.GradsOut(g0, g0 + 4 * di, g0, g0 + 4 * di, fp + 4 * n_dense, fp, W, W, W, W, 2)
-        tail = fp + 4 * (n_dense + n_cate)
-        out = L.StepOut(tail, self._gn_local.data_ptr(), None, tail + 4)
-        hp = L.HParams(float(lr), 0.0, self.clip, L.NORM_TF18, L.L2_DENSE, 0, 1, self.dropout,
-                       self.dropout_seed() if self.dropout > 0.0 else 0, int(sample0))
-        L.check(self.lib.tlsan_grads(C.byref(dims), C.byref(cp), C.byref(cb), C.byref(hp), C.byref(go), C.byref(out),
-                                     sl["state"].data_ptr(), self._ws.data_ptr(), self._ws.numel(), sp), "tlsan_grads")
-        if ahead:
-            plan_ahead()
-        if weight != 1.0:
-            kk = n_dense + n_cate
-            flat[:kk + 1].mul_(float(weight))
-            flat[kk + 1:kk + 2].mul_(float(weight) ** 2)
-            gf.mul_(float(weight))
-        if G > 1:
-            allreduce_sum(flat, self.group)
-        L.check(self.lib.tlsan_shard_summary_opt(fp, n_dense, n_cate, G, float(lr), self.reg, self.clip,
-                                                 self._sq.data_ptr() + 8, self.dense.data_ptr(), self.dense_KT.data_ptr(),
-                                                 C.byref(self.dims_full), self._step_dev.data_ptr(),
-                                                 self.last_loss.data_ptr(), self.last_gnorm.data_ptr(),
-                                                 C.byref(self._sopt_lazy), sp), "tlsan_shard_summary")
-        vals = gf
-        if G > 1:
-            vals = st["vals"]
-            a2a(vals.view(-1), gf.view(-1), None, None, self.group)
-        L.check(self.lib.tlsan_shard_apply_lazy_static(self.shard.data_ptr(), W, self.cI, self.router.R, W, di, di + Ls,
-                                                       vals.data_ptr(), W, sl["recv_rows"].data_ptr(), st["cap"], G,
-                                                       self._slots64.data_ptr(), st["stamp"].data_ptr(), 1, 1.0 / G,
-                                                       self._step_dev.data_ptr(), self.cate_emb.data_ptr(), Cc, self.dc,
-                                                       fp + 4 * n_dense, self._sq.data_ptr(), tail + 8, self._P.data_ptr(),
-                                                       st["lws"].data_ptr(), st["lws"].numel(), sp),
-                "tlsan_shard_apply_lazy_static")
+        plans, late = [], []          # argument blocks the step's own call issues / plans whose id exchange Python issues
+        for b_, kk in ahead:
+            if self._static_ids_in_plan(st["side"], st["side_group"]):
+                late.append((b_, kk))
+            else:
+                pa = self._static_plan(b_, kk, st["side"], st["side_group"], st["side2"], defer=True)
+                pa.ev_fork = None if use_flag else st["fork"].cuda_event
+                plans.append(pa)
+        parr = (C.POINTER(L.StaticPlan) * max(1, len(plans)))(*[C.pointer(x) for x in plans]) if plans else None
+
+        def run(phases, with_plans=False):
+            L.check(self.lib.tlsan_shard_step_static(C.byref(ss), phases, parr if with_plans else None,
+                                                     len(plans) if with_plans else 0, sp), "tlsan_shard_step_static")
+
+        if use_flag:      # the fused kernel stores the step's number into a pinned word when it begins to run
+            st["start_seq"] = (st["start_seq"] + 1) & 0x7FFFFFFF
+            ss.out.started, ss.out.started_value = st["started"].data_ptr(), st["start_seq"]
+            # the announced batches' plans go to slots that steps t - 2 and t - 3 were the last to use: "step t - 1 has
+            # started" is all they wait for -- long true when this step is queued, so the host does not block
+            ss.plans_after = (st["start_seq"] - 1) & 0x7FFFFFFF
+        else:
+            ss.out.started, ss.out.started_value = None, 0
+
+        def plan_late():
+            if use_flag:
+                word, want, t0, polls = st["started_word"], (st["start_seq"] - 1) & 0x7FFFFFFF, None, 0
+                while ((word.value - want) & 0x7FFFFFFF) >= 0x40000000:     # (not yet reached; the numbers wrap at 2^31)
+                    polls += 1
+                    if polls & 255:
+                        continue
+                    time.sleep(0)
+                    if t0 is None:
+                        t0 = time.perf_counter()
+                    elif time.perf_counter() - t0 > 30.0:
+                        raise RuntimeError("train_async: the step's first kernel did not start within 30 s")
+            else:
+                st["side"].wait_event(st["fork"])
+            for b_, kk in late:
+                self._static_plan(b_, kk, st["side"], st["side_group"], st["side2"])
+
+        if st["wire"]:
+            st["cate_bf16"].copy_(self.cate_emb)      # (round to nearest even; the table is small and replicated)
+        if G == 1 and weight == 1.0 and not late:
+            run(L.PHASE_GATHER | L.PHASE_GRADS | L.PHASE_SUMMARY | L.PHASE_APPLY, True)
+        else:
+            run(L.PHASE_GATHER)
+            if G > 1:
+                a2a(sl["table"].view(-1), sl["rows"].view(-1), None, None, self.group)
+            run(L.PHASE_GRADS, True)
+            if late:
+                plan_late()
+            if weight != 1.0:
+                kk = n_dense + n_cate
+                flat[:kk + 1].mul_(float(weight))
+                flat[kk + 1:kk + 2].mul_(float(weight) ** 2)
+                gf.mul_(float(weight))
+            if G > 1:
+                allreduce_sum(flat, self.group)
+            run(L.PHASE_SUMMARY)
+            if G > 1:
+                a2a(st["vals"].view(-1), gf.view(-1), None, None, self.group)
+            run(L.PHASE_APPLY)
         if ahead and capturing:              # a recording must join its forks; eager steps wait where a plan is used
             main.wait_stream(st["side"])
             main.wait_stream(st["side2"])
@@ -1083,6 +1177,11 @@ class ShardedModel:
             sl["pending"] = False
         if st["slots"][k0]["db"] is not db or not st["slots"][k0]["fresh"]:   # the recorded step expects its plan in place
             self._static_plan(db, k0, main, self.group)
+        if self.world > 1 and not self._static_ids_in_plan(st["side"], st["side_group"]):
+            # plans built ahead leave their id exchange to the step that uses them: EVERY replay of this step consumes a
+            # plan the previous graph built, so the recording must carry the exchange itself -- whatever the eager plan
+            # above has already sent (round 3 recorded g0 without it and replays consumed the first exchange's result)
+            st["slots"][k0]["ids_sent"] = False
         if st["slots"][k1]["fresh"]:                          # (an eager step announced a batch into k1: the graph builds the
             self._static_discard(st["slots"][k1], main)       #  next plan itself, every replay -- not on top of that one)
         st["slots"][k1]["fresh"] = False
