@@ -497,6 +497,7 @@ int tlsan_shard_apply_lazy_static(float* shard, int32_t ld, int32_t cI, int32_t 
 #define TLSAN_PHASE_GRADS 2
 #define TLSAN_PHASE_SUMMARY 4
 #define TLSAN_PHASE_APPLY 8
+#define TLSAN_PLAN_ASYNC 256   /* `plans` are issued by the library's launch thread (see tlsan_shard_plans_flush) */
 typedef struct {
   const int32_t* keys; int32_t n_keys, R, G; const int32_t* cate_by_key;
   int32_t *flags, *rank, *uniq, *n_uniq, *sendbuf; int32_t cap;
@@ -525,6 +526,14 @@ typedef struct {
   uint32_t plans_after;
 } tlsan_static_step;
 int tlsan_shard_plan_static(const tlsan_static_plan* p);
+/* With TLSAN_PLAN_ASYNC in `phases` (needs s->out.started) the plans are copied and handed to ONE launch thread of the
+ * library's own, which waits for the pinned word and issues them while the caller goes on with the main stream: a plan
+ * is seven launches + a copy + four event operations, the step six launches, and one host thread issuing both was the
+ * step's bound (85 us of HIP runtime calls per step for 77 us of kernels).  The only threading in the library (the header's
+ * "single host thread per GPU" holds for every other entry point).  tlsan_shard_plans_flush() returns when the thread has
+ * issued everything handed to it, with its first error if any: call it before waiting on a plan's events, before
+ * touching what a queued plan writes (discarding a slot), before a stream capture, before tearing the streams down. */
+int tlsan_shard_plans_flush(void);
 int tlsan_shard_step_static(const tlsan_static_step* s, int32_t phases, const tlsan_static_plan* const* plans, int32_t n_plans,
                             void* stream);
 

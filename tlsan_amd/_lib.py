@@ -27,7 +27,7 @@ EXPORTS = [
     "tlsan_route_plan", "tlsan_shard_gather", "tlsan_shard_summary", "tlsan_shard_apply_workspace", "tlsan_shard_apply",
     "tlsan_shard_summary_opt", "tlsan_shard_apply_opt", "tlsan_shard_apply_lazy_workspace", "tlsan_shard_apply_lazy",
     "tlsan_route_plan_static", "tlsan_shard_gather_static", "tlsan_shard_apply_lazy_static", "tlsan_shard_gather_wire_bf16",
-    "tlsan_shard_plan_static", "tlsan_shard_step_static",
+    "tlsan_shard_plan_static", "tlsan_shard_step_static", "tlsan_shard_plans_flush",
 ]
 PROF_SEGMENTS = ("index_build", "fwd_bwd", "dk_partial", "dense_finalize", "apply_rows")
 
@@ -117,7 +117,7 @@ class StaticStep(C.Structure):      # tlsan_static_step (include/tlsan.h)
                 ("lws", C.c_void_p), ("lws_bytes", C.c_size_t), ("plans_after", C.c_uint32)]
 
 
-PHASE_GATHER, PHASE_GRADS, PHASE_SUMMARY, PHASE_APPLY = 1, 2, 4, 8
+PHASE_GATHER, PHASE_GRADS, PHASE_SUMMARY, PHASE_APPLY, PLAN_ASYNC = 1, 2, 4, 8, 256
 
 _lib = None
 
@@ -234,6 +234,8 @@ def load():
     lib.tlsan_shard_plan_static.restype = C.c_int
     lib.tlsan_shard_step_static.argtypes = [P(StaticStep), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
     lib.tlsan_shard_step_static.restype = C.c_int
+    lib.tlsan_shard_plans_flush.argtypes = []
+    lib.tlsan_shard_plans_flush.restype = C.c_int
     lib.tlsan_shard_apply_workspace.argtypes = [C.c_int32, C.c_int32]
     lib.tlsan_shard_apply_workspace.restype = C.c_size_t
     lib.tlsan_shard_apply.argtypes = [C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,

@@ -2,6 +2,10 @@
 // and kernel sequencing.  No allocation, no synchronisation; everything is enqueued on the
 // caller's stream (so a whole step can be captured into a hipGraph).
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1530,6 +1534,76 @@ int tlsan_shard_plan_static(const tlsan_static_plan* p) {
   return TLSAN_OK;
 }
 
+// ---- the announced batches' plans on a launch thread of the library's own ------------------------------------------
+// A plan is seven launches, a copy and four event operations on streams of its own; the step beside it is six launches
+// on the main stream.  Issued by one host thread they cost it ~85 us per step for 77 us of kernels (the HIP runtime, not
+// Python: scripts/shard_cprof.py), so the step was bound by its host.  With TLSAN_PLAN_ASYNC (phases bit) the plans are
+// handed, by value, to one worker thread per process, which waits for the pinned word and issues them while the calling
+// thread goes on with the main stream.  tlsan_shard_plans_flush() returns once the worker has issued everything handed
+// to it (and reports its first error): call it before waiting on a plan's events, before re-using what a plan writes
+// from the calling thread, and before a stream capture.
+struct PlanJob {
+  tlsan_static_plan p;
+  tlsan_dims dims; tlsan_params cp; tlsan_batch cb;
+  volatile uint32_t* word; uint32_t after;
+  int device;
+};
+// (never destroyed: the worker sleeps on g_pcv when the process exits, and destroying a condition variable that has a
+//  waiter blocks in glibc -- every process that had used the thread would hang at exit)
+static std::mutex& g_pm = *new std::mutex;
+static std::condition_variable& g_pcv = *new std::condition_variable;
+static std::condition_variable& g_pidle = *new std::condition_variable;
+static std::deque<PlanJob>& g_pq = *new std::deque<PlanJob>;
+static bool g_pbusy = false, g_pstarted = false;
+static int g_prc = 0;
+static char g_pmsg[512] = "";
+
+static void plan_worker() {
+  for (;;) {
+    PlanJob j;
+    {
+      std::unique_lock<std::mutex> lk(g_pm);
+      g_pcv.wait(lk, [] { return !g_pq.empty(); });
+      j = g_pq.front();
+      g_pq.pop_front();
+      g_pbusy = true;
+    }
+    int rc = TLSAN_OK;
+    if (hipSetDevice(j.device) != hipSuccess) rc = fail(TLSAN_E_LAUNCH, "plan worker: hipSetDevice(%d)", j.device);
+    if (!rc && j.word != nullptr) {
+      const auto t0 = std::chrono::steady_clock::now();
+      unsigned long polls = 0;
+      while ((int32_t)(*j.word - j.after) < 0) {
+        if ((++polls & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
+          rc = fail(TLSAN_E_LAUNCH, "plan worker: step %u did not start within 30 s", j.after);
+          break;
+        }
+      }
+    }
+    if (!rc) {
+      j.p.dims = &j.dims; j.p.cp = &j.cp; j.p.cb = &j.cb;
+      rc = tlsan_shard_plan_static(&j.p);
+    }
+    {
+      std::lock_guard<std::mutex> lk(g_pm);
+      if (rc && !g_prc) { g_prc = rc; snprintf(g_pmsg, sizeof(g_pmsg), "%s", g_err); }
+      g_pbusy = false;
+      if (g_pq.empty()) g_pidle.notify_all();
+    }
+  }
+}
+
+int tlsan_shard_plans_flush(void) {
+  std::unique_lock<std::mutex> lk(g_pm);
+  g_pidle.wait(lk, [] { return g_pq.empty() && !g_pbusy; });
+  if (g_prc) {
+    const int rc = g_prc;
+    g_prc = 0;
+    return fail(rc, "%s", g_pmsg);
+  }
+  return TLSAN_OK;
+}
+
 int tlsan_shard_step_static(const tlsan_static_step* s, int32_t phases, const tlsan_static_plan* const* plans, int32_t n_plans,
                             void* stream) {
   if (!s) return fail(TLSAN_E_BADARG, "tlsan_shard_step_static: NULL argument");
@@ -1556,7 +1630,24 @@ int tlsan_shard_step_static(const tlsan_static_step* s, int32_t phases, const tl
                                             s->lws, s->lws_bytes, stream)))
       return rc;
   }
-  if (plans && n_plans > 0) {
+  if (plans && n_plans > 0 && (phases & TLSAN_PLAN_ASYNC)) {
+    if (s->out.started == nullptr) return fail(TLSAN_E_BADARG, "TLSAN_PLAN_ASYNC needs the started word (out.started)");
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_pm);
+    if (!g_pstarted) {
+      std::thread(plan_worker).detach();
+      g_pstarted = true;
+    }
+    for (int k = 0; k < n_plans; ++k) {
+      if (!plans[k]) continue;
+      PlanJob j;
+      j.p = *plans[k]; j.dims = *plans[k]->dims; j.cp = *plans[k]->cp; j.cb = *plans[k]->cb;
+      j.word = (volatile uint32_t*)s->out.started; j.after = s->plans_after; j.device = dev;
+      g_pq.push_back(j);
+    }
+    g_pcv.notify_one();
+  } else if (plans && n_plans > 0) {
     // The plans go to slots that earlier steps were the last to use: wait (on the host) until the pinned word says that
     // step `plans_after` has started -- everything queued before that step is then complete.  No event on the main stream.
     if (s->out.started != nullptr) {

@@ -545,6 +545,7 @@ class ShardedModel:
         step and the successor it has announced (whose plan and indices are waiting in the other slots)."""
         if self._st is not None:   # static-shape training: plans announced ahead may be running on the side streams
             main = torch.cuda.current_stream(self.device)     # (they use the same mark scratch as this plan)
+            self._flush_plans()
             main.wait_stream(self._st["side"])
             main.wait_stream(self._st["side2"])
         return self._plan_stage2(self._plan_stage1(db, 2))
@@ -926,6 +927,12 @@ class ShardedModel:
         sl["step_args"][id(db)] = (db, ss, self._ws)
         return ss
 
+    def _flush_plans(self):
+        """Plans handed to the library's launch thread (tlsan_shard_step_static, TLSAN_PLAN_ASYNC) are issued when that
+        thread gets to them: wait until it has, before anything on this thread that must come BEHIND a plan's launches
+        (waiting on its events or streams, clearing what it writes, a stream capture)."""
+        L.check(self.lib.tlsan_shard_plans_flush(), "tlsan_shard_plans_flush")
+
     def _static_discard(self, sl, stream):
         """A plan that was built into the slot and never trained (an announcement that was abandoned, a restore, a
         capture over a slot an eager step had planned): its destination index is still counted into the slot's
@@ -933,6 +940,8 @@ class ShardedModel:
         zero -- so a second plan on top would double every count and the row sums would run past their segments.
         Clear everything behind the state's header (the category index is rebuilt by every plan anyway), after
         whatever the abandoned plan still has in flight."""
+        if not torch.cuda.is_current_stream_capturing():
+            self._flush_plans()
         if sl["pending"] and not torch.cuda.is_current_stream_capturing():
             stream.wait_event(sl["done"][0])
             stream.wait_event(sl["done"][1])
@@ -1022,6 +1031,7 @@ class ShardedModel:
         st = self._st
         if st is None:
             return
+        self._flush_plans()
         need = int(st["status"].item())
         if need > st["cap"]:
             raise RuntimeError("static_rows: a batch needed %d rows of one owner, the exchange holds %d per pair; "
@@ -1045,6 +1055,7 @@ class ShardedModel:
         sl = st["slots"][k]
         if sl["db"] is not db or not sl["fresh"]:      # not announced by an earlier step: plan it now, in line
             if not capturing:
+                self._flush_plans()
                 main.wait_stream(st["side"])     # (whatever an abandoned announcement left running in the slots)
                 main.wait_stream(st["side2"])
             self._static_plan(db, k, main, self.group)
@@ -1052,6 +1063,7 @@ class ShardedModel:
             if not capturing:                    # (recorded steps join their side work at their own end)
                 # a HOST wait: announced two batches ahead the plan is long done, and a device-side wait is a barrier packet
                 # in the main queue (~6 us of idle GPU each; the single-GPU Model waits on the host for the same reason)
+                self._flush_plans()                  # (the launch thread has recorded the events by then)
                 sl["done"][0].synchronize()
                 sl["done"][1].synchronize()
             sl["pending"] = False
@@ -1090,6 +1102,9 @@ class ShardedModel:
         parr = (C.POINTER(L.StaticPlan) * max(1, len(plans)))(*[C.pointer(x) for x in plans]) if plans else None
 
         def run(phases, with_plans=False):
+            # (plans: issued by the library's launch thread while this one goes on with the main stream -- not under capture)
+            if with_plans and plans and use_flag:
+                phases |= L.PLAN_ASYNC
             L.check(self.lib.tlsan_shard_step_static(C.byref(ss), phases, parr if with_plans else None,
                                                      len(plans) if with_plans else 0, sp), "tlsan_shard_step_static")
 
@@ -1169,6 +1184,7 @@ class ShardedModel:
         if st is None or not st["warm"]:
             raise RuntimeError("capture_step: run one eager step first (one-time initialisation cannot be recorded)")
         main = torch.cuda.current_stream(self.device)
+        self._flush_plans()
         main.wait_stream(st["side"])                          # nothing of the eager steps is left in flight
         main.wait_stream(st["side2"])
         k0, step0 = st["next"], self._step
@@ -1447,6 +1463,7 @@ class ShardedModel:
             self._st["stamp"].fill_(1)
             self._st["next"] = 0
             main = torch.cuda.current_stream(self.device)
+            self._flush_plans()
             main.wait_stream(self._st["side"])
             main.wait_stream(self._st["side2"])
             for sl in self._st["slots"]:
