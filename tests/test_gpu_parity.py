@@ -274,9 +274,9 @@ def test_errors():
     cfg = make_config(d=64, optimizer="adagrad")          # not one of model.py:188-195
     with pytest.raises(ValueError):
         Model(cfg, np.zeros(cfg["item_count"], np.int32))
-    cfg = make_config(d=64, dropout=0.1)                   # dropout is built for fp32 tables
+    cfg = make_config(d=64, dropout=0.1)                   # dropout is built for fp32 matrix products (any table storage)
     with pytest.raises(NotImplementedError):
-        Model(cfg, np.zeros(cfg["item_count"], np.int32), table_dtype="bf16")
+        Model(cfg, np.zeros(cfg["item_count"], np.int32), matrix_dtype="bf16")
     cfg = make_config(d=64)
     m = Model(cfg, np.zeros(cfg["item_count"], np.int32))
     b, _ = random_batch(cfg, B=4, Sn=2, seed=1)
