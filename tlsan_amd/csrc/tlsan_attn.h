@@ -437,8 +437,18 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   float* sL = FLAT ? sB0 : sB0 + NSB * LSTR;   // [NSB][LSTR]  long, kept for the fused dK product (TRAIN && FUSE_DK) and for FLAT's backward
   float* sS = sL + ((TRAIN && ((G::FUSE_DK && FUSE_RT) || (FLAT && !FLATG))) ? NSB * LSTR : 0);  // [NW][4] scalar staging  (sL exists in launches that fuse: tlsan_attn_inst.h)
   float* sH = sS + NW * 4;            // [NSB][2*LS] hist_t and usert*hist_t of the pass  (FLAT: [2][NF], by flat index)
-  float* sW = sH + NSB * 2 * LSC;     // [2][WB] attention weights (W1,b1,W2,b2) of both blocks
-  int* sP = (int*)(sW + (USE_SW ? 2 * WB : 0));  // [NSB][PSTR] destination-sorted row of every use
+  float* sW = sH + NSB * 2 * LSC;     // [2][WB] attention weights (W1,b1,W2,b2) of both blocks  (PERM: [2][WBP], see below)
+  // PERM (two 16-channel blocks per column, d = 256): the weight fragments are re-read from the LDS at every position
+  // (Geo::AT_USE), and read from the row-major copy that costs 8 two-dword reads with computed addresses per fragment,
+  // four-way bank-conflicted (a fragment's lanes (q, r) read W[(16 kb + 4 q + s) * 32 + 16 jb + r]: the four q hit the
+  // same banks) -- 26 M conflict cycles per launch, 28 % of the kernel's time (profiles/r04_pmc_d256_summary.txt).  The LDS
+  // copy is therefore kept in FRAGMENT order, every matrix twice: table [pair][lane][4] with pair = the fragment's
+  // (out block, in block) -- a fragment is NB * NB conflict-free 16-byte reads at constant offsets from the lane's base.
+  // Per attention block: [W1 as T fragments | W2 as T | W1 as N | W2 as N | b1 | b2].
+  constexpr bool PERM = USE_SW && NB > 1 && !LSTREAM;   // (streamed windows with dropout keep the row-major copy: the 16 KB more do not fit beside their position tables)
+  constexpr int PP = NB * NB * 256;            // floats of one fragment table
+  constexpr int WBP = 4 * PP + 2 * DH;         // floats of one attention block's weights in fragment order
+  int* sP = (int*)(sW + (USE_SW ? (PERM ? 2 * WBP : 2 * WB) : 0));  // [NSB][PSTR] destination-sorted row of every use
   // CSEG (FwdArgs.cseg, many categories): the category half of an item use's gradient row goes to the category's own
   // segment of Gc -- its position, drawn from the category's cursor, sits in sPc beside the item position in sP
   int* sPc = sP + (TRAIN ? NSB * PSTR : 0);      // [NSB][PSTR], only when a.cseg
@@ -494,15 +504,36 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   const float P = a.p.scale ? *a.p.scale : 1.0f;  // tables hold W / P (lazy L2 decay)
   const int Ls = a.Ls, Sn = a.b.Sn, B = a.b.B;
   // attention weights -> LDS once per workgroup (both blocks are contiguous runs of `dense`)
-  if constexpr (USE_SW) {
+  if constexpr (PERM) {
+    for (int o = tid; o < 2 * WBP; o += NW * 64) {
+      const int m = o / WBP, x = o - m * WBP;
+      const float* src = dn + (m ? a.lay.f2_W1 : a.lay.f1_W1);   // [W1 | b1 | W2 | b2] of the block, row-major
+      float v;
+      if (x < 4 * PP) {
+        const int tab = x / PP, y = x - tab * PP, pair = y >> 8, ln = (y >> 2) & 63, s_ = y & 3;
+        const int qq = ln >> 4, rr = ln & 15, pa = pair / NB, pb = pair % NB;
+        const float* W = src + ((tab & 1) ? DH * DH + DH : 0);    // W1 or W2
+        // T fragment (tab 0, 1): F[jb = pa][kb = pb][s] = W[16 kb + 4 q + s][16 jb + r]; N (tab 2, 3): F[kb = pa][jb = pb][s] = W[16 kb + r][16 jb + 4 q + s]
+        v = tab < 2 ? weff<DH>(W, 16 * pb + 4 * qq + s_, 16 * pa + rr) : weff<DH>(W, 16 * pa + rr, 16 * pb + 4 * qq + s_);
+      } else {
+        const int y = x - 4 * PP;
+        v = y < DH ? src[DH * DH + y] : src[2 * DH * DH + DH + (y - DH)];
+      }
+      sW[o] = v;
+    }
+    __syncthreads();
+  } else if constexpr (USE_SW) {
     for (int o = tid; o < 2 * WB; o += NW * 64)
       sW[o] = (o < WB) ? dn[a.lay.f1_W1 + o] : dn[a.lay.f2_W1 + (o - WB)];
     __syncthreads();
   }
   const float* wb1 = USE_SW ? sW : dn + a.lay.f1_W1;
-  const float* wb2 = USE_SW ? sW + WB : dn + a.lay.f2_W1;
-  const float *w1W1 = wb1, *w1b1 = wb1 + DH * DH, *w1W2 = w1b1 + DH, *w1b2 = w1W2 + DH * DH;
-  const float *w2W1 = wb2, *w2b1 = w2W1 + DH * DH, *w2W2 = w2b1 + DH, *w2b2 = w2W2 + DH * DH;
+  const float* wb2 = USE_SW ? sW + (PERM ? WBP : WB) : dn + a.lay.f2_W1;
+  // (PERM: wXW1 / wXW2 are the T-fragment tables; the N tables lie 2 * PP floats behind them)
+  const float *w1W1 = wb1, *w1b1 = wb1 + (PERM ? 4 * PP : DH * DH), *w1W2 = PERM ? wb1 + PP : w1b1 + DH, *w1b2 = PERM ? w1b1 + DH : w1W2 + DH * DH;
+  const float *w2W1 = wb2, *w2b1 = wb2 + (PERM ? 4 * PP : DH * DH), *w2W2 = PERM ? wb2 + PP : w2b1 + DH, *w2b2 = PERM ? w2b1 + DH : w2W2 + DH * DH;
+#define LD_T(W_, F_) do { if constexpr (PERM) load_frag_P<NB, MM>((W_), lane, F_); else load_frag_T<DH, NB, MM>((W_), q, r, F_); } while (0)
+#define LD_N(W_, F_) do { if constexpr (PERM) load_frag_P<NB, MM>((W_) + 2 * PP, lane, F_); else load_frag_N<DH, NB, MM>((W_), q, r, F_); } while (0)
 
   // diagnostic cycle stamps: only in a -DTLSAN_STAMPS=1 build (scripts/stamps.py loads it through TLSAN_LIB_PATH;
   // the production kernel carries no stamp code).  Kept in the LDS while the pass runs -- a global store per stamp
@@ -696,8 +727,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       ct_i = a.p.item_cate[it_i];
       opd FT1[NB][NB], FT2[NB][NB];
       f32x4 b1[NB], b2[NB];
-      load_frag_T<DH, NB, MM>(w1W1, q, r, FT1);
-      load_frag_T<DH, NB, MM>(w1W2, q, r, FT2);
+      LD_T(w1W1, FT1);
+      LD_T(w1W2, FT2);
       load_bias<DH, NB>(w1b1, q, b1);
       load_bias<DH, NB>(w1b2, q, b2);
       if constexpr (TRAIN) {
@@ -928,8 +959,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       ct_i = a.p.item_cate[it_i];
       opd FT1[NB][NB], FT2[NB][NB];
       f32x4 b1[NB], b2[NB], Zl[NB];
-      load_frag_T<DH, NB, MM>(w1W1, q, r, FT1);
-      load_frag_T<DH, NB, MM>(w1W2, q, r, FT2);
+      LD_T(w1W1, FT1);
+      LD_T(w1W2, FT2);
       load_bias<DH, NB>(w1b1, q, b1);
       load_bias<DH, NB>(w1b2, q, b2);
       if constexpr (TRAIN) {
@@ -1072,8 +1103,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       TLSAN_STAMP(21);
       opd FT1[NB][NB], FT2[NB][NB];
       f32x4 b1[NB], b2[NB];
-      load_frag_T<DH, NB, MM>(w1W1, q, r, FT1);
-      load_frag_T<DH, NB, MM>(w1W2, q, r, FT2);
+      LD_T(w1W1, FT1);
+      LD_T(w1W2, FT2);
       load_bias<DH, NB>(w1b1, q, b1);
       load_bias<DH, NB>(w1b2, q, b2);
       TLSAN_STAMP(22);
@@ -1188,8 +1219,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     }
     opd FT1[NB][NB], FT2[NB][NB];
     f32x4 b1[NB], b2[NB];
-    load_frag_T<DH, NB, MM>(w2W1, q, r, FT1);
-    load_frag_T<DH, NB, MM>(w2W2, q, r, FT2);
+    LD_T(w2W1, FT1);
+    LD_T(w2W2, FT2);
     load_bias<DH, NB>(w2b1, q, b1);
     load_bias<DH, NB>(w2b2, q, b2);
     load_chunk(0);
@@ -1285,9 +1316,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       f32x4 xv[NB], z[NB], m2[NB];
       if constexpr (G::AT_USE && !LSTREAM && G::AT_USE_T) {  // weight fragments from LDS at the use
         const int zz = opaque_zero(p);
-        load_frag_T<DH, NB, MM>(w2W1 + zz, q, r, FT1);
+        LD_T(w2W1 + zz, FT1);
         load_bias<DH, NB>(w2b1 + zz, q, b1);
-        load_frag_T<DH, NB, MM>(w2W2 + zz, q, r, FT2);
+        LD_T(w2W2 + zz, FT2);
         load_bias<DH, NB>(w2b2 + zz, q, b2);
       }
 
@@ -1448,8 +1479,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       TLSAN_STAMP(26);
       {
         opd FN1[NB][NB], FN2[NB][NB];
-        load_frag_N<DH, NB, MM>(w2W1, q, r, FN1);
-        load_frag_N<DH, NB, MM>(w2W2, q, r, FN2);
+        LD_N(w2W1, FN1);
+        LD_N(w2W2, FN2);
         AccSet<NB> acc;
         acc.zero();
         if (pmax2 - 1 > NL) load_chunk(0);  // (wave-uniform) the forward loop moved past chunk 0
@@ -1480,13 +1511,13 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           if constexpr (G::AT_USE && !LSTREAM) {  // weight fragments from LDS at the use
             const int zz = opaque_zero(p);
             if constexpr (G::AT_USE_T) {
-              load_frag_T<DH, NB, MM>(w2W1 + zz, q, r, FT1);
+              LD_T(w2W1 + zz, FT1);
               load_bias<DH, NB>(w2b1 + zz, q, b1);
-              load_frag_T<DH, NB, MM>(w2W2 + zz, q, r, FT2);
+              LD_T(w2W2 + zz, FT2);
               load_bias<DH, NB>(w2b2 + zz, q, b2);
             }
-            load_frag_N<DH, NB, MM>(w2W1 + zz, q, r, FN1);
-            load_frag_N<DH, NB, MM>(w2W2 + zz, q, r, FN2);
+            LD_N(w2W1 + zz, FN1);
+            LD_N(w2W2 + zz, FN2);
           }
 
           if (p == 0) {
@@ -1679,12 +1710,12 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) dlong[kb] = *(const f32x4*)(sB + srow * LSTR + chb[kb]);
         opd FN1[NB][NB], FN2[NB][NB];
-        load_frag_T<DH, NB, MM>(w1W1, q, r, FT1);
+        LD_T(w1W1, FT1);
         load_bias<DH, NB>(w1b1, q, b1);
-        load_frag_T<DH, NB, MM>(w1W2, q, r, FT2);
+        LD_T(w1W2, FT2);
         load_bias<DH, NB>(w1b2, q, b2);
-        load_frag_N<DH, NB, MM>(w1W1, q, r, FN1);
-        load_frag_N<DH, NB, MM>(w1W2, q, r, FN2);
+        LD_N(w1W1, FN1);
+        LD_N(w1W2, FN2);
         // ---- pieces of the software-pipelined loops below (PIPE5: window in registers; FLAT: the streamed windows' list)
         static_assert(!PIPE5 || NB == 1, "one 16-channel block per column");
         f32x4 ta[NB], tb[NB];   // transposed tiles of the previous position: (x, dz1), then (m1, dm2)
@@ -2240,13 +2271,13 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           if constexpr (G::AT_USE && !LSTREAM) {  // weight fragments from LDS at the use
             const int zz = opaque_zero(p);
             if constexpr (G::AT_USE_T) {
-              load_frag_T<DH, NB, MM>(w1W1 + zz, q, r, FT1);
+              LD_T(w1W1 + zz, FT1);
               load_bias<DH, NB>(w1b1 + zz, q, b1);
-              load_frag_T<DH, NB, MM>(w1W2 + zz, q, r, FT2);
+              LD_T(w1W2 + zz, FT2);
               load_bias<DH, NB>(w1b2 + zz, q, b2);
             }
-            load_frag_N<DH, NB, MM>(w1W1 + zz, q, r, FN1);
-            load_frag_N<DH, NB, MM>(w1W2 + zz, q, r, FN2);
+            LD_N(w1W1 + zz, FN1);
+            LD_N(w1W2 + zz, FN2);
           }
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) xv[kb] = e1[p][kb] * scp;

@@ -20,7 +20,7 @@ static size_t fwd_smem_bytes(bool train, bool lstream, bool fuse_dk, int Sn, boo
   const int pstr = (flat ? 0 : lsc) + ((cseg || flatg || G::NSB < 16) ? ((Sn + 3) & ~3) : TLSAN_SN_CAP) + 4;      // position slots per sample (k_fwd_bwd: PSTR), twice with CSEG
   const int nf = flat ? G::NSB * TLSAN_LS_CAP : 0;
   return sizeof(float) * ((train ? G::NSB * pstr * (cseg ? 2 : 1) : 0) + 2 * G::NSB * G::LSTR + ((train && ((G::FUSE_DK && fuse_dk) || (flat && !flatg))) ? G::NSB * G::LSTR : 0) + G::NW * 4 + G::NSB * 2 * lsc +
-                          ((G::USE_SW && !flatg) ? 2 * (2 * DH * DH + 2 * DH) : 0) + G::NW * G::WSCR +
+                          ((G::USE_SW && !flatg) ? ((G::NB > 1 && !lstream) ? 2 * (4 * G::NB * G::NB * 256 + 2 * DH) : 2 * (2 * DH * DH + 2 * DH)) : 0) + G::NW * G::WSCR +
                           ((G::KEEP_A && train && !lstream) ? G::NW * TLSAN_LS_MAX * G::NB * 256 : 0) +
                           nf * (3 + (train ? 1 : 0) + ((train && cseg) ? 1 : 0)) + ((flat && !flatg && train) ? 2 * G::NSB * G::LSTR : 0) + (flatg ? G::NSB : 0) +
                           ((flat && !train) ? G::NSB : 0) /* evaluation: the slots' samples (sSb) */ +

@@ -257,6 +257,17 @@ __device__ __forceinline__ void load_frag_N(const float* __restrict__ W, int q, 
     }
 }
 
+// a fragment from a table kept in fragment order in the LDS ([pair = a * NB + b][lane][4]): NB * NB 16-byte reads at
+// constant offsets from the lane's base, conflict-free (k_fwd_bwd: PERM)
+template <int NB, int MM = TLSAN_MATRIX_F32>
+__device__ __forceinline__ void load_frag_P(const float* __restrict__ tab, int lane, typename MMT<MM>::opd (&F)[NB][NB]) {
+  const float* base = tab + lane * 4;
+#pragma unroll
+  for (int x = 0; x < NB; ++x)
+#pragma unroll
+    for (int y = 0; y < NB; ++y) F[x][y] = mm_pack<MM>(*(const f32x4*)(base + (x * NB + y) * 256));
+}
+
 // bias in C-layout: lane (q, .) reg i of block jb  <->  channel-in-column 16jb + 4q + i
 template <int DH, int NB>
 __device__ __forceinline__ void load_bias(const float* __restrict__ b, int q, f32x4 (&out)[NB]) {
