@@ -78,6 +78,9 @@ seg("P3: forward positions + normalise", 24, 25)
 seg("P3: logit, BCE, candidate / user stores", 25, 26)
 seg("P3: backward positions", 26, 27)
 seg("P3: stage accumulators + dlong B loads", 27, 6)
+seg("P4: reduction of the short block's staged accumulators", 7, 30, raw[:, :, 7] > 0)
+seg("P4: dlong GEMM", 30, 31, raw[:, :, 7] > 0)
+seg("P4: dK product of the pass", 31, 8, raw[:, :, 7] > 0)
 if not ("Ls" in kw and int(kw["Ls"]) > 10):
     seg("P5: entry -> start of position 1 (frags, pos 0)", 9, 16)
     seg("P5 pos1: after dW -> start of position 2 (stores)", 15, 17)

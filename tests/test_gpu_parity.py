@@ -1145,3 +1145,39 @@ def test_attention_weights_match_oracle(d, Ls, B, Sn):
         masked = np.arange(T)[None, :] >= np.tile(np.asarray(length), H)[:, None]  # [H*B, T]
         assert (g[masked] == 0.0).all()                                            # masked positions: exactly 0
         assert np.abs(g.sum(1) - 1.0).max() < 1e-5                                 # a softmax over positions per channel
+
+
+@pytest.mark.parametrize("optimizer,lr", [("adam", 0.01), ("rmsprop", 0.01), ("adadelta", 1.0)])
+def test_other_optimizers_with_bf16_tables(optimizer, lr):
+    """adam / rmsprop / adadelta on bf16 tables (round 3 refused the combination): the accumulators stay fp32 and follow
+    the oracle run from the stored (bf16-rounded) tables; every stored table element is one of the two bf16 neighbours of
+    the oracle's updated value (stochastic rounding on the write-back); the fp32-kept parameters match as usual; two runs
+    leave the same bits."""
+    cfg = make_config(U=30, I=45, C=7, d=64, regulation_rate=1e-3, max_gradient_norm=0.05, optimizer=optimizer)
+    p = _p32(random_params(cfg, seed=63))
+    for k in BF16_TABLES:
+        p[k] = _bf16_round(p[k]).astype(np.float64)
+    b, cat = random_batch(cfg, B=36, Sn=3, seed=631)
+    st = orc.init_opt_state(p, optimizer)
+    loss, q, info = orc.train_step(p, cat, b, 8, cfg["regulation_rate"], lr=lr, clip=0.05, optimizer=optimizer, opt_state=st)
+    outs = []
+    for rep in range(2):
+        m = _model(cfg, cat, p, table_dtype="bf16")
+        l = m.train(None, _tuple(b), lr)
+        assert abs(l - loss) < 2e-4 * max(1.0, abs(loss))
+        outs.append((m.get_params(), m.get_slots()))
+    got, (s1, s2) = outs[0]
+    for k in q:
+        assert np.array_equal(outs[0][0][k], outs[1][0][k]), k
+        if k.endswith("_b2"):
+            continue              # (gradient = rounding noise, see test_other_optimizers_track_oracle)
+        a, r = np.asarray(got[k], np.float64).reshape(q[k].shape), q[k]
+        if k in BF16_TABLES:
+            ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(r), 1e-30))) - 7)
+            assert (np.abs(a - r) <= ulp * 1.001 + 2e-3 * np.abs(r - p[k]).max()).all(), k
+            assert np.array_equal(a.astype(np.float32), _bf16_round(a)), k
+        else:
+            step = np.abs(r - p[k]).max()
+            assert np.abs(a - r).max() < 2e-3 * step + 1e-7, k
+        for gs, ref in ((s1[k], st["slot1"][k]), (s2[k], st["slot2"][k])):
+            assert np.abs(np.asarray(gs, np.float64).reshape(ref.shape) - ref).max() < 2e-3 * np.abs(ref).max() + 1e-9, k

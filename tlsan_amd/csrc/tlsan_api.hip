@@ -975,7 +975,6 @@ int tlsan_train_step_opt(const tlsan_dims* d, const tlsan_params* p, const tlsan
     if (opt->kind != TLSAN_OPT_ADAM && opt->kind != TLSAN_OPT_RMSPROP && opt->kind != TLSAN_OPT_ADADELTA)
       return fail(TLSAN_E_BADARG, "tlsan_optimizer: kind %d", opt->kind);
     if (hp->l2_mode != TLSAN_L2_DENSE) return fail(TLSAN_E_UNSUPPORTED, "optimizers other than sgd update every row: l2_mode must be TLSAN_L2_DENSE");
-    if (p->table_dtype != TLSAN_TABLE_F32) return fail(TLSAN_E_UNSUPPORTED, "optimizers other than sgd need fp32 tables");
     if ((rc = check_slot(opt->slot1, "slot1")) || (rc = check_slot(opt->slot2, "slot2"))) return rc;
     if (opt->kind == TLSAN_OPT_ADAM && opt->step < 1) return fail(TLSAN_E_BADARG, "tlsan_optimizer: Adam's step counts from 1");
   }

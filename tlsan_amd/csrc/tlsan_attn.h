@@ -1625,6 +1625,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       TLSAN_STAMP(7);
       if constexpr (G::SPLIT) reduce_part<G, true, 1>(sT, prec, G::P_F2W2, G::P_F2B2, tid);
       else reduce_staged<G, true>(sT, prec, G::P_F2W1, G::P_F2B1, G::P_F2W2, G::P_F2B2, tid);
+      TLSAN_STAMP(30);
       // ---------------------------------------------------------------- P4: dlong GEMM
       // dlong[s][k] = sum_j dbridge[s][j] K[k][j]
 #pragma unroll
@@ -1657,6 +1658,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           for (int jc = 0; jc < D / 16; ++jc) bfr[jc] = bnx[jc];
         }
       }
+      TLSAN_STAMP(31);
       if constexpr (G::FUSE_DK) {
        if (FUSE_RT) {
         // ---- dK partial of this pass: C[k][j] = sum over the 16 samples of long[s][k] * dbridge[s][j]

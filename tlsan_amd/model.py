@@ -241,8 +241,6 @@ class Model(object):
             # makes the reference's gradients dense), so the lazy-L2 form does not apply
             if l2_mode != "dense":
                 raise NotImplementedError("optimizer=%r needs l2_mode='dense'" % self.optimizer)
-            if table_dtype != "f32":
-                raise NotImplementedError("optimizer=%r needs fp32 tables" % self.optimizer)
         self.train_writer = _Writer(os.path.join(config.get("model_dir", "."), "train"))
         self.eval_writer = _Writer(os.path.join(config.get("model_dir", "."), "eval"))
         d = config["hidden_units"]
