@@ -299,8 +299,10 @@ def _nccl_worker(rank, world, port, ret):
         _, cat = random_batch(cfg, B=4, Sn=2, seed=0)
         tup = lambda b: (b["u"], b["i"], b["y"], b["hist_i"], b["hist_i_new"], b["hist_t"], b["sl"], b["sl_new"], b["u_cate"])
         steps = [[random_batch(cfg, B=24, Sn=3, seed=1000 + 10 * s + r)[0] for r in range(world)] for s in range(3)]
-        for lazy, static in ((False, False), (True, False), (True, True)):   # static: fixed-size exchanges, nothing through the host
-            m = ShardedModel(cfg, cat, device="cuda:%d" % rank, l2_mode="lazy" if lazy else "dense", static_rows=static)
+        # static: fixed-size exchanges, nothing through the host; coalesce: its two exchanges behind the kernels as one RCCL group
+        for lazy, static, coalesce in ((False, False, False), (True, False, False), (True, True, False), (True, True, True)):
+            m = ShardedModel(cfg, cat, device="cuda:%d" % rank, l2_mode="lazy" if lazy else "dense", static_rows=static,
+                             coalesce=coalesce)
             m.set_params({k: np.asarray(v, np.float32) for k, v in p.items()})
             dbs = [m.device_batch(tup(per[rank])) for per in steps]
             losses = []
@@ -320,7 +322,7 @@ def _nccl_worker(rank, world, port, ret):
                 for k in q:
                     du = np.asarray(got[k], np.float64).reshape(q[k].shape) - p[k]
                     dr = q[k] - p[k]
-                    assert np.abs(du - dr).max() < 5e-4 * (np.abs(dr).max() + 1e-9) + 5e-7, (lazy, static, k)
+                    assert np.abs(du - dr).max() < 5e-4 * (np.abs(dr).max() + 1e-9) + 5e-7, (lazy, static, coalesce, k)
         ret[rank] = "ok"
     except Exception:
         import traceback

@@ -263,7 +263,7 @@ class ShardedModel:
     """Model surface (train / eval_auc / ...) over row-sharded tables; see module docstring."""
 
     def __init__(self, config, item_cate_list, device="cuda:0", seed=1234, group=None, l2_mode="dense", static_rows=False,
-                 wire_dtype="f32", init="numpy", deferred_ids=False):
+                 wire_dtype="f32", init="numpy", deferred_ids=False, coalesce=False):
         """l2_mode: "dense" -- every owner decays every one of its rows every step, as the reference's dense L2
         gradient does; "lazy" (sgd) -- the same update kept as W = P * W_stored with one scale P that all ranks
         advance alike, so an owner touches only the rows whose gradients arrived (tlsan_shard_apply_lazy).
@@ -275,7 +275,11 @@ class ShardedModel:
         graph (capture_step / replay).  A batch that needs more slots than that raises at the next host check.
           deferred_ids (static_rows): plans built ahead never carry their own id all-to-all -- the step that uses a plan
         issues it, on the main stream -- which is what runs by default over RCCL (no second communicator); True forces
-        the same under the gloo exchange of the tests, whose default keeps a side group."""
+        the same under the gloo exchange of the tests, whose default keeps a side group.
+          coalesce (static_rows, RCCL only): the all-reduce of the dense gradients and the all-to-all of the row gradients,
+        which do not depend on each other, are issued as ONE RCCL group (one launch, one latency) ahead of the summary.
+        Off by default: no hardware with more than one GPU has ever run it (tests/test_gpu_configs.py covers it where
+        there are two)."""
         if l2_mode not in ("dense", "lazy"):
             raise ValueError("l2_mode must be 'dense' or 'lazy'")
         self.lazy = l2_mode == "lazy"
@@ -292,9 +296,12 @@ class ShardedModel:
         self.wire_dtype = wire_dtype
         self.static_rows = static_rows
         self.deferred_ids = bool(deferred_ids)
+        self.coalesce = bool(coalesce)
         self._st = None            # static-shape buffers (made at the first training batch)
         if not dist.is_initialized():
             raise RuntimeError("ShardedModel needs torch.distributed to be initialised (one process per GPU)")
+        if self.coalesce and (not static_rows or _staged(group)):
+            raise NotImplementedError("coalesce=True is the static-shape step's option over RCCL")
         from .model import OPTIMIZERS
         if config.get("num_blocks", 1) != 1:
             raise NotImplementedError("num_blocks != 1 (see tlsan_amd.model.Model)")
@@ -1150,12 +1157,20 @@ class ShardedModel:
                 flat[:kk + 1].mul_(float(weight))
                 flat[kk + 1:kk + 2].mul_(float(weight) ** 2)
                 gf.mul_(float(weight))
-            if G > 1:
-                allreduce_sum(flat, self.group)
-            run(L.PHASE_SUMMARY)
-            if G > 1:
-                a2a(st["vals"].view(-1), gf.view(-1), None, None, self.group)
-            run(L.PHASE_APPLY)
+            if G > 1 and self.coalesce:
+                # the two exchanges behind the kernels are independent of each other (the row sums travel unscaled: the
+                # clip coefficient reaches the owners through the summary): one RCCL group instead of two collectives
+                with dist._coalescing_manager(group=self.group, device=torch.device(self.device), async_ops=False):
+                    dist.all_reduce(flat, group=self.group)
+                    dist.all_to_all_single(st["vals"].view(-1), gf.view(-1), group=self.group)
+                run(L.PHASE_SUMMARY | L.PHASE_APPLY)
+            else:
+                if G > 1:
+                    allreduce_sum(flat, self.group)
+                run(L.PHASE_SUMMARY)
+                if G > 1:
+                    a2a(st["vals"].view(-1), gf.view(-1), None, None, self.group)
+                run(L.PHASE_APPLY)
         if ahead and capturing:              # a recording must join its forks; eager steps wait where a plan is used
             main.wait_stream(st["side"])
             main.wait_stream(st["side2"])
