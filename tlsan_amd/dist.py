@@ -73,6 +73,11 @@ class ModPartition:
         return torch.arange(rank, self.n, self.world, device=device)
 
 
+# the announced batches' plans are issued by a launch thread of the library (tlsan_shard_step_static, TLSAN_PLAN_ASYNC);
+# TLSAN_PLAN_THREAD=0 keeps them on the calling thread (an escape hatch: the thread has only ever run on one-GPU boxes)
+_PLAN_THREAD = os.environ.get("TLSAN_PLAN_THREAD", "1") != "0"
+
+
 def _staged(group):
     """gloo has no device all-to-all: stage CUDA tensors through the host (used only by the
     single-GPU multi-process tests; RCCL moves device buffers directly)."""
@@ -1110,7 +1115,7 @@ class ShardedModel:
 
         def run(phases, with_plans=False):
             # (plans: issued by the library's launch thread while this one goes on with the main stream -- not under capture)
-            if with_plans and plans and use_flag:
+            if with_plans and plans and use_flag and _PLAN_THREAD:
                 phases |= L.PLAN_ASYNC
             L.check(self.lib.tlsan_shard_step_static(C.byref(ss), phases, parr if with_plans else None,
                                                      len(plans) if with_plans else 0, sp), "tlsan_shard_step_static")
