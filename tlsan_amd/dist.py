@@ -939,6 +939,15 @@ class ShardedModel:
         sl["step_args"][id(db)] = (db, ss, self._ws)
         return ss
 
+    def __del__(self):
+        # plans still queued with the library's launch thread hold raw pointers into this model's buffers: let the
+        # thread issue them before the buffers go (the streams then order their kernels before the frees)
+        try:
+            if getattr(self, "_st", None) is not None:
+                self.lib.tlsan_shard_plans_flush()
+        except Exception:
+            pass
+
     def _flush_plans(self):
         """Plans handed to the library's launch thread (tlsan_shard_step_static, TLSAN_PLAN_ASYNC) are issued when that
         thread gets to them: wait until it has, before anything on this thread that must come BEHIND a plan's launches
