@@ -1,5 +1,5 @@
 // What does a kernel boundary cost behind a kernel that wrote B bytes?  (scripts/micro: measurement only)
-//   hipcc --offload-arch=gfx950 -O3 scripts/micro/boundary.hip -o ab_diag/boundary && rocprofv3 --kernel-trace ... ab_diag/boundary
+//   hipcc --offload-arch=gfx950 -O3 scripts/micro/boundary.hip -o gpurun_out/boundary && rocprofv3 --kernel-trace ... gpurun_out/boundary
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

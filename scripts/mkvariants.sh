@@ -1,6 +1,6 @@
 #!/bin/bash
 # Build variants of libtlsan_hip.so that differ in compile-time toggles of the fused kernel (HERE; hipcc cross-compiles):
-#   scripts/mkvariants.sh name1:"-DTLSAN_EXP_X=1" name2:"-DTLSAN_EXP_Y=2 ..." ...
+#   scripts/mkvariants.sh stamps:"-DTLSAN_STAMPS=1" name2:"-DOTHER=2 ..." ...
 # -> ab_libs/<name>.so (git-ignored, shipped by gpurun).  `base` (no flags) is always built.  Run them on ONE box with
 #   scripts/abrun.sh (interleaved rounds in one gpurun call).
 set -e
