@@ -80,7 +80,7 @@ seg("P3: backward positions", 26, 27)
 seg("P3: stage accumulators + dlong B loads", 27, 6)
 seg("P4: reduction of the short block's staged accumulators", 7, 30, raw[:, :, 7] > 0)
 seg("P4: dlong GEMM", 30, 31, raw[:, :, 7] > 0)
-seg("P4: dK product of the pass", 31, 8, raw[:, :, 7] > 0)
+seg("P4: dlong GEMM -> barrier 4 (reset of the dK ticket)", 31, 8, raw[:, :, 7] > 0)
 if not ("Ls" in kw and int(kw["Ls"]) > 10):
     seg("P5: entry -> start of position 1 (frags, pos 0)", 9, 16)
     seg("P5 pos1: after dW -> start of position 2 (stores)", 15, 17)
@@ -88,7 +88,7 @@ if not ("Ls" in kw and int(kw["Ls"]) > 10):
     seg("P5: positions 2..8 (7 positions)", 17, 18, full)
     seg("P5: position 9 + last dW", 18, 19, full)
     seg("P5: dsp reductions + Gu stores", 19, 20)
-    seg("P5: stage accumulators (to stamp 10)", 20, 10)
+    seg("P5: stage accumulators + dK tile groups drawn by ticket (to stamp 10)", 20, 10)
 # the workgroup's critical path: a barrier releases when its slowest wavefront arrives
 arr = [1, 3, 6, 8, 10]   # stamps taken on arrival at the five barriers
 rel0 = s[:, :, 0].min(1)

@@ -1660,48 +1660,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       }
       TLSAN_STAMP(31);
       if constexpr (G::FUSE_DK) {
-       if (FUSE_RT) {
-        // ---- dK partial of this pass: C[k][j] = sum over the 16 samples of long[s][k] * dbridge[s][j]
-        // (A from sL, B from sA: both [sample][channel] rows in the LDS).  Samples are the K dimension: NSB / 4 k-steps of
-        // 4 samples.  A wavefront owns half of a 64 x 64 quadrant: lane (q, r) reads channels 4r .. 4r+3 of sample
-        // 4*step + q from both operands as 16-B pieces, and element t of a piece feeds tile t -- tile (ta, tb) holds
-        // rows 4m + ta, columns 4n + tb of the quadrant -- so the accumulators of one (ta, i) are four consecutive
-        // columns: 16-B stores, 256 B contiguous per 16 lanes.
-        constexpr int NQ = D / 64;                       // quadrants per side
-        constexpr int WPQ = NW / (NQ * NQ);              // wavefronts per quadrant (8 / 4 = 2 at D = 128, 4 / 1 at D = 64)
-        static_assert(WPQ >= 1 && 4 % WPQ == 0, "tiles of a quadrant must divide over its wavefronts");
-        constexpr int NTA = 4 / WPQ;                     // values of ta this wavefront takes
-        const int quad = wave / WPQ, ta0 = (wave % WPQ) * NTA;
-        const int M0 = (quad / NQ) * 64, N0 = (quad % NQ) * 64;
-        f32x4 acc[NTA][4];
-#pragma unroll
-        for (int x = 0; x < NTA; ++x)
-#pragma unroll
-          for (int tb = 0; tb < 4; ++tb) acc[x][tb] = (f32x4)(0.0f);
-#pragma unroll
-        for (int step = 0; step < NSB / 4; ++step) {
-          const f32x4 va = *(const f32x4*)(sL + (4 * step + q) * LSTR + M0 + 4 * r);
-          const f32x4 vb = *(const f32x4*)(sA + (4 * step + q) * LSTR + N0 + 4 * r);
-#pragma unroll
-          for (int x = 0; x < NTA; ++x)
-#pragma unroll
-            for (int tb = 0; tb < 4; ++tb) acc[x][tb] = TLSAN_MFMA(va[ta0 + x], vb[tb], acc[x][tb]);
-        }
-        // acc[x][tb][i] = C[M0 + 4 (4q + i) + ta0 + x][N0 + 4 r + tb]
-        float* kp = a.Kp + (size_t)blockIdx.x * D * D;
-        const bool first = g == (int)blockIdx.x;         // later passes of this workgroup add to its partial
-#pragma unroll
-        for (int x = 0; x < NTA; ++x)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            f32x4 v;
-#pragma unroll
-            for (int tb = 0; tb < 4; ++tb) v[tb] = acc[x][tb][i];
-            float* dst = kp + (size_t)(M0 + 4 * (4 * q + i) + ta0 + x) * D + N0 + 4 * r;
-            if (!first) v += *(const f32x4*)dst;
-            st4_out(dst, v);
-          }
-      }
+        if (FUSE_RT && tid == 0) *(int*)(sS + 3) = 0;   // ticket counter of the pass's dK tile groups (taken behind P5; this barrier and the next lie between)
       }
       TLSAN_STAMP(8);
       __syncthreads();
@@ -2390,6 +2349,54 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           sS[wave * 4 + 1] = s1;
           sS[wave * 4 + 2] = s2;
         }
+      }
+      if constexpr (G::FUSE_DK) {
+       if (FUSE_RT) {
+        // ---- dK partial of this pass: C[k][j] = sum over the pass's samples of long[s][k] * dbridge[s][j]
+        // (A from sL, B from sA: both [sample][channel] rows in the LDS, untouched since P4).  Nothing in the kernel
+        // consumes it, so it is not formed between barriers 3 and 4, where all eight wavefronts waited for the matrix pipe
+        // (3.7 k cycles of every workgroup's critical path), but here, behind the long backward, by whoever arrives first:
+        // the wavefronts draw groups of four 16 x 16 tiles from a counter in the LDS until none is left -- the
+        // wavefronts that finish P5 early (shorter windows, the first-dispatched half) take them while the others still
+        // run, and the last to arrive finds the counter exhausted.  A tile's value does not depend on who forms it.
+        // Samples are the K dimension: NSB / 4 k-steps of 4 samples.  Group (quadrant, ta): lane (q, r) reads channels
+        // 4r .. 4r+3 of sample 4*step + q from both operands as 16-B pieces; element ta of the A piece and element tb of
+        // the B piece feed tile tb, which holds rows 4m + ta, columns 4n + tb of the 64 x 64 quadrant -- the accumulators
+        // of one i are four consecutive columns: 16-B stores, 256 B contiguous per 16 lanes.
+        constexpr int NQ = D / 64;                       // quadrants per side
+        constexpr int NGRP = NQ * NQ * 4;
+        int* tk = (int*)(sS + 3);
+        float* kp = a.Kp + (size_t)blockIdx.x * D * D;
+        const bool first = g == (int)blockIdx.x;         // later passes of this workgroup add to its partial
+        for (;;) {
+          int t = 0;
+          if (lane == 0) t = atomicAdd(tk, 1);
+          t = __builtin_amdgcn_readfirstlane(t);
+          if (t >= NGRP) break;
+          const int quad = t >> 2, ta = t & 3;
+          const int M0 = (quad / NQ) * 64, N0 = (quad % NQ) * 64;
+          f32x4 acc[4];
+#pragma unroll
+          for (int tb = 0; tb < 4; ++tb) acc[tb] = (f32x4)(0.0f);
+#pragma unroll
+          for (int step = 0; step < NSB / 4; ++step) {
+            const float va = sL[(4 * step + q) * LSTR + M0 + 4 * r + ta];
+            const f32x4 vb = *(const f32x4*)(sA + (4 * step + q) * LSTR + N0 + 4 * r);
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb) acc[tb] = TLSAN_MFMA(va, vb[tb], acc[tb]);
+          }
+          // acc[tb][i] = C[M0 + 4 (4q + i) + ta][N0 + 4 r + tb]
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            f32x4 v;
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb) v[tb] = acc[tb][i];
+            float* dst = kp + (size_t)(M0 + 4 * (4 * q + i) + ta) * D + N0 + 4 * r;
+            if (!first) v += *(const f32x4*)dst;
+            st4_out(dst, v);
+          }
+        }
+       }
       }
       TLSAN_STAMP(10);
       __syncthreads();

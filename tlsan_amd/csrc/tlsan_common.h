@@ -167,7 +167,8 @@ struct Geo {
   static constexpr int TPW = RT * NT / NW;      // bridge tiles per wavefront
   static constexpr int LSTR = D + 4;            // LDS row stride of [sample][channel] buffers
   // dK = long^T . dbridge (gradient of the bridge's kernel, model.py:347): for D <= 128 every workgroup forms the
-  // product over its own 16 samples right after the dlong GEMM, while both operands sit in the LDS, and leaves one
+  // product over its own 16 samples while both operands sit in the LDS (behind the long backward, drawn tile group by
+  // tile group by whichever wavefront gets there first: k_fwd_bwd, end of P5), and leaves one
   // D x D partial per workgroup for k_dense_finalize -- no k_dk_partial launch, no [B, D] round trip through HBM.
   // (D = 256: the partials would be 256 KB per workgroup; the separate kernel stays.)
   // Costs and gains (round 2): the k_dk_partial launch (7.2 us + a gap) goes away, k_fwd_bwd grows by ~1.3 us (six
