@@ -1070,10 +1070,16 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       const float ut_k = a.p.usert_emb[(size_t)uid * a.p.ld_usert + kc];
       ucat = a.b.u_cate[bb];
       ct_i = a.p.item_cate[it_i];   // (with the stage that already waits for the sample's scalars: no trip of its own later)
+      sid = (Sn > 0) ? a.b.hist_i_new[(size_t)bb * Sn + min(kk, max(Sn - 1, 0))] : 0;   // first chunk of session ids (load_chunk(0)), with the window's ids
       // (round 2 measured the short block's first ids / categories / cursor draws / first row riding with these stages
-      //  instead of three trips of their own at the start of P3: no gain, profiles/r02_ab)
+      //  instead of three trips of their own at the start of P3: no gain in the step time then, profiles/r02_ab.  Round 4
+      //  with the stamps: those trips were 1.9 k cycles at the head of P3 on every workgroup's critical path.  Now the ids
+      //  and categories ride here (two registers) and the first ROW is issued at the end of P1, in flight over barrier 1
+      //  and P2: P3's head 1.9 k -> 0.5 k cycles, critical path 68.2 k -> 67.0 k, step -0.4 us, d = 64 -0.9 us
+      //  (profiles/r04_sess_prefetch_ab.md); the cursor draws stay in P3)
       __builtin_amdgcn_sched_barrier(0);
       const int ct_k = a.p.item_cate[id_k];
+      scat = a.p.item_cate[sid];   // ... and their categories with the window's
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int p = 0; p < LS; ++p) {
@@ -1147,6 +1153,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       iemb[kb] = gather_item4c<DT>(a, it_i, ct_i, c) * P;
     }
     const float ib_i = a.p.item_b[(size_t)it_i * a.p.ld_itemb];
+    if constexpr (!LSTREAM) {   // the first session row as well (ids and categories came with the window's): it is in flight over barrier 1 and P2
+      if (wave_max_samples<CPS>(n_s + 1) > 1) fetch_row(0, xnext);
+    }
 
     // B fragments of the bridge GEMM (K^T rows, L2-resident) do not depend on the barrier:
     // fetch them first so their latency overlaps the wait for the slowest wavefront
@@ -1223,12 +1232,12 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     LD_T(w2W2, FT2);
     load_bias<DH, NB>(w2b1, q, b1);
     load_bias<DH, NB>(w2b2, q, b2);
-    load_chunk(0);
+    if constexpr (LSTREAM) load_chunk(0);
     if constexpr (TRAIN) {
       spos0 = (vs && kk < n_s) ? atomicAdd(&a.cur_item[sid], 1) : 0;
       if constexpr (CSEG) scpos0 = (vs && kk < n_s) ? atomicAdd(&a.cur_uc[scat], 1) : 0;
     }
-    if (pmax2 > 1) fetch_row(0, xnext);
+    if constexpr (LSTREAM) { if (pmax2 > 1) fetch_row(0, xnext); }
     TLSAN_STAMP(24);
     f32x4 mx[NB], Zs[NB], short4[NB];
     {
