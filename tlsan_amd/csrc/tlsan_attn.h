@@ -400,9 +400,6 @@ __device__ __forceinline__ void online_step(f32x4 (&mx)[NB], f32x4 (&Z)[NB], f32
 // loops of the variant that does not need it (C3 shape: 61.0 -> 62.9 us/step).
 // NWV (0 = the width's default): wavefronts per workgroup, see Geo.  The register budget is that of two wavefronts per
 // SIMD either way (__launch_bounds__(512)): an 8-wavefront workgroup fills a CU, two 4-wavefront ones share it.
-#ifndef TLSAN_FRAG_EARLY
-#define TLSAN_FRAG_EARLY 1
-#endif
 template <int D, int DH, bool TRAIN, bool LSTREAM, int DT = TLSAN_TABLE_F32, bool DROP = false, int MM = TLSAN_MATRIX_F32, bool CSEG = false, int NWV = 0>
 __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   static_assert(!DROP || TRAIN, "dropout: train steps only");
@@ -1210,12 +1207,10 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     // (the short block's weight fragments: LDS reads issued before barrier 2, see P5)
     opd FT1[NB][NB], FT2[NB][NB];
     f32x4 b1[NB], b2[NB];
-#if TLSAN_FRAG_EARLY
     LD_T(w2W1, FT1);
     LD_T(w2W2, FT2);
     load_bias<DH, NB>(w2b1, q, b1);
     load_bias<DH, NB>(w2b2, q, b2);
-#endif
     TLSAN_STAMP(3);
     __syncthreads();
     TLSAN_STAMP(4);
@@ -1238,12 +1233,6 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         if (CSEG && kku <= LS) sPc[srow * PSTR + (kku < LS ? kku : P_TGT)] = ucpos;
       }
     }
-#if !TLSAN_FRAG_EARLY
-    LD_T(w2W1, FT1);
-    LD_T(w2W2, FT2);
-    load_bias<DH, NB>(w2b1, q, b1);
-    load_bias<DH, NB>(w2b2, q, b2);
-#endif
     if constexpr (LSTREAM) load_chunk(0);
     if constexpr (TRAIN) {
       spos0 = (vs && kk < n_s) ? atomicAdd(&a.cur_item[sid], 1) : 0;
@@ -1684,16 +1673,14 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         if (FUSE_RT && tid == 0) *(int*)(sS + 3) = 0;   // ticket counter of the pass's dK tile groups (taken behind P5; this barrier and the next lie between)
       }
       // the long block's weight fragments (LDS copies that no barrier guards) are read BEFORE barrier 4: the compiler does
-      // not move LDS reads across a barrier, and P5's first map waited for them (TLSAN_FRAG_EARLY)
+      // not move LDS reads across a barrier, and P5's first map waited for them (kernel -0.5 us, Movies-TV shape -1.5 us/step: profiles/r04_frag_early_ab.md)
       opd FN1[NB][NB], FN2[NB][NB];
-#if TLSAN_FRAG_EARLY
       LD_T(w1W1, FT1);
       load_bias<DH, NB>(w1b1, q, b1);
       LD_T(w1W2, FT2);
       load_bias<DH, NB>(w1b2, q, b2);
       LD_N(w1W1, FN1);
       LD_N(w1W2, FN2);
-#endif
       TLSAN_STAMP(8);
       __syncthreads();
       TLSAN_STAMP(9);
@@ -1702,14 +1689,6 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         f32x4 dlong[NB], dummy[NB];
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) dlong[kb] = *(const f32x4*)(sB + srow * LSTR + chb[kb]);
-#if !TLSAN_FRAG_EARLY
-        LD_T(w1W1, FT1);
-        load_bias<DH, NB>(w1b1, q, b1);
-        LD_T(w1W2, FT2);
-        load_bias<DH, NB>(w1b2, q, b2);
-        LD_N(w1W1, FN1);
-        LD_N(w1W2, FN2);
-#endif
         // ---- pieces of the software-pipelined loops below (PIPE5: window in registers; FLAT: the streamed windows' list)
         static_assert(!PIPE5 || NB == 1, "one 16-channel block per column");
         f32x4 ta[NB], tb[NB];   // transposed tiles of the previous position: (x, dz1), then (m1, dm2)
