@@ -55,7 +55,8 @@ _AMAZON_SESSION_HIST = np.array([33124, 3366, 848, 324, 150, 50, 44, 26, 16, 8, 
 
 def make_batches(cfg, n_batches, batch_size=None, seed=1234, test=False, sessions="geometric"):
     """List of 9-tuples in the layout of TLSAN/input.py:54 (train) / :107 (test).
-    sessions: "geometric" (the bench's distribution since round 1) or "amazon" (the empirical, longer-tailed one)."""
+    sessions: "geometric" (the bench's distribution since round 1), "amazon" (the empirical, longer-tailed one) or
+    "capN" (diagnostic: geometric, cut at N entries)."""
     rng = np.random.default_rng(seed + (1 if test else 0))
     U, I, C, Ls = cfg["user_count"], cfg["item_count"], cfg["cate_count"], cfg["Ls"]
     B = batch_size or cfg["train_batch_size"]
@@ -69,6 +70,8 @@ def make_batches(cfg, n_batches, batch_size=None, seed=1234, test=False, session
             sl_new = 1 + rng.choice(12, B, p=_AMAZON_SESSION_HIST / _AMAZON_SESSION_HIST.sum())
         else:
             sl_new = np.minimum(18, rng.geometric(0.82, B))
+            if sessions.startswith("cap"):   # (diagnostic: the geometric lengths cut at N -- what the long sessions cost a launch)
+                sl_new = np.minimum(sl_new, int(sessions[3:]))
         ar = np.arange(Ls)[None, :]
         valid = ar < sl[:, None]
         hist_i = np.where(valid, sampler.draw(rng, (B, Ls)), 0).astype(np.int64)
