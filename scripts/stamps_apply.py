@@ -66,3 +66,21 @@ for nm, lo, hi in [("cate", 0, C), ("item", C, C + nbI), ("user", C + nbI, C + n
         print("  %-9s start p0/10/50/90/100 %s | end p50/90/100 %s | dur p50 %.2f" % (
             nm, " ".join("%5.2f" % v for v in np.percentile(st, [0, 10, 50, 90, 100])),
             " ".join("%5.2f" % v for v in np.percentile(en, [50, 90, 100])), np.median(en - st)))
+# how many workgroups run at once (the launch's residency): running blocks sampled every 0.5 us
+x = s[s[:, 4] > 0]
+st, en = (x[:, 4] - r0) / 100, (x[:, 5] - r0) / 100
+print("resident workgroups at t (us): " + "  ".join("%.1f:%d" % (t, int(((st <= t) & (en > t)).sum())) for t in np.arange(0.5, en.max(), 1.0)))
+# the category blocks that end last, with their use counts (item uses of the category's items + its u_cate uses)
+if C == cfg["cate_count"]:
+    icl = synth.item_cate_list(cfg)
+    u_, i_, y_, hi_, hn_, ht_, sl_, sn_, c_ = hb
+    ids = [np.asarray(i_)]
+    ids += [np.asarray(hi_)[k, :int(sl_[k])] for k in range(B)]
+    ids += [np.asarray(hn_)[k, :int(sn_[k])] for k in range(B)]
+    ids = np.concatenate(ids)
+    uses = np.bincount(icl[ids], minlength=C) + np.bincount(np.asarray(c_), minlength=C)
+    x = s[:C]
+    en = (x[:, 5] - r0) / 100
+    order = np.argsort(-en)[:8]
+    print("category blocks by end time: " + "  ".join("c%d end %.2f dur %.2f uses %d items %d" % (k, en[k], (x[k, 5] - x[k, 4]) / 100, uses[k], int((icl == k).sum())) for k in order))
+    print("uses per category: p50 %d p90 %d max %d;  duration vs uses correlation %.2f" % (np.median(uses), np.percentile(uses, 90), uses.max(), np.corrcoef(uses, (x[:, 5] - x[:, 4]))[0, 1]))

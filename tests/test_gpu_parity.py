@@ -1011,19 +1011,6 @@ def test_train_driver_variants(extra, tmp_path):
         assert "slot1/item_emb" in z.files and "slot2/dense_K" in z.files
 
 
-def test_dk_product_in_the_tail_launch():
-    """TLSAN_DK_TAIL=1 (read once per process): the fused kernel leaves the [B, D] operands of dK = long^T . dbridge and the
-    finalize blocks form the product (FinArgs.dk_gemm) -- 28 MB less traffic per step at the bench shape, 4.7 us more time,
-    so not the default; the oracle tests of gradients and train steps must hold in that mode too."""
-    import subprocess, sys
-    env = dict(os.environ, TLSAN_DK_TAIL="1")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-m", "gpu", "-q", "-x", "-k",
-                        "test_gradients or test_train_step_matches_oracle or test_multi_step_tracks_oracle_and_is_deterministic or test_full_size_batch_matches_oracle"],
-                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-
-
 def test_user_index_from_a_sort_of_the_batch():
     """Tables of 65 536 users or more take the user side of a batch's destination index from a partitioned counting sort of
     the batch's user ids (IsortArgs: three short launches whose blocks keep a bucket's counters in the LDS) instead of

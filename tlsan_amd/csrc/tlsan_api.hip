@@ -113,9 +113,6 @@ static int ru4(int x) { return (x + 3) / 4 * 4; }
 // k_dense_finalize the long pole of its launch (77 -> 91 us/step), and the separate k_dk_partial launch (<= 64 partials)
 // is the better deal again
 #define FUSED_DK_MAX_GROUPS 256
-#ifndef TLSAN_DK_TAIL_DEFAULT
-#define TLSAN_DK_TAIL_DEFAULT 0
-#endif
 // tables with at least this many categories take the category-segment path (cate_seg below; TLSAN_CSEG_MIN=<n> for tests
 // and experiments, read once per process)
 #define TLSAN_CSEG_MIN_CATES 2048
@@ -137,12 +134,6 @@ static int train_group(const Shape& s, const tlsan_dims* d, const tlsan_batch* b
 }
 static int fwd_train_grid(int ngroups) { return ngroups; }    // (fused: ngroups <= FUSED_DK_MAX_GROUPS, one pass per workgroup)
 
-// dK in the tail launch (FinArgs.dk_gemm): the fused kernel leaves the [B, D] operands, DK_KS finalize blocks per 16 x 16
-// tile form the product (TLSAN_DK_TAIL=0/1)
-static bool dk_tail(int D) {
-  static const int on = [] { const char* v = getenv("TLSAN_DK_TAIL"); return v ? atoi(v) : TLSAN_DK_TAIL_DEFAULT; }();
-  return on != 0 && D <= 128;
-}
 // windows longer than TLSAN_LS_MAX are streamed (the list form of the long block); shorter ones stay in registers
 static bool streamed(int Ls) { return Ls > TLSAN_LS_MAX; }
 
@@ -157,7 +148,7 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
   // dK partials: one per batch split of k_dk_partial, or (fused into the forward/backward kernel, D <= 128) one per
   // workgroup of that launch -- which of the two, and how many, is the launch's choice (run_backward)
   const int ngroups = (B + s.NSB - 1) / s.NSB;
-  w->nbK = (s.D * s.D + 255) / 256 * (dk_tail(s.D) ? DK_KS : 1);   // (dK in the tail launch: DK_KS blocks per tile)
+  w->nbK = (s.D * s.D + 255) / 256;
   w->nbS = (L.n_dense - s.D * s.D + 15) / 16;
   w->nfin = w->nbK + w->nbS;
   // (+1 row: k_apply reads clamped addresses instead of branching, see AP_OWN)
@@ -179,7 +170,6 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
     const int fmax = ng8 < FUSED_DK_MAX_GROUPS ? ng8 : FUSED_DK_MAX_GROUPS;
     if (fmax > kp_slots) kp_slots = fmax;
   }
-  if (dk_tail(s.D) && kp_slots < DK_KS) kp_slots = DK_KS;   // (the slices' tiles of the tail product)
   w->Kp = (float*)take(sizeof(float) * kp_slots * D * D);
   w->gd = (float*)take(sizeof(float) * L.n_dense);
   w->sqd = (float*)take(sizeof(float) * w->nfin);
@@ -252,7 +242,6 @@ struct St {  // persistent state
   DeltaRec* S_delta;                                      // per-workgroup changes of the sum of squares, tagged by step (tlsan_update.h)
   long long* scan_bsum[TLSAN_INDEX_SLOTS];                                // per-chunk sums of the index scan (large tables), per slot
   int32_t* perm[TLSAN_INDEX_SLOTS];                                       // samples of every workgroup of the fused kernel (BalArgs), BAL_CAP each
-  int32_t* dk_ticket;                                                     // per dK tile: slices arrived (FinArgs.dk_ticket), zero at rest
   int32_t* scan_ticket;                                                   // [index slot] arrivals of k_scan_block_sums (ScanArgs.bs_ticket), zero at rest
   int32_t* flag_user[TLSAN_INDEX_SLOTS];                                  // 256-row pieces of the user table that hold a count (ScanArgs.flag), zero at rest
   int32_t* uc_list[TLSAN_INDEX_SLOTS];                                    // samples of every category (u_cate uses), UC_LIST_CAP each
@@ -298,7 +287,6 @@ static void carve_state(const tlsan_dims* d, char* base, St* s) {
     s->scan_bsum[k] = (long long*)take(8 * ((size_t)(d->item_count + 4095) / 4096 + (d->cate_count + 4095) / 4096 +
                                             (d->user_count + 4095) / 4096));
   for (int k = 0; k < TLSAN_INDEX_SLOTS; ++k) s->perm[k] = (int32_t*)take(4 * (size_t)BAL_CAP);
-  s->dk_ticket = (int32_t*)take(4 * 256);
   s->scan_ticket = (int32_t*)take(4 * 64);
   for (int k = 0; k < TLSAN_INDEX_SLOTS; ++k) s->flag_user[k] = (int32_t*)take(4 * (((size_t)d->user_count + 255) / 256));
   {
@@ -819,15 +807,12 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   const int grp = train_group(s, d, b, hp);  // samples per workgroup pass of the fused kernel (= per partial record)
   a.ngroups = (b->B + grp - 1) / grp;
   a.fuse_dk = fused_dk(s.D, a.ngroups) ? 1 : 0;
-  // dK in the tail launch: the fused kernel leaves the [B, D] operands, the finalize blocks form the product (FinArgs.dk_gemm)
-  const bool dkt = dk_tail(s.D);
-  if (dkt) a.fuse_dk = 0;
   prof_mark(1, hs);
   if ((rc = launch_fwd(s, true, a, hs, grp))) return rc;
   prof_mark(2, hs);
   const int nsplit = a.fuse_dk ? fwd_train_grid(a.ngroups) : dk_nsplit(b->B);   // dK partials the finalize sums
   // --- dense-parameter gradients (D <= 128: the dK partials were left by k_fwd_bwd, one per workgroup)
-  if (!a.fuse_dk && !dkt) {
+  if (!a.fuse_dk) {
     const int spw = dk_spw(b->B), nq = (s.D / 64) * (s.D / 64);
     const dim3 grid(nq * nsplit), blk(DK_WAVES * 64);
 #define DK_LAUNCH(DD)                                                                                           \
@@ -852,8 +837,6 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   f.out_loss = out ? out->loss : nullptr;
   f.out_gnorm = out ? out->gnorm : nullptr;
   f.out_sq = out ? out->sq_rows : nullptr;
-  f.gLong = w.gLong; f.gDB = w.gDB; f.B = b->B; f.dk_gemm = dkt ? 1 : 0;
-  f.dk_part = w.Kp; f.dk_ticket = st.dk_ticket;
   if (presum) {
     // lazy update: the exact row sums of the apply pass share the launch (they wait for nothing it produces)
     ApplyArgs A = *presum;

@@ -920,17 +920,7 @@ struct FinArgs {
   int32_t commit;          // lazy L2 update: advance the table scale P (P_prev keeps the old value)
   int32_t count_step;      // an update follows (train step, not tlsan_grads): advance hdr->nstep
   float* out_loss; float* out_gnorm; float* out_sq;
-  // dk_gemm != 0: no dK partials -- the K blocks form their 16 x 16 tile of dK = long^T . dbridge themselves, over the
-  // whole batch, from the [B, D] operands the fused kernel left (gLong, gDB)
-  // (DK_KS blocks per tile, each over a slice of the batch; the last of a tile to arrive -- a ticket per tile, zero at
-  //  rest in the state -- sums the slices' tiles in slice order; hand-over as below: published with returning atomics,
-  //  read with device-scope loads)
-  const float* gLong; const float* gDB;
-  int32_t B, dk_gemm;
-  float* dk_part;         // [DK_KS][D*D] the slices' tiles
-  int32_t* dk_ticket;     // [(D/16)^2]
 };
-#define DK_KS 8
 
 // The step's scalars, computed once by the last workgroup of k_dense_finalize instead of by every
 // workgroup of k_apply: global norm (tf18: per-use rows + (reg*W)^2 + dense; model.py:198-201),
@@ -1058,58 +1048,6 @@ __device__ __forceinline__ void dense_finalize_block(const FinArgs& a, int nbK, 
   float g = 0.0f;
   bool owner = false;
   if (blk == nbK + nbS) {
-  } else if (blk < nbK && a.dk_gemm) {
-    // dK[k][j] = sum over the batch of long[b][k] * dbridge[b][j] (model.py:347's kernel): a 16 x 16 tile over one of
-    // DK_KS slices of the batch, the slice split over the block's four wavefronts (f32 MFMA, samples as the K dimension:
-    // lane (q, r) supplies channel r of sample s0 + q of either operand -- 64 contiguous bytes per sample row), four
-    // accumulators per wavefront, wavefronts and slices summed in fixed order.  The operands are 2 x B x D x 4 bytes
-    // (4 MB at the bench shape, L2-resident) where the per-workgroup partials of the fused form are 256 x D x D x 4
-    // (16 MB written and read back).
-    __shared__ float shK[4 * 256];
-    __shared__ int sh_tlast;
-    const int wave = tid >> 6, lane = tid & 63, q = lane >> 4, r = lane & 15;
-    constexpr int NTD = D / 16, NT = NTD * NTD;
-    const int tile = blk % NT, ks = blk / NT;
-    const int bi = tile / NTD, bj = tile % NTD;
-    const int per_b = (((a.B + DK_KS - 1) / DK_KS) + 15) & ~15;   // samples per block, per wavefront a multiple of four
-    const int per_w = per_b / 4;
-    const int s_lo = ks * per_b + wave * per_w, s_hi = min(min(s_lo + per_w, (ks + 1) * per_b), a.B);
-    const float* pa = a.gLong + 16 * bi + r;
-    const float* pb = a.gDB + 16 * bj + r;
-    f32x4 acc[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) acc[u] = (f32x4)(0.0f);
-    for (int s0 = s_lo; s0 < s_hi; s0 += 64) {    // sixteen k-steps: 32 loads in flight (clamped addresses, masked A)
-      float va[16], vb[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int sx = s0 + 4 * u + q, sc = min(sx, a.B - 1);
-        va[u] = pa[(size_t)sc * D];
-        vb[u] = pb[(size_t)sc * D];
-        va[u] = sx < s_hi ? va[u] : 0.0f;
-      }
-#pragma unroll
-      for (int u = 0; u < 16; ++u) acc[u & 3] = TLSAN_MFMA(va[u], vb[u], acc[u & 3]);
-    }
-    const f32x4 c = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) shK[wave * 256 + (4 * q + i) * 16 + r] = c[i];   // C layout: row 4 q + i, column r
-    __syncthreads();
-    const float part = (shK[tid] + shK[256 + tid]) + (shK[512 + tid] + shK[768 + tid]);
-    pub_f32(a.dk_part + ((size_t)ks * NT + tile) * 256 + tid, part);
-    __syncthreads();
-    if (tid == 0) sh_tlast = atomicAdd(&a.dk_ticket[tile], 1) == DK_KS - 1;
-    __syncthreads();
-    if (sh_tlast) {   // (block-uniform) the tile's last slice to arrive: every slice's tile is published
-      float t[DK_KS];
-#pragma unroll
-      for (int k = 0; k < DK_KS; ++k) t[k] = acq_f32(a.dk_part + ((size_t)k * NT + tile) * 256 + tid);
-      static_assert(DK_KS == 8, "the slices' fixed-order sum below is written for eight");
-      g = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
-      a.gd[L.K + (16 * bi + (tid >> 4)) * D + 16 * bj + (tid & 15)] = g;
-      owner = true;
-      if (tid == 0) a.dk_ticket[tile] = 0;   // zero at rest
-    }
   } else if (blk < nbK) {
     const int idx = blk * 256 + tid;
     if (idx < D * D) {
