@@ -615,6 +615,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     // back to back: three dependent round trips (ids -> categories -> rows) for all LS positions
     // together; padding is applied afterwards by selects (padded slots contribute exactly 0).
     f32x4 e1[LS][NB], long4[NB], mx1[NB], iz1[NB];
+    int idk_w = 0, ctk_w = 0;   // this lane's window entry (id, category): NB > 1 re-gathers the window's rows in P5 (E1RG below)
     int posv[(TRAIN && LSTREAM) ? LS + 3 : 1];   // (streamed window: the three single uses, drawn by the lead lane)
     int upos = 0;                                // (window in registers: the cursor draw of this lane's use slot)
     int ucpos = 0, cposv = 0, scpos0 = 0;        // (CSEG: the category-cursor draws of the same uses)
@@ -1081,6 +1082,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       const int ct_k = a.p.item_cate[id_k];
       scat = a.p.item_cate[sid];   // ... and their categories with the window's
       __builtin_amdgcn_sched_barrier(0);
+      idk_w = id_k;
+      ctk_w = ct_k;
 #pragma unroll
       for (int p = 0; p < LS; ++p) {
         const int it = sample_pick<CPS>(id_k, p / CPS, p % CPS, s_loc), ct = sample_pick<CPS>(ct_k, p / CPS, p % CPS, s_loc);
@@ -2227,6 +2230,19 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           }
         }
         } else {
+        // E1RG (two 16-channel blocks per column, d = 256): the window's rows are NOT carried from P1 to here in registers
+        // (80 of them, live across three phases: the stamps showed 27 k cycles of spill traffic at the end of P1 and 19 k at
+        // the end of P3 where d = 128 spends 1 k) but fetched again, one position ahead -- they are L2 / Infinity-Cache
+        // resident, and a reload from scratch memory costs the same trip.  d = 256, Ls = 10: 206 -> 183 us/step, with bf16
+        // tables and operands 178 -> 139 (profiles/r04_d256_regather_ab.md); spilled registers 166 -> 114 / 223 -> 84
+        constexpr bool E1RG = NB > 1 && !LSTREAM;
+        f32x4 e_nx[NB];
+        auto e1_fetch = [&](int p_, f32x4 (&dst)[NB]) {
+          const int it = sample_pick<CPS>(idk_w, p_ / CPS, p_ % CPS, s_loc), ct = sample_pick<CPS>(ctk_w, p_ / CPS, p_ % CPS, s_loc);
+#pragma unroll
+          for (int kb = 0; kb < NB; ++kb) dst[kb] = gather_item4c<DT>(a, it, ct, chb[kb]);
+        };
+        if constexpr (E1RG) e1_fetch(0, e_nx);
 #pragma unroll
         for (int p = 0; p < LS; ++p) {
           dsp[p] = 0.0f;
@@ -2252,8 +2268,17 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             LD_N(w1W1 + zz, FN1);
             LD_N(w1W2 + zz, FN2);
           }
+            f32x4 ep[NB];   // the position's row: from P1's registers, or (E1RG) fetched again one position ahead
+            if constexpr (E1RG) {
 #pragma unroll
-            for (int kb = 0; kb < NB; ++kb) xv[kb] = e1[p][kb] * scp;
+              for (int kb = 0; kb < NB; ++kb) ep[kb] = e_nx[kb];
+              if (p + 1 < LS && p + 1 < pmax1) e1_fetch(p + 1, e_nx);
+            } else {
+#pragma unroll
+              for (int kb = 0; kb < NB; ++kb) ep[kb] = e1[p][kb];
+            }
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) xv[kb] = ep[kb] * scp;
             if (p == 1) TLSAN_STAMP(12);
             f32x4 k1[NB], k2[NB];
             if constexpr (DROP) {
@@ -2293,7 +2318,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             bwd_dw<NB, TSTR, MM>(T, q, r, acc.dW1, acc.dW2);
             if (p == 1) TLSAN_STAMP(15);
 #pragma unroll
-            for (int kb = 0; kb < NB; ++kb) dsp[p] += dot4(dx[kb], e1[p][kb]);
+            for (int kb = 0; kb < NB; ++kb) dsp[p] += dot4(dx[kb], ep[kb]);
             if (vs && vp) {
               if (lead) a.Gb[posp] = 0.0f;
 #pragma unroll
