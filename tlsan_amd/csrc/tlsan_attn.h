@@ -532,8 +532,12 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   // (PERM: wXW1 / wXW2 are the T-fragment tables; the N tables lie 2 * PP floats behind them)
   const float *w1W1 = wb1, *w1b1 = wb1 + (PERM ? 4 * PP : DH * DH), *w1W2 = PERM ? wb1 + PP : w1b1 + DH, *w1b2 = PERM ? w1b1 + DH : w1W2 + DH * DH;
   const float *w2W1 = wb2, *w2b1 = wb2 + (PERM ? 4 * PP : DH * DH), *w2W2 = PERM ? wb2 + PP : w2b1 + DH, *w2b2 = PERM ? w2b1 + DH : w2W2 + DH * DH;
-#define LD_T(W_, F_) do { if constexpr (PERM) load_frag_P<NB, MM>((W_), lane, F_); else load_frag_T<DH, NB, MM>((W_), q, r, F_); } while (0)
-#define LD_N(W_, F_) do { if constexpr (PERM) load_frag_P<NB, MM>((W_) + 2 * PP, lane, F_); else load_frag_N<DH, NB, MM>((W_), q, r, F_); } while (0)
+// (FLATG reads the weights from global memory: their per-lane addresses, formed early, were kept in spilled registers, and
+//  every reload from scratch memory drains the vector-memory queue -- 62 such drains in the C5 kernel; behind an opaque zero
+//  the address arithmetic stays at the use: d = 256, Ls = 90 344 -> 312 us/step, the C5 shape 412 -> 366, in bf16 317 -> 287)
+#define LD_Q (q + (FLATG ? opaque_zero(q) : 0))
+#define LD_T(W_, F_) do { if constexpr (PERM) load_frag_P<NB, MM>((W_), lane, F_); else load_frag_T<DH, NB, MM>((W_), LD_Q, r, F_); } while (0)
+#define LD_N(W_, F_) do { if constexpr (PERM) load_frag_P<NB, MM>((W_) + 2 * PP, lane, F_); else load_frag_N<DH, NB, MM>((W_), LD_Q, r, F_); } while (0)
 
   // diagnostic cycle stamps: only in a -DTLSAN_STAMPS=1 build (scripts/stamps.py loads it through TLSAN_LIB_PATH;
   // the production kernel carries no stamp code).  Kept in the LDS while the pass runs -- a global store per stamp
@@ -1132,14 +1136,18 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       }
     }
     TLSAN_STAMP(23);
+    // (d = 256: the addresses below are formed HERE, from the ids, behind a zero the compiler cannot see through -- formed
+    //  early they sat in spilled 64-bit registers, and each reload from scratch memory drained the vector-memory queue)
+    const int ozt = (NB > 1 && MM == TLSAN_MATRIX_F32) ? opaque_zero(tid) : 0;   // (fp32 operands: 182 -> 177 us/step at Ls = 10; with bf16 operands the kernel spills elsewhere and this cost 0.8 us)
+    const int bidx_t = bidx + ozt, uid_t = uid + ozt, ucat_t = ucat + ozt, it_t = it_i + ozt, ct_t = ct_i + ozt;
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
       *(f32x4*)(sA + srow * LSTR + chb[kb]) = long4[kb];
       if constexpr (TRAIN && G::FUSE_DK) {
         if (FUSE_RT || FLAT) *(f32x4*)(sL + srow * LSTR + chb[kb]) = long4[kb];
-        if (!FUSE_RT && vs) *(f32x4*)(a.gLong + (size_t)bidx * D + chb[kb]) = long4[kb];
+        if (!FUSE_RT && vs) *(f32x4*)(a.gLong + (size_t)bidx_t * D + chb[kb]) = long4[kb];
       } else if (TRAIN && vs) {
-        *(f32x4*)(a.gLong + (size_t)bidx * D + chb[kb]) = long4[kb];
+        *(f32x4*)(a.gLong + (size_t)bidx_t * D + chb[kb]) = long4[kb];
       }
     }
     // rows the short block needs that depend only on ids: issue now, consume after P2
@@ -1150,12 +1158,12 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       {
         const bool usr = c < a.di;
         const float* ub = usr ? a.p.user_emb : a.p.cate_emb;
-        const size_t ui = usr ? (size_t)uid * a.p.ld_user + c : (size_t)ucat * a.dc + (c - a.di);
+        const size_t ui = usr ? (size_t)uid_t * a.p.ld_user + c : (size_t)ucat_t * a.dc + (c - a.di);
         uemb[kb] = tbl_ld4<DT>(ub, ui) * P;
       }
-      iemb[kb] = gather_item4c<DT>(a, it_i, ct_i, c) * P;
+      iemb[kb] = gather_item4c<DT>(a, it_t, ct_t, c) * P;
     }
-    const float ib_i = a.p.item_b[(size_t)it_i * a.p.ld_itemb];
+    const float ib_i = a.p.item_b[(size_t)it_t * a.p.ld_itemb];
     if constexpr (!LSTREAM) {   // the first session row as well (ids and categories came with the window's): it is in flight over barrier 1 and P2
       if (wave_max_samples<CPS>(n_s + 1) > 1) fetch_row(0, xnext);
     }
