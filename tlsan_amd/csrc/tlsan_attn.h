@@ -734,8 +734,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       f32x4 b1[NB], b2[NB];
       LD_T(w1W1, FT1);
       LD_T(w1W2, FT2);
-      load_bias<DH, NB>(w1b1, q, b1);
-      load_bias<DH, NB>(w1b2, q, b2);
+      load_bias<DH, NB>(w1b1, LD_Q, b1);
+      load_bias<DH, NB>(w1b2, LD_Q, b2);
       if constexpr (TRAIN) {
         posv[LS] = (lead && vs) ? atomicAdd(&a.cur_item[it_i], 1) : 0;
         cposv = (lead && vs && CSEG) ? atomicAdd(&a.cur_uc[ct_i], 1) : 0;
@@ -966,8 +966,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       f32x4 b1[NB], b2[NB], Zl[NB];
       LD_T(w1W1, FT1);
       LD_T(w1W2, FT2);
-      load_bias<DH, NB>(w1b1, q, b1);
-      load_bias<DH, NB>(w1b2, q, b2);
+      load_bias<DH, NB>(w1b1, LD_Q, b1);
+      load_bias<DH, NB>(w1b2, LD_Q, b2);
       if constexpr (TRAIN) {
         posv[LS] = (lead && vs) ? atomicAdd(&a.cur_item[it_i], 1) : 0;
         cposv = (lead && vs && CSEG) ? atomicAdd(&a.cur_uc[ct_i], 1) : 0;
@@ -1118,8 +1118,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       f32x4 b1[NB], b2[NB];
       LD_T(w1W1, FT1);
       LD_T(w1W2, FT2);
-      load_bias<DH, NB>(w1b1, q, b1);
-      load_bias<DH, NB>(w1b2, q, b2);
+      load_bias<DH, NB>(w1b1, LD_Q, b1);
+      load_bias<DH, NB>(w1b2, LD_Q, b2);
       TLSAN_STAMP(22);
       f32x4 att_r[TRAIN ? 1 : LS][NB];
       fwa_forward<NB, LS, DROP, MM>(FT1, b1, FT2, b2, e1, sc1, n_l, pmax1, mx1, iz1, long4, KEEP_A ? sAw : nullptr, dc, 0, chb,
@@ -1220,8 +1220,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     f32x4 b1[NB], b2[NB];
     LD_T(w2W1, FT1);
     LD_T(w2W2, FT2);
-    load_bias<DH, NB>(w2b1, q, b1);
-    load_bias<DH, NB>(w2b2, q, b2);
+    load_bias<DH, NB>(w2b1, LD_Q, b1);
+    load_bias<DH, NB>(w2b2, LD_Q, b2);
     TLSAN_STAMP(3);
     __syncthreads();
     TLSAN_STAMP(4);
@@ -1338,9 +1338,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       if constexpr (G::AT_USE && !LSTREAM && G::AT_USE_T) {  // weight fragments from LDS at the use
         const int zz = opaque_zero(p);
         LD_T(w2W1 + zz, FT1);
-        load_bias<DH, NB>(w2b1 + zz, q, b1);
+        load_bias<DH, NB>(w2b1 + zz, LD_Q, b1);
         LD_T(w2W2 + zz, FT2);
-        load_bias<DH, NB>(w2b2 + zz, q, b2);
+        load_bias<DH, NB>(w2b2 + zz, LD_Q, b2);
       }
 
       use_row(xnext, xv);
@@ -1533,9 +1533,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             const int zz = opaque_zero(p);
             if constexpr (G::AT_USE_T) {
               LD_T(w2W1 + zz, FT1);
-              load_bias<DH, NB>(w2b1 + zz, q, b1);
+              load_bias<DH, NB>(w2b1 + zz, LD_Q, b1);
               LD_T(w2W2 + zz, FT2);
-              load_bias<DH, NB>(w2b2 + zz, q, b2);
+              load_bias<DH, NB>(w2b2 + zz, LD_Q, b2);
             }
             LD_N(w2W1 + zz, FN1);
             LD_N(w2W2 + zz, FN2);
@@ -1687,9 +1687,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       // not move LDS reads across a barrier, and P5's first map waited for them (kernel -0.5 us, Movies-TV shape -1.5 us/step: profiles/r04_frag_early_ab.md)
       opd FN1[NB][NB], FN2[NB][NB];
       LD_T(w1W1, FT1);
-      load_bias<DH, NB>(w1b1, q, b1);
+      load_bias<DH, NB>(w1b1, LD_Q, b1);
       LD_T(w1W2, FT2);
-      load_bias<DH, NB>(w1b2, q, b2);
+      load_bias<DH, NB>(w1b2, LD_Q, b2);
       LD_N(w1W1, FN1);
       LD_N(w1W2, FN2);
       TLSAN_STAMP(8);
@@ -2269,9 +2269,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             const int zz = opaque_zero(p);
             if constexpr (G::AT_USE_T) {
               LD_T(w1W1 + zz, FT1);
-              load_bias<DH, NB>(w1b1 + zz, q, b1);
+              load_bias<DH, NB>(w1b1 + zz, LD_Q, b1);
               LD_T(w1W2 + zz, FT2);
-              load_bias<DH, NB>(w1b2 + zz, q, b2);
+              load_bias<DH, NB>(w1b2 + zz, LD_Q, b2);
             }
             LD_N(w1W1 + zz, FN1);
             LD_N(w1W2 + zz, FN2);
