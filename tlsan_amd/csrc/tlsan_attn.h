@@ -536,6 +536,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 //  every reload from scratch memory drains the vector-memory queue -- 62 such drains in the C5 kernel; behind an opaque zero
 //  the address arithmetic stays at the use: d = 256, Ls = 90 344 -> 312 us/step, the C5 shape 412 -> 366, in bf16 317 -> 287)
 #define LD_Q (q + (FLATG ? opaque_zero(q) : 0))
+// (the same for the rows fetched inside loops at d = 256: the lane's channel offset -- with it the choice of table and the
+//  64-bit base of the lane's half of the row, invariants of those loops -- is formed behind the id of the row)
+#define CH_USE(c_, id_) ((c_) + ((NB > 1 && LSTREAM) ? opaque_zero(id_) : 0))   // (streamed: Ls = 90 296 -> 284 us/step, C5 375 -> 358; with the window in registers it added drains)
 #define LD_T(W_, F_) do { if constexpr (PERM) load_frag_P<NB, MM>((W_), lane, F_); else load_frag_T<DH, NB, MM>((W_), LD_Q, r, F_); } while (0)
 #define LD_N(W_, F_) do { if constexpr (PERM) load_frag_P<NB, MM>((W_) + 2 * PP, lane, F_); else load_frag_N<DH, NB, MM>((W_), LD_Q, r, F_); } while (0)
 
@@ -663,7 +666,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       scx = (gamma * P * P) * uth;  // x = e_stored * scx
       sce = (gamma * P) * uth;      // d x / d e_true
 #pragma unroll
-      for (int kb = 0; kb < NB; ++kb) xr[kb] = gather_item4c<DT>(a, it, ct, chb[kb]);
+      for (int kb = 0; kb < NB; ++kb) xr[kb] = gather_item4c<DT>(a, it, ct, CH_USE(chb[kb], it));
     };
     using raw4 = typename TblRaw<DT>::type;
     auto fetch_lrow_raw = [&](int p, raw4 (&xr)[NB], float& scx, float& sce) {  // the same, the row as loaded (widened at its use)
@@ -673,7 +676,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       scx = (gamma * P * P) * uth;
       sce = (gamma * P) * uth;
 #pragma unroll
-      for (int kb = 0; kb < NB; ++kb) xr[kb] = gather_item4c_raw<DT>(a, it, ct, chb[kb]);
+      for (int kb = 0; kb < NB; ++kb) xr[kb] = gather_item4c_raw<DT>(a, it, ct, CH_USE(chb[kb], it));
     };
     // session ids (and their categories) are fetched once, one per lane of the sample
     // (lane k = q*CPS + col holds entry k of the current chunk of NL entries), then broadcast
@@ -708,7 +711,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       }
       o.v = t0 + dt < n_sel;
 #pragma unroll
-      for (int kb = 0; kb < NB; ++kb) o.r[kb] = gather_item4c_raw<DT>(a, it, ct, chb[kb]);
+      for (int kb = 0; kb < NB; ++kb) o.r[kb] = gather_item4c_raw<DT>(a, it, ct, CH_USE(chb[kb], it));
     };
     auto fetch_row = [&](int t, RowPF& o) { fetch_row_of(t, 0, false, o, s_loc, n_s); };
     int spos0 = 0;  // position of session use kk (first chunk): one returning atomic per use
@@ -786,7 +789,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       };
       auto issue = [&](const Ent& e, raw4 (&row)[NB]) {
 #pragma unroll
-        for (int kb = 0; kb < NB; ++kb) row[kb] = gather_item4c_raw<DT>(a, e.id, e.ct, chb[kb]);
+        for (int kb = 0; kb < NB; ++kb) row[kb] = gather_item4c_raw<DT>(a, e.id, e.ct, CH_USE(chb[kb], e.id));
       };
       f32x4 smx[NB], sZ[NB], sN[NB];
 #pragma unroll
@@ -1759,7 +1762,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             uhN = sFuh[ic];
             const int sb = sBx[stN >> 8];
 #pragma unroll
-            for (int kb = 0; kb < NB; ++kb) en[kb] = gather_item4c_raw<DT>(a, id, ct, chb[kb]);
+            for (int kb = 0; kb < NB; ++kb) en[kb] = gather_item4c_raw<DT>(a, id, ct, CH_USE(chb[kb], id));
             const float* gs = a.gStat + (size_t)sb * 2 * D;
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) {
@@ -1878,7 +1881,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           int posuB = 0;
           auto fetch_into = [&](RowBuf& E) {    // the entry read from the list last goes out; the one after it is read
 #pragma unroll
-            for (int kb = 0; kb < NB; ++kb) E.r[kb] = gather_item4c_raw<DT>(a, idN, ctN, chb[kb]);
+            for (int kb = 0; kb < NB; ++kb) E.r[kb] = gather_item4c_raw<DT>(a, idN, ctN, CH_USE(chb[kb], idN));
             E.st = stN;
             E.uh = uhN;
           };
