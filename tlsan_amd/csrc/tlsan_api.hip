@@ -164,7 +164,7 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
   w->partials = (float*)take(sizeof(float) * w->ngroups * s.NPB);
   // (sized so that the workspace of a batch also holds every smaller batch: the fused form of a smaller batch can
   //  need more partials than the split form of a larger one)
-  int kp_slots = dk_nsplit(B);
+  int kp_slots = dk_nsplit(B, s.D);
   if (s.D <= 128) {
     const int ng8 = s.D == 128 ? (B + 7) / 8 : ngroups;    // (8-sample workgroups: twice the groups)
     const int fmax = ng8 < FUSED_DK_MAX_GROUPS ? ng8 : FUSED_DK_MAX_GROUPS;
@@ -810,10 +810,10 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   prof_mark(1, hs);
   if ((rc = launch_fwd(s, true, a, hs, grp))) return rc;
   prof_mark(2, hs);
-  const int nsplit = a.fuse_dk ? fwd_train_grid(a.ngroups) : dk_nsplit(b->B);   // dK partials the finalize sums
+  const int nsplit = a.fuse_dk ? fwd_train_grid(a.ngroups) : dk_nsplit(b->B, s.D);   // dK partials the finalize sums
   // --- dense-parameter gradients (D <= 128: the dK partials were left by k_fwd_bwd, one per workgroup)
   if (!a.fuse_dk) {
-    const int spw = dk_spw(b->B), nq = (s.D / 64) * (s.D / 64);
+    const int spw = dk_spw(b->B, s.D), nq = (s.D / 64) * (s.D / 64);
     const dim3 grid(nq * nsplit), blk(DK_WAVES * 64);
 #define DK_LAUNCH(DD)                                                                                           \
   do {                                                                                                          \
