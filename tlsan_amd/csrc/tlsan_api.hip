@@ -844,7 +844,10 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
     A.nbC = A.cseg ? (A.C + AP_ROWS_PB - 1) / AP_ROWS_PB : A.C * A.csplit;
     A.nbH = AP_HOT_CAP;   // hot item rows: a workgroup each, leading the grid
     const dim3 grid(w.nfin + 1 + A.nbH + A.nbC + A.nbI + A.nbU);
-    const bool wide = apply_wide(A);
+    // (the row-sum launch covers user rows of up to 256 floats in two passes of its narrow form -- 92 registers, five
+    //  workgroups per CU, instead of 135 and three; the sharded step's fused rows keep the wide form.  d = 128 with 90-entry
+    //  windows: Movies-TV shape 106.6 -> 104.3 us/step, with 673 categories 116.2 -> 106.2: profiles/r04_presum_narrow_ab.md)
+    const bool wide = A.di > 64 || A.dc > 64 || (A.WU > 128 && A.presum_rows != 0);
 #define FP_LAUNCH(DD, HH)                                                                                         \
   do {                                                                                                            \
     if (A.csplit > 1) {                                                                                           \

@@ -1596,7 +1596,9 @@ __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx
 // ================= 16 item rows or 16 user rows per workgroup (one row per 16-lane group) =========
 // NCH float4 chunks per lane cover the row (item rows: the item half only), OWN gradient rows are
 // in flight per group; longer segments are finished by the whole wavefront.
-template <int MODE, bool LAZY, bool IS_ITEM, int NCH, int OWN, int DT>
+// C0: first 16-byte chunk per lane this call covers (a row wider than 16 lanes x NCH chunks is covered by two calls:
+// the row sums of 154-float user rows -- d = 128 with 90-entry windows -- without the wide variant's registers)
+template <int MODE, bool LAZY, bool IS_ITEM, int NCH, int OWN, int DT, int C0 = 0>
 __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx& x, int slot0, double* shp) {
   constexpr bool RESET = MODE == AP_UPDATE || MODE == AP_GRADS || MODE == AP_PRESUM;
   const int lane = x.lane, grp = x.grp, l16 = x.l16;
@@ -1635,7 +1637,7 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
   if constexpr (MODE != AP_PRESUM) {
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-      const int cc = 4 * (l16 + 16 * ch);
+      const int cc = 4 * (l16 + 16 * (ch + C0));
       if (cc < a.di) {
         w[ch] = tbl_ld4<DT>(Wtab, wrow + cc);
       } else if (!IS_ITEM) {
@@ -1659,7 +1661,7 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
         const float* src = Gs + (size_t)(off + min(u, last)) * ld;  // (buffers carry a pad row)
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch)
-          if (l16 + 16 * ch < W4) v[u][ch] = *(const f32x4*)(src + 4 * (l16 + 16 * ch));
+          if (l16 + 16 * (ch + C0) < W4) v[u][ch] = *(const f32x4*)(src + 4 * (l16 + 16 * (ch + C0)));
       }
       float gb = 0.0f;
       if (IS_ITEM) gb = a.Gb[off + min(l16, last)];
@@ -1668,7 +1670,7 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
         if (u < n_own) {
 #pragma unroll
           for (int ch = 0; ch < NCH; ++ch)
-            if (l16 + 16 * ch < W4) {
+            if (l16 + 16 * (ch + C0) < W4) {
 #pragma unroll
               for (int i = 0; i < 4; ++i) acc[ch][i] += exact_term(v[u][ch][i]);
             }
@@ -1684,7 +1686,7 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
         const int og = __shfl(off, g * 16);
         double t[NCH][4];
         zero_acc(t);
-        seg_accum<NCH>(Gs, ld, og + OWN + grp, og + ng, 4, W4, l16, t);
+        seg_accum<NCH>(Gs + 64 * C0, ld, og + OWN + grp, og + ng, 4, W4 - 16 * C0, l16, t);
         double tb = 0.0;
         if (IS_ITEM)
           for (int k = og + OWN + lane; k < og + ng; k += 64) tb += exact_term(a.Gb[k]);
@@ -1713,7 +1715,7 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
       if (by_row) R = IS_ITEM ? a.go.item_emb + (size_t)row * a.go.ld_item : a.go.user_emb + (size_t)row * a.go.ld_user;
 #pragma unroll
       for (int ch = 0; ch < NCH; ++ch) {
-        const int c4 = l16 + 16 * ch;
+        const int c4 = l16 + 16 * (ch + C0);
         if (c4 < W4) {
           f32x4 g;
 #pragma unroll
@@ -1747,7 +1749,7 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
     // column cc of the row: cc < di -> item_emb / user_emb;  user rows, di <= cc < di+Ls -> usert_emb
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-      const int cc = 4 * (l16 + 16 * ch);
+      const int cc = 4 * (l16 + 16 * (ch + C0));
       if (cc >= 4 * W4) continue;
       f32x4 g;
       if (cc < a.di) {
@@ -2156,7 +2158,12 @@ __global__ __launch_bounds__(256) void k_finalize_presum(FinArgs f, int nbK, int
     else apply_cate_block<AP_PRESUM, true, NC, TLSAN_TABLE_F32, CSPLIT>(a, x, shd, shp, sh_pos, sh_lo, sh_n, sh_wtot);
   }
   else if (blk < a.nbC + a.nbI) apply_rows_block<AP_PRESUM, true, true, NI, AP_OWN, TLSAN_TABLE_F32>(a, x, (blk - a.nbC) * AP_ROWS_PB, shp);
-  else apply_rows_block<AP_PRESUM, true, false, NU, AP_OWN / 2, TLSAN_TABLE_F32>(a, x, (blk - a.nbC - a.nbI) * AP_ROWS_PB, shp);
+  else {
+    apply_rows_block<AP_PRESUM, true, false, NU, AP_OWN / 2, TLSAN_TABLE_F32>(a, x, (blk - a.nbC - a.nbI) * AP_ROWS_PB, shp);
+    if constexpr (!WIDE) {   // user rows wider than 128 floats with narrow item / category rows: the second half of the row
+      if (a.WU > 128) apply_rows_block<AP_PRESUM, true, false, NU, AP_OWN / 2, TLSAN_TABLE_F32, NU>(a, x, (blk - a.nbC - a.nbI) * AP_ROWS_PB, shp);
+    }
+  }
   if (stp && x.tid == 0) { stp[6] = __builtin_amdgcn_s_memtime(); stp[5] = __builtin_amdgcn_s_memrealtime(); }
 }
 
