@@ -6,11 +6,13 @@ import os, re, subprocess, sys, tempfile
 from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "tlsan_amd", "csrc")
-UNITS = ("tlsan_attn_d64", "tlsan_attn_d128", "tlsan_attn_d128w4", "tlsan_attn_d256")
+UNITS = ("tlsan_attn_d64", "tlsan_attn_d128", "tlsan_attn_d128w4", "tlsan_attn_d256", "tlsan_attn_d256s")
+sys.path.insert(0, ROOT)
+from tlsan_amd.build import SOURCE_FLAGS   # (per-source compiler flags of the product build)
 def run(u):
     with tempfile.TemporaryDirectory() as td:
         r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
-                            "-I" + CSRC, "--cuda-device-only", "-c", os.path.join(CSRC, u + ".hip"), "-o", os.path.join(td, "o.o"),
+                            "-I" + CSRC] + SOURCE_FLAGS.get(u + ".hip", []) + ["--cuda-device-only", "-c", os.path.join(CSRC, u + ".hip"), "-o", os.path.join(td, "o.o"),
                             "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
         return r.stderr
 with ThreadPoolExecutor(4) as ex:

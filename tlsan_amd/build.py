@@ -1,5 +1,6 @@
-"""Build libtlsan_hip.so (gfx950) in-tree with hipcc.  No torch, no cmake: five translation
-units (the C ABI with every kernel but the fused one; k_fwd_bwd for d = 64 / 128 / 128 as 8-sample workgroups / 256)
+"""Build libtlsan_hip.so (gfx950) in-tree with hipcc.  No torch, no cmake: six translation
+units (the C ABI with every kernel but the fused one; k_fwd_bwd for d = 64 / 128 / 128 as 8-sample workgroups / 256 with
+the window in registers / 256 streamed)
 compiled in parallel, one link.  `python -m tlsan_amd.build` or `build()`."""
 from __future__ import annotations
 
@@ -12,7 +13,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libtlsan_hip.so")
-SOURCES = ["tlsan_api.hip", "tlsan_attn_d64.hip", "tlsan_attn_d128.hip", "tlsan_attn_d128w4.hip", "tlsan_attn_d256.hip"]
+SOURCES = ["tlsan_api.hip", "tlsan_attn_d64.hip", "tlsan_attn_d128.hip", "tlsan_attn_d128w4.hip", "tlsan_attn_d256.hip", "tlsan_attn_d256s.hip"]
+# per-source extra flags (see the source's header comment)
+SOURCE_FLAGS = {"tlsan_attn_d256s.hip": ["-mllvm", "-disable-machine-licm"]}
 HEADERS = ["tlsan_common.h", "tlsan_attn.h", "tlsan_attn_inst.h", "tlsan_update.h", "tlsan_eval.h", "tlsan_rows.h", "tlsan_shard.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC] + \
         os.environ.get("TLSAN_HIPCC_EXTRA", "").split()   # (experiments: extra compiler flags)
@@ -46,7 +49,7 @@ def build(force=False, verbose=False):
 
     def run(job):
         s, o = job
-        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        cmd = [hipcc] + FLAGS + SOURCE_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -54,7 +57,7 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed for %s:\n%s" % (s, r.stderr[-4000:]))
         return o
 
-    with ThreadPoolExecutor(max_workers=5) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         list(ex.map(run, jobs))
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):

@@ -83,6 +83,13 @@ static hipError_t launch_fwd_bwd_impl(bool train, bool lstream, const FwdArgs& a
   return lstream ? launch_variant<D, DH, false, true>(a, grid, st, ev) : launch_variant<D, DH, false, false>(a, grid, st, ev);
 }
 
+// one window form only (a translation unit of its own for the streamed form of d = 256, which is compiled with other flags)
+template <int D, int DH, bool LSTREAM>
+static hipError_t launch_fwd_bwd_form(bool train, const FwdArgs& a, int grid, hipStream_t st, LaunchEvents ev) {
+  if (train) return launch_variant<D, DH, true, LSTREAM>(a, grid, st, ev);
+  return launch_variant<D, DH, false, LSTREAM>(a, grid, st, ev);
+}
+
 // training step with the window in registers, no dropout, as NWV-wavefront workgroups (d = 128: 4 wavefronts, 8 samples)
 template <int D, int DH, int NWV>
 static hipError_t launch_train_nw(const FwdArgs& a, int grid, hipStream_t st, LaunchEvents ev) {
