@@ -15,7 +15,11 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libtlsan_hip.so")
 SOURCES = ["tlsan_api.hip", "tlsan_attn_d64.hip", "tlsan_attn_d128.hip", "tlsan_attn_d128w4.hip", "tlsan_attn_d256.hip", "tlsan_attn_d256s.hip"]
 # per-source extra flags (see the source's header comment)
-SOURCE_FLAGS = {"tlsan_attn_d256s.hip": ["-mllvm", "-disable-machine-licm"]}
+SOURCE_FLAGS = {"tlsan_attn_d256.hip": ["-mllvm", "-sink-insts-to-avoid-spills"],
+                "tlsan_attn_d256s.hip": ["-mllvm", "-disable-machine-licm", "-mllvm", "-sink-insts-to-avoid-spills"]}
+if os.environ.get("TLSAN_SOURCE_FLAGS"):   # (experiments: JSON {source: [flags]}, replaces the entries it names)
+    import json
+    SOURCE_FLAGS.update(json.loads(os.environ["TLSAN_SOURCE_FLAGS"]))
 HEADERS = ["tlsan_common.h", "tlsan_attn.h", "tlsan_attn_inst.h", "tlsan_update.h", "tlsan_eval.h", "tlsan_rows.h", "tlsan_shard.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC] + \
         os.environ.get("TLSAN_HIPCC_EXTRA", "").split()   # (experiments: extra compiler flags)
