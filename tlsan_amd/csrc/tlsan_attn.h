@@ -846,7 +846,26 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       };
       // (d = 256: one row at a time -- two in flight as at d <= 128 were no faster there, the kernel is bound by its
       //  matrix work and its spilled registers: C5 shape 439 vs 430 us/step)
-      if (FTn > 0 && NB > 1) {
+      if (FTn > 0 && NB > 1 && DT == TLSAN_TABLE_F32) {
+        // (d = 256, fp32 tables: one row in flight ahead of the entry being computed.  Nothing in round 3, when every reload
+        //  of a spilled address drained the queue and the prefetch with it; under the final compiler switches the C5 shape
+        //  goes 325 -> 317 us/step, small tables and bf16 tables stay equal; the same in the list's backward costs 26 us --
+        //  32 more live registers there)
+        Ent e, en;
+        raw4 rw[NB], rn[NB];
+        read_ent(i0, e);
+        issue(e, rw);
+        for (int k = 0; k < FTn; ++k) {
+          f32x4 xa[NB];
+          read_ent(i0 + k + 1, en);
+          issue(en, rn);
+          take(i0 + k, e, rw, xa);
+          compute(i0 + k, e.st, xa);
+          e = en;
+#pragma unroll
+          for (int kb = 0; kb < NB; ++kb) rw[kb] = rn[kb];
+        }
+      } else if (FTn > 0 && NB > 1) {
         for (int k = 0; k < FTn; ++k) {
           Ent e;
           raw4 rw[NB];
