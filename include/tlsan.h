@@ -205,7 +205,11 @@ int tlsan_forward(const tlsan_dims* dims, const tlsan_params* p, const tlsan_bat
 /* The same, and the two attention-weight tensors the reference keeps on the model (model.py:122: self.att0, self.att1 =
  * `soft` of feature_wise_attention, model.py:386-394, heads split along the batch axis) when non-NULL:
  *   att0[num_heads * B, Ls, d / num_heads]      long-term block, row h * B + b; exactly 0 past sl[b]
- *   att1[num_heads * B, 1 + Sn, d / num_heads]  short-term block, position 0 = the bridge; exactly 0 past 1 + sl_new[b] */
+ *   att1[num_heads * B, 1 + Sn, d / num_heads]  short-term block, position 0 = the bridge; exactly 0 past 1 + sl_new[b]
+ * One deviation, for a sample with sl[b] == 0 (an empty history: never in the reference's data, build_dataset.py:49-52):
+ * the reference's softmax over a fully masked row (model.py:384-386) is the uniform 1 / Ls; here that row of att0 is 0.1
+ * at every position when the window is held in registers (Ls <= 10) and exactly 0 when it is streamed (Ls > 10).  No
+ * other output depends on it: the long-term vector of such a sample is 0 in the reference and here. */
 int tlsan_forward_att(const tlsan_dims* dims, const tlsan_params* p, const tlsan_batch* b,
                       float* logits_i, float* logits_j, float* u_t, float* att0, float* att1,
                       void* ws, size_t ws_bytes, void* stream);

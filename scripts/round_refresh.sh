@@ -2,7 +2,7 @@
 # One gpurun call that regenerates everything profiles/ holds for a round: the full GPU test suite, the profile set of
 # scripts/refresh_profiles.sh (bench under a kernel trace, PMC passes in fp32 / bf16 tables / bf16 operands, traffic.json),
 # the in-kernel stamps (fp32, bf16, streamed), the other shapes, PMC + register reports of the d = 256 kernels, the
-# sharded static step (kernel stats, bench line).  Needs ab_libs/stamps.so (scripts/mkvariants.sh stamps:"-DTLSAN_STAMPS=1").
+# sharded static step (kernel stats, bench line).  Needs ab_run/stamps.so (scripts/mkvariants.sh stamps:"-DTLSAN_STAMPS=1").
 R=${GRAFT_REPO_ROOT:-/root/repo}
 tag=${1:-r04}
 cd $R
@@ -10,9 +10,9 @@ timeout 3000 python3 -m pytest tests -m gpu -x -q > gpurun_out/${tag}_pytest_gpu
 tail -3 gpurun_out/${tag}_pytest_gpu.log
 timeout 1500 bash scripts/refresh_profiles.sh $tag
 cd $R
-TLSAN_LIB_PATH=$R/ab_libs/stamps.so timeout 300 python3 scripts/stamps.py > gpurun_out/${tag}_stamps.txt 2>&1
-TLSAN_LIB_PATH=$R/ab_libs/stamps.so MM=bf16 TD=bf16 timeout 300 python3 scripts/stamps.py > gpurun_out/${tag}_stamps_bf16.txt 2>&1
-TLSAN_LIB_PATH=$R/ab_libs/stamps.so timeout 300 python3 scripts/stamps.py d=128 Ls=90 U=35896 I=28589 C=15 > gpurun_out/${tag}_stamps_streamed.txt 2>&1
+TLSAN_LIB_PATH=$R/ab_run/stamps.so timeout 300 python3 scripts/stamps.py > gpurun_out/${tag}_stamps.txt 2>&1
+TLSAN_LIB_PATH=$R/ab_run/stamps.so MM=bf16 TD=bf16 timeout 300 python3 scripts/stamps.py > gpurun_out/${tag}_stamps_bf16.txt 2>&1
+TLSAN_LIB_PATH=$R/ab_run/stamps.so timeout 300 python3 scripts/stamps.py d=128 Ls=90 U=35896 I=28589 C=15 > gpurun_out/${tag}_stamps_streamed.txt 2>&1
 timeout 1500 bash scripts/shapes_all.sh > gpurun_out/${tag}_shapes.txt 2>&1
 timeout 600 bash scripts/pmc_shape.sh ${tag}_pmc_d256 d=256 Ls=10 > /dev/null 2>&1
 timeout 600 bash scripts/pmc_shape.sh ${tag}_pmc_c5 d=256 Ls=90 U=10000000 I=5000000 C=10000 > /dev/null 2>&1

@@ -1,8 +1,8 @@
 #!/bin/bash
-# On the GPU box: kernel-trace stats of one shape of scripts/shape_bench.py for every ab_libs/*.so: scripts/shape_kstats.sh shape-args...
+# On the GPU box: kernel-trace stats of one shape of scripts/shape_bench.py for every ab_run/*.so: scripts/shape_kstats.sh shape-args...
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-for so in $R/ab_libs/*.so; do
+for so in $R/ab_run/*.so; do
   n=$(basename $so .so)
   export TLSAN_LIB_PATH=$so
   rm -rf /tmp/ks_$n

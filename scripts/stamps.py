@@ -3,7 +3,7 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # the production kernel carries no stamp code: build the variant first (scripts/mkvariants.sh stamps:"-DTLSAN_STAMPS=1")
-os.environ.setdefault("TLSAN_LIB_PATH", os.path.join(ROOT, "ab_libs", "stamps.so"))
+os.environ.setdefault("TLSAN_LIB_PATH", os.path.join(ROOT, "ab_run", "stamps.so"))
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,4 +1,7 @@
-"""GPU tests at the shapes BASELINE.json's `configs` name (SURVEY 8 C2 / C4 / C5), all through the C ABI:
+"""GPU tests at the shapes BASELINE.json's `configs` name (SURVEY 8 C2 / C3 / C4 / C5), all through the C ABI:
+
+  C3  Electronics (39991 / 22048 / 673), d = 128, batch 4096 -- the bench's own tables and inputs through one forward
+      pass and one train step (lazy and dense L2; fp32 and bf16 table storage) against the fp64 oracle AT SIZE;
 
   C2  Digital-Music (1659 / 1583 / 53), d = 128 (64/64/64), fp32, batch 1024 -- the real fixture batch
       `DataInput_bs1024_k10_b0` (captured from the reference's input.py) through one train step and an
@@ -32,6 +35,52 @@ def _free_port():
     p = s.getsockname()[1]
     s.close()
     return p
+
+
+# ------------------------------------------------------------------------------------------- C3
+@pytest.mark.parametrize("table_dtype", ["f32", "bf16"])
+def test_c3_electronics_one_step_matches_oracle(table_dtype):
+    """BASELINE.json configs[2] at its own size -- Electronics (39991 / 22048 / 673), d = 128 (64/64/64), batch 4096, the
+    bench's synthetic inputs -- against the fp64 oracle (TLSAN/model.py:56-205 restated; one oracle step at this size is
+    ~8 s of numpy): logits and u_t of the forward pass, then one train step in lazy and in dense L2 mode -- loss, clip
+    norm, every parameter.  Second case: the precision the config names, bf16 table storage -- the oracle runs on the
+    tables as stored (rounded to bf16), fp32 parameters are held to the same bound, and every stored bf16 element must
+    be a bf16 neighbour of the oracle's exact update (stochastic rounding on the write-back)."""
+    from tlsan_amd import synth
+    from tlsan_amd.model import Model
+    cfg = synth.make_config("electronics")
+    icl = synth.item_cate_list(cfg)
+    batch = synth.make_batches(cfg, 1, 4096, seed=1234)[0]
+    p = {k: np.asarray(v, np.float32).astype(np.float64) for k, v in orc.init_params(cfg, seed=1234, dtype=np.float32).items()}
+    bf = ("item_emb", "user_emb", "cate_emb")
+    if table_dtype == "bf16":
+        for k in bf:
+            u32 = np.asarray(p[k], np.float32).view(np.uint32).astype(np.uint64)
+            u32 = ((u32 + 0x7FFF + ((u32 >> 16) & 1)) >> 16) << 16          # round to nearest even
+            p[k] = u32.astype(np.uint32).view(np.float32).reshape(p[k].shape).astype(np.float64)
+    b = orc.as_batch(batch)
+    ref = orc.forward(p, icl, b, 8)
+    loss, newp, info = orc.train_step(p, icl, b, 8, cfg["regulation_rate"], lr=1.0)
+    for l2 in ("lazy", "dense"):
+        m = Model(cfg, icl, l2_mode=l2, table_dtype=table_dtype)
+        m.set_params({k: np.asarray(v, np.float32) for k, v in p.items()})
+        li, _, ut, _ = m.forward(batch, is_test=False, want_u_t=True)
+        assert np.abs(li.cpu().numpy() - ref["logits"]).max() < LOGIT_TOL, l2
+        assert np.abs(ut.cpu().numpy() - ref["u_t"]).max() < LOGIT_TOL, l2
+        got_loss = m.train(None, batch, 1.0)
+        assert abs(got_loss - loss) < 1e-4 * max(1.0, abs(loss)), (l2, got_loss, loss)
+        assert abs(m.last_gnorm() - info["norm"]) < 3e-4 * info["norm"], l2
+        got = m.get_params()
+        for k in newp:
+            a, r = np.asarray(got[k], np.float64).reshape(p[k].shape), newp[k]
+            if table_dtype == "bf16" and k in bf:
+                ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(r), 1e-30))) - 7)
+                nround = 2 if l2 == "lazy" else 1     # (lazy: reading the parameters folds the table scale in, a second rounding)
+                assert (np.abs(a - r) <= ulp * (nround + 1e-3) + 1e-12).all(), (l2, k)
+                assert abs(((a - r) / ulp).mean()) < 0.02, (l2, k)       # unbiased
+            else:
+                du, dr = a - p[k], r - p[k]
+                assert np.abs(du - dr).max() < 3e-4 * (np.abs(dr).max() + 1e-9) + 2e-7, (l2, k)
 
 
 # ------------------------------------------------------------------------------------------- C2

@@ -564,8 +564,9 @@ def test_prefetched_index_equals_inline():
 
 
 def test_full_scale_properties():
-    """BASELINE.json configs[2] at full size (U=39991, I=22048, C=673, d=128, batch 4096), where the
-    oracle is too slow: size-independent properties of the train step.
+    """BASELINE.json configs[2] at full size (U=39991, I=22048, C=673, d=128, batch 4096): size-independent properties of
+    the train step over three steps (one step at this size against the oracle itself: tests/test_gpu_configs.py,
+    test_c3_electronics_one_step_matches_oracle).
       * determinism: two runs of 3 steps are bitwise equal;
       * the lazy-L2 step is the reference's dense-L2 step: after folding the scale, parameters of
         l2_mode=lazy and l2_mode=dense agree to fp32 rounding, losses and norms too;
@@ -624,7 +625,8 @@ def test_full_scale_properties():
 @pytest.mark.parametrize("matrix_dtype", ["f32", "bf16"])
 def test_full_scale_bf16(matrix_dtype):
     """BASELINE.json configs[2] in the precision it names -- bf16 table storage (and, second case, bf16 matrix
-    operands) -- at its own size (U=39991, I=22048, C=673, d=128, batch 4096), where the oracle is too slow:
+    operands) -- at its own size (U=39991, I=22048, C=673, d=128, batch 4096); properties over three steps (one step
+    with bf16 tables against the oracle at this size: test_c3_electronics_one_step_matches_oracle):
       * determinism: two runs of 3 steps leave bitwise equal tables and losses (stochastic rounding included);
       * the L2 term and the clip norm follow the STORED values: the loss a step reports equals the BCE of its logits
         plus reg/2 * ||P * stored tables||^2 recomputed from the tables themselves, after three updates whose changes
@@ -1168,3 +1170,20 @@ def test_other_optimizers_with_bf16_tables(optimizer, lr):
             assert np.abs(a - r).max() < 2e-3 * step + 1e-7, k
         for gs, ref in ((s1[k], st["slot1"][k]), (s2[k], st["slot2"][k])):
             assert np.abs(np.asarray(gs, np.float64).reshape(ref.shape) - ref).max() < 2e-3 * np.abs(ref).max() + 1e-9, k
+
+
+@pytest.mark.parametrize("nw4", ["0", "2"])
+def test_d128_parity_in_both_workgroup_geometries(nw4):
+    """d = 128 training launches of up to 1024 sequences take the 8-sample geometry (Geo<128, 16, 4>) by default, so the
+    small-batch parity tests above only reach the 16-sample kernel -- the one the bench shape runs -- through the B = 4096
+    cases.  TLSAN_NW4 (read once per process) pins the geometry: 0 = 16-sample workgroups always, 2 = 8-sample always.
+    The d = 128 gradient / train-step / bf16 / category-segment cases must hold to the oracle in both."""
+    import subprocess, sys
+    env = dict(os.environ, TLSAN_NW4=nw4)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-m", "gpu", "-q", "-x", "-k",
+                        "(test_gradients and 128) or test_train_step_matches_oracle or test_multi_step_tracks_oracle_and_is_deterministic "
+                        "or (test_category_segments_match_oracle and 128-10) or test_bf16_tables or (test_bf16_matrix_products and 128) "
+                        "or test_lazy_l2_matches_dense_oracle or test_long_sessions_and_short_window or (test_empty_histories and 128-10)"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

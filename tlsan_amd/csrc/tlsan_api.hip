@@ -5,6 +5,7 @@
 #include <condition_variable>
 #include <deque>
 #include <mutex>
+#include <sched.h>
 #include <thread>
 #include <stdarg.h>
 #include <stdio.h>
@@ -1543,23 +1544,42 @@ static bool g_pbusy = false, g_pstarted = false;
 static int g_prc = 0;
 static char g_pmsg[512] = "";
 
+// a polite spin on a word the GPU writes: a pause instruction per poll, the time slice handed back every 64 polls -- the
+// host normally runs ahead of the GPU, and a thread spinning flat out takes a core from the rank's own launch thread
+static inline void spin_pause(unsigned long polls) {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#endif
+  if ((polls & 63) == 0) sched_yield();
+}
+
 static void plan_worker() {
   for (;;) {
     PlanJob j;
+    bool skip = false;
     {
       std::unique_lock<std::mutex> lk(g_pm);
       g_pcv.wait(lk, [] { return !g_pq.empty(); });
       j = g_pq.front();
       g_pq.pop_front();
       g_pbusy = true;
+      skip = g_prc != 0;     // (an earlier job failed: the error is latched until the caller flushes; later jobs are dropped, not issued)
     }
     int rc = TLSAN_OK;
+    if (skip) {
+      std::lock_guard<std::mutex> lk(g_pm);
+      g_pbusy = false;
+      if (g_pq.empty()) g_pidle.notify_all();
+      continue;
+    }
     if (hipSetDevice(j.device) != hipSuccess) rc = fail(TLSAN_E_LAUNCH, "plan worker: hipSetDevice(%d)", j.device);
     if (!rc && j.word != nullptr) {
       const auto t0 = std::chrono::steady_clock::now();
       unsigned long polls = 0;
+      // (sequence numbers run over the full 32 bits on both sides of the ABI: "reached" is (int32)(word - after) >= 0)
       while ((int32_t)(*j.word - j.after) < 0) {
-        if ((++polls & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
+        spin_pause(++polls);
+        if ((polls & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
           rc = fail(TLSAN_E_LAUNCH, "plan worker: step %u did not start within 30 s", j.after);
           break;
         }
@@ -1640,7 +1660,8 @@ int tlsan_shard_step_static(const tlsan_static_step* s, int32_t phases, const tl
       const auto t0 = std::chrono::steady_clock::now();
       unsigned long polls = 0;
       while ((int32_t)(*w - s->plans_after) < 0) {
-        if ((++polls & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
+        spin_pause(++polls);
+        if ((polls & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
           return fail(TLSAN_E_LAUNCH, "tlsan_shard_step_static: step %u did not start within 30 s", s->plans_after);
       }
     }

@@ -85,7 +85,7 @@ __device__ __forceinline__ void fwa_forward(const typename MMT<MM>::opd (&FT1)[N
     for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        float ev = __expf(a[p][kb][i] - mx[kb][i]);  // softmax over positions, model.py:386
+        float ev = exp2s(a[p][kb][i] - mx[kb][i]);  // softmax over positions, model.py:386
         a[p][kb][i] = ev;
         Z[kb][i] += ev;
       }
@@ -386,7 +386,7 @@ __device__ __forceinline__ void online_step(f32x4 (&mx)[NB], f32x4 (&Z)[NB], f32
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float mn = fmaxf(mx[kb][i], m2[kb][i]);
-      const float so = __expf(mx[kb][i] - mn), ev = __expf(m2[kb][i] - mn);
+      const float so = exp2s(mx[kb][i] - mn), ev = exp2s(m2[kb][i] - mn);
       Z[kb][i] = Z[kb][i] * so + ev;
       N[kb][i] = N[kb][i] * so + ev * xv[kb][i];
       mx[kb][i] = mn;
@@ -415,6 +415,11 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   // per-sample position slots: long, session (the batch's padded session length, rounded up to 4), 3 singles
   // (CSEG keeps two such arrays and sizes them by the batch; otherwise the slot count is a compile-time constant)
 
+#ifndef TLSAN_LKEY
+#define TLSAN_LKEY 1
+#endif
+  constexpr bool LKEY = TLSAN_LKEY && NB == 1 && !LSTREAM;   // row keys reach a sample's lanes through the LDS (see g_item below, P1, fetch_row_of)
+  constexpr int NLK = 16;                                    // session entries per chunk of keys
   const bool FUSE_RT = a.fuse_dk != 0;   // (this launch forms the dK partials itself; as a compile-time constant: -0.2 us/step, not worth a variant)
   // FLAT (streamed windows): the window positions of the workgroup's 16 samples form ONE list that is dealt out evenly
   // to its 16 column groups (a wavefront's lanes that share a sample slot) -- see P1.  Its entries, the per-sample
@@ -436,7 +441,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   float* sB0 = sA + NSB * LSTR;       // [NSB][LSTR]  bridge -> dlong  (FLAT: placed in front of sT instead, see sPart)
   float* sL = FLAT ? sB0 : sB0 + NSB * LSTR;   // [NSB][LSTR]  long, kept for the fused dK product (TRAIN && FUSE_DK) and for FLAT's backward
   float* sS = sL + ((TRAIN && ((G::FUSE_DK && FUSE_RT) || (FLAT && !FLATG))) ? NSB * LSTR : 0);  // [NW][4] scalar staging  (sL exists in launches that fuse: tlsan_attn_inst.h)
-  float* sH = sS + NW * 4;            // [NSB][2*LS] hist_t and usert*hist_t of the pass  (FLAT: [2][NF], by flat index)
+  int* sSK = (int*)(sS + NW * 4);     // LKEY: [NW][2][SPW][NLK] item ids | categories of the current chunk of session entries
+  float* sH = (float*)(sSK + (LKEY ? NW * 2 * SPW * NLK : 0));   // [NSB][2*LS] hist_t and usert*hist_t of the pass  (FLAT: [2][NF], by flat index)
   float* sW = sH + NSB * 2 * LSC;     // [2][WB] attention weights (W1,b1,W2,b2) of both blocks  (PERM: [2][WBP], see below)
   // PERM (two 16-channel blocks per column, d = 256): the weight fragments are re-read from the LDS at every position
   // (Geo::AT_USE), and read from the row-major copy that costs 8 two-dword reads with computed addresses per fragment,
@@ -484,6 +490,15 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
   for (int kb = 0; kb < NB; ++kb) chb[kb] = col * CW + 16 * kb + 4 * q;
   const bool lead = (q == 0) && (col == 0);  // one lane per sample
+  // LKEY (windows in registers, one 16-channel block per column): the lane's half of a concatenated [item_emb | cate_emb]
+  // row as per-lane constants -- table, row stride, offset of its four channels -- so that a gather's address is
+  // key * g_ld + g_off with key = the item id or the item's category (see P1)
+  // (element index of the lane's piece of row `key`: one v_mad_u64_u32 -- ids, strides and offsets are non-negative 32-bit values)
+  auto g_idx = [&](int key, int ld, int off) -> size_t { return (size_t)((unsigned long long)(unsigned)key * (unsigned)ld + (unsigned)off); };
+  const bool g_item = chb[0] < a.di;
+  const float* g_base = g_item ? a.p.item_emb : a.p.cate_emb;
+  const int g_ld = g_item ? a.p.ld_item : a.dc;
+  const int g_off = g_item ? chb[0] : chb[0] - a.di;
   // where channels [c, c+4) of an item use's gradient row go: the use's row of Gi, or (CSEG, category half) the use's
   // row in its category's segment of Gc
   auto use_dst = [&](int pos, int cpos, int c) -> float* {
@@ -515,9 +530,10 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         const float* W = src + ((tab & 1) ? DH * DH + DH : 0);    // W1 or W2
         // T fragment (tab 0, 1): F[jb = pa][kb = pb][s] = W[16 kb + 4 q + s][16 jb + r]; N (tab 2, 3): F[kb = pa][jb = pb][s] = W[16 kb + r][16 jb + 4 q + s]
         v = tab < 2 ? weff<DH>(W, 16 * pb + 4 * qq + s_, 16 * pa + rr) : weff<DH>(W, 16 * pa + rr, 16 * pb + 4 * qq + s_);
+        if (tab == 1) v *= TLSAN_LOG2E;   // W2 as forward fragments: scores in units of log 2 (TLSAN_LOG2E)
       } else {
         const int y = x - 4 * PP;
-        v = y < DH ? src[DH * DH + y] : src[2 * DH * DH + DH + (y - DH)];
+        v = y < DH ? src[DH * DH + y] : src[2 * DH * DH + DH + (y - DH)] * TLSAN_LOG2E;
       }
       sW[o] = v;
     }
@@ -540,6 +556,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 //  64-bit base of the lane's half of the row, invariants of those loops -- is formed behind the id of the row)
 #define CH_USE(c_, id_) ((c_) + ((NB > 1 && LSTREAM) ? opaque_zero(id_) : 0))   // (streamed: Ls = 90 296 -> 284 us/step, C5 375 -> 358; with the window in registers it added drains)
 #define LD_T(W_, F_) do { if constexpr (PERM) load_frag_P<NB, MM>((W_), lane, F_); else load_frag_T<DH, NB, MM>((W_), LD_Q, r, F_); } while (0)
+// the forward fragment of W2 and the bias b2: in units of log 2 (tlsan_common.h, TLSAN_LOG2E; PERM: the LDS tables hold them scaled)
+#define LD_T2(W_, F_) do { if constexpr (PERM) load_frag_P<NB, MM>((W_), lane, F_); else load_frag_T<DH, NB, MM>((W_), LD_Q, r, F_, TLSAN_LOG2E); } while (0)
+#define LD_B2(b_, out_) load_bias<DH, NB>((b_), LD_Q, out_, PERM ? 1.0f : TLSAN_LOG2E)
 #define LD_N(W_, F_) do { if constexpr (PERM) load_frag_P<NB, MM>((W_) + 2 * PP, lane, F_); else load_frag_N<DH, NB, MM>((W_), LD_Q, r, F_); } while (0)
 
   // diagnostic cycle stamps: only in a -DTLSAN_STAMPS=1 build (scripts/stamps.py loads it through TLSAN_LIB_PATH;
@@ -560,9 +579,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #endif
 
   for (int g = blockIdx.x; g < a.ngroups; g += gridDim.x) {
-    if constexpr (FLAT) {
-      if (g != blockIdx.x) __syncthreads();   // (the partial states of P1 lie over sT, which the previous pass read to its end)
-    }
+    // later passes of a workgroup: the previous pass's closing reduction reads EVERY wavefront's scratch (sT) -- a wavefront
+    // that ran ahead into this pass would write its own (sPerm, the window's keys; FLAT: the partial states of P1)
+    if (g != blockIdx.x) __syncthreads();
     TLSAN_STAMP(0);
 #if TLSAN_STAMPS
     if (a.stamps != nullptr && lane == 0) sStamp[28] = __builtin_amdgcn_s_memrealtime();   // (100 MHz, one clock for the whole device)
@@ -681,13 +700,24 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     // session ids (and their categories) are fetched once, one per lane of the sample
     // (lane k = q*CPS + col holds entry k of the current chunk of NL entries), then broadcast
     // with a cross-lane read: no dependent index loads inside the position loops.
-    constexpr int NL = 4 * CPS;
+    constexpr int NL = LKEY ? NLK : 4 * CPS;   // (LKEY: lanes kk >= NL hold clamped copies and neither file keys nor draw cursors)
     const int kk = q * CPS + col;
     int sid = 0, scat = 0;
+    int* sSKi = sSK + wave * (2 * SPW * NLK);   // LKEY: this wavefront's [SPW][NLK] ids, then [SPW][NLK] categories
+    int* sSKc = sSKi + SPW * NLK;
+    auto file_chunk = [&]() {                   // (DS operations of a wavefront execute in order: the fences only bind the compiler)
+      wave_lds_fence();
+      if (kk < NL) {
+        sSKi[s_loc * NLK + kk] = sid;
+        sSKc[s_loc * NLK + kk] = scat;
+      }
+      wave_lds_fence();
+    };
     auto load_chunk = [&](int base) {
       const int t = min(base + kk, max(Sn - 1, 0));
       sid = (Sn > 0) ? a.b.hist_i_new[(size_t)bb * Sn + t] : 0;
       scat = a.p.item_cate[sid];
+      if constexpr (LKEY) file_chunk();
     };
     // row of session entry t0 + dt of the wavefront's sample s_sel (n_sel entries; its chunk must be loaded): normally
     // the lane's own sample and dt = 0; while one half of the lanes helps with a long session (HELP, see P3) both halves
@@ -702,6 +732,13 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     };
     auto fetch_row_of = [&](int t0, int dt, bool two, RowPF& o, int s_sel, int n_sel) {
       const int k = t0 % NL;
+      if constexpr (LKEY) {   // the key of the lane's half of the row: one LDS read at a per-lane address, one multiply-add
+        const int kx = two ? min(k + dt, NL - 1) : k;
+        const int key = ((g_item ? sSKi : sSKc) + s_sel * NLK)[kx];
+        o.v = t0 + dt < n_sel;
+        o.r[0] = tbl_ld4_raw<DT>(g_base, g_idx(key, g_ld, g_off));
+        return;
+      }
       int it = sample_pick<CPS>(sid, k / CPS, k % CPS, s_sel), ct = sample_pick<CPS>(scat, k / CPS, k % CPS, s_sel);
       if (two) {
         const int k1 = min(k + 1, NL - 1);
@@ -736,9 +773,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       opd FT1[NB][NB], FT2[NB][NB];
       f32x4 b1[NB], b2[NB];
       LD_T(w1W1, FT1);
-      LD_T(w1W2, FT2);
+      LD_T2(w1W2, FT2);
       load_bias<DH, NB>(w1b1, LD_Q, b1);
-      load_bias<DH, NB>(w1b2, LD_Q, b2);
+      LD_B2(w1b2, b2);
       if constexpr (TRAIN) {
         posv[LS] = (lead && vs) ? atomicAdd(&a.cur_item[it_i], 1) : 0;
         cposv = (lead && vs && CSEG) ? atomicAdd(&a.cur_uc[ct_i], 1) : 0;
@@ -827,7 +864,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             const float mx0 = fresh ? TLSAN_NEG : smx[kb][i], Z0 = fresh ? 0.0f : sZ[kb][i], N0 = fresh ? 0.0f : sN[kb][i];
             const float m2m = v ? m2[kb][i] : TLSAN_NEG;
             const float mn = fmaxf(mx0, m2m);
-            const float so = __expf(mx0 - mn), ev = __expf(m2m - mn) * mk;
+            const float so = exp2s(mx0 - mn), ev = exp2s(m2m - mn) * mk;
             sZ[kb][i] = Z0 * so + ev;
             sN[kb][i] = N0 * so + ev * xv[kb][i];
             smx[kb][i] = mn;
@@ -936,7 +973,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const float mn = fmaxf(mx1[kb][i], pm[i]);
-            const float sa = __expf(mx1[kb][i] - mn), sb = __expf(pm[i] - mn);
+            const float sa = exp2s(mx1[kb][i] - mn), sb = exp2s(pm[i] - mn);
             mx1[kb][i] = in ? mn : mx1[kb][i];
             Zl[kb][i] = in ? Zl[kb][i] * sa + pZ[i] * sb : Zl[kb][i];
             long4[kb][i] = in ? long4[kb][i] * sa + pN[i] * sb : long4[kb][i];
@@ -974,7 +1011,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
               if (p < n_l) {
                 const f32x4 raw = *(const f32x4*)pa;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) w[i] = __expf(raw[i] - mx1[kb][i]) * iz1[kb][i];
+                for (int i = 0; i < 4; ++i) w[i] = exp2s(raw[i] - mx1[kb][i]) * iz1[kb][i];
               }
               *(f32x4*)pa = w;
             }
@@ -987,9 +1024,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       opd FT1[NB][NB], FT2[NB][NB];
       f32x4 b1[NB], b2[NB], Zl[NB];
       LD_T(w1W1, FT1);
-      LD_T(w1W2, FT2);
+      LD_T2(w1W2, FT2);
       load_bias<DH, NB>(w1b1, LD_Q, b1);
-      load_bias<DH, NB>(w1b2, LD_Q, b2);
+      LD_B2(w1b2, b2);
       if constexpr (TRAIN) {
         posv[LS] = (lead && vs) ? atomicAdd(&a.cur_item[it_i], 1) : 0;
         cposv = (lead && vs && CSEG) ? atomicAdd(&a.cur_uc[ct_i], 1) : 0;
@@ -1110,11 +1147,36 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       idk_w = id_k;
       ctk_w = ct_k;
+      if constexpr (LKEY) {
+        // The window's keys reach the sample's lanes through the LDS: lane k files (id, category) of entry k in the wave's
+        // own scratch (free until P3), every lane reads back the ten keys of ITS half of the row -- item ids for the
+        // lanes whose channels lie in item_emb, categories for the others -- as three 16-byte broadcast reads, and a
+        // row address is one multiply-add on per-lane constants.  (v_readlane + select per key and lane, sample_pick,
+        // were 5 vector instructions per pick, 20 picks, plus the table select per gather: ~250 of the kernel's 3 100.)
+        int* sKI = (int*)T + 32;            // [SPW][16] item ids      (T[0, 32): sPerm, read for the last time above)
+        int* sKC = sKI + SPW * 16;          // [SPW][16] categories
+        if (kku < 16) {
+          sKI[s_loc * 16 + kku] = id_k;
+          sKC[s_loc * 16 + kku] = ct_k;
+        }
+        file_chunk();   // (the first chunk of session keys with them)
+        const int* ksrc = (g_item ? sKI : sKC) + s_loc * 16;
+        int keyv[12];
+#pragma unroll
+        for (int k4 = 0; k4 < 3; ++k4) {
+          const int4 kq = *(const int4*)(ksrc + 4 * k4);
+          keyv[4 * k4] = kq.x; keyv[4 * k4 + 1] = kq.y; keyv[4 * k4 + 2] = kq.z; keyv[4 * k4 + 3] = kq.w;
+        }
+        static_assert(LS <= 12, "three 16-byte reads cover the window's keys");
+#pragma unroll
+        for (int p = 0; p < LS; ++p) e1[p][0] = tbl_ld4<DT>(g_base, g_idx(keyv[p], g_ld, g_off));
+      } else {
 #pragma unroll
       for (int p = 0; p < LS; ++p) {
         const int it = sample_pick<CPS>(id_k, p / CPS, p % CPS, s_loc), ct = sample_pick<CPS>(ct_k, p / CPS, p % CPS, s_loc);
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) e1[p][kb] = gather_item4c<DT>(a, it, ct, chb[kb]);
+      }
       }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (TRAIN) {
@@ -1129,19 +1191,28 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       // padded slots: scale 0 (model.py:384 gives them weight exactly 0; their clamped rows are finite table rows),
       // so no select on the rows themselves -- the forward can start on position 0 while later rows are in flight
       const float uth_k = (kku < n_l) ? ut_k * ht_k : 0.0f;
-      if (TRAIN && kku < LS) {   // lane k files its own entry: hist_t and usert * hist_t of the pass (0 on padded slots)
+      if ((TRAIN || LKEY) && kku < LS) {   // lane k files its own entry: hist_t and usert * hist_t of the pass (0 on padded slots)
         sH[srow * 2 * LSC + kku] = (kku < n_l) ? ht_k : 0.0f;
         sH[srow * 2 * LSC + LSC + kku] = uth_k;
       }
+      if constexpr (LKEY) {   // usert * hist_t of the sample's positions: read back from sH (filed above by lane k), three 16-byte reads
+        wave_lds_fence();
+        static_assert(LSC == 10, "usert * hist_t occupies floats 10 .. 19 of a sample's sH row");
+        const f32x4 u2 = *(const f32x4*)(sH + srow * 2 * LSC + 8), u3 = *(const f32x4*)(sH + srow * 2 * LSC + 12), u4 = *(const f32x4*)(sH + srow * 2 * LSC + 16);
+        const float uthv[10] = {u2[2], u2[3], u3[0], u3[1], u3[2], u3[3], u4[0], u4[1], u4[2], u4[3]};
+#pragma unroll
+        for (int p = 0; p < LS; ++p) sc1[p] = (gamma * P * P) * uthv[p];
+      } else {
 #pragma unroll
       for (int p = 0; p < LS; ++p) sc1[p] = (gamma * P * P) * sample_pick<CPS>(uth_k, p / CPS, p % CPS, s_loc);  // model.py:100-102,109
+      }
       TLSAN_STAMP(21);
       opd FT1[NB][NB], FT2[NB][NB];
       f32x4 b1[NB], b2[NB];
       LD_T(w1W1, FT1);
-      LD_T(w1W2, FT2);
+      LD_T2(w1W2, FT2);
       load_bias<DH, NB>(w1b1, LD_Q, b1);
-      load_bias<DH, NB>(w1b2, LD_Q, b2);
+      LD_B2(w1b2, b2);
       TLSAN_STAMP(22);
       f32x4 att_r[TRAIN ? 1 : LS][NB];
       fwa_forward<NB, LS, DROP, MM>(FT1, b1, FT2, b2, e1, sc1, n_l, pmax1, mx1, iz1, long4, KEEP_A ? sAw : nullptr, dc, 0, chb,
@@ -1183,7 +1254,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         const size_t ui = usr ? (size_t)uid_t * a.p.ld_user + c : (size_t)ucat_t * a.dc + (c - a.di);
         uemb[kb] = tbl_ld4<DT>(ub, ui) * P;
       }
-      iemb[kb] = gather_item4c<DT>(a, it_t, ct_t, c) * P;
+      if constexpr (LKEY) iemb[kb] = tbl_ld4<DT>(g_base, g_idx(g_item ? it_t : ct_t, g_ld, g_off)) * P;
+      else iemb[kb] = gather_item4c<DT>(a, it_t, ct_t, c) * P;
     }
     const float ib_i = a.p.item_b[(size_t)it_t * a.p.ld_itemb];
     if constexpr (!LSTREAM) {   // the first session row as well (ids and categories came with the window's): it is in flight over barrier 1 and P2
@@ -1241,9 +1313,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     opd FT1[NB][NB], FT2[NB][NB];
     f32x4 b1[NB], b2[NB];
     LD_T(w2W1, FT1);
-    LD_T(w2W2, FT2);
+    LD_T2(w2W2, FT2);
     load_bias<DH, NB>(w2b1, LD_Q, b1);
-    load_bias<DH, NB>(w2b2, LD_Q, b2);
+    LD_B2(w2b2, b2);
     TLSAN_STAMP(3);
     __syncthreads();
     TLSAN_STAMP(4);
@@ -1268,8 +1340,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     }
     if constexpr (LSTREAM) load_chunk(0);
     if constexpr (TRAIN) {
-      spos0 = (vs && kk < n_s) ? atomicAdd(&a.cur_item[sid], 1) : 0;
-      if constexpr (CSEG) scpos0 = (vs && kk < n_s) ? atomicAdd(&a.cur_uc[scat], 1) : 0;
+      spos0 = (vs && kk < n_s && kk < NL) ? atomicAdd(&a.cur_item[sid], 1) : 0;
+      if constexpr (CSEG) scpos0 = (vs && kk < n_s && kk < NL) ? atomicAdd(&a.cur_uc[scat], 1) : 0;
     }
     if constexpr (LSTREAM) { if (pmax2 > 1) fetch_row(0, xnext); }
     TLSAN_STAMP(24);
@@ -1361,8 +1433,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         const int zz = opaque_zero(p);
         LD_T(w2W1 + zz, FT1);
         load_bias<DH, NB>(w2b1 + zz, LD_Q, b1);
-        LD_T(w2W2 + zz, FT2);
-        load_bias<DH, NB>(w2b2 + zz, LD_Q, b2);
+        LD_T2(w2W2 + zz, FT2);
+        LD_B2(w2b2 + zz, b2);
       }
 
       use_row(xnext, xv);
@@ -1400,7 +1472,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const float mn = fmaxf(mx[kb][i], m2[kb][i]);
-            const float so = __expf(mx[kb][i] - mn), ev = __expf(m2[kb][i] - mn);
+            const float so = exp2s(mx[kb][i] - mn), ev = exp2s(m2[kb][i] - mn);
             Zs[kb][i] = Zs[kb][i] * so + ev;
             short4[kb][i] = short4[kb][i] * so + ev * xv[kb][i];
             mx[kb][i] = mn;
@@ -1420,7 +1492,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             const float o_mx = dpp_f32<TLSAN_DPP_ROR(8)>(mx[kb][i]), o_Z = dpp_f32<TLSAN_DPP_ROR(8)>(Zs[kb][i]);
             const float o_N = dpp_f32<TLSAN_DPP_ROR(8)>(short4[kb][i]);
             const float mn = fmaxf(mx[kb][i], o_mx);
-            const float sa = __expf(mx[kb][i] - mn), sb = __expf(o_mx - mn);
+            const float sa = exp2s(mx[kb][i] - mn), sb = exp2s(o_mx - mn);
             mx[kb][i] = helper ? own_mx[i] : mn;
             Zs[kb][i] = helper ? own_Z[i] : Zs[kb][i] * sa + o_Z * sb;
             short4[kb][i] = helper ? own_N[i] : short4[kb][i] * sa + o_N * sb;
@@ -1446,7 +1518,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             if (p <= n_s) {
               const f32x4 raw = *(const f32x4*)pa;
 #pragma unroll
-              for (int i = 0; i < 4; ++i) w[i] = __expf(raw[i] - mx[kb][i]) * Zs[kb][i];
+              for (int i = 0; i < 4; ++i) w[i] = exp2s(raw[i] - mx[kb][i]) * Zs[kb][i];
             }
             *(f32x4*)pa = w;
           }
@@ -1454,11 +1526,11 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       }
     }
     if constexpr (TRAIN) {  // publish the session positions (the atomics are long back by now)
-      if (vs && kk < n_s) sP[srow * PSTR + LSCP + kk] = spos0;
-      if (CSEG && vs && kk < n_s) sPc[srow * PSTR + LSCP + kk] = scpos0;
+      if (vs && kk < n_s && kk < NL) sP[srow * PSTR + LSCP + kk] = spos0;
+      if (CSEG && vs && kk < n_s && kk < NL) sPc[srow * PSTR + LSCP + kk] = scpos0;
       for (int base = NL; base < pmax2 - 1; base += NL) {  // sessions longer than one chunk (rare)
         const int t = base + kk;
-        if (vs && t < n_s) {
+        if (vs && t < n_s && kk < NL) {
           const int sidt = a.b.hist_i_new[(size_t)bb * Sn + t];
           sP[srow * PSTR + LSCP + t] = atomicAdd(&a.cur_item[sidt], 1);
           if constexpr (CSEG) sPc[srow * PSTR + LSCP + t] = atomicAdd(&a.cur_uc[a.p.item_cate[sidt]], 1);
@@ -1556,8 +1628,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             if constexpr (G::AT_USE_T) {
               LD_T(w2W1 + zz, FT1);
               load_bias<DH, NB>(w2b1 + zz, LD_Q, b1);
-              LD_T(w2W2 + zz, FT2);
-              load_bias<DH, NB>(w2b2 + zz, LD_Q, b2);
+              LD_T2(w2W2 + zz, FT2);
+              LD_B2(w2b2 + zz, b2);
             }
             LD_N(w2W1 + zz, FN1);
             LD_N(w2W2 + zz, FN2);
@@ -1612,7 +1684,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
                 const float mxs = oth ? o_mx : mx[kb][i], zss = oth ? o_Z : Zs[kb][i];
                 outs[kb][i] = oth ? o_out : short4[kb][i];
                 douts[kb][i] = oth ? o_do : dout[kb][i];
-                av[kb][i] = vt ? __expf(m2[kb][i] - mxs) * zss : 0.0f;
+                av[kb][i] = vt ? exp2s(m2[kb][i] - mxs) * zss : 0.0f;
               }
           } else {
 #pragma unroll
@@ -1620,7 +1692,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
               outs[kb] = short4[kb];
               douts[kb] = dout[kb];
 #pragma unroll
-              for (int i = 0; i < 4; ++i) av[kb][i] = vt ? __expf(m2[kb][i] - mx[kb][i]) * Zs[kb][i] : 0.0f;
+              for (int i = 0; i < 4; ++i) av[kb][i] = vt ? exp2s(m2[kb][i] - mx[kb][i]) * Zs[kb][i] : 0.0f;
             }
           }
           bwd_compute<NB, TSTR, DROP, MM>(FN2, FN1, xv, z1, av, outs, douts, T, q, r, acc.db1, acc.db2, dx, k1, k2);
@@ -1710,8 +1782,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       opd FN1[NB][NB], FN2[NB][NB];
       LD_T(w1W1, FT1);
       load_bias<DH, NB>(w1b1, LD_Q, b1);
-      LD_T(w1W2, FT2);
-      load_bias<DH, NB>(w1b2, LD_Q, b2);
+      LD_T2(w1W2, FT2);
+      LD_B2(w1b2, b2);
       LD_N(w1W1, FN1);
       LD_N(w1W2, FN2);
       TLSAN_STAMP(8);
@@ -1743,6 +1815,15 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         };
         // a map as two half-chains whose sum is taken a group later (the sum right behind the chain would wait for it)
         auto map_issue = [&](const opd (&F)[NB][NB], const f32x4 (&v)[NB], f32x4 (&h0)[NB], f32x4 (&h1)[NB], const f32x4* bias) {
+          if constexpr (MM == TLSAN_MATRIX_F32 && TLSAN_CHAIN1) {
+#pragma unroll
+            for (int ob = 0; ob < NB; ++ob) {
+              h0[ob] = bias ? TLSAN_MFMA(F[ob][0][0], v[0][0], bias[ob]) : TLSAN_MFMA(F[ob][0][0], v[0][0], (f32x4)(0.0f));
+#pragma unroll
+              for (int s = 1; s < 4; ++s) h0[ob] = TLSAN_MFMA(F[ob][0][s], v[0][s], h0[ob]);
+              h1[ob] = (f32x4)(0.0f);
+            }
+          } else
           if constexpr (MM == TLSAN_MATRIX_F32) {
 #pragma unroll
             for (int ob = 0; ob < NB; ++ob) {
@@ -1833,7 +1914,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
-              for (int i = 0; i < 4; ++i) av[kb][i] = __expf(fminf(m2[kb][i] - mxc[kb][i], 0.0f)) * (izc[kb][i] * mk);
+              for (int i = 0; i < 4; ++i) av[kb][i] = exp2s(fminf(m2[kb][i] - mxc[kb][i], 0.0f)) * (izc[kb][i] * mk);
             bwd_compute<NB, TSTR, false, MM>(FN2, FN1, xv, z1, av, loc, dl, T, q, r, acc.db1, acc.db2, dx);
             bwd_dw<NB, TSTR, MM>(T, q, r, acc.dW1, acc.dW2);
             float dsp = 0.0f;
@@ -1992,7 +2073,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             for (int kb = 0; kb < NB; ++kb) {
 #pragma unroll
               for (int i = 0; i < 4; ++i)   // (m2 <= max on valid entries: the clamp changes nothing there; no branch around the exponentials)
-                avF[kb][i] = __expf(fminf((ha[kb][i] + hb[kb][i]) - mxf[kb][i], 0.0f)) * (izf[kb][i] * mkF);
+                avF[kb][i] = exp2s(fminf((ha[kb][i] + hb[kb][i]) - mxf[kb][i], 0.0f)) * (izf[kb][i] * mkF);
               *(f32x4*)(T + (0 * NB + kb) * 16 * TSTR + wofs) = xvB[kb];  // entry k - 1's tiles (behind the reads above: in-order DS)
               *(f32x4*)(T + (1 * NB + kb) * 16 * TSTR + wofs) = dz1[kb];
               *(f32x4*)(T + (2 * NB + kb) * 16 * TSTR + wofs) = m1[kb];
@@ -2111,7 +2192,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
               for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                  av[kb][i] = vp ? __expf(m2[kb][i] - mx1[kb][i]) * iz1[kb][i] : 0.0f;
+                  av[kb][i] = vp ? exp2s(m2[kb][i] - mx1[kb][i]) * iz1[kb][i] : 0.0f;
               bwd_compute<NB, TSTR, DROP, MM>(FN2, FN1, xv, z1, av, long4, dlong, T, q, r, acc.db1, acc.db2, dx, k1, k2);
               bwd_dw<NB, TSTR, MM>(T, q, r, acc.dW1, acc.dW2);
               float dsp = 0.0f;
@@ -2292,8 +2373,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             if constexpr (G::AT_USE_T) {
               LD_T(w1W1 + zz, FT1);
               load_bias<DH, NB>(w1b1 + zz, LD_Q, b1);
-              LD_T(w1W2 + zz, FT2);
-              load_bias<DH, NB>(w1b2 + zz, LD_Q, b2);
+              LD_T2(w1W2 + zz, FT2);
+              LD_B2(w1b2 + zz, b2);
             }
             LD_N(w1W1 + zz, FN1);
             LD_N(w1W2 + zz, FN2);
@@ -2340,7 +2421,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
               for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                  av[kb][i] = vp ? __expf(m2[kb][i] - mx1[kb][i]) * iz1[kb][i] : 0.0f;
+                  av[kb][i] = vp ? exp2s(m2[kb][i] - mx1[kb][i]) * iz1[kb][i] : 0.0f;
             }
             if (p == 1) TLSAN_STAMP(13);
             bwd_compute<NB, TSTR, DROP, MM>(FN2, FN1, xv, z1, av, long4, dlong, T, q, r, acc.db1, acc.db2, dx, k1, k2);

@@ -63,6 +63,14 @@ __device__ __forceinline__ f32x4 mm_mma(typename MMT<MM>::opd a, typename MMT<MM
   }
 }
 #define TLSAN_NEG (-1e30f)  // VERY_NEGATIVE_NUMBER, reference TLSAN/model.py:10-11
+// The attention scores m2 = relu(x W1 + b1) W2 + b2 (model.py:380-382) are only ever used as exponents of the softmax over
+// positions (model.py:386).  The kernels keep them in units of log 2: the FORWARD fragments of W2 and b2 are multiplied by
+// log2(e) where they are loaded (load_frag_T / load_bias with scl; the fragment-order LDS tables hold them scaled), every
+// exponential of a score difference is then one v_exp_f32 (exp2s) instead of v_mul + v_exp, and the mask constant and
+// the running maxima live in the same units.  The backward never differentiates through the scaled copy: dm2 is formed
+// from the softmax weights, and dm1 = dm2 W2^T, dW2 = m1^T dm2 use the unscaled W2.
+#define TLSAN_LOG2E 1.44269504088896340736f
+__device__ __forceinline__ float exp2s(float x) { return __builtin_amdgcn_exp2f(x); }
 
 #define TLSAN_LS_MAX 10  // long-term windows up to this size stay in registers (reference default Ls = 10)
 #define TLSAN_LS_CAP 96  // larger windows (up to the reference's max_length = 90) are streamed
@@ -230,14 +238,14 @@ __device__ __forceinline__ float weff(const float* __restrict__ W, int k, int j)
 //   F[jb][kb][s] on lane (q, m=r)  = W_eff[16kb + 4q + s][16jb + r]
 template <int DH, int NB, int MM = TLSAN_MATRIX_F32>
 __device__ __forceinline__ void load_frag_T(const float* __restrict__ W, int q, int r,
-                                            typename MMT<MM>::opd (&F)[NB][NB]) {
+                                            typename MMT<MM>::opd (&F)[NB][NB], float scl = 1.0f) {
 #pragma unroll
   for (int jb = 0; jb < NB; ++jb)
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
       f32x4 t;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) t[s] = weff<DH>(W, 16 * kb + 4 * q + s, 16 * jb + r);
+      for (int s = 0; s < 4; ++s) t[s] = weff<DH>(W, 16 * kb + 4 * q + s, 16 * jb + r) * scl;
       F[jb][kb] = mm_pack<MM>(t);
     }
 }
@@ -271,11 +279,11 @@ __device__ __forceinline__ void load_frag_P(const float* __restrict__ tab, int l
 
 // bias in C-layout: lane (q, .) reg i of block jb  <->  channel-in-column 16jb + 4q + i
 template <int DH, int NB>
-__device__ __forceinline__ void load_bias(const float* __restrict__ b, int q, f32x4 (&out)[NB]) {
+__device__ __forceinline__ void load_bias(const float* __restrict__ b, int q, f32x4 (&out)[NB], float scl = 1.0f) {
 #pragma unroll
   for (int jb = 0; jb < NB; ++jb)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) out[jb][i] = b[(16 * jb + 4 * q + i) % DH];
+    for (int i = 0; i < 4; ++i) out[jb][i] = b[(16 * jb + 4 * q + i) % DH] * scl;
 }
 
 // out = bias + F (x) v  in C-layout (see header comment).  Two accumulators per output block
@@ -284,6 +292,20 @@ __device__ __forceinline__ void load_bias(const float* __restrict__ b, int q, f3
 template <int NB, int MM = TLSAN_MATRIX_F32>
 __device__ __forceinline__ void map_apply(const typename MMT<MM>::opd (&F)[NB][NB], const f32x4 (&bias)[NB],
                                           const f32x4 (&v)[NB], f32x4 (&out)[NB]) {
+#ifndef TLSAN_CHAIN1
+#define TLSAN_CHAIN1 0
+#endif
+  if constexpr (MM == TLSAN_MATRIX_F32 && TLSAN_CHAIN1) {
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob) {
+      f32x4 acc = bias[ob];
+#pragma unroll
+      for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = TLSAN_MFMA(F[ob][ib][s], v[ib][s], acc);
+      out[ob] = acc;
+    }
+  } else
   if constexpr (MM == TLSAN_MATRIX_F32) {
 #pragma unroll
     for (int ob = 0; ob < NB; ++ob) {

@@ -74,8 +74,11 @@ class ModPartition:
 
 
 # the announced batches' plans are issued by a launch thread of the library (tlsan_shard_step_static, TLSAN_PLAN_ASYNC);
-# TLSAN_PLAN_THREAD=0 keeps them on the calling thread (an escape hatch: the thread has only ever run on one-GPU boxes)
-_PLAN_THREAD = os.environ.get("TLSAN_PLAN_THREAD", "1") != "0"
+# TLSAN_PLAN_THREAD=0 keeps them on the calling thread.  The thread has only ever run on one-GPU boxes, so it is the default
+# at ONE rank only (where the step is bound by its host thread: 93.6 -> 83.9 us); over several ranks it is opt-in
+# (TLSAN_PLAN_THREAD=1) until a node has exercised it -- there the exchanges, not the host, bound the step.
+_PLAN_THREAD_ENV = os.environ.get("TLSAN_PLAN_THREAD")
+_PLAN_THREAD = _PLAN_THREAD_ENV != "0"
 
 
 def _staged(group):
@@ -1095,7 +1098,12 @@ class ShardedModel:
         st["next"] = (k + 1) % NS
         ahead = [(self.device_batch(b), (k + 1 + j) % NS) for j, b in enumerate((next_batch, after_next)) if b is not None]
         ahead = [(b, kk) for b, kk in ahead if not (st["slots"][kk]["db"] is b and st["slots"][kk]["fresh"])]
-        use_flag = bool(ahead) and not capturing       # (see tlsan_shard_step_static: no event on the main stream)
+        # EVERY eager step stamps the pinned word when its fused kernel starts (not only the steps that announce a batch:
+        # a plan waits for "step t - 1 has started", which only names step t - 1 if that step carried a stamp -- ADVICE r4).
+        # The word paces a plan only when the step before this one was such a stamped eager step; behind a graph replay, a
+        # capture or the first step of a model the plans are ordered by an event on the main stream instead.
+        stamp = not capturing
+        use_flag = bool(ahead) and stamp and st.get("prev_stamped", False)     # (see tlsan_shard_step_static: no event on the main stream)
         if ahead and not use_flag:
             st["fork"].record(main)      # everything before this step: the slots the new plans go to are free from here
 
@@ -1124,24 +1132,24 @@ class ShardedModel:
 
         def run(phases, with_plans=False):
             # (plans: issued by the library's launch thread while this one goes on with the main stream -- not under capture)
-            if with_plans and plans and use_flag and _PLAN_THREAD:
+            if with_plans and plans and use_flag and _PLAN_THREAD and (G == 1 or _PLAN_THREAD_ENV == "1"):
                 phases |= L.PLAN_ASYNC
             L.check(self.lib.tlsan_shard_step_static(C.byref(ss), phases, parr if with_plans else None,
                                                      len(plans) if with_plans else 0, sp), "tlsan_shard_step_static")
 
-        if use_flag:      # the fused kernel stores the step's number into a pinned word when it begins to run
-            st["start_seq"] = (st["start_seq"] + 1) & 0x7FFFFFFF
+        if stamp:         # the fused kernel stores the step's number into a pinned word when it begins to run
+            st["start_seq"] = (st["start_seq"] + 1) & 0xFFFFFFFF       # (the full 32 bits: the library compares (int32)(word - after))
             ss.out.started, ss.out.started_value = st["started"].data_ptr(), st["start_seq"]
             # the announced batches' plans go to slots that steps t - 2 and t - 3 were the last to use: "step t - 1 has
             # started" is all they wait for -- long true when this step is queued, so the host does not block
-            ss.plans_after = (st["start_seq"] - 1) & 0x7FFFFFFF
+            ss.plans_after = (st["start_seq"] - 1) & 0xFFFFFFFF
         else:
             ss.out.started, ss.out.started_value = None, 0
 
         def plan_late():
             if use_flag:
-                word, want, t0, polls = st["started_word"], (st["start_seq"] - 1) & 0x7FFFFFFF, None, 0
-                while ((word.value - want) & 0x7FFFFFFF) >= 0x40000000:     # (not yet reached; the numbers wrap at 2^31)
+                word, want, t0, polls = st["started_word"], (st["start_seq"] - 1) & 0xFFFFFFFF, None, 0
+                while ((word.value - want) & 0xFFFFFFFF) >= 0x80000000:     # (not yet reached: the library's (int32)(word - after) < 0)
                     polls += 1
                     if polls & 255:
                         continue
@@ -1191,6 +1199,7 @@ class ShardedModel:
             for b, kk in ahead:
                 st["slots"][kk]["pending"] = False
         self._step += 1
+        st["prev_stamped"] = stamp          # (a recorded step never stamps: the step behind a capture or replay takes the event path)
         if not capturing:
             st["warm"] = True
             if self.renorm_every and self._step % self.renorm_every == 0:
@@ -1259,6 +1268,7 @@ class ShardedModel:
         st["slots"][k1]["fresh"] = True
         st["slots"][k1]["pending"] = False
         st["next"] = k1
+        st["prev_stamped"] = False      # (a recorded step carries no stamp: the next eager step orders its plans by an event)
         self._step += 1
 
     def _lazy_stamp(self):
