@@ -74,9 +74,12 @@ def test_c3_electronics_one_step_matches_oracle(table_dtype):
         for k in newp:
             a, r = np.asarray(got[k], np.float64).reshape(p[k].shape), newp[k]
             if table_dtype == "bf16" and k in bf:
-                ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(r), 1e-30))) - 7)
+                # (the ulp of the larger of the two: an element next to a power of two, or one that the second rounding of the
+                #  lazy read -- the table scale folded in -- carries across one, has neighbours in two binades)
+                ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.maximum(np.abs(r), np.abs(a)), 1e-30))) - 7)
                 nround = 2 if l2 == "lazy" else 1     # (lazy: reading the parameters folds the table scale in, a second rounding)
-                assert (np.abs(a - r) <= ulp * (nround + 1e-3) + 1e-12).all(), (l2, k)
+                dev = np.abs(a - r) / ulp
+                assert dev.max() <= nround + 1e-3, (l2, k, dev.max())
                 assert abs(((a - r) / ulp).mean()) < 0.02, (l2, k)       # unbiased
             else:
                 du, dr = a - p[k], r - p[k]

@@ -15,7 +15,12 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libtlsan_hip.so")
 SOURCES = ["tlsan_api.hip", "tlsan_attn_d64.hip", "tlsan_attn_d128.hip", "tlsan_attn_d128w4.hip", "tlsan_attn_d256.hip", "tlsan_attn_d256s.hip"]
 # per-source extra flags (see the source's header comment)
-SOURCE_FLAGS = {"tlsan_attn_d256.hip": ["-mllvm", "-sink-insts-to-avoid-spills"],
+# -fno-honor-nans on the d <= 128 units: fmaxf on an MFMA result otherwise gets a canonicalising v_max x, x, x in front of it
+# (cdna_hip_programming.md, pitfalls): 78 vector instructions of the bf16-operand kernel, 18 of the fp32 one; same results on
+# finite data (round 5 A/B, profiles/r05_isa_budget.md)
+_NONAN = ["-fno-honor-nans"]
+SOURCE_FLAGS = {"tlsan_attn_d64.hip": _NONAN, "tlsan_attn_d128.hip": _NONAN, "tlsan_attn_d128w4.hip": _NONAN,
+                "tlsan_attn_d256.hip": ["-mllvm", "-sink-insts-to-avoid-spills"],
                 "tlsan_attn_d256s.hip": ["-mllvm", "-disable-machine-licm", "-mllvm", "-sink-insts-to-avoid-spills"]}
 if os.environ.get("TLSAN_SOURCE_FLAGS"):   # (experiments: JSON {source: [flags]}, replaces the entries it names)
     import json

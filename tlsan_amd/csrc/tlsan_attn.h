@@ -415,10 +415,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   // per-sample position slots: long, session (the batch's padded session length, rounded up to 4), 3 singles
   // (CSEG keeps two such arrays and sizes them by the batch; otherwise the slot count is a compile-time constant)
 
-#ifndef TLSAN_LKEY
-#define TLSAN_LKEY 1
-#endif
-  constexpr bool LKEY = TLSAN_LKEY && NB == 1 && !LSTREAM;   // row keys reach a sample's lanes through the LDS (see g_item below, P1, fetch_row_of)
+  constexpr bool LKEY = NB == 1 && !LSTREAM;   // row keys reach a sample's lanes through the LDS (see g_item below, P1, fetch_row_of)
   constexpr int NLK = 16;                                    // session entries per chunk of keys
   const bool FUSE_RT = a.fuse_dk != 0;   // (this launch forms the dK partials itself; as a compile-time constant: -0.2 us/step, not worth a variant)
   // FLAT (streamed windows): the window positions of the workgroup's 16 samples form ONE list that is dealt out evenly
@@ -513,6 +510,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     // (tlsan_step_out.started: this kernel running means everything queued before the step is complete)
     if (a.started != nullptr && blockIdx.x == 0 && tid == 0)
       __hip_atomic_store(a.started, a.started_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (a.tail_epoch != nullptr && blockIdx.x == 0 && tid == 64) *a.tail_epoch += 1u;   // (the row-sum launch behind this kernel hands over under a new epoch)
   }
   const float* dn = a.p.dense;
   const float gamma = dn[a.lay.gamma];
@@ -1815,15 +1813,6 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         };
         // a map as two half-chains whose sum is taken a group later (the sum right behind the chain would wait for it)
         auto map_issue = [&](const opd (&F)[NB][NB], const f32x4 (&v)[NB], f32x4 (&h0)[NB], f32x4 (&h1)[NB], const f32x4* bias) {
-          if constexpr (MM == TLSAN_MATRIX_F32 && TLSAN_CHAIN1) {
-#pragma unroll
-            for (int ob = 0; ob < NB; ++ob) {
-              h0[ob] = bias ? TLSAN_MFMA(F[ob][0][0], v[0][0], bias[ob]) : TLSAN_MFMA(F[ob][0][0], v[0][0], (f32x4)(0.0f));
-#pragma unroll
-              for (int s = 1; s < 4; ++s) h0[ob] = TLSAN_MFMA(F[ob][0][s], v[0][s], h0[ob]);
-              h1[ob] = (f32x4)(0.0f);
-            }
-          } else
           if constexpr (MM == TLSAN_MATRIX_F32) {
 #pragma unroll
             for (int ob = 0; ob < NB; ++ob) {

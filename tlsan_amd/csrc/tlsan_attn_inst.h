@@ -9,10 +9,6 @@ struct LaunchEvents { hipEvent_t start, stop; };   // optional time stamps of th
 #ifndef TLSAN_STAMPS
 #define TLSAN_STAMPS 0
 #endif
-#ifndef TLSAN_LKEY
-#define TLSAN_LKEY 1
-#endif
-#define TLSAN_LKEY_ON TLSAN_LKEY
 
 // (mirrors the carve-up at the top of k_fwd_bwd; flat = the FLAT variant of the streamed windows, tlsan_attn.h)
 template <int D, int DH, int NWV = 0>
@@ -23,7 +19,7 @@ static size_t fwd_smem_bytes(bool train, bool lstream, bool fuse_dk, int Sn, boo
   const int lsc = lstream ? TLSAN_LS_CAP : TLSAN_LS_MAX;
   const int pstr = (flat ? 0 : lsc) + ((cseg || flatg || G::NSB < 16) ? ((Sn + 3) & ~3) : TLSAN_SN_CAP) + 4;      // position slots per sample (k_fwd_bwd: PSTR), twice with CSEG
   const int nf = flat ? G::NSB * TLSAN_LS_CAP : 0;
-  return sizeof(float) * ((train ? G::NSB * pstr * (cseg ? 2 : 1) : 0) + 2 * G::NSB * G::LSTR + ((train && ((G::FUSE_DK && fuse_dk) || (flat && !flatg))) ? G::NSB * G::LSTR : 0) + G::NW * 4 + ((TLSAN_LKEY_ON && G::NB == 1 && !lstream) ? G::NW * 2 * G::SPW * 16 : 0) /* LKEY: session keys (sSK) */ + G::NSB * 2 * lsc +
+  return sizeof(float) * ((train ? G::NSB * pstr * (cseg ? 2 : 1) : 0) + 2 * G::NSB * G::LSTR + ((train && ((G::FUSE_DK && fuse_dk) || (flat && !flatg))) ? G::NSB * G::LSTR : 0) + G::NW * 4 + ((G::NB == 1 && !lstream) ? G::NW * 2 * G::SPW * 16 : 0) /* LKEY: session keys (sSK) */ + G::NSB * 2 * lsc +
                           ((G::USE_SW && !flatg) ? ((G::NB > 1 && !lstream) ? 2 * (4 * G::NB * G::NB * 256 + 2 * DH) : 2 * (2 * DH * DH + 2 * DH)) : 0) + G::NW * G::WSCR +
                           ((G::KEEP_A && train && !lstream) ? G::NW * TLSAN_LS_MAX * G::NB * 256 : 0) +
                           nf * (3 + (train ? 1 : 0) + ((train && cseg) ? 1 : 0)) + ((flat && !flatg && train) ? 2 * G::NSB * G::LSTR : 0) + (flatg ? G::NSB : 0) +
