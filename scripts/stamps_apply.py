@@ -60,21 +60,12 @@ r0 = s[s[:, 4] > 0, 4].min()
 print("timeline (us after the first workgroup start; 100 MHz s_memrealtime): kernel span %.2f us" % ((s[:, 5].max() - r0) / 100))
 for nm, lo, hi in [("cate", 0, C), ("item", C, C + nbI), ("user", C + nbI, C + nbI + nbU), ("dense/fin", C + nbI + nbU, n)]:
     x = s[lo:hi]
-    x = x[(x[:, 4] > 0) & (x[:, 7] == 0)]      # ([7] > 0: an update block of the fused form, listed below)
+    x = x[x[:, 4] > 0]
     if len(x):
         st, en = (x[:, 4] - r0) / 100, (x[:, 5] - r0) / 100
         print("  %-9s start p0/10/50/90/100 %s | end p50/90/100 %s | dur p50 %.2f" % (
             nm, " ".join("%5.2f" % v for v in np.percentile(st, [0, 10, 50, 90, 100])),
             " ".join("%5.2f" % v for v in np.percentile(en, [50, 90, 100])), np.median(en - st)))
-# the fused form (k_finalize_presum<..., FUSE>): the trailing update blocks stamp [4] placed, [7] past the wait, [5] done
-upd = s[s[:, 7] > 0]
-if len(upd):
-    pl, pw, en = (upd[:, 4] - r0) / 100, (upd[:, 7] - r0) / 100, (upd[:, 5] - r0) / 100
-    pc = lambda v: " ".join("%5.2f" % q for q in np.percentile(v, [0, 10, 50, 90, 100]))
-    print("  update    placed p0/10/50/90/100 %s | past the wait %s | end %s | work p50 %.2f" % (pc(pl), pc(pw), pc(en), np.median(en - pw)))
-    s = s.copy(); s[s[:, 7] > 0, 4] = 0          # (not part of the residency count below as row-sum blocks)
-    ust, uen = pl, en
-    print("  update blocks resident at t (us): " + "  ".join("%.1f:%d" % (t, int(((ust <= t) & (uen > t)).sum())) for t in np.arange(0.5, uen.max(), 1.0)))
 # how many workgroups run at once (the launch's residency): running blocks sampled every 0.5 us
 x = s[s[:, 4] > 0]
 st, en = (x[:, 4] - r0) / 100, (x[:, 5] - r0) / 100

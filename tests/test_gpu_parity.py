@@ -1188,47 +1188,3 @@ def test_d128_parity_in_both_workgroup_geometries(nw4):
                        cwd=root, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
-
-_TAIL_DIGEST = r'''
-import hashlib, sys
-import numpy as np
-sys.path.insert(0, %r)
-from tests.helpers import make_config, random_batch, random_params
-from tlsan_amd.model import Model
-h = hashlib.sha256()
-for d, Ls, U, I, C, B, td in ((128, 10, 900, 1500, 40, 700, "f32"), (64, 10, 300, 400, 9, 257, "f32"), (128, 10, 500, 800, 33, 300, "bf16"),
-                              (256, 10, 200, 300, 17, 130, "f32"), (128, 33, 300, 500, 21, 150, "f32")):
-    cfg = make_config(U=U, I=I, C=C, d=d, Ls=Ls, regulation_rate=1e-3)
-    p = {k: np.asarray(v, np.float32) for k, v in random_params(cfg, seed=13).items()}
-    _, cat = random_batch(cfg, B=8, Sn=3, seed=0)
-    m = Model(cfg, cat, l2_mode="lazy", table_dtype=td)
-    m.set_params(p)
-    bs = [random_batch(cfg, B=B, Sn=1 + s, seed=60 + s)[0] for s in range(4)]
-    tup = lambda b: (b["u"], b["i"], b["y"], b["hist_i"], b["hist_i_new"], b["hist_t"], b["sl"], b["sl_new"], b["u_cate"])
-    dbs = [m.device_batch(tup(b)) for b in bs]
-    for s in range(len(dbs)):
-        m.train_async(dbs[s], 0.7, next_batch=dbs[s + 1] if s + 1 < len(dbs) else None, after_next=dbs[s + 2] if s + 2 < len(dbs) else None)
-    h.update(np.float32(m._out[0].item()).tobytes())
-    assert m.tail_timeouts() == 0
-    got = m.get_params()
-    for k in sorted(got):
-        h.update(np.ascontiguousarray(got[k]).tobytes())
-print("DIGEST", h.hexdigest())
-'''
-
-
-def test_update_as_trailing_blocks_of_the_row_sum_launch():
-    """The lazy SGD step's update runs as trailing blocks of the row-sum launch (k_finalize_presum<..., FUSE>: they wait
-    for every block in front of them on arrival counters in the state) -- the same arithmetic per element as the
-    k_update_lazy launch it replaces (TLSAN_TAIL_FUSE=0, read once per process): four announced steps on five shapes
-    (fp32 / bf16 tables, d = 64 / 128 / 256, a streamed window) must leave the same losses and the same parameters bit
-    for bit either way, and no update block may ever have given up waiting (StateHdr::tail_timeout)."""
-    import subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    digests = {}
-    for fuse in ("1", "0"):
-        env = dict(os.environ, TLSAN_TAIL_FUSE=fuse)
-        r = subprocess.run([sys.executable, "-c", _TAIL_DIGEST % root], cwd=root, env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        digests[fuse] = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1]
-    assert digests["1"] == digests["0"], digests

@@ -121,13 +121,6 @@ static int cseg_min_cates() {
   static const int v = [] { const char* e = getenv("TLSAN_CSEG_MIN"); return e ? atoi(e) : TLSAN_CSEG_MIN_CATES; }();
   return v;
 }
-// TLSAN_TAIL_FUSE=1 (read once): the lazy update as trailing blocks of the row-sum launch instead of a launch of its own.
-// Built and measured in round 5 (profiles/r05_tail_fuse.md): bit-equal, at parity at the bench shape (59.5 vs 59.8 us/step),
-// slower for small batches (B = 32: 34.2 vs 32.4) and for 10^7-row tables (C5 338 vs 310) -- off, and removed by the next commit.
-static bool tail_fuse() {
-  static const bool v = [] { const char* e = getenv("TLSAN_TAIL_FUSE"); return e && atoi(e) != 0; }();
-  return v;
-}
 static bool fused_dk(int D, int ngroups) { return D <= 128 && ngroups <= FUSED_DK_MAX_GROUPS; }
 // Samples per workgroup pass of a TRAINING launch of the fused kernel (= per partial record): the width's NSB, or 8 at
 // d = 128 (4-wavefront workgroups: Geo<128, 16, 4>) with the window in registers and no dropout, when the batch is so
@@ -254,7 +247,6 @@ struct St {  // persistent state
   int32_t* flag_user[TLSAN_INDEX_SLOTS];                                  // 256-row pieces of the user table that hold a count (ScanArgs.flag), zero at rest
   int32_t* uc_list[TLSAN_INDEX_SLOTS];                                    // samples of every category (u_cate uses), UC_LIST_CAP each
   double* Rc64;                                           // category sums of a split PRESUM pass, zero at rest
-  int32_t* arrive;                                        // arrival counters of the fused row-sum / update launch (tail_arrive), zero at rest
   int32_t* hot_list[TLSAN_INDEX_SLOTS];                                   // slots (urec_item) of the hot item rows, AP_HOT_CAP each
   // the item side of the index from a partitioned counting sort of the batch's ids (IsortArgs; tables of isort_min_rows() rows or more)
   int32_t *is_bh[TLSAN_INDEX_SLOTS], *is_ids[TLSAN_INDEX_SLOTS], *is_bstart[TLSAN_INDEX_SLOTS], *is_nd[TLSAN_INDEX_SLOTS];
@@ -308,7 +300,6 @@ static void carve_state(const tlsan_dims* d, char* base, St* s) {
       s->is_tmp[k] = (int4*)take(on ? 16 * (size_t)ISORT_MAX_SLOTS : 0);
     }
   }
-  s->arrive = (int32_t*)take(4 * (size_t)(2 * TAIL_NCNT + 1) * TAIL_STRIDE);
   s->S_total = base ? &s->hdr->St : nullptr;
   s->bytes = o;
 }
@@ -440,7 +431,6 @@ static void category_split(ApplyArgs& A, const tlsan_dims* d, const tlsan_batch*
 // second half of the split lazy update (the first half rides with the dense finalize, run_backward)
 static int launch_update_lazy(ApplyArgs A, int B, int Sn, hipStream_t hs) {
   lazy_blocks(A, B, Sn);
-  A.nbI_u = A.nbI; A.nbU_u = A.nbU;
   const int nbC16 = (A.C + 15) / 16;
   const dim3 g1(nbC16 + A.nbI + A.nbU + A.nbD), blk(256);
   const bool wide = apply_wide(A);
@@ -800,7 +790,6 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   fill_fwd(a, d, s, p, b, w, L);
   a.logits_i = (out && out->logits) ? out->logits : w.logits;
   if (out && out->started) { a.started = out->started; a.started_val = out->started_value; }
-  if (presum && presum->arrive) a.tail_epoch = &st.hdr->tail_epoch;
   a.Gi = w.Gi; a.Gb = w.Gb; a.Gu = w.Gu; a.Gc = w.Gc; a.WU = w.WU;
   a.cur_item = st.cur_item[k]; a.cur_user = st.cur_user[k]; a.cur_uc = st.cur_uc[k];
   a.perm = balanced(d, b) ? st.perm[k] : nullptr;
@@ -855,32 +844,14 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
     lazy_blocks(A, b->B, b->Sn);
     A.nbC = A.cseg ? (A.C + AP_ROWS_PB - 1) / AP_ROWS_PB : A.C * A.csplit;
     A.nbH = AP_HOT_CAP;   // hot item rows: a workgroup each, leading the grid
-    int ngrid = w.nfin + 1 + A.nbH + A.nbC + A.nbI + A.nbU;
-    // the lazy update as trailing blocks of this launch (tail_fuse(): lazy SGD step, one workgroup per category, the same
-    // row width class in both halves): k_update_lazy's grid behind the row-sum blocks
-    const bool fuse = A.arrive != nullptr;
-    if (fuse) {
-      A.nb_pre = ngrid;
-      A.nbC16 = (A.C + 15) / 16;
-      // (the update blocks take TAIL_RPG rows per 16-lane group: half as many blocks as the row-sum blocks in front)
-      A.nbI_u = (A.nbI + TAIL_RPG - 1) / TAIL_RPG;
-      A.nbU_u = (A.nbU + TAIL_RPG - 1) / TAIL_RPG;
-      ngrid += A.nbC16 + A.nbI_u + A.nbU_u + A.nbD;
-    }
-    const dim3 grid(ngrid);
+    const dim3 grid(w.nfin + 1 + A.nbH + A.nbC + A.nbI + A.nbU);
     // (the row-sum launch covers user rows of up to 256 floats in two passes of its narrow form -- 92 registers, five
     //  workgroups per CU, instead of 135 and three; the sharded step's fused rows keep the wide form.  d = 128 with 90-entry
     //  windows: Movies-TV shape 106.6 -> 104.3 us/step, with 673 categories 116.2 -> 106.2: profiles/r04_presum_narrow_ab.md)
     const bool wide = A.di > 64 || A.dc > 64 || (A.WU > 128 && A.presum_rows != 0);
 #define FP_LAUNCH(DD, HH)                                                                                         \
   do {                                                                                                            \
-    if (fuse) {                                                                                                   \
-      const bool bf = A.p.table_dtype == TLSAN_TABLE_BF16;                                                        \
-      if (wide && bf) hipLaunchKernelGGL((k_finalize_presum<DD, HH, true, false, true, true, TLSAN_TABLE_BF16>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);   \
-      else if (wide) hipLaunchKernelGGL((k_finalize_presum<DD, HH, true, false, true, true, TLSAN_TABLE_F32>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);     \
-      else if (bf) hipLaunchKernelGGL((k_finalize_presum<DD, HH, false, false, true, false, TLSAN_TABLE_BF16>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);    \
-      else hipLaunchKernelGGL((k_finalize_presum<DD, HH, false, false, true, false, TLSAN_TABLE_F32>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);             \
-    } else if (A.csplit > 1) {                                                                                           \
+    if (A.csplit > 1) {                                                                                           \
       if (wide) hipLaunchKernelGGL((k_finalize_presum<DD, HH, true, true>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);  \
       else hipLaunchKernelGGL((k_finalize_presum<DD, HH, false, true>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);      \
     } else if (wide) hipLaunchKernelGGL((k_finalize_presum<DD, HH, true>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);   \
@@ -1008,12 +979,8 @@ int tlsan_train_step_opt(const tlsan_dims* d, const tlsan_params* p, const tlsan
   }
   if (hp->l2_mode == TLSAN_L2_LAZY) {   // row sums beside the finalize, then the short elementwise update
     category_split(A, d, b);
-    // ... as trailing blocks of the same launch (k_finalize_presum<..., FUSE>) where the two halves agree on the row
-    // width class and a category has one workgroup; otherwise as a launch of its own
-    const bool fuse = tail_fuse() && A.csplit == 1 && apply_wide(A) == (A.di > 64 || A.dc > 64);
-    if (fuse) A.arrive = st.arrive;
     if ((rc = run_backward(d, s, p, b, hp, true, out, w, st, L, hs, &A))) return rc;
-    if (!fuse && (rc = launch_update_lazy(A, b->B, b->Sn, hs))) return rc;
+    if ((rc = launch_update_lazy(A, b->B, b->Sn, hs))) return rc;
   } else {
     if ((rc = run_backward(d, s, p, b, hp, true, out, w, st, L, hs))) return rc;
     if (hp->norm_mode == TLSAN_NORM_DEDUP && (rc = clip_dedup(A, hp, out, w, st, b, hs))) return rc;

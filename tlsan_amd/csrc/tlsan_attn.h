@@ -510,7 +510,6 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     // (tlsan_step_out.started: this kernel running means everything queued before the step is complete)
     if (a.started != nullptr && blockIdx.x == 0 && tid == 0)
       __hip_atomic_store(a.started, a.started_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (a.tail_epoch != nullptr && blockIdx.x == 0 && tid == 64) *a.tail_epoch += 1u;   // (the row-sum launch behind this kernel hands over under a new epoch)
   }
   const float* dn = a.p.dense;
   const float gamma = dn[a.lay.gamma];

@@ -465,10 +465,6 @@ __device__ __forceinline__ double exact_term(float v) {
 
 #define TLSAN_SN_CAP 96  // longest session the training kernel keeps positions for (reference: <= 90)
 
-// arrival counters of the fused row-sum / update launch (tlsan_update.h: tail_arrive), each on a 128-byte line of its own
-#define TAIL_NCNT 16
-#define TAIL_STRIDE 32     // ints per counter line
-
 struct FwdArgs {
   tlsan_params p;
   tlsan_batch b;
@@ -510,9 +506,6 @@ struct FwdArgs {
   uint32_t drop_sample0;          // index of this batch's first sample in the pattern (a rank's share of a global batch)
   uint32_t* started;              // optional host-visible word: workgroup 0 stores started_val there when the kernel begins
   uint32_t started_val;
-  // training, optional: the hand-over epoch of the fused row-sum / update launch that follows (tlsan_update.h: tail_arrive):
-  // this kernel runs between two such launches and advances it
-  uint32_t* tail_epoch;
 };
 
 // Keep / drop pattern of tf.nn.dropout as the scale the element is multiplied with (0 or 1/keep_prob):

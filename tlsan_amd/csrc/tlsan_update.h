@@ -9,7 +9,6 @@
 // Determinism: integer atomics only build *which* rows belong to a destination; the float
 // sums are order-independent (exact_term) or in a fixed order, so two runs are bitwise equal.
 #pragma once
-#include <stddef.h>
 #include "tlsan_common.h"
 
 // index slots of the state: the batch being trained and up to two announced successors (tlsan_batch_index)
@@ -26,15 +25,12 @@ struct StateHdr {
   int32_t spart_n;         // leading records of S_delta the last update may have written
   int32_t n_hot[TLSAN_INDEX_SLOTS];        // [index slot] item rows with more than AP_HOT uses (k_index_scan; listed in the state)
   uint32_t folded;         // the step (nstep) whose S_delta records are already part of St (a step is folded once)
-  uint32_t tail_timeout;   // != 0: an update block of a fused row-sum / update launch gave up waiting (tail_wait: a logic error)
-  uint32_t tail_epoch;     // epoch of the fused row-sum / update launch's hand-over (tail_arrive); advanced by k_fwd_bwd
-  float pad0[13];
+  float pad0[15];
   // ---- its own 128-B line: hammered by atomics, must not share a line with anything that is read
   int32_t ticket;          // arrival counter of k_dense_finalize: the last workgroup writes the step summary
   int32_t pad1[31];
 };
 static_assert(sizeof(StateHdr) == 256, "StateHdr layout");
-static_assert(offsetof(StateHdr, tail_timeout) == 68, "Model.tail_timeouts() reads this word");
 
 // A workgroup's change of the stored tables' sum of squares, tagged with the step that made it (StateHdr::nstep after
 // that step).  The next step's finalize adds up the records of the previous step, once (StateHdr::folded), and ignores
@@ -910,85 +906,6 @@ __global__ __launch_bounds__(DK_WAVES * 64) void k_dk_partial(const float* __res
   }
 }
 
-// ---- hand-over inside ONE launch: the row-sum and finalize blocks of k_finalize_presum arrive, its trailing update blocks
-// wait for all of them.  A grid's workgroups are placed in the order of their numbers, so by the time an update block holds
-// a slot of the chip every block it waits for is resident or done: it cannot starve what it waits for (the waiting of
-// round 3's one-launch form sat INSIDE the row blocks, which then held their slots against the blocks behind them).
-// Arrivals are spread over TAIL_NCNT counters on cache lines of their own (thousands of same-address atomics queue up at
-// one memory channel).  No fences: an agent-scope release is a write-back of the XCD's whole L2 and an acquire drops it --
-// 2 500 blocks doing that took the launch from 14.5 + 7.3 us to 160 (round 5, first form).  Instead everything the update
-// blocks read of what this launch produced -- row sums, dense gradients, the step summary -- is STORED agent-coherently
-// (write-through: st4_wt / st1_wt, i.e. `global_store ... sc1`; the arrival only waits for the block's own stores) and
-// LOADED agent-coherently (ld4_g<true> / ld1_coh).
-// (TAIL_NCNT counters, TAIL_STRIDE ints apart: tlsan_common.h)
-__device__ __forceinline__ void st4_wt(float* p, f32x4 v) {
-  // (the s_nop: a later vector write to the data registers of a >64-bit store needs a wait state the compiler cannot see)
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void st1_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st1_wt(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ld1_coh(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint32_t ld1_coh(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// COH: an agent-coherent 16-byte load whose result may only be used behind coh_wait on the same registers
-template <bool COH>
-__device__ __forceinline__ f32x4 ld4_g(const float* p) {
-  if constexpr (COH) {
-    f32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-    return v;
-  } else {
-    return *(const f32x4*)p;
-  }
-}
-template <bool COH, int N>
-__device__ __forceinline__ void coh_wait(f32x4 (&g)[N]) {
-  if constexpr (COH) {
-    static_assert(N <= 4, "up to four chunks");
-    if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[0]) : : "memory");
-    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[0]), "+v"(g[1]) : : "memory");
-    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]) : : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]) : : "memory");
-  }
-}
-// Arrival: a counter per line (blocks blk % TAIL_NCNT == k count on line k), a second-level counter for the lines that are
-// complete, and the block that completes the last line writes the launch's epoch into TAIL_NCNT "go" words, one per line.
-// The waiting blocks poll ONE go word each, lightly: a thousand of them polling all the counters flat out took the memory
-// channels of those lines from the blocks they were waiting for (categories 8 -> 19 us, profiles/r05_tail_fuse.md).  A
-// counter is put back to zero by the block that completes it -- the last to touch it in this launch -- so everything is
-// zero at rest; the epoch (StateHdr::tail_epoch) is advanced by the step's first kernel, k_fwd_bwd, between two such
-// launches, so a go word left by the launch before never matches.
-// layout of `arrive` (ints): [k * TAIL_STRIDE] line counters, [TAIL_NCNT * TAIL_STRIDE] lines complete, [(TAIL_NCNT + 1 + k) * TAIL_STRIDE] go words
-__device__ __forceinline__ void tail_arrive(int32_t* arrive, int blk, int nb_pre, uint32_t epoch) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's (write-through) stores have been performed ...
-  __syncthreads();                                   // ... every thread's have
-  if (threadIdx.x == 0) {
-    const int k = blk % TAIL_NCNT, n_k = (nb_pre - k + TAIL_NCNT - 1) / TAIL_NCNT;
-    if (atomicAdd(arrive + k * TAIL_STRIDE, 1) + 1 == n_k) {
-      __hip_atomic_store(arrive + k * TAIL_STRIDE, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int32_t* top = arrive + TAIL_NCNT * TAIL_STRIDE;
-      if (atomicAdd(top, 1) + 1 == (nb_pre < TAIL_NCNT ? nb_pre : TAIL_NCNT)) {
-        __hip_atomic_store(top, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int j = 0; j < TAIL_NCNT; ++j)
-          __hip_atomic_store((uint32_t*)arrive + (TAIL_NCNT + 1 + j) * TAIL_STRIDE, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-  }
-}
-// returns false on a timeout (a logic error, never a normal outcome: the caller records it and goes on -- no hang)
-__device__ __forceinline__ bool tail_wait(const int32_t* arrive, int blk, uint32_t epoch, int* sh_flag) {
-  if (threadIdx.x == 0) {
-    const uint32_t* go = (const uint32_t*)arrive + (TAIL_NCNT + 1 + blk % TAIL_NCNT) * TAIL_STRIDE;
-    bool ok = false;
-    for (int polls = 0; polls < (1 << 21); ++polls) {
-      if (__hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) { ok = true; break; }
-      __builtin_amdgcn_s_sleep(8);
-    }
-    *sh_flag = ok ? 1 : 0;
-  }
-  __syncthreads();
-  return *sh_flag != 0;
-}
-
 // ------------------------------------------------------------------------------------------
 struct FinArgs {
   tlsan_dense_layout lay;
@@ -1052,9 +969,9 @@ __device__ __forceinline__ void step_summary(const FinArgs& a, int nsqd, double*
     sq = shd[0] + (double)sc1 + (double)a.reg * (double)a.reg * St;
     const float norm = (float)sqrt(sq);
     const float coef = a.clip / fmaxf(norm, a.clip);
-    st1_wt(&a.hdr->coef, coef);        // (these three are read by the update blocks of a fused launch: agent-coherent)
-    st1_wt(&a.hdr->P_prev, P);
-    if (a.count_step) st1_wt(&a.hdr->nstep, a.hdr->nstep + 1u);
+    a.hdr->coef = coef;
+    a.hdr->P_prev = P;
+    if (a.count_step) a.hdr->nstep += 1;
     if (a.commit) a.hdr->P = P * (1.0f - a.lr * coef * a.reg);
     if (a.norm_mode == TLSAN_NORM_TF18 && a.out_gnorm) *a.out_gnorm = norm;
     if (a.out_loss) *a.out_loss = sc0 * a.inv_B + a.reg * (float)(0.5 * St);
@@ -1156,7 +1073,7 @@ __device__ __forceinline__ void dense_finalize_block(const FinArgs& a, int nbK, 
         }
       }
       g = (g0 + g1) + (g2 + g3);
-      st1_wt(a.gd + L.K + idx, g);     // (agent-coherent: read by the update blocks of a fused launch, tail_arrive)
+      a.gd[L.K + idx] = g;
       owner = true;
     }
   } else {
@@ -1201,7 +1118,7 @@ __device__ __forceinline__ void dense_finalize_block(const FinArgs& a, int nbK, 
       for (int o = 1; o < 16; o <<= 1) t += __shfl_xor(t, o);
       g = t;
       if (rl == 0) {
-        st1_wt(a.gd + n, g);
+        a.gd[n] = g;
         owner = true;
       }
     }
@@ -1318,11 +1235,6 @@ struct ApplyArgs {
   int32_t opt;
   float ob1, ob2, oeps, oalpha;   // oalpha: Adam's lr * sqrt(1 - beta2^t) / (1 - beta1^t)
   unsigned long long* stamps;  // debug: 8 s_memtime stamps per workgroup (tlsan_debug_stamps)
-  // the lazy update as trailing blocks of the row-sum launch (k_finalize_presum<..., FUSE>): arrival counters in the state
-  // (tail_arrive; zero at rest), the number of row-sum / finalize blocks in front of the update blocks
-  int32_t* arrive;
-  int32_t nb_pre, nbC16;
-  int32_t nbI_u, nbU_u;    // item / user blocks of the lazy update (k_update_lazy: = nbI, nbU; the fused form: TAIL_RPG rows per group)
 };
 
 #define AP_OWN 8        // uses a 16-lane group sums alone before the wavefront helps
@@ -1513,9 +1425,6 @@ __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx
   }
   const int W4 = a.dc / 4;
   const size_t wrow = (size_t)c * a.dc;  // element index of the row in cate_emb
-#ifdef TLSAN_TIMING_NOCATE   // (timing-only experiment: what the row-sum launch takes when its category blocks cost nothing; results are WRONG)
-  if constexpr (MODE == AP_PRESUM) { if (tid == 0) a.cnt_uc[c] = 0; return; }
-#endif
   f32x4 w[NCH];
   if constexpr (MODE != AP_PRESUM) {
 #pragma unroll
@@ -1631,7 +1540,7 @@ __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx
             f32x4 g;
 #pragma unroll
             for (int i = 0; i < 4; ++i) g[i] = (float)acc[ch][i];
-            st4_wt(a.Rc + wrow + 4 * c4, g);
+            *(f32x4*)(a.Rc + wrow + 4 * c4) = g;
           }
         }
       }
@@ -1812,8 +1721,7 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
 #pragma unroll
           for (int i = 0; i < 4; ++i) g[i] = (float)acc[ch][i];
           if (!by_row || 4 * c4 < a.di) {
-            if (by_row) *(f32x4*)(R + 4 * c4) = g;
-            else st4_wt(R + 4 * c4, g);
+            *(f32x4*)(R + 4 * c4) = g;
           } else {  // usert_emb columns of a user row
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -1824,10 +1732,7 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
         }
       }
       if (l16 == 0) {
-        if (IS_ITEM) {
-          if (by_row) a.go.item_b[(size_t)row * a.go.ld_itemb] = (float)bacc;
-          else st1_wt(a.Rb + slot, (float)bacc);
-        }
+        if (IS_ITEM) (by_row ? a.go.item_b[(size_t)row * a.go.ld_itemb] : a.Rb[slot]) = (float)bacc;
         if (n > 0) (IS_ITEM ? a.cnt_item : a.cnt_user)[row] = 0;
       }
       if (a.presum_rows == 2) {
@@ -2020,7 +1925,7 @@ __device__ __forceinline__ void apply_cseg_block(const ApplyArgs& a, const ApCtx
           f32x4 g;
 #pragma unroll
           for (int i = 0; i < 4; ++i) g[i] = (float)acc[ch][i];
-          st4_wt(a.Rc + wrow + 4 * c4, g);
+          *(f32x4*)(a.Rc + wrow + 4 * c4) = g;
         }
       }
       if (l16 == 0 && n > 0) a.cnt_uc[c] = 0;
@@ -2130,14 +2035,12 @@ __device__ __forceinline__ void presum_hot_block(const ApplyArgs& a, int h, doub
           for (int w_ = 0; w_ < 4; ++w_) s += shd[((w_ * 16 + l16) * NCH + ch) * 4 + i];
           g[i] = (float)s;
         }
-        if (by_row) *(f32x4*)(R + 4 * c4) = g;
-        else st4_wt(R + 4 * c4, g);
+        *(f32x4*)(R + 4 * c4) = g;
       }
     }
     if (l16 == 0) {
       const float gb = (float)((shp[0] + shp[1]) + (shp[2] + shp[3]));
-      if (by_row) a.go.item_b[(size_t)row * a.go.ld_itemb] = gb;
-      else st1_wt(a.Rb + slot, gb);
+      (by_row ? a.go.item_b[(size_t)row * a.go.ld_itemb] : a.Rb[slot]) = gb;
       a.cnt_item[row] = 0;
     }
     if (a.presum_rows == 2)
@@ -2219,16 +2122,7 @@ __global__ __launch_bounds__(256) void k_apply(ApplyArgs a) {
 //                       PRESUM mode (exact per-row sums -> Rc / Ri / Rb / Ru, counters reset)
 //   k_update_lazy     : elementwise w -= scale * sum for the used rows + the dense parameters
 // Same arithmetic per element as k_apply<AP_UPDATE, lazy> (the sums are rounded to float there too).
-template <bool WIDE, int DT, bool COH, int RPG, class WaitF>
-__device__ __forceinline__ void update_lazy_block(const ApplyArgs& a, int nbC16, int blk, double* shp, WaitF wait);
-#define TAIL_RPG 2      // rows per 16-lane group of an update block of the fused form
-template <int D, int DH, bool WIDE, bool CSPLIT>
-__device__ __forceinline__ void presum_roles(const FinArgs& f, int nbK, int nbS, const ApplyArgs& a, double* shd, double* shp,
-                                             int* sh_pos, int* sh_lo, int* sh_n, int* sh_wtot, int* sh_last_p);
-
-// FUSE: the lazy update (k_update_lazy's blocks, update_lazy_block<WIDE_U, DT>) as trailing blocks of this launch; they wait
-// for every block in front of them (tail_arrive / tail_wait above) -- one launch and one kernel boundary less per step.
-template <int D, int DH, bool WIDE, bool CSPLIT = false, bool FUSE = false, bool WIDE_U = false, int DT = TLSAN_TABLE_F32>
+template <int D, int DH, bool WIDE, bool CSPLIT = false>
 __global__ __launch_bounds__(256) void k_finalize_presum(FinArgs f, int nbK, int nbS, ApplyArgs a) {
   constexpr int NC = WIDE ? 2 : 1, NI = WIDE ? 2 : 1, NU = WIDE ? 4 : 2;
   __shared__ double shd[4 * 16 * NC * 4 > 256 ? 4 * 16 * NC * 4 : 256];
@@ -2237,34 +2131,12 @@ __global__ __launch_bounds__(256) void k_finalize_presum(FinArgs f, int nbK, int
   __shared__ int sh_lo[256], sh_n[256];
   __shared__ int sh_wtot[4];
   __shared__ int sh_last;
-  if constexpr (FUSE) {
-    if ((int)blockIdx.x >= a.nb_pre) {     // ---- a block of the lazy update: everything in front of it must have arrived
-      // (debug stamps, 100 MHz device clock: [4] placed, [7] past the wait, [5] done; rows behind the row-sum blocks')
-      unsigned long long* stp = a.stamps ? a.stamps + (size_t)blockIdx.x * 8 : nullptr;
-      if (stp && threadIdx.x == 0) { stp[0] = __builtin_amdgcn_s_memtime(); stp[4] = __builtin_amdgcn_s_memrealtime(); }
-      auto wait = [&]() {
-        if (!tail_wait(a.arrive, (int)blockIdx.x - a.nb_pre, a.hdr->tail_epoch, &sh_last) && threadIdx.x == 0) a.hdr->tail_timeout = 1u;
-        if (stp && threadIdx.x == 0) stp[7] = __builtin_amdgcn_s_memrealtime();
-      };
-      update_lazy_block<WIDE_U, DT, true, TAIL_RPG>(a, a.nbC16, (int)blockIdx.x - a.nb_pre, shp, wait);
-      if (stp && threadIdx.x == 0) { stp[6] = __builtin_amdgcn_s_memtime(); stp[5] = __builtin_amdgcn_s_memrealtime(); }
-      return;
-    }
-  }
-  presum_roles<D, DH, WIDE, CSPLIT>(f, nbK, nbS, a, shd, shp, sh_pos, sh_lo, sh_n, sh_wtot, &sh_last);
-  if constexpr (FUSE) tail_arrive(a.arrive, (int)blockIdx.x, a.nb_pre, a.hdr->tail_epoch);
-}
-
-template <int D, int DH, bool WIDE, bool CSPLIT>
-__device__ __forceinline__ void presum_roles(const FinArgs& f, int nbK, int nbS, const ApplyArgs& a, double* shd, double* shp,
-                                             int* sh_pos, int* sh_lo, int* sh_n, int* sh_wtot, int* sh_last_p) {
-  constexpr int NC = WIDE ? 2 : 1, NI = WIDE ? 2 : 1, NU = WIDE ? 4 : 2;
   const int nfin = nbK + nbS + 1;
   if ((int)blockIdx.x < nfin) {
     // (debug stamps: the finalize workgroups are listed after the apply workgroups)
-    unsigned long long* stp = a.stamps ? a.stamps + (size_t)((a.nb_pre ? a.nb_pre : (int)gridDim.x) - nfin + blockIdx.x) * 8 : nullptr;
+    unsigned long long* stp = a.stamps ? a.stamps + (size_t)(gridDim.x - nfin + blockIdx.x) * 8 : nullptr;
     if (stp && threadIdx.x == 0) { stp[0] = __builtin_amdgcn_s_memtime(); stp[4] = __builtin_amdgcn_s_memrealtime(); }
-    dense_finalize_block<D, DH>(f, nbK, nbS, blockIdx.x, shd, sh_last_p);
+    dense_finalize_block<D, DH>(f, nbK, nbS, blockIdx.x, shd, &sh_last);
     if (stp && threadIdx.x == 0) { stp[6] = __builtin_amdgcn_s_memtime(); stp[5] = __builtin_amdgcn_s_memrealtime(); }
     return;
   }
@@ -2305,53 +2177,35 @@ __global__ void k_rc64_to_float(double* __restrict__ r64, float* __restrict__ ou
 }
 
 // grid: nbC16 = ceil(C / 16) blocks of category rows, nbI / nbU blocks of used item / user rows
-// (RPG rows per 16-lane group), nbD blocks of 256 dense parameters
-// COH (the fused form, k_finalize_presum<..., FUSE>): the block first issues the loads that do not depend on this launch --
-// the used-row records, the parameter rows -- then calls wait() (tail_wait: every block in front has arrived; blocks that
-// have nothing to do return without waiting), and only then reads what the launch produced (row sums, dense gradients, the
-// step summary), agent-coherently.  RPG = 2 there: half as many blocks, all of them resident and waiting with their
-// parameter rows in flight when the hand-over comes (with 16 rows per block a third of the 1 900 blocks only got a slot
-// when the first ones had finished: profiles/r05_tail_fuse.md).
-struct NoWait { __device__ __forceinline__ void operator()() const {} };
-template <bool WIDE, int DT, bool COH, int RPG, class WaitF>
-__device__ __forceinline__ void update_lazy_block(const ApplyArgs& a, int nbC16, int blk, double* shp, WaitF wait) {
+// (one row per 16-lane group), nbD blocks of 256 dense parameters
+template <bool WIDE, int DT>
+__global__ __launch_bounds__(256) void k_update_lazy(ApplyArgs a, int nbC16) {
   constexpr int NC = WIDE ? 2 : 1, NI = WIDE ? 2 : 1, NU = WIDE ? 4 : 2;
-  const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, gid = tid >> 4;
-  float P, step, lazy_scale;
-  uint32_t salt;
-  auto summary = [&]() {     // (behind wait(): the step summary was written by a block of this launch in the fused form)
-    P = COH ? ld1_coh(&a.hdr->P_prev) : a.hdr->P_prev;  // (the step summary already advanced hdr->P)
-    step = a.lr * (COH ? ld1_coh(&a.hdr->coef) : a.hdr->coef);
-    lazy_scale = step / (P * (1.0f - step * a.reg));
-    salt = COH ? ld1_coh(&a.hdr->nstep) : a.hdr->nstep;
-  };
-  if (blk == 0 && tid == 0) a.hdr->spart_n = nbC16 + a.nbI_u + a.nbU_u;
+  __shared__ double shp[4];
+  const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, gid = tid >> 4, blk = blockIdx.x;
+  const float P = a.hdr->P_prev;  // (the step summary already advanced hdr->P)
+  const float step = a.lr * a.hdr->coef;
+  const float lazy_scale = step / (P * (1.0f - step * a.reg));
+  const uint32_t salt = a.hdr->nstep;
+  if (blk == 0 && tid == 0) a.hdr->spart_n = nbC16 + a.nbI + a.nbU;
   double part = 0.0;
   if (blk < nbC16) {
     const int c = blk * 16 + gid;
-    const bool vc = c < a.C;
-    const size_t wrow = (size_t)(vc ? c : 0) * a.dc;
-    f32x4 w[NC], g[NC];
-#pragma unroll
-    for (int ch = 0; ch < NC; ++ch)
-      if (vc && 4 * (l16 + 16 * ch) < a.dc) w[ch] = tbl_ld4<DT>(a.p.cate_emb, wrow + 4 * (l16 + 16 * ch));
-    wait();
-    summary();
-    if (vc) {
+    if (c < a.C) {
+      const size_t wrow = (size_t)c * a.dc;
+      f32x4 w[NC], g[NC];
 #pragma unroll
       for (int ch = 0; ch < NC; ++ch)
         if (4 * (l16 + 16 * ch) < a.dc) {
-          if (a.csplit > 1) {   // (never with COH: a launch that splits categories keeps the update a launch of its own)
+          w[ch] = tbl_ld4<DT>(a.p.cate_emb, wrow + 4 * (l16 + 16 * ch));
+          if (a.csplit > 1) {
             double* r64 = a.Rc64 + wrow + 4 * (l16 + 16 * ch);
 #pragma unroll
             for (int i = 0; i < 4; ++i) { g[ch][i] = (float)r64[i]; r64[i] = 0.0; }
           } else {
-            g[ch] = ld4_g<COH>(a.Rc + wrow + 4 * (l16 + 16 * ch));
+            g[ch] = *(const f32x4*)(a.Rc + wrow + 4 * (l16 + 16 * ch));
           }
-        } else {
-          g[ch] = (f32x4)(0.0f);
         }
-      coh_wait<COH>(g);
 #pragma unroll
       for (int ch = 0; ch < NC; ++ch)
         if (4 * (l16 + 16 * ch) < a.dc) {
@@ -2362,108 +2216,68 @@ __device__ __forceinline__ void update_lazy_block(const ApplyArgs& a, int nbC16,
           for (int i = 0; i < 4; ++i) part += (double)w[ch][i] * (double)w[ch][i] - (double)w0[i] * (double)w0[i];
         }
     }
-  } else if (blk < nbC16 + a.nbI_u) {
-    const int slot0 = (blk - nbC16) * (AP_ROWS_PB * RPG);
+  } else if (blk < nbC16 + a.nbI) {
+    const int slot0 = (blk - nbC16) * AP_ROWS_PB, slot = slot0 + gid;
     const int nuq = *a.n_uniq_item;
-    if (slot0 >= nuq) return;     // (workgroup-uniform; nothing of this launch is read: no wait)
-    int row[RPG];
-    f32x4 w[RPG][NI];
-    float wb[RPG];
-#pragma unroll
-    for (int r = 0; r < RPG; ++r) {
-      const int slot = slot0 + gid + 16 * r;
-      row[r] = slot < nuq ? a.urec_item[slot].x : -1;
-    }
-#pragma unroll
-    for (int r = 0; r < RPG; ++r) {
-      const size_t wrow = (size_t)(row[r] < 0 ? 0 : row[r]) * a.p.ld_item;
-#pragma unroll
-      for (int ch = 0; ch < NI; ++ch)
-        if (row[r] >= 0 && 4 * (l16 + 16 * ch) < a.di) w[r][ch] = tbl_ld4<DT>(a.p.item_emb, wrow + 4 * (l16 + 16 * ch));
-      wb[r] = (row[r] >= 0 && l16 == 0) ? a.p.item_b[(size_t)row[r] * a.p.ld_itemb] : 0.0f;
-    }
-    wait();
-    summary();
-#pragma unroll
-    for (int r = 0; r < RPG; ++r) {
-      if (row[r] < 0) continue;
-      const int slot = slot0 + gid + 16 * r;
-      const size_t wrow = (size_t)row[r] * a.p.ld_item;
-      f32x4 g[NI];
-      float gb = 0.0f;
-#pragma unroll
-      for (int ch = 0; ch < NI; ++ch)
-        g[ch] = 4 * (l16 + 16 * ch) < a.di ? ld4_g<COH>(a.Ri + (size_t)slot * a.di + 4 * (l16 + 16 * ch)) : (f32x4)(0.0f);
-      if (l16 == 0) gb = COH ? ld1_coh(a.Rb + slot) : a.Rb[slot];
-      coh_wait<COH>(g);
+    if (slot0 >= nuq) return;
+    if (slot < nuq) {
+      const int row = a.urec_item[slot].x;
+      const size_t wrow = (size_t)row * a.p.ld_item;
+      f32x4 w[NI], g[NI];
+      float wb = 0.0f, gb = 0.0f;
 #pragma unroll
       for (int ch = 0; ch < NI; ++ch)
         if (4 * (l16 + 16 * ch) < a.di) {
-          const f32x4 w0 = w[r][ch];
-          w[r][ch] = w0 - lazy_scale * g[ch];
-          tbl_st4<DT>(a.p.item_emb, wrow + 4 * (l16 + 16 * ch), w[r][ch], salt ^ 0x85ebca6bu);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) part += (double)w[r][ch][i] * (double)w[r][ch][i] - (double)w0[i] * (double)w0[i];
+          w[ch] = tbl_ld4<DT>(a.p.item_emb, wrow + 4 * (l16 + 16 * ch));
+          g[ch] = *(const f32x4*)(a.Ri + (size_t)slot * a.di + 4 * (l16 + 16 * ch));
         }
-      if (l16 == 0) a.p.item_b[(size_t)row[r] * a.p.ld_itemb] = wb[r] - step * gb;  // not regularised, never scaled
+      if (l16 == 0) { wb = a.p.item_b[(size_t)row * a.p.ld_itemb]; gb = a.Rb[slot]; }
+#pragma unroll
+      for (int ch = 0; ch < NI; ++ch)
+        if (4 * (l16 + 16 * ch) < a.di) {
+          const f32x4 w0 = w[ch];
+          w[ch] = w0 - lazy_scale * g[ch];
+          tbl_st4<DT>(a.p.item_emb, wrow + 4 * (l16 + 16 * ch), w[ch], salt ^ 0x85ebca6bu);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) part += (double)w[ch][i] * (double)w[ch][i] - (double)w0[i] * (double)w0[i];
+        }
+      if (l16 == 0) a.p.item_b[(size_t)row * a.p.ld_itemb] = wb - step * gb;  // not regularised, never scaled
     }
-  } else if (blk < nbC16 + a.nbI_u + a.nbU_u) {
-    const int slot0 = (blk - nbC16 - a.nbI_u) * (AP_ROWS_PB * RPG);
+  } else if (blk < nbC16 + a.nbI + a.nbU) {
+    const int slot0 = (blk - nbC16 - a.nbI) * AP_ROWS_PB, slot = slot0 + gid;
     const int nuq = *a.n_uniq_user;
     if (slot0 >= nuq) return;
-    int row[RPG];
-    f32x4 w[RPG][NU];
-#pragma unroll
-    for (int r = 0; r < RPG; ++r) {
-      const int slot = slot0 + gid + 16 * r;
-      row[r] = slot < nuq ? a.urec_user[slot].x : -1;
-    }
-#pragma unroll
-    for (int r = 0; r < RPG; ++r) {
-      const size_t wrow = (size_t)(row[r] < 0 ? 0 : row[r]) * a.p.ld_user;
-      const float* Trow = a.p.usert_emb + (size_t)(row[r] < 0 ? 0 : row[r]) * a.p.ld_usert;
+    if (slot < nuq) {
+      const int row = a.urec_user[slot].x;
+      const size_t wrow = (size_t)row * a.p.ld_user;
+      float* Trow = a.p.usert_emb + (size_t)row * a.p.ld_usert;
+      f32x4 w[NU], g[NU];
 #pragma unroll
       for (int ch = 0; ch < NU; ++ch) {
         const int cc = 4 * (l16 + 16 * ch);
-        if (row[r] < 0) continue;
+        if (cc < a.WU) g[ch] = *(const f32x4*)(a.Ru + (size_t)slot * a.WU + cc);
         if (cc < a.di) {
-          w[r][ch] = tbl_ld4<DT>(a.p.user_emb, wrow + cc);
+          w[ch] = tbl_ld4<DT>(a.p.user_emb, wrow + cc);
         } else if (cc < a.WU) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) w[r][ch][i] = (cc + i - a.di < a.Ls) ? Trow[cc + i - a.di] : 0.0f;
+          for (int i = 0; i < 4; ++i) w[ch][i] = (cc + i - a.di < a.Ls) ? Trow[cc + i - a.di] : 0.0f;
         }
       }
-    }
-    wait();
-    summary();
-#pragma unroll
-    for (int r = 0; r < RPG; ++r) {
-      if (row[r] < 0) continue;
-      const int slot = slot0 + gid + 16 * r;
-      const size_t wrow = (size_t)row[r] * a.p.ld_user;
-      float* Trow = a.p.usert_emb + (size_t)row[r] * a.p.ld_usert;
-      f32x4 g[NU];
-#pragma unroll
-      for (int ch = 0; ch < NU; ++ch) {
-        const int cc = 4 * (l16 + 16 * ch);
-        g[ch] = cc < a.WU ? ld4_g<COH>(a.Ru + (size_t)slot * a.WU + cc) : (f32x4)(0.0f);
-      }
-      coh_wait<COH>(g);
 #pragma unroll
       for (int ch = 0; ch < NU; ++ch) {
         const int cc = 4 * (l16 + 16 * ch);
         if (cc < a.di) {
-          const f32x4 w0 = w[r][ch];
-          w[r][ch] = w0 - lazy_scale * g[ch];
-          tbl_st4<DT>(a.p.user_emb, wrow + cc, w[r][ch], salt ^ 0xc2b2ae35u);
+          const f32x4 w0 = w[ch];
+          w[ch] = w0 - lazy_scale * g[ch];
+          tbl_st4<DT>(a.p.user_emb, wrow + cc, w[ch], salt ^ 0xc2b2ae35u);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) part += (double)w[r][ch][i] * (double)w[r][ch][i] - (double)w0[i] * (double)w0[i];
+          for (int i = 0; i < 4; ++i) part += (double)w[ch][i] * (double)w[ch][i] - (double)w0[i] * (double)w0[i];
         } else if (cc < a.WU) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int p = cc + i - a.di;
             if (p < a.Ls) {
-              const float w0 = w[r][ch][i], wn = w0 - lazy_scale * g[ch][i];
+              const float w0 = w[ch][i], wn = w0 - lazy_scale * g[ch][i];
               Trow[p] = wn;
               part += (double)wn * (double)wn - (double)w0 * (double)w0;
             }
@@ -2472,12 +2286,9 @@ __device__ __forceinline__ void update_lazy_block(const ApplyArgs& a, int nbC16,
       }
     }
   } else {
-    const int nd = (blk - nbC16 - a.nbI_u - a.nbU_u) * 256 + tid;
-    const float w0 = nd < a.lay.n_dense ? a.p.dense[nd] : 0.0f;
-    wait();
-    summary();
+    const int nd = (blk - nbC16 - a.nbI - a.nbU) * 256 + tid;
     if (nd < a.lay.n_dense) {
-      const float wn = w0 - step * (COH ? ld1_coh(a.gd + nd) : a.gd[nd]);
+      const float wn = a.p.dense[nd] - step * a.gd[nd];
       a.p.dense[nd] = wn;
       if (nd >= a.lay.K && nd < a.lay.k0) {
         const int idx = nd - a.lay.K;
@@ -2487,12 +2298,6 @@ __device__ __forceinline__ void update_lazy_block(const ApplyArgs& a, int nbC16,
     return;
   }
   block_delta_store(part, shp, &a.delta_out[blk], salt);
-}
-
-template <bool WIDE, int DT>
-__global__ __launch_bounds__(256) void k_update_lazy(ApplyArgs a, int nbC16) {
-  __shared__ double shp[4];
-  update_lazy_block<WIDE, DT, false, 1>(a, nbC16, blockIdx.x, shp, NoWait());
 }
 
 

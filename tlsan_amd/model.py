@@ -461,11 +461,6 @@ class Model(object):
     def table_scale(self):
         return float(self.state[:4].view(torch.float32).item())
 
-    def tail_timeouts(self):
-        """StateHdr::tail_timeout (csrc/tlsan_update.h): non-zero if an update block of a fused row-sum / update launch ever gave
-        up waiting for the blocks in front of it -- a logic error, never a normal outcome (tests assert 0)."""
-        return int(self.state[68:72].view(torch.int32).item())
-
     def get_params(self):
         self.fold_scale()
         out = {k: getattr(self, k).detach().float().cpu().numpy().copy() for k in TABLE_KEYS}
