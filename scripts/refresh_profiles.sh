@@ -11,6 +11,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
   # the same in the precisions BASELINE.json configs[2] names: bf16 tables, bf16 tables + bf16 matrix operands
   rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/${tag}_${c}_bf16t -- python3 $R/scripts/pmc_run.py 4096 td=bf16 > /dev/null 2>&1
   rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/${tag}_${c}_bf16mm -- python3 $R/scripts/pmc_run.py 4096 td=bf16 mm=bf16 > /dev/null 2>&1
+  # ... and at the two shapes whose step is not the bench's: C5 (tables beyond every cache) and Movies-TV with 90-entry windows
+  rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/${tag}_${c}_c5 -- python3 $R/scripts/pmc_run.py 4096 d=256 Ls=90 U=10000000 I=5000000 C=10000 > /dev/null 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/${tag}_${c}_mtv -- python3 $R/scripts/pmc_run.py 4096 d=128 Ls=90 U=35896 I=28589 C=15 > /dev/null 2>&1
 done
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $R/gpurun_out/${tag}_sq1 -- python3 $R/scripts/pmc_run.py > /dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT --output-format csv -d $R/gpurun_out/${tag}_sq2 -- python3 $R/scripts/pmc_run.py > /dev/null 2>&1

@@ -30,3 +30,6 @@ head -12 gpurun_out/${tag}_sharded_static_kernel_stats.txt
 head -12 gpurun_out/${tag}_stamps.txt
 cut -c1-300 gpurun_out/${tag}_sharded_bench_line.json
 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+# (the traffic nodes of the C5 / Movies-TV shapes take their kernel durations from the traces above)
+python3 scripts/traffic_json.py ${tag#r} gpurun_out/${tag} > gpurun_out/${tag}_traffic.json 2>&1
+timeout 900 bash scripts/batch_sweep.sh > gpurun_out/${tag}_batch_sweep.txt 2>&1

@@ -89,6 +89,34 @@ def _one_rank_worker(port, ret):
         for k in pa:
             assert np.array_equal(pa[k], pb[k]), ("abandoned announcement", k)
 
+        # steps that announce nothing followed by a step that announces two batches, with the GPU's queue running behind the
+        # host (no loss is read until the end): the plans of the announcing step go to slots that the two steps before it
+        # used last, so they may only be issued once the step before has STARTED -- which the pinned word can only tell if
+        # that step, too, carried a stamp (before, only announcing steps stamped, and the plan was ordered behind
+        # the step before the silent ones).  Same numbers as the dynamic step, bit for bit.
+        def run_gaps(static):
+            m = ShardedModel(cfg, icl, device="cuda:0", l2_mode="lazy", static_rows=static)
+            dbs = [m.device_batch(b) for b in batches]
+            losses = []
+            for s in range(24):
+                silent = s % 6 in (3, 4)                      # two silent steps, then one that announces two ahead
+                kw = {}
+                if not silent:
+                    kw = dict(next_batch=dbs[(s + 1) % 4])
+                    if static:
+                        kw["after_next"] = dbs[(s + 2) % 4]
+                m.train_async(dbs[s % 4], 0.7, **kw)
+                losses.append(m.last_loss.clone())
+            if static:
+                m.check_static_overflow()
+            return [float(l.item()) for l in losses], m.gather_params()
+
+        lg0, pg0 = run_gaps(False)
+        lg1, pg1 = run_gaps(True)
+        assert lg0 == lg1, ("silent steps before an announcing one", lg0, lg1)
+        for k in pg0:
+            assert np.array_equal(pg0[k], pg1[k]), ("silent steps before an announcing one", k)
+
         # a batch that needs more rows of an owner than the exchange holds is reported, not silently truncated
         m = ShardedModel(cfg, icl, device="cuda:0", l2_mode="lazy", static_rows=64)
         m.train_async(m.device_batch(batches[0]), 0.7)
@@ -131,8 +159,8 @@ def _two_rank_worker(rank, world, port, ret):
         icl = synth.item_cate_list(cfg)
         per_step = [[synth.make_batches(cfg, 1, 256, seed=700 + 10 * s + r, sessions="amazon")[0] for r in range(world)] for s in range(4)]
 
-        def run(static, ahead, deferred=False, graphs=False):
-            m = ShardedModel(cfg, icl, device="cuda:0", l2_mode="lazy", static_rows=static, deferred_ids=deferred)
+        def run(static, ahead, deferred=False, graphs=False, coalesce=False):
+            m = ShardedModel(cfg, icl, device="cuda:0", l2_mode="lazy", static_rows=static, deferred_ids=deferred, coalesce=coalesce)
             dbs = [m.device_batch(per[rank]) for per in per_step]
             losses = []
             if graphs:      # one eager step, then the cycle of four recorded steps, replayed: 2 + 4 = the six steps below
@@ -161,7 +189,9 @@ def _two_rank_worker(rank, world, port, ret):
         #  where no second communicator is opened.  Recorded steps cannot be part of this test: gloo's exchange is staged
         #  through the host, which a stream capture cannot hold; test_sharded_step_over_rccl replays graphs where there
         #  are two GPUs.)
-        for args in ((True, 1), (True, 2), (True, 1, True), (True, 2, True)):
+        # (coalesce: the row gradients' all-to-all issued with the all-reduce, AHEAD of the summary -- under gloo as two
+        #  staged calls back to back: the order of the step's phases is what is under test)
+        for args in ((True, 1), (True, 2), (True, 1, True), (True, 2, True), (True, 2, False, False, True), (True, 1, True, False, True)):
             l1, p1 = run(*args)
             assert l1 == l0, (args, l0, l1)
             for k in p0:

@@ -284,10 +284,13 @@ class ShardedModel:
           deferred_ids (static_rows): plans built ahead never carry their own id all-to-all -- the step that uses a plan
         issues it, on the main stream -- which is what runs by default over RCCL (no second communicator); True forces
         the same under the gloo exchange of the tests, whose default keeps a side group.
-          coalesce (static_rows, RCCL only): the all-reduce of the dense gradients and the all-to-all of the row gradients,
-        which do not depend on each other, are issued as ONE RCCL group (one launch, one latency) ahead of the summary.
-        Off by default: no hardware with more than one GPU has ever run it (tests/test_gpu_configs.py covers it where
-        there are two)."""
+          coalesce (static_rows): the all-reduce of the dense gradients and the all-to-all of the row gradients, which do
+        not depend on each other, are issued as ONE RCCL group (one launch, one latency) ahead of the summary -- the row
+        gradients then travel BEFORE the clip coefficient exists (unscaled; the coefficient reaches the owners through the
+        summary).  Under the gloo exchange of the tests the group is two staged calls back to back: the ORDER of the
+        phases of the step, which is what differs from the default, is covered by the two-process tests
+        (tests/test_gpu_shard_static.py); the RCCL group itself only where there are two GPUs (tests/test_gpu_configs.py).
+        Off by default: no hardware with more than one GPU has ever run it."""
         if l2_mode not in ("dense", "lazy"):
             raise ValueError("l2_mode must be 'dense' or 'lazy'")
         self.lazy = l2_mode == "lazy"
@@ -308,8 +311,8 @@ class ShardedModel:
         self._st = None            # static-shape buffers (made at the first training batch)
         if not dist.is_initialized():
             raise RuntimeError("ShardedModel needs torch.distributed to be initialised (one process per GPU)")
-        if self.coalesce and (not static_rows or _staged(group)):
-            raise NotImplementedError("coalesce=True is the static-shape step's option over RCCL")
+        if self.coalesce and not static_rows:
+            raise NotImplementedError("coalesce=True is the static-shape step's option")
         from .model import OPTIMIZERS
         if config.get("num_blocks", 1) != 1:
             raise NotImplementedError("num_blocks != 1 (see tlsan_amd.model.Model)")
@@ -1077,7 +1080,9 @@ class ShardedModel:
                                    % (self._step, need, st["cap"], need))
         k = st["next"]
         sl = st["slots"][k]
+        planned_inline = False
         if sl["db"] is not db or not sl["fresh"]:      # not announced by an earlier step: plan it now, in line
+            planned_inline = True
             if not capturing:
                 self._flush_plans()
                 main.wait_stream(st["side"])     # (whatever an abandoned announcement left running in the slots)
@@ -1103,7 +1108,9 @@ class ShardedModel:
         # The word paces a plan only when the step before this one was such a stamped eager step; behind a graph replay, a
         # capture or the first step of a model the plans are ordered by an event on the main stream instead.
         stamp = not capturing
-        use_flag = bool(ahead) and stamp and st.get("prev_stamped", False)     # (see tlsan_shard_step_static: no event on the main stream)
+        # (... nor when this step has just planned its own batch in line, on the main stream: the plans share their mark
+        #  scratch, and "the step before has started" says nothing about a plan queued behind it -- the event does)
+        use_flag = bool(ahead) and stamp and st.get("prev_stamped", False) and not planned_inline     # (see tlsan_shard_step_static: no event on the main stream)
         if ahead and not use_flag:
             st["fork"].record(main)      # everything before this step: the slots the new plans go to are free from here
 
@@ -1182,9 +1189,13 @@ class ShardedModel:
             if G > 1 and self.coalesce:
                 # the two exchanges behind the kernels are independent of each other (the row sums travel unscaled: the
                 # clip coefficient reaches the owners through the summary): one RCCL group instead of two collectives
-                with dist._coalescing_manager(group=self.group, device=torch.device(self.device), async_ops=False):
-                    dist.all_reduce(flat, group=self.group)
-                    dist.all_to_all_single(st["vals"].view(-1), gf.view(-1), group=self.group)
+                if _staged(self.group):      # (gloo: no groups of collectives -- the same two exchanges, back to back, in the same place)
+                    allreduce_sum(flat, self.group)
+                    a2a(st["vals"].view(-1), gf.view(-1), None, None, self.group)
+                else:
+                    with dist._coalescing_manager(group=self.group, device=torch.device(self.device), async_ops=False):
+                        dist.all_reduce(flat, group=self.group)
+                        dist.all_to_all_single(st["vals"].view(-1), gf.view(-1), group=self.group)
                 run(L.PHASE_SUMMARY | L.PHASE_APPLY)
             else:
                 if G > 1:
