@@ -273,7 +273,10 @@ def main():
     lib_fused = cfg["hidden_units"] <= 128 and (B + nsb - 1) // nsb <= 256
     graphs = [model.capture_step(db, lr) for db in dbs] if use_graph else None
 
-    def run(n, first, timed=False):
+    host = [0.0]      # seconds the host spent inside the enqueue calls of the timed steps (is the step bound by its host thread?)
+
+    def run(n, first, timed=False, clock=False):
+        t_in, p_in = (time.perf_counter(), getattr(stepper, "poll_seconds", 0.0)) if clock else (0.0, 0.0)
         for s in range(n):
             k = (first + s) % len(dbs)
             if use_graph:
@@ -293,6 +296,8 @@ def main():
                                     after_next=dbs[(k + 2) % len(dbs)] if args.prefetch >= 2 else None)
             else:
                 stepper.train_async(dbs[k], lr)
+        if clock:
+            host[0] = time.perf_counter() - t_in - (getattr(stepper, "poll_seconds", 0.0) - p_in)
 
     def fence():
         torch.cuda.synchronize()
@@ -310,7 +315,7 @@ def main():
         torch.cuda.synchronize()
     fence()
     t0 = time.perf_counter()
-    run(args.steps, fence_warm, timed=False)
+    run(args.steps, fence_warm, timed=False, clock=True)
     fence()
     dt = time.perf_counter() - t0
     # the kernel's own duration: a pair of HIP events ATTACHED TO k_fwd_bwd's dispatch on its stream (hipExtLaunchKernelGGL
@@ -404,6 +409,9 @@ def main():
             "warmup": args.warmup,
             "pipeline_fill_steps": fill,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
+            # (time the host needed to ENQUEUE the timed steps, per step, without its waits for the GPU -- the poll of the
+            #  `started` word --: well below ms_per_step when the GPU is the bound)
+            "host_enqueue_ms_per_step": round(host[0] / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -4,7 +4,7 @@
 # the in-kernel stamps (fp32, bf16, streamed), the other shapes, PMC + register reports of the d = 256 kernels, the
 # sharded static step (kernel stats, bench line).  Needs ab_run/stamps.so (scripts/mkvariants.sh stamps:"-DTLSAN_STAMPS=1").
 R=${GRAFT_REPO_ROOT:-/root/repo}
-tag=${1:-r04}
+tag=${1:-r05}
 cd $R
 timeout 3000 python3 -m pytest tests -m gpu -x -q > gpurun_out/${tag}_pytest_gpu.log 2>&1; echo "pytest rc=$?"
 tail -3 gpurun_out/${tag}_pytest_gpu.log

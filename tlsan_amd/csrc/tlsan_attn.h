@@ -20,6 +20,9 @@
 // batched after the loops.
 #pragma once
 #include "tlsan_common.h"
+#ifndef TLSAN_STAMPS
+#define TLSAN_STAMPS 0   // 1: the diagnostic build with in-kernel cycle stamps (scripts/stamps.py)
+#endif
 
 // ---------------------------------------------------------------------------------------
 // feature_wise_attention forward (model.py:370-394) over NPOS static positions held in
@@ -430,7 +433,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   constexpr bool USE_SW = G::USE_SW && !FLATG;          // attention weights staged in LDS (when they fit)
   constexpr int LSCP = FLAT ? 0 : LSC;                  // long slots of the position tables (FLAT: the list holds them)
   // (8-sample workgroups size them by the batch as well: two workgroups must fit a CU's LDS)
-  const int SNS = (CSEG || FLATG || NSB < 16) ? ((a.b.Sn + 3) & ~3) : TLSAN_SN_CAP;
+  // (the diagnostic stamps build as well: its 2 KB of stamps must fit beside the 160 KB the d = 128 training kernel fills)
+  const int SNS = (CSEG || FLATG || NSB < 16 || TLSAN_STAMPS) ? ((a.b.Sn + 3) & ~3) : TLSAN_SN_CAP;
   const int PSTR = LSCP + SNS + 4;
   const int P_TGT = LSCP + SNS, P_USR = P_TGT + 1, P_UC = P_TGT + 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -486,6 +490,16 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   int chb[NB];
 #pragma unroll
   for (int kb = 0; kb < NB; ++kb) chb[kb] = col * CW + 16 * kb + 4 * q;
+  // chl: where the lane's float4 of 16-channel block kb sits inside a [slot][channel] row of the partial softmax states
+  // (sPart, streamed windows).  Indexed by the channel itself the eight column groups of a sample are CW dwords apart --
+  // the same banks: a 16-byte store is served in groups of 8 consecutive lanes (one sample's eight columns at one q), all
+  // eight on ONE set of four banks, 8 LDS cycles per group instead of 1, six such stores per list entry and wavefront
+  // (58 % of the C5 kernel's LDS cycles were bank conflicts: profiles/r04_pmc_c5_summary.txt).  Each column's block is
+  // therefore rotated by 4 * col dwords (CW = 32; by 4 * (col / 2) at CW = 16, where two columns span the 32 banks): the
+  // eight lanes of a group then cover all 32 banks.  Writer and reader address by channel, so both see the same rotation.
+  int chl[NB];
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb) chl[kb] = col * CW + ((16 * kb + 4 * q + 4 * (NB > 1 ? col : (col >> 1))) & (CW - 1));
   const bool lead = (q == 0) && (col == 0);  // one lane per sample
   // LKEY (windows in registers, one 16-channel block per column): the lane's half of a concatenated [item_emb | cate_emb]
   // row as per-lane constants -- table, row stride, offset of its four channels -- so that a gather's address is
@@ -866,7 +880,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             sN[kb][i] = N0 * so + ev * xv[kb][i];
             smx[kb][i] = mn;
           }
-          float* ps = sPart + slot * 3 * D + chb[kb];
+          float* ps = sPart + slot * 3 * D + chl[kb];
           *(f32x4*)(ps) = smx[kb];
           *(f32x4*)(ps + D) = sZ[kb];
           *(f32x4*)(ps + 2 * D) = sN[kb];
@@ -965,7 +979,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         const int slot = in ? srow + gs : 31;
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) {
-          const float* ps = sPart + slot * 3 * D + chb[kb];
+          const float* ps = sPart + slot * 3 * D + chl[kb];
           const f32x4 pm = *(const f32x4*)(ps), pZ = *(const f32x4*)(ps + D), pN = *(const f32x4*)(ps + 2 * D);
 #pragma unroll
           for (int i = 0; i < 4; ++i) {

@@ -17,7 +17,7 @@ static size_t fwd_smem_bytes(bool train, bool lstream, bool fuse_dk, int Sn, boo
   const bool flat = lstream && !drop;
   const bool flatg = flat && G::NB > 1;      // (d = 256: statistics / long vectors in global memory, no LDS copy of the weights, no long slots)
   const int lsc = lstream ? TLSAN_LS_CAP : TLSAN_LS_MAX;
-  const int pstr = (flat ? 0 : lsc) + ((cseg || flatg || G::NSB < 16) ? ((Sn + 3) & ~3) : TLSAN_SN_CAP) + 4;      // position slots per sample (k_fwd_bwd: PSTR), twice with CSEG
+  const int pstr = (flat ? 0 : lsc) + ((cseg || flatg || G::NSB < 16 || TLSAN_STAMPS) ? ((Sn + 3) & ~3) : TLSAN_SN_CAP) + 4;      // position slots per sample (k_fwd_bwd: PSTR), twice with CSEG
   const int nf = flat ? G::NSB * TLSAN_LS_CAP : 0;
   return sizeof(float) * ((train ? G::NSB * pstr * (cseg ? 2 : 1) : 0) + 2 * G::NSB * G::LSTR + ((train && ((G::FUSE_DK && fuse_dk) || (flat && !flatg))) ? G::NSB * G::LSTR : 0) + G::NW * 4 + ((G::NB == 1 && !lstream) ? G::NW * 2 * G::SPW * 16 : 0) /* LKEY: session keys (sSK) */ + G::NSB * 2 * lsc +
                           ((G::USE_SW && !flatg) ? ((G::NB > 1 && !lstream) ? 2 * (4 * G::NB * G::NB * 256 + 2 * DH) : 2 * (2 * DH * DH + 2 * DH)) : 0) + G::NW * G::WSCR +

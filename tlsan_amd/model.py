@@ -290,6 +290,7 @@ class Model(object):
         self._started_addr = self._started.data_ptr()
         self._started_word = C.c_uint32.from_address(self._started_addr)
         self._start_seq = 0
+        self.poll_seconds = 0.0     # time train_async spent polling the `started` word (the host waiting for the GPU)
         self._side = None
         self._step = 0
         self._epoch = 0
@@ -597,6 +598,7 @@ class Model(object):
                 self._side.wait_event(self._pre_event)
             else:
                 word, want, t0, polls = self._started_word, self._start_seq, None, 0
+                tp = time.perf_counter()
                 while word.value != want:
                     polls += 1
                     if polls & 255:
@@ -606,6 +608,7 @@ class Model(object):
                         t0 = time.perf_counter()
                     elif time.perf_counter() - t0 > 30.0:
                         raise RuntimeError("train_async: the step's first kernel did not start within 30 s")
+                self.poll_seconds += time.perf_counter() - tp     # (waiting for the GPU, not host work: bench.py subtracts it)
             for ndb, kk in ahead:
                 flag = L.INDEX_FOR_LAZY_SGD if (self.l2_mode == L.L2_LAZY and self.optimizer == "sgd") else 0
                 L.check(self.lib.tlsan_batch_index(C.byref(self.dims), C.byref(ndb.c), self.cparams.item_cate, self.state.data_ptr(), kk | flag,
