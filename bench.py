@@ -90,6 +90,17 @@ def self_launch(args):
     print(lines[-1], flush=True)
 
 
+def lib_id(path):
+    import hashlib
+    try:
+        with open(path, "rb") as f:
+            h = hashlib.sha256(f.read()).hexdigest()[:16]
+    except OSError:
+        h = None
+    return {"path": os.path.relpath(path, ROOT) if path.startswith(ROOT) else path, "sha256_16": h,
+            "overridden_by_TLSAN_LIB_PATH": bool(os.environ.get("TLSAN_LIB_PATH"))}
+
+
 def accuracy_leg(nsteps, dev):
     """BASELINE.json's metric names accuracy beside throughput ("AUC@20": AUC, and P@20 / R@20): the
     reference's protocol (train.py:26-49: d=64, batch 32, lr 1.0, L2 5e-5, clip 5; its shuffle stream) on the real
@@ -449,6 +460,8 @@ def main():
                                          "batch %s on a second stream" % (3 if lib_fused else 4, "after next" if args.prefetch >= 2 else "next")
                                          if (args.prefetch and not sharded) else "eager"),
             "static_overflow_checked": True if (sharded and static_rows) else None,
+            # which build was measured (TLSAN_LIB_PATH can point the loader at a diagnostic build: it would show here)
+            "library": lib_id(L.LIB_PATH),
             "final_loss": round(loss, 6),
         }
         if also is not None:
