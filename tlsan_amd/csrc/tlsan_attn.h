@@ -1347,6 +1347,10 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
         const int kku = q * CPS + col;   // use slot of this lane (P_TGT, P_USR, P_UC are consecutive)
         if (kku < LS + 3) sP[srow * PSTR + (kku < LS ? kku : P_TGT + (kku - LS))] = upos;
         if (CSEG && kku <= LS) sPc[srow * PSTR + (kku < LS ? kku : P_TGT)] = ucpos;
+        // item_b's gradient is 0 for every use but the candidate's: the lane that drew a window use's position clears it
+        // here, ONE store instruction for the wavefront's twenty uses (it was a lead-lane store inside a branch at every
+        // position of the long backward: ten pairs of exec-mask edges in the pipelined loop)
+        if (vs && kku < n_l) a.Gb[upos] = 0.0f;
       }
     }
     if constexpr (LSTREAM) load_chunk(0);
@@ -1537,13 +1541,18 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       }
     }
     if constexpr (TRAIN) {  // publish the session positions (the atomics are long back by now)
-      if (vs && kk < n_s && kk < NL) sP[srow * PSTR + LSCP + kk] = spos0;
+      if (vs && kk < n_s && kk < NL) {
+        sP[srow * PSTR + LSCP + kk] = spos0;
+        a.Gb[spos0] = 0.0f;      // (a session use's item_b gradient is 0: cleared by the lane that drew the position)
+      }
       if (CSEG && vs && kk < n_s && kk < NL) sPc[srow * PSTR + LSCP + kk] = scpos0;
       for (int base = NL; base < pmax2 - 1; base += NL) {  // sessions longer than one chunk (rare)
         const int t = base + kk;
         if (vs && t < n_s && kk < NL) {
           const int sidt = a.b.hist_i_new[(size_t)bb * Sn + t];
-          sP[srow * PSTR + LSCP + t] = atomicAdd(&a.cur_item[sidt], 1);
+          const int spt = atomicAdd(&a.cur_item[sidt], 1);
+          sP[srow * PSTR + LSCP + t] = spt;
+          a.Gb[spt] = 0.0f;
           if constexpr (CSEG) sPc[srow * PSTR + LSCP + t] = atomicAdd(&a.cur_uc[a.p.item_cate[sidt]], 1);
         }
       }
@@ -1726,7 +1735,6 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
           } else if ((vs || oth) && vt) {
             const int pos = sP[(wave * SPW + s_sel) * PSTR + LSCP + t];
             const int cpos = CSEG ? sPc[(wave * SPW + s_sel) * PSTR + LSCP + t] : 0;
-            if (lead) a.Gb[pos] = 0.0f;
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) {
               st4_out(use_dst(pos, cpos, chb[kb]), dx[kb]);
@@ -2326,8 +2334,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
               dsp[p] += dot4(dx[kb], e1[p][kb]);
             }
             if (p == 1) TLSAN_STAMP(15);
-            if (vs && vp) {
-              if (lead) a.Gb[posp] = 0.0f;
+            if (vs && vp) {     // (Gb[posp]: cleared by the lane that drew the position, head of P3)
 #pragma unroll
               for (int kb = 0; kb < NB; ++kb) {
                 const f32x4 de = dx[kb] * sce;
@@ -2432,8 +2439,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             if (p == 1) TLSAN_STAMP(15);
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) dsp[p] += dot4(dx[kb], ep[kb]);
-            if (vs && vp) {
-              if (lead) a.Gb[posp] = 0.0f;
+            if (vs && vp) {     // (Gb[posp]: cleared by the lane that drew the position, head of P3)
 #pragma unroll
               for (int kb = 0; kb < NB; ++kb) {
                 const f32x4 de = dx[kb] * sce;
