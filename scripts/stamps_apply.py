@@ -84,3 +84,18 @@ if C == cfg["cate_count"]:
     order = np.argsort(-en)[:8]
     print("category blocks by end time: " + "  ".join("c%d end %.2f dur %.2f uses %d items %d" % (k, en[k], (x[k, 5] - x[k, 4]) / 100, uses[k], int((icl == k).sum())) for k in order))
     print("uses per category: p50 %d p90 %d max %d;  duration vs uses correlation %.2f" % (np.median(uses), np.percentile(uses, 90), uses.max(), np.corrcoef(uses, (x[:, 5] - x[:, 4]))[0, 1]))
+# the finalize workgroups by role (they are listed last, in launch order: dK entry blocks, small-parameter blocks, the
+# block that folds the sum-of-squares records); the last one to arrive also writes the step summary
+D = cfg["hidden_units"]
+nbK = D * D // 256
+x = s[C + nbI + nbU:]
+x = x[x[:, 4] > 0]
+if len(x) > nbK + 1:
+    en = (x[:, 5] - r0) / 100
+    stt = (x[:, 4] - r0) / 100
+    for nm, lo, hi in [("dK entries", 0, nbK), ("small params", nbK, len(x) - 1), ("fold", len(x) - 1, len(x))]:
+        e, d_ = en[lo:hi], (en - stt)[lo:hi]
+        print("  finalize %-12s n %3d | end p50/90/100 %5.2f %5.2f %5.2f | dur p50/90/100 %5.2f %5.2f %5.2f" % (
+            nm, hi - lo, *np.percentile(e, [50, 90, 100]), *np.percentile(d_, [50, 90, 100])))
+    k = int(np.argmax(en))
+    print("  last to end: finalize block %d (end %.2f, dur %.2f); second %.2f" % (k, en[k], en[k] - stt[k], np.sort(en)[-2]))

@@ -230,17 +230,6 @@ static bool isort_rows_ok(int rows) { return rows >= isort_min_rows() && (long)r
 static inline bool cate_seg(const tlsan_dims* d, const tlsan_batch* b) {
   return d->cate_count >= cseg_min_cates() && !uc_by_list(d, b);
 }
-// category position lists (k_cate_pos, tlsan_update.h): built with a batch's index when the table has few enough
-// categories for a fixed first piece per category, the categories are walked through their items (no category segments)
-// by ONE workgroup each (category_split below splits above 512 uses per category), and the batch's uses fit the shared piece
-#define CPL_MAXC 4096
-#define CPL_REST_CAP (1 << 20)
-static inline bool cpl_on(const tlsan_dims* d, const tlsan_batch* b) {
-  static const int en = [] { const char* e = getenv("TLSAN_CPL"); return e ? atoi(e) : 1; }();
-  if (!en || !b || d->cate_count > CPL_MAXC || cate_seg(d, b)) return false;
-  const long uses = (long)b->B * (d->Ls + b->Sn + 2);
-  return uses <= CPL_REST_CAP && (uses + d->cate_count - 1) / d->cate_count <= 512;
-}
 struct St {  // persistent state
   // two index slots (a batch's destination index depends only on its ids, so it lives with the
   // state, not in the per-call workspace whose layout follows the batch shape):
@@ -262,8 +251,6 @@ struct St {  // persistent state
   // the item side of the index from a partitioned counting sort of the batch's ids (IsortArgs; tables of isort_min_rows() rows or more)
   int32_t *is_bh[TLSAN_INDEX_SLOTS], *is_ids[TLSAN_INDEX_SLOTS], *is_bstart[TLSAN_INDEX_SLOTS], *is_nd[TLSAN_INDEX_SLOTS];
   int4* is_tmp[TLSAN_INDEX_SLOTS];
-  // category position lists (CplArgs), tables of at most CPL_MAXC categories
-  int2* cpl_hdr[TLSAN_INDEX_SLOTS]; int32_t *cpl_fix[TLSAN_INDEX_SLOTS], *cpl_rest[TLSAN_INDEX_SLOTS], *cpl_alloc;
   size_t bytes;
   int nbI, nbU, nbC;
 };
@@ -312,15 +299,6 @@ static void carve_state(const tlsan_dims* d, char* base, St* s) {
       s->is_nd[k] = (int32_t*)take(on ? 4 * (size_t)IS_MAXB : 0);
       s->is_tmp[k] = (int4*)take(on ? 16 * (size_t)ISORT_MAX_SLOTS : 0);
     }
-  }
-  {
-    const bool on = d->cate_count <= CPL_MAXC;
-    for (int k = 0; k < TLSAN_INDEX_SLOTS; ++k) {
-      s->cpl_hdr[k] = (int2*)take(on ? 8 * (size_t)d->cate_count : 0);
-      s->cpl_fix[k] = (int32_t*)take(on ? 4 * (size_t)d->cate_count * CPL_F : 0);
-      s->cpl_rest[k] = (int32_t*)take(on ? 4 * (size_t)CPL_REST_CAP : 0);
-    }
-    s->cpl_alloc = (int32_t*)take(4 * 64);
   }
   s->S_total = base ? &s->hdr->St : nullptr;
   s->bytes = o;
@@ -412,7 +390,6 @@ static void fill_apply(ApplyArgs& A, const tlsan_dims* d, const Shape& s, const 
   A.cate_off = st.cate_off; A.cate_cnt = st.cate_cnt; A.cate_items = st.cate_items;
   A.uc_list = uc_by_list(d, b) ? st.uc_list[k] : nullptr;
   A.cseg = (b && cate_seg(d, b)) ? 1 : 0;
-  if (cpl_on(d, b)) { A.cpl_hdr = st.cpl_hdr[k]; A.cpl_fix = st.cpl_fix[k]; A.cpl_rest = st.cpl_rest[k]; }
   A.Rc64 = st.Rc64;
   A.csplit = 1; A.cpass = 256;
   A.hot_n = st.hdr ? &st.hdr->n_hot[k] : nullptr; A.hot_list = st.hot_list[k]; A.nbH = 0;
@@ -713,7 +690,6 @@ static int build_index(const tlsan_dims* d, const tlsan_batch* b, const int32_t*
   memset(&ca, 0, sizeof(ca));
   ca.b = *b; ca.Ls = d->Ls;
   ca.n_hot = &st.hdr->n_hot[k];
-  ca.cpl_alloc = cpl_on(d, b) ? st.cpl_alloc + k : nullptr;   // (reset by the counting launch: a memset node costs the host 30 us)
   ca.cnt_item = st.cnt_item[k]; ca.cnt_user = st.cnt_user[k]; ca.cnt_uc = st.cnt_uc[k];
   ca.item_cate = cseg ? item_cate : nullptr; ca.cseg = cseg ? 1 : 0;
   ca.ncate = d->cate_count;
@@ -795,15 +771,6 @@ static int build_index(const tlsan_dims* d, const tlsan_batch* b, const int32_t*
   if (uc_by_list(d, b)) {
     hipLaunchKernelGGL(k_uc_fill, dim3((b->B + 255) / 256), dim3(256), 0, hs, b->u_cate, b->B, d->cate_count, st.cur_uc[k], st.uc_list[k]);
     CHECK_LAUNCH("k_uc_fill");
-  }
-  if (cpl_on(d, b)) {   // the categories' position lists for the row sums (after the scan and the sample lists they read)
-    CplArgs c;
-    c.cate_off = st.cate_off; c.cate_cnt = st.cate_cnt; c.cate_items = st.cate_items;
-    c.off_item = st.off_item[k]; c.off_uc = st.off_uc[k];
-    c.uc_list = uc_by_list(d, b) ? st.uc_list[k] : nullptr;
-    c.hdr = st.cpl_hdr[k]; c.fix = st.cpl_fix[k]; c.rest = st.cpl_rest[k]; c.alloc = st.cpl_alloc + k; c.rest_cap = CPL_REST_CAP;
-    hipLaunchKernelGGL(k_cate_pos, dim3((d->cate_count + CPL_WPB - 1) / CPL_WPB), dim3(64 * CPL_WPB), 0, hs, c, d->cate_count);
-    CHECK_LAUNCH("k_cate_pos");
   }
   return TLSAN_OK;
 }

@@ -48,7 +48,6 @@ struct DeltaRec {
 #define AP_HOT_CAP 64    // ... when there are at most this many (the head of a Zipf distribution: a handful)
 struct CountArgs {
   int32_t* n_hot;       // reset here for the scan that follows
-  int32_t* cpl_alloc;   // optional: cursor of the category position lists (CplArgs.alloc), reset here for k_cate_pos
   tlsan_batch b;
   int32_t Ls;
   int32_t* cnt_item; int32_t* cnt_user; int32_t* cnt_uc;  // persistent, zero at rest
@@ -73,7 +72,6 @@ struct CountArgs {
 __device__ __forceinline__ void count_samples_block(const CountArgs& a, int* hist, int b, int nthr) {
   const int B = a.b.B;
   if (b == 0 && a.n_hot) *a.n_hot = 0;
-  if (b == 0 && a.cpl_alloc) *a.cpl_alloc = 0;
   const bool small = a.ncate <= COUNT_LDS_CATES;
   if (small) {
     for (int c = threadIdx.x; c < a.ncate; c += nthr) hist[c] = 0;
@@ -154,86 +152,6 @@ __global__ __launch_bounds__(256) void k_uc_fill(const int32_t* __restrict__ u_c
   }
   __syncthreads();
   if (b < B) uc_list[hist[c] + rank] = b;
-}
-
-// Category position lists (round 5): where the row-sum pass finds a category's gradient rows.  A category workgroup of the
-// row-sum launch used to walk category -> items (static CSR) -> item offsets -> LDS expansion -> rows: four dependent
-// memory round trips where the item and user workgroups need two.  The expansion depends only on the batch's index, so it
-// runs here, with the index, two batches ahead on the side stream: entry j of category c's list = a position of Gi (>= 0:
-// the category half of that row) or ~(position of Gc) (the u_cate uses), items in CSR order, then the u_cate uses.  The
-// first CPL_F entries of every category sit at a fixed place (fix[c * CPL_F ..]: loaded with the header, one round
-// trip), the others at `rest + base`, drawn from one cursor (the order of the draws does not matter: a list is found
-// through its header).
-#define CPL_F 128
-struct CplArgs {
-  const int32_t* cate_off; const int32_t* cate_cnt; const int32_t* cate_items;   // static CSR category -> items
-  const int32_t* off_item; const int32_t* off_uc;
-  const int32_t* uc_list;   // optional: samples of every category (then Gc is in sample order)
-  int2* hdr;                // [C] (entries, base of the entries past CPL_F in rest); entries < 0: no list, walk the items
-  int32_t* fix;             // [C][CPL_F]
-  int32_t* rest; int32_t* alloc; int32_t rest_cap;
-};
-
-// One wavefront per category, CPL_WPB categories per workgroup, no LDS and no barriers: the launch shares the GPU with the
-// main stream, whose fused kernel needs whole CUs -- few, fat workgroups touch few of them.
-#define CPL_WPB 16
-__global__ __launch_bounds__(64 * CPL_WPB) void k_cate_pos(CplArgs a, int C) {
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * CPL_WPB + (threadIdx.x >> 6);
-  if (c >= C) return;
-  const int i0 = a.cate_off[c], ni = a.cate_cnt[c];
-  const int ou = a.off_uc[c], nu = a.off_uc[c + 1] - ou;
-  // ---- the first 64 items' segments (most categories have no more), and the category's item uses in all
-  int lo0 = 0, cnt0 = 0;
-  if (lane < ni) {
-    const int item = a.cate_items[i0 + lane];
-    lo0 = a.off_item[item];
-    cnt0 = a.off_item[item + 1] - lo0;
-  }
-  int tot = cnt0;
-  for (int p0 = 64; p0 < ni; p0 += 64)
-    if (p0 + lane < ni) {
-      const int item = a.cate_items[i0 + p0 + lane];
-      tot += a.off_item[item + 1] - a.off_item[item];
-    }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) tot += __shfl_xor(tot, o);
-  const int n = tot + nu;
-  int base = 0;
-  if (n > CPL_F) {
-    if (lane == 0) base = atomicAdd(a.alloc, n - CPL_F);
-    base = __shfl(base, 0);
-  }
-  const bool ok = n <= CPL_F || base + (n - CPL_F) <= a.rest_cap;
-  if (lane == 0) a.hdr[c] = make_int2(ok ? n : -1, base);
-  if (!ok) return;
-  auto put = [&](int k, int v) {
-    if (k < CPL_F) a.fix[(size_t)c * CPL_F + k] = v;
-    else a.rest[(size_t)base + (k - CPL_F)] = v;
-  };
-  // ---- expansion, 64 items per pass
-  int run = 0;
-  for (int p0 = 0; p0 < ni; p0 += 64) {
-    int lo = lo0, cnt = cnt0;
-    if (p0 > 0) {
-      lo = 0; cnt = 0;
-      if (p0 + lane < ni) {
-        const int item = a.cate_items[i0 + p0 + lane];
-        lo = a.off_item[item];
-        cnt = a.off_item[item + 1] - lo;
-      }
-    }
-    int inc = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int t = __shfl_up(inc, o);
-      if (lane >= o) inc += t;
-    }
-    const int pre = run + inc - cnt;
-    for (int j = 0; j < cnt; ++j) put(pre + j, lo + j);
-    run += __shfl(inc, 63);
-  }
-  for (int j = lane; j < nu; j += 64) put(run + j, ~(a.uc_list ? a.uc_list[ou + j] : ou + j));
 }
 
 struct PackArgs {
@@ -1039,6 +957,15 @@ __device__ __forceinline__ double acq_f64(const double* p) {
 
 __device__ __forceinline__ void step_summary(const FinArgs& a, int nsqd, double* shd) {
   const int tid = threadIdx.x;
+  // (thread 0's scalars first: their round trip overlaps the partial sums')
+  float P = 0.0f, sc0 = 0.0f, sc1 = 0.0f;
+  double St0 = 0.0;
+  if (tid == 0) {
+    P = a.hdr->P;
+    St0 = acq_f64(a.S_total);
+    sc0 = acq_f32(a.scal + 0);
+    sc1 = acq_f32(a.scal + 1);
+  }
   double sq = 0.0;
   for (int k = tid; k < nsqd; k += 256) sq += (double)acq_f32(a.sqd + k);
   shd[tid] = sq;
@@ -1048,9 +975,7 @@ __device__ __forceinline__ void step_summary(const FinArgs& a, int nsqd, double*
     __syncthreads();
   }
   if (tid == 0) {
-    const float P = a.hdr->P;
-    const double St = acq_f64(a.S_total) * (double)P * (double)P;  // true tables = P * stored
-    const float sc0 = acq_f32(a.scal + 0), sc1 = acq_f32(a.scal + 1);
+    const double St = St0 * (double)P * (double)P;  // true tables = P * stored
     sq = shd[0] + (double)sc1 + (double)a.reg * (double)a.reg * St;
     const float norm = (float)sqrt(sq);
     const float coef = a.clip / fmaxf(norm, a.clip);
@@ -1143,9 +1068,10 @@ __device__ __forceinline__ void dense_finalize_block(const FinArgs& a, int nbK, 
     const int idx = blk * 256 + tid;
     if (idx < D * D) {
       // the partials in chunks of KCH, all loads of a chunk in flight at once (clamped addresses, masked sum), fixed order
-      // (64 since round 5: 256 partials in four dependent rounds instead of eight; the sum's order does not depend on the
-      //  chunk.  64 entries per workgroup with a wavefront per class of partials -- 256 workgroups, one round -- was
-      //  slower: the extra workgroups delay the row sums behind them, profiles/r05_cate_lists.md)
+      // (64 since round 5: 256 partials in four dependent rounds instead of eight, about 2 us each; the sum's order does
+      //  not depend on the chunk.  Measured and not kept, profiles/r05_cate_lists.md: 64 entries per workgroup with a
+      //  wavefront per class of partials -- 256 workgroups, one round -- delays the row sums behind them by more than
+      //  it gains; 256 B of padding between the partials, against channel conflicts of the 64 KB stride, is slower)
       constexpr int KCH = TLSAN_KCH;
       float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f;
       for (int s0 = 0; s0 < a.nsplit; s0 += KCH) {
@@ -1219,7 +1145,8 @@ __device__ __forceinline__ void dense_finalize_block(const FinArgs& a, int nbK, 
     __syncthreads();
   }
   if (tid == 0 && blk < nbK + nbS) pub_f32(a.sqd + blk, (float)shd[0]);
-  if (blk == 0 && tid < 32) {  // loss sum and per-use square sum: 16 lanes each, fixed order
+  // (in the workgroup that folds the sum-of-squares records: it ends early; the dK entry blocks end the dense chain)
+  if (blk == nbK + nbS && tid < 32) {  // loss sum and per-use square sum: 16 lanes each, fixed order
     const int which = tid >> 4, rl = tid & 15;
     float t = 0.0f;
     for (int r0 = rl; r0 < a.nrec; r0 += 16 * 8) {
@@ -1297,8 +1224,6 @@ struct ApplyArgs {
   const int4* urec_item; const int4* urec_user;   // lazy L2: (row, first position, uses) of the rows used this step
   const int32_t* cate_off; const int32_t* cate_cnt; const int32_t* cate_items;  // static CSR
   const int32_t* uc_list;  // optional: samples of every category (segments off_uc); then Gc is in sample order
-  // optional: the categories' position lists (k_cate_pos, built with the index): header, first CPL_F entries, the others
-  const int2* cpl_hdr; const int32_t* cpl_fix; const int32_t* cpl_rest;
   int32_t cseg;            // != 0 (many categories): a category's segment of Gc holds its u_cate uses AND the category halves
                            // of its items' uses (k_fwd_bwd, FwdArgs.cseg): the category blocks sum that one segment and
                            // do not walk the category's items
@@ -1529,54 +1454,10 @@ __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx
   if constexpr (MODE != AP_SUMSQ) {
     // (CSEG: nothing to walk -- the category halves of the items' uses sit in this category's segment of Gc, with the
     //  u_cate uses: `nu` below counts both)
+    const int i0 = a.cseg ? 0 : a.cate_off[c], ni = a.cseg ? 0 : a.cate_cnt[c];
     int ou = a.off_uc[c];
     const int nu_all = a.off_uc[c + 1] - ou;
     nu = nu_all;
-    // ---- the category's position list, when the index build left one (k_cate_pos): header and first entries in ONE
-    // round trip (their addresses follow from c alone), then the rows; the entries past CPL_F are loaded while the first
-    // rows are in flight
-    bool listed = false;
-    if constexpr (!CSPLIT) {
-      if (a.cpl_hdr != nullptr && !a.cseg) {
-        const int2 h = a.cpl_hdr[c];
-        const int p0v = tid < CPL_F ? a.cpl_fix[(size_t)c * CPL_F + tid] : 0;
-        if (h.x >= 0) {
-          listed = true;
-          const int nrest = h.x - CPL_F;
-          const int32_t* rest = a.cpl_rest + h.y;
-          // the entries past CPL_F go from memory straight into the LDS list (global_load_lds: no registers held while
-          // the first rows are summed), behind the first CPL_F entries: up to CH0 of them, then chunks of AP_CAP
-          constexpr int CH0 = ((AP_CAP - CPL_F) / 256) * 256;
-          const int wv = __builtin_amdgcn_readfirstlane(wave);
-          auto lds_fill = [&](int k0, int at, int cap) {   // entries [k0, k0 + cap) of rest -> sh_pos[at ...]
-            for (int u = 0; u * 256 < cap && k0 + u * 256 < nrest; ++u) {
-              const int k = min(k0 + u * 256 + tid, nrest - 1);   // (clamped: the lanes past the end fill unused words)
-              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rest + k),
-                                               (__attribute__((address_space(3))) void*)(sh_pos + at + u * 256 + wv * 64), 4, 0, 0);
-            }
-          };
-          if (tid < CPL_F) sh_pos[tid] = p0v;
-          if (nrest > 0) lds_fill(0, CPL_F, CH0);
-          __syncthreads();
-          AP_STAMP(1);
-          list_accum<NCH>(a, sh_pos, min(h.x, CPL_F), gid, l16, W4, acc);
-          if (nrest > 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            list_accum<NCH>(a, sh_pos + CPL_F, min(CH0, nrest), gid, l16, W4, acc);
-            for (int k0 = CH0; k0 < nrest; k0 += AP_CAP) {   // (a very hot category)
-              __syncthreads();   // the readers of the chunk before
-              lds_fill(k0, 0, AP_CAP);
-              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-              __syncthreads();
-              list_accum<NCH>(a, sh_pos, min(AP_CAP, nrest - k0), gid, l16, W4, acc);
-            }
-          }
-          AP_STAMP(2);
-        }
-      }
-    }
-    const int i0 = (a.cseg || listed) ? 0 : a.cate_off[c], ni = (a.cseg || listed) ? 0 : a.cate_cnt[c];
     int PS = 256;  // items per pass
     if constexpr (CSPLIT) {  // this workgroup's share of the u_cate uses and its pass size
       PS = a.cpass;
@@ -1584,7 +1465,7 @@ __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx
       ou += split * chunk;
       nu = max(0, min(chunk, nu_all - split * chunk));
     }
-    bool first = !listed;
+    bool first = true;
     for (int p0 = split * PS; first || p0 < ni; p0 += nsplit * PS, first = false) {
       int lo = 0, n = 0;
       if (tid < PS && p0 + tid < ni) {
@@ -2257,6 +2138,8 @@ __global__ __launch_bounds__(256) void k_apply(ApplyArgs a) {
 //                       PRESUM mode (exact per-row sums -> Rc / Ri / Rb / Ru, counters reset)
 //   k_update_lazy     : elementwise w -= scale * sum for the used rows + the dense parameters
 // Same arithmetic per element as k_apply<AP_UPDATE, lazy> (the sums are rounded to float there too).
+// (the narrow form is held to 96 registers -- five workgroups per CU: left alone, the compiler takes 124 for the 64 loads the
+//  dK entry blocks keep in flight and costs the launch a fifth of its residency; held, it needs 91 and spills nothing)
 template <int D, int DH, bool WIDE, bool CSPLIT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? 3 : 5))) void k_finalize_presum(FinArgs f, int nbK, int nbS, ApplyArgs a) {
   constexpr int NC = WIDE ? 2 : 1, NI = WIDE ? 2 : 1, NU = WIDE ? 4 : 2;
