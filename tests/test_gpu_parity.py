@@ -274,9 +274,6 @@ def test_errors():
     cfg = make_config(d=64, optimizer="adagrad")          # not one of model.py:188-195
     with pytest.raises(ValueError):
         Model(cfg, np.zeros(cfg["item_count"], np.int32))
-    cfg = make_config(d=64, dropout=0.1)                   # dropout is built for fp32 matrix products (any table storage)
-    with pytest.raises(NotImplementedError):
-        Model(cfg, np.zeros(cfg["item_count"], np.int32), matrix_dtype="bf16")
     cfg = make_config(d=64)
     m = Model(cfg, np.zeros(cfg["item_count"], np.int32))
     b, _ = random_batch(cfg, B=4, Sn=2, seed=1)
@@ -821,7 +818,7 @@ def test_bf16_matrix_products(d, table_dtype, Ls):
         assert np.linalg.norm(a - r) < 0.15 * np.linalg.norm(r) + 1e-9, (k, np.linalg.norm(a - r) / np.linalg.norm(r))
     for k in outs[0]["grads"]:
         assert np.array_equal(outs[0]["grads"][k], outs[1]["grads"][k]), k
-    # a train step: lazy == dense to fp32 rounding in this mode too, and dropout is refused
+    # a train step: lazy == dense to fp32 rounding in this mode too
     ms = [_model(cfg, cat, p, l2_mode=l2, table_dtype=table_dtype, matrix_dtype="bf16") for l2 in ("dense", "lazy")]
     ls = [m.train(None, _tuple(b), 0.5) for m in ms]
     assert abs(ls[0] - ls[1]) < 1e-5 * max(1.0, abs(ls[0]))
@@ -829,11 +826,41 @@ def test_bf16_matrix_products(d, table_dtype, Ls):
     for k in pa:
         tol = 2e-6 if table_dtype == "f32" else 2e-2     # (bf16 tables: two stochastic roundings apart)
         assert np.abs(np.asarray(pa[k], np.float64) - pb[k]).max() <= tol * np.abs(pa[k]).max() + 1e-9, k
-    from tlsan_amd._lib import TlsanError
-    with pytest.raises((TlsanError, NotImplementedError)):
-        cfg2 = make_config(U=50, I=60, C=5, d=128, dropout=0.1)
-        b2, cat2 = random_batch(cfg2, B=8, Sn=2, seed=1)
-        _model(cfg2, cat2, None, matrix_dtype="bf16").train(None, _tuple(b2), 0.5)
+
+
+@pytest.mark.parametrize("d,table_dtype,rate,Ls", [(64, "f32", 0.2, 10), (128, "bf16", 0.3, 10), (128, "f32", 0.3, 33),
+                                                  (256, "f32", 0.4, 10)])
+def test_dropout_with_bf16_matrix_products(d, table_dtype, rate, Ls):
+    """config['dropout'] > 0 (model.py:116-118, 428-431) with matrix_dtype='bf16' (round 5; refused before): the
+    same keep / drop pattern as the fp32 kernels draw -- a train step follows the oracle's step under that pattern
+    to the bf16 tolerances of test_bf16_matrix_products (loss 5e-4, parameter changes to 15 % of their norm), far
+    inside the distance to the step WITHOUT the pattern; a second model repeats it bitwise."""
+    cfg = make_config(U=60, I=80, C=9, d=d, regulation_rate=1e-3, dropout=rate, Ls=Ls)
+    p = _p32(random_params(cfg, seed=97))
+    if table_dtype == "bf16":
+        for k in BF16_TABLES:
+            p[k] = _bf16_round(p[k]).astype(np.float64)
+    b, cat = random_batch(cfg, B=45, Sn=3, seed=98)
+    outs = []
+    for rep in range(2):
+        m = _model(cfg, cat, p, table_dtype=table_dtype, matrix_dtype="bf16")
+        seed = m.dropout_seed()
+        l = m.train(None, _tuple(b), 0.6)
+        outs.append((l, m.get_params()))
+    loss, newq, info = orc.train_step(p, cat, b, 8, cfg["regulation_rate"], lr=0.6, dropout=(rate, seed))
+    plain = orc.loss_fn(p, cat, b, 8, cfg["regulation_rate"])
+    l, got = outs[0]
+    tol = 5e-4 * max(1.0, abs(loss))
+    assert abs(l - loss) < tol, (l, loss, plain)
+    assert abs(plain - loss) > 4 * tol, (plain, loss)          # the pattern matters, well beyond the bf16 tolerance
+    for k in ("fwa1_W1", "fwa1_W2", "fwa2_W1", "fwa2_W2", "dense_K", "dense_b"):
+        du = np.asarray(got[k], np.float64).reshape(p[k].shape) - p[k]
+        dr = newq[k] - p[k]
+        assert np.linalg.norm(du - dr) < 0.15 * np.linalg.norm(dr) + 1e-9, (k, np.linalg.norm(du - dr) / np.linalg.norm(dr))
+    if table_dtype == "f32":
+        assert outs[0][0] == outs[1][0]
+        for k in got:
+            assert np.array_equal(np.asarray(got[k]), np.asarray(outs[1][1][k])), k
 
 
 @pytest.mark.parametrize("optimizer,lr", [("adam", 0.05), ("rmsprop", 0.02), ("adadelta", 1.0)])

@@ -636,7 +636,7 @@ static int launch_fwd(const Shape& s, bool train, const FwdArgs& a, hipStream_t 
   else if (s.D == 128) e = tlsan_launch_fwd_bwd_d128(train, lstream, a, grid, hs, ev);
   else e = tlsan_launch_fwd_bwd_d256(train, lstream, a, grid, hs, ev);
   if (e == hipErrorNotSupported)
-    return fail(TLSAN_E_UNSUPPORTED, "dropout > 0 is built for fp32 matrix products (and for train steps only)");
+    return fail(TLSAN_E_UNSUPPORTED, "dropout > 0 is built for train steps only (and not for the 8-sample workgroup form)");
   if (e != hipSuccess) return fail(TLSAN_E_LAUNCH, "k_fwd_bwd: %s", hipGetErrorString(e));
   return TLSAN_OK;
 }

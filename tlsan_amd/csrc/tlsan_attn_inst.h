@@ -55,11 +55,18 @@ static hipError_t launch_variant_dt(const FwdArgs& a, int grid, hipStream_t st, 
   return hipGetLastError();
 }
 
-// bf16 table storage and bf16 matrix products: window in registers or streamed; dropout with fp32 matrix products only
+// bf16 table storage and bf16 matrix products: window in registers or streamed; dropout with either kind of matrix product
 template <int D, int DH, bool TRAIN, bool LSTREAM>
 static hipError_t launch_variant(const FwdArgs& a, int grid, hipStream_t st, LaunchEvents ev) {
-  if (a.p.matrix_dtype == TLSAN_MATRIX_BF16) {  // bf16 matrix products: either window form, either table storage, no dropout
-    if (a.drop_thr != 0) return hipErrorNotSupported;
+  if (a.p.matrix_dtype == TLSAN_MATRIX_BF16) {  // bf16 matrix products: either window form, either table storage
+    if (a.drop_thr != 0) {   // dropout (model.py:428-431): training only
+      if constexpr (TRAIN) {
+        if (a.p.table_dtype == TLSAN_TABLE_BF16) return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_BF16, true, TLSAN_MATRIX_BF16>(a, grid, st, ev);
+        return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_F32, true, TLSAN_MATRIX_BF16>(a, grid, st, ev);
+      } else {
+        return hipErrorNotSupported;
+      }
+    }
     if (a.p.table_dtype == TLSAN_TABLE_BF16) return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_BF16, false, TLSAN_MATRIX_BF16>(a, grid, st, ev);
     return launch_variant_dt<D, DH, TRAIN, LSTREAM, TLSAN_TABLE_F32, false, TLSAN_MATRIX_BF16>(a, grid, st, ev);
   }

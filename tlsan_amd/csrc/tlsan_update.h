@@ -10,6 +10,7 @@
 // sums are order-independent (exact_term) or in a fixed order, so two runs are bitwise equal.
 #pragma once
 #include "tlsan_common.h"
+#include <type_traits>
 
 // index slots of the state: the batch being trained and up to two announced successors (tlsan_batch_index)
 #define TLSAN_INDEX_SLOTS 3
@@ -1072,21 +1073,26 @@ __device__ __forceinline__ void dense_finalize_block(const FinArgs& a, int nbK, 
       //  not depend on the chunk.  Measured and not kept, profiles/r05_cate_lists.md: 64 entries per workgroup with a
       //  wavefront per class of partials -- 256 workgroups, one round -- delays the row sums behind them by more than
       //  it gains; 256 B of padding between the partials, against channel conflicts of the 64 KB stride, is slower)
-      constexpr int KCH = TLSAN_KCH;
+      //  (32 when there are no more partials than that -- k_dk_partial's launches at d = 256: clamped loads are still loads)
       float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f;
-      for (int s0 = 0; s0 < a.nsplit; s0 += KCH) {
-        float v[KCH];
+      auto chunks = [&](auto kch) {
+        constexpr int KCH = decltype(kch)::value;
+        for (int s0 = 0; s0 < a.nsplit; s0 += KCH) {
+          float v[KCH];
 #pragma unroll
-        for (int u = 0; u < KCH; ++u)
-          v[u] = a.Kp[(size_t)min(s0 + u, a.nsplit - 1) * D * D + idx];
+          for (int u = 0; u < KCH; ++u)
+            v[u] = a.Kp[(size_t)min(s0 + u, a.nsplit - 1) * D * D + idx];
 #pragma unroll
-        for (int u = 0; u < KCH; u += 4) {
-          g0 += s0 + u + 0 < a.nsplit ? v[u + 0] : 0.0f;
-          g1 += s0 + u + 1 < a.nsplit ? v[u + 1] : 0.0f;
-          g2 += s0 + u + 2 < a.nsplit ? v[u + 2] : 0.0f;
-          g3 += s0 + u + 3 < a.nsplit ? v[u + 3] : 0.0f;
+          for (int u = 0; u < KCH; u += 4) {
+            g0 += s0 + u + 0 < a.nsplit ? v[u + 0] : 0.0f;
+            g1 += s0 + u + 1 < a.nsplit ? v[u + 1] : 0.0f;
+            g2 += s0 + u + 2 < a.nsplit ? v[u + 2] : 0.0f;
+            g3 += s0 + u + 3 < a.nsplit ? v[u + 3] : 0.0f;
+          }
         }
-      }
+      };
+      if (a.nsplit > 32) chunks(std::integral_constant<int, TLSAN_KCH>());
+      else chunks(std::integral_constant<int, 32>());
       g = (g0 + g1) + (g2 + g3);
       a.gd[L.K + idx] = g;
       owner = true;

@@ -212,7 +212,7 @@ class Model(object):
             raise ValueError("init must be 'numpy' or 'device'")
         # matrix_dtype: arithmetic of the fused kernel's matrix products -- "f32": exact fp32 MFMA (the reference's
         # precision); "bf16": operands rounded to bfloat16, fp32 products and sums (include/tlsan.h,
-        # tlsan_params.matrix_dtype).  An extension for BASELINE.json configs[2]; any window the kernels take (in registers or streamed), no dropout.
+        # tlsan_params.matrix_dtype).  An extension for BASELINE.json configs[2]; any window the kernels take (in registers or streamed), with or without dropout.
         if matrix_dtype not in ("f32", "bf16"):
             raise ValueError("matrix_dtype must be 'f32' or 'bf16'")
         self.matrix_dtype = matrix_dtype
@@ -230,8 +230,6 @@ class Model(object):
         self.dropout = float(config.get("dropout", 0.0))           # model.py:116-118, 428-431
         if not 0.0 <= self.dropout < 1.0:
             raise ValueError("dropout must be in [0, 1)")
-        if self.dropout > 0.0 and matrix_dtype != "f32":
-            raise NotImplementedError("dropout > 0 is built for fp32 matrix products")
         self._seed = int(seed)
         self.optimizer = config.get("optimizer", "sgd")           # model.py:188-195
         if self.optimizer not in OPTIMIZERS:
