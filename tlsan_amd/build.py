@@ -18,10 +18,15 @@ SOURCES = ["tlsan_api.hip", "tlsan_attn_d64.hip", "tlsan_attn_d128.hip", "tlsan_
 # -fno-honor-nans on the d <= 128 units: fmaxf on an MFMA result otherwise gets a canonicalising v_max x, x, x in front of it
 # (cdna_hip_programming.md, pitfalls): 78 vector instructions of the bf16-operand kernel, 18 of the fp32 one; same results on
 # finite data (round 5 A/B, profiles/r05_isa_budget.md)
-_NONAN = ["-fno-honor-nans"]
+# -fno-signed-zeros on the same units: 2 722 -> 2 692 vector instructions (bf16 operands 3 019 -> 2 930); step 59.3 -> 58.5 us
+# (bf16 50.65 -> 50.2), four interleaved rounds, same loss to the last digit (profiles/r05_ab_fpflags.txt); -ffast-math
+# gains no more and reassociates
+_NONAN = ["-fno-honor-nans", "-fno-signed-zeros"]   # (no canonicalising v_max before fmaxf; x + 0 / 0 - x folds: the sign of a zero is never looked at)
 SOURCE_FLAGS = {"tlsan_attn_d64.hip": _NONAN, "tlsan_attn_d128.hip": _NONAN, "tlsan_attn_d128w4.hip": _NONAN,
                 "tlsan_attn_d256.hip": ["-mllvm", "-sink-insts-to-avoid-spills"],
-                "tlsan_attn_d256s.hip": ["-mllvm", "-disable-machine-licm", "-mllvm", "-sink-insts-to-avoid-spills"]}
+                # (the two FP switches on the streamed d = 256 unit: C5 305-307 -> 302-304 us/step, three interleaved rounds,
+                #  profiles/r05_ab_fpflags_d256.txt; nothing on the Ls = 10 unit, which keeps its flags)
+                "tlsan_attn_d256s.hip": ["-mllvm", "-disable-machine-licm", "-mllvm", "-sink-insts-to-avoid-spills"] + _NONAN}
 if os.environ.get("TLSAN_SOURCE_FLAGS"):   # (experiments: JSON {source: [flags]}, replaces the entries it names)
     import json
     SOURCE_FLAGS.update(json.loads(os.environ["TLSAN_SOURCE_FLAGS"]))
