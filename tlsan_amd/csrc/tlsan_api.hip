@@ -13,9 +13,6 @@
 #include <string.h>
 
 #include "tlsan_common.h"
-#if TLSAN_CHAIN
-#include <unordered_map>
-#endif
 #include "tlsan_eval.h"
 #include "tlsan_update.h"
 #include "tlsan_shard.h"
@@ -254,9 +251,6 @@ struct St {  // persistent state
   // the item side of the index from a partitioned counting sort of the batch's ids (IsortArgs; tables of isort_min_rows() rows or more)
   int32_t *is_bh[TLSAN_INDEX_SLOTS], *is_ids[TLSAN_INDEX_SLOTS], *is_bstart[TLSAN_INDEX_SLOTS], *is_nd[TLSAN_INDEX_SLOTS];
   int4* is_tmp[TLSAN_INDEX_SLOTS];
-#if TLSAN_CHAIN
-  int32_t* chain;   // timing prototype: placed / arrived counters and 64 go words, 128 bytes apart (FwdArgs.chain)
-#endif
   size_t bytes;
   int nbI, nbU, nbC;
 };
@@ -306,9 +300,6 @@ static void carve_state(const tlsan_dims* d, char* base, St* s) {
       s->is_tmp[k] = (int4*)take(on ? 16 * (size_t)ISORT_MAX_SLOTS : 0);
     }
   }
-#if TLSAN_CHAIN
-  s->chain = (int32_t*)take(128 * 66);
-#endif
   s->S_total = base ? &s->hdr->St : nullptr;
   s->bytes = o;
 }
@@ -633,28 +624,6 @@ int tlsan_state_recategorize(const tlsan_dims* d, const tlsan_params* p, void* s
   return build_cate_csr(d, p, st, (hipStream_t)stream);
 }
 
-#if TLSAN_CHAIN
-// ---- timing prototype of VERDICT r4 item 2: k_fwd_bwd on one stream, the row sums + update on another, chained by memory
-// flags; the streams swap roles every step, so that the next k_fwd_bwd follows the update in stream order.  NOT coherent
-// (k_fwd_bwd's stores are not released to the other XCDs before the flag): the numbers it produces may be wrong, its
-// TIMING is what is looked at.
-struct ChainHost {
-  hipStream_t s[2] = {nullptr, nullptr};
-  int flip = 0;
-  bool busy = false;                       // the two streams hold work of chained steps
-  std::unordered_map<void*, long> placed, arrived;   // cumulative workgroup counts per state
-  std::unordered_map<void*, uint32_t> seq;
-  bool on = false;                         // this step is chained
-  hipStream_t X = nullptr, Y = nullptr;    // this step's k_fwd_bwd stream / tail stream
-  void* state = nullptr;
-};
-static ChainHost g_ch;
-static bool chain_env() {
-  static const int v = [] { const char* e = getenv("TLSAN_CHAIN_ON"); return e ? atoi(e) : 1; }();
-  return v != 0;
-}
-#endif
-
 static int launch_fwd(const Shape& s, bool train, const FwdArgs& a, hipStream_t hs, int grp = 0) {
   int grid = a.ngroups < 4096 ? a.ngroups : 4096;
   if (train && a.fuse_dk) grid = fwd_train_grid(a.ngroups);
@@ -840,28 +809,6 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   a.ngroups = (b->B + grp - 1) / grp;
   a.fuse_dk = fused_dk(s.D, a.ngroups) ? 1 : 0;
   prof_mark(1, hs);
-#if TLSAN_CHAIN
-  uint32_t ch_seq = 0;
-  if (g_ch.on) {
-    const int grid = a.fuse_dk ? fwd_train_grid(a.ngroups) : (a.ngroups < 4096 ? a.ngroups : 4096);
-    g_ch.placed[g_ch.state] += grid; g_ch.arrived[g_ch.state] += grid;
-    ch_seq = ++g_ch.seq[g_ch.state];
-    a.chain = st.chain; a.chain_placed = (int32_t)g_ch.placed[g_ch.state]; a.chain_arrived = (int32_t)g_ch.arrived[g_ch.state];
-    a.chain_seq = ch_seq;
-    if ((rc = launch_fwd(s, true, a, g_ch.X, grp))) return rc;
-    // every workgroup of k_fwd_bwd resident: the row sums may go to the other stream (they wait for the go words)
-    volatile uint32_t* w = (volatile uint32_t*)out->started;
-    const auto t0 = std::chrono::steady_clock::now();
-    unsigned long polls = 0;
-    while (*w != out->started_value) {
-      ++polls;
-      __builtin_ia32_pause();
-      if ((polls & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
-        return fail(TLSAN_E_LAUNCH, "chain: k_fwd_bwd was not resident within 30 s");
-    }
-    hs = g_ch.Y;
-  } else
-#endif
   if ((rc = launch_fwd(s, true, a, hs, grp))) return rc;
   prof_mark(2, hs);
   const int nsplit = a.fuse_dk ? fwd_train_grid(a.ngroups) : dk_nsplit(b->B, s.D);   // dK partials the finalize sums
@@ -891,15 +838,9 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   f.out_loss = out ? out->loss : nullptr;
   f.out_gnorm = out ? out->gnorm : nullptr;
   f.out_sq = out ? out->sq_rows : nullptr;
-#if TLSAN_CHAIN
-  if (g_ch.on) { f.chain_go = st.chain + 64; f.chain_seq = ch_seq; }
-#endif
   if (presum) {
     // lazy update: the exact row sums of the apply pass share the launch (they wait for nothing it produces)
     ApplyArgs A = *presum;
-#if TLSAN_CHAIN
-    if (g_ch.on) { A.chain_go = st.chain + 64; A.chain_seq = ch_seq; }
-#endif
     lazy_blocks(A, b->B, b->Sn);
     A.nbC = A.cseg ? (A.C + AP_ROWS_PB - 1) / AP_ROWS_PB : A.C * A.csplit;
     A.nbH = AP_HOT_CAP;   // hot item rows: a workgroup each, leading the grid
@@ -1038,29 +979,8 @@ int tlsan_train_step_opt(const tlsan_dims* d, const tlsan_params* p, const tlsan
   }
   if (hp->l2_mode == TLSAN_L2_LAZY) {   // row sums beside the finalize, then the short elementwise update
     category_split(A, d, b);
-#if TLSAN_CHAIN
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(hs, &cs);
-    g_ch.on = chain_env() && hp->index_prebuilt && out && out->started && cs == hipStreamCaptureStatusNone && !other;
-    if (g_ch.on) {
-      if (!g_ch.s[0]) {
-        if (hipStreamCreateWithFlags(&g_ch.s[0], hipStreamNonBlocking) != hipSuccess ||
-            hipStreamCreateWithFlags(&g_ch.s[1], hipStreamNonBlocking) != hipSuccess) return fail(TLSAN_E_LAUNCH, "chain streams");
-      }
-      if (!g_ch.busy) (void)hipStreamSynchronize(hs);   // (what the caller queued before the first chained step)
-      g_ch.X = g_ch.s[g_ch.flip]; g_ch.Y = g_ch.s[g_ch.flip ^ 1]; g_ch.state = state;
-      g_ch.busy = true;
-    } else if (g_ch.busy) {   // back to the caller's stream: the chained steps first
-      (void)hipStreamSynchronize(g_ch.s[0]); (void)hipStreamSynchronize(g_ch.s[1]);
-      g_ch.busy = false;
-    }
-    if ((rc = run_backward(d, s, p, b, hp, true, out, w, st, L, hs, &A))) { g_ch.on = false; return rc; }
-    if ((rc = launch_update_lazy(A, b->B, b->Sn, g_ch.on ? g_ch.Y : hs))) { g_ch.on = false; return rc; }
-    if (g_ch.on) { g_ch.flip ^= 1; g_ch.on = false; }
-#else
     if ((rc = run_backward(d, s, p, b, hp, true, out, w, st, L, hs, &A))) return rc;
     if ((rc = launch_update_lazy(A, b->B, b->Sn, hs))) return rc;
-#endif
   } else {
     if ((rc = run_backward(d, s, p, b, hp, true, out, w, st, L, hs))) return rc;
     if (hp->norm_mode == TLSAN_NORM_DEDUP && (rc = clip_dedup(A, hp, out, w, st, b, hs))) return rc;

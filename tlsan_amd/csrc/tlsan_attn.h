@@ -522,12 +522,6 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   };
   if constexpr (TRAIN) {
     // (tlsan_step_out.started: this kernel running means everything queued before the step is complete)
-#if TLSAN_CHAIN
-    if (a.chain != nullptr) {
-      if (tid == 0 && atomicAdd(&a.chain[0], 1) == a.chain_placed - 1 && a.started != nullptr)
-        __hip_atomic_store(a.started, a.started_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    } else
-#endif
     if (a.started != nullptr && blockIdx.x == 0 && tid == 0)
       __hip_atomic_store(a.started, a.started_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -2582,17 +2576,4 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     // P5), sH rows are wave-private, sT/sS are rewritten in P3/P5 (last read right above; the
     // P1->P2 barrier separates) -> no extra barrier.
   }
-#if TLSAN_CHAIN
-  if constexpr (TRAIN) {
-    if (a.chain != nullptr) {   // (timing prototype: the stores are NOT released to the other XCDs here)
-      __syncthreads();
-      if (wave == 0) {
-        int last = 0;
-        if (lane == 0) last = atomicAdd(&a.chain[32], 1) == a.chain_arrived - 1 ? 1 : 0;
-        last = __builtin_amdgcn_readfirstlane(last);
-        if (last) __hip_atomic_store((uint32_t*)&a.chain[64 + 32 * lane], a.chain_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-  }
-#endif
 }

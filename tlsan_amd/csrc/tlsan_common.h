@@ -69,9 +69,6 @@ __device__ __forceinline__ f32x4 mm_mma(typename MMT<MM>::opd a, typename MMT<MM
 // exponential of a score difference is then one v_exp_f32 (exp2s) instead of v_mul + v_exp, and the mask constant and
 // the running maxima live in the same units.  The backward never differentiates through the scaled copy: dm2 is formed
 // from the softmax weights, and dm1 = dm2 W2^T, dW2 = m1^T dm2 use the unscaled W2.
-#ifndef TLSAN_CHAIN
-#define TLSAN_CHAIN 0
-#endif
 #define TLSAN_LOG2E 1.44269504088896340736f
 __device__ __forceinline__ float exp2s(float x) { return __builtin_amdgcn_exp2f(x); }
 
@@ -509,13 +506,6 @@ struct FwdArgs {
   uint32_t drop_sample0;          // index of this batch's first sample in the pattern (a rank's share of a global batch)
   uint32_t* started;              // optional host-visible word: workgroup 0 stores started_val there when the kernel begins
   uint32_t started_val;
-#if TLSAN_CHAIN
-  // timing prototype: the row-sum launch chained to this one by memory flags instead of the queue.
-  // chain[0]: workgroups placed (the one that completes chain_placed stores `started`: every workgroup is resident, the
-  // host may launch the row sums on another stream), chain[32]: workgroups done (the one that completes chain_arrived
-  // sets the 64 go words chain[64 + 32 i] = chain_seq)
-  int32_t* chain; int32_t chain_placed, chain_arrived; uint32_t chain_seq;
-#endif
 };
 
 // Keep / drop pattern of tf.nn.dropout as the scale the element is multiplied with (0 or 1/keep_prob):

@@ -930,27 +930,7 @@ struct FinArgs {
   int32_t commit;          // lazy L2 update: advance the table scale P (P_prev keeps the old value)
   int32_t count_step;      // an update follows (train step, not tlsan_grads): advance hdr->nstep
   float* out_loss; float* out_gnorm; float* out_sq;
-#if TLSAN_CHAIN
-  const int32_t* chain_go; uint32_t chain_seq;   // timing prototype: wait for k_fwd_bwd's go words (FwdArgs.chain)
-#endif
 };
-
-#if TLSAN_CHAIN
-// a workgroup of the row-sum launch waits here until every workgroup of k_fwd_bwd is done (one of 64 go words per
-// workgroup: ~20 pollers per cache line)
-__device__ __forceinline__ void chain_wait(const int32_t* go, uint32_t seq) {
-  if (go == nullptr) return;
-  if (threadIdx.x == 0) {
-    const uint32_t* w = (const uint32_t*)(go + 32 * ((int)blockIdx.x & 63));
-    for (int it = 0; it < 200000 && (int32_t)(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0; ++it)   // (bounded: a prototype must not hang the GPU)
-      __builtin_amdgcn_s_sleep(4);
-  }
-  __syncthreads();
-}
-#define CHAIN_WAIT(go, seq) chain_wait(go, seq)
-#else
-#define CHAIN_WAIT(go, seq) do { } while (0)
-#endif
 
 // The step's scalars, computed once by the last workgroup of k_dense_finalize instead of by every
 // workgroup of k_apply: global norm (tf18: per-use rows + (reg*W)^2 + dense; model.py:198-201),
@@ -1074,9 +1054,6 @@ __device__ __forceinline__ void dense_finalize_block(const FinArgs& a, int nbK, 
   constexpr int CW = G::CW, NPB = G::NPB, HPC = CW / DH;  // heads per 16-wide column block
   const int tid = threadIdx.x;
   const tlsan_dense_layout& L = a.lay;
-#if TLSAN_CHAIN
-  CHAIN_WAIT(a.chain_go, a.chain_seq);
-#endif
   if (blk == nbK + nbS) {
     // the apply kernels leave per-workgroup CHANGES of the tables' sum of squares: fold them in
     // and clear them (consumed exactly once)
@@ -1252,9 +1229,6 @@ struct ApplyArgs {
   const int32_t* off_item; const int32_t* off_user; const int32_t* off_uc;   // n+1 entries each
   const int4* urec_item; const int4* urec_user;   // lazy L2: (row, first position, uses) of the rows used this step
   const int32_t* cate_off; const int32_t* cate_cnt; const int32_t* cate_items;  // static CSR
-#if TLSAN_CHAIN
-  const int32_t* chain_go; uint32_t chain_seq;
-#endif
   const int32_t* uc_list;  // optional: samples of every category (segments off_uc); then Gc is in sample order
   int32_t cseg;            // != 0 (many categories): a category's segment of Gc holds its u_cate uses AND the category halves
                            // of its items' uses (k_fwd_bwd, FwdArgs.cseg): the category blocks sum that one segment and
@@ -1524,18 +1498,12 @@ __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx
         for (int j = tid; j < extra; j += 256) sh_pos[T + j] = ~(a.uc_list ? a.uc_list[ou + j] : ou + j);
         __syncthreads();
         AP_STAMP(1);
-#if TLSAN_CHAIN
-        CHAIN_WAIT(a.chain_go, a.chain_seq);
-#endif
         list_accum<NCH>(a, sh_pos, T + extra, gid, l16, W4, acc);
         AP_STAMP(2);
       } else {  // very hot category: segment after segment, the 16 groups striding over each
         sh_lo[tid] = lo;
         sh_n[tid] = n;
         __syncthreads();
-#if TLSAN_CHAIN
-        CHAIN_WAIT(a.chain_go, a.chain_seq);
-#endif
         const int cnt = max(0, min(PS, ni - p0));
         for (int t = 0; t < cnt; ++t) {
           const int nt = sh_n[t], lt = sh_lo[t];
@@ -1679,9 +1647,6 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
     }
   }
   AP_STAMP(1);
-#if TLSAN_CHAIN
-  if constexpr (MODE == AP_PRESUM) CHAIN_WAIT(a.chain_go, a.chain_seq);
-#endif
   const float* Gs = IS_ITEM ? a.Gi : a.Gu;
   const int ld = IS_ITEM ? a.D : a.WU;
   const int W4 = (IS_ITEM ? a.di : a.WU) / 4;
@@ -2045,9 +2010,6 @@ __device__ __forceinline__ void presum_hot_block(const ApplyArgs& a, int h, doub
   const int W4 = a.di / 4;
   double acc[NCH][4];
   zero_acc(acc);
-#if TLSAN_CHAIN
-  CHAIN_WAIT(a.chain_go, a.chain_seq);
-#endif
   for (int k = off + gid; k < off + n; k += 16 * AP_OWN) {
     f32x4 v[AP_OWN][NCH];
 #pragma unroll
