@@ -467,7 +467,7 @@ def test_chunked_evaluation_equals_the_reference_batches():
 
 
 @pytest.mark.parametrize("d,Ls,Sn,B", [(128, 20, 3, 37), (128, 90, 5, 21), (64, 33, 2, 50), (256, 16, 2, 9), (256, 90, 4, 19),
-                                       (128, 40, 3, 300), (64, 90, 2, 131), (256, 33, 2, 70)])
+                                       (128, 40, 3, 300), (64, 90, 2, 131), (256, 33, 2, 70), (256, 90, 4, 150)])
 def test_long_windows_streamed(d, Ls, Sn, B):
     """Ls > 10 (BASELINE configs 3/4: seq <= 90): the long block is streamed with an online
     softmax; forward, one training step (dense and lazy L2) and eval against the oracle.
