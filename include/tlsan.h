@@ -137,7 +137,7 @@ typedef struct {
    * the inputs of the two linear maps of both attention blocks, train steps only (forward / evaluation
    * never drop).  TF's random stream is not reproducible; the keep / drop pattern is a hash of
    * (dropout_seed, sample, block, position, map, channel) -- pass a different seed every step.
-   * 0 = off (the reference's default).  Supported for fp32 tables. */
+   * 0 = off (the reference's default).  Supported for fp32 and bf16 tables, fp32 and bf16 matrix products. */
   float dropout;
   uint32_t dropout_seed;
   uint32_t dropout_sample0;   /* position of this batch's first sample in the pattern: a rank's offset into the global batch */
