@@ -196,13 +196,21 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
 }
 
 #define BAL_CAP (1 << 14)      // batches up to this many samples are ranked for the fused kernel's workgroups (BalArgs, tlsan_update.h)
-// Streamed windows only: with windows in registers a workgroup's time hardly depends on its samples (C3 shape: 33.3 us
-// median, 35.9 us slowest) and evenly loaded workgroups ran no faster (bench 61.0 vs 61.1 us/step; Amazon session
-// lengths 65.6 vs 66.2), with streamed windows it is proportional to their total length (d = 64, Ls = 90: 98 -> 87
-// us/step; d = 256 at the C5 shape 496 -> 471; d = 128: the kernel alone 94 -> 72 us, 104 -> 93 beside the index build
-// of the batch after next).
+// Streamed windows: a workgroup's time is proportional to its windows' total length (d = 64, Ls = 90: 98 -> 87 us/step;
+// d = 256 at the C5 shape 496 -> 471; d = 128: the kernel alone 94 -> 72 us, 104 -> 93 beside the index build of the batch
+// after next).  Windows in registers: evenly loaded workgroups (ranked by session length alone) ran no faster in round 4
+// (bench 61.0 vs 61.1 us/step; Amazon session lengths 65.6 vs 66.2) -- the launch ends with the workgroups that hold one
+// of the few long sessions, however they are dealt; what does help is giving THOSE workgroups the batch's shortest
+// windows (round 5, BalArgs: bench 58.2 -> 57.15, Amazon session lengths 61.85 -> 59.05, d = 256 169.4 -> 162.0:
+// profiles/r05_ab_bal_reg.txt).
+// (round 5: windows in registers as well, with a ranking that gives the workgroups of the batch's longest sessions its
+//  shortest windows -- BalArgs; TLSAN_BAL_REG=0: streamed windows only, as before)
+static int bal_reg_mode() {   // 0 off, 1 on, 2 on without the reversed group numbering (A/B)
+  static const int reg = [] { const char* e = getenv("TLSAN_BAL_REG"); return e ? atoi(e) : 1; }();
+  return reg;
+}
 static bool balanced(const tlsan_dims* d, const tlsan_batch* b) {
-  return b && b->B > 16 && b->B <= BAL_CAP && streamed(d->Ls);
+  return b && b->B > 16 && b->B <= BAL_CAP && (streamed(d->Ls) || (bal_reg_mode() != 0 && b->Sn > 0));
 }
 #define UC_LIST_CAP (1 << 18)  // batches up to this many samples may keep a per-category sample list in the state
 // ... and do when a category sees many of the batch's samples (cursor atomics on few addresses inside the
@@ -764,7 +772,7 @@ static int build_index(const tlsan_dims* d, const tlsan_batch* b, const int32_t*
   if (balanced(d, b)) {
     sa.bal.sl = b->sl; sa.bal.sl_new = b->sl_new;
     sa.bal.B = b->B; sa.bal.Ls = d->Ls; sa.bal.Sn = b->Sn;
-    sa.bal.by_window = streamed(d->Ls) ? 1 : 0;
+    sa.bal.by_window = streamed(d->Ls) ? 1 : (bal_reg_mode() == 2 ? -1 : 0);
     sa.bal.perm = st.perm[k];
   }
   if ((rc = launch_scan(sa, nscan, st.scan_bsum[k], hs))) return rc;
@@ -792,7 +800,6 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   if (out && out->started) { a.started = out->started; a.started_val = out->started_value; }
   a.Gi = w.Gi; a.Gb = w.Gb; a.Gu = w.Gu; a.Gc = w.Gc; a.WU = w.WU;
   a.cur_item = st.cur_item[k]; a.cur_user = st.cur_user[k]; a.cur_uc = st.cur_uc[k];
-  a.perm = balanced(d, b) ? st.perm[k] : nullptr;
   a.uc_by_sample = uc_by_list(d, b) ? 1 : 0;
   a.cseg = cate_seg(d, b) ? 1 : 0;
   a.gLong = w.gLong; a.gDB = w.gDB; a.gStat = w.gStat; a.partials = w.partials; a.Kp = w.Kp;
@@ -806,6 +813,8 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
     a.drop_sample0 = hp->dropout_sample0;
   }
   const int grp = train_group(s, d, b, hp);  // samples per workgroup pass of the fused kernel (= per partial record)
+  // (the ranking deals the batch out in groups of 16: the 8-sample workgroups of small d = 128 batches take the batch's order)
+  a.perm = balanced(d, b) && grp == s.NSB ? st.perm[k] : nullptr;
   a.ngroups = (b->B + grp - 1) / grp;
   a.fuse_dk = fused_dk(s.D, a.ngroups) ? 1 : 0;
   prof_mark(1, hs);

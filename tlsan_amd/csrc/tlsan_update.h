@@ -202,7 +202,15 @@ struct BalArgs {
   int32_t blk;        // index of the block that does this (the first one behind the scan's blocks)
   int32_t* perm;      // NULL: no balancing
 };
-#define BAL_KEYS 97     // costs 0 .. 96 (TLSAN_LS_CAP / TLSAN_SN_CAP)
+// Windows in registers (by_window == 0; round 5): a workgroup's time is its longest wavefront's -- session steps in P3,
+// window positions in P1 / P5 -- and the launch ends with the workgroups that hold one of the batch's few long sessions
+// (25 of 4096 sessions have four or more entries at the bench shape: +1.9 us in P3).  Those workgroups are given short
+// WINDOWS to make up for it: samples with sessions of two or more rank first (longest first) and are dealt out in snake
+// order as above; the others are ranked by window length, shortest first, and handed out in contiguous runs -- group 0,
+// which holds the longest session, gets the shortest windows, the last groups get full windows only (which most
+// wavefronts have anyway: half the batch's windows are full).
+#define BAL_KEYS 192    // by_window: costs 0 .. 96 (TLSAN_LS_CAP); else 11 * min(session, 15) + window for sessions >= 2, 10 - window below
+#define BAL_TAIL_KEY 10 // (by_window == 0) the largest key of a sample with a session of one entry or none
 
 __device__ __forceinline__ void balance_block(const BalArgs& b) {   // 1024 threads = 16 wavefronts
   __shared__ int wcnt[16][BAL_KEYS];   // samples of every cost per wavefront -> where the wavefront's first one of that cost ranks
@@ -213,8 +221,9 @@ __device__ __forceinline__ void balance_block(const BalArgs& b) {   // 1024 thre
   for (int o = tid; o < 16 * BAL_KEYS; o += 1024) (&wcnt[0][0])[o] = 0;
   __syncthreads();
   auto key_of = [&](int i) {
-    const int v = b.by_window ? min(b.sl[i], b.Ls) : min(b.sl_new[i], b.Sn);
-    return min(max(v, 0), BAL_KEYS - 1);
+    if (b.by_window > 0) return min(max(min(b.sl[i], b.Ls), 0), BAL_KEYS - 1);
+    const int cs = min(max(min(b.sl_new[i], b.Sn), 0), 15), cl = min(max(min(b.sl[i], b.Ls), 0), 10);
+    return cs >= 2 ? 11 * cs + cl : BAL_TAIL_KEY - cl;
   };
   for (int c = 0; c < CH; ++c) {
     const int i = wave * nper + c * 64 + lane;
@@ -240,20 +249,32 @@ __device__ __forceinline__ void balance_block(const BalArgs& b) {   // 1024 thre
     }
   }
   __syncthreads();
+  // rounds dealt out in snake order: all of them (by_window), or those that hold the samples with sessions of two or more
+  const int n_heavy = b.by_window > 0 ? 16 * G : start[BAL_TAIL_KEY];   // (rank of the first sample of the tail)
+  const int H = min(16, (n_heavy + G - 1) / G);
+  // (by_window == 0: the groups are numbered backwards -- the full-window groups, the slowest ones now, get the lowest
+  //  block numbers and start first; the launch places its workgroups over 0.6 us.  by_window < 0: not, for A/B)
+  const bool rev = b.by_window == 0;
   auto place = [&](int rank, int sample) {
-    const int j = rank / G, idx = rank - j * G;
-    const int g = (j & 1) ? G - 1 - idx : idx;
-    b.perm[g * 16 + j] = sample;
+    if (rank < H * G) {
+      const int j = rank / G, idx = rank - j * G;
+      const int g = (j & 1) ? G - 1 - idx : idx;
+      b.perm[(rev ? G - 1 - g : g) * 16 + j] = sample;
+    } else {   // the tail, shortest windows first: a contiguous run per group
+      const int r2 = rank - H * G, per = 16 - H;
+      const int g = r2 / per;
+      b.perm[(rev ? G - 1 - g : g) * 16 + H + (r2 - g * per)] = sample;
+    }
   };
   volatile int* mine = &wcnt[wave][0];   // (wave-private from here on: DS operations of a wavefront execute in order)
   for (int c = 0; c < CH; ++c) {
     const int i = wave * nper + c * 64 + lane;
     const bool v = i < B;
-    const int k = v ? key_of(i) : BAL_KEYS;   // (7 bits; the lanes past the batch form a group of their own)
-    // lanes of this round with the same cost: seven ballots, one per bit of the cost
+    const int k = v ? key_of(i) : 255;   // (8 bits; the lanes past the batch form a group of their own)
+    // lanes of this round with the same cost: eight ballots, one per bit of the cost
     unsigned long long m = ~0ull;
 #pragma unroll
-    for (int bit = 0; bit < 7; ++bit) {
+    for (int bit = 0; bit < 8; ++bit) {
       const unsigned long long bb = __ballot((k >> bit) & 1);
       m &= ((k >> bit) & 1) ? bb : ~bb;
     }
