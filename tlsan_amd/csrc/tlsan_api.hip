@@ -210,7 +210,13 @@ static int bal_reg_mode() {   // 0 off, 1 on, 2 on without the reversed group nu
   return reg;
 }
 static bool balanced(const tlsan_dims* d, const tlsan_batch* b) {
-  return b && b->B > 16 && b->B <= BAL_CAP && (streamed(d->Ls) || (bal_reg_mode() != 0 && b->Sn > 0));
+  if (!b || b->B <= 16 || b->B > BAL_CAP) return false;
+  if (streamed(d->Ls)) return true;
+  // windows in registers: where it was measured to win -- one round of workgroups (<= 256 groups of 16: a second round
+  // evens the workgroups out by itself, and 16384 sequences ran 5 % SLOWER ranked: 207 vs 196 us/step) and tables that the
+  // caches hold (10 M users / 5 M items: 101.7 vs 97.4 -- full windows side by side mean more HBM rows in flight at once);
+  // profiles/r05_ab_bal_reg_shapes2.txt
+  return bal_reg_mode() != 0 && b->Sn > 0 && (b->B + 15) / 16 <= FUSED_DK_MAX_GROUPS && d->item_count <= (1 << 18);
 }
 #define UC_LIST_CAP (1 << 18)  // batches up to this many samples may keep a per-category sample list in the state
 // ... and do when a category sees many of the batch's samples (cursor atomics on few addresses inside the
