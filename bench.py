@@ -325,10 +325,15 @@ def main():
     if fill:          # (no fence between the fill steps and the timed ones would be better still; the contract wants one)
         torch.cuda.synchronize()
     fence()
+    if hasattr(stepper, "started_at") and not use_graph:
+        stepper.started_at = []      # host time stamps of the steps' kernel starts (no extra GPU work: the word is polled anyway)
     t0 = time.perf_counter()
     run(args.steps, fence_warm, timed=False, clock=True)
     fence()
     dt = time.perf_counter() - t0
+    starts = np.asarray(getattr(stepper, "started_at", None) or [], np.float64)
+    if hasattr(stepper, "started_at"):
+        stepper.started_at = None
     # the kernel's own duration: a pair of HIP events ATTACHED TO k_fwd_bwd's dispatch on its stream (hipExtLaunchKernelGGL
     # through tlsan_profile_*: the dispatch's own begin / end time stamps, which is what a rocprofv3 kernel trace reports),
     # live, in a pass of the SAME steps right behind the timed ones.  (Rounds 2-3 recorded two events AROUND the launch:
@@ -364,12 +369,15 @@ def main():
             for s in range(fence_warm):
                 mv.train_async(dbs[s % len(dbs)], lr, next_batch=dbs[(s + 1) % len(dbs)], after_next=dbs[(s + 2) % len(dbs)])
             torch.cuda.synchronize()
+            mv.started_at = []
             t1 = time.perf_counter()
             for s in range(args.steps):
                 k = (fence_warm + s) % len(dbs)
                 mv.train_async(dbs[k], lr, next_batch=dbs[(k + 1) % len(dbs)], after_next=dbs[(k + 2) % len(dbs)])
             torch.cuda.synchronize()
             dtv = time.perf_counter() - t1
+            sv, mv.started_at = np.asarray(mv.started_at, np.float64), None
+            spread = {"ms_per_step_p%d" % q: round(float(np.percentile(np.diff(sv), q)) * 1e3, 4) for q in (10, 50, 90)} if len(sv) >= 3 else {}
             lib.tlsan_profile_stride(args.event_every)      # (kernel time: a pass of its own, as for the headline)
             lib.tlsan_profile_enable(args.profile_level)
             for s in range(args.steps):
@@ -383,7 +391,7 @@ def main():
             abv = [synth.algorithmic_bytes(cfg, host_batches[(fence_warm + s) % len(host_batches)], 2) for s in range(args.steps)]
             step_b, k_b = float(np.mean([x["train_step"] for x in abv])), float(np.mean([x["fwd_bwd_kernel"] for x in abv]))
             ach = k_b / (kms * 1e-3) / 1e9
-            return {"value": round(args.steps * B / dtv, 1), "unit": "user-sequences/s", "ms_per_step": round(dtv / args.steps * 1e3, 4),
+            return {"value": round(args.steps * B / dtv, 1), "unit": "user-sequences/s", "ms_per_step": round(dtv / args.steps * 1e3, 4), **spread,
                     "what": what, "step_algorithmic_bytes": round(step_b),
                     "step_frac": round(step_b / (dtv / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
                     "roofline": {"bound": "hbm", "kernel": "k_fwd_bwd", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -420,6 +428,12 @@ def main():
             "warmup": args.warmup,
             "pipeline_fill_steps": fill,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
+            # spread of the timed window's steps: intervals between consecutive steps' kernel starts as the host saw them
+            # (the pinned `started` word train_async polls anyway: no event, no extra launch).  K - 1 intervals of K steps;
+            # `value` is still whole-window sequences / wall time (fences included)
+            **({"ms_per_step_p10": round(float(np.percentile(np.diff(starts), 10)) * 1e3, 4),
+                "ms_per_step_p50": round(float(np.percentile(np.diff(starts), 50)) * 1e3, 4),
+                "ms_per_step_p90": round(float(np.percentile(np.diff(starts), 90)) * 1e3, 4)} if len(starts) >= 3 else {}),
             # (time the host needed to ENQUEUE the timed steps, per step, without its waits for the GPU -- the poll of the
             #  `started` word --: well below ms_per_step when the GPU is the bound)
             "host_enqueue_ms_per_step": round(host[0] / args.steps * 1e3, 4),

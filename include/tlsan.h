@@ -143,7 +143,16 @@ typedef struct {
   uint32_t dropout_sample0;   /* position of this batch's first sample in the pattern: a rank's offset into the global batch */
 } tlsan_hparams;
 
-/* Device-side results of a train step (all optional except loss). */
+/* Device-side results of a train step (all optional except loss).
+ *
+ * Divergence: the reference's loss goes NaN when training diverges (model.py:171, printed at train.py:205) and
+ * tf.clip_by_global_norm hands a non-finite norm on to every gradient.  The same holds here: a NaN or Inf in any
+ * gathered row or weight reaches `loss` and `gnorm` (plain IEEE arithmetic carries it through the logit, the BCE and
+ * the square sums; the fused kernel's units are built with -fno-honor-nans, which only frees the compiler from
+ * canonicalising in front of fmaxf -- no comparison there decides whether a value is reported), and the clip
+ * coefficient is formed so that a non-finite norm is not swallowed (clip_coef: NaN -> NaN, +Inf -> 0), i.e. the
+ * step's update and the lazy table scale carry it on.  No separate "finite" flag: a caller tests the loss, as the
+ * reference's driver does.  Pinned by tests/test_gpu_parity.py::test_nonfinite_inputs_give_nonfinite_loss. */
 typedef struct {
   float* loss;    /* [1]  mean BCE + reg * l2 (model.py:171-172), value BEFORE the update */
   float* gnorm;   /* [1]  global gradient norm used for clipping                           */

@@ -237,8 +237,12 @@ def _fwa_backward(dout, c, W1, W2, H):
     return dx.reshape(B, L, Hh * dh), dict(W1=dW1, b1=db1, W2=dW2, b2=db2)
 
 
-def backward(p, item_cate_list, b, H, reg, dlogits=None, dropout=None):
+def backward(p, item_cate_list, b, H, reg, dlogits=None, dropout=None, l2_extra=0.0):
     """Gradients of model.py:171-172's loss w.r.t. every trainable (model.py:198).
+
+    l2_extra: sum of squares of regularised-table rows that are NOT in `p` (tests that run the oracle on the rows a
+    batch touches, extracted from tables too large for numpy: the model depends on the other rows only through this
+    number -- they add reg/2 * l2_extra to the loss (:164-172) and decay by the dense L2 gradient reg * W).
 
     Returns ``(loss, logits, grads, sparse)`` where ``grads[k]`` is the mathematically
     summed dense gradient (sparse gather-gradients scatter-added, plus ``reg*W`` for the
@@ -256,7 +260,7 @@ def backward(p, item_cate_list, b, H, reg, dlogits=None, dropout=None):
     if dlogits is None:
         y = b["y"].astype(dt)
         bce = bce_with_logits(logits, y).mean()
-        loss = bce + reg * l2_term(p)
+        loss = bce + reg * (l2_term(p) + 0.5 * float(l2_extra))
         dlogits = (1.0 / (1.0 + np.exp(-logits)) - y) / B
     else:
         bce = loss = None
@@ -299,7 +303,7 @@ def backward(p, item_cate_list, b, H, reg, dlogits=None, dropout=None):
     return loss, logits, g, sparse
 
 
-def global_norm(p, g, sparse, reg, mode="tf18"):
+def global_norm(p, g, sparse, reg, mode="tf18", l2_extra=0.0):
     """Norm used by tf.clip_by_global_norm (model.py:201).
 
     ``tf18``: TF-1.8 aggregates a variable's IndexedSlices (from gathers) and dense
@@ -307,7 +311,7 @@ def global_norm(p, g, sparse, reg, mode="tf18"):
     *concatenating* values; global_norm then squares the raw values: no de-duplication
     and no cross term between the sparse part and reg*W.  ``dedup``: the mathematically
     summed gradient.  Dense-only variables are identical in both."""
-    tot = 0.0
+    tot = reg * reg * float(l2_extra)   # rows outside `p` (backward's l2_extra): their gradient is reg * W in either mode
     sparse_vars = set(REG_TABLES) | {"item_b"}
     for k in p:
         if mode == "tf18" and k in sparse_vars:
@@ -379,12 +383,12 @@ def apply_optimizer(p, g, lr, optimizer, state, used_item_b=None):
 
 
 def train_step(p, item_cate_list, b, H, reg, lr, clip=5.0, norm_mode="tf18", optimizer="sgd", opt_state=None,
-               dropout=None):
+               dropout=None, l2_extra=0.0):
     """One step of model.py:185-205: grads -> clip_by_global_norm(clip) -> optimizer.  The default
     'sgd' (:195) is W -= lr * g; adam | rmsprop | adadelta (:188-193) keep their slots in
     `opt_state` (init_opt_state).  Returns (loss, new_params, info)."""
-    loss, logits, g, sparse = backward(p, item_cate_list, b, H, reg, dropout=dropout)
-    norm = global_norm(p, g, sparse, reg, norm_mode)
+    loss, logits, g, sparse = backward(p, item_cate_list, b, H, reg, dropout=dropout, l2_extra=l2_extra)
+    norm = global_norm(p, g, sparse, reg, norm_mode, l2_extra=l2_extra)
     coef = clip / max(norm, clip)                             # clip_by_global_norm
     if optimizer == "sgd":
         newp = {k: (p[k] - lr * coef * g[k]).astype(p[k].dtype) for k in p}

@@ -74,3 +74,26 @@ def fixture_batch(name, cls_name="DataInput", bs=32, k=10, bi=0):
     pk = np.load(os.path.join(GOLDEN, "packed_%s.npz" % name))
     counts = tuple(int(x) for x in pk["counts"])
     return batch, counts, pk["item_cate_list"].astype(np.int32)
+
+
+def compact_problem(batch, item_cate_list):
+    """Id compaction: the model depends on its tables only through the rows a batch gathers plus the tables' sum of
+    squares (the L2 term of TLSAN/model.py:164-172 and its gradient reg * W).  Returns the ids the batch touches --
+    `items` (candidates, valid window and session entries, and id 0: padded slots gather row 0, input.py:47-51), `users`,
+    `cates` (of those items and the u_cate column), all sorted -- the batch with its ids renumbered into those lists,
+    and the renumbered item -> category map.  Running the oracle on tables restricted to these rows, with the sum of
+    squares of the rows left out as `l2_extra`, is the oracle on the full tables (tests/test_oracle.py checks that on a
+    case numpy can hold); the C4 / C5 tests use it where it cannot."""
+    u, i, y, hist_i, hist_i_new, hist_t, sl, sl_new, c = [np.asarray(x) for x in batch]
+    B, Ls = hist_i.shape
+    hist_i_new = hist_i_new.reshape(B, -1)
+    vl = np.arange(Ls)[None, :] < sl[:, None]
+    vs = np.arange(hist_i_new.shape[1])[None, :] < sl_new[:, None]
+    assert (hist_i[~vl] == 0).all() and (hist_i_new[~vs] == 0).all(), "padded slots hold id 0"
+    icl = np.asarray(item_cate_list, np.int64)
+    items = np.unique(np.concatenate([i.ravel(), hist_i[vl], hist_i_new[vs], [0]])).astype(np.int64)
+    users = np.unique(u).astype(np.int64)
+    cates = np.unique(np.concatenate([icl[items], c.ravel()])).astype(np.int64)
+    ri = lambda x: np.searchsorted(items, x)
+    cb = (np.searchsorted(users, u), ri(i), y, ri(hist_i), ri(hist_i_new), hist_t, sl, sl_new, np.searchsorted(cates, c))
+    return dict(items=items, users=users, cates=cates, batch=cb, item_cate=np.searchsorted(cates, icl[items]).astype(np.int32))

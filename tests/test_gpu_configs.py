@@ -6,12 +6,13 @@
   C2  Digital-Music (1659 / 1583 / 53), d = 128 (64/64/64), fp32, batch 1024 -- the real fixture batch
       `DataInput_bs1024_k10_b0` (captured from the reference's input.py) through one train step and an
       evaluation, against the fp64 oracle;
-  C4  Movies-TV sizes (35896 / 28589 / 15), window of 90 positions, tables row-sharded over 2 ranks
-      (two processes on cuda:0, gloo): where the oracle is too slow, properties -- bitwise determinism and
-      sharded == single-GPU `Model` on the concatenated batch;
-  C5  10 M users / 5 M items / 10 k categories, d = 256 (128/128/128), window 90, batch 4096 on one GPU:
-      bitwise determinism, lazy L2 == dense L2 (the reference's update) on every row, untouched rows not
-      written, the item_b checksum.
+  C4  Movies-TV sizes (35896 / 28589 / 15), window of 90 positions: one train step at batch 4096 against the fp64
+      oracle AT SIZE (round 6, id compaction); tables row-sharded over 2 ranks (two processes on cuda:0, gloo):
+      bitwise determinism and sharded == single-GPU `Model` on the concatenated batch;
+  C5  10 M users / 5 M items / 10 k categories, d = 256 (128/128/128), window 90, batch 4096 on one GPU: one train step
+      against the fp64 oracle AT SIZE (round 6: the oracle steps the rows the batch touches, the other rows enter through
+      their sum of squares); bitwise determinism, lazy L2 == dense L2 (the reference's update) on every row,
+      untouched rows not written, the item_b checksum.
 Plus the driver's resume flow (train.py:71-76,124-127) and the captured-graph workspace.
 """
 import os
@@ -170,6 +171,97 @@ def test_c5_ten_million_users_d256_window_90():
     coef = min(1.0, cfg["max_gradient_norm"] / m.last_gnorm())
     ib1 = m.item_b.double().sum().item()
     assert abs((ib0 - ib1) - coef * dl_sum) < 1e-5 * max(1.0, abs(dl_sum)) + 1e-6
+
+
+# ------------------------------------------------------------------------------------------- C4 / C5 against the oracle, at size
+def _sumsq64(t, chunk=1 << 26):
+    """sum of squares of a device tensor in fp64 without a full-size fp64 copy (10^7-row tables)"""
+    flat, tot = t.reshape(-1), 0.0
+    for lo in range(0, flat.numel(), chunk):
+        tot += float(flat[lo:lo + chunk].double().pow(2).sum().item())
+    return tot
+
+
+def _one_step_against_oracle_at_size(cfg, icl, batch, seed, n_probe=4096):
+    """One train step of a FULL-SIZE device model against the fp64 oracle (TLSAN/model.py:56-205 restated) by id compaction
+    (tests/helpers.compact_problem; pinned on a case numpy can hold by tests/test_oracle.py): the rows the batch touches
+    are extracted from the device tables into small tables with renumbered ids, the rest of the regularised tables enters
+    through its sum of squares (chunked fp64 on the device) -- the L2 term of the loss and of clip_by_global_norm's norm --
+    and the oracle steps that problem.  Compared: logits and u_t of the forward pass, loss, clip norm, EVERY touched row
+    of the five tables, every dense parameter, and a sample of untouched rows, which must have decayed by the dense L2
+    gradient (lazy L2: after the table scale is folded in).  Lazy and dense L2 from the same initial values."""
+    from tests.helpers import compact_problem
+    from tlsan_amd.model import Model
+    cp = compact_problem(batch, icl)
+    sel = dict(item_emb="items", item_b="items", user_emb="users", usert_emb="users", cate_emb="cates")
+    counts = dict(items=cfg["item_count"], users=cfg["user_count"], cates=cfg["cate_count"])
+    rng = np.random.default_rng(seed)
+    probe = {}
+    for s_, n in counts.items():     # rows the batch does not touch
+        cand = np.unique(rng.integers(0, n, min(n_probe, n)))
+        probe[s_] = cand[~np.isin(cand, cp[s_])]
+    lr, reg, clip = 1.0, cfg["regulation_rate"], cfg["max_gradient_norm"]
+    ref = q0 = None
+    for l2 in ("lazy", "dense"):
+        m = Model(cfg, icl, l2_mode=l2, init="device", seed=seed)
+        ids = {s_: torch.as_tensor(cp[s_], device=m.device) for s_ in counts}
+        pids = {s_: torch.as_tensor(probe[s_], device=m.device) for s_ in counts}
+        q = {k: getattr(m, k)[ids[s_]].double().cpu().numpy() for k, s_ in sel.items()}
+        q.update({k: np.asarray(v, np.float64) for k, v in m.unpack_dense(m.dense.cpu().numpy()).items()})
+        old_probe = {k: getattr(m, k)[pids[s_]].double().cpu().numpy() for k, s_ in sel.items()}
+        if ref is None:
+            q0 = q
+            extra = sum(_sumsq64(getattr(m, k)) - float((q[k] ** 2).sum()) for k in orc.REG_TABLES)
+            ob = orc.as_batch(cp["batch"])
+            fwd = orc.forward(q, cp["item_cate"], ob, cfg["num_heads"])
+            ref = (fwd,) + orc.train_step(q, cp["item_cate"], ob, cfg["num_heads"], reg, lr=lr, clip=clip, l2_extra=extra)
+        else:
+            for k in q:      # (the same seed draws the same tables on the device: one oracle step serves both modes)
+                assert np.array_equal(q[k], q0[k]), k
+        fwd, loss, newp, info = ref
+        li, _, ut, _ = m.forward(batch, is_test=False, want_u_t=True)
+        assert np.abs(li.cpu().numpy() - fwd["logits"]).max() < LOGIT_TOL, l2
+        assert np.abs(ut.cpu().numpy() - fwd["u_t"]).max() < LOGIT_TOL, l2
+        got_loss = m.train(None, batch, lr)
+        assert abs(got_loss - loss) < 3e-6 * abs(loss) + 1e-4, (l2, got_loss, loss)
+        assert abs(m.last_gnorm() - info["norm"]) < 3e-4 * info["norm"], (l2, m.last_gnorm(), info["norm"])
+        m.fold_scale()
+        got = {k: getattr(m, k)[ids[s_]].double().cpu().numpy() for k, s_ in sel.items()}
+        got.update({k: np.asarray(v, np.float64) for k, v in m.unpack_dense(m.dense.cpu().numpy()).items()})
+        for k in newp:
+            du, dr = got[k].reshape(q0[k].shape) - q0[k], newp[k] - q0[k]
+            assert np.abs(du - dr).max() < 3e-4 * (np.abs(dr).max() + 1e-9) + 2e-7, (l2, k, float(np.abs(du - dr).max()), float(np.abs(dr).max()))
+        decay = 1.0 - lr * info["coef"] * reg
+        for k, s_ in sel.items():
+            if len(probe[s_]) == 0:      # (Movies-TV: a batch touches all 15 categories)
+                continue
+            now = getattr(m, k)[pids[s_]].double().cpu().numpy()
+            want = old_probe[k] * (decay if k in orc.REG_TABLES else 1.0)      # item_b is not regularised (model.py:164-169)
+            assert np.abs(now - want).max() <= 3e-7 * np.abs(want).max() + 1e-12, (l2, k)
+        del m
+        torch.cuda.empty_cache()
+    return cp
+
+
+def test_c5_one_step_matches_oracle_at_size():
+    """BASELINE.json configs[4] at its own size -- 10 M users / 5 M items / 10 k categories, d = 256 (128/128/128), window
+    90, batch 4096 -- against the oracle, by id compaction (one oracle step on the ~70 k touched item rows: ~1 min of numpy)."""
+    from tlsan_amd import synth
+    cfg = synth.make_config("electronics", Ls=90, hidden_units=256, itemid_embedding_size=128, userid_embedding_size=128,
+                            cateid_embedding_size=128, user_count=10_000_000, item_count=5_000_000, cate_count=10_000)
+    icl = synth.item_cate_list(cfg)
+    cp = _one_step_against_oracle_at_size(cfg, icl, synth.make_batches(cfg, 1, 4096, seed=55)[0], seed=7)
+    assert len(cp["items"]) > 50_000 and len(cp["users"]) > 4000          # (tens of thousands of rows, spread over tables of 10^7)
+
+
+def test_c4_one_step_matches_oracle_at_size():
+    """BASELINE.json configs[3]'s shape -- Movies-TV (35896 / 28589 / 15), d = 128, window 90, batch 4096 -- on one GPU
+    against the oracle at size (the sharded step is held to this single-GPU step by
+    test_c4_movies_tv_window_90_sharded_over_two_ranks)."""
+    from tlsan_amd import synth
+    cfg = _c4_cfg()
+    icl = synth.item_cate_list(cfg)
+    _one_step_against_oracle_at_size(cfg, icl, synth.make_batches(cfg, 1, 4096, seed=300)[0], seed=9, n_probe=20000)
 
 
 # ------------------------------------------------------------------------------------------- C4

@@ -190,3 +190,34 @@ def test_dropout_backward_against_autograd(d, H, Ls, Sn):
     assert abs((big > 0).mean() - 0.7) < 0.01
     assert np.array_equal(big[5:9], orc.dropout_scale(rate, seed, 4, 16, 128, 0, 0, sample0=5))
     assert not np.array_equal(big, orc.dropout_scale(rate, seed + 1, 64, 16, 128, 0, 0))
+
+
+def test_oracle_on_the_touched_rows_is_the_oracle_on_the_full_tables():
+    """Id compaction (tests/helpers.compact_problem; what lets the C4 / C5 GPU tests meet the oracle at sizes numpy
+    cannot hold): one train step on the rows a batch touches, with the rest of the regularised tables entering through
+    their sum of squares only (`l2_extra`), reproduces the step on the full tables -- loss, clip norm, every touched row,
+    every dense parameter; rows the batch does not touch decay by the dense L2 gradient (model.py:164-172, 198-205)."""
+    from tests.helpers import compact_problem
+    cfg = make_config(U=400, I=900, C=700, d=64, Ls=14, regulation_rate=2e-3, max_gradient_norm=0.05)
+    p = random_params(cfg, seed=21)
+    b, cat = random_batch(cfg, B=24, Sn=3, seed=22)
+    tup = (b["u"], b["i"], b["y"], b["hist_i"], b["hist_i_new"], b["hist_t"], b["sl"], b["sl_new"], b["u_cate"])
+    for mode in ("tf18", "dedup"):
+        loss, newp, info = orc.train_step(p, cat, b, 8, cfg["regulation_rate"], lr=0.9, clip=0.05, norm_mode=mode)
+        assert info["coef"] < 1.0
+        cp = compact_problem(tup, cat)
+        sel = dict(item_emb=cp["items"], item_b=cp["items"], user_emb=cp["users"], usert_emb=cp["users"], cate_emb=cp["cates"])
+        q = {k: (p[k][sel[k]] if k in sel else p[k]) for k in p}
+        extra = sum(float((p[k] ** 2).sum() - (q[k] ** 2).sum()) for k in orc.REG_TABLES)
+        closs, cnew, cinfo = orc.train_step(q, cp["item_cate"], orc.as_batch(cp["batch"]), 8, cfg["regulation_rate"], lr=0.9,
+                                            clip=0.05, norm_mode=mode, l2_extra=extra)
+        assert abs(closs - loss) < 1e-12 * max(1.0, abs(loss)) and abs(cinfo["norm"] - info["norm"]) < 1e-12 * info["norm"]
+        for k in p:
+            ref = newp[k][sel[k]] if k in sel else newp[k]
+            assert np.abs(cnew[k] - ref).max() < 1e-13, (mode, k)
+        decay = 1.0 - 0.9 * info["coef"] * cfg["regulation_rate"]
+        for k in orc.REG_TABLES:
+            rest = np.setdiff1d(np.arange(p[k].shape[0]), sel[k])
+            assert len(rest) > 0 and np.abs(newp[k][rest] - decay * p[k][rest]).max() < 1e-15, k
+        rest = np.setdiff1d(np.arange(cfg["item_count"]), cp["items"])
+        assert np.array_equal(newp["item_b"][rest], p["item_b"][rest])          # item_b is not regularised (model.py:164-169)

@@ -439,6 +439,12 @@ __device__ __forceinline__ float sample_pick(float v, int row, int c, int s_loc)
 // normalisers (sums of exponentials of non-positive numbers, >= 1) and on 1 + e^-|x| (in (1, 2])
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
+// clip_by_global_norm's coefficient clip / max(norm, clip) (model.py:201), written so that a non-finite norm is NOT
+// swallowed: fmaxf(NaN, clip) is clip, i.e. a diverged step would update with coefficient 1 and look healthy.  TF 1.8
+// forms scale = clip * min(1 / norm, 1 / clip) with Eigen's (y < x ? y : x), which hands a NaN norm on to every clipped
+// gradient; here NaN -> NaN (the table scale and every parameter of the step follow), +Inf -> 0.
+__device__ __forceinline__ float clip_coef(float norm, float clip) { return norm <= clip ? 1.0f : clip / norm; }
+
 __device__ __forceinline__ float dot4(f32x4 a, f32x4 b) {
   return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
 }

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(1024) void k_shard_summary(SummaryArgs a) {
     const double S_tot = ((double)tail[2] + *a.S_cate) * (double)P * (double)P;   // stored sums -> true tables
     const double sq = (double)tail[1] * (double)(inv_g * inv_g) + (double)a.reg * (double)a.reg * S_tot + sh[0];
     const float norm = (float)sqrt(sq);
-    const float coef = a.clip / fmaxf(norm, a.clip);  // clip_by_global_norm (model.py:201)
+    const float coef = clip_coef(norm, a.clip);  // clip_by_global_norm (model.py:201)
     sh_step = coef * a.lr;
     sh_coef = coef;
     if (blockIdx.x == 0) {

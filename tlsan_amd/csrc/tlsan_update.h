@@ -1000,7 +1000,7 @@ __device__ __forceinline__ void step_summary(const FinArgs& a, int nsqd, double*
     const double St = St0 * (double)P * (double)P;  // true tables = P * stored
     sq = shd[0] + (double)sc1 + (double)a.reg * (double)a.reg * St;
     const float norm = (float)sqrt(sq);
-    const float coef = a.clip / fmaxf(norm, a.clip);
+    const float coef = clip_coef(norm, a.clip);
     a.hdr->coef = coef;
     a.hdr->P_prev = P;
     if (a.count_step) a.hdr->nstep += 1;
@@ -1220,7 +1220,7 @@ __global__ __launch_bounds__(256) void k_clip_dedup(const double* rown_part, int
   }
   if (tid == 0) {
     const float norm = (float)sqrt(shd[0]);
-    hdr->coef = clip / fmaxf(norm, clip);
+    hdr->coef = clip_coef(norm, clip);
     if (out_gnorm) *out_gnorm = norm;
   }
 }

@@ -289,6 +289,7 @@ class Model(object):
         self._started_word = C.c_uint32.from_address(self._started_addr)
         self._start_seq = 0
         self.poll_seconds = 0.0     # time train_async spent polling the `started` word (the host waiting for the GPU)
+        self.started_at = None      # a list: train_async appends the host time at which it saw each step's first kernel start
         self._side = None
         self._step = 0
         self._epoch = 0
@@ -606,7 +607,10 @@ class Model(object):
                         t0 = time.perf_counter()
                     elif time.perf_counter() - t0 > 30.0:
                         raise RuntimeError("train_async: the step's first kernel did not start within 30 s")
-                self.poll_seconds += time.perf_counter() - tp     # (waiting for the GPU, not host work: bench.py subtracts it)
+                tq = time.perf_counter()
+                self.poll_seconds += tq - tp     # (waiting for the GPU, not host work: bench.py subtracts it)
+                if self.started_at is not None:  # (when the host SAW this step's first kernel start: bench.py's spread of step times)
+                    self.started_at.append(tq)
             for ndb, kk in ahead:
                 flag = L.INDEX_FOR_LAZY_SGD if (self.l2_mode == L.L2_LAZY and self.optimizer == "sgd") else 0
                 L.check(self.lib.tlsan_batch_index(C.byref(self.dims), C.byref(ndb.c), self.cparams.item_cate, self.state.data_ptr(), kk | flag,
