@@ -1,0 +1,12 @@
+#!/bin/bash
+# On the GPU box: interleaved rounds of the bench over every ab_run/*.so, fp32 AND the bf16 tables + operands leg; the
+# in-tree library is never overwritten: each run loads its variant through TLSAN_LIB_PATH.
+#   scripts/abrun3.sh [rounds] [bench args...]
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+rounds=${1:-3}; shift
+for i in $(seq $rounds); do
+  for so in ab_run/*.so; do
+    n=$(basename $so .so)
+    TLSAN_LIB_PATH=$PWD/$so timeout 300 python bench.py --no-cpu-baseline --accuracy-steps 0 --also-bf16 1 "$@" 2>&1 | grep '"metric"' | python -c "import json,sys; d=json.loads(sys.stdin.read()); b=d['bf16_mfma']; print('%-10s fp32 step %.2f us k_fwd_bwd %.2f | bf16 step %.2f us k_fwd_bwd %.2f | loss %s %s' % ('$n', d['ms_per_step']*1e3, d['roofline']['kernel_ms']*1e3, b['ms_per_step']*1e3, b['roofline']['kernel_ms']*1e3, d['final_loss'], b['final_loss']))"
+  done
+done

@@ -6,5 +6,5 @@ tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/ks_$tag
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$tag -- python3 $R/scripts/shape_bench.py "$@" > /tmp/ks_$tag.log 2>&1
-echo "== $tag: $(tail -1 /tmp/ks_$tag.log)"
+echo "== $tag: $(grep us/step /tmp/ks_$tag.log | tail -1)"
 python3 $R/scripts/kstats.py /tmp/ks_$tag ${KSTATS_TOP:-8}
