@@ -218,13 +218,6 @@ static bool balanced(const tlsan_dims* d, const tlsan_batch* b) {
   // profiles/r05_ab_bal_reg_shapes2.txt
   return bal_reg_mode() != 0 && b->Sn > 0 && (b->B + 15) / 16 <= FUSED_DK_MAX_GROUPS && d->item_count <= (1 << 18);
 }
-// The head of every pass of the fused kernel as one record per sample slot (BalArgs.plan / FwdArgs.plan, round 6): built
-// with the index of every training batch whose windows stay in registers; consumed by launches without dropout (the
-// dropout variants keep a window per column group and rank differently).  TLSAN_PLAN=0: off (A/B).
-static bool planned(const tlsan_dims* d, const tlsan_batch* b) {
-  static const int on = [] { const char* e = getenv("TLSAN_PLAN"); return e ? atoi(e) : 1; }();
-  return on != 0 && b && b->B <= BAL_PLAN_CAP && !streamed(d->Ls);
-}
 #define UC_LIST_CAP (1 << 18)  // batches up to this many samples may keep a per-category sample list in the state
 // ... and do when a category sees many of the batch's samples (cursor atomics on few addresses inside the
 // fused kernel cost more than the extra launch on the index stream): more than 32 samples per category
@@ -264,7 +257,6 @@ struct St {  // persistent state
   DeltaRec* S_delta;                                      // per-workgroup changes of the sum of squares, tagged by step (tlsan_update.h)
   long long* scan_bsum[TLSAN_INDEX_SLOTS];                                // per-chunk sums of the index scan (large tables), per slot
   int32_t* perm[TLSAN_INDEX_SLOTS];                                       // samples of every workgroup of the fused kernel (BalArgs), BAL_CAP each
-  int4* plan[TLSAN_INDEX_SLOTS];                                          // the head of every sample slot's pass (BalArgs.plan), BAL_CAP + 16 each
   int32_t* scan_ticket;                                                   // [index slot] arrivals of k_scan_block_sums (ScanArgs.bs_ticket), zero at rest
   int32_t* flag_user[TLSAN_INDEX_SLOTS];                                  // 256-row pieces of the user table that hold a count (ScanArgs.flag), zero at rest
   int32_t* uc_list[TLSAN_INDEX_SLOTS];                                    // samples of every category (u_cate uses), UC_LIST_CAP each
@@ -310,7 +302,6 @@ static void carve_state(const tlsan_dims* d, char* base, St* s) {
     s->scan_bsum[k] = (long long*)take(8 * ((size_t)(d->item_count + 4095) / 4096 + (d->cate_count + 4095) / 4096 +
                                             (d->user_count + 4095) / 4096));
   for (int k = 0; k < TLSAN_INDEX_SLOTS; ++k) s->perm[k] = (int32_t*)take(4 * (size_t)BAL_CAP);
-  for (int k = 0; k < TLSAN_INDEX_SLOTS; ++k) s->plan[k] = (int4*)take(16 * ((size_t)BAL_CAP + 16));
   s->scan_ticket = (int32_t*)take(4 * 64);
   for (int k = 0; k < TLSAN_INDEX_SLOTS; ++k) s->flag_user[k] = (int32_t*)take(4 * (((size_t)d->user_count + 255) / 256));
   {
@@ -508,7 +499,7 @@ static int launch_scan(ScanArgs& sa, int nscan, long long* bsum, hipStream_t hs)
     CHECK_LAUNCH("k_scan_block_sums");
   }
   sa.bal.blk = nscan;
-  sa.us.blk = nscan + ((sa.bal.perm || sa.bal.plan) ? 1 : 0);
+  sa.us.blk = nscan + (sa.bal.perm ? 1 : 0);
   sa.is.blk = sa.us.blk + (sa.us.u ? 1 : 0);       // (the finishing blocks of the item side's counting sort come last)
   hipLaunchKernelGGL(k_index_scan, dim3(sa.is.blk + (sa.is.on ? sa.is.nfin : 0)), dim3(1024), 0, hs, sa);
   CHECK_LAUNCH("k_index_scan");
@@ -784,21 +775,16 @@ static int build_index(const tlsan_dims* d, const tlsan_batch* b, const int32_t*
   // (category segments: nothing walks the item offsets per category either -- 5 M items: 40 MB of writes per step less)
   sa.sparse = sparse_users ? ((1 << 2) | (cseg ? 1 : 0)) : 0;
   sa.n_uniq[0] = &st.hdr->n_uniq[k][0]; sa.n_uniq[1] = nullptr; sa.n_uniq[2] = &st.hdr->n_uniq[k][1];
-  if (balanced(d, b) || planned(d, b)) {
+  // (no ranking block for a launch that will not read it -- the 8-sample workgroups of small d = 128 batches take
+  //  the batch's own order; the index is built ahead of the step's hyper-parameters, so the groups are sized for a launch
+  //  without dropout, and run_backward asks the same question)
+  Shape shp;
+  if ((rc = shape_of(d, &shp))) return rc;
+  if (balanced(d, b) && train_group(shp, d, b, nullptr) == shp.NSB) {
     sa.bal.sl = b->sl; sa.bal.sl_new = b->sl_new;
     sa.bal.B = b->B; sa.bal.Ls = d->Ls; sa.bal.Sn = b->Sn;
     sa.bal.by_window = streamed(d->Ls) ? 1 : (bal_reg_mode() == 2 ? -1 : 0);
-    Shape s;
-    if ((rc = shape_of(d, &s))) return rc;
-    const int grp = train_group(s, d, b, nullptr);     // samples per pass of the launch that will consume the index (no dropout)
-    // (the ranking deals the batch out in groups of 16: the 8-sample workgroups of small d = 128 batches take the batch's order)
-    sa.bal.perm = balanced(d, b) && grp == s.NSB ? st.perm[k] : nullptr;
-    if (planned(d, b)) {
-      sa.bal.plan = st.plan[k];
-      sa.bal.u = b->u; sa.bal.i = b->i; sa.bal.u_cate = b->u_cate;
-      sa.bal.nsb = grp;
-      sa.bal.pair = (s.D / s.CW) == 8 ? 1 : 0;       // (Geo: CPS = D / CW columns per sample, SPW = 16 / CPS = 2 samples per wavefront)
-    }
+    sa.bal.perm = st.perm[k];
   }
   if ((rc = launch_scan(sa, nscan, st.scan_bsum[k], hs))) return rc;
   if (uc_by_list(d, b)) {
@@ -839,10 +825,7 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   }
   const int grp = train_group(s, d, b, hp);  // samples per workgroup pass of the fused kernel (= per partial record)
   // (the ranking deals the batch out in groups of 16: the 8-sample workgroups of small d = 128 batches take the batch's order)
-  // (what build_index left: it sizes the groups for a launch without dropout -- the index is built ahead of the step's
-  //  hyper-parameters; a dropout launch of a small d = 128 batch takes 16-sample groups in the batch's own order)
-  a.perm = balanced(d, b) && grp == s.NSB && train_group(s, d, b, nullptr) == s.NSB ? st.perm[k] : nullptr;
-  a.plan = planned(d, b) && hp->dropout == 0.0f ? st.plan[k] : nullptr;
+  a.perm = balanced(d, b) && grp == s.NSB && train_group(s, d, b, nullptr) == s.NSB ? st.perm[k] : nullptr;   // (what build_index left)
   a.ngroups = (b->B + grp - 1) / grp;
   a.fuse_dk = fused_dk(s.D, a.ngroups) ? 1 : 0;
   prof_mark(1, hs);

@@ -529,17 +529,6 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
   const float gamma = dn[a.lay.gamma];
   const float P = a.p.scale ? *a.p.scale : 1.0f;  // tables hold W / P (lazy L2 decay)
   const int Ls = a.Ls, Sn = a.b.Sn, B = a.b.B;
-  // PLANK (round 6; windows in registers, no dropout): the head of a pass comes as ONE record per sample slot, built
-  // with the batch's index two steps ahead (FwdArgs.plan, BalArgs.plan) -- which sample the slot takes, its user,
-  // candidate, u_cate and lengths -- where the kernel used to make three dependent trips (perm -> the candidates' lengths,
-  // ranked here -> the slot's ids) before it could ask for its window.  The first pass's record is requested HERE, in
-  // front of the weights' copy to the LDS, so that it arrives with them: the dependent trips ahead of the first row
-  // gather go from seven (weights, perm, lengths, ids, window, categories, rows) to four.  Same slot assignment, same
-  // arithmetic: bit-equal results.
-  constexpr bool PLANK = TRAIN && !LSTREAM && !DROP && NB == 1;   // (d = 256: the second code path costs its kernels more in spilled registers than the trips save)
-  const bool use_plan = PLANK && a.plan != nullptr;   // (wave-uniform)
-  int4 rec0 = make_int4(0, 0, 0, 0);
-  if (PLANK && use_plan && (int)blockIdx.x < a.ngroups) rec0 = a.plan[(size_t)blockIdx.x * NSB + srow];
   // attention weights -> LDS once per workgroup (both blocks are contiguous runs of `dense`)
   if constexpr (PERM) {
     for (int o = tid; o < 2 * WBP; o += NW * 64) {
@@ -616,12 +605,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     // of the batch, so results stay bitwise reproducible.
     // (lane r of a row speaks for candidate r % NSB: with 8 samples per pass the upper half of a row repeats the lower)
     int bidx;
-    int4 prec = make_int4(0, 0, 0, 0);
     int offv = 0, f_total = 0;   // FLAT: lane r = where slot r's window starts in the flat list; the list's length
-    if (PLANK && use_plan) {
-      prec = g == (int)blockIdx.x ? rec0 : a.plan[(size_t)g * NSB + srow];
-      bidx = prec.x & 0xffff;
-    } else
     {
       const int rc = r % NSB;
       const int cand = a.perm != nullptr ? a.perm[g * NSB + rc] : g * NSB + rc;   // (the batch's samples ranked and dealt out: BalArgs)
@@ -656,20 +640,12 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
     DropCtx dc;
     dc.seed = a.drop_seed; dc.thr = a.drop_thr; dc.inv = a.drop_inv; dc.sbase = 2u * ((uint32_t)bidx + a.drop_sample0);
     const int bb = vs ? bidx : 0;
-    int uid, it_i, n_l, n_s;
-    if (PLANK && use_plan) {   // (the record holds what the loads below fetch: lengths already clamped, 0 for a slot past the batch)
-      uid = prec.y;
-      it_i = prec.z;
-      n_l = (prec.x >> 16) & 0xff;
-      n_s = (int)((unsigned)prec.x >> 24);
-    } else {
-      uid = a.b.u[bb];
-      it_i = a.b.i[bb];
-      n_l = vs ? a.b.sl[bb] : 0;
-      n_l = min(n_l, Ls);
-      n_s = vs ? a.b.sl_new[bb] : 0;
-      n_s = min(n_s, Sn);
-    }
+    const int uid = a.b.u[bb];
+    const int it_i = a.b.i[bb];
+    int n_l = vs ? a.b.sl[bb] : 0;
+    n_l = min(n_l, Ls);
+    int n_s = vs ? a.b.sl_new[bb] : 0;
+    n_s = min(n_s, Sn);
     float loss_acc = 0.0f, sq_acc = 0.0f, dgam = 0.0f;
     // ------------------------------------------------------------------ P1: long block
     // All loads are unconditional on clamped (always valid) addresses so that they are issued
@@ -1167,7 +1143,7 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
       const int id_k = a.b.hist_i[(size_t)bb * Ls + kc];
       const float ht_k = a.b.hist_t[(size_t)bb * Ls + kc];
       const float ut_k = a.p.usert_emb[(size_t)uid * a.p.ld_usert + kc];
-      ucat = (PLANK && use_plan) ? prec.w : a.b.u_cate[bb];
+      ucat = a.b.u_cate[bb];
       ct_i = a.p.item_cate[it_i];   // (with the stage that already waits for the sample's scalars: no trip of its own later)
       sid = (Sn > 0) ? a.b.hist_i_new[(size_t)bb * Sn + min(kk, max(Sn - 1, 0))] : 0;   // first chunk of session ids (load_chunk(0)), with the window's ids
       // (round 2 measured the short block's first ids / categories / cursor draws / first row riding with these stages

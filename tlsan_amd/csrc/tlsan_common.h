@@ -495,7 +495,6 @@ struct FwdArgs {
   float* Gc;        // [B, dc]           u_cate rows, grouped by category
   int32_t* cur_item; int32_t* cur_user; int32_t* cur_uc;
   const int32_t* perm;    // optional: perm[16 g + j] = sample j of workgroup pass g (>= B: none); BalArgs, tlsan_update.h
-  const int4* plan;       // optional (windows in registers, no dropout): plan[NSB g + slot] = the slot's sample, lengths, user, candidate, u_cate -- BalArgs.plan
   int32_t uc_by_sample;   // != 0: Gc rows are written in SAMPLE order (row b = sample b) and the index holds the
                           // samples of every category (uc_list, k_uc_fill): no cursor is drawn for the u_cate use
   int32_t fuse_dk;  // != 0: this launch forms the dK partials itself (Geo::FUSE_DK builds; chosen per launch, tlsan_api.hip)

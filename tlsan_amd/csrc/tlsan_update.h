@@ -200,17 +200,7 @@ struct BalArgs {
   const int32_t* sl; const int32_t* sl_new;
   int32_t B, Ls, Sn, by_window;
   int32_t blk;        // index of the block that does this (the first one behind the scan's blocks)
-  int32_t* perm;      // NULL: the batch's own order (groups of consecutive samples)
-  // Round 6: the head of a pass of the fused kernel as ONE record per sample slot (FwdArgs.plan).  A pass used to start
-  // with three dependent trips before it could ask for its window -- perm -> the candidates' lengths (ranked in the
-  // kernel: which sample takes which slot) -> the slot's user / candidate / lengths; all of it is a function of the ids,
-  // known two batches ahead.  plan[nsb g + slot] = {sample | window << 16 | session << 24, user, candidate, u_cate}
-  // with the slot assignment k_fwd_bwd itself would make (its ranking of the group's candidates, restated below).
-  // NULL: none (streamed windows, batches beyond BAL_CAP).
-  int4* plan;
-  const int32_t* u; const int32_t* i; const int32_t* u_cate;
-  int32_t nsb;        // samples per pass of the launch that will consume the plan (16, or 8: Geo<128, 16, 4>)
-  int32_t pair;       // != 0: two samples per wavefront (k_fwd_bwd: SPW == 2) -- slot = rank < nsb / 2 ? 2 rank : 2 (nsb - 1 - rank) + 1
+  int32_t* perm;      // NULL: no balancing
 };
 // Windows in registers (by_window == 0; round 5): a workgroup's time is its longest wavefront's -- session steps in P3,
 // window positions in P1 / P5 -- and the launch ends with the workgroups that hold one of the batch's few long sessions
@@ -219,39 +209,15 @@ struct BalArgs {
 // order as above; the others are ranked by window length, shortest first, and handed out in contiguous runs -- group 0,
 // which holds the longest session, gets the shortest windows, the last groups get full windows only (which most
 // wavefronts have anyway: half the batch's windows are full).
-#define BAL_PLAN_CAP 4096   // batches up to this many samples get a plan (BalArgs.plan): their ranking keys sit in the block's LDS
 #define BAL_KEYS 192    // by_window: costs 0 .. 96 (TLSAN_LS_CAP); else 11 * min(session, 15) + window for sessions >= 2, 10 - window below
 #define BAL_TAIL_KEY 10 // (by_window == 0) the largest key of a sample with a session of one entry or none
 
 __device__ __forceinline__ void balance_block(const BalArgs& b) {   // 1024 threads = 16 wavefronts
   __shared__ int wcnt[16][BAL_KEYS];   // samples of every cost per wavefront -> where the wavefront's first one of that cost ranks
   __shared__ int start[BAL_KEYS];      // rank of the first sample of every cost
-  __shared__ int pkey[BAL_PLAN_CAP + 16];   // plan: the kernel's ranking key of the sample at every position of perm (0: none)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int B = b.B, G = (B + 15) / 16;
   const int CH = (B + 1023) / 1024, nper = 64 * CH;   // wavefront w owns samples [w nper, (w + 1) nper), 64 per round
-  const bool plan = b.plan != nullptr;              // (B <= BAL_PLAN_CAP then: CH <= BAL_PLAN_CAP / 1024)
-  const int nsb = plan ? b.nsb : 16, NG = (B + nsb - 1) / nsb;
-  // plan: what the sample's owner knows -- its position in perm, and its record but for the slot (requested with the
-  // lengths the ranking reads: no trip of its own)
-  constexpr int PCH = BAL_PLAN_CAP / 1024;
-  int ppos[PCH];
-  int4 prec[PCH];
-  if (plan) {
-    for (int o = tid; o < nsb * NG; o += 1024) pkey[o] = 0;
-#pragma unroll
-    for (int c = 0; c < PCH; ++c) {
-      const int i = wave * nper + c * 64 + lane;
-      ppos[c] = -1;
-      prec[c] = make_int4(0, 0, 0, 0);
-      if (c < CH && i < B) {
-        const int cl = min(max(b.sl[i], 0), b.Ls), cs = min(max(b.sl_new[i], 0), b.Sn);
-        prec[c] = make_int4(i | (cl << 16) | (cs << 24), b.u[i], b.i[i], b.u_cate[i]);   // (B <= BAL_PLAN_CAP < 2^16, window <= 10, session < 128)
-        ppos[c] = i;                                // (the batch's own order, unless the ranking below places it)
-      }
-    }
-  }
-  if (b.perm != nullptr) {
   for (int o = tid; o < 16 * BAL_KEYS; o += 1024) (&wcnt[0][0])[o] = 0;
   __syncthreads();
   auto key_of = [&](int i) {
@@ -289,19 +255,16 @@ __device__ __forceinline__ void balance_block(const BalArgs& b) {   // 1024 thre
   // (by_window == 0: the groups are numbered backwards -- the full-window groups, the slowest ones now, get the lowest
   //  block numbers and start first; the launch places its workgroups over 0.6 us.  by_window < 0: not, for A/B)
   const bool rev = b.by_window == 0;
-  auto place = [&](int rank, int sample) -> int {
-    int at;
+  auto place = [&](int rank, int sample) {
     if (rank < H * G) {
       const int j = rank / G, idx = rank - j * G;
       const int g = (j & 1) ? G - 1 - idx : idx;
-      at = (rev ? G - 1 - g : g) * 16 + j;
+      b.perm[(rev ? G - 1 - g : g) * 16 + j] = sample;
     } else {   // the tail, shortest windows first: a contiguous run per group
       const int r2 = rank - H * G, per = 16 - H;
       const int g = r2 / per;
-      at = (rev ? G - 1 - g : g) * 16 + H + (r2 - g * per);
+      b.perm[(rev ? G - 1 - g : g) * 16 + H + (r2 - g * per)] = sample;
     }
-    b.perm[at] = sample;
-    return at;
   };
   volatile int* mine = &wcnt[wave][0];   // (wave-private from here on: DS operations of a wavefront execute in order)
   for (int c = 0; c < CH; ++c) {
@@ -318,43 +281,10 @@ __device__ __forceinline__ void balance_block(const BalArgs& b) {   // 1024 thre
     const unsigned long long below = m & ((1ull << lane) - 1ull);
     const int kk = v ? k : 0;
     const int base = start[kk] + mine[kk];                 // ranks taken by earlier wavefronts and earlier rounds
-    if (v) {
-      const int at = place(base + __popcll(below), i);     // within a cost and a round: lane order = sample order
-      if (plan && c < PCH) ppos[c] = at;
-    }
+    if (v) place(base + __popcll(below), i);               // within a cost and a round: lane order = sample order
     if (v && below == 0ull) mine[k] = mine[k] + __popcll(m);   // the group's first lane counts the round in
   }
   if (B + tid < 16 * G) place(B + tid, B);   // (a last group that is not full)
-  }
-  if (!plan) return;
-  // ---- the plan: every owner files its sample's ranking key at its position; after one barrier it reads the keys of its
-  // group, ranks itself as k_fwd_bwd would (session length, then window length, then the place in the group) and writes
-  // its record to the slot the kernel gives that rank.  The empty positions of a last, partial group rank behind every
-  // sample (the kernel's keys for them are <= 0) in the order of their places.
-  __syncthreads();   // (pkey is cleared)
-#pragma unroll
-  for (int c = 0; c < PCH; ++c)
-    if (ppos[c] >= 0) {
-      const int rc = ppos[c] % nsb, cl = (prec[c].x >> 16) & 0xff, cs = (int)((unsigned)prec[c].x >> 24);
-      pkey[ppos[c]] = (((cs << 12) | (cl << 4)) | (15 - rc)) + 1;     // distinct inside a group; larger = heavier (k_fwd_bwd, windows in registers)
-    }
-  __syncthreads();
-  auto slot_of = [&](int rank) { return b.pair ? (rank < nsb / 2 ? 2 * rank : 2 * (nsb - 1 - rank) + 1) : rank; };
-#pragma unroll
-  for (int c = 0; c < PCH; ++c)
-    if (ppos[c] >= 0) {
-      const int g0 = ppos[c] - ppos[c] % nsb, key = pkey[ppos[c]];
-      int rank = 0;
-      for (int j = 0; j < nsb; ++j) rank += pkey[g0 + j] > key ? 1 : 0;
-      b.plan[g0 + slot_of(rank)] = prec[c];
-    }
-  for (int t = tid; t < nsb * NG; t += 1024)      // positions without a sample
-    if (pkey[t] == 0) {
-      const int g0 = t - t % nsb;
-      int rank = 0;
-      for (int j = 0; j < nsb; ++j) rank += (pkey[g0 + j] > 0 || (pkey[g0 + j] == 0 && j < t - g0)) ? 1 : 0;
-      b.plan[g0 + slot_of(rank)] = make_int4(B, 0, 0, 0);
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -817,7 +747,7 @@ __global__ __launch_bounds__(1024) void k_scan_block_sums(ScanArgs a) {
 }
 
 __global__ __launch_bounds__(1024) void k_index_scan(ScanArgs a) {
-  if ((a.bal.perm != nullptr || a.bal.plan != nullptr) && (int)blockIdx.x == a.bal.blk) {
+  if (a.bal.perm != nullptr && (int)blockIdx.x == a.bal.blk) {
     balance_block(a.bal);
     return;
   }
