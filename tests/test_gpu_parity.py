@@ -1109,6 +1109,35 @@ def test_item_index_from_a_counting_sort_of_the_batch():
     assert digests[0] == digests[1], digests
 
 
+def test_speculative_one_pass_lazy_update():
+    """Tables that live in HBM (more than 512 MB of user / item rows, category segments) take the lazy-L2 step as ONE pass
+    over the used rows BESIDE the finalize, with clip coefficient 1, and a second launch that commits the table scale and --
+    after a clipped step only -- corrects the rows (k_finalize_update / k_spec_commit, tlsan_update.h).
+    TLSAN_LAZY_ONE_PASS=2 with TLSAN_CSEG_MIN=1 (both read once per process) sends every table that way: the oracle tests of
+    lazy train steps must hold -- clip inactive AND active (test_lazy_l2_matches_dense_oracle[0.02]: the correcting pass),
+    bf16 tables, hipGraph replay, a diverged step -- and unclipped steps must leave the SAME BITS as the one-pass form that
+    waits for the finalize (TLSAN_LAZY_SPEC=0)."""
+    import re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TLSAN_LAZY_ONE_PASS="2", TLSAN_CSEG_MIN="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-m", "gpu", "-q", "-x", "-k",
+                        "test_lazy_l2_matches_dense_oracle or test_lazy_is_deterministic or test_category_segments_match_oracle "
+                        "or test_full_size_batch_matches_oracle or test_one_hot_row_takes_every_use or test_multi_step_tracks_oracle "
+                        "or test_prefetched_index_equals_inline or test_periodic_scale_fold or test_bf16_tables or test_graph_replay_equals_eager "
+                        "or test_nonfinite_inputs_give_nonfinite_loss or test_real_fixture_batches"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stdout[-6000:] + r.stderr[-2000:]
+    mt = re.search(r"(\d+) passed", r.stdout)
+    assert mt and int(mt.group(1)) >= 25, r.stdout[-2000:]
+    digests = []
+    for spec in ("1", "0"):
+        env = dict(os.environ, TLSAN_LAZY_ONE_PASS="2", TLSAN_CSEG_MIN="1", TLSAN_LAZY_SPEC=spec)
+        r = subprocess.run([sys.executable, "-c", _ISORT_DIGEST % root], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        digests.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1])
+    assert digests[0] == digests[1], digests
+
+
 @pytest.mark.parametrize("d,Ls", [(128, 10), (64, 10), (128, 33), (256, 10)])
 def test_dropout_with_bf16_tables(d, Ls):
     """config['dropout'] > 0 with table_dtype='bf16' (round 3 refused the combination): the gradients equal the oracle's

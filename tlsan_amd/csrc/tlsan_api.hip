@@ -442,6 +442,20 @@ static void category_split(ApplyArgs& A, const tlsan_dims* d, const tlsan_batch*
   }
 }
 
+// The lazy update as ONE pass (round 6).  The split form (row sums in the finalize's launch, then k_update_lazy) hides the
+// finalize's chain behind the row sums and wins where the tables sit in the caches (the bench shape); where they live in
+// HBM the summed rows' round trip through memory (written by one launch, read by the next, beside the parameter rows'
+// read-modify-write) is what the tail spends its time on.  Category segments only (the tables this is about have
+// thousands of categories; few, large categories need the split form's shared category workgroups).
+// TLSAN_LAZY_ONE_PASS: 0 never, 1 (default) by table size, 2 whenever the tables take category segments.
+static bool lazy_one_pass(const tlsan_dims* d, const ApplyArgs& A) {
+  static const int mode = [] { const char* e = getenv("TLSAN_LAZY_ONE_PASS"); return e ? atoi(e) : 1; }();
+  if (mode == 0 || !A.cseg) return false;
+  if (mode == 2) return true;
+  const double bytes = 4.0 * ((double)d->item_count * d->d_item + (double)d->user_count * (d->d_item + d->Ls));
+  return bytes > 512e6;      // (well beyond the 256 MiB Infinity Cache)
+}
+
 // second half of the split lazy update (the first half rides with the dense finalize, run_backward)
 static int launch_update_lazy(ApplyArgs A, int B, int Sn, hipStream_t hs) {
   lazy_blocks(A, B, Sn);
@@ -459,7 +473,7 @@ static int launch_update_lazy(ApplyArgs A, int B, int Sn, hipStream_t hs) {
   return TLSAN_OK;
 }
 
-static int launch_apply(int mode, ApplyArgs A, bool with_dense, hipStream_t hs) {
+static int launch_apply(int mode, ApplyArgs A, bool with_dense, hipStream_t hs, bool lazy = false) {
   const dim3 g1(A.nbC + A.nbI + A.nbU + (with_dense ? A.nbD : 0)), blk(256);
   const bool wide = apply_wide(A);
   const bool bf16 = A.p.table_dtype == TLSAN_TABLE_BF16;
@@ -474,7 +488,7 @@ static int launch_apply(int mode, ApplyArgs A, bool with_dense, hipStream_t hs) 
     }                                                                                                        \
   } while (0)
   switch (mode) {
-    case AP_UPDATE: AP_LAUNCH(AP_UPDATE, false); break;
+    case AP_UPDATE: if (lazy) AP_LAUNCH(AP_UPDATE, true); else AP_LAUNCH(AP_UPDATE, false); break;
     case AP_GRADS: AP_LAUNCH(AP_GRADS, false); break;
     case AP_SUMSQ: AP_LAUNCH(AP_SUMSQ, false); break;
     default: AP_LAUNCH(AP_ROWNORM, false); break;
@@ -798,12 +812,12 @@ static int build_index(const tlsan_dims* d, const tlsan_batch* b, const int32_t*
 static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params* p, const tlsan_batch* b,
                         const tlsan_hparams* hp, bool update, const tlsan_step_out* out, const Ws& w, const St& st,
                         const tlsan_dense_layout& L, hipStream_t hs, const ApplyArgs* presum = nullptr,
-                        float* gd_out = nullptr) {
-  const bool commit = update && hp->l2_mode == TLSAN_L2_LAZY;
+                        float* gd_out = nullptr, bool sparse_index = false, bool spec = false) {
+  const bool commit = update && hp->l2_mode == TLSAN_L2_LAZY && !spec;
   const int k = hp->index_slot;
   int rc;
   prof_mark(0, hs);
-  if (!hp->index_prebuilt && (rc = build_index(d, b, p->item_cate, st, k, hs, presum != nullptr))) return rc;
+  if (!hp->index_prebuilt && (rc = build_index(d, b, p->item_cate, st, k, hs, presum != nullptr || sparse_index))) return rc;
   // --- fused forward + backward
   FwdArgs a;
   fill_fwd(a, d, s, p, b, w, L);
@@ -858,6 +872,32 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   f.out_loss = out ? out->loss : nullptr;
   f.out_gnorm = out ? out->gnorm : nullptr;
   f.out_sq = out ? out->sq_rows : nullptr;
+  if (presum && spec) {
+    // tables in HBM: the row workgroups UPDATE beside the finalize, with clip coefficient 1 (k_finalize_update; the commit
+    // and -- after a clipped step -- the correction follow in k_spec_commit, tlsan_train_step_opt)
+    ApplyArgs A = *presum;
+    lazy_blocks(A, b->B, b->Sn);
+    f.count_step = 0; f.spec = 1;
+    const dim3 grid(w.nfin + 1 + A.nbC + A.nbI + A.nbU);
+    const bool wide = apply_wide(A), bf16 = A.p.table_dtype == TLSAN_TABLE_BF16;
+#define FU_LAUNCH(DD, HH)                                                                                                            \
+  do {                                                                                                                               \
+    if (bf16) {                                                                                                                      \
+      if (wide) hipLaunchKernelGGL((k_finalize_update<DD, HH, true, TLSAN_TABLE_BF16>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);  \
+      else hipLaunchKernelGGL((k_finalize_update<DD, HH, false, TLSAN_TABLE_BF16>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);      \
+    } else {                                                                                                                         \
+      if (wide) hipLaunchKernelGGL((k_finalize_update<DD, HH, true, TLSAN_TABLE_F32>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);   \
+      else hipLaunchKernelGGL((k_finalize_update<DD, HH, false, TLSAN_TABLE_F32>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);       \
+    }                                                                                                                                \
+  } while (0)
+    if (s.D == 64) FU_LAUNCH(64, 8);
+    else if (s.D == 128) FU_LAUNCH(128, 16);
+    else FU_LAUNCH(256, 32);
+#undef FU_LAUNCH
+    CHECK_LAUNCH("k_finalize_update");
+    prof_mark(4, hs);
+    return TLSAN_OK;
+  }
   if (presum) {
     // lazy update: the exact row sums of the apply pass share the launch (they wait for nothing it produces)
     ApplyArgs A = *presum;
@@ -997,7 +1037,30 @@ int tlsan_train_step_opt(const tlsan_dims* d, const tlsan_params* p, const tlsan
     if (opt->kind == TLSAN_OPT_ADAM)  // adam.py: lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)
       A.oalpha = (float)((double)hp->lr * sqrt(1.0 - pow((double)opt->beta2, opt->step)) / (1.0 - pow((double)opt->beta1, opt->step)));
   }
-  if (hp->l2_mode == TLSAN_L2_LAZY) {   // row sums beside the finalize, then the short elementwise update
+  if (hp->l2_mode == TLSAN_L2_LAZY && lazy_one_pass(d, A)) {
+    // tables that live in HBM: ONE pass over the used rows behind the finalize (k_apply<AP_UPDATE, lazy>: segment sums and
+    // the update of a row by the same lanes) instead of row sums beside the finalize + an elementwise update -- the
+    // summed rows make no round trip through memory (see lazy_one_pass)
+    static const int spec_on = [] { const char* e = getenv("TLSAN_LAZY_SPEC"); return e ? atoi(e) : 1; }();
+    ApplyArgs A1 = A;
+    lazy_blocks(A1, b->B, b->Sn);
+    if (spec_on) {   // the row update beside the finalize, with coefficient 1; then the commit (+ the correction of a clipped step)
+      if ((rc = run_backward(d, s, p, b, hp, true, out, w, st, L, hs, &A, nullptr, true, true))) return rc;
+      const dim3 grid(A1.nbD + A1.nbC + A1.nbI + A1.nbU);
+      const bool wide = apply_wide(A1);
+      if (A1.p.table_dtype == TLSAN_TABLE_BF16) {
+        if (wide) hipLaunchKernelGGL((k_spec_commit<true, TLSAN_TABLE_BF16>), grid, dim3(256), 0, hs, A1);
+        else hipLaunchKernelGGL((k_spec_commit<false, TLSAN_TABLE_BF16>), grid, dim3(256), 0, hs, A1);
+      } else {
+        if (wide) hipLaunchKernelGGL((k_spec_commit<true, TLSAN_TABLE_F32>), grid, dim3(256), 0, hs, A1);
+        else hipLaunchKernelGGL((k_spec_commit<false, TLSAN_TABLE_F32>), grid, dim3(256), 0, hs, A1);
+      }
+      CHECK_LAUNCH("k_spec_commit");
+    } else {         // (A/B: the finalize's whole chain, then one pass over the rows)
+      if ((rc = run_backward(d, s, p, b, hp, true, out, w, st, L, hs, nullptr, nullptr, true))) return rc;
+      if ((rc = launch_apply(AP_UPDATE, A1, true, hs, true))) return rc;
+    }
+  } else if (hp->l2_mode == TLSAN_L2_LAZY) {   // row sums beside the finalize, then the short elementwise update
     category_split(A, d, b);
     if ((rc = run_backward(d, s, p, b, hp, true, out, w, st, L, hs, &A))) return rc;
     if ((rc = launch_update_lazy(A, b->B, b->Sn, hs))) return rc;

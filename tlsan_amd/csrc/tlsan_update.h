@@ -26,7 +26,12 @@ struct StateHdr {
   int32_t spart_n;         // leading records of S_delta the last update may have written
   int32_t n_hot[TLSAN_INDEX_SLOTS];        // [index slot] item rows with more than AP_HOT uses (k_index_scan; listed in the state)
   uint32_t folded;         // the step (nstep) whose S_delta records are already part of St (a step is folded once)
-  float pad0[15];
+  // the speculative one-pass lazy update (k_finalize_update / k_spec_commit): the step summary leaves the table scale
+  // AFTER the step and the step's salt here; P and nstep themselves are committed by the second launch, so that both
+  // stay put while the first launch's row workgroups read them
+  float P_next;
+  uint32_t spec_salt;
+  float pad0[13];
   // ---- its own 128-B line: hammered by atomics, must not share a line with anything that is read
   int32_t ticket;          // arrival counter of k_dense_finalize: the last workgroup writes the step summary
   int32_t pad1[31];
@@ -950,6 +955,8 @@ struct FinArgs {
   int32_t norm_mode;
   int32_t commit;          // lazy L2 update: advance the table scale P (P_prev keeps the old value)
   int32_t count_step;      // an update follows (train step, not tlsan_grads): advance hdr->nstep
+  int32_t spec;            // speculative one-pass lazy update: neither P nor nstep are touched here (commit = count_step = 0);
+                           // the scale after the step and the step's salt go to hdr->P_next / hdr->spec_salt (k_spec_commit)
   float* out_loss; float* out_gnorm; float* out_sq;
 };
 
@@ -1005,6 +1012,10 @@ __device__ __forceinline__ void step_summary(const FinArgs& a, int nsqd, double*
     a.hdr->P_prev = P;
     if (a.count_step) a.hdr->nstep += 1;
     if (a.commit) a.hdr->P = P * (1.0f - a.lr * coef * a.reg);
+    if (a.spec) {
+      a.hdr->P_next = P * (1.0f - a.lr * coef * a.reg);
+      a.hdr->spec_salt = a.hdr->nstep + 1;
+    }
     if (a.norm_mode == TLSAN_NORM_TF18 && a.out_gnorm) *a.out_gnorm = norm;
     if (a.out_loss) *a.out_loss = sc0 * a.inv_B + a.reg * (float)(0.5 * St);
     if (a.out_sq) *a.out_sq = sc1;
@@ -1325,14 +1336,16 @@ __device__ __forceinline__ void combine_groups(double (&acc)[NCH][4]) {
     }
 }
 
-__device__ __forceinline__ void block_delta_store(double part, double* shd, DeltaRec* dst, unsigned long long tag) {
+// accum: add to the record this step's first launch left (the correcting pass of a speculative update, k_spec_commit)
+__device__ __forceinline__ void block_delta_store(double part, double* shd, DeltaRec* dst, unsigned long long tag, bool accum = false) {
   __syncthreads();
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) part += __shfl_xor(part, o);
   if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = part;
   __syncthreads();
   if (threadIdx.x == 0) {
-    dst->v = shd[0] + shd[1] + shd[2] + shd[3];
+    const double v = shd[0] + shd[1] + shd[2] + shd[3];
+    dst->v = (accum && dst->tag == tag) ? dst->v + v : v;
     dst->tag = tag;
   }
 }
@@ -1449,6 +1462,7 @@ struct ApCtx {
   uint32_t salt;      // per-step salt of the stochastic rounding (bf16 tables)
   float coef;         // clip coefficient (optimizers other than SGD)
   OptCtx oc;
+  bool accum = false; // UPDATE: add the block's change of the sum of squares to its record of this step (k_spec_commit)
 };
 
 #define AP_STAMP(k)                                                                      \
@@ -1632,7 +1646,7 @@ __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx
   if constexpr (RESET) {
     if (tid == 0 && nu > 0) a.cnt_uc[c] = 0;
   }
-  if constexpr (MODE == AP_UPDATE) block_delta_store(part, shp, &a.delta_out[x.blk], x.salt);
+  if constexpr (MODE == AP_UPDATE) block_delta_store(part, shp, &a.delta_out[x.blk], x.salt, x.accum);
   else if constexpr (MODE != AP_GRADS) block_part_store(part, shp, &a.part_out[x.blk]);
 }
 
@@ -1886,7 +1900,7 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
       if (n > 0 && l16 == 0) (IS_ITEM ? a.cnt_item : a.cnt_user)[row] = 0;
     }
   }
-  if constexpr (MODE == AP_UPDATE) block_delta_store(part, shp, &a.delta_out[x.blk], x.salt);
+  if constexpr (MODE == AP_UPDATE) block_delta_store(part, shp, &a.delta_out[x.blk], x.salt, x.accum);
   else if constexpr (MODE != AP_GRADS) block_part_store(part, shp, &a.part_out[x.blk]);
 }
 
@@ -2015,7 +2029,7 @@ __device__ __forceinline__ void apply_cseg_block(const ApplyArgs& a, const ApCtx
       if (l16 == 0 && n > 0) a.cnt_uc[c] = 0;
     }
   }
-  if constexpr (MODE == AP_UPDATE) block_delta_store(part, shp, &a.delta_out[x.blk], x.salt);
+  if constexpr (MODE == AP_UPDATE) block_delta_store(part, shp, &a.delta_out[x.blk], x.salt, x.accum);
   else if constexpr (MODE != AP_GRADS) block_part_store(part, shp, &a.part_out[x.blk]);
 }
 
@@ -2210,6 +2224,103 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? 3 : 
     }
   }
   if (stp && x.tid == 0) { stp[6] = __builtin_amdgcn_s_memtime(); stp[5] = __builtin_amdgcn_s_memrealtime(); }
+}
+
+// ------------------------------------------------------------------------------------------
+// The lazy-L2 step for tables that live in HBM (round 6): the SPECULATIVE one-pass update.
+// The split form above sends every summed row through memory (written by the row-sum launch, read by k_update_lazy beside
+// the parameter row's read-modify-write): at 10 M users / 5 M items that round trip is a third of the tail's traffic.  One
+// pass over the used rows (segment sums and the row's update by the same lanes, k_apply<AP_UPDATE, lazy>) avoids it but
+// needs the clip coefficient first, i.e. the finalize's whole chain in front of it (C5: 26 us).  clip_by_global_norm's
+// coefficient is 1 unless the global norm exceeds the clip (model.py:201) -- so:
+//   k_finalize_update : the finalize's workgroups lead the grid; the row workgroups update with coefficient 1 beside them.
+//                       Neither P nor nstep change during the launch (FinArgs.spec): the summary leaves P_next / spec_salt.
+//   k_spec_commit     : the dense parameters (which need the reduced gradients), the commit of P and nstep, and -- only if
+//                       the coefficient turned out to be < 1 (or not finite) -- a correcting pass over the same rows:
+//                       w += (scale_spec - scale_true) * sum, i.e. w_old - scale_true * sum up to one rounding.
+// Unclipped steps are bit-equal to the one-pass form; results stay a fixed function of the batch.  Category segments only.
+// (rows of tables with millions of rows are used once or twice per batch: two gradient rows in flight per 16-lane group
+//  instead of AP_OWN = 8 clamped loads of the same row -- 60 registers fewer, five workgroups per CU instead of three;
+//  longer segments are finished by the whole wavefront as everywhere, and the sums are exact: same bits)
+#ifndef SPEC_OWN
+#define SPEC_OWN 2
+#endif
+// (the wide form -- rows of 128 floats and more, C5 -- is held to four waves per SIMD: 149 registers left alone, i.e. three;
+//  at four 88 bytes per lane spill in the user-row role and C5 runs 281.5 -> 273.5 us/step.  The narrow form keeps three:
+//  at d = 128 with 10 M / 5 M tables the step is bound by the index stream, whose 1024-thread blocks find no slot beside
+//  five row workgroups per CU -- 80.5 us/step with three, 92 with five: profiles/r06_lazy_one_pass.md)
+#ifndef SPEC_WPE
+#define SPEC_WPE 4
+#endif
+template <int D, int DH, bool WIDE, int DT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? SPEC_WPE : 3))) void k_finalize_update(FinArgs f, int nbK, int nbS, ApplyArgs a) {
+  constexpr int NC = WIDE ? 2 : 1, NI = WIDE ? 2 : 1, NU = WIDE ? 4 : 2;
+  __shared__ double shd[256];
+  __shared__ double shp[4];
+  __shared__ int sh_last;
+  const int nfin = nbK + nbS + 1;
+  if ((int)blockIdx.x < nfin) {
+    dense_finalize_block<D, DH>(f, nbK, nbS, blockIdx.x, shd, &sh_last);
+    return;
+  }
+  ApCtx x;
+  x.tid = threadIdx.x; x.wave = x.tid >> 6; x.lane = x.tid & 63; x.grp = x.lane >> 4; x.l16 = x.lane & 15;
+  x.gid = x.wave * 4 + x.grp;
+  x.blk = blockIdx.x - nfin;
+  x.P = a.hdr->P;               // (stable: this launch's summary does not commit)
+  x.invP = 1.0f / x.P;
+  x.step = a.lr;                // coefficient 1
+  x.lazy_scale = x.step / (x.P * (1.0f - x.step * a.reg));
+  x.salt = a.hdr->nstep + 1;    // what the step's salt and record tag will be (hdr->spec_salt)
+  x.coef = 1.0f;
+  if (x.blk == 0 && x.tid == 0) a.hdr->spart_n = a.nbC + a.nbI + a.nbU;
+  const int blk = x.blk;
+  if (blk < a.nbC) apply_cseg_block<AP_UPDATE, true, NC, (WIDE ? SPEC_OWN : AP_OWN), DT>(a, x, blk * AP_ROWS_PB, shp);
+  else if (blk < a.nbC + a.nbI) apply_rows_block<AP_UPDATE, true, true, NI, (WIDE ? SPEC_OWN : AP_OWN), DT>(a, x, (blk - a.nbC) * AP_ROWS_PB, shp);
+  else apply_rows_block<AP_UPDATE, true, false, NU, (WIDE ? SPEC_OWN : AP_OWN / 2), DT>(a, x, (blk - a.nbC - a.nbI) * AP_ROWS_PB, shp);
+}
+
+// grid: nbD blocks of 256 dense parameters, then the row blocks of k_finalize_update (which return at once when the step was not clipped)
+template <bool WIDE, int DT>
+__global__ __launch_bounds__(256) void k_spec_commit(ApplyArgs a) {
+  constexpr int NC = WIDE ? 2 : 1, NI = WIDE ? 2 : 1, NU = WIDE ? 4 : 2;
+  __shared__ double shp[4];
+  const int tid = threadIdx.x;
+  const float coef = a.hdr->coef;
+  if ((int)blockIdx.x < a.nbD) {
+    if (blockIdx.x == 0 && tid == 0) {   // (nothing in this launch reads P or nstep: P_prev / spec_salt hold what it needs)
+      a.hdr->P = a.hdr->P_next;
+      a.hdr->nstep += 1;
+    }
+    const float step = a.lr * coef;
+    const int nd = blockIdx.x * 256 + tid;
+    if (nd < a.lay.n_dense) {
+      const float wn = a.p.dense[nd] - step * a.gd[nd];
+      a.p.dense[nd] = wn;
+      if (nd >= a.lay.K && nd < a.lay.k0) {
+        const int idx = nd - a.lay.K;
+        a.p.dense_KT[(size_t)(idx % a.D) * a.D + idx / a.D] = wn;
+      }
+    }
+    return;
+  }
+  if (coef == 1.0f) return;   // (block-uniform) the speculation held.  (A NaN coefficient takes the correcting pass and poisons the rows.)
+  ApCtx x;
+  x.tid = tid; x.wave = tid >> 6; x.lane = tid & 63; x.grp = x.lane >> 4; x.l16 = x.lane & 15;
+  x.gid = x.wave * 4 + x.grp;
+  x.blk = blockIdx.x - a.nbD;
+  x.P = a.hdr->P_prev;
+  x.invP = 1.0f / x.P;
+  const float st_true = a.lr * coef;
+  x.step = st_true - a.lr;                                                   // item_b: w_spec - (st_true - lr) g = w_old - st_true g
+  x.lazy_scale = st_true / (x.P * (1.0f - st_true * a.reg)) - a.lr / (x.P * (1.0f - a.lr * a.reg));
+  x.salt = a.hdr->spec_salt;
+  x.coef = coef;
+  x.accum = true;
+  const int blk = x.blk;
+  if (blk < a.nbC) apply_cseg_block<AP_UPDATE, true, NC, (WIDE ? SPEC_OWN : AP_OWN), DT>(a, x, blk * AP_ROWS_PB, shp);
+  else if (blk < a.nbC + a.nbI) apply_rows_block<AP_UPDATE, true, true, NI, (WIDE ? SPEC_OWN : AP_OWN), DT>(a, x, (blk - a.nbC) * AP_ROWS_PB, shp);
+  else apply_rows_block<AP_UPDATE, true, false, NU, (WIDE ? SPEC_OWN : AP_OWN / 2), DT>(a, x, (blk - a.nbC - a.nbI) * AP_ROWS_PB, shp);
 }
 
 // split category sums (Rc64, exact doubles) -> float output, and back to zero at rest (tlsan_grads)
