@@ -1306,9 +1306,9 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
             acc0 = TLSAN_MFMA(av0[s], bfr[kc][s], acc0);
             acc1 = TLSAN_MFMA(av1[s], bfr[kc + 1][s], acc1);
           }
-        } else {
-          acc0 = mm_mma<MM>(av0, bfr[kc], acc0);
-          acc1 = mm_mma<MM>(av1, bfr[kc + 1], acc1);
+        } else {   // (one 16x16x32 per pair of k-chunks, two accumulators alternating)
+          if ((kc >> 1) & 1) acc1 = mm_mma2<MM>(av0, av1, bfr[kc], bfr[kc + 1], acc1);
+          else acc0 = mm_mma2<MM>(av0, av1, bfr[kc], bfr[kc + 1], acc0);
         }
       }
       acc0 += acc1;
@@ -1779,8 +1779,8 @@ __global__ __launch_bounds__(512) void k_fwd_bwd(FwdArgs a) {
               acc1 = TLSAN_MFMA(av1[s], bfr[jc + 1][s], acc1);
             }
           } else {
-            acc0 = mm_mma<MM>(av0, bfr[jc], acc0);
-            acc1 = mm_mma<MM>(av1, bfr[jc + 1], acc1);
+            if ((jc >> 1) & 1) acc1 = mm_mma2<MM>(av0, av1, bfr[jc], bfr[jc + 1], acc1);
+            else acc0 = mm_mma2<MM>(av0, av1, bfr[jc], bfr[jc + 1], acc0);
           }
         }
         acc0 += acc1;

@@ -62,6 +62,23 @@ __device__ __forceinline__ f32x4 mm_mma(typename MMT<MM>::opd a, typename MMT<MM
     return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc, 0, 0, 0);
   }
 }
+// acc += A0 . B0 + A1 . B1 for two 16-deep contractions that share the accumulator: bf16 operands as ONE gfx950
+// v_mfma_f32_16x16x32_bf16 (round 6) -- lane (q, .) supplies k-slots 8q .. 8q+7, which are simply the lane's four values of
+// the first contraction followed by its four of the second (the k order inside a contraction is free as long as both
+// operands agree), so the fragments of the two 16-deep products are concatenated as they stand: half the matrix
+// instructions and half the dependent chain of a d = 256 map (two 16-channel blocks per column) and of the bridge GEMMs.
+template <int MM>
+__device__ __forceinline__ f32x4 mm_mma2(typename MMT<MM>::opd a0, typename MMT<MM>::opd a1, typename MMT<MM>::opd b0,
+                                         typename MMT<MM>::opd b1, f32x4 acc) {
+  if constexpr (MM == TLSAN_MATRIX_F32) {
+    return mm_mma<MM>(a1, b1, mm_mma<MM>(a0, b0, acc));
+  } else {
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 A = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7), B = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), acc, 0, 0, 0);
+  }
+}
 #define TLSAN_NEG (-1e30f)  // VERY_NEGATIVE_NUMBER, reference TLSAN/model.py:10-11
 // The attention scores m2 = relu(x W1 + b1) W2 + b2 (model.py:380-382) are only ever used as exponents of the softmax over
 // positions (model.py:386).  The kernels keep them in units of log 2: the FORWARD fragments of W2 and b2 are multiplied by
@@ -312,8 +329,12 @@ __device__ __forceinline__ void map_apply(const typename MMT<MM>::opd (&F)[NB][N
 #pragma unroll
     for (int ob = 0; ob < NB; ++ob) {
       f32x4 acc = bias[ob];
+      if constexpr (NB == 2) {
+        acc = mm_mma2<MM>(F[ob][0], F[ob][1], pv[0], pv[1], acc);
+      } else {
 #pragma unroll
-      for (int ib = 0; ib < NB; ++ib) acc = mm_mma<MM>(F[ob][ib], pv[ib], acc);
+        for (int ib = 0; ib < NB; ++ib) acc = mm_mma<MM>(F[ob][ib], pv[ib], acc);
+      }
       out[ob] = acc;
     }
   }
@@ -344,9 +365,14 @@ __device__ __forceinline__ void map_apply0(const typename MMT<MM>::opd (&F)[NB][
     for (int ib = 0; ib < NB; ++ib) pv[ib] = mm_pack<MM>(v[ib]);
 #pragma unroll
     for (int ob = 0; ob < NB; ++ob) {
-      f32x4 acc = mm_mma<MM>(F[ob][0], pv[0], (f32x4)(0.0f));
+      f32x4 acc;
+      if constexpr (NB == 2) {
+        acc = mm_mma2<MM>(F[ob][0], F[ob][1], pv[0], pv[1], (f32x4)(0.0f));
+      } else {
+        acc = mm_mma<MM>(F[ob][0], pv[0], (f32x4)(0.0f));
 #pragma unroll
-      for (int ib = 1; ib < NB; ++ib) acc = mm_mma<MM>(F[ob][ib], pv[ib], acc);
+        for (int ib = 1; ib < NB; ++ib) acc = mm_mma<MM>(F[ob][ib], pv[ib], acc);
+      }
       out[ob] = acc;
     }
   }
