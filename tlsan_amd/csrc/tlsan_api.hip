@@ -1046,7 +1046,8 @@ int tlsan_train_step_opt(const tlsan_dims* d, const tlsan_params* p, const tlsan
     lazy_blocks(A1, b->B, b->Sn);
     if (spec_on) {   // the row update beside the finalize, with coefficient 1; then the commit (+ the correction of a clipped step)
       if ((rc = run_backward(d, s, p, b, hp, true, out, w, st, L, hs, &A, nullptr, true, true))) return rc;
-      const dim3 grid(A1.nbD + A1.nbC + A1.nbI + A1.nbU);
+      const int nrow = A1.nbC + A1.nbI + A1.nbU;
+      const dim3 grid(A1.nbD + (nrow < SPEC_FIX_BLOCKS ? nrow : SPEC_FIX_BLOCKS));
       const bool wide = apply_wide(A1);
       if (A1.p.table_dtype == TLSAN_TABLE_BF16) {
         if (wide) hipLaunchKernelGGL((k_spec_commit<true, TLSAN_TABLE_BF16>), grid, dim3(256), 0, hs, A1);

@@ -2245,6 +2245,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? 3 : 
 #ifndef SPEC_OWN
 #define SPEC_OWN 2
 #endif
+#define SPEC_FIX_BLOCKS 512
 // (the wide form -- rows of 128 floats and more, C5 -- is held to four waves per SIMD: 149 registers left alone, i.e. three;
 //  at four 88 bytes per lane spill in the user-row role and C5 runs 281.5 -> 273.5 us/step.  The narrow form keeps three:
 //  at d = 128 with 10 M / 5 M tables the step is bound by the index stream, whose 1024-thread blocks find no slot beside
@@ -2308,7 +2309,6 @@ __global__ __launch_bounds__(256) void k_spec_commit(ApplyArgs a) {
   ApCtx x;
   x.tid = tid; x.wave = tid >> 6; x.lane = tid & 63; x.grp = x.lane >> 4; x.l16 = x.lane & 15;
   x.gid = x.wave * 4 + x.grp;
-  x.blk = blockIdx.x - a.nbD;
   x.P = a.hdr->P_prev;
   x.invP = 1.0f / x.P;
   const float st_true = a.lr * coef;
@@ -2317,10 +2317,15 @@ __global__ __launch_bounds__(256) void k_spec_commit(ApplyArgs a) {
   x.salt = a.hdr->spec_salt;
   x.coef = coef;
   x.accum = true;
-  const int blk = x.blk;
-  if (blk < a.nbC) apply_cseg_block<AP_UPDATE, true, NC, (WIDE ? SPEC_OWN : AP_OWN), DT>(a, x, blk * AP_ROWS_PB, shp);
-  else if (blk < a.nbC + a.nbI) apply_rows_block<AP_UPDATE, true, true, NI, (WIDE ? SPEC_OWN : AP_OWN), DT>(a, x, (blk - a.nbC) * AP_ROWS_PB, shp);
-  else apply_rows_block<AP_UPDATE, true, false, NU, (WIDE ? SPEC_OWN : AP_OWN / 2), DT>(a, x, (blk - a.nbC - a.nbI) * AP_ROWS_PB, shp);
+  // (the launch carries at most SPEC_FIX_BLOCKS correcting workgroups, each walking row blocks with the grid's stride: an
+  //  unclipped step -- nearly every step -- pays for a few hundred workgroups that return at once, not for one per 16 rows)
+  for (int blk = (int)blockIdx.x - a.nbD; blk < a.nbC + a.nbI + a.nbU; blk += (int)gridDim.x - a.nbD) {
+    x.blk = blk;
+    if (blk < a.nbC) apply_cseg_block<AP_UPDATE, true, NC, (WIDE ? SPEC_OWN : AP_OWN), DT>(a, x, blk * AP_ROWS_PB, shp);
+    else if (blk < a.nbC + a.nbI) apply_rows_block<AP_UPDATE, true, true, NI, (WIDE ? SPEC_OWN : AP_OWN), DT>(a, x, (blk - a.nbC) * AP_ROWS_PB, shp);
+    else apply_rows_block<AP_UPDATE, true, false, NU, (WIDE ? SPEC_OWN : AP_OWN / 2), DT>(a, x, (blk - a.nbC - a.nbI) * AP_ROWS_PB, shp);
+    __syncthreads();   // (shp is reused by the next row block)
+  }
 }
 
 // split category sums (Rc64, exact doubles) -> float output, and back to zero at rest (tlsan_grads)
