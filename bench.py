@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--event-every", type=int, default=4,
                     help="kernel-timing pass (behind the timed region): every Nth step carries the HIP events that bracket k_fwd_bwd")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded (multi-GPU) code path even at N=1")
+    ap.add_argument("--sharded-graph", type=int, default=1,
+                    help="sharded path at ONE rank (--force-sharded), static-shape step: replay hipGraph-captured steps (ShardedModel.capture_step); "
+                         "over several ranks the steps are always issued eagerly")
     ap.add_argument("--wire-dtype", default="f32", choices=["f32", "bf16"],
                     help="sharded path: rows cross the wire with fp32 or bf16 embedding values (the owners' weights stay fp32)")
     ap.add_argument("--static-rows", type=int, default=1,
@@ -283,6 +286,19 @@ def main():
     nsb = 16
     lib_fused = cfg["hidden_units"] <= 128 and (B + nsb - 1) // nsb <= 256
     graphs = [model.capture_step(db, lr) for db in dbs] if use_graph else None
+    # the one-rank sharded step as recorded graphs: capture and replay alternately along the batch cycle
+    # (its length is a multiple of the four plan slots), then replay in that order -- ShardedModel.capture_step
+    use_graph_sh = bool(sharded and world == 1 and args.sharded_graph and model.static_rows and len(dbs) % 4 == 0)
+    if use_graph_sh:
+        for s in range(4):        # (one-time initialisation cannot be recorded)
+            stepper.train_async(dbs[s % len(dbs)], lr, next_batch=dbs[(s + 1) % len(dbs)])
+        torch.cuda.synchronize()
+        graphs = []
+        for k in range(len(dbs)):
+            g = model.capture_step(dbs[k], dbs[(k + 1) % len(dbs)], lr)
+            model.replay(g)
+            graphs.append(g)
+        torch.cuda.synchronize()
 
     host = [0.0]      # seconds the host spent inside the enqueue calls of the timed steps (is the step bound by its host thread?)
 
@@ -295,6 +311,8 @@ def main():
                     stepper.train_async(dbs[k], lr)
                 else:
                     model.replay(graphs[k])
+            elif use_graph_sh:
+                model.replay(graphs[k])
             elif sharded and model.static_rows:
                 # the next two batches are known (as in any input pipeline): their routing plans are built beside this step
                 stepper.train_async(dbs[k], lr, next_batch=dbs[(k + 1) % len(dbs)], after_next=dbs[(k + 2) % len(dbs)])
@@ -319,7 +337,7 @@ def main():
     # the destination indices are built two batches ahead: the first steps behind a fence still build their own (and
     # their successors') -- a few untimed steps beyond --warmup let that pipeline fill, so that a short timed window
     # (the round-end driver times 20 steps after 5) reads the steady state (round 3: 65.8 us/step there, 61.3 over 200)
-    fill = 4 if (args.prefetch >= 2 or (sharded and model.static_rows)) and not use_graph else 0
+    fill = 4 if (args.prefetch >= 2 or (sharded and model.static_rows)) and not use_graph and not use_graph_sh else 0
     run(args.warmup + fill, 0)
     fence_warm = args.warmup + fill
     if fill:          # (no fence between the fill steps and the timed ones would be better still; the contract wants one)
@@ -470,7 +488,7 @@ def main():
                               "frac": None if not nrec else round(k_flops / (k_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
                               "algorithmic_flops_per_launch": round(k_flops)},
             "launch": ("hipGraph replay (1 graph/step; every %dth step eager for the HIP-event kernel timing)" % args.event_every)
-                      if use_graph else ("eager, %d launches/step on the main stream + the destination index (2 launches) of the "
+                      if use_graph else "hipGraph replay of the recorded static-shape sharded step (1 graph/step, the next batch's plan inside)" if use_graph_sh else ("eager, %d launches/step on the main stream + the destination index (2 launches) of the "
                                          "batch %s on a second stream" % (3 if lib_fused else 4, "after next" if args.prefetch >= 2 else "next")
                                          if (args.prefetch and not sharded) else "eager"),
             "static_overflow_checked": True if (sharded and static_rows) else None,
