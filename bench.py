@@ -55,9 +55,10 @@ def parse():
     ap.add_argument("--event-every", type=int, default=4,
                     help="kernel-timing pass (behind the timed region): every Nth step carries the HIP events that bracket k_fwd_bwd")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded (multi-GPU) code path even at N=1")
-    ap.add_argument("--sharded-graph", type=int, default=1,
+    ap.add_argument("--sharded-graph", type=int, default=0,
                     help="sharded path at ONE rank (--force-sharded), static-shape step: replay hipGraph-captured steps (ShardedModel.capture_step); "
-                         "over several ranks the steps are always issued eagerly")
+                         "over several ranks the steps are always issued eagerly.  Off by default: measured SLOWER than eager steps "
+                         "(104-105 vs 85 us/step at one rank, profiles/r06_sharded.md: a recorded step joins its side streams at its end)")
     ap.add_argument("--wire-dtype", default="f32", choices=["f32", "bf16"],
                     help="sharded path: rows cross the wire with fp32 or bf16 embedding values (the owners' weights stay fp32)")
     ap.add_argument("--static-rows", type=int, default=1,

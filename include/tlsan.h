@@ -501,7 +501,7 @@ int tlsan_shard_apply_lazy_static(float* shard, int32_t ld, int32_t cI, int32_t 
  *   it is complete -- instead of ordering the side streams behind an event recorded on the main stream (a barrier
  *   packet in the main queue: ~6 us of idle GPU per step).  Without the word the plans carry ev_fork.
  * tlsan_shard_plan_static(p): a batch's routing plan, category index and destination index on p->stream / p->stream2
- *   (tlsan_route_plan_static, the overflow word's copy to pinned memory, tlsan_state_recategorize, tlsan_batch_index),
+ *   (tlsan_route_plan_static -- its closing kernel stores an overflow count into the pinned word --, tlsan_state_recategorize, tlsan_batch_index),
  *   ordered by the caller's HIP events (raw hipEvent_t / hipStream_t handles; NULL events are skipped):
  *     stream waits ev_fork; ev_planned recorded behind the route plan; stream2 waits ev_planned, builds the index,
  *     records ev_done1; ev_done0 recorded on stream last when record_done0 != 0 (the caller records it itself when it
@@ -515,7 +515,7 @@ typedef struct {
   const int32_t* keys; int32_t n_keys, R, G; const int32_t* cate_by_key;
   int32_t *flags, *rank, *uniq, *n_uniq, *sendbuf; int32_t cap;
   int32_t *cate_c, *comp, *status;
-  int32_t* status_host;                  /* optional PINNED host word: status is copied there behind the plan */
+  int32_t* status_host;                  /* optional PINNED host word: receives the count of an overflowing owner (a system-scope store of the plan's kernel) */
   const tlsan_dims* dims; const tlsan_params* cp; const tlsan_batch* cb; void* state;
   void *stream, *stream2;                /* hipStream_t */
   void *ev_fork, *ev_planned, *ev_done0, *ev_done1;   /* hipEvent_t or NULL */

@@ -1457,9 +1457,17 @@ int tlsan_shard_apply_lazy(float* shard, int32_t ld, int32_t cI, int32_t R, int3
 }
 
 // ---- static-shape forms of the three calls above (include/tlsan.h): fixed `cap` row slots per (source, owner) pair
+static int route_plan_static_impl(const int32_t* keys, int32_t n_keys, int32_t R, int32_t G, const int32_t* cate_by_key,
+                                  int32_t* flags, int32_t* rank, int32_t* uniq, int32_t* n_uniq, int32_t* sendbuf, int32_t cap,
+                                  int32_t* cate_c, int32_t* comp, int32_t* counts_out, int32_t* status, int32_t* status_host, void* stream);
 int tlsan_route_plan_static(const int32_t* keys, int32_t n_keys, int32_t R, int32_t G, const int32_t* cate_by_key,
                             int32_t* flags, int32_t* rank, int32_t* uniq, int32_t* n_uniq, int32_t* sendbuf, int32_t cap,
                             int32_t* cate_c, int32_t* comp, int32_t* counts_out, int32_t* status, void* stream) {
+  return route_plan_static_impl(keys, n_keys, R, G, cate_by_key, flags, rank, uniq, n_uniq, sendbuf, cap, cate_c, comp, counts_out, status, nullptr, stream);
+}
+static int route_plan_static_impl(const int32_t* keys, int32_t n_keys, int32_t R, int32_t G, const int32_t* cate_by_key,
+                                  int32_t* flags, int32_t* rank, int32_t* uniq, int32_t* n_uniq, int32_t* sendbuf, int32_t cap,
+                                  int32_t* cate_c, int32_t* comp, int32_t* counts_out, int32_t* status, int32_t* status_host, void* stream) {
   if (!keys || !cate_by_key || !flags || !rank || !uniq || !n_uniq || !sendbuf || !cate_c || !comp || !status)
     return fail(TLSAN_E_BADARG, "tlsan_route_plan_static: NULL pointer");
   if (n_keys < 1 || R < 1 || G < 1 || (long long)R * G >= (1LL << 31)) return fail(TLSAN_E_BADARG, "tlsan_route_plan_static: bad sizes");
@@ -1480,7 +1488,7 @@ int tlsan_route_plan_static(const int32_t* keys, int32_t n_keys, int32_t R, int3
   int rc = scan_compact_impl(flags, nkeys, rank, uniq, n_uniq, bsum, hs);
   if (rc) return rc;
   int nt = n_keys > G * cap ? n_keys : G * cap;
-  hipLaunchKernelGGL(k_route_finish_static, dim3((nt + 255) / 256), dim3(256), 0, hs, a, status);
+  hipLaunchKernelGGL(k_route_finish_static, dim3((nt + 255) / 256), dim3(256), 0, hs, a, status, status_host);
   CHECK_LAUNCH("k_route_finish_static");
   return TLSAN_OK;
 }
@@ -1586,11 +1594,10 @@ int tlsan_shard_plan_static(const tlsan_static_plan* p) {
   if (!p || !p->dims || !p->cp || !p->cb || !p->state) return fail(TLSAN_E_BADARG, "tlsan_shard_plan_static: NULL argument");
   hipStream_t s1 = (hipStream_t)p->stream, s2 = (hipStream_t)p->stream2;
   if (p->ev_fork && hipStreamWaitEvent(s1, (hipEvent_t)p->ev_fork, 0) != hipSuccess) return fail(TLSAN_E_LAUNCH, "wait(fork)");
-  int rc = tlsan_route_plan_static(p->keys, p->n_keys, p->R, p->G, p->cate_by_key, p->flags, p->rank, p->uniq, p->n_uniq,
-                                   p->sendbuf, p->cap, p->cate_c, p->comp, nullptr, p->status, p->stream);
+  // (the overflow word reaches the pinned host copy by a store of the kernel that raises it: no copy behind the plan)
+  int rc = route_plan_static_impl(p->keys, p->n_keys, p->R, p->G, p->cate_by_key, p->flags, p->rank, p->uniq, p->n_uniq,
+                                  p->sendbuf, p->cap, p->cate_c, p->comp, nullptr, p->status, (int32_t*)p->status_host, p->stream);
   if (rc) return rc;
-  if (p->status_host && hipMemcpyAsync(p->status_host, p->status, 4, hipMemcpyDeviceToHost, s1) != hipSuccess)
-    return fail(TLSAN_E_LAUNCH, "copy of the overflow word");
   if (p->ev_planned && hipEventRecord((hipEvent_t)p->ev_planned, s1) != hipSuccess) return fail(TLSAN_E_LAUNCH, "record(planned)");
   if ((rc = tlsan_state_recategorize(p->dims, p->cp, p->state, p->stream))) return rc;
   if (p->stream2 != nullptr) {

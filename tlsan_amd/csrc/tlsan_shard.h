@@ -54,7 +54,10 @@ __global__ void k_route_finish(RouteArgs a) {
 // plain compact numbering).  Unused slots: category -1, never referenced by the batch.
 //   status[0] = largest per-owner count seen so far (atomicMax): the host compares it with cap when it next looks
 //   (a batch that needs more than cap rows of one owner is truncated -- the step is then wrong and must be reported).
-__global__ void k_route_finish_static(RouteArgs a, int32_t* status) {
+// status_host (nullable): a word in pinned host memory that receives the count of an overflowing owner directly (a
+// system-scope store by the lane that saw it; any such value exceeds cap, which is all the host's per-step look asks) --
+// round 5 copied `status` to the host behind every plan: a blit dispatch of 3.5 us on the plan's stream, every step
+__global__ void k_route_finish_static(RouteArgs a, int32_t* status, int32_t* status_host) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int nu = *a.n_uniq;
   if (t < a.n_keys) {
@@ -76,7 +79,10 @@ __global__ void k_route_finish_static(RouteArgs a, int32_t* status) {
     if (j == 0) {
       a.sendbuf[(size_t)g * (1 + a.cap)] = min(cnt, a.cap);
       if (a.counts_out) a.counts_out[g] = cnt;
-      if (cnt > a.cap) atomicMax(status, cnt);
+      if (cnt > a.cap) {
+        atomicMax(status, cnt);
+        if (status_host != nullptr) __hip_atomic_store(status_host, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
   if (t < nu) a.flags[a.uniq[t]] = 0;  // the marks are zero at rest: no memset per step
