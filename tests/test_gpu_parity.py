@@ -1119,6 +1119,17 @@ def test_speculative_one_pass_lazy_update():
     waits for the finalize (TLSAN_LAZY_SPEC=0)."""
     import re, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sel = ("test_lazy_l2_matches_dense_oracle or test_lazy_is_deterministic or test_category_segments_match_oracle "
+           "or test_full_size_batch_matches_oracle or test_one_hot_row_takes_every_use or test_multi_step_tracks_oracle "
+           "or test_prefetched_index_equals_inline or test_periodic_scale_fold or test_bf16_tables or test_graph_replay_equals_eager "
+           "or test_nonfinite_inputs_give_nonfinite_loss or test_real_fixture_batches")
+    # (3: every table shape the one-pass form takes -- the item-walk category workgroups and the hot-row workgroups of
+    #  tables with few categories, which TLSAN_CSEG_MIN=1 would hide)
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-m", "gpu", "-q", "-x", "-k", sel],
+                       cwd=root, env=dict(os.environ, TLSAN_LAZY_ONE_PASS="3"), capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stdout[-6000:] + r.stderr[-2000:]
+    mt = re.search(r"(\d+) passed", r.stdout)
+    assert mt and int(mt.group(1)) >= 25, r.stdout[-2000:]
     env = dict(os.environ, TLSAN_LAZY_ONE_PASS="2", TLSAN_CSEG_MIN="1")
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-m", "gpu", "-q", "-x", "-k",
                         "test_lazy_l2_matches_dense_oracle or test_lazy_is_deterministic or test_category_segments_match_oracle "

@@ -294,7 +294,7 @@ static void carve_state(const tlsan_dims* d, char* base, St* s) {
   s->cate_cur = (int32_t*)take(4 * (size_t)d->cate_count);
   s->cate_items = (int32_t*)take(4 * (size_t)d->item_count);
   s->S_part = (double*)take(8 * (size_t)(s->nbI + s->nbU + s->nbC));
-  s->S_delta = (DeltaRec*)take(sizeof(DeltaRec) * (size_t)(s->nbI + s->nbU + s->nbC));
+  s->S_delta = (DeltaRec*)take(sizeof(DeltaRec) * ((size_t)(s->nbI + s->nbU + s->nbC) + AP_HOT_CAP));   // (+ the hot-row workgroups of a one-pass update)
   for (int k = 0; k < TLSAN_INDEX_SLOTS; ++k) s->uc_list[k] = (int32_t*)take(4 * (size_t)UC_LIST_CAP);
   s->Rc64 = (double*)take(8 * (size_t)d->cate_count * d->d_cate);
   for (int k = 0; k < TLSAN_INDEX_SLOTS; ++k) s->hot_list[k] = (int32_t*)take(4 * (size_t)AP_HOT_CAP);
@@ -448,12 +448,17 @@ static void category_split(ApplyArgs& A, const tlsan_dims* d, const tlsan_batch*
 // read-modify-write) is what the tail spends its time on.  Category segments only (the tables this is about have
 // thousands of categories; few, large categories need the split form's shared category workgroups).
 // TLSAN_LAZY_ONE_PASS: 0 never, 1 (default) by table size, 2 whenever the tables take category segments.
-static bool lazy_one_pass(const tlsan_dims* d, const ApplyArgs& A) {
+static bool lazy_one_pass(const tlsan_dims* d, const tlsan_batch* b, const ApplyArgs& A) {
   static const int mode = [] { const char* e = getenv("TLSAN_LAZY_ONE_PASS"); return e ? atoi(e) : 1; }();
-  if (mode == 0 || !A.cseg) return false;
-  if (mode == 2) return true;
+  if (mode == 0) return false;
+  // few, large categories (Movies-TV: 15) share a category among several row-sum workgroups that add exact doubles with
+  // atomics (category_split): that form has no one-pass counterpart
+  ApplyArgs T = A;
+  category_split(T, d, b);
+  if (T.csplit > 1) return false;
+  if (mode >= 2) return mode == 2 ? A.cseg != 0 : true;      // (2: whenever the tables take category segments; 3: everywhere)
   const double bytes = 4.0 * ((double)d->item_count * d->d_item + (double)d->user_count * (d->d_item + d->Ls));
-  return bytes > 512e6;      // (well beyond the 256 MiB Infinity Cache)
+  return A.cseg && bytes > 512e6;      // (well beyond the 256 MiB Infinity Cache)
 }
 
 // second half of the split lazy update (the first half rides with the dense finalize, run_backward)
@@ -603,7 +608,7 @@ int tlsan_state_renorm(const tlsan_dims* d, const tlsan_params* p, void* state, 
   hipStream_t hs = (hipStream_t)stream;
   const int dt = q.table_dtype;
   // (changes of the sum of squares the last update left as records: part of St before St is rescaled)
-  hipLaunchKernelGGL(k_fold_delta, dim3(1), dim3(256), 0, hs, st.S_delta, st.nbI + st.nbU + st.nbC, st.hdr, st.S_total);
+  hipLaunchKernelGGL(k_fold_delta, dim3(1), dim3(256), 0, hs, st.S_delta, st.nbI + st.nbU + st.nbC + AP_HOT_CAP, st.hdr, st.S_total);
   hipLaunchKernelGGL(k_scale_table, dim3(1024), dim3(256), 0, hs, q.item_emb, d->item_count, d->d_item, q.ld_item, st.hdr, dt, 0x1b873593u);
   hipLaunchKernelGGL(k_scale_table, dim3(1024), dim3(256), 0, hs, q.user_emb, d->user_count, d->d_item, q.ld_user, st.hdr, dt, 0xcc9e2d51u);
   hipLaunchKernelGGL(k_scale_table, dim3(256), dim3(256), 0, hs, q.usert_emb, d->user_count, d->Ls, q.ld_usert, st.hdr, TLSAN_TABLE_F32, 0u);
@@ -866,7 +871,7 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   memset(&f, 0, sizeof(f));
   f.lay = L; f.partials = w.partials; f.nrec = (b->B + grp - 1) / grp; f.Kp = w.Kp; f.nsplit = nsplit;
   f.gd = gd_out ? gd_out : w.gd; f.sqd = w.sqd; f.scal = w.scal;
-  f.S_delta = st.S_delta; f.n_spart = st.nbI + st.nbU + st.nbC; f.S_total = st.S_total;
+  f.S_delta = st.S_delta; f.n_spart = st.nbI + st.nbU + st.nbC + AP_HOT_CAP; f.S_total = st.S_total;
   f.hdr = st.hdr; f.lr = hp->lr; f.reg = hp->reg; f.clip = hp->clip; f.inv_B = 1.0f / (float)b->B;
   f.norm_mode = hp->norm_mode; f.commit = commit ? 1 : 0; f.count_step = update ? 1 : 0;
   f.out_loss = out ? out->loss : nullptr;
@@ -877,8 +882,9 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
     // and -- after a clipped step -- the correction follow in k_spec_commit, tlsan_train_step_opt)
     ApplyArgs A = *presum;
     lazy_blocks(A, b->B, b->Sn);
+    A.nbH = AP_HOT_CAP;      // hot item rows: a workgroup each, leading the row workgroups (they return at once where there are none)
     f.count_step = 0; f.spec = 1;
-    const dim3 grid(w.nfin + 1 + A.nbC + A.nbI + A.nbU);
+    const dim3 grid(w.nfin + 1 + A.nbH + A.nbC + A.nbI + A.nbU);
     const bool wide = apply_wide(A), bf16 = A.p.table_dtype == TLSAN_TABLE_BF16;
 #define FU_LAUNCH(DD, HH)                                                                                                            \
   do {                                                                                                                               \
@@ -1037,7 +1043,7 @@ int tlsan_train_step_opt(const tlsan_dims* d, const tlsan_params* p, const tlsan
     if (opt->kind == TLSAN_OPT_ADAM)  // adam.py: lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)
       A.oalpha = (float)((double)hp->lr * sqrt(1.0 - pow((double)opt->beta2, opt->step)) / (1.0 - pow((double)opt->beta1, opt->step)));
   }
-  if (hp->l2_mode == TLSAN_L2_LAZY && lazy_one_pass(d, A)) {
+  if (hp->l2_mode == TLSAN_L2_LAZY && lazy_one_pass(d, b, A)) {
     // tables that live in HBM: ONE pass over the used rows behind the finalize (k_apply<AP_UPDATE, lazy>: segment sums and
     // the update of a row by the same lanes) instead of row sums beside the finalize + an elementwise update -- the
     // summed rows make no round trip through memory (see lazy_one_pass)
@@ -1046,7 +1052,8 @@ int tlsan_train_step_opt(const tlsan_dims* d, const tlsan_params* p, const tlsan
     lazy_blocks(A1, b->B, b->Sn);
     if (spec_on) {   // the row update beside the finalize, with coefficient 1; then the commit (+ the correction of a clipped step)
       if ((rc = run_backward(d, s, p, b, hp, true, out, w, st, L, hs, &A, nullptr, true, true))) return rc;
-      const int nrow = A1.nbC + A1.nbI + A1.nbU;
+      A1.nbH = AP_HOT_CAP;
+      const int nrow = A1.nbH + A1.nbC + A1.nbI + A1.nbU;
       const dim3 grid(A1.nbD + (nrow < SPEC_FIX_BLOCKS ? nrow : SPEC_FIX_BLOCKS));
       const bool wide = apply_wide(A1);
       if (A1.p.table_dtype == TLSAN_TABLE_BF16) {

@@ -1669,8 +1669,8 @@ __device__ __forceinline__ void apply_rows_block(const ApplyArgs& a, const ApCtx
     const int4 r = (IS_ITEM ? a.urec_item : a.urec_user)[slot];  // (row, first position, uses)
     vr = slot < nuq;
     if (vr) { row = r.x; off = r.y; n = r.z; }
-    if constexpr (MODE == AP_PRESUM && IS_ITEM) {
-      if (a.nbH > 0 && n > AP_HOT && *a.hot_n <= AP_HOT_CAP) { vr = false; n = 0; }   // a hot-row workgroup sums it
+    if constexpr ((MODE == AP_PRESUM || MODE == AP_UPDATE) && IS_ITEM) {
+      if (a.nbH > 0 && n > AP_HOT && *a.hot_n <= AP_HOT_CAP) { vr = false; n = 0; }   // a hot-row workgroup sums (speculative one-pass update: updates) it
     }
   } else {
     vr = slot < (IS_ITEM ? a.I : a.U);
@@ -2034,8 +2034,11 @@ __device__ __forceinline__ void apply_cseg_block(const ApplyArgs& a, const ApCtx
 }
 
 // ================= one hot item row per workgroup (PRESUM) =================
-template <int NCH>
-__device__ __forceinline__ void presum_hot_block(const ApplyArgs& a, int h, double* shd, double* shp) {
+// UPD (the speculative one-pass update, k_finalize_update / k_spec_commit): the workgroup updates the row itself --
+// w -= x.lazy_scale * sum, item_b -= x.step * sum_b -- and leaves its change of the sum of squares in record
+// nbC + nbI + nbU + h of S_delta (hot workgroups own the records behind the row blocks').
+template <int NCH, bool UPD = false, int DT = TLSAN_TABLE_F32>
+__device__ __forceinline__ void presum_hot_block(const ApplyArgs& a, int h, double* shd, double* shp, const ApCtx* xp = nullptr) {
   const int nh = *a.hot_n;
   if (nh > AP_HOT_CAP || h >= nh) return;  // (workgroup-uniform) list overflowed: the item-row workgroups kept the rows
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, grp = lane >> 4, l16 = lane & 15, gid = wave * 4 + grp;
@@ -2043,6 +2046,16 @@ __device__ __forceinline__ void presum_hot_block(const ApplyArgs& a, int h, doub
   const int4 r = a.urec_item[slot];
   const int row = r.x, off = r.y, n = r.z;
   const int W4 = a.di / 4;
+  f32x4 w_row[NCH];
+  float wb_row = 0.0f;
+  if constexpr (UPD) {   // (the parameter row, requested with everything else)
+    if (wave == 0 && grp == 0) {
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch)
+        if (l16 + 16 * ch < W4) w_row[ch] = tbl_ld4<DT>(a.p.item_emb, (size_t)row * a.p.ld_item + 4 * (l16 + 16 * ch));
+      if (l16 == 0) wb_row = a.p.item_b[(size_t)row * a.p.ld_itemb];
+    }
+  }
   double acc[NCH][4];
   zero_acc(acc);
   for (int k = off + gid; k < off + n; k += 16 * AP_OWN) {
@@ -2078,6 +2091,36 @@ __device__ __forceinline__ void presum_hot_block(const ApplyArgs& a, int h, doub
   }
   if (lane == 0) shp[wave] = tb;
   __syncthreads();
+  if constexpr (UPD) {
+    const ApCtx& x = *xp;
+    double part = 0.0;
+    if (wave == 0 && grp == 0) {
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        const int c4 = l16 + 16 * ch;
+        if (c4 < W4) {
+          const f32x4 w0 = w_row[ch];
+          f32x4 wn;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            double s_ = 0.0;
+            for (int w_ = 0; w_ < 4; ++w_) s_ += shd[((w_ * 16 + l16) * NCH + ch) * 4 + i];
+            wn[i] = w0[i] - x.lazy_scale * (float)s_;      // (apply_elem<AP_UPDATE, lazy>)
+          }
+          tbl_st4<DT>(a.p.item_emb, (size_t)row * a.p.ld_item + 4 * c4, wn, x.salt ^ 0x85ebca6bu);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) part += (double)wn[i] * (double)wn[i] - (double)w0[i] * (double)w0[i];
+        }
+      }
+      if (l16 == 0) {
+        const float gb = (float)((shp[0] + shp[1]) + (shp[2] + shp[3]));
+        a.p.item_b[(size_t)row * a.p.ld_itemb] = wb_row - x.step * gb;    // not regularised, never scaled
+        a.cnt_item[row] = 0;
+      }
+    }
+    block_delta_store(part, shp, &a.delta_out[a.nbC + a.nbI + a.nbU + h], x.salt, x.accum);
+    return;
+  }
   if (wave == 0 && grp == 0) {
     const bool by_row = a.presum_rows != 0;
     float* R = by_row ? a.go.item_emb + (size_t)row * a.go.ld_item : a.Ri + (size_t)slot * a.di;
@@ -2253,11 +2296,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? 3 : 
 #ifndef SPEC_WPE
 #define SPEC_WPE 4
 #endif
+#ifndef SPEC_WPE_NARROW
+#define SPEC_WPE_NARROW 3
+#endif
 template <int D, int DH, bool WIDE, int DT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? SPEC_WPE : 3))) void k_finalize_update(FinArgs f, int nbK, int nbS, ApplyArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? SPEC_WPE : SPEC_WPE_NARROW))) void k_finalize_update(FinArgs f, int nbK, int nbS, ApplyArgs a) {
   constexpr int NC = WIDE ? 2 : 1, NI = WIDE ? 2 : 1, NU = WIDE ? 4 : 2;
-  __shared__ double shd[256];
+  constexpr int OWN = WIDE ? SPEC_OWN : AP_OWN;
+  __shared__ double shd[4 * 16 * NC * 4 > 256 ? 4 * 16 * NC * 4 : 256];
   __shared__ double shp[4];
+  __shared__ int sh_pos[AP_CAP];
+  __shared__ int sh_lo[256], sh_n[256];
+  __shared__ int sh_wtot[4];
   __shared__ int sh_last;
   const int nfin = nbK + nbS + 1;
   if ((int)blockIdx.x < nfin) {
@@ -2274,18 +2324,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? SPEC
   x.lazy_scale = x.step / (x.P * (1.0f - x.step * a.reg));
   x.salt = a.hdr->nstep + 1;    // what the step's salt and record tag will be (hdr->spec_salt)
   x.coef = 1.0f;
-  if (x.blk == 0 && x.tid == 0) a.hdr->spart_n = a.nbC + a.nbI + a.nbU;
+  if (x.blk == 0 && x.tid == 0) a.hdr->spart_n = a.nbC + a.nbI + a.nbU + a.nbH;
+  if (x.blk < a.nbH) {          // hot item rows lead the row workgroups
+    presum_hot_block<NI, true, DT>(a, x.blk, shd, shp, &x);
+    return;
+  }
+  x.blk -= a.nbH;
   const int blk = x.blk;
-  if (blk < a.nbC) apply_cseg_block<AP_UPDATE, true, NC, (WIDE ? SPEC_OWN : AP_OWN), DT>(a, x, blk * AP_ROWS_PB, shp);
-  else if (blk < a.nbC + a.nbI) apply_rows_block<AP_UPDATE, true, true, NI, (WIDE ? SPEC_OWN : AP_OWN), DT>(a, x, (blk - a.nbC) * AP_ROWS_PB, shp);
+  if (blk < a.nbC) {
+    if (a.cseg) apply_cseg_block<AP_UPDATE, true, NC, OWN, DT>(a, x, blk * AP_ROWS_PB, shp);
+    else apply_cate_block<AP_UPDATE, true, NC, DT>(a, x, shd, shp, sh_pos, sh_lo, sh_n, sh_wtot);
+  }
+  else if (blk < a.nbC + a.nbI) apply_rows_block<AP_UPDATE, true, true, NI, OWN, DT>(a, x, (blk - a.nbC) * AP_ROWS_PB, shp);
   else apply_rows_block<AP_UPDATE, true, false, NU, (WIDE ? SPEC_OWN : AP_OWN / 2), DT>(a, x, (blk - a.nbC - a.nbI) * AP_ROWS_PB, shp);
 }
 
-// grid: nbD blocks of 256 dense parameters, then the row blocks of k_finalize_update (which return at once when the step was not clipped)
+// grid: nbD blocks of 256 dense parameters, then at most SPEC_FIX_BLOCKS correcting workgroups (which return at once when the step was not clipped)
 template <bool WIDE, int DT>
 __global__ __launch_bounds__(256) void k_spec_commit(ApplyArgs a) {
   constexpr int NC = WIDE ? 2 : 1, NI = WIDE ? 2 : 1, NU = WIDE ? 4 : 2;
+  constexpr int OWN = WIDE ? SPEC_OWN : AP_OWN;
+  __shared__ double shd[4 * 16 * NC * 4];
   __shared__ double shp[4];
+  __shared__ int sh_pos[AP_CAP];
+  __shared__ int sh_lo[256], sh_n[256];
+  __shared__ int sh_wtot[4];
   const int tid = threadIdx.x;
   const float coef = a.hdr->coef;
   if ((int)blockIdx.x < a.nbD) {
@@ -2319,12 +2382,20 @@ __global__ __launch_bounds__(256) void k_spec_commit(ApplyArgs a) {
   x.accum = true;
   // (the launch carries at most SPEC_FIX_BLOCKS correcting workgroups, each walking row blocks with the grid's stride: an
   //  unclipped step -- nearly every step -- pays for a few hundred workgroups that return at once, not for one per 16 rows)
-  for (int blk = (int)blockIdx.x - a.nbD; blk < a.nbC + a.nbI + a.nbU; blk += (int)gridDim.x - a.nbD) {
-    x.blk = blk;
-    if (blk < a.nbC) apply_cseg_block<AP_UPDATE, true, NC, (WIDE ? SPEC_OWN : AP_OWN), DT>(a, x, blk * AP_ROWS_PB, shp);
-    else if (blk < a.nbC + a.nbI) apply_rows_block<AP_UPDATE, true, true, NI, (WIDE ? SPEC_OWN : AP_OWN), DT>(a, x, (blk - a.nbC) * AP_ROWS_PB, shp);
-    else apply_rows_block<AP_UPDATE, true, false, NU, (WIDE ? SPEC_OWN : AP_OWN / 2), DT>(a, x, (blk - a.nbC - a.nbI) * AP_ROWS_PB, shp);
-    __syncthreads();   // (shp is reused by the next row block)
+  for (int v = (int)blockIdx.x - a.nbD; v < a.nbH + a.nbC + a.nbI + a.nbU; v += (int)gridDim.x - a.nbD) {
+    if (v < a.nbH) {
+      presum_hot_block<NI, true, DT>(a, v, shd, shp, &x);
+    } else {
+      const int blk = v - a.nbH;
+      x.blk = blk;
+      if (blk < a.nbC) {
+        if (a.cseg) apply_cseg_block<AP_UPDATE, true, NC, OWN, DT>(a, x, blk * AP_ROWS_PB, shp);
+        else apply_cate_block<AP_UPDATE, true, NC, DT>(a, x, shd, shp, sh_pos, sh_lo, sh_n, sh_wtot);
+      }
+      else if (blk < a.nbC + a.nbI) apply_rows_block<AP_UPDATE, true, true, NI, OWN, DT>(a, x, (blk - a.nbC) * AP_ROWS_PB, shp);
+      else apply_rows_block<AP_UPDATE, true, false, NU, (WIDE ? SPEC_OWN : AP_OWN / 2), DT>(a, x, (blk - a.nbC - a.nbI) * AP_ROWS_PB, shp);
+    }
+    __syncthreads();   // (the shared scratch is reused by the next block of rows)
   }
 }
 
