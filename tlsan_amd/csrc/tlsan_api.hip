@@ -442,12 +442,18 @@ static void category_split(ApplyArgs& A, const tlsan_dims* d, const tlsan_batch*
   }
 }
 
-// The lazy update as ONE pass (round 6).  The split form (row sums in the finalize's launch, then k_update_lazy) hides the
-// finalize's chain behind the row sums and wins where the tables sit in the caches (the bench shape); where they live in
-// HBM the summed rows' round trip through memory (written by one launch, read by the next, beside the parameter rows'
-// read-modify-write) is what the tail spends its time on.  Category segments only (the tables this is about have
-// thousands of categories; few, large categories need the split form's shared category workgroups).
-// TLSAN_LAZY_ONE_PASS: 0 never, 1 (default) by table size, 2 whenever the tables take category segments.
+// The lazy update as ONE pass over the used rows (round 6; k_finalize_update / k_spec_commit, tlsan_update.h).  The split
+// form (row sums in the finalize's launch, then k_update_lazy) sends every summed row through memory -- written by one
+// launch, read by the next beside the parameter row's read-modify-write -- and ends in a launch of its own; in the one-pass
+// form a 16-lane group sums its row's segment and updates the row, speculating on clip coefficient 1, beside the finalize.
+static bool tables_in_hbm(const tlsan_dims* d) {      // (well beyond the 256 MiB Infinity Cache)
+  return 4.0 * ((double)d->item_count * d->d_item + (double)d->user_count * (d->d_item + d->Ls)) > 512e6;
+}
+// Where the one-pass form was measured to win (profiles/r06_lazy_one_pass.md): rows of up to 64 floats per table half
+// (d <= 128) at any table size -- bench shape 56.9 -> 55.4 us/step, 8192 sequences 106.5 -> 103.6, Amazon session lengths
+// 59.9 -> 57.8, 10 M / 5 M tables 97 -> 80 --; wider rows (d = 256) only where the tables live in HBM (C5 300 -> 267; with
+// cache-resident tables it loses 2.5 us to the split form).  TLSAN_LAZY_ONE_PASS: 0 never, 1 (default) as described,
+// 2 whenever the tables take category segments, 3 wherever the form is built.
 static bool lazy_one_pass(const tlsan_dims* d, const tlsan_batch* b, const ApplyArgs& A) {
   static const int mode = [] { const char* e = getenv("TLSAN_LAZY_ONE_PASS"); return e ? atoi(e) : 1; }();
   if (mode == 0) return false;
@@ -456,9 +462,10 @@ static bool lazy_one_pass(const tlsan_dims* d, const tlsan_batch* b, const Apply
   ApplyArgs T = A;
   category_split(T, d, b);
   if (T.csplit > 1) return false;
-  if (mode >= 2) return mode == 2 ? A.cseg != 0 : true;      // (2: whenever the tables take category segments; 3: everywhere)
-  const double bytes = 4.0 * ((double)d->item_count * d->d_item + (double)d->user_count * (d->d_item + d->Ls));
-  return A.cseg && bytes > 512e6;      // (well beyond the 256 MiB Infinity Cache)
+  if (apply_wide(A) && !A.cseg) return false;      // (the wide form is built for category segments only)
+  if (mode >= 2) return mode == 2 ? A.cseg != 0 : true;
+  if (!apply_wide(A)) return true;
+  return A.cseg && tables_in_hbm(d);
 }
 
 // second half of the split lazy update (the first half rides with the dense finalize, run_backward)
@@ -885,14 +892,16 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
     A.nbH = AP_HOT_CAP;      // hot item rows: a workgroup each, leading the row workgroups (they return at once where there are none)
     f.count_step = 0; f.spec = 1;
     const dim3 grid(w.nfin + 1 + A.nbH + A.nbC + A.nbI + A.nbU);
-    const bool wide = apply_wide(A), bf16 = A.p.table_dtype == TLSAN_TABLE_BF16;
+    const bool wide = apply_wide(A), bf16 = A.p.table_dtype == TLSAN_TABLE_BF16, low = tables_in_hbm(d);
 #define FU_LAUNCH(DD, HH)                                                                                                            \
   do {                                                                                                                               \
     if (bf16) {                                                                                                                      \
       if (wide) hipLaunchKernelGGL((k_finalize_update<DD, HH, true, TLSAN_TABLE_BF16>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);  \
+      else if (low) hipLaunchKernelGGL((k_finalize_update<DD, HH, false, TLSAN_TABLE_BF16, true>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A); \
       else hipLaunchKernelGGL((k_finalize_update<DD, HH, false, TLSAN_TABLE_BF16>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);      \
     } else {                                                                                                                         \
       if (wide) hipLaunchKernelGGL((k_finalize_update<DD, HH, true, TLSAN_TABLE_F32>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);   \
+      else if (low) hipLaunchKernelGGL((k_finalize_update<DD, HH, false, TLSAN_TABLE_F32, true>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A); \
       else hipLaunchKernelGGL((k_finalize_update<DD, HH, false, TLSAN_TABLE_F32>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);       \
     }                                                                                                                                \
   } while (0)

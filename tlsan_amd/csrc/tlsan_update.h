@@ -217,13 +217,16 @@ struct BalArgs {
 #define BAL_KEYS 192    // by_window: costs 0 .. 96 (TLSAN_LS_CAP); else 11 * min(session, 15) + window for sessions >= 2, 10 - window below
 #define BAL_TAIL_KEY 10 // (by_window == 0) the largest key of a sample with a session of one entry or none
 
-__device__ __forceinline__ void balance_block(const BalArgs& b) {   // 1024 threads = 16 wavefronts
-  __shared__ int wcnt[16][BAL_KEYS];   // samples of every cost per wavefront -> where the wavefront's first one of that cost ranks
+template <int NWV = 16>
+__device__ __forceinline__ void balance_block(const BalArgs& b) {   // NWV wavefronts
+  constexpr int NT = NWV * 64;
+  static_assert(NT >= BAL_KEYS, "a thread per cost");
+  __shared__ int wcnt[NWV][BAL_KEYS];  // samples of every cost per wavefront -> where the wavefront's first one of that cost ranks
   __shared__ int start[BAL_KEYS];      // rank of the first sample of every cost
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int B = b.B, G = (B + 15) / 16;
-  const int CH = (B + 1023) / 1024, nper = 64 * CH;   // wavefront w owns samples [w nper, (w + 1) nper), 64 per round
-  for (int o = tid; o < 16 * BAL_KEYS; o += 1024) (&wcnt[0][0])[o] = 0;
+  const int CH = (B + NT - 1) / NT, nper = 64 * CH;   // wavefront w owns samples [w nper, (w + 1) nper), 64 per round
+  for (int o = tid; o < NWV * BAL_KEYS; o += NT) (&wcnt[0][0])[o] = 0;
   __syncthreads();
   auto key_of = [&](int i) {
     if (b.by_window > 0) return min(max(min(b.sl[i], b.Ls), 0), BAL_KEYS - 1);
@@ -237,7 +240,7 @@ __device__ __forceinline__ void balance_block(const BalArgs& b) {   // 1024 thre
   __syncthreads();
   if (tid < BAL_KEYS) {
     int run = 0;
-    for (int w = 0; w < 16; ++w) {
+    for (int w = 0; w < NWV; ++w) {
       const int x = wcnt[w][tid];
       wcnt[w][tid] = run;
       run += x;
@@ -751,38 +754,31 @@ __global__ __launch_bounds__(1024) void k_scan_block_sums(ScanArgs a) {
   if (tid == 0) *a.bs_ticket = 0;   // zero at rest
 }
 
-__global__ __launch_bounds__(1024) void k_index_scan(ScanArgs a) {
-  if (a.bal.perm != nullptr && (int)blockIdx.x == a.bal.blk) {
-    balance_block(a.bal);
-    return;
-  }
-  if (a.us.u != nullptr && (int)blockIdx.x == a.us.blk) {
-    usort_block(a.us);
-    return;
-  }
-  if (a.is.on != 0 && (int)blockIdx.x >= a.is.blk) {
-    isort_finish_block(a.is, (int)blockIdx.x - a.is.blk);
-    return;
-  }
-  __shared__ long long wsum[16];
+// one scan block of NT threads: chunk `blk` of its table, 4 NT consecutive counts.  (Round 6 also ran the scan of cache-resident
+// tables as 256-thread workgroups over chunks of 1024 counts, so that its blocks find a slot beside the row-sum workgroups:
+// the kernel itself 16 -> 28 us beside the step, the step equal or 1-2 us slower -- profiles/r06_ab_scan_small.txt; removed.)
+template <int NT>
+__device__ __forceinline__ void index_scan_block(const ScanArgs& a, int blk) {
+  constexpr int CHK = 4 * NT;
+  __shared__ long long wsum[NT / 64];
   __shared__ long long prefix;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int which = 0;
-  if ((int)blockIdx.x >= a.blk0[1]) which = 1;
-  if ((int)blockIdx.x >= a.blk0[2]) which = 2;
+  if (blk >= a.blk0[1]) which = 1;
+  if (blk >= a.blk0[2]) which = 2;
   const int32_t* __restrict__ cnt = a.cnt[which];
   const int n = a.n[which];
-  const int base = ((int)blockIdx.x - a.blk0[which]) * 4096;
+  const int base = (blk - a.blk0[which]) * CHK;
   auto pack = [](int c) { return (long long)c + ((long long)(c > 0) << 32); };
   // ---- packed sum over cnt[0, base)
   long long part = 0;
   if (a.bsum != nullptr && a.bs_ticket != nullptr) {
-    part = tid == 0 ? a.bsum[blockIdx.x] : 0;   // (k_scan_block_sums left the exclusive prefix of this block's table)
+    part = tid == 0 ? a.bsum[blk] : 0;   // (k_scan_block_sums left the exclusive prefix of this block's table)
   } else if (a.bsum != nullptr) {
-    for (int k = a.blk0[which] + tid; k < (int)blockIdx.x; k += 1024) part += a.bsum[k];
+    for (int k = a.blk0[which] + tid; k < blk; k += NT) part += a.bsum[k];
   } else {
-    for (int k = tid * 4; k < base; k += 4096) {
-      const int4 v = *(const int4*)(cnt + k);  // base is a multiple of 4096 -> always in range
+    for (int k = tid * 4; k < base; k += CHK) {
+      const int4 v = *(const int4*)(cnt + k);  // base is a multiple of the chunk -> always in range
       part += pack(v.x) + pack(v.y) + pack(v.z) + pack(v.w);
     }
   }
@@ -793,7 +789,7 @@ __global__ __launch_bounds__(1024) void k_index_scan(ScanArgs a) {
   if (tid == 0) {
     long long t = 0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) t += wsum[w];
+    for (int w = 0; w < NT / 64; ++w) t += wsum[w];
     prefix = t;
   }
   __syncthreads();
@@ -802,7 +798,7 @@ __global__ __launch_bounds__(1024) void k_index_scan(ScanArgs a) {
   // ---- own chunk
   const int i0 = base + tid * 4;
   int v[4] = {0, 0, 0, 0};
-  const bool full = i0 + 3 < n;          // (chunks start at multiples of 4096: 16-byte accesses)
+  const bool full = i0 + 3 < n;          // (chunks start at multiples of 4 NT: 16-byte accesses)
   const bool marked = a.flag[which] == nullptr || i0 >= n || a.flag[which][i0 >> 8] != 0;   // (wave-uniform: a wavefront = one 256-row piece)
   if (!marked) {
   } else if (full) {
@@ -823,7 +819,7 @@ __global__ __launch_bounds__(1024) void k_index_scan(ScanArgs a) {
   __syncthreads();
   long long run = pre + inc - tsum;
 #pragma unroll
-  for (int w = 0; w < 16; ++w) run += (w < wave) ? wsum[w] : 0;
+  for (int w = 0; w < NT / 64; ++w) run += (w < wave) ? wsum[w] : 0;
   int32_t* off = a.off[which];
   int32_t* cur = a.cur[which];
   int32_t* uniq = a.uniq[which];
@@ -857,6 +853,22 @@ __global__ __launch_bounds__(1024) void k_index_scan(ScanArgs a) {
     }
   }
   if (a.flag[which] != nullptr && marked && lane == 0 && i0 < n) a.flag[which][i0 >> 8] = 0;   // zero at rest
+}
+
+__global__ __launch_bounds__(1024) void k_index_scan(ScanArgs a) {
+  if (a.bal.perm != nullptr && (int)blockIdx.x == a.bal.blk) {
+    balance_block<16>(a.bal);
+    return;
+  }
+  if (a.us.u != nullptr && (int)blockIdx.x == a.us.blk) {
+    usort_block(a.us);
+    return;
+  }
+  if (a.is.on != 0 && (int)blockIdx.x >= a.is.blk) {
+    isort_finish_block(a.is, (int)blockIdx.x - a.is.blk);
+    return;
+  }
+  index_scan_block<1024>(a, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2290,17 +2302,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? 3 : 
 #endif
 #define SPEC_FIX_BLOCKS 512
 // (the wide form -- rows of 128 floats and more, C5 -- is held to four waves per SIMD: 149 registers left alone, i.e. three;
-//  at four 88 bytes per lane spill in the user-row role and C5 runs 281.5 -> 273.5 us/step.  The narrow form keeps three:
-//  at d = 128 with 10 M / 5 M tables the step is bound by the index stream, whose 1024-thread blocks find no slot beside
-//  five row workgroups per CU -- 80.5 us/step with three, 92 with five: profiles/r06_lazy_one_pass.md)
+//  at four 88 bytes per lane spill in the user-row role and C5 runs 281.5 -> 273.5 us/step.  The narrow form: five (fp32
+//  tables) / four (bf16 tables) where the caches hold the tables -- the bench shape 56.9 -> 55.4 us/step against the split
+//  form, at three it LOSES to it (59.3) --, three (LOWOCC) where they live in HBM: at d = 128 with 10 M / 5 M tables the step
+//  is bound by the index stream, whose 1024-thread blocks find no slot beside five row workgroups per CU -- 80.5 us/step
+//  with three, 92 with five: profiles/r06_lazy_one_pass.md)
 #ifndef SPEC_WPE
 #define SPEC_WPE 4
 #endif
 #ifndef SPEC_WPE_NARROW
-#define SPEC_WPE_NARROW 3
+#define SPEC_WPE_NARROW 5        // fp32 tables: 93 registers, nothing spilled
+#define SPEC_WPE_NARROW_BF16 4   // bf16 tables (the stochastic rounding's hash): 113 registers; at five, 180 bytes per lane spill
 #endif
-template <int D, int DH, bool WIDE, int DT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? SPEC_WPE : SPEC_WPE_NARROW))) void k_finalize_update(FinArgs f, int nbK, int nbS, ApplyArgs a) {
+// LOWOCC (narrow form, tables in HBM): three waves per SIMD -- see the note above
+template <int D, int DH, bool WIDE, int DT, bool LOWOCC = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? SPEC_WPE : (LOWOCC ? 3 : (DT == TLSAN_TABLE_F32 ? SPEC_WPE_NARROW : SPEC_WPE_NARROW_BF16))))) void k_finalize_update(FinArgs f, int nbK, int nbS, ApplyArgs a) {
   constexpr int NC = WIDE ? 2 : 1, NI = WIDE ? 2 : 1, NU = WIDE ? 4 : 2;
   constexpr int OWN = WIDE ? SPEC_OWN : AP_OWN;
   __shared__ double shd[4 * 16 * NC * 4 > 256 ? 4 * 16 * NC * 4 : 256];
@@ -2332,7 +2348,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? SPEC
   x.blk -= a.nbH;
   const int blk = x.blk;
   if (blk < a.nbC) {
-    if (a.cseg) apply_cseg_block<AP_UPDATE, true, NC, OWN, DT>(a, x, blk * AP_ROWS_PB, shp);
+    // (the wide form takes category segments only -- lazy_one_pass, tlsan_api.hip: the item-walk category workgroups in its
+    //  kernel cost the row roles 44 more spilled bytes per lane)
+    if (WIDE || a.cseg) apply_cseg_block<AP_UPDATE, true, NC, OWN, DT>(a, x, blk * AP_ROWS_PB, shp);
     else apply_cate_block<AP_UPDATE, true, NC, DT>(a, x, shd, shp, sh_pos, sh_lo, sh_n, sh_wtot);
   }
   else if (blk < a.nbC + a.nbI) apply_rows_block<AP_UPDATE, true, true, NI, OWN, DT>(a, x, (blk - a.nbC) * AP_ROWS_PB, shp);
@@ -2389,7 +2407,7 @@ __global__ __launch_bounds__(256) void k_spec_commit(ApplyArgs a) {
       const int blk = v - a.nbH;
       x.blk = blk;
       if (blk < a.nbC) {
-        if (a.cseg) apply_cseg_block<AP_UPDATE, true, NC, OWN, DT>(a, x, blk * AP_ROWS_PB, shp);
+        if (WIDE || a.cseg) apply_cseg_block<AP_UPDATE, true, NC, OWN, DT>(a, x, blk * AP_ROWS_PB, shp);
         else apply_cate_block<AP_UPDATE, true, NC, DT>(a, x, shd, shp, sh_pos, sh_lo, sh_n, sh_wtot);
       }
       else if (blk < a.nbC + a.nbI) apply_rows_block<AP_UPDATE, true, true, NI, OWN, DT>(a, x, (blk - a.nbC) * AP_ROWS_PB, shp);
