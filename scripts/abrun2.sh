@@ -1,14 +1,3 @@
 #!/bin/bash
-# On the GPU box: interleaved rounds of the bench over every ab_run/*.so, fp32 AND the bf16 tables + operands leg.
-#   scripts/abrun2.sh [rounds]
-cd ${GRAFT_REPO_ROOT:-/root/repo}
-rounds=${1:-3}
-cp tlsan_amd/libtlsan_hip.so /tmp/orig.so
-for i in $(seq $rounds); do
-  for so in ab_run/*.so; do
-    n=$(basename $so .so)
-    cp $so tlsan_amd/libtlsan_hip.so
-    timeout 300 python bench.py --no-cpu-baseline --accuracy-steps 0 --also-bf16 1 2>&1 | grep '"metric"' | python -c "import json,sys; d=json.loads(sys.stdin.read()); b=d['bf16_mfma']; print('%-10s fp32 step %.2f us k_fwd_bwd %.2f | bf16 step %.2f us k_fwd_bwd %.2f | loss %s %s' % ('$n', d['ms_per_step']*1e3, d['roofline']['kernel_ms']*1e3, b['ms_per_step']*1e3, b['roofline']['kernel_ms']*1e3, d['final_loss'], b['final_loss']))"
-  done
-done
-cp /tmp/orig.so tlsan_amd/libtlsan_hip.so
+# (superseded by scripts/abrun3.sh, which it now runs: fp32 AND the bf16 leg, every variant through TLSAN_LIB_PATH)
+exec "$(dirname "$0")/abrun3.sh" "$@"

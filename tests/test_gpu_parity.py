@@ -1053,6 +1053,9 @@ def test_user_index_from_a_sort_of_the_batch():
                         "or test_full_size_batch_matches_oracle or test_long_windows_streamed or test_graph_replay_equals_eager or test_prefetched_index_equals_inline"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    import re
+    mt = re.search(r"(\d+) passed", r.stdout)      # (the selection is by name: it must not shrink silently)
+    assert mt and int(mt.group(1)) >= 18, r.stdout[-2000:]
 
 
 _ISORT_DIGEST = r'''
@@ -1100,6 +1103,9 @@ def test_item_index_from_a_counting_sort_of_the_batch():
                         "or test_prefetched_index_equals_inline or test_periodic_scale_fold"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    import re
+    mt = re.search(r"(\d+) passed", r.stdout)
+    assert mt and int(mt.group(1)) >= 18, r.stdout[-2000:]
     digests = []
     for isort_min in ("1", str(1 << 30)):
         env = dict(os.environ, TLSAN_ISORT_MIN=isort_min, TLSAN_CSEG_MIN="1")
@@ -1107,6 +1113,50 @@ def test_item_index_from_a_counting_sort_of_the_batch():
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         digests.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1])
     assert digests[0] == digests[1], digests
+
+
+_RANK_DUMP = r'''
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+from tests.helpers import make_config, random_batch, random_params
+from tlsan_amd.model import Model
+cfg = make_config(U=300, I=500, C=23, d=128, regulation_rate=1e-3)
+p = {k: np.asarray(v, np.float32) for k, v in random_params(cfg, seed=5).items()}
+_, cat = random_batch(cfg, B=8, Sn=3, seed=0)
+m = Model(cfg, cat, l2_mode="lazy")
+m.set_params(p)
+tup = lambda b: (b["u"], b["i"], b["y"], b["hist_i"], b["hist_i_new"], b["hist_t"], b["sl"], b["sl_new"], b["u_cate"])
+losses = [m.train(None, tup(random_batch(cfg, B=1224, Sn=2 + s, seed=70 + s)[0]), 0.5) for s in range(3)]   # (1224 = 76 groups of 16 + 8: a partial last group; > 1024: 16-sample workgroups)
+np.savez(sys.argv[1], losses=np.asarray(losses), **m.get_params())
+'''
+
+
+def test_ranking_of_the_batch_changes_results_by_rounding_only(tmp_path):
+    """ADVICE r5: which samples share a workgroup of the fused kernel is a ranked function of the batch where that was measured
+    to win (tlsan_api.hip `balanced`: table size, group count, TLSAN_BAL_REG) -- so the fp32 grouping of the per-group partial
+    sums, and with it the last bits of a step, depend on those.  Each setting is bitwise reproducible by itself (the
+    determinism tests); across settings results may differ by fp32 rounding ONLY: three lazy steps of a batch with a partial
+    last group, ranked (TLSAN_BAL_REG=1) and in the batch's own order (=0)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for reg in ("1", "0"):
+        f = str(tmp_path / ("bal%s.npz" % reg))
+        r = subprocess.run([sys.executable, "-c", _RANK_DUMP % root, f], cwd=root, env=dict(os.environ, TLSAN_BAL_REG=reg),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        out.append(dict(np.load(f)))
+    a, b = out
+    assert np.allclose(a["losses"], b["losses"], rtol=2e-6, atol=0)
+    differ = False
+    for k in a:
+        if k == "losses":
+            continue
+        scale = float(np.abs(a[k]).max()) + 1e-12
+        assert np.abs(a[k].astype(np.float64) - b[k]).max() <= 2e-5 * scale, k
+        differ = differ or not np.array_equal(a[k], b[k])
+    assert differ      # (the ranking did change the grouping: otherwise this test checks nothing)
 
 
 def test_speculative_one_pass_lazy_update():

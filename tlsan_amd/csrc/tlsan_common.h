@@ -86,6 +86,10 @@ __device__ __forceinline__ f32x4 mm_mma2(typename MMT<MM>::opd a0, typename MMT<
 // exponential of a score difference is then one v_exp_f32 (exp2s) instead of v_mul + v_exp, and the mask constant and
 // the running maxima live in the same units.  The backward never differentiates through the scaled copy: dm2 is formed
 // from the softmax weights, and dm1 = dm2 W2^T, dW2 = m1^T dm2 use the unscaled W2.
+// (bf16 matrix products, ADVICE r5: the forward fragment is bf16(W2 * log2 e) while the backward's is bf16(W2), so the
+//  two see weights that differ by up to one bf16 ulp per entry -- the forward's effective W2 is bf16(W2 log2 e) / log2 e.
+//  Known and accepted: it is inside the rounding the bf16 extension already makes (its tests hold gradients to 15 % in L2
+//  against the fp64 oracle); scaling the fp32 accumulator instead would put a v_mul back behind every score.)
 #define TLSAN_LOG2E 1.44269504088896340736f
 __device__ __forceinline__ float exp2s(float x) { return __builtin_amdgcn_exp2f(x); }
 
