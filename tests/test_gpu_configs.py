@@ -334,6 +334,17 @@ def _c4_worker(rank, world, port, ret):
             ps = ms.get_params()
             assert np.allclose(l1, ls, rtol=3e-6, atol=0), (l1, ls)
             p0 = Model.init_params(cfg, 1234)
+            # ... and directly against the fp64 oracle on the concatenated batches (round 6: the oracle holds Movies-TV's tables)
+            q = {k: np.asarray(v, np.float64) for k, v in p0.items()}
+            lo = []
+            for per in per_step:
+                l, q, _ = orc.train_step(q, icl, orc.as_batch(cat2(per)), 8, cfg["regulation_rate"], lr=1.0)
+                lo.append(l)
+            assert np.allclose(l1, lo, rtol=2e-5, atol=0), (l1, lo)
+            for k in q:
+                du = np.asarray(p1[k], np.float64).reshape(q[k].shape) - np.asarray(p0[k], np.float64)
+                dr = q[k] - np.asarray(p0[k], np.float64)
+                assert np.abs(du - dr).max() < 5e-4 * (np.abs(dr).max() + 1e-12) + 5e-7, ("oracle", k, float(np.abs(du - dr).max()), float(np.abs(dr).max()))
             for k in ps:
                 du = np.asarray(p1[k], np.float64).reshape(np.shape(ps[k])) - np.asarray(p0[k], np.float64)
                 dr = np.asarray(ps[k], np.float64) - np.asarray(p0[k], np.float64)
@@ -409,6 +420,83 @@ def _c5_sharded_worker(rank, world, port, ret):
         ret[rank] = "FAIL: " + traceback.format_exc()
     finally:
         dist.destroy_process_group()
+
+
+def _c5_sharded_oracle_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tests.helpers import compact_problem
+        from tlsan_amd import synth
+        from tlsan_amd.dist import ShardedModel
+        cfg = synth.make_config("electronics", Ls=90, hidden_units=256, itemid_embedding_size=128, userid_embedding_size=128,
+                                cateid_embedding_size=128, user_count=10_000_000, item_count=5_000_000, cate_count=10_000)
+        icl = synth.item_cate_list(cfg)
+        B, di, Ls, G = 1024, 128, 90, world
+        per = [synth.make_batches(cfg, 1, B, seed=700 + r)[0] for r in range(world)]      # (every rank can build every part)
+        Sn = max(np.asarray(b[4]).shape[1] for b in per)
+        gb = tuple(np.concatenate([np.pad(np.asarray(b[c]), ((0, 0), (0, Sn - np.asarray(b[c]).shape[1]))) if c == 4 else np.asarray(b[c])
+                                   for b in per], 0) for c in range(9))
+        cp = compact_problem(gb, icl)
+        m = ShardedModel(cfg, icl, device="cuda:0", l2_mode="lazy", init="device", seed=13)
+        dev = m.device
+
+        def mine(ids, base):      # the touched rows this rank owns (ModPartition: id % G, local row id // G), as fused shard rows
+            own = ids[ids % G == rank]
+            return own, m.shard[torch.as_tensor(base + own // G, device=dev)].double().cpu().numpy()
+
+        def collect():
+            parts = [None] * world
+            dist.all_gather_object(parts, (mine(cp["items"], 0), mine(cp["users"], m.cI)))
+            it = np.zeros((len(cp["items"]), m.W)); us = np.zeros((len(cp["users"]), m.W))
+            for (ii, ir), (ui, ur) in parts:
+                it[np.searchsorted(cp["items"], ii)] = ir
+                us[np.searchsorted(cp["users"], ui)] = ur
+            q = dict(item_emb=it[:, :di].copy(), item_b=it[:, di].copy(), user_emb=us[:, :di].copy(), usert_emb=us[:, di:di + Ls].copy(),
+                     cate_emb=m.cate_emb[torch.as_tensor(cp["cates"], device=dev)].double().cpu().numpy())
+            q.update({k: np.asarray(v, np.float64) for k, v in m._unpack_dense(m.dense.cpu().numpy()).items()})
+            return q
+
+        q0 = collect()
+        # sum of squares of the regularised tables over ALL ranks (chunked fp64 on the device), minus the compact part
+        ssq = torch.tensor([_sumsq64(m.shard[:m.cI, :di]) + _sumsq64(m.shard[m.cI:, :di + Ls])], dtype=torch.float64)
+        dist.all_reduce(ssq)
+        extra = float(ssq.item()) + _sumsq64(m.cate_emb) - sum(float((q0[k] ** 2).sum()) for k in orc.REG_TABLES)
+        m.train_async(per[rank], 1.0)
+        loss, norm = float(m.last_loss.item()), float(m.last_gnorm.item())
+        m.fold_scale()
+        q1 = collect()
+        if rank == 0:
+            lo, newp, info = orc.train_step(q0, cp["item_cate"], orc.as_batch(cp["batch"]), 8, cfg["regulation_rate"], lr=1.0, l2_extra=extra)
+            assert abs(loss - lo) < 3e-6 * abs(lo) + 1e-4, (loss, lo)
+            assert abs(norm - info["norm"]) < 3e-4 * info["norm"], (norm, info["norm"])
+            for k in newp:
+                du, dr = q1[k].reshape(q0[k].shape) - q0[k], newp[k] - q0[k]
+                assert np.abs(du - dr).max() < 5e-4 * (np.abs(dr).max() + 1e-9) + 5e-7, (k, float(np.abs(du - dr).max()), float(np.abs(dr).max()))
+        ret[rank] = "ok"
+    except Exception:
+        import traceback
+        ret[rank] = "FAIL: " + traceback.format_exc()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_c5_sharded_step_matches_oracle_at_size():
+    """BASELINE.json configs[4] through the SHARDED step against the fp64 oracle (round 6): two ranks (two processes on
+    cuda:0, gloo), tables of 10 M users / 5 M items row-sharded by id % 2, one lazy step of 2 x 1024 sequences.  The rows
+    the global batch touches are collected from their owners' shards (before and after the step), the other rows enter the
+    oracle through their sum of squares -- the id compaction of `_one_step_against_oracle_at_size`."""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_c5_sharded_oracle_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(1500)
+    assert all(ret.get(r) == "ok" for r in range(world)), dict(ret)
 
 
 def test_c5_tables_sharded_over_two_ranks():
