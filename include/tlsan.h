@@ -226,7 +226,14 @@ int tlsan_forward_att(const tlsan_dims* dims, const tlsan_params* p, const tlsan
 /* One optimisation step -- replaces `sess.run([self.loss, self.train_op])`
  * (model.py:208-234): forward, BCE + L2 loss, backward, global-norm clip, SGD update of
  * every trainable, deterministic (bitwise reproducible) scatter-add of the embedding
- * gradients. */
+ * gradients.
+ * TLSAN_L2_LAZY, how the update is issued (round 6; an implementation note, the results are those of the
+ * reference's update either way): where it was measured to win the used rows are summed AND updated by one launch beside
+ * the gradient finalize, with clip coefficient 1 -- clip_by_global_norm's coefficient whenever the norm does not exceed
+ * the clip --, and a second launch commits the table scale, updates the dense weights and, after a clipped or non-finite
+ * step only, corrects the rows (w_spec - (s_true - s_spec) g = w_old - s_true g up to one rounding).  Unclipped steps
+ * are bit-equal to the form that waits for the coefficient.  `state` grew by 64 sum-of-squares records for it
+ * (tlsan_state_bytes); nothing else in the ABI changed (TLSAN_ABI_VERSION stays 14). */
 int tlsan_train_step(const tlsan_dims* dims, const tlsan_params* p, const tlsan_batch* b,
                      const tlsan_hparams* hp, const tlsan_step_out* out,
                      void* state, void* ws, size_t ws_bytes, void* stream);
