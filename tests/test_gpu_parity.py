@@ -1159,6 +1159,32 @@ def test_ranking_of_the_batch_changes_results_by_rounding_only(tmp_path):
     assert differ      # (the ranking did change the grouping: otherwise this test checks nothing)
 
 
+@pytest.mark.parametrize("d,di,Ls", [(128, 96, 10), (128, 32, 10), (64, 48, 10), (64, 16, 10), (128, 96, 24), (256, 128, 10)])
+def test_unequal_embedding_widths(d, di, Ls):
+    """The reference's `itemid_embedding_size` and `cateid_embedding_size` are separate flags (train.py:26-49; only their sum
+    must equal hidden_units, model.py:100-109): item / user rows of `di` floats beside category rows of `d - di`.  Every
+    other test takes the two halves equal.  Forward logits and one train step (lazy and dense L2) against the oracle with
+    the concatenated row split anywhere a 16-byte piece allows (rows wider than 64 floats take the wide row workgroups)."""
+    cfg = make_config(U=60, I=80, C=9, d=d, Ls=Ls, di=di, regulation_rate=1e-3)
+    p = _p32(random_params(cfg, seed=d + di))
+    b, cat = random_batch(cfg, B=45, Sn=4, seed=di)
+    ref = orc.forward(p, cat, b, 8)
+    loss, newp, info = orc.train_step(p, cat, b, 8, cfg["regulation_rate"], lr=0.7)
+    for l2 in ("lazy", "dense"):
+        m = _model(cfg, cat, p, l2_mode=l2)
+        li, _, ut, _ = m.forward(_tuple(b), is_test=False, want_u_t=True)
+        assert np.abs(li.cpu().numpy() - ref["logits"]).max() < LOGIT_TOL, l2
+        assert np.abs(ut.cpu().numpy() - ref["u_t"]).max() < LOGIT_TOL, l2
+        got_loss = m.train(None, _tuple(b), 0.7)
+        assert abs(got_loss - loss) < 1e-4 * max(1.0, abs(loss)), l2
+        assert abs(m.last_gnorm() - info["norm"]) < 2e-4 * info["norm"], l2
+        got = m.get_params()
+        for k in newp:
+            du = np.asarray(got[k], np.float64).reshape(p[k].shape) - p[k]
+            dr = newp[k] - p[k]
+            assert np.abs(du - dr).max() < 2e-4 * (np.abs(dr).max() + 1e-9) + 2e-7, (l2, k)
+
+
 def test_speculative_one_pass_lazy_update():
     """Tables that live in HBM (more than 512 MB of user / item rows, category segments) take the lazy-L2 step as ONE pass
     over the used rows BESIDE the finalize, with clip coefficient 1, and a second launch that commits the table scale and --
