@@ -989,13 +989,15 @@ def test_empty_histories(d, Ls):
         assert np.abs(du - dr).max() < 3e-4 * (np.abs(dr).max() + 1e-9) + 3e-7, k
 
 
-@pytest.mark.parametrize("l2_mode", ["lazy", "dense"])
-def test_one_hot_row_takes_every_use(l2_mode):
+@pytest.mark.parametrize("l2_mode,C,clip", [("lazy", 4, 5.0), ("dense", 4, 5.0), ("lazy", 40, 5.0), ("lazy", 40, 0.02)])
+def test_one_hot_row_takes_every_use(l2_mode, C, clip):
     """Collisions at their worst: every sample is the same user, every window and session the same item,
     the candidate the last item of the table -- one destination row receives all 3000+ per-use gradient
     rows (long segments finished by the whole wavefront, one category with every use), one user row
-    all 256; one train step against the oracle, bitwise reproducible."""
-    cfg = make_config(U=9, I=31, C=4, d=128, regulation_rate=1e-3)
+    all 256; one train step against the oracle, bitwise reproducible.  Four categories: a category shared by several
+    row-sum workgroups (the split form of the lazy tail); forty: the one-pass form, whose hot-row workgroup updates the
+    row itself -- with coefficient 1, and corrected by k_spec_commit when the step is clipped (clip 0.02)."""
+    cfg = make_config(U=9, I=31, C=C, d=128, regulation_rate=1e-3, max_gradient_norm=clip)
     p = _p32(random_params(cfg, seed=97))
     b, cat = random_batch(cfg, B=256, Sn=2, seed=98, full=True)
     b["u"][:] = cfg["user_count"] - 1
@@ -1003,7 +1005,8 @@ def test_one_hot_row_takes_every_use(l2_mode):
     b["hist_i_new"][:] = 7
     b["i"][:] = cfg["item_count"] - 1
     b["u_cate"][:] = int(cat[7])
-    loss, newp, info = orc.train_step(p, cat, b, 8, cfg["regulation_rate"], lr=0.5)
+    loss, newp, info = orc.train_step(p, cat, b, 8, cfg["regulation_rate"], lr=0.5, clip=clip)
+    assert (info["coef"] < 1.0) == (clip < 1.0)
     outs = []
     for rep in range(2):
         m = _model(cfg, cat, p, l2_mode=l2_mode)
