@@ -532,6 +532,66 @@ def test_bf16_tables_with_streamed_windows(d, Ls, Sn, B):
         assert np.array_equal(outs[0][k], outs[1][k]), k
 
 
+_BF16_CLIP_DUMP = r'''
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+from tests.helpers import make_config, random_batch, random_params
+from tests.test_gpu_parity import BF16_TABLES, _bf16_round, _p32, _tuple
+from tlsan_amd.model import Model
+cfg = make_config(U=40, I=60, C=9, d=128, max_gradient_norm=0.02, regulation_rate=1e-3)
+p = _p32(random_params(cfg, seed=41))
+for k in BF16_TABLES:
+    p[k] = _bf16_round(p[k]).astype(np.float64)
+b, cat = random_batch(cfg, B=48, Sn=4, seed=42)
+m = Model(cfg, cat, l2_mode="lazy", table_dtype="bf16")
+m.set_params({k: np.asarray(v, np.float32) for k, v in p.items()})
+loss = m.train(None, _tuple(b), 0.7)
+np.savez(sys.argv[1], loss=loss, gnorm=m.last_gnorm(), **m.get_params())
+'''
+
+
+def test_bf16_tables_clipped_step_in_the_one_pass_form(tmp_path):
+    """bf16 table storage through the speculative one-pass tail with the clip ACTIVE (TLSAN_LAZY_ONE_PASS=3: by default only
+    HBM-resident bf16 tables take this form, tlsan_api.hip `lazy_one_pass`).  The rows are written with coefficient 1
+    (stochastic rounding at the magnitude of w - lr g), corrected by k_spec_commit (a second rounding) and read back through
+    the folded table scale (a third): a stored element may be off by one bf16 ulp of the SPECULATIVE value plus two of the
+    result -- not more; fp32 parameters keep the usual bound; two runs are bitwise equal.  (The split form, the default for
+    cache-resident bf16 tables, rounds once: test_bf16_tables.)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = make_config(U=40, I=60, C=9, d=128, max_gradient_norm=0.02, regulation_rate=1e-3)
+    p = _p32(random_params(cfg, seed=41))
+    for k in BF16_TABLES:
+        p[k] = _bf16_round(p[k]).astype(np.float64)
+    b, cat = random_batch(cfg, B=48, Sn=4, seed=42)
+    loss, newp, info = orc.train_step(p, cat, b, 8, cfg["regulation_rate"], lr=0.7, clip=0.02)
+    _, spec, _ = orc.train_step(p, cat, b, 8, cfg["regulation_rate"], lr=0.7, clip=1e30)      # what coefficient 1 writes first
+    assert info["coef"] < 0.1
+    outs = []
+    for rep in range(2):
+        f = str(tmp_path / ("run%d.npz" % rep))
+        r = subprocess.run([sys.executable, "-c", _BF16_CLIP_DUMP % root, f], cwd=root, env=dict(os.environ, TLSAN_LAZY_ONE_PASS="3"),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append(dict(np.load(f)))
+    assert abs(float(outs[0]["loss"]) - loss) < 1e-4 * max(1.0, abs(loss))
+    assert abs(float(outs[0]["gnorm"]) - info["norm"]) < 3e-4 * info["norm"]
+    ulp_of = lambda x: 2.0 ** (np.floor(np.log2(np.maximum(np.abs(x), 1e-30))) - 7)
+    worst = 0.0
+    for k in newp:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+        a, r = np.asarray(outs[0][k], np.float64).reshape(p[k].shape), newp[k]
+        if k in BF16_TABLES:
+            bound = ulp_of(spec[k]) + 2.0 * ulp_of(np.maximum(np.abs(r), np.abs(a)))
+            assert (np.abs(a - r) <= bound * 1.001).all(), (k, float((np.abs(a - r) / bound).max()))
+            worst = max(worst, float((np.abs(a - r) / ulp_of(r)).max()))
+        else:
+            du, dr = a - p[k], r - p[k]
+            assert np.abs(du - dr).max() < 3e-4 * (np.abs(dr).max() + 1e-9) + 2e-7, k
+    assert worst > 3.0      # (the case does exercise the second rounding: otherwise it checks nothing the split form's test does not)
+
+
 def test_prefetched_index_equals_inline():
     """train_async(next_batch=..., after_next=...) builds the destination index of the next batch(es) on a second
     stream (tlsan_batch_index) one or two steps ahead; the result must be bitwise the same as building it inside the

@@ -464,6 +464,12 @@ static bool lazy_one_pass(const tlsan_dims* d, const tlsan_batch* b, const Apply
   if (T.csplit > 1) return false;
   if (apply_wide(A) && !A.cseg) return false;      // (the wide form is built for category segments only)
   if (mode >= 2) return mode == 2 ? A.cseg != 0 : true;
+  // bf16 tables: a clipped step rounds twice in this form -- the speculative write at the magnitude of w - lr g, the
+  // correction at that of the result -- so its stored elements can be off by one ulp of the SPECULATIVE value (unbiased,
+  // and only in clipped steps; fp32 tables: 2^-24 of it, far inside every bound).  Taken where it pays for that (tables in
+  // HBM: C5 in bf16 227 -> 202 us/step); with cache-resident bf16 tables (0.4-1.0 us) the split form and its
+  // one-rounding guarantee stay.
+  if (A.p.table_dtype == TLSAN_TABLE_BF16 && !tables_in_hbm(d)) return false;
   if (!apply_wide(A)) return true;
   return A.cseg && tables_in_hbm(d);
 }
