@@ -9,7 +9,7 @@ from tlsan_amd.model import Model
 B = int(sys.argv[1]) if len(sys.argv) > 1 and "=" not in sys.argv[1] else 4096
 kw = dict(x.split("=") for x in sys.argv[1:] if "=" in x)     # e.g. U=35896 I=28589 C=15 (Movies-TV shape)
 cfg = synth.make_config("electronics", user_count=int(kw.get("U", 39991)), item_count=int(kw.get("I", 22048)),
-                        cate_count=int(kw.get("C", 673)))
+                        cate_count=int(kw.get("C", 673)), Ls=int(kw.get("Ls", 10)))
 m = Model(cfg, synth.item_cate_list(cfg), l2_mode="lazy")
 lib = L.load()
 hb = synth.make_batches(cfg, 1, B, seed=7)[0]

@@ -1049,14 +1049,15 @@ def test_empty_histories(d, Ls):
         assert np.abs(du - dr).max() < 3e-4 * (np.abs(dr).max() + 1e-9) + 3e-7, k
 
 
-@pytest.mark.parametrize("l2_mode,C,clip", [("lazy", 4, 5.0), ("dense", 4, 5.0), ("lazy", 40, 5.0), ("lazy", 40, 0.02)])
+@pytest.mark.parametrize("l2_mode,C,clip", [("lazy", 4, 5.0), ("dense", 4, 5.0), ("lazy", 40, 5.0), ("lazy", 40, 0.02), ("lazy", 4, 0.02)])
 def test_one_hot_row_takes_every_use(l2_mode, C, clip):
     """Collisions at their worst: every sample is the same user, every window and session the same item,
     the candidate the last item of the table -- one destination row receives all 3000+ per-use gradient
     rows (long segments finished by the whole wavefront, one category with every use), one user row
     all 256; one train step against the oracle, bitwise reproducible.  Four categories: a category shared by several
-    row-sum workgroups (the split form of the lazy tail); forty: the one-pass form, whose hot-row workgroup updates the
-    row itself -- with coefficient 1, and corrected by k_spec_commit when the step is clipped (clip 0.02)."""
+    row-sum workgroups (summed beside the one-pass update of the item / user rows, updated by the commit launch); forty:
+    the one-pass form throughout, whose hot-row workgroup updates the row itself -- with coefficient 1, and corrected by
+    k_spec_commit when the step is clipped (clip 0.02)."""
     cfg = make_config(U=9, I=31, C=C, d=128, regulation_rate=1e-3, max_gradient_norm=clip)
     p = _p32(random_params(cfg, seed=97))
     b, cat = random_batch(cfg, B=256, Sn=2, seed=98, full=True)
@@ -1246,6 +1247,82 @@ def test_unequal_embedding_widths(d, di, Ls):
             du = np.asarray(got[k], np.float64).reshape(p[k].shape) - p[k]
             dr = newp[k] - p[k]
             assert np.abs(du - dr).max() < 2e-4 * (np.abs(dr).max() + 1e-9) + 2e-7, (l2, k)
+
+
+_CSPL_DIGEST = r'''
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+from tests.helpers import make_config, random_batch, random_params
+from tlsan_amd.model import Model
+h = hashlib.sha256()
+for d, Ls, C, td in ((128, 10, 3, "f32"), (128, 90, 2, "f32"), (64, 33, 5, "f32"), (128, 70, 3, "bf16")):
+    cfg = make_config(U=500, I=900, C=C, d=d, Ls=Ls, regulation_rate=1e-3, max_gradient_norm=1e4)
+    p = {k: np.asarray(v, np.float32) for k, v in random_params(cfg, seed=13).items()}
+    _, cat = random_batch(cfg, B=8, Sn=3, seed=0)
+    m = Model(cfg, cat, l2_mode="lazy", table_dtype=td)
+    m.set_params(p)
+    bs = [random_batch(cfg, B=700, Sn=1 + s, seed=60 + s)[0] for s in range(4)]
+    for b in bs[:2]:                 # (collisions: some rows hot)
+        for k in ("hist_i", "hist_i_new", "i"):
+            b[k] %%= 61
+    tup = lambda b: (b["u"], b["i"], b["y"], b["hist_i"], b["hist_i_new"], b["hist_t"], b["sl"], b["sl_new"], b["u_cate"])
+    dbs = [m.device_batch(tup(b)) for b in bs]
+    for s in range(len(dbs)):
+        m.train_async(dbs[s], 0.7, next_batch=dbs[s + 1] if s + 1 < len(dbs) else None, after_next=dbs[s + 2] if s + 2 < len(dbs) else None)
+    h.update(np.float32(m._out[0].item()).tobytes())
+    m.fold_scale()
+    got = m.get_params()
+    for k in sorted(got):
+        h.update(np.ascontiguousarray(got[k]).tobytes())
+print("DIGEST", h.hexdigest())
+'''
+
+
+@pytest.mark.parametrize("d,Ls,C,clip", [(128, 10, 3, 5.0), (128, 10, 3, 0.02), (128, 90, 2, 5.0), (128, 90, 2, 0.05), (64, 33, 5, 0.02)])
+def test_shared_categories_in_the_one_pass_form(d, Ls, C, clip):
+    """Few, large categories (Movies-TV: 15) are shared by several row-sum workgroups that add exact doubles into Rc64
+    (category_split) -- a sum no single workgroup holds, so their rows cannot be updated in the pass that sums them.  The
+    lazy-L2 step then takes the one-pass update for the item and user rows only (k_finalize_update<.., CSPL>: the category
+    workgroups sum beside them) and updates the category rows in the commit launch, which knows the coefficient
+    (k_spec_commit<.., CSPL>).  One train step against the oracle, clip inactive and active, user rows of up to 128 floats
+    and wider (d = 128 with a 90-entry window: two passes of the narrow form), bitwise reproducible."""
+    cfg = make_config(U=300, I=500, C=C, d=d, Ls=Ls, regulation_rate=1e-3, max_gradient_norm=clip)
+    p = _p32(random_params(cfg, seed=131))
+    b, cat = random_batch(cfg, B=640, Sn=3, seed=132)
+    for k in ("hist_i", "hist_i_new"):     # (some hot rows)
+        b[k][::3] %= 5
+    assert 640 * (Ls + 3 + 2) // C > 512       # (category_split: more than one workgroup per category)
+    loss, newp, info = orc.train_step(p, cat, b, 8, cfg["regulation_rate"], lr=0.5, clip=clip)
+    assert (info["coef"] < 1.0) == (clip < 1.0)
+    outs = []
+    for rep in range(2):
+        m = _model(cfg, cat, p, l2_mode="lazy")
+        l = m.train(None, _tuple(b), 0.5)
+        assert abs(l - loss) < 1e-4 * max(1.0, abs(loss))
+        assert abs(m.last_gnorm() - info["norm"]) < 2e-4 * info["norm"]
+        outs.append(m.get_params())
+    for k in newp:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+        du = np.asarray(outs[0][k], np.float64).reshape(p[k].shape) - p[k]
+        dr = newp[k] - p[k]
+        assert np.abs(du - dr).max() < 3e-4 * (np.abs(dr).max() + 1e-9) + 3e-7, k
+
+
+def test_shared_categories_one_pass_equals_the_split_form():
+    """Unclipped steps of the form above leave the SAME BITS as the split form (row sums beside the finalize, then
+    k_update_lazy; TLSAN_LAZY_CSPL=0, read once per process): four steps announced two ahead on four table shapes, fp32 and
+    bf16 tables (TLSAN_LAZY_ONE_PASS=3 sends cache-resident bf16 tables through the one-pass form too), losses and every
+    parameter."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for cspl in ("1", "0"):
+        env = dict(os.environ, TLSAN_LAZY_ONE_PASS="3", TLSAN_LAZY_CSPL=cspl)
+        r = subprocess.run([sys.executable, "-c", _CSPL_DIGEST % root], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        digests.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1])
+    assert digests[0] == digests[1], digests
 
 
 def test_speculative_one_pass_lazy_update():

@@ -454,24 +454,30 @@ static bool tables_in_hbm(const tlsan_dims* d) {      // (well beyond the 256 Mi
 // 59.9 -> 57.8, 10 M / 5 M tables 97 -> 80 --; wider rows (d = 256) only where the tables live in HBM (C5 300 -> 267; with
 // cache-resident tables it loses 2.5 us to the split form).  TLSAN_LAZY_ONE_PASS: 0 never, 1 (default) as described,
 // 2 whenever the tables take category segments, 3 wherever the form is built.
-static bool lazy_one_pass(const tlsan_dims* d, const tlsan_batch* b, const ApplyArgs& A) {
+// Returns 0 (the split form), 1 (one pass), or 2: one pass over the item and user rows while the category rows -- few, large
+// categories (Movies-TV: 15) that several row-sum workgroups share, adding exact doubles with atomics (category_split) -- are
+// summed beside them and updated by the commit launch (k_finalize_update / k_spec_commit<.., CSPL>; TLSAN_LAZY_CSPL=0: off).
+static int lazy_one_pass(const tlsan_dims* d, const tlsan_batch* b, const ApplyArgs& A) {
   static const int mode = [] { const char* e = getenv("TLSAN_LAZY_ONE_PASS"); return e ? atoi(e) : 1; }();
-  if (mode == 0) return false;
-  // few, large categories (Movies-TV: 15) share a category among several row-sum workgroups that add exact doubles with
-  // atomics (category_split): that form has no one-pass counterpart
+  static const int cspl = [] { const char* e = getenv("TLSAN_LAZY_CSPL"); return e ? atoi(e) : 1; }();
+  if (mode == 0) return 0;
   ApplyArgs T = A;
   category_split(T, d, b);
-  if (T.csplit > 1) return false;
-  if (apply_wide(A) && !A.cseg) return false;      // (the wide form is built for category segments only)
-  if (mode >= 2) return mode == 2 ? A.cseg != 0 : true;
+  if (T.csplit > 1) {
+    if (!cspl || mode == 2 || A.di > 64 || A.dc > 64 || A.WU > 256) return 0;   // (built in the narrow form: d <= 128)
+    if (mode == 1 && A.p.table_dtype == TLSAN_TABLE_BF16 && !tables_in_hbm(d)) return 0;   // (as below)
+    return 2;
+  }
+  if (apply_wide(A) && !A.cseg) return 0;      // (the wide form is built for category segments only)
+  if (mode >= 2) return mode == 2 ? A.cseg != 0 : 1;
   // bf16 tables: a clipped step rounds twice in this form -- the speculative write at the magnitude of w - lr g, the
   // correction at that of the result -- so its stored elements can be off by one ulp of the SPECULATIVE value (unbiased,
   // and only in clipped steps; fp32 tables: 2^-24 of it, far inside every bound).  Taken where it pays for that (tables in
   // HBM: C5 in bf16 227 -> 202 us/step); with cache-resident bf16 tables (0.4-1.0 us) the split form and its
   // one-rounding guarantee stay.
-  if (A.p.table_dtype == TLSAN_TABLE_BF16 && !tables_in_hbm(d)) return false;
-  if (!apply_wide(A)) return true;
-  return A.cseg && tables_in_hbm(d);
+  if (A.p.table_dtype == TLSAN_TABLE_BF16 && !tables_in_hbm(d)) return 0;
+  if (!apply_wide(A)) return 1;
+  return A.cseg && tables_in_hbm(d) ? 1 : 0;
 }
 
 // second half of the split lazy update (the first half rides with the dense finalize, run_backward)
@@ -897,11 +903,20 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
     lazy_blocks(A, b->B, b->Sn);
     A.nbH = AP_HOT_CAP;      // hot item rows: a workgroup each, leading the row workgroups (they return at once where there are none)
     f.count_step = 0; f.spec = 1;
-    const dim3 grid(w.nfin + 1 + A.nbH + A.nbC + A.nbI + A.nbU);
-    const bool wide = apply_wide(A), bf16 = A.p.table_dtype == TLSAN_TABLE_BF16, low = tables_in_hbm(d);
+    const bool shared = A.csplit > 1;   // (lazy_one_pass form 2: A.nbC = the commit launch's category blocks; this launch carries C * csplit)
+    const dim3 grid(w.nfin + 1 + A.nbH + (shared ? A.C * A.csplit : A.nbC) + A.nbI + A.nbU);
+    const bool wide = apply_wide(A) && !shared, bf16 = A.p.table_dtype == TLSAN_TABLE_BF16, low = tables_in_hbm(d);
 #define FU_LAUNCH(DD, HH)                                                                                                            \
   do {                                                                                                                               \
-    if (bf16) {                                                                                                                      \
+    if (shared) {                                                                                                                    \
+      if (bf16) {                                                                                                                    \
+        if (low) hipLaunchKernelGGL((k_finalize_update<DD, HH, false, TLSAN_TABLE_BF16, true, true>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);  \
+        else hipLaunchKernelGGL((k_finalize_update<DD, HH, false, TLSAN_TABLE_BF16, false, true>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);     \
+      } else {                                                                                                                       \
+        if (low) hipLaunchKernelGGL((k_finalize_update<DD, HH, false, TLSAN_TABLE_F32, true, true>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);   \
+        else hipLaunchKernelGGL((k_finalize_update<DD, HH, false, TLSAN_TABLE_F32, false, true>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);      \
+      }                                                                                                                              \
+    } else if (bf16) {                                                                                                                      \
       if (wide) hipLaunchKernelGGL((k_finalize_update<DD, HH, true, TLSAN_TABLE_BF16>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);  \
       else if (low) hipLaunchKernelGGL((k_finalize_update<DD, HH, false, TLSAN_TABLE_BF16, true>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A); \
       else hipLaunchKernelGGL((k_finalize_update<DD, HH, false, TLSAN_TABLE_BF16>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);      \
@@ -911,6 +926,7 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
       else hipLaunchKernelGGL((k_finalize_update<DD, HH, false, TLSAN_TABLE_F32>), grid, dim3(256), 0, hs, f, w.nbK, w.nbS, A);       \
     }                                                                                                                                \
   } while (0)
+    if (shared && s.D > 128) return fail(TLSAN_E_UNSUPPORTED, "shared categories in the one-pass update: d <= 128");   // (lazy_one_pass never asks)
     if (s.D == 64) FU_LAUNCH(64, 8);
     else if (s.D == 128) FU_LAUNCH(128, 16);
     else FU_LAUNCH(256, 32);
@@ -1058,20 +1074,29 @@ int tlsan_train_step_opt(const tlsan_dims* d, const tlsan_params* p, const tlsan
     if (opt->kind == TLSAN_OPT_ADAM)  // adam.py: lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)
       A.oalpha = (float)((double)hp->lr * sqrt(1.0 - pow((double)opt->beta2, opt->step)) / (1.0 - pow((double)opt->beta1, opt->step)));
   }
-  if (hp->l2_mode == TLSAN_L2_LAZY && lazy_one_pass(d, b, A)) {
+  static const int spec_on = [] { const char* e = getenv("TLSAN_LAZY_SPEC"); return e ? atoi(e) : 1; }();
+  int form = hp->l2_mode == TLSAN_L2_LAZY ? lazy_one_pass(d, b, A) : 0;
+  if (form == 2 && !spec_on) form = 0;     // (shared categories: built in the speculative form only)
+  if (form != 0) {
     // tables that live in HBM: ONE pass over the used rows behind the finalize (k_apply<AP_UPDATE, lazy>: segment sums and
     // the update of a row by the same lanes) instead of row sums beside the finalize + an elementwise update -- the
     // summed rows make no round trip through memory (see lazy_one_pass)
-    static const int spec_on = [] { const char* e = getenv("TLSAN_LAZY_SPEC"); return e ? atoi(e) : 1; }();
+    if (form == 2) {   // shared categories: summed in the first launch (C * csplit workgroups), updated by 16-row blocks of the commit
+      category_split(A, d, b);
+      A.nbC = (A.C + 15) / 16;
+    }
     ApplyArgs A1 = A;
     lazy_blocks(A1, b->B, b->Sn);
     if (spec_on) {   // the row update beside the finalize, with coefficient 1; then the commit (+ the correction of a clipped step)
       if ((rc = run_backward(d, s, p, b, hp, true, out, w, st, L, hs, &A, nullptr, true, true))) return rc;
       A1.nbH = AP_HOT_CAP;
-      const int nrow = A1.nbH + A1.nbC + A1.nbI + A1.nbU;
-      const dim3 grid(A1.nbD + (nrow < SPEC_FIX_BLOCKS ? nrow : SPEC_FIX_BLOCKS));
-      const bool wide = apply_wide(A1);
-      if (A1.p.table_dtype == TLSAN_TABLE_BF16) {
+      const int nrow = A1.nbH + (form == 2 ? 0 : A1.nbC) + A1.nbI + A1.nbU;
+      const dim3 grid(A1.nbD + (form == 2 ? A1.nbC : 0) + (nrow < SPEC_FIX_BLOCKS ? nrow : SPEC_FIX_BLOCKS));
+      const bool wide = apply_wide(A1) && form != 2;
+      if (form == 2) {
+        if (A1.p.table_dtype == TLSAN_TABLE_BF16) hipLaunchKernelGGL((k_spec_commit<false, TLSAN_TABLE_BF16, true>), grid, dim3(256), 0, hs, A1);
+        else hipLaunchKernelGGL((k_spec_commit<false, TLSAN_TABLE_F32, true>), grid, dim3(256), 0, hs, A1);
+      } else if (A1.p.table_dtype == TLSAN_TABLE_BF16) {
         if (wide) hipLaunchKernelGGL((k_spec_commit<true, TLSAN_TABLE_BF16>), grid, dim3(256), 0, hs, A1);
         else hipLaunchKernelGGL((k_spec_commit<false, TLSAN_TABLE_BF16>), grid, dim3(256), 0, hs, A1);
       } else {

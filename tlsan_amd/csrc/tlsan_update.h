@@ -2281,6 +2281,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? 3 : 
   if (stp && x.tid == 0) { stp[6] = __builtin_amdgcn_s_memtime(); stp[5] = __builtin_amdgcn_s_memrealtime(); }
 }
 
+// 16 category rows, one per 16-lane group: w -= lazy_scale * (the row's presummed gradient: Rc, or Rc64 -- the exact doubles the
+// split category workgroups left, rounded to float as a single workgroup would have, and cleared).  Returns the lane's share
+// of the change of the stored table's sum of squares.  (k_update_lazy; k_spec_commit<.., CSPL>)
+template <int NC, int DT>
+__device__ __forceinline__ double update_cate_rows(const ApplyArgs& a, int c, int l16, float lazy_scale, uint32_t salt) {
+  double part = 0.0;
+  if (c < a.C) {
+    const size_t wrow = (size_t)c * a.dc;
+    f32x4 w[NC], g[NC];
+#pragma unroll
+    for (int ch = 0; ch < NC; ++ch)
+      if (4 * (l16 + 16 * ch) < a.dc) {
+        w[ch] = tbl_ld4<DT>(a.p.cate_emb, wrow + 4 * (l16 + 16 * ch));
+        if (a.csplit > 1) {
+          double* r64 = a.Rc64 + wrow + 4 * (l16 + 16 * ch);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { g[ch][i] = (float)r64[i]; r64[i] = 0.0; }
+        } else {
+          g[ch] = *(const f32x4*)(a.Rc + wrow + 4 * (l16 + 16 * ch));
+        }
+      }
+#pragma unroll
+    for (int ch = 0; ch < NC; ++ch)
+      if (4 * (l16 + 16 * ch) < a.dc) {
+        const f32x4 w0 = w[ch];
+        w[ch] = w0 - lazy_scale * g[ch];
+        tbl_st4<DT>(a.p.cate_emb, wrow + 4 * (l16 + 16 * ch), w[ch], salt ^ 0x3c6ef372u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part += (double)w[ch][i] * (double)w[ch][i] - (double)w0[i] * (double)w0[i];
+      }
+  }
+  return part;
+}
+
 // ------------------------------------------------------------------------------------------
 // The lazy-L2 step for tables that live in HBM (round 6): the SPECULATIVE one-pass update.
 // The split form above sends every summed row through memory (written by the row-sum launch, read by k_update_lazy beside
@@ -2315,8 +2349,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? 3 : 
 #define SPEC_WPE_NARROW_BF16 4   // bf16 tables (the stochastic rounding's hash): 113 registers; at five, 180 bytes per lane spill
 #endif
 // LOWOCC (narrow form, tables in HBM): three waves per SIMD -- see the note above
-template <int D, int DH, bool WIDE, int DT, bool LOWOCC = false>
+// CSPL (narrow form; few, large categories -- Movies-TV: 15 -- that several workgroups share, category_split): the category
+// workgroups of this launch only SUM (exact doubles added into Rc64, as in k_finalize_presum<.., CSPLIT>) and the category
+// rows are updated by k_spec_commit<.., CSPL>, which knows the coefficient; item and user rows as everywhere.  a.nbC is then
+// the number of category-row blocks of the COMMIT launch (16 rows each: they own the records [0, nbC) of S_delta); this
+// launch carries C * csplit category workgroups.  User rows of up to 256 floats (d = 128 with 90-entry windows) in two
+// passes of the narrow form, as the row-sum launch takes them.
+template <int D, int DH, bool WIDE, int DT, bool LOWOCC = false, bool CSPL = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? SPEC_WPE : (LOWOCC ? 3 : (DT == TLSAN_TABLE_F32 ? SPEC_WPE_NARROW : SPEC_WPE_NARROW_BF16))))) void k_finalize_update(FinArgs f, int nbK, int nbS, ApplyArgs a) {
+  static_assert(!(WIDE && CSPL), "shared categories: narrow form only");
   constexpr int NC = WIDE ? 2 : 1, NI = WIDE ? 2 : 1, NU = WIDE ? 4 : 2;
   constexpr int OWN = WIDE ? SPEC_OWN : AP_OWN;
   __shared__ double shd[4 * 16 * NC * 4 > 256 ? 4 * 16 * NC * 4 : 256];
@@ -2346,6 +2387,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? SPEC
     return;
   }
   x.blk -= a.nbH;
+  if constexpr (CSPL) {
+    const int nbCg = a.C * a.csplit;       // category workgroups of this launch (category, share)
+    if (x.blk < nbCg) {
+      apply_cate_block<AP_PRESUM, true, NC, DT, true>(a, x, shd, shp, sh_pos, sh_lo, sh_n, sh_wtot);
+      return;
+    }
+    // (the row blocks' records follow the commit launch's category blocks': [nbC | nbI | nbU].  Two-pass user blocks are the
+    //  longer ones and lead the item blocks -- the launch ends when its last-placed blocks do)
+    int rb = x.blk - nbCg;
+    const bool ufirst = a.WU > 128;
+    const bool is_user = ufirst ? rb < a.nbU : rb >= a.nbI;
+    if (is_user) rb -= ufirst ? 0 : a.nbI; else rb -= ufirst ? a.nbU : 0;
+    x.blk = a.nbC + (is_user ? a.nbI : 0) + rb;
+    if (!is_user) {
+      apply_rows_block<AP_UPDATE, true, true, NI, OWN, DT>(a, x, rb * AP_ROWS_PB, shp);
+    } else {
+      apply_rows_block<AP_UPDATE, true, false, NU, AP_OWN / 2, DT>(a, x, rb * AP_ROWS_PB, shp);
+      if (ufirst) {                        // the second half of a wide user row (its change of the sum of squares: added to the record)
+        __syncthreads();
+        x.accum = true;
+        apply_rows_block<AP_UPDATE, true, false, NU, AP_OWN / 2, DT, NU>(a, x, rb * AP_ROWS_PB, shp);
+      }
+    }
+    return;
+  }
   const int blk = x.blk;
   if (blk < a.nbC) {
     // (the wide form takes category segments only -- lazy_one_pass, tlsan_api.hip: the item-walk category workgroups in its
@@ -2357,8 +2423,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? SPEC
   else apply_rows_block<AP_UPDATE, true, false, NU, (WIDE ? SPEC_OWN : AP_OWN / 2), DT>(a, x, (blk - a.nbC - a.nbI) * AP_ROWS_PB, shp);
 }
 
-// grid: nbD blocks of 256 dense parameters, then at most SPEC_FIX_BLOCKS correcting workgroups (which return at once when the step was not clipped)
-template <bool WIDE, int DT>
+// grid: nbD blocks of 256 dense parameters, (CSPL: a.nbC blocks of 16 category rows, updated here from the shared categories'
+// exact sums with the step's true coefficient,) then at most SPEC_FIX_BLOCKS correcting workgroups (which return at once
+// when the step was not clipped)
+template <bool WIDE, int DT, bool CSPL = false>
 __global__ __launch_bounds__(256) void k_spec_commit(ApplyArgs a) {
   constexpr int NC = WIDE ? 2 : 1, NI = WIDE ? 2 : 1, NU = WIDE ? 4 : 2;
   constexpr int OWN = WIDE ? SPEC_OWN : AP_OWN;
@@ -2386,13 +2454,24 @@ __global__ __launch_bounds__(256) void k_spec_commit(ApplyArgs a) {
     }
     return;
   }
+  const float st_true = a.lr * coef;
+  int fix0 = a.nbD;              // first correcting workgroup
+  if constexpr (CSPL) {
+    fix0 += a.nbC;
+    if ((int)blockIdx.x < fix0) {   // 16 category rows: nothing speculative about them
+      const float Pp = a.hdr->P_prev;
+      const int cb = (int)blockIdx.x - a.nbD;
+      const double part = update_cate_rows<NC, DT>(a, cb * 16 + (tid >> 4), tid & 15, st_true / (Pp * (1.0f - st_true * a.reg)), a.hdr->spec_salt);
+      block_delta_store(part, shp, &a.delta_out[cb], a.hdr->spec_salt);
+      return;
+    }
+  }
   if (coef == 1.0f) return;   // (block-uniform) the speculation held.  (A NaN coefficient takes the correcting pass and poisons the rows.)
   ApCtx x;
   x.tid = tid; x.wave = tid >> 6; x.lane = tid & 63; x.grp = x.lane >> 4; x.l16 = x.lane & 15;
   x.gid = x.wave * 4 + x.grp;
   x.P = a.hdr->P_prev;
   x.invP = 1.0f / x.P;
-  const float st_true = a.lr * coef;
   x.step = st_true - a.lr;                                                   // item_b: w_spec - (st_true - lr) g = w_old - st_true g
   x.lazy_scale = st_true / (x.P * (1.0f - st_true * a.reg)) - a.lr / (x.P * (1.0f - a.lr * a.reg));
   x.salt = a.hdr->spec_salt;
@@ -2400,6 +2479,27 @@ __global__ __launch_bounds__(256) void k_spec_commit(ApplyArgs a) {
   x.accum = true;
   // (the launch carries at most SPEC_FIX_BLOCKS correcting workgroups, each walking row blocks with the grid's stride: an
   //  unclipped step -- nearly every step -- pays for a few hundred workgroups that return at once, not for one per 16 rows)
+  if constexpr (CSPL) {
+    for (int v = (int)blockIdx.x - fix0; v < a.nbH + a.nbI + a.nbU; v += (int)gridDim.x - fix0) {
+      if (v < a.nbH) {
+        presum_hot_block<NI, true, DT>(a, v, shd, shp, &x);
+      } else {
+        const int rb = v - a.nbH;
+        x.blk = a.nbC + rb;
+        if (rb < a.nbI) {
+          apply_rows_block<AP_UPDATE, true, true, NI, OWN, DT>(a, x, rb * AP_ROWS_PB, shp);
+        } else {
+          apply_rows_block<AP_UPDATE, true, false, NU, AP_OWN / 2, DT>(a, x, (rb - a.nbI) * AP_ROWS_PB, shp);
+          if (a.WU > 128) {
+            __syncthreads();
+            apply_rows_block<AP_UPDATE, true, false, NU, AP_OWN / 2, DT, NU>(a, x, (rb - a.nbI) * AP_ROWS_PB, shp);
+          }
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
   for (int v = (int)blockIdx.x - a.nbD; v < a.nbH + a.nbC + a.nbI + a.nbU; v += (int)gridDim.x - a.nbD) {
     if (v < a.nbH) {
       presum_hot_block<NI, true, DT>(a, v, shd, shp, &x);
@@ -2440,32 +2540,7 @@ __global__ __launch_bounds__(256) void k_update_lazy(ApplyArgs a, int nbC16) {
   if (blk == 0 && tid == 0) a.hdr->spart_n = nbC16 + a.nbI + a.nbU;
   double part = 0.0;
   if (blk < nbC16) {
-    const int c = blk * 16 + gid;
-    if (c < a.C) {
-      const size_t wrow = (size_t)c * a.dc;
-      f32x4 w[NC], g[NC];
-#pragma unroll
-      for (int ch = 0; ch < NC; ++ch)
-        if (4 * (l16 + 16 * ch) < a.dc) {
-          w[ch] = tbl_ld4<DT>(a.p.cate_emb, wrow + 4 * (l16 + 16 * ch));
-          if (a.csplit > 1) {
-            double* r64 = a.Rc64 + wrow + 4 * (l16 + 16 * ch);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { g[ch][i] = (float)r64[i]; r64[i] = 0.0; }
-          } else {
-            g[ch] = *(const f32x4*)(a.Rc + wrow + 4 * (l16 + 16 * ch));
-          }
-        }
-#pragma unroll
-      for (int ch = 0; ch < NC; ++ch)
-        if (4 * (l16 + 16 * ch) < a.dc) {
-          const f32x4 w0 = w[ch];
-          w[ch] = w0 - lazy_scale * g[ch];
-          tbl_st4<DT>(a.p.cate_emb, wrow + 4 * (l16 + 16 * ch), w[ch], salt ^ 0x3c6ef372u);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) part += (double)w[ch][i] * (double)w[ch][i] - (double)w0[i] * (double)w0[i];
-        }
-    }
+    part = update_cate_rows<NC, DT>(a, blk * 16 + gid, l16, lazy_scale, salt);
   } else if (blk < nbC16 + a.nbI) {
     const int slot0 = (blk - nbC16) * AP_ROWS_PB, slot = slot0 + gid;
     const int nuq = *a.n_uniq_item;
