@@ -2368,7 +2368,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? SPEC
   __shared__ int sh_last;
   const int nfin = nbK + nbS + 1;
   if ((int)blockIdx.x < nfin) {
+    // (debug stamps, scripts/stamps_apply.py: the finalize workgroups are listed after the row workgroups)
+    unsigned long long* stp = a.stamps ? a.stamps + (size_t)(gridDim.x - nfin - a.nbH + blockIdx.x) * 8 : nullptr;
+    if (stp && threadIdx.x == 0) { stp[0] = __builtin_amdgcn_s_memtime(); stp[4] = __builtin_amdgcn_s_memrealtime(); }
     dense_finalize_block<D, DH>(f, nbK, nbS, blockIdx.x, shd, &sh_last);
+    if (stp && threadIdx.x == 0) { stp[6] = __builtin_amdgcn_s_memtime(); stp[5] = __builtin_amdgcn_s_memrealtime(); }
     return;
   }
   ApCtx x;
@@ -2387,6 +2391,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? SPEC
     return;
   }
   x.blk -= a.nbH;
+  unsigned long long* stp = a.stamps ? a.stamps + (size_t)x.blk * 8 : nullptr;
+  if (stp && x.tid == 0) { stp[0] = __builtin_amdgcn_s_memtime(); stp[4] = __builtin_amdgcn_s_memrealtime(); }
   if constexpr (CSPL) {
     const int nbCg = a.C * a.csplit;       // category workgroups of this launch (category, share)
     if (x.blk < nbCg) {
@@ -2421,6 +2427,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? SPEC
   }
   else if (blk < a.nbC + a.nbI) apply_rows_block<AP_UPDATE, true, true, NI, OWN, DT>(a, x, (blk - a.nbC) * AP_ROWS_PB, shp);
   else apply_rows_block<AP_UPDATE, true, false, NU, (WIDE ? SPEC_OWN : AP_OWN / 2), DT>(a, x, (blk - a.nbC - a.nbI) * AP_ROWS_PB, shp);
+  if (stp && x.tid == 0) { stp[6] = __builtin_amdgcn_s_memtime(); stp[5] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 // grid: nbD blocks of 256 dense parameters, (CSPL: a.nbC blocks of 16 category rows, updated here from the shared categories'
