@@ -353,6 +353,9 @@ def main():
     starts = np.asarray(getattr(stepper, "started_at", None) or [], np.float64)
     if hasattr(stepper, "started_at"):
         stepper.started_at = None
+    if os.environ.get("BENCH_DUMP_STARTS") and rank == 0 and len(starts) > 1:     # (diagnostic: where a short window's extra time goes)
+        print("window %.1f us; first start +%.1f us after t0, last start %.1f us before the end; start-to-start (us): %s" % (
+            dt * 1e6, (starts[0] - t0) * 1e6, (t0 + dt - starts[-1]) * 1e6, " ".join("%.0f" % (x * 1e6) for x in np.diff(starts))), file=sys.stderr)
     # the kernel's own duration: a pair of HIP events ATTACHED TO k_fwd_bwd's dispatch on its stream (hipExtLaunchKernelGGL
     # through tlsan_profile_*: the dispatch's own begin / end time stamps, which is what a rocprofv3 kernel trace reports),
     # live, in a pass of the SAME steps right behind the timed ones.  (Rounds 2-3 recorded two events AROUND the launch:
