@@ -897,7 +897,7 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
   f.out_gnorm = out ? out->gnorm : nullptr;
   f.out_sq = out ? out->sq_rows : nullptr;
   if (presum && spec) {
-    // tables in HBM: the row workgroups UPDATE beside the finalize, with clip coefficient 1 (k_finalize_update; the commit
+    // the one-pass form: the row workgroups UPDATE beside the finalize, with clip coefficient 1 (k_finalize_update; the commit
     // and -- after a clipped step -- the correction follow in k_spec_commit, tlsan_train_step_opt)
     ApplyArgs A = *presum;
     lazy_blocks(A, b->B, b->Sn);
@@ -1078,9 +1078,8 @@ int tlsan_train_step_opt(const tlsan_dims* d, const tlsan_params* p, const tlsan
   int form = hp->l2_mode == TLSAN_L2_LAZY ? lazy_one_pass(d, b, A) : 0;
   if (form == 2 && !spec_on) form = 0;     // (shared categories: built in the speculative form only)
   if (form != 0) {
-    // tables that live in HBM: ONE pass over the used rows behind the finalize (k_apply<AP_UPDATE, lazy>: segment sums and
-    // the update of a row by the same lanes) instead of row sums beside the finalize + an elementwise update -- the
-    // summed rows make no round trip through memory (see lazy_one_pass)
+    // ONE pass over the used rows (segment sums and the update of a row by the same lanes) instead of row sums beside the
+    // finalize + an elementwise update: the summed rows make no round trip through memory (lazy_one_pass says where)
     if (form == 2) {   // shared categories: summed in the first launch (C * csplit workgroups), updated by 16-row blocks of the commit
       category_split(A, d, b);
       A.nbC = (A.C + 15) / 16;
