@@ -231,7 +231,9 @@ int tlsan_forward_att(const tlsan_dims* dims, const tlsan_params* p, const tlsan
  * reference's update either way): where it was measured to win the used rows are summed AND updated by one launch beside
  * the gradient finalize, with clip coefficient 1 -- clip_by_global_norm's coefficient whenever the norm does not exceed
  * the clip --, and a second launch commits the table scale, updates the dense weights and, after a clipped or non-finite
- * step only, corrects the rows (w_spec - (s_true - s_spec) g = w_old - s_true g up to one rounding).  Unclipped steps
+ * step only, corrects the rows (w_spec - (s_true - s_spec) g = w_old - s_true g up to one rounding: one ulp of the
+ * SPECULATIVE value, which is why bf16 tables that the caches hold keep the form that waits).  Category rows that several
+ * workgroups share (a few, large categories) are updated by the second launch, with the true coefficient.  Unclipped steps
  * are bit-equal to the form that waits for the coefficient.  `state` grew by 64 sum-of-squares records for it
  * (tlsan_state_bytes); nothing else in the ABI changed (TLSAN_ABI_VERSION stays 14). */
 int tlsan_train_step(const tlsan_dims* dims, const tlsan_params* p, const tlsan_batch* b,
