@@ -427,16 +427,36 @@ static void lazy_blocks(ApplyArgs& A, int B, int Sn) {  // at most min(rows, use
 
 static bool apply_wide(const ApplyArgs& A) { return A.di > 64 || A.dc > 64 || A.WU > 128; }  // more float4 chunks per lane
 
-// few, large categories: several workgroups per category in the row-sum pass, about 128 uses each
-// (estimated from the batch shape; up to 64 per category), every one with its share of the items
+// few, large categories: several workgroups per category in the row-sum pass, every one with its share of the items and of the
+// u_cate uses (estimated from the batch shape; up to 64 per category).
+//  * from 512 uses per category on: about 128 uses per workgroup (round 3; Movies-TV's 15 categories at batch 4096);
+//  * round 6 -- where the launch has SLOTS TO SPARE (its other workgroups and the category workgroups all resident at once:
+//    small batches), from ~100 uses on and ~48 per workgroup: a category workgroup is a chain of dependent trips (3 us
+//    before its first gradient row arrives) plus ~0.03 us per use, and such a launch ends with its longest chain --
+//    Digital-Music's 53 categories at batch 1024 (300 uses each) took 9-13 us where everything else had finished after 7:
+//    51.4 -> 48.2 us/step.  Where the launch is bound by slots (batch 4096: the bench's 673 categories of ~100 uses,
+//    Movies-TV) every workgroup more costs its lead-in again: 64 instead of 46 per category at Movies-TV, Ls = 10:
+//    59.1 -> 61.5 (profiles/r06_ab_csplit.txt).
+// TLSAN_CSPLIT_FINE=0 (read once): the first rule only (A/B).
 static void category_split(ApplyArgs& A, const tlsan_dims* d, const tlsan_batch* b) {
   // category segments (A.cseg) sum a category as ONE contiguous segment, 16 categories per workgroup
   // (apply_cseg_block): there is nothing to split, and the split kernels decode blocks as (category, share)
   if (A.cseg) return;
   const long uses = ((long)b->B * (d->Ls + b->Sn + 2) + d->cate_count - 1) / d->cate_count;
   const int per = (d->item_count + d->cate_count - 1) / d->cate_count;
-  if (uses > 512) {
-    A.csplit = (int)(uses / 128 < 64 ? uses / 128 : 64);
+  static const int fine = [] { const char* e = getenv("TLSAN_CSPLIT_FINE"); return e ? atoi(e) : 1; }();
+  long n = uses > 512 ? (uses / 128 < 64 ? uses / 128 : 64) : 1;
+  if (fine && uses > 96) {
+    // the launch's other workgroups: the finalize's and the hot rows' (~206), 16 used item / user rows each (lazy_blocks)
+    const long ni = (long)b->B * (d->Ls + b->Sn + 1);
+    const long others = 206 + ((ni < d->item_count ? ni : d->item_count) + 15) / 16 + ((b->B < d->user_count ? b->B : d->user_count) + 15) / 16;
+    long nf = uses / 48 < 64 ? uses / 48 : 64;
+    const long spare = (1280 - others) / d->cate_count;     // (256 CUs x five 256-thread workgroups)
+    if (nf > spare) nf = spare;
+    if (nf > n) n = nf;
+  }
+  if (n > 1) {
+    A.csplit = (int)n;
     const int ps = (per + A.csplit - 1) / A.csplit;
     A.cpass = ps < 1 ? 1 : (ps > 256 ? 256 : ps);
   }
