@@ -8,8 +8,10 @@ from tlsan_amd import _lib as L, synth
 from tlsan_amd.model import Model
 B = int(sys.argv[1]) if len(sys.argv) > 1 and "=" not in sys.argv[1] else 4096
 kw = dict(x.split("=") for x in sys.argv[1:] if "=" in x)     # e.g. U=35896 I=28589 C=15 (Movies-TV shape)
+dh = int(kw.get("d", 128))
 cfg = synth.make_config("electronics", user_count=int(kw.get("U", 39991)), item_count=int(kw.get("I", 22048)),
-                        cate_count=int(kw.get("C", 673)), Ls=int(kw.get("Ls", 10)))
+                        cate_count=int(kw.get("C", 673)), Ls=int(kw.get("Ls", 10)), hidden_units=dh, itemid_embedding_size=dh // 2,
+                        userid_embedding_size=dh // 2, cateid_embedding_size=dh // 2)
 m = Model(cfg, synth.item_cate_list(cfg), l2_mode="lazy")
 lib = L.load()
 hb = synth.make_batches(cfg, 1, B, seed=7)[0]
@@ -31,10 +33,14 @@ t0 = s[used[:n], 0].min()
 C = cfg["cate_count"]
 Sn = db.Sn
 uses = -(-(B * (cfg["Ls"] + db.Sn + 2)) // C)
-C = C * (min(64, uses // 128) if uses > 512 else 1)     # workgroups of the category part (split categories, tlsan_train_step)
 ni = min(cfg["item_count"], B * (cfg["Ls"] + Sn + 1))
 nbI = (ni + 15) // 16
 nbU = (min(B, cfg["user_count"]) + 15) // 16
+# workgroups of the category part (category_split, tlsan_api.hip; TLSAN_CSPLIT_FINE)
+nsh = min(64, uses // 128) if uses > 512 else 1
+if uses > 96 and os.environ.get("TLSAN_CSPLIT_FINE", "1") != "0":
+    nsh = max(nsh, min(64, uses // 48, (1280 - (206 + nbI + nbU)) // C))
+C = C * max(nsh, 1)
 print("blocks %d: cate %d, item %d, user %d, dense %d; span %.0f ticks (100 MHz -> %.1f us)" % (n, C, nbI, nbU, n - C - nbI - nbU, s[:, 6].max() - t0, (s[:, 6].max() - t0) / 100))
 def show(name, lo, hi):
     x = s[lo:hi]

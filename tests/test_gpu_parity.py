@@ -1256,8 +1256,9 @@ sys.path.insert(0, %r)
 from tests.helpers import make_config, random_batch, random_params
 from tlsan_amd.model import Model
 h = hashlib.sha256()
-for d, Ls, C, td in ((128, 10, 3, "f32"), (128, 90, 2, "f32"), (64, 33, 5, "f32"), (128, 70, 3, "bf16")):
-    cfg = make_config(U=500, I=900, C=C, d=d, Ls=Ls, regulation_rate=1e-3, max_gradient_norm=1e4)
+# (categories of 300-450 items: shared by item; of 60-70: by use position -- category_split, tlsan_api.hip)
+for d, Ls, C, td, I in ((128, 10, 3, "f32", 900), (128, 90, 2, "f32", 900), (64, 33, 5, "f32", 300), (128, 70, 3, "bf16", 200)):
+    cfg = make_config(U=500, I=I, C=C, d=d, Ls=Ls, regulation_rate=1e-3, max_gradient_norm=1e4)
     p = {k: np.asarray(v, np.float32) for k, v in random_params(cfg, seed=13).items()}
     _, cat = random_batch(cfg, B=8, Sn=3, seed=0)
     m = Model(cfg, cat, l2_mode="lazy", table_dtype=td)
@@ -1279,14 +1280,16 @@ print("DIGEST", h.hexdigest())
 '''
 
 
-@pytest.mark.parametrize("d,Ls,C,clip", [(128, 10, 3, 5.0), (128, 10, 3, 0.02), (128, 90, 2, 5.0), (128, 90, 2, 0.05), (64, 33, 5, 0.02)])
+@pytest.mark.parametrize("d,Ls,C,clip", [(128, 10, 3, 5.0), (128, 10, 3, 0.02), (128, 90, 2, 5.0), (128, 90, 2, 0.05), (64, 33, 5, 0.02),
+                                         (128, 10, 8, 5.0)])
 def test_shared_categories_in_the_one_pass_form(d, Ls, C, clip):
     """Few, large categories (Movies-TV: 15) are shared by several row-sum workgroups that add exact doubles into Rc64
     (category_split) -- a sum no single workgroup holds, so their rows cannot be updated in the pass that sums them.  The
     lazy-L2 step then takes the one-pass update for the item and user rows only (k_finalize_update<.., CSPL>: the category
     workgroups sum beside them) and updates the category rows in the commit launch, which knows the coefficient
     (k_spec_commit<.., CSPL>).  One train step against the oracle, clip inactive and active, user rows of up to 128 floats
-    and wider (d = 128 with a 90-entry window: two passes of the narrow form), bitwise reproducible."""
+    and wider (d = 128 with a 90-entry window: two passes of the narrow form), categories of 100-250 items (shared by
+    item) and of 62 (C = 8: shared by use position), bitwise reproducible."""
     cfg = make_config(U=300, I=500, C=C, d=d, Ls=Ls, regulation_rate=1e-3, max_gradient_norm=clip)
     p = _p32(random_params(cfg, seed=131))
     b, cat = random_batch(cfg, B=640, Sn=3, seed=132)
@@ -1319,12 +1322,13 @@ def test_shared_categories_one_pass_equals_the_split_form():
     digests = []
     # (third run: round 5's rule for how many workgroups share a category -- 27 instead of 64 here; the sums are exact, so
     #  the number of workgroups that share a category must not change a bit either)
-    for cspl, fine in (("1", "1"), ("0", "1"), ("1", "0")):
-        env = dict(os.environ, TLSAN_LAZY_ONE_PASS="3", TLSAN_LAZY_CSPL=cspl, TLSAN_CSPLIT_FINE=fine)
+    # (fourth run: the sharers deal a category's uses out by item instead of by position)
+    for cspl, fine, pos in (("1", "1", "1"), ("0", "1", "1"), ("1", "0", "1"), ("1", "1", "0")):
+        env = dict(os.environ, TLSAN_LAZY_ONE_PASS="3", TLSAN_LAZY_CSPL=cspl, TLSAN_CSPLIT_FINE=fine, TLSAN_CSPLIT_POS=pos)
         r = subprocess.run([sys.executable, "-c", _CSPL_DIGEST % root], cwd=root, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         digests.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1])
-    assert digests[0] == digests[1] == digests[2], digests
+    assert len(set(digests)) == 1, digests
 
 
 def test_speculative_one_pass_lazy_update():

@@ -405,7 +405,7 @@ static void fill_apply(ApplyArgs& A, const tlsan_dims* d, const Shape& s, const 
   A.uc_list = uc_by_list(d, b) ? st.uc_list[k] : nullptr;
   A.cseg = (b && cate_seg(d, b)) ? 1 : 0;
   A.Rc64 = st.Rc64;
-  A.csplit = 1; A.cpass = 256;
+  A.csplit = 1; A.cpass = 256; A.cpos = 0;
   A.hot_n = st.hdr ? &st.hdr->n_hot[k] : nullptr; A.hot_list = st.hot_list[k]; A.nbH = 0;
   A.gd = w.gd;
   A.Rc = w.Rc; A.Ri = w.Ri; A.Rb = w.Rb; A.Ru = w.Ru;
@@ -459,6 +459,11 @@ static void category_split(ApplyArgs& A, const tlsan_dims* d, const tlsan_batch*
     A.csplit = (int)n;
     const int ps = (per + A.csplit - 1) / A.csplit;
     A.cpass = ps < 1 ? 1 : (ps > 256 ? 256 : ps);
+    // categories of at most 256 items (one pass of the walk: the static CSR's counts, not the average, would say; the
+    // kernel takes further passes the same way if one is larger): shares by use position instead of by item, so that a
+    // hot item does not make its share the launch's longest chain.  TLSAN_CSPLIT_POS=0: by item (A/B)
+    static const int by_pos = [] { const char* e = getenv("TLSAN_CSPLIT_POS"); return e ? atoi(e) : 1; }();
+    A.cpos = (by_pos && per <= 128) ? 1 : 0;
   }
 }
 

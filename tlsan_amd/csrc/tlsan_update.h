@@ -1286,6 +1286,10 @@ struct ApplyArgs {
   // sums of 2^-40-grid values are exact in any order, so the result stays bitwise reproducible;
   // k_update_lazy rounds them to float (as a single workgroup would have) and clears them
   int32_t csplit, cpass;
+  // cpos != 0 (categories of at most 256 items -- one pass): the sharing workgroups all scan the category's items and
+  // each takes an equal slice of the concatenated USE POSITIONS instead of every csplit-th group of items: a hot item no
+  // longer makes its share the launch's longest chain (Digital-Music, batch 2048: one share 14 us, the rest 7)
+  int32_t cpos;
   // hot item rows (more than AP_HOT uses) get a workgroup each in the row-sum pass: nbH = AP_HOT_CAP such
   // workgroups lead the grid, the item-row workgroups leave those rows to them (when the list did not overflow)
   const int32_t* hot_n; const int32_t* hot_list; int32_t nbH;
@@ -1512,14 +1516,17 @@ __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx
     const int nu_all = a.off_uc[c + 1] - ou;
     nu = nu_all;
     int PS = 256;  // items per pass
+    bool by_pos = false;     // (CSPLIT) shares are slices of the use positions, not groups of items
     if constexpr (CSPLIT) {  // this workgroup's share of the u_cate uses and its pass size
-      PS = a.cpass;
+      by_pos = a.cpos != 0;
+      if (!by_pos) PS = a.cpass;
       const int chunk = (nu_all + nsplit - 1) / nsplit;
       ou += split * chunk;
       nu = max(0, min(chunk, nu_all - split * chunk));
     }
+    const int pstart = by_pos ? 0 : split * PS, pstep = by_pos ? PS : nsplit * PS;
     bool first = true;
-    for (int p0 = split * PS; first || p0 < ni; p0 += nsplit * PS, first = false) {
+    for (int p0 = pstart; first || p0 < ni; p0 += pstep, first = false) {
       int lo = 0, n = 0;
       if (tid < PS && p0 + tid < ni) {
         const int item = a.cate_items[i0 + p0 + tid];
@@ -1537,11 +1544,18 @@ __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx
       int pre = inc - n;
 #pragma unroll
       for (int w_ = 0; w_ < 4; ++w_) pre += (w_ < wave) ? sh_wtot[w_] : 0;
-      const int T = (sh_wtot[0] + sh_wtot[1]) + (sh_wtot[2] + sh_wtot[3]);
-      const bool last = p0 + nsplit * PS >= ni;  // this workgroup's last pass
+      int T = (sh_wtot[0] + sh_wtot[1]) + (sh_wtot[2] + sh_wtot[3]);
+      const bool last = p0 + pstep >= ni;  // this workgroup's last pass
       const int extra = last ? nu : 0;  // the u_cate uses ride along with the last pass
+      // by_pos: this workgroup's slice [s_lo, s_hi) of the pass's T concatenated use positions
+      int s_lo = 0, s_hi = T;
+      if (by_pos) {
+        s_lo = (int)((long long)T * split / nsplit);
+        s_hi = (int)((long long)T * (split + 1) / nsplit);
+        T = s_hi - s_lo;
+      }
       if (T + extra <= AP_CAP) {
-        for (int j = 0; j < n; ++j) sh_pos[pre + j] = lo + j;
+        for (int j = max(0, s_lo - pre); j < min(n, s_hi - pre); ++j) sh_pos[pre + j - s_lo] = lo + j;
         for (int j = tid; j < extra; j += 256) sh_pos[T + j] = ~(a.uc_list ? a.uc_list[ou + j] : ou + j);
         __syncthreads();
         AP_STAMP(1);
@@ -1552,9 +1566,12 @@ __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx
         sh_n[tid] = n;
         __syncthreads();
         const int cnt = max(0, min(PS, ni - p0));
+        int run = 0;   // (by_pos) concatenated position of the segment's first use
         for (int t = 0; t < cnt; ++t) {
           const int nt = sh_n[t], lt = sh_lo[t];
-          if (nt > 0) seg_accum<NCH>(a.Gi + a.di, a.D, lt + gid, lt + nt, 16, W4, l16, acc);
+          const int o_lo = max(run, s_lo), o_hi = min(run + nt, s_hi);   // the part of the segment inside the slice
+          if (o_hi > o_lo) seg_accum<NCH>(a.Gi + a.di, a.D, lt + (o_lo - run) + gid, lt + (o_hi - run), 16, W4, l16, acc);
+          run += nt;
         }
         if (last) {
           if (a.uc_list == nullptr) {
@@ -2397,36 +2414,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? SPEC
     const int nbCg = a.C * a.csplit;       // category workgroups of this launch (category, share)
     if (x.blk < nbCg) {
       apply_cate_block<AP_PRESUM, true, NC, DT, true>(a, x, shd, shp, sh_pos, sh_lo, sh_n, sh_wtot);
-      return;
-    }
-    // (the row blocks' records follow the commit launch's category blocks': [nbC | nbI | nbU].  Two-pass user blocks are the
-    //  longer ones and lead the item blocks -- the launch ends when its last-placed blocks do)
-    int rb = x.blk - nbCg;
-    const bool ufirst = a.WU > 128;
-    const bool is_user = ufirst ? rb < a.nbU : rb >= a.nbI;
-    if (is_user) rb -= ufirst ? 0 : a.nbI; else rb -= ufirst ? a.nbU : 0;
-    x.blk = a.nbC + (is_user ? a.nbI : 0) + rb;
-    if (!is_user) {
-      apply_rows_block<AP_UPDATE, true, true, NI, OWN, DT>(a, x, rb * AP_ROWS_PB, shp);
     } else {
-      apply_rows_block<AP_UPDATE, true, false, NU, AP_OWN / 2, DT>(a, x, rb * AP_ROWS_PB, shp);
-      if (ufirst) {                        // the second half of a wide user row (its change of the sum of squares: added to the record)
-        __syncthreads();
-        x.accum = true;
-        apply_rows_block<AP_UPDATE, true, false, NU, AP_OWN / 2, DT, NU>(a, x, rb * AP_ROWS_PB, shp);
+      // (the row blocks' records follow the commit launch's category blocks': [nbC | nbI | nbU].  Two-pass user blocks are the
+      //  longer ones and lead the item blocks -- the launch ends when its last-placed blocks do)
+      int rb = x.blk - nbCg;
+      const bool ufirst = a.WU > 128;
+      const bool is_user = ufirst ? rb < a.nbU : rb >= a.nbI;
+      if (is_user) rb -= ufirst ? 0 : a.nbI; else rb -= ufirst ? a.nbU : 0;
+      x.blk = a.nbC + (is_user ? a.nbI : 0) + rb;
+      if (!is_user) {
+        apply_rows_block<AP_UPDATE, true, true, NI, OWN, DT>(a, x, rb * AP_ROWS_PB, shp);
+      } else {
+        apply_rows_block<AP_UPDATE, true, false, NU, AP_OWN / 2, DT>(a, x, rb * AP_ROWS_PB, shp);
+        if (ufirst) {                        // the second half of a wide user row (its change of the sum of squares: added to the record)
+          __syncthreads();
+          x.accum = true;
+          apply_rows_block<AP_UPDATE, true, false, NU, AP_OWN / 2, DT, NU>(a, x, rb * AP_ROWS_PB, shp);
+        }
       }
     }
-    return;
+  } else {
+    const int blk = x.blk;
+    if (blk < a.nbC) {
+      // (the wide form takes category segments only -- lazy_one_pass, tlsan_api.hip: the item-walk category workgroups in its
+      //  kernel cost the row roles 44 more spilled bytes per lane)
+      if (WIDE || a.cseg) apply_cseg_block<AP_UPDATE, true, NC, OWN, DT>(a, x, blk * AP_ROWS_PB, shp);
+      else apply_cate_block<AP_UPDATE, true, NC, DT>(a, x, shd, shp, sh_pos, sh_lo, sh_n, sh_wtot);
+    }
+    else if (blk < a.nbC + a.nbI) apply_rows_block<AP_UPDATE, true, true, NI, OWN, DT>(a, x, (blk - a.nbC) * AP_ROWS_PB, shp);
+    else apply_rows_block<AP_UPDATE, true, false, NU, (WIDE ? SPEC_OWN : AP_OWN / 2), DT>(a, x, (blk - a.nbC - a.nbI) * AP_ROWS_PB, shp);
   }
-  const int blk = x.blk;
-  if (blk < a.nbC) {
-    // (the wide form takes category segments only -- lazy_one_pass, tlsan_api.hip: the item-walk category workgroups in its
-    //  kernel cost the row roles 44 more spilled bytes per lane)
-    if (WIDE || a.cseg) apply_cseg_block<AP_UPDATE, true, NC, OWN, DT>(a, x, blk * AP_ROWS_PB, shp);
-    else apply_cate_block<AP_UPDATE, true, NC, DT>(a, x, shd, shp, sh_pos, sh_lo, sh_n, sh_wtot);
-  }
-  else if (blk < a.nbC + a.nbI) apply_rows_block<AP_UPDATE, true, true, NI, OWN, DT>(a, x, (blk - a.nbC) * AP_ROWS_PB, shp);
-  else apply_rows_block<AP_UPDATE, true, false, NU, (WIDE ? SPEC_OWN : AP_OWN / 2), DT>(a, x, (blk - a.nbC - a.nbI) * AP_ROWS_PB, shp);
   if (stp && x.tid == 0) { stp[6] = __builtin_amdgcn_s_memtime(); stp[5] = __builtin_amdgcn_s_memrealtime(); }
 }
 
