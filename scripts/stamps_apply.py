@@ -19,7 +19,7 @@ db = m.device_batch(hb)
 for _ in range(5):
     m.train_async(db, 1.0)
 OFF = 1 << 20
-NBLK = 8192
+NBLK = 65536
 st = torch.zeros(OFF + NBLK * 8, dtype=torch.int64, device="cuda")
 lib.tlsan_debug_stamps(st.data_ptr())
 m.train_async(db, 1.0)
@@ -41,6 +41,8 @@ nsh = min(64, uses // 128) if uses > 512 else 1
 if uses > 96 and os.environ.get("TLSAN_CSPLIT_FINE", "1") != "0":
     nsh = max(nsh, min(64, uses // 48, (1280 - (206 + nbI + nbU)) // C))
 C = C * max(nsh, 1)
+if cfg["cate_count"] >= int(os.environ.get("TLSAN_CSEG_MIN", 2048)):      # category segments: 16 categories per workgroup
+    C = (cfg["cate_count"] + 15) // 16
 print("blocks %d: cate %d, item %d, user %d, dense %d; span %.0f ticks (100 MHz -> %.1f us)" % (n, C, nbI, nbU, n - C - nbI - nbU, s[:, 6].max() - t0, (s[:, 6].max() - t0) / 100))
 def show(name, lo, hi):
     x = s[lo:hi]

@@ -1352,7 +1352,9 @@ def test_speculative_one_pass_lazy_update():
     assert r.returncode == 0, r.stdout[-6000:] + r.stderr[-2000:]
     mt = re.search(r"(\d+) passed", r.stdout)
     assert mt and int(mt.group(1)) >= 25, r.stdout[-2000:]
-    env = dict(os.environ, TLSAN_LAZY_ONE_PASS="2", TLSAN_CSEG_MIN="1")
+    # (TLSAN_SPEC_ITEM_BLOCKS=3: the launch carries three item-row workgroups, each walking every third block of 16 used rows
+    #  -- the form tables of millions of rows take, whose batches can touch far more rows than they do)
+    env = dict(os.environ, TLSAN_LAZY_ONE_PASS="2", TLSAN_CSEG_MIN="1", TLSAN_SPEC_ITEM_BLOCKS="3")
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-m", "gpu", "-q", "-x", "-k",
                         "test_lazy_l2_matches_dense_oracle or test_lazy_is_deterministic or test_category_segments_match_oracle "
                         "or test_full_size_batch_matches_oracle or test_one_hot_row_takes_every_use or test_multi_step_tracks_oracle "

@@ -929,7 +929,12 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
     A.nbH = AP_HOT_CAP;      // hot item rows: a workgroup each, leading the row workgroups (they return at once where there are none)
     f.count_step = 0; f.spec = 1;
     const bool shared = A.csplit > 1;   // (lazy_one_pass form 2: A.nbC = the commit launch's category blocks; this launch carries C * csplit)
-    const dim3 grid(w.nfin + 1 + A.nbH + (shared ? A.C * A.csplit : A.nbC) + A.nbI + A.nbU);
+    // (item-row workgroups launched: at most SPEC_ITEM_BLOCKS -- ApplyArgs.nbI_l; TLSAN_SPEC_ITEM_BLOCKS=<n>, 0: all, for A/B)
+    static const int item_cap = [] { const char* e = getenv("TLSAN_SPEC_ITEM_BLOCKS"); return e ? atoi(e) : SPEC_ITEM_BLOCKS; }();
+    A.nbI_l = (!shared && item_cap > 0 && A.nbI > item_cap) ? item_cap : 0;
+    static const int ufirst = [] { const char* e = getenv("TLSAN_SPEC_UFIRST"); return e ? atoi(e) : 1; }();
+    A.ufirst = (ufirst && apply_wide(A) && !shared) ? 1 : 0;
+    const dim3 grid(w.nfin + 1 + A.nbH + (shared ? A.C * A.csplit : A.nbC) + (A.nbI_l > 0 ? A.nbI_l : A.nbI) + A.nbU);
     const bool wide = apply_wide(A) && !shared, bf16 = A.p.table_dtype == TLSAN_TABLE_BF16, low = tables_in_hbm(d);
 #define FU_LAUNCH(DD, HH)                                                                                                            \
   do {                                                                                                                               \

@@ -1300,6 +1300,11 @@ struct ApplyArgs {
   const int32_t* n_uniq_item; const int32_t* n_uniq_user;   // used-row counts of this step's index slot
   float lr, reg;
   int32_t nbI, nbU, nbC, nbD;
+  // k_finalize_update: item-row workgroups LAUNCHED (0: nbI).  The host sizes nbI for the most rows the batch can touch
+  // (C5: 25.8 k blocks of 16 rows; 4.4 k are real, the rest start, find nothing and leave -- 5 us of the launch's slots);
+  // with nbI_l < nbI a workgroup takes the blocks nbI_l apart until the used rows end
+  int32_t nbI_l;
+  int32_t ufirst;          // k_finalize_update: the user-row workgroups lead the item-row workgroups
   // optimizers other than SGD (dense UPDATE only): accumulator tables shaped like p, see tlsan_optimizer
   tlsan_params s1, s2;
   int32_t opt;
@@ -2352,6 +2357,7 @@ __device__ __forceinline__ double update_cate_rows(const ApplyArgs& a, int c, in
 #define SPEC_OWN 2
 #endif
 #define SPEC_FIX_BLOCKS 512
+#define SPEC_ITEM_BLOCKS 2048   // item-row workgroups k_finalize_update launches at most (ApplyArgs.nbI_l)
 // (the wide form -- rows of 128 floats and more, C5 -- is held to four waves per SIMD: 149 registers left alone, i.e. three;
 //  at four 88 bytes per lane spill in the user-row role and C5 runs 281.5 -> 273.5 us/step.  The narrow form: five (fp32
 //  tables) / four (bf16 tables) where the caches hold the tables -- the bench shape 56.9 -> 55.4 us/step against the split
@@ -2440,9 +2446,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? SPEC
       //  kernel cost the row roles 44 more spilled bytes per lane)
       if (WIDE || a.cseg) apply_cseg_block<AP_UPDATE, true, NC, OWN, DT>(a, x, blk * AP_ROWS_PB, shp);
       else apply_cate_block<AP_UPDATE, true, NC, DT>(a, x, shd, shp, sh_pos, sh_lo, sh_n, sh_wtot);
+    } else {
+      // (records: [nbC | nbI | nbU] whatever the order of the workgroups.  The wide form's user rows -- 220 floats at C5,
+      //  5.7-11 us a workgroup -- lead the item rows: placed last they WERE the launch's last 8 us: 60.5 -> 55)
+      const int nbIl = a.nbI_l > 0 ? a.nbI_l : a.nbI;
+      int rb = blk - a.nbC;
+      const bool uf = a.ufirst != 0;
+      const bool is_user = uf ? rb < a.nbU : rb >= nbIl;
+      if (is_user) {
+        rb -= uf ? 0 : nbIl;
+        x.blk = a.nbC + a.nbI + rb;
+        apply_rows_block<AP_UPDATE, true, false, NU, (WIDE ? SPEC_OWN : AP_OWN / 2), DT>(a, x, rb * AP_ROWS_PB, shp);
+      } else {
+        rb -= uf ? a.nbU : 0;
+        const int nuq = *a.n_uniq_item;
+        for (int g = rb; g * AP_ROWS_PB < nuq && g < a.nbI; g += nbIl) {
+          x.blk = a.nbC + g;
+          apply_rows_block<AP_UPDATE, true, true, NI, OWN, DT>(a, x, g * AP_ROWS_PB, shp);
+          __syncthreads();   // (the shared scratch is reused by the next block of rows)
+        }
+      }
     }
-    else if (blk < a.nbC + a.nbI) apply_rows_block<AP_UPDATE, true, true, NI, OWN, DT>(a, x, (blk - a.nbC) * AP_ROWS_PB, shp);
-    else apply_rows_block<AP_UPDATE, true, false, NU, (WIDE ? SPEC_OWN : AP_OWN / 2), DT>(a, x, (blk - a.nbC - a.nbI) * AP_ROWS_PB, shp);
   }
   if (stp && x.tid == 0) { stp[6] = __builtin_amdgcn_s_memtime(); stp[5] = __builtin_amdgcn_s_memrealtime(); }
 }
