@@ -44,6 +44,14 @@ C = C * max(nsh, 1)
 if cfg["cate_count"] >= int(os.environ.get("TLSAN_CSEG_MIN", 2048)):      # category segments: 16 categories per workgroup
     C = (cfg["cate_count"] + 15) // 16
 print("blocks %d: cate %d, item %d, user %d, dense %d; span %.0f ticks (100 MHz -> %.1f us)" % (n, C, nbI, nbU, n - C - nbI - nbU, s[:, 6].max() - t0, (s[:, 6].max() - t0) / 100))
+# the one-pass row launch places the user-row workgroups ahead of the item-row workgroups where rows are wide (tlsan_api.hip:
+# ApplyArgs.ufirst, and the shared-category form's own rule), and launches at most SPEC_ITEM_BLOCKS item-row workgroups
+WU = (cfg["hidden_units"] // 2 + cfg["Ls"] + 3) // 4 * 4
+ufirst = (cfg["hidden_units"] // 2 > 64 or WU > 128) and os.environ.get("TLSAN_LAZY_ONE_PASS", "1") != "0"
+cap = int(os.environ.get("TLSAN_SPEC_ITEM_BLOCKS", 2048))
+if cap > 0 and nbI > cap and nsh <= 1 and os.environ.get("TLSAN_LAZY_ONE_PASS", "1") != "0":
+    nbI = cap
+ROLES = [("cate", 0, C), ("user", C, C + nbU), ("item", C + nbU, C + nbU + nbI)] if ufirst else [("cate", 0, C), ("item", C, C + nbI), ("user", C + nbI, C + nbI + nbU)]
 def show(name, lo, hi):
     x = s[lo:hi]
     x = x[x[:, 0] > 0]
@@ -58,15 +66,14 @@ def show(name, lo, hi):
     if ok.any():
         d = np.diff(y[ok], axis=1)
         print("        phases (median / p90 ticks): " + " ".join("%d-%d: %.0f/%.0f" % (cols[i], cols[i + 1], np.median(d[:, i]), np.percentile(d[:, i], 90)) for i in range(4)))
-show("cate", 0, C)
-show("item", C, C + nbI)
-show("user", C + nbI, C + nbI + nbU)
+for nm_, lo_, hi_ in ROLES:
+    show(nm_, lo_, hi_)
 show("dense/fin", C + nbI + nbU, n)
 
 # timeline on the device-wide 100 MHz clock (slots 4/5)
 r0 = s[s[:, 4] > 0, 4].min()
 print("timeline (us after the first workgroup start; 100 MHz s_memrealtime): kernel span %.2f us" % ((s[:, 5].max() - r0) / 100))
-for nm, lo, hi in [("cate", 0, C), ("item", C, C + nbI), ("user", C + nbI, C + nbI + nbU), ("dense/fin", C + nbI + nbU, n)]:
+for nm, lo, hi in ROLES + [("dense/fin", C + nbI + nbU, n)]:
     x = s[lo:hi]
     x = x[x[:, 4] > 0]
     if len(x):

@@ -931,11 +931,16 @@ static int run_backward(const tlsan_dims* d, const Shape& s, const tlsan_params*
     const bool shared = A.csplit > 1;   // (lazy_one_pass form 2: A.nbC = the commit launch's category blocks; this launch carries C * csplit)
     // (item-row workgroups launched: at most SPEC_ITEM_BLOCKS -- ApplyArgs.nbI_l; TLSAN_SPEC_ITEM_BLOCKS=<n>, 0: all, for A/B)
     static const int item_cap = [] { const char* e = getenv("TLSAN_SPEC_ITEM_BLOCKS"); return e ? atoi(e) : SPEC_ITEM_BLOCKS; }();
-    A.nbI_l = (!shared && item_cap > 0 && A.nbI > item_cap) ? item_cap : 0;
+    // (the shared-category form: the same cap -- Movies-TV's 1787 blocks stay below it; fewer, 1024 / 640 / 384, measured a
+    //  loss there: profiles/r06_ab_hot_cate.txt; TLSAN_SPEC_ITEM_BLOCKS_SHARED=<n> for A/B)
+    static const int item_cap_sh = [] { const char* e = getenv("TLSAN_SPEC_ITEM_BLOCKS_SHARED"); return e ? atoi(e) : SPEC_ITEM_BLOCKS; }();
+    const int cap_here = shared ? item_cap_sh : item_cap;
+    A.nbI_l = (cap_here > 0 && A.nbI > cap_here) ? cap_here : 0;
     static const int ufirst = [] { const char* e = getenv("TLSAN_SPEC_UFIRST"); return e ? atoi(e) : 1; }();
     A.ufirst = (ufirst && apply_wide(A) && !shared) ? 1 : 0;
     const dim3 grid(w.nfin + 1 + A.nbH + (shared ? A.C * A.csplit : A.nbC) + (A.nbI_l > 0 ? A.nbI_l : A.nbI) + A.nbU);
-    const bool wide = apply_wide(A) && !shared, bf16 = A.p.table_dtype == TLSAN_TABLE_BF16, low = tables_in_hbm(d);
+    static const int low_env = [] { const char* e = getenv("TLSAN_SPEC_LOWOCC"); return e ? atoi(e) : -1; }();   // (A/B: 0 / 1 force it)
+    const bool wide = apply_wide(A) && !shared, bf16 = A.p.table_dtype == TLSAN_TABLE_BF16, low = low_env < 0 ? tables_in_hbm(d) : low_env != 0;
 #define FU_LAUNCH(DD, HH)                                                                                                            \
   do {                                                                                                                               \
     if (shared) {                                                                                                                    \

@@ -2424,12 +2424,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? SPEC
       // (the row blocks' records follow the commit launch's category blocks': [nbC | nbI | nbU].  Two-pass user blocks are the
       //  longer ones and lead the item blocks -- the launch ends when its last-placed blocks do)
       int rb = x.blk - nbCg;
+      const int nbIl = a.nbI_l > 0 ? a.nbI_l : a.nbI;     // item-row workgroups launched (ApplyArgs.nbI_l)
       const bool ufirst = a.WU > 128;
-      const bool is_user = ufirst ? rb < a.nbU : rb >= a.nbI;
-      if (is_user) rb -= ufirst ? 0 : a.nbI; else rb -= ufirst ? a.nbU : 0;
+      const bool is_user = ufirst ? rb < a.nbU : rb >= nbIl;
+      if (is_user) rb -= ufirst ? 0 : nbIl; else rb -= ufirst ? a.nbU : 0;
       x.blk = a.nbC + (is_user ? a.nbI : 0) + rb;
       if (!is_user) {
-        apply_rows_block<AP_UPDATE, true, true, NI, OWN, DT>(a, x, rb * AP_ROWS_PB, shp);
+        const int nuq = *a.n_uniq_item;
+        for (int g = rb; g * AP_ROWS_PB < nuq && g < a.nbI; g += nbIl) {
+          x.blk = a.nbC + g;
+          apply_rows_block<AP_UPDATE, true, true, NI, OWN, DT>(a, x, g * AP_ROWS_PB, shp);
+          __syncthreads();   // (the shared scratch is reused by the next block of rows)
+        }
       } else {
         apply_rows_block<AP_UPDATE, true, false, NU, AP_OWN / 2, DT>(a, x, rb * AP_ROWS_PB, shp);
         if (ufirst) {                        // the second half of a wide user row (its change of the sum of squares: added to the record)
