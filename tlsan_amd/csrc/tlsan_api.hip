@@ -150,7 +150,8 @@ static void carve(const tlsan_dims* d, const Shape& s, int B, int Sn, char* base
   // workgroup of that launch -- which of the two, and how many, is the launch's choice (run_backward)
   const int ngroups = (B + s.NSB - 1) / s.NSB;
   w->nbK = (s.D * s.D + 255) / 256;
-  w->nbS = (L.n_dense - s.D * s.D + 15) / 16;
+  const int small_pb = s.D > 128 ? FIN_SMALL_PB : 16;      // (small parameters per finalize workgroup: dense_finalize_block)
+  w->nbS = (L.n_dense - s.D * s.D + small_pb - 1) / small_pb;
   w->nfin = w->nbK + w->nbS;
   // (+1 row: k_apply reads clamped addresses instead of branching, see AP_OWN)
   w->Gi = (float*)take(sizeof(float) * (NI + 1) * D);

@@ -50,6 +50,10 @@ struct DeltaRec {
 #ifndef TLSAN_KCH
 #define TLSAN_KCH 64     // dK partials a finalize thread has in flight (dense_finalize_block)
 #endif
+#define FIN_SMALL_PB 64  // small dense parameters per finalize workgroup (dense_finalize_block; the host's nbS)
+#ifndef FIN_SMALL_KCH
+#define FIN_SMALL_KCH 16 // records a lane has in flight there
+#endif
 #define AP_HOT 48        // item rows with more uses than this are summed by a workgroup of their own ...
 #define AP_HOT_CAP 64    // ... when there are at most this many (the head of a Zipf distribution: a handful)
 struct CountArgs {
@@ -1090,7 +1094,7 @@ __global__ __launch_bounds__(256) void k_fold_delta(const DeltaRec* recs, int n_
 
 // Grid: [0, nbK) blocks reduce the D*D kernel gradient over the batch splits (one thread per
 // entry); [nbK, nbK+nbS) blocks reduce the small parameters over the per-pass partial records
-// with 16 lanes per parameter (lane l sums records l, l+16, ...; fixed xor tree after);
+// with a lane per parameter (64 per block; a wavefront per quarter of the records, fixed order);
 // the last block reduces S_part -> S_total.  Every sum has a fixed order -> deterministic.
 template <int D, int DH>
 __device__ __forceinline__ void dense_finalize_block(const FinArgs& a, int nbK, int nbS, int blk, double* shd, int* sh_last) {
@@ -1141,7 +1145,78 @@ __device__ __forceinline__ void dense_finalize_block(const FinArgs& a, int nbK, 
       a.gd[L.K + idx] = g;
       owner = true;
     }
+  } else if constexpr (D > 128) {
+    // d = 256: FIN_SMALL_PB = 64 parameters per workgroup, a lane per parameter: consecutive parameters are consecutive entries of a
+    // record, so a wavefront's load touches two lines of ONE record; the four wavefronts take a quarter of the records
+    // each, 16 loads in flight, fixed order.  (Until round 6: 16 lanes per parameter, each lane its own records -- every
+    // load instruction touched 16 lines 18 KB apart: at d = 256 its 281 workgroups took 8.6 us each and held a third of the
+    // row launch's slots for its first 10 us.)
+    const int lane = tid & 63, wave = tid >> 6;
+    const int m = (blk - nbK) * FIN_SMALL_PB + lane;
+    const int n_small = L.n_dense - D * D;
+    const bool valid = m < n_small;
+    int n = 0, e0 = 0, e1 = 0;
+    bool two = false;
+    if (valid) {
+      n = m < L.K ? m : m + D * D;
+      // map the true parameter index to 1..HPC entries of the effective-layout record
+      int e[2] = {-1, -1};
+      const int wofs[4] = {L.f1_W1, L.f1_W2, L.f2_W1, L.f2_W2};
+      const int bofs[4] = {L.f1_b1, L.f1_b2, L.f2_b1, L.f2_b2};
+      const int pw[4] = {G::P_F1W1, G::P_F1W2, G::P_F2W1, G::P_F2W2};
+      const int pb[4] = {G::P_F1B1, G::P_F1B2, G::P_F2B1, G::P_F2B2};
+      for (int mm = 0; mm < 4; ++mm) {
+        if (n >= wofs[mm] && n < wofs[mm] + DH * DH) {
+          const int k = (n - wofs[mm]) / DH, j = (n - wofs[mm]) % DH;
+          for (int h = 0; h < HPC; ++h) e[h] = pw[mm] + (h * DH + k) * CW + h * DH + j;
+        }
+        if (n >= bofs[mm] && n < bofs[mm] + DH) {
+          const int j = n - bofs[mm];
+          for (int h = 0; h < HPC; ++h) e[h] = pb[mm] + h * DH + j;
+        }
+      }
+      if (n >= L.k0 && n < L.k0 + D) e[0] = G::P_K0 + (n - L.k0);
+      if (n == L.gamma) e[0] = G::P_GAMMA;
+      two = HPC > 1 && e[1] >= 0;
+      e0 = e[0];
+      e1 = two ? e[1] : e[0];
+    }
+    const int q = (a.nrec + 3) / 4, r_lo = wave * q, r_hi = min(a.nrec, r_lo + q);   // this wavefront's records
+    float t = 0.0f;
+    if (valid) {
+      // (chunks of FIN_SMALL_KCH loads in flight; of 4 when a wavefront has no more records than that -- small batches: clamped loads
+      //  are still loads; the sum's order does not depend on the chunk)
+      auto chunks = [&](auto kch) {
+        constexpr int KCH = decltype(kch)::value;
+        for (int r0 = r_lo; r0 < r_hi; r0 += KCH) {
+          float v0[KCH], v1[KCH];
+#pragma unroll
+          for (int u = 0; u < KCH; ++u) {
+            const float* p = a.partials + (size_t)(r0 + u < r_hi ? r0 + u : r0) * NPB;
+            v0[u] = p[e0];
+            if (HPC > 1) v1[u] = p[e1];
+          }
+#pragma unroll
+          for (int u = 0; u < KCH; ++u)
+            if (r0 + u < r_hi) t += (HPC > 1 && two) ? v0[u] + v1[u] : v0[u];
+        }
+      };
+      if (q > 4) chunks(std::integral_constant<int, FIN_SMALL_KCH>());
+      else chunks(std::integral_constant<int, 4>());
+    }
+    float* shf = (float*)shd;   // (256 floats of the 256 doubles)
+    shf[tid] = t;
+    __syncthreads();
+    if (wave == 0 && valid) {
+      g = (shf[lane] + shf[64 + lane]) + (shf[128 + lane] + shf[192 + lane]);
+      a.gd[n] = g;
+      owner = true;
+    }
+    __syncthreads();   // (shd is reused below)
+  
   } else {
+    // (d <= 128: 16 lanes per parameter, each lane its own records -- 77 / 23 such workgroups, never the launch's long pole;
+    //  the form above costs the narrow row kernels two spilled registers)
     const int m = (blk - nbK) * 16 + (tid >> 4), rl = tid & 15;
     const int n_small = L.n_dense - D * D;
     if (m < n_small) {
@@ -1187,6 +1262,7 @@ __device__ __forceinline__ void dense_finalize_block(const FinArgs& a, int nbK, 
         owner = true;
       }
     }
+  
   }
   shd[tid] = owner ? (double)g * (double)g : 0.0;
   __syncthreads();
@@ -1560,7 +1636,11 @@ __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx
         T = s_hi - s_lo;
       }
       if (T + extra <= AP_CAP) {
-        for (int j = max(0, s_lo - pre); j < min(n, s_hi - pre); ++j) sh_pos[pre + j - s_lo] = lo + j;
+        if constexpr (CSPLIT) {
+          for (int j = max(0, s_lo - pre); j < min(n, s_hi - pre); ++j) sh_pos[pre + j - s_lo] = lo + j;
+        } else {   // (the whole pass: no slice arithmetic in the registers of the one-workgroup-per-category form)
+          for (int j = 0; j < n; ++j) sh_pos[pre + j] = lo + j;
+        }
         for (int j = tid; j < extra; j += 256) sh_pos[T + j] = ~(a.uc_list ? a.uc_list[ou + j] : ou + j);
         __syncthreads();
         AP_STAMP(1);
@@ -1574,9 +1654,13 @@ __device__ __forceinline__ void apply_cate_block(const ApplyArgs& a, const ApCtx
         int run = 0;   // (by_pos) concatenated position of the segment's first use
         for (int t = 0; t < cnt; ++t) {
           const int nt = sh_n[t], lt = sh_lo[t];
-          const int o_lo = max(run, s_lo), o_hi = min(run + nt, s_hi);   // the part of the segment inside the slice
-          if (o_hi > o_lo) seg_accum<NCH>(a.Gi + a.di, a.D, lt + (o_lo - run) + gid, lt + (o_hi - run), 16, W4, l16, acc);
-          run += nt;
+          if constexpr (CSPLIT) {
+            const int o_lo = max(run, s_lo), o_hi = min(run + nt, s_hi);   // the part of the segment inside the slice
+            if (o_hi > o_lo) seg_accum<NCH>(a.Gi + a.di, a.D, lt + (o_lo - run) + gid, lt + (o_hi - run), 16, W4, l16, acc);
+            run += nt;
+          } else {
+            if (nt > 0) seg_accum<NCH>(a.Gi + a.di, a.D, lt + gid, lt + nt, 16, W4, l16, acc);
+          }
         }
         if (last) {
           if (a.uc_list == nullptr) {
