@@ -2342,8 +2342,11 @@ __global__ __launch_bounds__(256) void k_apply(ApplyArgs a) {
 // Same arithmetic per element as k_apply<AP_UPDATE, lazy> (the sums are rounded to float there too).
 // (the narrow form is held to 96 registers -- five workgroups per CU: left alone, the compiler takes 124 for the 64 loads the
 //  dK entry blocks keep in flight and costs the launch a fifth of its residency; held, it needs 91 and spills nothing)
+#ifndef PRESUM_WPE_WIDE
+#define PRESUM_WPE_WIDE 4     // (128 registers, a few spilled in the wide row roles; three -- 138, nothing spilled -- measured slower: d = 256, Ls = 90 244.8 vs 238.5 us/step)
+#endif
 template <int D, int DH, bool WIDE, bool CSPLIT = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? 3 : 5))) void k_finalize_presum(FinArgs f, int nbK, int nbS, ApplyArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? PRESUM_WPE_WIDE : 5))) void k_finalize_presum(FinArgs f, int nbK, int nbS, ApplyArgs a) {
   constexpr int NC = WIDE ? 2 : 1, NI = WIDE ? 2 : 1, NU = WIDE ? 4 : 2;
   __shared__ double shd[4 * 16 * NC * 4 > 256 ? 4 * 16 * NC * 4 : 256];
   __shared__ double shp[4];
