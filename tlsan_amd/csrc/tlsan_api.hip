@@ -430,7 +430,8 @@ static bool apply_wide(const ApplyArgs& A) { return A.di > 64 || A.dc > 64 || A.
 
 // few, large categories: several workgroups per category in the row-sum pass, every one with its share of the items and of the
 // u_cate uses (estimated from the batch shape; up to 64 per category).
-//  * from 512 uses per category on: about 128 uses per workgroup (round 3; Movies-TV's 15 categories at batch 4096);
+//  * from 512 uses per category on: about 128 uses per workgroup (round 3; Movies-TV's 15 categories at batch 4096), within
+//    a budget of ~700 category workgroups (round 6, below);
 //  * round 6 -- where the launch has SLOTS TO SPARE (its other workgroups and the category workgroups all resident at once:
 //    small batches), from ~100 uses on and ~48 per workgroup: a category workgroup is a chain of dependent trips (3 us
 //    before its first gradient row arrives) plus ~0.03 us per use, and such a launch ends with its longest chain --
@@ -446,7 +447,16 @@ static void category_split(ApplyArgs& A, const tlsan_dims* d, const tlsan_batch*
   const long uses = ((long)b->B * (d->Ls + b->Sn + 2) + d->cate_count - 1) / d->cate_count;
   const int per = (d->item_count + d->cate_count - 1) / d->cate_count;
   static const int fine = [] { const char* e = getenv("TLSAN_CSPLIT_FINE"); return e ? atoi(e) : 1; }();
-  long n = uses > 512 ? (uses / 128 < 64 ? uses / 128 : 64) : 1;
+  // (the first rule's budget of category workgroups, round 6: every share repeats the category's lead-in, and a launch
+  //  bound by slots pays for it 1:1 -- 673 categories of 620 uses (Ls = 90) as four shares each: 2 692 workgroups of 8.8 us,
+  //  24 of the launch's 32 k slot-us; unshared: d = 256 239 -> 224 us/step, d = 128 103.5 -> 97.4.  Movies-TV's 15
+  //  categories run best as ~46 shares each at Ls = 10 AND at Ls = 90 (64: 97.7, 46: 94.4, 30: 94.9, 11: 104), i.e. ~700
+  //  category workgroups beside the rows' on 1 280 slots.  TLSAN_CSPLIT_PER / TLSAN_CSPLIT_BUDGET for A/B.)
+  static const int per_share = [] { const char* e = getenv("TLSAN_CSPLIT_PER"); return e && atoi(e) > 0 ? atoi(e) : 128; }();
+  static const int budget = [] { const char* e = getenv("TLSAN_CSPLIT_BUDGET"); return e && atoi(e) > 0 ? atoi(e) : 700; }();
+  long n = uses > 512 ? (uses / per_share < 64 ? uses / per_share : 64) : 1;
+  if (n > budget / d->cate_count) n = budget / d->cate_count;
+  if (n < 1) n = 1;
   if (fine && uses > 96) {
     // the launch's other workgroups: the finalize's and the hot rows' (~206), 16 used item / user rows each (lazy_blocks)
     const long ni = (long)b->B * (d->Ls + b->Sn + 1);
